@@ -1,0 +1,226 @@
+#!/usr/bin/env python3
+"""Generate golden vectors by running the REAL reference (msm_we @ /root/reference) on small
+synthetic WE-shaped inputs.  Run in the build container only:
+
+    OMP_NUM_THREADS=1 python tests/golden/make_golden.py [case ...]
+
+Outputs ``tests/golden/<case>.npz`` (inputs + every observable of the hot path).  The tests only
+read those files.  Versions of numpy/scipy/sklearn are recorded in each file (parity target is
+scikit-learn 1.7.2 as installed; SURVEY.md §7 hard part 6).
+"""
+from __future__ import annotations
+
+import json
+import os
+import sys
+
+os.environ.setdefault("OMP_NUM_THREADS", "1")
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, HERE)
+
+import numpy as np  # noqa: E402
+
+from msm_we_amd import synthetic  # noqa: E402
+import ref_harness  # noqa: E402
+
+# case -> (generator config, n_iters override, per-case options)
+CASES = {
+    # C1' of SURVEY §8d: 40 iters x 128 segs, 2 strata x 25 clusters, seed 1337
+    "c1p_d10": dict(cfg="c1p_d10"),
+    "c1p_d30": dict(cfg="c1p_d30"),
+    # sample weights in clustering (`_clustering.py:853-854,898-899`)
+    "c1p_d10_weighted": dict(cfg="c1p_d10", use_weights=True),
+    # a stratum that is never visited -> we_remap / find_nearest_bin (`_clustering.py:721-731`), quirk Q3
+    "gap_d10": dict(cfg=synthetic.WEConfig("gap_d10", 77, 30, 160, 10, 4, 12), drop_stratum=2),
+    # multi-iteration accumulation: too few segments per iteration to fill a stratum at once (`:794-886`)
+    "sparse_d10": dict(cfg=synthetic.WEConfig("sparse_d10", 5, 60, 24, 10, 2, 20)),
+}
+
+
+def build_inputs(case):
+    spec = CASES[case]
+    cfg = spec["cfg"] if isinstance(spec["cfg"], synthetic.WEConfig) else synthetic.CONFIGS[spec["cfg"]]
+    lat = synthetic.latent_centres(cfg)
+    iters = {}
+    for it in range(1, cfg.n_iters + 1):
+        d = synthetic.make_iteration(cfg, it, lat)
+        if "drop_stratum" in spec:  # carve a hole in pcoord space: move those frames to stratum+1
+            s = spec["drop_stratum"]
+            for key, xkey in (("p0", "Xp"), ("p1", "Xc")):
+                m = np.floor(d[key][:, 0]) == s
+                d[key][m, 0] += 1.0
+        iters[it] = d
+    return cfg, iters
+
+
+def run_case(case):
+    spec = CASES[case]
+    cfg, iters = build_inputs(case)
+    msm_we = ref_harness.load_reference()
+    import sklearn
+    import scipy
+    import sklearn.cluster._kmeans as skk
+    import msm_we.stratified_clustering as sc
+
+    seed = 1337
+    log = {"fit": [], "pp": []}
+
+    # --- recorders -----------------------------------------------------------------------
+    orig_pp = skk._kmeans_plusplus
+
+    def rec_pp(X, n_clusters, x_squared_norms, sample_weight, random_state, n_local_trials=None):
+        centers, indices = orig_pp(X, n_clusters, x_squared_norms, sample_weight, random_state, n_local_trials)
+        log["pp"].append(dict(n=X.shape[0], indices=np.array(indices), centers=centers.copy()))
+        return centers, indices
+
+    skk._kmeans_plusplus = rec_pp
+
+    class RecordingKMeans(sc.mini_kmeans.__mro__[0]):
+        _bin = -1
+
+        def partial_fit(self, X, y=None, sample_weight=None):
+            first = not hasattr(self, "cluster_centers_")
+            npp = len(log["pp"])
+            out = super().partial_fit(X, y, sample_weight=sample_weight)
+            log["fit"].append(
+                dict(
+                    bin=self._bin,
+                    n=X.shape[0],
+                    first=first,
+                    pp=(npp if first else -1),
+                    xsum=float(np.sum(X)),
+                    centers=self.cluster_centers_.copy(),
+                    counts=self._counts.copy(),
+                    n_since=self._n_since_last_reassign,
+                )
+            )
+            return out
+
+    RecordingKMeans.__name__ = "MiniBatchKMeans"
+    RecordingKMeans.__qualname__ = "MiniBatchKMeans"
+    base_cls = sc.mini_kmeans
+
+    def factory(**kw):
+        m = RecordingKMeans(**kw)
+        m._bin = factory.count
+        factory.count += 1
+        return m
+
+    factory.count = 0
+    sc.mini_kmeans = factory
+
+    # --- model ---------------------------------------------------------------------------
+    Model = ref_harness.make_model_class(msm_we)
+    Model._iters = iters
+    Model.seg_weights = {}
+    model = Model()
+    basis, target = synthetic.basis_target_bounds(cfg.S)
+    model.initialize(
+        ["in-memory.h5"],
+        {"coords": np.zeros((cfg.D, 1)), "nAtoms": cfg.D, "coord_ndim": 1},
+        "golden",
+        basis_pcoord_bounds=basis,
+        target_pcoord_bounds=target,
+        dim_reduce_method="none",
+        tau=1e-9,
+        pcoord_ndim=1,
+        use_weights_in_clustering=bool(spec.get("use_weights", False)),
+    )
+    model.get_iterations()
+    model.get_coordSet(last_iter=model.maxIter)
+    model.dimReduce()
+    bm = ref_harness.RectilinearBinMapper([synthetic.strata_boundaries(cfg.S)])
+    model.cluster_coordinates(
+        n_clusters=cfg.K_s, streaming=True, use_ray=True, stratified=True,
+        user_bin_mapper=bm, random_state=seed,
+    )
+    out = {}
+    out["remap_post_cluster"] = np.array([model.clusters.we_remap[b] for b in range(bm.nbins)], dtype=np.int64)
+    out["n_clusters_post_cluster"] = np.int64(model.n_clusters)
+    fitted = [hasattr(m, "cluster_centers_") for m in model.clusters.cluster_models]
+    out["fitted_post_cluster"] = np.array(fitted)
+    for b, m in enumerate(model.clusters.cluster_models):
+        if fitted[b]:
+            out[f"centers_post_cluster_{b}"] = m.cluster_centers_.copy()
+            out[f"counts_post_cluster_{b}"] = m._counts.copy()
+    out["dtrajs_post_cluster"] = np.concatenate(model.dtrajs).astype(np.int64)
+    out["dtraj_sizes"] = np.array([len(d) for d in model.dtrajs], dtype=np.int64)
+    out["pairs_post_cluster"] = np.concatenate([np.array(p) for p in model.pair_dtrajs]).astype(np.int64)
+    out["target_bins_post_cluster"] = np.array(sorted(model.clusters.target_bins), dtype=np.int64)
+    out["basis_bins_post_cluster"] = np.array(sorted(model.clusters.basis_bins), dtype=np.int64)
+
+    model.get_fluxMatrix(0, first_iter=1, last_iter=model.maxIter, use_ray=True)
+    out["fluxMatrixRaw"] = model.fluxMatrixRaw.copy()
+
+    model.organize_fluxMatrix(use_ray=True)
+    out["fluxMatrix"] = model.fluxMatrix.copy()
+    out["n_clusters_clean"] = np.int64(model.n_clusters)
+    out["remap_clean"] = np.array([model.clusters.we_remap[b] for b in range(bm.nbins)], dtype=np.int64)
+    for b, m in enumerate(model.clusters.cluster_models):
+        if hasattr(m, "cluster_centers_"):
+            out[f"centers_clean_{b}"] = m.cluster_centers_.copy()
+    out["dtrajs_clean"] = np.concatenate(model.dtrajs).astype(np.int64)
+    out["pairs_clean"] = np.concatenate([np.array(p) for p in model.pair_dtrajs]).astype(np.int64)
+    out["targetRMSD_centers"] = np.asarray(model.targetRMSD_centers, dtype=np.float64)
+    out["targetRMSD_minmax"] = np.asarray(model.targetRMSD_minmax, dtype=np.float64)
+    out["all_centers"] = np.asarray(model.all_centers, dtype=np.float64)
+    out["indBasis"] = np.asarray(model.indBasis)
+    out["indTargets"] = np.asarray(model.indTargets)
+    # fluxMatrixRaw of the cleaned model before the pcoord sort (recomputed: organize restores the pre-clean one)
+    model.get_Tmatrix()
+    out["Tmatrix"] = model.Tmatrix.copy()
+    model.get_steady_state()
+    out["pSS"] = np.asarray(model.pSS).copy()
+    model.get_steady_state_target_flux()
+    out["JtargetSS"] = np.float64(model.JtargetSS)
+
+    # --- training log ----------------------------------------------------------------------
+    out["fit_bin"] = np.array([f["bin"] for f in log["fit"]], dtype=np.int64)
+    out["fit_n"] = np.array([f["n"] for f in log["fit"]], dtype=np.int64)
+    out["fit_first"] = np.array([f["first"] for f in log["fit"]])
+    out["fit_xsum"] = np.array([f["xsum"] for f in log["fit"]])
+    out["fit_n_since"] = np.array([f["n_since"] for f in log["fit"]], dtype=np.int64)
+    out["fit_centers"] = np.stack([f["centers"] for f in log["fit"]])
+    out["fit_counts"] = np.stack([f["counts"] for f in log["fit"]])
+    out["fit_pp"] = np.array([f["pp"] for f in log["fit"]], dtype=np.int64)
+    out["pp_indices"] = np.stack([p["indices"] for p in log["pp"]]).astype(np.int64)
+    out["pp_centers"] = np.stack([p["centers"] for p in log["pp"]])
+    out["pp_n"] = np.array([p["n"] for p in log["pp"]], dtype=np.int64)
+
+    # --- inputs ----------------------------------------------------------------------------
+    its = sorted(iters)
+    for k in ("Xp", "Xc", "p0", "p1", "w"):
+        out["in_" + k] = np.concatenate([iters[i][k] for i in its])
+    sizes = np.array([iters[i]["w"].shape[0] for i in its], dtype=np.int64)
+    out["in_offsets"] = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)
+    meta = dict(
+        case=case, seed=seed, D=cfg.D, S=cfg.S, K_s=cfg.K_s, n_iters=cfg.n_iters, maxIter=int(model.maxIter),
+        tau=1e-9, use_weights=bool(spec.get("use_weights", False)),
+        boundaries=[float(x) for x in synthetic.strata_boundaries(cfg.S)],
+        basis=basis.tolist(), target=target.tolist(),
+        numpy=np.__version__, scipy=scipy.__version__, sklearn=sklearn.__version__,
+        reference="jdrusso/msm_we 0.1.28.dev1 @ /root/reference", omp_num_threads=os.environ.get("OMP_NUM_THREADS"),
+    )
+    out["meta"] = np.array(json.dumps(meta))
+    sc.mini_kmeans = base_cls
+    skk._kmeans_plusplus = orig_pp
+    path = os.path.join(HERE, f"{case}.npz")
+    np.savez_compressed(path, **out)
+    print(
+        f"{case}: K={out['n_clusters_post_cluster']} -> clean {out['n_clusters_clean']}, "
+        f"{len(log['fit'])} partial_fits, J={out['JtargetSS']:.6e}, file {os.path.getsize(path)/1e6:.2f} MB"
+    )
+
+
+if __name__ == "__main__":
+    cases = sys.argv[1:] or list(CASES)
+    for c in cases:
+        # one process per case: the harness patches module globals
+        if len(cases) > 1:
+            import subprocess
+
+            subprocess.check_call([sys.executable, os.path.abspath(__file__), c])
+        else:
+            run_case(c)
