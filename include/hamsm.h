@@ -1,0 +1,197 @@
+/* hamsm.h -- C ABI of the MI355X-native haMSM construction hot path.
+ *
+ * Drop-in boundary for the hot path of jdrusso/msm_we (reference @ /root/reference): featurized
+ * frames -> stratified mini-batch k-means (train + assign) -> segment-pair flux matrix -> cluster
+ * pcoord statistics -> CSR transition matrix for the host solver.  The reference has no FFI: its
+ * boundary is duck-typed Python (levels B2/B3).  Each entry point below names the
+ * reference interface it replaces; the ctypes binding a maintainer adds is shown in INTEGRATION.md.
+ *
+ * Conventions
+ *  - extern "C", plain pointers and sizes, no C++/torch types.
+ *  - every function returns 0 on success or a negative HAMSM_E* code; hamsm_last_error(ctx) gives
+ *    the message.  Nothing throws or longjmps across the boundary.
+ *  - `d_` parameters are DEVICE addresses (from hamsm_malloc, or any HIP allocation of the same
+ *    device, e.g. a torch tensor's data_ptr); `h_` parameters are HOST addresses owned by the caller.
+ *  - one ctx per host thread / per GPU; a ctx is not thread-safe.
+ *  - random draws are INPUTS (the host keeps numpy's legacy RandomState in the reference's call
+ *    order, SURVEY.md §7 hard part 2): nothing in the library generates random numbers.
+ *  - arithmetic contract: distances are csq[j] - 2*dot(x, c_j) with dot an f64 FMA
+ *    chain over ascending feature index starting from +0.0; first minimum wins.  Two libraries
+ *    export this ABI: csrc (HIP, gfx950; the product) and oracle/ (plain C; test infrastructure).
+ */
+#ifndef HAMSM_H
+#define HAMSM_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define HAMSM_ABI_VERSION 1
+
+#define HAMSM_OK 0
+#define HAMSM_EINVAL (-1)   /* bad argument / call order                                         */
+#define HAMSM_ENOMEM (-2)
+#define HAMSM_EDEVICE (-3)  /* HIP / RCCL runtime error                                           */
+#define HAMSM_EUNFIT (-4)   /* frame maps to a stratum without centroids (AssertionError at
+                               stratified_clustering.py:187-189)                                 */
+#define HAMSM_ERANGE (-5)   /* label outside [0, K+2) in the flux build (ValueError from
+                               coo_matrix, _fluxmatrix.py:143-158)                               */
+#define HAMSM_ENOTSUP (-6)
+
+#define HAMSM_F32 0 /* frame features stored float32 (WESTPA auxdata/coord), widened exactly     */
+#define HAMSM_F64 1
+
+typedef struct hamsm_ctx hamsm_ctx;
+
+/* ---- lifecycle ------------------------------------------------------------------------------ */
+int hamsm_abi_version(void);
+const char *hamsm_backend_name(void); /* "hip-gfx950" (product) or "cpu-oracle" (tests only)      */
+int hamsm_create(int device, hamsm_ctx **out);
+void hamsm_destroy(hamsm_ctx *ctx);
+const char *hamsm_last_error(hamsm_ctx *ctx);
+
+/* ---- device memory (the reference keeps everything in NumPy arrays; these replace ray.put of
+ *      the model/coordinates, _clustering.py:1169-1176) ---------------------------------------- */
+int hamsm_malloc(hamsm_ctx *ctx, size_t bytes, void **d_out);
+int hamsm_free(hamsm_ctx *ctx, void *d_ptr);
+int hamsm_memcpy_h2d(hamsm_ctx *ctx, void *d_dst, const void *h_src, size_t bytes);
+int hamsm_memcpy_d2h(hamsm_ctx *ctx, void *h_dst, const void *d_src, size_t bytes);
+int hamsm_memset(hamsm_ctx *ctx, void *d_dst, int byte, size_t bytes);
+int hamsm_sync(hamsm_ctx *ctx);
+
+/* ---- model state (replaces the attributes of StratifiedClusters / modelWE that predict() reads:
+ *      stratified_clustering.py:61-99, msm_we.py:301-347,398-444) ------------------------------ */
+/* D features per frame (after featurize+project), pcoord dimensionality, number of WE bins.      */
+int hamsm_set_geometry(hamsm_ctx *ctx, int D, int pcoord_ndim, int n_strata);
+/* RectilinearBinMapper: per dimension n_bounds[d] float32 boundaries, concatenated in h_bounds.
+ * bin_mapper.assign call sites: stratified_clustering.py:134, _clustering.py:877.                */
+int hamsm_set_mapper_rectilinear(hamsm_ctx *ctx, const int32_t *h_n_bounds, const float *h_bounds);
+/* we_remap table (stratified_clustering.py:85,135; written at _clustering.py:730,1078).          */
+int hamsm_set_remap(hamsm_ctx *ctx, const int32_t *h_remap);
+/* basis / target pcoord boxes [ndim][2], strict inequalities (msm_we.py:462-527).                */
+int hamsm_set_bounds(hamsm_ctx *ctx, const double *h_basis, const double *h_target);
+/* cluster_models[stratum].cluster_centers_ (get/SET: cleaning deletes rows, _clustering.py:1041).
+ * h_csq: ||c||^2 as the caller computed it (sklearn: einsum, _k_means_lloyd.pyx:96) or NULL to
+ * let the library compute it (FMA chain).  h_counts: MiniBatchKMeans._counts or NULL (zeros).
+ * K_s == 0 marks the stratum unfitted (no cluster_centers_ attribute).                           */
+int hamsm_set_centroids(hamsm_ctx *ctx, int stratum, int K_s, const double *h_C,
+                        const double *h_csq, const double *h_counts);
+int hamsm_get_centroids(hamsm_ctx *ctx, int stratum, double *h_C, double *h_counts, double *h_csq);
+int hamsm_num_centroids(hamsm_ctx *ctx, int stratum); /* >=0, or negative error                    */
+
+/* ---- a3/a4: stratum id + basis/target flags per frame ---------------------------------------
+ * d_bin[i]  = mapper.assign(p_i) (then we_remap if apply_remap)           (int32)
+ * d_flags[i]= bit0 basis(p_i) | bit1 target(p_i)                          (uint8)                 */
+int hamsm_classify(hamsm_ctx *ctx, const double *d_pcoord, int64_t n, int apply_remap,
+                   int32_t *d_bin, uint8_t *d_flags);
+
+/* ---- a9: StratifiedClusters.predict (stratified_clustering.py:101-212) fused with a3/a4 -------
+ * label = Kfit+1 if target(p) else Kfit if basis(p) else off(s) + argmin_j ||x - c_j||^2 over
+ * the centroids of s = remap[bin(p)].  d_seen (nullable): int32[2][n_strata], [0][s]=1 when a
+ * target frame was seen in stratum s, [1][s]=1 for basis (target_bins / basis_bins sets, :159-169).
+ * ldx = row stride of d_X in elements (>= D).                                                    */
+int hamsm_assign(hamsm_ctx *ctx, const void *d_X, int x_dtype, int64_t ldx, const double *d_pcoord,
+                 int64_t n, int32_t *d_labels, int32_t *d_seen);
+/* Same, host buffers in and out (the drop-in `predict(coords)` call of B3).                      */
+int hamsm_predict_host(hamsm_ctx *ctx, const void *h_X, int x_dtype, const double *h_pcoord,
+                       int64_t n, int32_t *h_labels, int32_t *h_seen);
+
+/* ---- a10: flux matrix (FluxMatrixMixin.build_flux_matrix, _fluxmatrix.py:97-164) --------------
+ * F[(a,b)] += w with a = parent label, b = child label, then b=K+1 if target(p1); a=K if
+ * basis(p0); b=K if basis(p1) (that order, :135-137).  d_F is (K+2)^2 f64, caller-zeroed.
+ * mode 0: f64 atomics (order-free, within 1e-6 rel of the reference); mode 1: deterministic,
+ * bit-identical to summing per-iteration dense matrices in ascending iteration order
+ * (needs d_iter_offsets).  d_iter_offsets (int64[n_iters+1], device, nullable): when given, the
+ * segments processed are [offs[0], offs[n_iters]) RELATIVE TO THE ARRAY BASES and iteration t is
+ * [offs[t], offs[t+1]); n must equal offs[n_iters]-offs[0].  When NULL, segments [0, n) form one
+ * iteration.                                                                                     */
+int hamsm_flux_accumulate(hamsm_ctx *ctx, const int32_t *d_parent, const int32_t *d_child,
+                          const double *d_p0, const double *d_p1, const double *d_w, int64_t n,
+                          int K, double *d_F, int mode, const int64_t *d_iter_offsets,
+                          int64_t n_iters);
+/* fluxMatrix / nI (_fluxmatrix.py:342), elementwise true division.                               */
+int hamsm_scale(hamsm_ctx *ctx, double *d_F, int64_t count, double divisor);
+
+/* ---- a11: per-cluster pcoord statistics (ClusteringMixin.get_cluster_centers,
+ *      _clustering.py:1559-1591): over frames with label c: sum, min, max of pcoord dim 0 and
+ *      count.  All outputs length nstates, device, caller-initialised (0, +inf, -inf, 0).
+ *      Sums are accumulated in ascending frame order per cluster (deterministic).               */
+int hamsm_cluster_stats(hamsm_ctx *ctx, const int32_t *d_labels, const double *d_pcoord, int64_t n,
+                        int nstates, double *d_sum, double *d_min, double *d_max, int64_t *d_count);
+
+/* ---- a13 feed: row-normalised transition matrix as CSR (AnalysisMixin.get_Tmatrix,
+ *      _analysis.py:23-79): zero rows -> self loop, target rows -> uniform over basis.
+ *      d_F is nstates^2 (already organised).  Outputs are HOST arrays: h_indptr[nstates+1],
+ *      h_indices/h_data capacity `cap`; *h_nnz receives the count (returns HAMSM_ENOMEM if > cap). */
+int hamsm_tmatrix_csr(hamsm_ctx *ctx, const double *d_F, int nstates, const int32_t *h_basis, int nb,
+                      const int32_t *h_target, int nt, int64_t *h_indptr, int32_t *h_indices,
+                      double *h_data, int64_t cap, int64_t *h_nnz);
+
+/* ---- a5: training-call planning support (do_stratified_clustering, _clustering.py:843-886) ----
+ * d_bin[i] = mapper.assign(p_i) WITHOUT we_remap, or -1 when basis(p_i) or target(p_i)
+ * (:872-877).  h_hist[it][s] = number of frames of iteration `it` in bin s (rows of
+ * h_iter_offsets int64[n_iters+1] delimit iterations).                                           */
+int hamsm_train_prepass(hamsm_ctx *ctx, const double *d_pcoord, int64_t n,
+                        const int64_t *h_iter_offsets, int64_t n_iters, int32_t *d_bin,
+                        int64_t *h_hist);
+/* Row lists of one training call over frames [0,n) of d_bin: the reference computes indices in the
+ * basis/target-FILTERED list and applies them to the UNFILTERED coordinates (quirk Q1,
+ * _clustering.py:872-877 vs :892-899); d_rows receives, bin by bin (ascending), the ascending
+ * filtered ranks of the frames whose h_call_remap[bin] equals that bin.  h_counts[s] = rows of
+ * bin s; h_starts[s] = offset of its list in d_rows.                                             */
+int hamsm_train_build_rows(hamsm_ctx *ctx, const int32_t *d_bin, int64_t n,
+                           const int32_t *h_call_remap, int32_t *d_rows, int64_t *h_counts,
+                           int64_t *h_starts);
+
+/* ---- a6: k-means++ seeding (sklearn _kmeans.py:174-276, via _init_centroids :955-1035) --------
+ * Batch = rows d_rows[0..n_b) of d_X (NULL d_rows = identity); d_w per-FRAME weights indexed like
+ * d_X (NULL = ones).  h_sub/n_sub: the randint(0,n,init_size) subsample (:1006-1011) or NULL.
+ * first = random_state.choice(n, p=w/sum w) drawn by the host; h_u = uniform(size=L) draws for
+ * seeds 1..K_s-1 in call order, L = 2+int(ln K_s).  Result becomes the stratum's centroids with
+ * counts = 0.  h_chosen (nullable) receives the K_s chosen batch indices.                        */
+int hamsm_kmeans_seed(hamsm_ctx *ctx, int stratum, const void *d_X, int x_dtype, int64_t ldx,
+                      const int32_t *d_rows, int64_t n_b, const double *d_w, const int64_t *h_sub,
+                      int64_t n_sub, int K_s, int64_t first, const double *h_u, int L,
+                      int64_t *h_chosen);
+
+/* ---- a7: one MiniBatchKMeans step on a batch (sklearn _kmeans.py:1620-1642:
+ *      _labels_inertia + _minibatch_update_dense, _k_means_minibatch.pyx:59-108) -----------------
+ * assign the batch to the stratum's centroids, then per cluster, in ascending sample order:
+ * c*=count; c+=x*w...; count+=wsum; c*=1/count.  d_labels (nullable) receives the batch labels.  */
+int hamsm_minibatch_step(hamsm_ctx *ctx, int stratum, const void *d_X, int x_dtype, int64_t ldx,
+                         const int32_t *d_rows, int64_t n_b, const double *d_w, int32_t *d_labels);
+/* counts of a stratum (for the host-side low-count test, _kmeans.py:1643-1650).                  */
+int hamsm_get_counts(hamsm_ctx *ctx, int stratum, double *h_counts);
+/* random reassignment (_kmeans.py:1652-1673): centroid h_cluster[i] := batch row h_batch_row[i];
+ * counts[h_cluster[i]] := new_count.  The choice() draw is the host's.                           */
+int hamsm_reassign(hamsm_ctx *ctx, int stratum, const void *d_X, int x_dtype, int64_t ldx,
+                   const int32_t *d_rows, const int32_t *h_cluster, const int64_t *h_batch_row,
+                   int n_re, double new_count);
+
+/* ---- multi-GPU: frames shard by WE iteration; these are the only exchanges.
+ *      Replaces the driver-side sum of per-task flux matrices (_fluxmatrix.py:325-327) and
+ *      ray.put broadcasts (_clustering.py:1169-1176).  RCCL over xGMI in the product.           */
+int hamsm_comm_unique_id(char *h_id128);
+int hamsm_comm_init(hamsm_ctx *ctx, int nranks, int rank, const char *h_id128);
+int hamsm_comm_destroy(hamsm_ctx *ctx);
+int hamsm_allreduce_sum_f64(hamsm_ctx *ctx, double *d_buf, int64_t count);
+int hamsm_allreduce_min_f64(hamsm_ctx *ctx, double *d_buf, int64_t count);
+int hamsm_allreduce_max_f64(hamsm_ctx *ctx, double *d_buf, int64_t count);
+int hamsm_allreduce_sum_i64(hamsm_ctx *ctx, int64_t *d_buf, int64_t count);
+int hamsm_bcast(hamsm_ctx *ctx, void *d_buf, size_t bytes, int root);
+/* broadcast the whole model state (centroids, counts, csq, remap) from root to every rank.       */
+int hamsm_bcast_model(hamsm_ctx *ctx, int root);
+
+/* ---- timers: seconds of device time per stage since the last reset, measured with HIP events on
+ *      the library's stream.  h_out[8]: assign, flux, stats, seed, step, reassign, prepass, other */
+int hamsm_timers(hamsm_ctx *ctx, double *h_out, int reset);
+/* last kernel-only duration (ms) of the named stage: 0 assign, 1 flux, 4 step                    */
+int hamsm_last_kernel_ms(hamsm_ctx *ctx, int stage, double *h_ms);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HAMSM_H */

@@ -1,0 +1,397 @@
+"""ctypes binding of the C ABI in ``include/hamsm.h``.
+
+``load()`` returns the product library (``csrc/libhamsm_hip.so``, HIP for gfx950) and raises when
+it is missing -- there is no CPU fallback.  ``Hamsm`` wraps *a* loaded library; tests construct it
+around the oracle's CDLL to validate the host logic without a GPU (the oracle exports the same ABI).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+__all__ = ["Hamsm", "HamsmError", "load", "library_path", "F32", "F64", "SYMBOLS"]
+
+F32, F64 = 0, 1
+_HERE = os.path.dirname(os.path.abspath(__file__))
+
+_vp, _i32, _i64, _f64, _sz = C.c_void_p, C.c_int32, C.c_int64, C.c_double, C.c_size_t
+_int = C.c_int
+
+# name -> (restype, argtypes); kept in the order of include/hamsm.h
+SYMBOLS = {
+    "hamsm_abi_version": (_int, []),
+    "hamsm_backend_name": (C.c_char_p, []),
+    "hamsm_create": (_int, [_int, C.POINTER(_vp)]),
+    "hamsm_destroy": (None, [_vp]),
+    "hamsm_last_error": (C.c_char_p, [_vp]),
+    "hamsm_malloc": (_int, [_vp, _sz, C.POINTER(_vp)]),
+    "hamsm_free": (_int, [_vp, _vp]),
+    "hamsm_memcpy_h2d": (_int, [_vp, _vp, _vp, _sz]),
+    "hamsm_memcpy_d2h": (_int, [_vp, _vp, _vp, _sz]),
+    "hamsm_memset": (_int, [_vp, _vp, _int, _sz]),
+    "hamsm_sync": (_int, [_vp]),
+    "hamsm_set_geometry": (_int, [_vp, _int, _int, _int]),
+    "hamsm_set_mapper_rectilinear": (_int, [_vp, _vp, _vp]),
+    "hamsm_set_remap": (_int, [_vp, _vp]),
+    "hamsm_set_bounds": (_int, [_vp, _vp, _vp]),
+    "hamsm_set_centroids": (_int, [_vp, _int, _int, _vp, _vp, _vp]),
+    "hamsm_get_centroids": (_int, [_vp, _int, _vp, _vp, _vp]),
+    "hamsm_num_centroids": (_int, [_vp, _int]),
+    "hamsm_classify": (_int, [_vp, _vp, _i64, _int, _vp, _vp]),
+    "hamsm_assign": (_int, [_vp, _vp, _int, _i64, _vp, _i64, _vp, _vp]),
+    "hamsm_predict_host": (_int, [_vp, _vp, _int, _vp, _i64, _vp, _vp]),
+    "hamsm_flux_accumulate": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _int, _vp, _int, _vp, _i64]),
+    "hamsm_scale": (_int, [_vp, _vp, _i64, _f64]),
+    "hamsm_cluster_stats": (_int, [_vp, _vp, _vp, _i64, _int, _vp, _vp, _vp, _vp]),
+    "hamsm_tmatrix_csr": (_int, [_vp, _vp, _int, _vp, _int, _vp, _int, _vp, _vp, _vp, _i64, _vp]),
+    "hamsm_train_prepass": (_int, [_vp, _vp, _i64, _vp, _i64, _vp, _vp]),
+    "hamsm_train_build_rows": (_int, [_vp, _vp, _i64, _vp, _vp, _vp, _vp]),
+    "hamsm_kmeans_seed": (_int, [_vp, _int, _vp, _int, _i64, _vp, _i64, _vp, _vp, _i64, _int, _i64, _vp, _int, _vp]),
+    "hamsm_minibatch_step": (_int, [_vp, _int, _vp, _int, _i64, _vp, _i64, _vp, _vp]),
+    "hamsm_get_counts": (_int, [_vp, _int, _vp]),
+    "hamsm_reassign": (_int, [_vp, _int, _vp, _int, _i64, _vp, _vp, _vp, _int, _f64]),
+    "hamsm_comm_unique_id": (_int, [_vp]),
+    "hamsm_comm_init": (_int, [_vp, _int, _int, _vp]),
+    "hamsm_comm_destroy": (_int, [_vp]),
+    "hamsm_allreduce_sum_f64": (_int, [_vp, _vp, _i64]),
+    "hamsm_allreduce_min_f64": (_int, [_vp, _vp, _i64]),
+    "hamsm_allreduce_max_f64": (_int, [_vp, _vp, _i64]),
+    "hamsm_allreduce_sum_i64": (_int, [_vp, _vp, _i64]),
+    "hamsm_bcast": (_int, [_vp, _vp, _sz, _int]),
+    "hamsm_bcast_model": (_int, [_vp, _int]),
+    "hamsm_timers": (_int, [_vp, _vp, _int]),
+    "hamsm_last_kernel_ms": (_int, [_vp, _int, _vp]),
+}
+
+
+class HamsmError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"hamsm error {code}: {msg}")
+        self.code = code
+
+
+def library_path() -> str:
+    return os.path.join(_HERE, "csrc", "libhamsm_hip.so")
+
+
+def load() -> C.CDLL:
+    """The product library.  Fails loudly when the HIP extension has not been built."""
+    path = library_path()
+    if not os.path.exists(path):
+        raise ImportError(
+            f"{path} not found: build the HIP library first (python -c 'import __graft_entry__ as g; g.build()' "
+            "or make -C msm_we_amd/csrc).  msm_we_amd has no CPU fallback."
+        )
+    return C.CDLL(path, mode=C.RTLD_GLOBAL)
+
+
+def bind(lib: C.CDLL) -> C.CDLL:
+    for name, (res, args) in SYMBOLS.items():
+        fn = getattr(lib, name)  # AttributeError if the library does not export the ABI
+        fn.restype = res
+        fn.argtypes = args
+    return lib
+
+
+def _hp(a):
+    """host pointer of a numpy array (or None)"""
+    if a is None:
+        return None
+    return a.ctypes.data_as(_vp)
+
+
+class DevBuf:
+    """A device allocation owned through the ABI (freed with the ctx or explicitly)."""
+
+    __slots__ = ("h", "ptr", "nbytes", "dtype", "shape")
+
+    def __init__(self, h, ptr, nbytes, dtype=None, shape=None):
+        self.h, self.ptr, self.nbytes, self.dtype, self.shape = h, ptr, nbytes, dtype, shape
+
+    def free(self):
+        if self.ptr:
+            ptr, self.ptr = self.ptr, None
+            if getattr(self.h, "ctx", None):
+                self.h._free(ptr)
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+    def __deepcopy__(self, memo):
+        return self  # device buffers are shared by reference (never written after creation by the mixins)
+
+    def to_host(self):
+        out = np.empty(self.shape, dtype=self.dtype)
+        self.h.d2h(out, self)
+        return out
+
+    def offset(self, elems):
+        """device address `elems` elements (of self.dtype, row-major flat) past the start"""
+        return self.ptr + int(elems) * np.dtype(self.dtype).itemsize
+
+
+def _dp(b):
+    if b is None:
+        return None
+    if isinstance(b, DevBuf):
+        return b.ptr
+    return int(b)
+
+
+class Hamsm:
+    """One context (one GPU).  Thin, 1:1 with the C ABI; argument meaning as in hamsm.h."""
+
+    def __init__(self, lib: C.CDLL | None = None, device: int = 0):
+        self.lib = bind(lib if lib is not None else load())
+        if self.lib.hamsm_abi_version() != 1:
+            raise ImportError("hamsm ABI version mismatch")
+        ctx = _vp()
+        rc = self.lib.hamsm_create(int(device), C.byref(ctx))
+        if rc != 0:
+            raise HamsmError(rc, "hamsm_create failed")
+        self.ctx = ctx
+        self.device = device
+        self.D = self.ndim = self.S = None
+        self._bufs = []
+
+    # -- plumbing ---------------------------------------------------------------------------
+    @property
+    def backend(self) -> str:
+        return self.lib.hamsm_backend_name().decode()
+
+    def _ck(self, rc):
+        if rc != 0:
+            raise HamsmError(rc, self.lib.hamsm_last_error(self.ctx).decode(errors="replace"))
+
+    def close(self):
+        if getattr(self, "ctx", None):
+            self.lib.hamsm_destroy(self.ctx)
+            self.ctx = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def alloc(self, shape, dtype) -> DevBuf:
+        shape = (shape,) if np.isscalar(shape) else tuple(shape)
+        nbytes = int(np.prod(shape, dtype=np.int64)) * np.dtype(dtype).itemsize
+        p = _vp()
+        self._ck(self.lib.hamsm_malloc(self.ctx, max(nbytes, 1), C.byref(p)))
+        return DevBuf(self, p.value, nbytes, np.dtype(dtype), shape)
+
+    def _free(self, ptr):
+        self._ck(self.lib.hamsm_free(self.ctx, ptr))
+
+    def to_device(self, a: np.ndarray) -> DevBuf:
+        a = np.ascontiguousarray(a)
+        b = self.alloc(a.shape, a.dtype)
+        if a.nbytes:
+            self._ck(self.lib.hamsm_memcpy_h2d(self.ctx, b.ptr, _hp(a), a.nbytes))
+        return b
+
+    def h2d(self, dst, a: np.ndarray):
+        a = np.ascontiguousarray(a)
+        if a.nbytes:
+            self._ck(self.lib.hamsm_memcpy_h2d(self.ctx, _dp(dst), _hp(a), a.nbytes))
+
+    def d2h(self, out: np.ndarray, src, nbytes=None):
+        assert out.flags.c_contiguous
+        n = out.nbytes if nbytes is None else nbytes
+        if n:
+            self._ck(self.lib.hamsm_memcpy_d2h(self.ctx, _hp(out), _dp(src), n))
+        return out
+
+    def zeros(self, shape, dtype) -> DevBuf:
+        b = self.alloc(shape, dtype)
+        self.memset(b, 0, b.nbytes)
+        return b
+
+    def memset(self, dst, byte, nbytes):
+        if nbytes:
+            self._ck(self.lib.hamsm_memset(self.ctx, _dp(dst), int(byte), int(nbytes)))
+
+    def sync(self):
+        self._ck(self.lib.hamsm_sync(self.ctx))
+
+    # -- model state ------------------------------------------------------------------------
+    def set_geometry(self, D, pcoord_ndim, n_strata):
+        self._ck(self.lib.hamsm_set_geometry(self.ctx, int(D), int(pcoord_ndim), int(n_strata)))
+        self.D, self.ndim, self.S = int(D), int(pcoord_ndim), int(n_strata)
+
+    def set_mapper_rectilinear(self, boundaries):
+        bs = [np.ascontiguousarray(b, dtype=np.float32) for b in boundaries]
+        nb = np.array([len(b) for b in bs], dtype=np.int32)
+        flat = np.concatenate(bs).astype(np.float32)
+        self._ck(self.lib.hamsm_set_mapper_rectilinear(self.ctx, _hp(nb), _hp(flat)))
+
+    def set_remap(self, remap):
+        r = np.ascontiguousarray(remap, dtype=np.int32)
+        assert r.shape == (self.S,)
+        self._ck(self.lib.hamsm_set_remap(self.ctx, _hp(r)))
+
+    def set_bounds(self, basis, target):
+        b = np.ascontiguousarray(basis, dtype=np.float64).reshape(self.ndim, 2)
+        t = np.ascontiguousarray(target, dtype=np.float64).reshape(self.ndim, 2)
+        self._ck(self.lib.hamsm_set_bounds(self.ctx, _hp(b), _hp(t)))
+
+    def set_centroids(self, stratum, Cmat, csq=None, counts=None):
+        if Cmat is None or len(Cmat) == 0:
+            self._ck(self.lib.hamsm_set_centroids(self.ctx, int(stratum), 0, None, None, None))
+            return
+        Cm = np.ascontiguousarray(Cmat, dtype=np.float64)
+        assert Cm.ndim == 2 and Cm.shape[1] == self.D, (Cm.shape, self.D)
+        cs = None if csq is None else np.ascontiguousarray(csq, dtype=np.float64)
+        ct = None if counts is None else np.ascontiguousarray(counts, dtype=np.float64)
+        self._ck(self.lib.hamsm_set_centroids(self.ctx, int(stratum), Cm.shape[0], _hp(Cm), _hp(cs), _hp(ct)))
+
+    def num_centroids(self, stratum) -> int:
+        k = self.lib.hamsm_num_centroids(self.ctx, int(stratum))
+        if k < 0:
+            self._ck(k)
+        return k
+
+    def get_centroids(self, stratum):
+        k = self.num_centroids(stratum)
+        Cm = np.empty((k, self.D))
+        counts = np.empty(k)
+        csq = np.empty(k)
+        if k:
+            self._ck(self.lib.hamsm_get_centroids(self.ctx, int(stratum), _hp(Cm), _hp(counts), _hp(csq)))
+        return Cm, counts, csq
+
+    # -- ops --------------------------------------------------------------------------------
+    def classify(self, d_pcoord, n, apply_remap, d_bin, d_flags):
+        self._ck(self.lib.hamsm_classify(self.ctx, _dp(d_pcoord), int(n), int(apply_remap), _dp(d_bin), _dp(d_flags)))
+
+    def assign(self, d_X, x_dtype, ldx, d_pcoord, n, d_labels, d_seen=None):
+        self._ck(self.lib.hamsm_assign(self.ctx, _dp(d_X), int(x_dtype), int(ldx), _dp(d_pcoord), int(n),
+                                       _dp(d_labels), _dp(d_seen)))
+
+    def predict_host(self, X: np.ndarray, pcoord: np.ndarray, want_seen=False):
+        X = np.ascontiguousarray(X)
+        if X.dtype == np.float32:
+            dt = F32
+        else:
+            X = np.ascontiguousarray(X, dtype=np.float64)
+            dt = F64
+        p = np.ascontiguousarray(pcoord, dtype=np.float64).reshape(-1, self.ndim)
+        n = X.shape[0]
+        assert X.ndim == 2 and X.shape[1] == self.D and p.shape[0] == n, (X.shape, p.shape, self.D)
+        labels = np.empty(n, dtype=np.int32)
+        seen = np.zeros((2, self.S), dtype=np.int32) if want_seen else None
+        self._ck(self.lib.hamsm_predict_host(self.ctx, _hp(X), dt, _hp(p), n, _hp(labels), _hp(seen)))
+        return (labels, seen) if want_seen else labels
+
+    def flux_accumulate(self, d_parent, d_child, d_p0, d_p1, d_w, n, K, d_F, mode=0, d_iter_offsets=None, n_iters=0):
+        self._ck(self.lib.hamsm_flux_accumulate(self.ctx, _dp(d_parent), _dp(d_child), _dp(d_p0), _dp(d_p1), _dp(d_w),
+                                                int(n), int(K), _dp(d_F), int(mode), _dp(d_iter_offsets), int(n_iters)))
+
+    def scale(self, d_F, count, divisor):
+        self._ck(self.lib.hamsm_scale(self.ctx, _dp(d_F), int(count), float(divisor)))
+
+    def cluster_stats(self, d_labels, d_pcoord, n, nstates, d_sum, d_min, d_max, d_count):
+        self._ck(self.lib.hamsm_cluster_stats(self.ctx, _dp(d_labels), _dp(d_pcoord), int(n), int(nstates),
+                                              _dp(d_sum), _dp(d_min), _dp(d_max), _dp(d_count)))
+
+    def tmatrix_csr(self, d_F, nstates, basis_idx, target_idx):
+        b = np.ascontiguousarray(basis_idx, dtype=np.int32)
+        t = np.ascontiguousarray(target_idx, dtype=np.int32)
+        cap = int(nstates) * int(nstates)
+        indptr = np.empty(nstates + 1, dtype=np.int64)
+        indices = np.empty(cap, dtype=np.int32)
+        data = np.empty(cap, dtype=np.float64)
+        nnz = _i64(0)
+        self._ck(self.lib.hamsm_tmatrix_csr(self.ctx, _dp(d_F), int(nstates), _hp(b), len(b), _hp(t), len(t),
+                                            _hp(indptr), _hp(indices), _hp(data), cap, C.byref(nnz)))
+        k = nnz.value
+        return indptr, indices[:k].copy(), data[:k].copy()
+
+    def train_prepass(self, d_pcoord, n, iter_offsets, d_bin):
+        offs = np.ascontiguousarray(iter_offsets, dtype=np.int64)
+        n_iters = len(offs) - 1
+        hist = np.zeros((n_iters, self.S), dtype=np.int64)
+        self._ck(self.lib.hamsm_train_prepass(self.ctx, _dp(d_pcoord), int(n), _hp(offs), n_iters, _dp(d_bin), _hp(hist)))
+        return hist
+
+    def train_build_rows(self, d_bin, n, call_remap, d_rows):
+        cr = np.ascontiguousarray(call_remap, dtype=np.int32)
+        counts = np.zeros(self.S, dtype=np.int64)
+        starts = np.zeros(self.S, dtype=np.int64)
+        self._ck(self.lib.hamsm_train_build_rows(self.ctx, _dp(d_bin), int(n), _hp(cr), _dp(d_rows), _hp(counts), _hp(starts)))
+        return counts, starts
+
+    def kmeans_seed(self, stratum, d_X, x_dtype, ldx, d_rows, n_b, d_w, sub, K_s, first, u, L, want_chosen=False):
+        subh = None if sub is None else np.ascontiguousarray(sub, dtype=np.int64)
+        uh = np.ascontiguousarray(u, dtype=np.float64)
+        assert uh.size == (K_s - 1) * L
+        chosen = np.empty(K_s, dtype=np.int64) if want_chosen else None
+        self._ck(self.lib.hamsm_kmeans_seed(self.ctx, int(stratum), _dp(d_X), int(x_dtype), int(ldx), _dp(d_rows), int(n_b),
+                                            _dp(d_w), _hp(subh), 0 if subh is None else len(subh), int(K_s), int(first),
+                                            _hp(uh), int(L), _hp(chosen)))
+        return chosen
+
+    def minibatch_step(self, stratum, d_X, x_dtype, ldx, d_rows, n_b, d_w=None, d_labels=None):
+        self._ck(self.lib.hamsm_minibatch_step(self.ctx, int(stratum), _dp(d_X), int(x_dtype), int(ldx), _dp(d_rows),
+                                               int(n_b), _dp(d_w), _dp(d_labels)))
+
+    def get_counts(self, stratum):
+        k = self.num_centroids(stratum)
+        out = np.empty(k)
+        if k:
+            self._ck(self.lib.hamsm_get_counts(self.ctx, int(stratum), _hp(out)))
+        return out
+
+    def reassign(self, stratum, d_X, x_dtype, ldx, d_rows, clusters, batch_rows, new_count):
+        cl = np.ascontiguousarray(clusters, dtype=np.int32)
+        br = None if batch_rows is None else np.ascontiguousarray(batch_rows, dtype=np.int64)
+        self._ck(self.lib.hamsm_reassign(self.ctx, int(stratum), _dp(d_X), int(x_dtype), int(ldx), _dp(d_rows), _hp(cl),
+                                         _hp(br), len(cl), float(new_count)))
+
+    # -- exchange step ----------------------------------------------------------------------
+    def comm_unique_id(self) -> bytes:
+        buf = C.create_string_buffer(128)
+        self._ck(self.lib.hamsm_comm_unique_id(buf))
+        return buf.raw
+
+    def comm_init(self, nranks, rank, uid: bytes):
+        assert len(uid) == 128
+        self._ck(self.lib.hamsm_comm_init(self.ctx, int(nranks), int(rank), C.c_char_p(uid)))
+        self.nranks, self.rank = nranks, rank
+
+    def comm_destroy(self):
+        self._ck(self.lib.hamsm_comm_destroy(self.ctx))
+
+    def allreduce_sum_f64(self, d_buf, count):
+        self._ck(self.lib.hamsm_allreduce_sum_f64(self.ctx, _dp(d_buf), int(count)))
+
+    def allreduce_min_f64(self, d_buf, count):
+        self._ck(self.lib.hamsm_allreduce_min_f64(self.ctx, _dp(d_buf), int(count)))
+
+    def allreduce_max_f64(self, d_buf, count):
+        self._ck(self.lib.hamsm_allreduce_max_f64(self.ctx, _dp(d_buf), int(count)))
+
+    def allreduce_sum_i64(self, d_buf, count):
+        self._ck(self.lib.hamsm_allreduce_sum_i64(self.ctx, _dp(d_buf), int(count)))
+
+    def bcast(self, d_buf, nbytes, root=0):
+        self._ck(self.lib.hamsm_bcast(self.ctx, _dp(d_buf), int(nbytes), int(root)))
+
+    def bcast_model(self, root=0):
+        self._ck(self.lib.hamsm_bcast_model(self.ctx, int(root)))
+
+    def timers(self, reset=False):
+        out = np.zeros(8)
+        self._ck(self.lib.hamsm_timers(self.ctx, _hp(out), int(reset)))
+        return dict(zip(("assign", "flux", "stats", "seed", "step", "reassign", "prepass", "other"), out))
+
+    def last_kernel_ms(self, stage) -> float:
+        v = _f64(0.0)
+        self._ck(self.lib.hamsm_last_kernel_ms(self.ctx, int(stage), C.byref(v)))
+        return v.value

@@ -1,0 +1,169 @@
+"""``AnalysisMixin``: transition matrix, steady state, target flux, committor.
+
+The solve stays on the host (BASELINE.json north star) and is fed by the
+GPU-built CSR transition matrix (``hamsm_tmatrix_csr``).  Semantics follow the reference's
+``msm_we/_hamsm/_analysis.py:23-79, 97-282, 317-384, 527-606`` and ``utils.py:87-161``: dominant left
+eigenvector refined by inverse iteration, convergence on the target flux.  Where the reference forms
+an explicit sparse inverse (``utils.py:138``) this factorises once and solves (same SuperLU
+factorisation, no inverse); above ``dense_eig_max`` states the dense ``eig`` seed (``:222``) is
+replaced by ARPACK on the CSR matrix.
+"""
+from __future__ import annotations
+
+import logging
+
+import numpy as np
+import scipy.sparse as sp
+import scipy.sparse.csgraph as csgraph
+import scipy.sparse.linalg as spla
+
+log = logging.getLogger("msm_we_amd")
+
+__all__ = ["AnalysisMixin", "inverse_iteration", "is_connected"]
+
+
+def is_connected(matrix, source_states, target_states, directed=True):
+    """reference `utils.py:87-113`"""
+    d = csgraph.shortest_path(matrix, directed=directed, indices=source_states)
+    return np.inf not in d[:, target_states]
+
+
+def inverse_iteration(guess, matrix, mu=1):
+    """One step of inverse iteration towards the eigenvalue-1 left eigenvector (reference
+    `utils.py:116-161`): solve (T^T - mu I) x = guess, normalise; fall back to mu=0.999 when the
+    shifted matrix is exactly singular."""
+    n = guess.shape[0]
+    A = (matrix.T - mu * sp.eye(n)).tocsc()
+    try:
+        lu = spla.splu(A)
+    except RuntimeError:
+        if mu != 1:
+            raise
+        log.error("When solving steady-state, failed to perform inverse iteration! Trying again with mu=0.999.")
+        return inverse_iteration(guess, matrix, mu=0.999)
+    x = lu.solve(np.asarray(guess, dtype=np.float64))
+    x = x / sum(x)
+    return x
+
+
+class AnalysisMixin:
+    Tmatrix = None
+    pSS = None
+    lagtime = None
+    JtargetSS = None
+    dense_eig_max = 2500
+
+    def get_Tmatrix(self):
+        """`_analysis.py:23-79` on the device: row-normalise, zero rows -> self loop, target rows ->
+        uniform over the basis; returned as CSR (kept in ``Tmatrix_csr``) and, for API parity, dense."""
+        h = self.h
+        F = np.ascontiguousarray(self.fluxMatrix, dtype=np.float64)
+        n = F.shape[0]
+        d_F = h.to_device(F)
+        indptr, indices, data = h.tmatrix_csr(d_F, n, self.indBasis, self.indTargets)
+        d_F.free()
+        self.Tmatrix_csr = sp.csr_matrix((data, indices, indptr), shape=(n, n))
+        self.Tmatrix = self.Tmatrix_csr.toarray()
+
+    def _T_csr(self):
+        T = getattr(self, "Tmatrix_csr", None)
+        if T is None or T.shape != np.shape(self.Tmatrix):
+            T = sp.csr_matrix(self.Tmatrix)
+        return T
+
+    def get_steady_state_algebraic(self, max_iters=1000, check_negative=True, set=True):
+        """`_analysis.py:193-282`"""
+        n = self.Tmatrix.shape[0]
+        if n <= self.dense_eig_max:
+            vals, vecs = np.linalg.eig(np.transpose(self.Tmatrix))
+            pSS = np.real(vecs[:, np.argmax(np.real(vals))]).squeeze()
+        else:
+            vals, vecs = spla.eigs(self._T_csr().T.tocsc(), k=1, which="LR")
+            pSS = np.real(vecs[:, 0]).squeeze()
+        assert not np.isclose(np.sum(pSS), 0), "Steady-state distribution sums to 0!"
+        pSS = pSS / np.sum(pSS)
+        if sum(pSS < 0) > 0 and max_iters > 0:
+            # matrix-power correction, :236-260
+            last, Tp = pSS, self.Tmatrix.copy()
+            new = pSS
+            for N in range(max_iters):
+                new = Tp.T @ last
+                if sum(new < 0) == 0:
+                    break
+                last = new
+                Tp = np.matmul(self.Tmatrix, Tp)
+            if N != max_iters - 1:
+                pSS = new
+        if not np.all(pSS >= 0):
+            if check_negative:
+                assert np.all(pSS >= 0), f"Some negative elements in steady-state distribution: {pSS}"
+            else:
+                log.warning("Some negative  elements in pSS... Ignoring, and setting model.pSS anyways.")
+        if set:
+            self.pSS = pSS
+        else:
+            return pSS
+
+    def get_steady_state(self, flux_fractional_convergence=1e-4, max_iters=10):
+        """`_analysis.py:97-191`"""
+        T = self._T_csr()
+        last_pSS = self.get_steady_state_algebraic(max_iters=10, check_negative=False, set=False)
+        last_flux = self.get_steady_state_target_flux(pSS=last_pSS, _set=False)
+        for N in range(max_iters):
+            iterated = inverse_iteration(matrix=T, guess=last_pSS)
+            last_pSS = iterated
+            new_flux = self.get_steady_state_target_flux(pSS=last_pSS, _set=False)
+            flux_change = new_flux - last_flux
+            last_flux = new_flux
+            if abs(flux_change) < last_flux * flux_fractional_convergence:
+                break
+            elif N == max_iters - 1 and not last_flux == 0:
+                log.warning("Flux is nonzero and did not converge!")
+        assert (last_pSS >= 0).all(), "Negative elements in pSS"
+        assert last_flux >= 0, "Negative flux estimate from this pSS"
+        self.pSS = last_pSS
+
+    def get_steady_state_target_flux(self, pSS=None, _set=True):
+        """`_analysis.py:317-384`"""
+        T = self._T_csr()
+        if not is_connected(T, self.indBasis, self.indTargets, directed=True):
+            log.critical("There is no path in this matrix from the basis to the target, so no MFPT can be calculated.")
+            return -1
+        if pSS is None:
+            pSS = np.squeeze(np.array(self.pSS))
+        lagtime = self.tau * (self.n_lag + 1)
+        not_targets = np.setdiff1d(range(self.nBins), self.indTargets)
+        Jt = 0.0
+        for jj in self.indTargets:
+            col = np.asarray(T[:, int(jj)].todense()).ravel()
+            Jt = Jt + np.sum(np.multiply(pSS[not_targets], col[not_targets]))
+        if _set:
+            self.lagtime = lagtime
+            self.JtargetSS = Jt / self.lagtime
+        else:
+            return Jt / lagtime
+
+    def get_committor(self, conv=1e-5):
+        """`_analysis.py:527-606`: absorbing basis / target, iterate q <- T q until sum|dq| < conv."""
+        F = self.fluxMatrix.copy()
+        out = np.sum(F, 1)
+        for i in range(F.shape[0]):
+            if out[i] > 0:
+                F[i, :] = F[i, :] / out[i]
+            if out[i] == 0.0:
+                F[i, i] = 1.0
+        for ii in self.indBasis:
+            F[ii, :] = 0.0
+            F[ii, ii] = 1.0
+        Fs = sp.csr_matrix(F)
+        q = np.zeros((self.nBins, 1))
+        q[self.indTargets, 0] = 1.0
+        qp = np.ones_like(q)
+        dconv = 100.0
+        while dconv > conv:
+            q[self.indTargets, 0] = 1.0
+            q[self.indBasis, 0] = 0.0
+            q = Fs @ q
+            dconv = np.sum(np.abs(qp - q))
+            qp = q.copy()
+        self.q = q.squeeze()

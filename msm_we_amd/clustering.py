@@ -1,0 +1,368 @@
+"""``ClusteringMixin``: stratified k-means training, discretization and cleaning.
+
+Mirrors the stratified branch of the reference's ``msm_we/_hamsm/_clustering.py`` (``:142-196``,
+``:525-1142``, ``:1144-1396``, ``:1528-1611``): same method names, arguments, post-conditions and
+quirks, with the arithmetic in the HIP library.  The reference's
+fork-per-iteration / Ray task machinery (``:672-691``, ``:1183-1233``) has no counterpart: frames
+are HBM-resident and one launch covers every segment.
+"""
+from __future__ import annotations
+
+import logging
+from copy import deepcopy
+
+import numpy as np
+
+from .stratified_clustering import StratifiedClusters
+
+log = logging.getLogger("msm_we_amd")
+
+__all__ = ["ClusteringMixin", "find_connected_sets"]
+
+
+def find_connected_sets(C, directed=True):
+    """Strongly connected components, largest first, each sorted (reference ``utils.py:21-84``;
+    host-side by design)."""
+    import scipy.sparse as sp
+    import scipy.sparse.csgraph as csgraph
+
+    Cs = sp.csr_matrix(C)
+    nc, lab = csgraph.connected_components(Cs, directed=directed, connection="strong")
+    order = np.argsort(lab)
+    lab_sorted = lab[order]
+    cuts = np.concatenate([[0], np.cumsum(np.bincount(lab_sorted))])
+    cc = [np.sort(order[cuts[i]: cuts[i + 1]]) for i in range(nc)]
+    return sorted(cc, key=lambda x: -len(x))
+
+
+class ClusteringMixin:
+    n_clusters = None
+    clusters = None
+    post_cluster_model = None
+
+    # ------------------------------------------------------------------------------------------
+    def cluster_coordinates(self, n_clusters, streaming=False, first_cluster_iter=None, use_ray=False,
+                            stratified=True, iters_to_use=None, store_validation_model=False, progress_bar=None,
+                            **_cluster_args):
+        """`_clustering.py:142-196`."""
+        self.clustering_method = None
+        if not stratified:
+            raise NotImplementedError("cluster_aggregated (_clustering.py:197-523) is legacy and out of scope")
+        self.clustering_method = "stratified"
+        self.cluster_stratified(n_clusters=n_clusters, streaming=streaming, first_cluster_iter=first_cluster_iter,
+                                use_ray=use_ray, iters_to_use=iters_to_use, **_cluster_args)
+        if store_validation_model:
+            self.post_cluster_model = deepcopy(self)
+
+    # ------------------------------------------------------------------------------------------
+    def _configure_device(self, bin_mapper, D):
+        """Push geometry / mapper / bounds (the state `predict` reads, hamsm.h 'model state')."""
+        h = self.h
+        if type(bin_mapper).__name__ != "RectilinearBinMapper":
+            # `_clustering.py:604-609`: only static mappers are supported; Voronoi is not built yet
+            raise Exception(f"{type(bin_mapper)} mapper is not supported (RectilinearBinMapper only)")
+        bounds = [np.asarray(b, dtype=np.float32) for b in bin_mapper.boundaries]
+        h.set_geometry(D, self.pcoord_ndim, bin_mapper.nbins)
+        h.set_mapper_rectilinear(bounds)
+        h.set_bounds(self.basis_pcoord_bounds, self.target_pcoord_bounds)
+        h._active_clusters = None
+
+    def cluster_stratified(self, n_clusters, streaming=True, first_cluster_iter=None, use_ray=True, bin_iteration=2,
+                           iters_to_use=None, user_bin_mapper=None, progress_bar=None, **_cluster_args):
+        """`_clustering.py:525-746`."""
+        if user_bin_mapper is None:
+            raise NotImplementedError("loading the bin mapper from west.h5 (_clustering.py:584-609) needs westpa; "
+                                      "pass user_bin_mapper")
+        bin_mapper = user_bin_mapper
+        store = self.stage_iterations()
+        self._configure_device(bin_mapper, store.D)
+        h = self.h
+        clusters = StratifiedClusters(bin_mapper, self, n_clusters, [], h=h, **_cluster_args)
+
+        if iters_to_use is None:  # :640-651
+            iters_to_use = range(first_cluster_iter if first_cluster_iter is not None else 1, self.maxIter)
+        iters_to_use = [int(i) for i in iters_to_use]
+
+        # a5 planning support: raw bin (or -1 in basis/target) of every frame's PARENT pcoord
+        # (:849-852 pcoord0List, quirk Q2) + per-iteration histograms, one pass over p0
+        d_bin = h.alloc(store.N, np.int32)
+        hist = h.train_prepass(store.p0, store.N, store.offsets, d_bin)
+        d_rows = h.alloc(max(store.N, 1), np.int32)
+
+        self.dtrajs = []
+        all_filled, all_unfilled = set(), set()
+        S = bin_mapper.nbins
+        pos = 0
+        first_call = True
+        while pos < len(iters_to_use):
+            # ---- do_stratified_clustering (:748-918): pull iterations until every SEEN bin has >= k rows
+            group, counts = [], np.zeros(S, dtype=np.int64)
+            call_remap = np.arange(S, dtype=np.int32)
+            ran_out = False
+            while True:
+                if pos + len(group) >= len(iters_to_use):  # :798-826 IndexError branch
+                    ran_out = True
+                    break
+                it = iters_to_use[pos + len(group)]
+                if it > self.maxIter:  # :834-840
+                    break
+                group.append(it)
+                counts += hist[it - 1]
+                seen = counts > 0
+                if np.all(counts[seen] >= n_clusters):  # :885-886
+                    break
+            contiguous = all(b == a + 1 for a, b in zip(group, group[1:]))
+            if not contiguous:
+                raise NotImplementedError("non-contiguous iters_to_use within one training call")
+            unique_bins = np.nonzero(counts > 0)[0]
+            unfilled_ret = []
+            failed = False
+            if ran_out:
+                unfilled = unique_bins[counts[unique_bins] < n_clusters]
+                filled = np.setdiff1d(unique_bins, unfilled)
+                try:
+                    for ub in unfilled:
+                        call_remap[ub] = self.find_nearest_bin(bin_mapper, ub, list(filled))  # :811-821
+                except AssertionError:
+                    # :693-705: fatal on the very first call, swallowed afterwards
+                    if first_call:
+                        raise
+                    log.info("Clustering couldn't use last iteration, not all bins filled.")
+                    failed = True
+                unique_bins = filled
+                unfilled_ret = list(unfilled)
+            if not failed and len(group) and len(unique_bins):
+                f0, f1 = store.span(group[0], group[-1])
+                n = f1 - f0
+                cnt, starts = h.train_build_rows(d_bin.offset(f0), n, call_remap, d_rows)
+                X_base = store.Xc.offset(f0 * store.D)  # segment-END frames (_data.py:616)
+                w_base = store.w.offset(f0) if self.use_weights_in_clustering else None
+                w_host_all = None
+                if self.use_weights_in_clustering:
+                    w_host_all = np.empty(n)
+                    h.d2h(w_host_all, store.w.offset(f0))
+                rows_host = None
+                for b in unique_bins:  # :890 ascending (np.unique)
+                    nb = int(cnt[b])
+                    rows_b = d_rows.offset(int(starts[b]))
+                    w_rows = None
+                    if w_host_all is not None:
+                        if rows_host is None:
+                            rows_host = np.empty(int(cnt.sum()), dtype=np.int32)
+                            h.d2h(rows_host, d_rows, rows_host.nbytes)
+                        w_rows = w_host_all[rows_host[int(starts[b]): int(starts[b]) + nb]]
+                    clusters.cluster_models[b].partial_fit_device(X_base, store.x_dtype, store.D, rows_b, nb, w_base,
+                                                                  w_rows)
+            if not failed:
+                all_filled.update(int(b) for b in unique_bins)
+                all_unfilled.update(int(b) for b in unfilled_ret)
+            first_call = False
+            # :664-669,716: a call that consumed extra iterations skips them; a failed call only advances by one
+            pos += max(len(group), 1) if not failed else 1
+
+        d_bin.free()
+        d_rows.free()
+
+        # :718-731 never-trained bins are remapped to the nearest trained one
+        true_unfilled = np.setdiff1d(range(S), list(all_filled))
+        for ub in true_unfilled:
+            clusters.we_remap[int(ub)] = int(self.find_nearest_bin(bin_mapper, ub, list(all_filled)))
+
+        self.clusters = clusters
+        self.clusters.model = self
+        self.n_clusters = n_clusters * S  # :742 (quirk Q3)
+        self.clusters.toggle = False
+        self.launch_ray_discretization(progress_bar)
+
+    # ------------------------------------------------------------------------------------------
+    def launch_ray_discretization(self, progress_bar=None):
+        """`_clustering.py:1144-1329`: assign the parent and the child frame of every segment of
+        iterations 1..maxIter-1.  One fused launch per side instead of a Ray task per iteration."""
+        store = self.stage_iterations()
+        h = self.h
+        self.clusters._activate()
+        n_it = self.maxIter - 1
+        nseg = int(store.offsets[n_it]) if n_it > 0 else 0
+        d_parent = h.alloc(max(nseg, 1), np.int32)
+        d_child = h.alloc(max(nseg, 1), np.int32)
+        d_seen = h.zeros((2, self.clusters.bin_mapper.nbins), np.int32)
+        if nseg:
+            h.assign(store.Xp, store.x_dtype, store.D, store.p0, nseg, d_parent, d_seen)  # :1299-1301
+            h.assign(store.Xc, store.x_dtype, store.D, store.p1, nseg, d_child, d_seen)   # :1315-1316
+        seen = d_seen.to_host()
+        d_seen.free()
+        self.clusters.target_bins.update(np.nonzero(seen[0])[0].tolist())  # :1223-1224
+        self.clusters.basis_bins.update(np.nonzero(seen[1])[0].tolist())
+        self._d_parent, self._d_child, self._n_labelled = d_parent, d_child, nseg
+        self._dtrajs_cache = None
+        self._pairs_cache = None
+
+    # dtrajs / pair_dtrajs are host views of the device labels, materialised on first access
+    def _labels_host(self):
+        if getattr(self, "_dtrajs_cache", None) is None:
+            n = self._n_labelled
+            pa = np.empty(n, dtype=np.int32)
+            ch = np.empty(n, dtype=np.int32)
+            self.h.d2h(pa, self._d_parent, pa.nbytes)
+            self.h.d2h(ch, self._d_child, ch.nbytes)
+            offs = self._store.offsets
+            n_it = self.maxIter - 1
+            self._dtrajs_cache = [ch[offs[i]: offs[i + 1]].astype(np.int64) for i in range(n_it)]
+            self._pairs_cache = [np.stack([pa[offs[i]: offs[i + 1]], ch[offs[i]: offs[i + 1]]], axis=1).astype(np.int64)
+                                 for i in range(n_it)]
+        return self._dtrajs_cache, self._pairs_cache
+
+    @property
+    def dtrajs(self):
+        """list over iterations 1..maxIter-1 of child-frame labels (`_clustering.py:1226,1238`)."""
+        if getattr(self, "_d_child", None) is None:
+            return self.__dict__.get("_dtrajs_plain", [])
+        return self._labels_host()[0]
+
+    @dtrajs.setter
+    def dtrajs(self, v):
+        self.__dict__["_dtrajs_plain"] = v
+
+    @property
+    def pair_dtrajs(self):
+        """per iteration an (nSeg, 2) array of (parent, child) labels -- `np.array(pair_dtrajs[i])` of the
+        reference's list of tuples (`_clustering.py:1228,1240`; `_fluxmatrix.py:288`)."""
+        return self._labels_host()[1]
+
+    # ------------------------------------------------------------------------------------------
+    @staticmethod
+    def find_nearest_bin(bin_mapper, bin_idx, filled_bins):
+        """`_clustering.py:1331-1396`: Voronoi-style nearest *filled* bin by bin-centre distance."""
+        assert len(filled_bins) > 0, ("Can't find nearest populated bin -- no WE bins are populated with clusters! "
+                                      "Try fewer clusters/bin.")
+        name = type(bin_mapper).__name__
+        assert name in ("VoronoiBinMapper", "RectilinearBinMapper"), f"{type(bin_mapper)} is unsupported!"
+        if name == "VoronoiBinMapper":
+            centers, dist = bin_mapper.centers, bin_mapper.dfunc
+        else:
+            per_dim = [np.asarray(b)[:-1] + (np.asarray(b)[1:] - np.asarray(b)[:-1]) / 2 for b in bin_mapper.boundaries]
+            ndim = len(per_dim)
+            # same grid ordering as the reference's meshgrid(...).T.squeeze().reshape(-1, ndim)  (:1378-1380)
+            centers = np.array(np.meshgrid(*per_dim)).T.squeeze().reshape(-1, ndim)
+
+            def dist(point, others):
+                return np.sqrt(np.mean(np.power(point - others, 2), axis=1))
+
+        ignored = np.setdiff1d(range(centers.shape[0]), filled_bins)
+        kept = np.delete(centers, ignored, axis=0)
+        with np.errstate(invalid="ignore"):
+            closest = int(np.argmin(dist(centers[bin_idx], kept)))
+        for ig in sorted(ignored):  # :1391-1394 shift past the deleted indices
+            if closest >= ig:
+                closest += 1
+        return closest
+
+    # ------------------------------------------------------------------------------------------
+    def get_cluster_centers(self):
+        """`_clustering.py:1528-1599`: per-cluster mean / min / max of the child pcoord (dim 0) over
+        the discretized frames, then the pcoord sort order.  Segmented reduction on the device."""
+        h = self.h
+        store = self._store
+        K = self.n_clusters
+        ns = K + 2
+        n = self._n_labelled
+        d_sum = h.zeros(ns, np.float64)
+        d_min = h.to_device(np.full(ns, np.inf))
+        d_max = h.to_device(np.full(ns, -np.inf))
+        d_cnt = h.zeros(ns, np.int64)
+        h.cluster_stats(self._d_child, store.p1, n, ns, d_sum, d_min, d_max, d_cnt)
+        s, mn, mx, cnt = d_sum.to_host(), d_min.to_host(), d_max.to_host(), d_cnt.to_host()
+        for b in (d_sum, d_min, d_max, d_cnt):
+            b.free()
+        centers = np.zeros((ns, self.pcoord_ndim))
+        rng = np.zeros((ns, self.pcoord_ndim, 2))
+        # :1544-1555 basis/target rows get `self.{basis,target}_bin_center` (singular) == None -> NaN (quirk Q8)
+        centers[K + 1] = np.nan if self.target_bin_center is None else self.target_bin_center
+        centers[K] = np.nan if self.basis_bin_center is None else self.basis_bin_center
+        rng[K + 1] = centers[K + 1, 0]
+        rng[K] = centers[K, 0]
+        with np.errstate(invalid="ignore", divide="ignore"):
+            mean = s[:K] / cnt[:K]
+        empty = cnt[:K] == 0
+        for cl in np.nonzero(empty)[0]:
+            log.warning(f"No trajectories in cluster {cl}! (Target was {K + 1})")  # :1573-1577
+        centers[:K] = np.where(empty, np.nan, mean)[:, None]
+        rng[:K, :, 0] = np.where(empty, np.nan, mn[:K])[:, None]
+        rng[:K, :, 1] = np.where(empty, np.nan, mx[:K])[:, None]
+        order = np.argsort(centers[:, 0])  # :1593 NaNs (basis, target, empty clusters) sort last
+        self.targetRMSD_centers = centers[order]
+        self.targetRMSD_minmax = rng[order]
+        self.cluster_pcoord_counts = np.concatenate([cnt[:K], [0, 0]])[order]
+        return order
+
+    def update_sorted_cluster_centers(self):
+        """`_clustering.py:1601-1611`."""
+        bin_centers = self.targetRMSD_centers[:, 0]
+        bin_centers[self.indTargets] = self.target_bin_centers
+        bin_centers[self.indBasis] = self.basis_bin_centers
+        self.all_centers = bin_centers
+        self.sorted_centers = np.argsort(bin_centers)
+
+    # ------------------------------------------------------------------------------------------
+    def organize_stratified(self, use_ray=True, progress_bar=None):
+        """`_clustering.py:920-1142`: keep the largest strongly-connected set, delete the other
+        centroids, re-discretize, re-build the flux matrix, sort states by mean pcoord."""
+        fmatrix_original = self.fluxMatrixRaw.copy()
+        fmatrix = self.fluxMatrixRaw.copy()
+        fmatrix[-1, -2] = 1.0  # recycling edge target -> basis (:938)
+        connected_sets = find_connected_sets(fmatrix, directed=True)
+        start_cleaning_idx = 1
+        if len(connected_sets) == 1:
+            states_to_remove = np.array([], dtype=int)
+        else:
+            states_to_remove = np.concatenate(connected_sets[start_cleaning_idx:])
+
+        cl = self.clusters
+        pre = cl.n_fitted()  # :972-977
+        S = cl.bin_mapper.nbins
+        empty_we_bins = set()
+        for we_bin in range(S):
+            offset = sum(pre[:we_bin])
+            in_bin = range(offset, offset + pre[we_bin])
+            to_clean = np.intersect1d(states_to_remove, in_bin)
+            if len(to_clean) == 0:
+                if len(in_bin) == 0:
+                    empty_we_bins.add(we_bin)
+                continue
+            elif len(to_clean) == len(in_bin):
+                empty_we_bins.add(we_bin)
+            m = cl.cluster_models[we_bin]
+            m.cluster_centers_ = np.delete(m.cluster_centers_, to_clean - offset, 0)  # :1041-1045
+
+        log.info(f"Started with {self.n_clusters} clusters, and removed {len(states_to_remove)}")
+        self.n_clusters = self.n_clusters - len(states_to_remove)  # :1050 (quirk Q9)
+        assert self.n_clusters > 1, "All clusters would be cleaned! You probably need more data, fewer clusters, or both."
+
+        populated = np.setdiff1d(range(S), list(empty_we_bins))
+        for eb in empty_we_bins:  # :1070-1078
+            cl.we_remap[eb] = int(self.find_nearest_bin(cl.bin_mapper, eb, populated))
+        for we_bin in range(S):  # :1081-1094 every bin must now resolve to fitted centroids
+            tgt = cl.cluster_models[cl.we_remap[we_bin]]
+            if not tgt.fitted:
+                raise AttributeError(f"Error obtaining clusters for WE bin {we_bin}, remapped to {cl.we_remap[we_bin]}")
+
+        cl.toggle = False
+        cl.processing_from = False
+        self.launch_ray_discretization(progress_bar=progress_bar)  # :1101-1104
+        pcoord_sort_indices = self.get_cluster_centers()            # :1106
+        self.get_fluxMatrix(*self._fluxMatrixParams, use_ray=use_ray, progress_bar=progress_bar)  # :1108-1115
+
+        fluxMatrix = self.fluxMatrixRaw.copy()
+        fluxMatrix = fluxMatrix[pcoord_sort_indices, :]
+        fluxMatrix = fluxMatrix[:, pcoord_sort_indices]
+        self.fluxMatrix = fluxMatrix / np.sum(fluxMatrix)  # :1121
+        self.fluxMatrixRaw = fmatrix_original              # :1123
+        self.indBasis = np.array([self.n_clusters])
+        self.indTargets = np.array([self.n_clusters + 1])
+        self.nBins = self.n_clusters + 2
+        self.update_sorted_cluster_centers()
+        self.cluster_mapping = {x: x for x in range(self.n_clusters + 2)}
+
+        fm = self.fluxMatrix.copy()
+        fm[-1, -2] = 1.0
+        assert len(find_connected_sets(fm, directed=True)[start_cleaning_idx:]) == 0, "Still not clean after cleaning!"

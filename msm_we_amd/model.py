@@ -1,0 +1,253 @@
+"""``modelWE``: host-side mirror of the reference's model class for the haMSM construction path.
+
+Method names, arguments, attributes and error behaviour follow ``msm_we.modelWE`` (reference
+``msm_we/msm_we.py``, mixins in ``msm_we/_hamsm/``) so that a user of the reference finds the same
+calls; the arithmetic of every step on the hot path is executed by the HIP library
+through :mod:`msm_we_amd._abi`.  What stays on the host is what the reference's north star keeps
+there: control flow, RandomState draws, strongly-connected components and the sparse solve.
+
+Data enters through the same five loader hooks the reference reads HDF5 with (``load_iter_data``,
+``load_iter_coordinates``, ``load_iter_coordinates0``, ``get_transition_data_lag0``,
+``get_iterations``; ``_data.py``) -- see :mod:`msm_we_amd.data` for the in-memory and WESTPA-HDF5
+sources.  All iterations are staged once into HBM (``stage_iterations``) and stay resident across
+train -> discretize -> flux -> clean -> re-discretize -> re-flux and block validation.
+"""
+from __future__ import annotations
+
+import logging
+from copy import deepcopy
+
+import numpy as np
+
+from . import _abi
+from .analysis import AnalysisMixin
+from .clustering import ClusteringMixin
+from .data import DataMixin
+from .fluxmatrix import FluxMatrixMixin
+
+log = logging.getLogger("msm_we_amd")
+
+__all__ = ["modelWE"]
+
+
+class modelWE(DataMixin, ClusteringMixin, FluxMatrixMixin, AnalysisMixin):
+    """Reference: ``msm_we/msm_we.py:35-42`` (class assembled from mixins)."""
+
+    class BlockValidationError(Exception):
+        pass
+
+    def __init__(self, h: "_abi.Hamsm" = None, device: int = 0):
+        # msm_we.py:63-141
+        self.modelName = None
+        self._n_lag = 0
+        self.pcoord_ndim = None
+        self.pcoord_len = None
+        self.tau = None
+        self.target_bin_center = None  # singular: never set by the reference either (quirk Q8)
+        self.basis_bin_center = None
+        self._basis_pcoord_bounds = None
+        self._target_pcoord_bounds = None
+        self.nAtoms = None
+        self.coordinates = None
+        self.ndim = None
+        self.targetRMSD_centers = None
+        self.indBasis = None
+        self.clustering_method = None
+        self.validation_models = []
+        self.pre_discretization_model = None
+        self.use_weights_in_clustering = False
+        self.dimReduceMethod = "none"
+        self._h = h
+        self._device = device
+        self._store = None
+        self.seg_weights = {}
+
+    # -- device context ---------------------------------------------------------------------
+    @property
+    def h(self) -> "_abi.Hamsm":
+        if self._h is None:
+            self._h = _abi.Hamsm(device=self._device)  # raises if the HIP library is not built
+        return self._h
+
+    def __deepcopy__(self, memo):
+        # validation models share the device context and the staged iterations (read-only), but own
+        # their clusters / labels (reference: deepcopy(self) at _clustering.py:195, msm_we.py:941)
+        cls = self.__class__
+        new = cls.__new__(cls)
+        memo[id(self)] = new
+        for k, v in self.__dict__.items():
+            if k in ("_h", "_store", "_source", "_d_parent", "_d_child"):
+                new.__dict__[k] = v  # shared, read-only: discretization allocates fresh label buffers
+            else:
+                new.__dict__[k] = deepcopy(v, memo)
+        return new
+
+    # -- msm_we.py:143-277 ------------------------------------------------------------------
+    def initialize(self, fileSpecifier, refPDBfile, modelName, basis_pcoord_bounds=None, target_pcoord_bounds=None,
+                   dim_reduce_method="none", tau=None, pcoord_ndim=1, auxpath="coord",
+                   _suppress_boundary_warning=False, use_weights_in_clustering=False):
+        self.modelName = modelName
+        self.fileList = fileSpecifier if isinstance(fileSpecifier, list) else str(fileSpecifier).split(" ")
+        self.n_data_files = len(self.fileList)
+        self.pcoord_ndim = pcoord_ndim
+        self.pcoord_len = 2
+        if basis_pcoord_bounds is not None:
+            self.basis_pcoord_bounds = basis_pcoord_bounds
+        if target_pcoord_bounds is not None:
+            self.target_pcoord_bounds = target_pcoord_bounds
+        self.auxpath = auxpath
+        if tau is None:
+            log.warning("No tau provided, defaulting to 1.")
+            tau = 1.0
+        self.tau = float(tau)
+        self.set_topology(refPDBfile)
+        self.dimReduceMethod = "pca" if dim_reduce_method is None else dim_reduce_method
+        try:
+            self.load_iter_data(1)
+            self.load_iter_coordinates0()
+            self.coordsExist = True
+        except KeyError:
+            self.coordsExist = False
+        self.use_weights_in_clustering = use_weights_in_clustering
+
+    def set_topology(self, topology):
+        # msm_we.py:1071-1075: only the dict form is on the path; PDB parsing is out of scope
+        if isinstance(topology, dict):
+            self.reference_coord = topology["coords"]
+            self.nAtoms = topology["nAtoms"]
+            self.coord_ndim = topology["coord_ndim"]
+        else:
+            raise NotImplementedError("pass the topology as dict(coords=, nAtoms=, coord_ndim=)")
+
+    # msm_we.py:300-347 / 397-444
+    @staticmethod
+    def _check_bounds(bounds, ndim):
+        bounds = np.array(bounds, dtype=float)
+        if bounds.ndim == 1:
+            bounds = bounds.reshape(1, 2)
+        assert bounds.shape == (ndim, 2), f"Shape of bounds was {bounds.shape}, should've been ({ndim}, 2)"
+        assert np.all([b[0] < b[1] for b in bounds]), "A boundary has a lower bound larger than its upper bound"
+        centers = np.full(ndim, np.nan)
+        for i, (lo, hi) in enumerate(bounds):
+            if not abs(lo) == np.inf and not abs(hi) == np.inf:
+                centers[i] = np.mean([lo, hi])
+            else:
+                centers[i] = [lo, hi][int(abs(lo) == np.inf)]
+        return bounds, centers
+
+    @property
+    def basis_pcoord_bounds(self):
+        return self._basis_pcoord_bounds
+
+    @basis_pcoord_bounds.setter
+    def basis_pcoord_bounds(self, bounds):
+        self._basis_pcoord_bounds, self.basis_bin_centers = self._check_bounds(bounds, self.pcoord_ndim)
+
+    @property
+    def target_pcoord_bounds(self):
+        return self._target_pcoord_bounds
+
+    @target_pcoord_bounds.setter
+    def target_pcoord_bounds(self, bounds):
+        self._target_pcoord_bounds, self.target_bin_centers = self._check_bounds(bounds, self.pcoord_ndim)
+
+    @property
+    def n_lag(self):
+        return self._n_lag
+
+    @n_lag.setter
+    def n_lag(self, lag):
+        if not lag == 0:  # msm_we.py:353-362
+            raise NotImplementedError("Only a lag of 1 tau (n_lag = 0) is currently supported")
+        self._n_lag = lag
+
+    # msm_we.py:462-527 -- host copies for callers outside the hot path; the library applies the
+    # same strict f64 tests per frame inside assign / flux (hamsm_classify bit0/bit1)
+    def is_WE_basis(self, pcoords):
+        pcoords = np.asarray(pcoords)
+        b = self.basis_pcoord_bounds
+        return np.all((pcoords[:, : self.pcoord_ndim] > b[:, 0]) & (pcoords[:, : self.pcoord_ndim] < b[:, 1]), axis=1)
+
+    def is_WE_target(self, pcoords):
+        pcoords = np.asarray(pcoords)
+        b = self.target_pcoord_bounds
+        return np.all((pcoords[:, : self.pcoord_ndim] > b[:, 0]) & (pcoords[:, : self.pcoord_ndim] < b[:, 1]), axis=1)
+
+    # _dimensionality.py:110-345 -- only "none" (identity) is on the path this round
+    class Coordinates:
+        def transform(self, coords):
+            return coords
+
+    def dimReduce(self, **_):
+        if self.dimReduceMethod != "none":
+            raise NotImplementedError("dimReduceMethod other than 'none' is not built yet (SURVEY §8f-3)")
+        self.ndim = int(3 * self.nAtoms)
+        self.coordinates = self.Coordinates()
+
+    # msm_we.py:588-882, without the rich table / Ray bootstrap
+    def build_analyze_model(self, file_paths, ref_struct, modelName, basis_pcoord_bounds, target_pcoord_bounds,
+                            dimreduce_method, tau, n_clusters, stratified=True, streaming=True, use_ray=True,
+                            fluxmatrix_iters=(1, -1), fluxmatrix_iters_to_use=None, cross_validation_groups=2,
+                            cross_validation_blocks=4, show_live_display=False, allow_validation_failure=False,
+                            step_kwargs=None, max_coord_iter=-1, **_ignored):
+        step_kwargs = step_kwargs or {}
+        self.initialize(file_paths, ref_struct, modelName, basis_pcoord_bounds, target_pcoord_bounds,
+                        dimreduce_method, tau, **step_kwargs.get("initialize", {}))
+        self.get_iterations()
+        self.get_coordSet(self.maxIter if max_coord_iter == -1 else max_coord_iter)
+        self.dimReduce(**step_kwargs.get("dimReduce", {}))
+        self.cluster_coordinates(n_clusters=n_clusters, streaming=streaming, use_ray=use_ray, stratified=stratified,
+                                 store_validation_model=cross_validation_groups > 0,
+                                 **step_kwargs.get("clustering", {}))
+        fi = list(fluxmatrix_iters)
+        if fi[1] == -1:
+            fi[1] = self.maxIter
+        self.get_fluxMatrix(n_lag=0, first_iter=fi[0], last_iter=fi[1], iters_to_use=fluxmatrix_iters_to_use,
+                            use_ray=use_ray, **step_kwargs.get("fluxmatrix", {}))
+        self.organize_fluxMatrix(use_ray=use_ray, **step_kwargs.get("organize", {}))
+        self.get_Tmatrix()
+        self.get_steady_state()
+        self.get_steady_state_target_flux()
+        if cross_validation_groups > 0:
+            try:
+                self.do_block_validation(cross_validation_groups=cross_validation_groups,
+                                         cross_validation_blocks=cross_validation_blocks, use_ray=use_ray,
+                                         **step_kwargs.get("block_validation", {}))
+            except Exception as e:  # noqa: BLE001  (msm_we.py:865-872)
+                log.error(e)
+                if not allow_validation_failure:
+                    raise
+
+    # msm_we.py:884-1009
+    def do_block_validation(self, cross_validation_groups, cross_validation_blocks, use_ray=True, progress_bar=None):
+        """Split iterations into uniform blocks, deal blocks round-robin into groups, and rebuild
+        flux matrix -> clean -> T -> steady state -> target flux per group on a copy of the
+        post-clustering model.  Copies share the ctx and the staged frames; nothing is re-uploaded."""
+        assert getattr(self, "post_cluster_model", None) is not None, (
+            "Perform clustering with cluster_coordinates() before attempting"
+            "block validation -- self.post_cluster_model is not set.")
+        validation_models = [deepcopy(self.post_cluster_model) for _ in range(cross_validation_groups)]
+        maxIter = self.post_cluster_model.maxIter
+        per_block = maxIter // cross_validation_blocks  # :924
+        block_iterations = [[a, a + per_block] for a in range(1, maxIter, per_block)]
+        block_iterations[-1][-1] = block_iterations[-1][-1] - 1  # :931
+        group_blocks = [range(g, cross_validation_blocks, cross_validation_groups) for g in range(cross_validation_groups)]
+        validation_iterations = []
+        for group in range(cross_validation_groups):
+            its = []
+            for block in group_blocks[group]:
+                its.extend(range(*block_iterations[block]))
+            validation_iterations.append(its)
+            try:
+                m = validation_models[group]
+                m.clusters.model = m
+                m.get_fluxMatrix(0, iters_to_use=its, use_ray=use_ray)
+                m.organize_fluxMatrix(use_ray=use_ray)
+                m.get_Tmatrix()
+                m.get_steady_state()
+                m.get_steady_state_target_flux()
+            except Exception as e:  # noqa: BLE001 (msm_we.py:993-1003)
+                log.error("Error during block validation!")
+                raise modelWE.BlockValidationError(e)
+        self.validation_iterations = validation_iterations
+        self.validation_models = validation_models

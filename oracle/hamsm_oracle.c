@@ -1,0 +1,719 @@
+/* hamsm_oracle.c -- CPU restatement of the reference hot path, exporting the ABI of include/hamsm.h.
+ *
+ * TEST INFRASTRUCTURE ONLY.  This is the parity oracle and the `cpu_baseline` "port": only tests/,
+ * __graft_entry__.smoke() and bench.py's cpu_baseline leg may load it.  Nothing under msm_we_amd/
+ * references it; the product library is msm_we_amd/csrc (HIP, gfx950).
+ *
+ * Pinning: checked against golden vectors produced by the real reference
+ * (jdrusso/msm_we 0.1.28.dev1 + scikit-learn 1.7.2) in tests/golden/*.npz -- labels identical,
+ * centroids to 1e-12, flux/T/pSS/J to 1e-6 -- and against the reference's own NTL9 fixtures
+ * (tests/golden/ntl9/*.npy) for the transition-matrix stage.
+ *
+ * Arithmetic contract shared with the HIP library (bit-for-bit):
+ *  - dot(x, c) = fma chain over ascending feature index from +0.0 (what OpenBLAS dgemm computes
+ *    per element for K <= GEMM_Q; verified in this container for sklearn's single-row predict);
+ *    distance key = csq[j] - 2*dot (one rounding); first minimum wins (strict <).
+ *  - everything else is separate multiply / add (no contraction): build with -ffp-contract=off.
+ *  - reductions whose order the reference leaves to BLAS/NumPy SIMD (k-means++ potentials, row
+ *    norms) use the fixed, GPU-reproducible orders documented at each function.
+ */
+#include "../include/hamsm.h"
+
+#include <math.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#define MAX_NDIM 8
+#define POT_LANES 256 /* strided partial sums for potentials */
+#define SCAN_CHUNK 64 /* chunked cumulative sum              */
+
+typedef struct {
+  int K;          /* fitted centroids, 0 = unfitted */
+  double *C;      /* [K][D] */
+  double *csq;    /* [K]    */
+  double *counts; /* [K]    */
+} stratum_t;
+
+struct hamsm_ctx {
+  char err[512];
+  int D, ndim, S;
+  int nb[MAX_NDIM];
+  float *bounds[MAX_NDIM];
+  int32_t *remap;
+  double basis[MAX_NDIM][2], target[MAX_NDIM][2];
+  int have_bounds, have_mapper;
+  stratum_t *st;
+};
+
+static int fail(hamsm_ctx *c, int code, const char *fmt, ...) {
+  if (c) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(c->err, sizeof c->err, fmt, ap);
+    va_end(ap);
+  }
+  return code;
+}
+
+int hamsm_abi_version(void) { return HAMSM_ABI_VERSION; }
+const char *hamsm_backend_name(void) { return "cpu-oracle"; }
+
+int hamsm_create(int device, hamsm_ctx **out) {
+  (void)device;
+  hamsm_ctx *c = (hamsm_ctx *)calloc(1, sizeof *c);
+  if (!c) return HAMSM_ENOMEM;
+  *out = c;
+  return HAMSM_OK;
+}
+
+static void free_strata(hamsm_ctx *c) {
+  if (c->st) {
+    for (int s = 0; s < c->S; s++) {
+      free(c->st[s].C);
+      free(c->st[s].csq);
+      free(c->st[s].counts);
+    }
+    free(c->st);
+    c->st = NULL;
+  }
+  free(c->remap);
+  c->remap = NULL;
+}
+
+void hamsm_destroy(hamsm_ctx *c) {
+  if (!c) return;
+  free_strata(c);
+  for (int d = 0; d < MAX_NDIM; d++) free(c->bounds[d]);
+  free(c);
+}
+
+const char *hamsm_last_error(hamsm_ctx *c) { return c ? c->err : "null ctx"; }
+
+int hamsm_malloc(hamsm_ctx *c, size_t bytes, void **out) {
+  void *p = malloc(bytes ? bytes : 1);
+  if (!p) return fail(c, HAMSM_ENOMEM, "malloc(%zu)", bytes);
+  *out = p;
+  return HAMSM_OK;
+}
+int hamsm_free(hamsm_ctx *c, void *p) {
+  (void)c;
+  free(p);
+  return HAMSM_OK;
+}
+int hamsm_memcpy_h2d(hamsm_ctx *c, void *d, const void *h, size_t n) {
+  (void)c;
+  memcpy(d, h, n);
+  return HAMSM_OK;
+}
+int hamsm_memcpy_d2h(hamsm_ctx *c, void *h, const void *d, size_t n) {
+  (void)c;
+  memcpy(h, d, n);
+  return HAMSM_OK;
+}
+int hamsm_memset(hamsm_ctx *c, void *d, int b, size_t n) {
+  (void)c;
+  memset(d, b, n);
+  return HAMSM_OK;
+}
+int hamsm_sync(hamsm_ctx *c) {
+  (void)c;
+  return HAMSM_OK;
+}
+
+int hamsm_set_geometry(hamsm_ctx *c, int D, int ndim, int S) {
+  if (D < 1 || ndim < 1 || ndim > MAX_NDIM || S < 1) return fail(c, HAMSM_EINVAL, "bad geometry");
+  free_strata(c);
+  c->D = D;
+  c->ndim = ndim;
+  c->S = S;
+  c->st = (stratum_t *)calloc((size_t)S, sizeof(stratum_t));
+  c->remap = (int32_t *)malloc(sizeof(int32_t) * (size_t)S);
+  for (int s = 0; s < S; s++) c->remap[s] = s; /* stratified_clustering.py:85 */
+  return HAMSM_OK;
+}
+
+int hamsm_set_mapper_rectilinear(hamsm_ctx *c, const int32_t *nb, const float *b) {
+  if (!c->st) return fail(c, HAMSM_EINVAL, "set_geometry first");
+  long nbins = 1;
+  for (int d = 0; d < c->ndim; d++) {
+    if (nb[d] < 2) return fail(c, HAMSM_EINVAL, "need >=2 boundaries per dim");
+    free(c->bounds[d]);
+    c->bounds[d] = (float *)malloc(sizeof(float) * (size_t)nb[d]);
+    memcpy(c->bounds[d], b, sizeof(float) * (size_t)nb[d]);
+    c->nb[d] = nb[d];
+    b += nb[d];
+    nbins *= nb[d] - 1;
+  }
+  if (nbins != c->S) return fail(c, HAMSM_EINVAL, "mapper has %ld bins, geometry says %d", nbins, c->S);
+  c->have_mapper = 1;
+  return HAMSM_OK;
+}
+
+int hamsm_set_remap(hamsm_ctx *c, const int32_t *r) {
+  if (!c->st) return fail(c, HAMSM_EINVAL, "set_geometry first");
+  for (int s = 0; s < c->S; s++)
+    if (r[s] < 0 || r[s] >= c->S) return fail(c, HAMSM_EINVAL, "remap[%d]=%d out of range", s, r[s]);
+  memcpy(c->remap, r, sizeof(int32_t) * (size_t)c->S);
+  return HAMSM_OK;
+}
+
+int hamsm_set_bounds(hamsm_ctx *c, const double *basis, const double *target) {
+  if (!c->st) return fail(c, HAMSM_EINVAL, "set_geometry first");
+  for (int d = 0; d < c->ndim; d++) {
+    c->basis[d][0] = basis[2 * d];
+    c->basis[d][1] = basis[2 * d + 1];
+    c->target[d][0] = target[2 * d];
+    c->target[d][1] = target[2 * d + 1];
+  }
+  c->have_bounds = 1;
+  return HAMSM_OK;
+}
+
+/* ||c||^2: fma chain over ascending feature index (sklearn uses einsum, whose SIMD order is
+ * machine dependent; callers that need sklearn's bits pass h_csq, see hamsm.h). */
+static double sqnorm_chain(const double *v, int D) {
+  double a = 0.0;
+  for (int k = 0; k < D; k++) a = __builtin_fma(v[k], v[k], a);
+  return a;
+}
+
+int hamsm_set_centroids(hamsm_ctx *c, int s, int K, const double *C, const double *csq, const double *counts) {
+  if (!c->st || s < 0 || s >= c->S || K < 0) return fail(c, HAMSM_EINVAL, "bad stratum/K");
+  stratum_t *t = &c->st[s];
+  free(t->C);
+  free(t->csq);
+  free(t->counts);
+  t->C = t->csq = t->counts = NULL;
+  t->K = K;
+  if (K == 0) return HAMSM_OK;
+  t->C = (double *)malloc(sizeof(double) * (size_t)K * c->D);
+  t->csq = (double *)malloc(sizeof(double) * (size_t)K);
+  t->counts = (double *)calloc((size_t)K, sizeof(double));
+  memcpy(t->C, C, sizeof(double) * (size_t)K * c->D);
+  for (int j = 0; j < K; j++) t->csq[j] = csq ? csq[j] : sqnorm_chain(t->C + (size_t)j * c->D, c->D);
+  if (counts) memcpy(t->counts, counts, sizeof(double) * (size_t)K);
+  return HAMSM_OK;
+}
+
+int hamsm_get_centroids(hamsm_ctx *c, int s, double *C, double *counts, double *csq) {
+  if (!c->st || s < 0 || s >= c->S) return fail(c, HAMSM_EINVAL, "bad stratum");
+  stratum_t *t = &c->st[s];
+  if (C) memcpy(C, t->C, sizeof(double) * (size_t)t->K * c->D);
+  if (counts) memcpy(counts, t->counts, sizeof(double) * (size_t)t->K);
+  if (csq) memcpy(csq, t->csq, sizeof(double) * (size_t)t->K);
+  return HAMSM_OK;
+}
+
+int hamsm_num_centroids(hamsm_ctx *c, int s) {
+  if (!c->st || s < 0 || s >= c->S) return fail(c, HAMSM_EINVAL, "bad stratum");
+  return c->st[s].K;
+}
+
+/* --- a3: westpa RectilinearBinMapper.assign restated (third-party, source absent):
+ * float32 compare, half-open bins, row-major over dims.  -1 = outside the bin space. */
+static int bin_of(const hamsm_ctx *c, const double *p) {
+  int idx = 0;
+  for (int d = 0; d < c->ndim; d++) {
+    float pf = (float)p[d];
+    const float *b = c->bounds[d];
+    int n = c->nb[d], lo = 0, hi = n; /* first index with b[i] > pf (searchsorted side='right') */
+    while (lo < hi) {
+      int mid = (lo + hi) / 2;
+      if (b[mid] <= pf) lo = mid + 1; /* NaN: comparison false -> hi shrinks -> lo=0 -> j=-1 */
+      else hi = mid;
+    }
+    int j = lo - 1;
+    if (j < 0 || j >= n - 1) return -1;
+    idx = idx * (n - 1) + j;
+  }
+  return idx;
+}
+
+/* --- a4: msm_we.py:480-492, 515-527: all dims strictly inside (lo, hi), float64 */
+static int in_box(const double (*box)[2], int ndim, const double *p) {
+  for (int d = 0; d < ndim; d++)
+    if (!(p[d] > box[d][0] && p[d] < box[d][1])) return 0;
+  return 1;
+}
+
+int hamsm_classify(hamsm_ctx *c, const double *p, int64_t n, int apply_remap, int32_t *bin, uint8_t *flags) {
+  if (!c->have_mapper || !c->have_bounds) return fail(c, HAMSM_EINVAL, "mapper/bounds not set");
+  for (int64_t i = 0; i < n; i++) {
+    const double *pi = p + i * c->ndim;
+    int b = bin_of(c, pi);
+    if (b >= 0 && apply_remap) b = c->remap[b];
+    if (bin) bin[i] = b;
+    if (flags) flags[i] = (uint8_t)((in_box(c->basis, c->ndim, pi) ? 1 : 0) | (in_box(c->target, c->ndim, pi) ? 2 : 0));
+  }
+  return HAMSM_OK;
+}
+
+static inline double xval(const void *X, int dt, int64_t i) {
+  return dt == HAMSM_F32 ? (double)((const float *)X)[i] : ((const double *)X)[i];
+}
+
+/* --- sklearn _k_means_lloyd.pyx:188-218 (_update_chunk_dense, update_centers=False):
+ * pairwise = ||c||^2 - 2 x.c via dgemm (fma chain per element), first strict minimum. */
+static int argmin_row(const double *x, const stratum_t *t, int D) {
+  int best = 0;
+  double bd = 0.0;
+  for (int j = 0; j < t->K; j++) {
+    const double *cj = t->C + (size_t)j * D;
+    double acc = 0.0;
+    for (int k = 0; k < D; k++) acc = __builtin_fma(x[k], cj[k], acc);
+    double d = __builtin_fma(-2.0, acc, t->csq[j]);
+    if (j == 0 || d < bd) {
+      bd = d;
+      best = j;
+    }
+  }
+  return best;
+}
+
+/* --- a9: StratifiedClusters.predict, stratified_clustering.py:129-212 */
+int hamsm_assign(hamsm_ctx *c, const void *X, int dt, int64_t ldx, const double *p, int64_t n, int32_t *labels,
+                 int32_t *seen) {
+  if (!c->have_mapper || !c->have_bounds) return fail(c, HAMSM_EINVAL, "mapper/bounds not set");
+  if (dt != HAMSM_F32 && dt != HAMSM_F64) return fail(c, HAMSM_EINVAL, "x_dtype");
+  if (ldx < c->D) return fail(c, HAMSM_EINVAL, "ldx < D");
+  int D = c->D;
+  /* :143-150 total_clusters over all strata; :178-185 offset of earlier strata */
+  int Kfit = 0;
+  int *off = (int *)malloc(sizeof(int) * (size_t)c->S);
+  for (int s = 0; s < c->S; s++) {
+    off[s] = Kfit;
+    Kfit += c->st[s].K;
+  }
+  double *x = (double *)malloc(sizeof(double) * (size_t)D);
+  int rc = HAMSM_OK;
+  for (int64_t i = 0; i < n && rc == HAMSM_OK; i++) {
+    const double *pi = p + i * c->ndim;
+    int b = bin_of(c, pi); /* :134 assign is evaluated for every frame, basis/target included */
+    if (b < 0) {
+      rc = fail(c, HAMSM_ERANGE, "frame %lld: pcoord outside the bin space", (long long)i);
+      break;
+    }
+    int s = c->remap[b]; /* :135 */
+    if (in_box(c->target, c->ndim, pi)) { /* :159 target first */
+      labels[i] = Kfit + 1;
+      if (seen) seen[s] = 1;
+    } else if (in_box(c->basis, c->ndim, pi)) { /* :165 */
+      labels[i] = Kfit;
+      if (seen) seen[c->S + s] = 1;
+    } else {
+      const stratum_t *t = &c->st[s];
+      if (t->K == 0) { /* :187-189 */
+        rc = fail(c, HAMSM_EUNFIT, "Not initialized in seg %lld, bin %d", (long long)i, s);
+        break;
+      }
+      for (int k = 0; k < D; k++) x[k] = xval(X, dt, i * ldx + k);
+      labels[i] = off[s] + argmin_row(x, t, D); /* :195 */
+    }
+  }
+  free(x);
+  free(off);
+  return rc;
+}
+
+int hamsm_predict_host(hamsm_ctx *c, const void *X, int dt, const double *p, int64_t n, int32_t *labels,
+                       int32_t *seen) {
+  return hamsm_assign(c, X, dt, c->D, p, n, labels, seen);
+}
+
+/* --- a10: _fluxmatrix.py:97-164 (build_flux_matrix) + :325-327,342 (sum of per-iteration dense
+ * matrices in ascending iteration order).  Per iteration the COO->dense conversion adds duplicates
+ * in segment order (scipy coo_todense); iterations that do not touch a cell add +0.0, which is
+ * exact, so a lazily flushed per-cell partial is bit-identical to the dense sums. */
+int hamsm_flux_accumulate(hamsm_ctx *c, const int32_t *pa, const int32_t *ch, const double *p0, const double *p1,
+                          const double *w, int64_t n, int K, double *F, int mode, const int64_t *offs,
+                          int64_t n_iters) {
+  (void)mode;
+  if (!c->have_bounds) return fail(c, HAMSM_EINVAL, "bounds not set");
+  int64_t N2 = (int64_t)(K + 2) * (K + 2);
+  double *part = (double *)calloc((size_t)N2, sizeof(double));
+  int64_t *last = (int64_t *)malloc(sizeof(int64_t) * (size_t)N2);
+  int64_t *touched = (int64_t *)malloc(sizeof(int64_t) * (size_t)(n > 0 ? n : 1));
+  if (!part || !last || !touched) return fail(c, HAMSM_ENOMEM, "flux scratch");
+  for (int64_t i = 0; i < N2; i++) last[i] = -1;
+  int64_t one[2] = {0, n};
+  if (!offs) {
+    offs = one;
+    n_iters = 1;
+  }
+  int rc = HAMSM_OK;
+  for (int64_t t = 0; t < n_iters && rc == HAMSM_OK; t++) {
+    int64_t nt = 0;
+    for (int64_t i = offs[t]; i < offs[t + 1]; i++) {
+      int a = pa[i], b = ch[i];
+      if (in_box(c->target, c->ndim, p1 + i * c->ndim)) b = K + 1; /* :135 */
+      if (in_box(c->basis, c->ndim, p0 + i * c->ndim)) a = K;      /* :136 */
+      if (in_box(c->basis, c->ndim, p1 + i * c->ndim)) b = K;      /* :137 */
+      if (a < 0 || b < 0 || a >= K + 2 || b >= K + 2) {
+        rc = fail(c, HAMSM_ERANGE, "segment %lld: transition %d -> %d outside %d states", (long long)i, a, b, K + 2);
+        break;
+      }
+      int64_t cell = (int64_t)a * (K + 2) + b;
+      if (last[cell] != t) {
+        last[cell] = t;
+        part[cell] = 0.0;
+        touched[nt++] = cell;
+      }
+      part[cell] = part[cell] + w[i];
+    }
+    for (int64_t k = 0; k < nt; k++) F[touched[k]] = F[touched[k]] + part[touched[k]];
+  }
+  free(part);
+  free(last);
+  free(touched);
+  return rc;
+}
+
+int hamsm_scale(hamsm_ctx *c, double *F, int64_t count, double div) {
+  (void)c;
+  for (int64_t i = 0; i < count; i++) F[i] = F[i] / div; /* _fluxmatrix.py:342 */
+  return HAMSM_OK;
+}
+
+/* --- a11: _clustering.py:1559-1591.  (The reference averages with np.nanmean = pairwise sum;
+ * the mean only feeds an argsort, so the contract is sum in ascending frame order, |rel| 1e-12.) */
+int hamsm_cluster_stats(hamsm_ctx *c, const int32_t *lab, const double *p, int64_t n, int nstates, double *sum,
+                        double *mn, double *mx, int64_t *cnt) {
+  for (int64_t i = 0; i < n; i++) {
+    int l = lab[i];
+    if (l < 0 || l >= nstates) return fail(c, HAMSM_ERANGE, "label %d outside %d states", l, nstates);
+    double v = p[i * c->ndim];
+    sum[l] = sum[l] + v;
+    if (v < mn[l]) mn[l] = v;
+    if (v > mx[l]) mx[l] = v;
+    cnt[l]++;
+  }
+  return HAMSM_OK;
+}
+
+/* numpy pairwise summation (numpy/core/src/umath/loops_utils.h.src, pairwise_sum): what
+ * np.sum(fluxmatrix, 1) computes for a contiguous row -- reproduced so that Tmatrix is bit-equal
+ * to AnalysisMixin.get_Tmatrix (_analysis.py:48). */
+static double np_pairwise(const double *a, int64_t n) {
+  if (n < 8) {
+    double r = -0.0;
+    for (int64_t i = 0; i < n; i++) r = r + a[i];
+    return r;
+  } else if (n <= 128) {
+    double r[8];
+    for (int k = 0; k < 8; k++) r[k] = a[k];
+    int64_t i;
+    for (i = 8; i < n - (n % 8); i += 8)
+      for (int k = 0; k < 8; k++) r[k] = r[k] + a[i + k];
+    double res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+    for (; i < n; i++) res = res + a[i];
+    return res;
+  } else {
+    int64_t n2 = n / 2;
+    n2 -= n2 % 8;
+    return np_pairwise(a, n2) + np_pairwise(a + n2, n - n2);
+  }
+}
+
+/* --- a13 feed: _analysis.py:44-79 */
+int hamsm_tmatrix_csr(hamsm_ctx *c, const double *F, int ns, const int32_t *basis, int nb, const int32_t *target,
+                      int nt, int64_t *indptr, int32_t *indices, double *data, int64_t cap, int64_t *nnz_out) {
+  int64_t nnz = 0;
+  indptr[0] = 0;
+  for (int i = 0; i < ns; i++) {
+    int is_t = 0;
+    for (int k = 0; k < nt; k++) is_t |= (target[k] == i);
+    const double *row = F + (size_t)i * ns;
+    double out = np_pairwise(row, ns);
+    for (int j = 0; j < ns; j++) {
+      double v;
+      if (is_t) { /* :74-77 sink rows recycle uniformly into the basis */
+        v = 0.0;
+        for (int k = 0; k < nb; k++)
+          if (basis[k] == j) v = 1.0 / (double)nb;
+      } else {
+        v = row[j];
+        if (out > 0) v = v / out;            /* :53-56 */
+        if (out == 0.0 && j == i) v = 1.0;   /* :60-61 */
+      }
+      if (v != 0.0) {
+        if (nnz >= cap) return fail(c, HAMSM_ENOMEM, "csr capacity %lld too small", (long long)cap);
+        indices[nnz] = j;
+        data[nnz] = v;
+        nnz++;
+      }
+    }
+    indptr[i + 1] = nnz;
+  }
+  *nnz_out = nnz;
+  return HAMSM_OK;
+}
+
+/* --- a5 support: _clustering.py:872-886 */
+int hamsm_train_prepass(hamsm_ctx *c, const double *p, int64_t n, const int64_t *offs, int64_t n_iters, int32_t *bin,
+                        int64_t *hist) {
+  if (!c->have_mapper || !c->have_bounds) return fail(c, HAMSM_EINVAL, "mapper/bounds not set");
+  memset(hist, 0, sizeof(int64_t) * (size_t)n_iters * c->S);
+  for (int64_t t = 0; t < n_iters; t++)
+    for (int64_t i = offs[t]; i < offs[t + 1]; i++) {
+      const double *pi = p + i * c->ndim;
+      int b;
+      if (in_box(c->target, c->ndim, pi) || in_box(c->basis, c->ndim, pi)) b = -1; /* :872-874 */
+      else {
+        b = bin_of(c, pi); /* :877, no we_remap here */
+        if (b < 0) return fail(c, HAMSM_ERANGE, "frame %lld: pcoord outside the bin space", (long long)i);
+        hist[t * c->S + b]++;
+      }
+      bin[i] = b;
+    }
+  (void)n;
+  return HAMSM_OK;
+}
+
+int hamsm_train_build_rows(hamsm_ctx *c, const int32_t *bin, int64_t n, const int32_t *call_remap, int32_t *rows,
+                           int64_t *counts, int64_t *starts) {
+  memset(counts, 0, sizeof(int64_t) * (size_t)c->S);
+  for (int64_t i = 0; i < n; i++)
+    if (bin[i] >= 0) counts[call_remap[bin[i]]]++;
+  int64_t acc = 0;
+  for (int s = 0; s < c->S; s++) {
+    starts[s] = acc;
+    acc += counts[s];
+  }
+  int64_t *fill = (int64_t *)calloc((size_t)c->S, sizeof(int64_t));
+  int64_t rank = 0; /* position in the basis/target-filtered list (:874); applied to the unfiltered rows (:892-896) */
+  for (int64_t i = 0; i < n; i++)
+    if (bin[i] >= 0) {
+      int s = call_remap[bin[i]];
+      rows[starts[s] + fill[s]++] = (int32_t)rank;
+      rank++;
+    }
+  free(fill);
+  return HAMSM_OK;
+}
+
+/* batch row r -> frame index */
+static inline int64_t frame_of(const int32_t *rows, const int64_t *sub, int64_t r) {
+  if (sub) r = sub[r];
+  return rows ? rows[r] : r;
+}
+
+static void load_row(double *dst, const void *X, int dt, int64_t ldx, int64_t f, int D) {
+  for (int k = 0; k < D; k++) dst[k] = xval(X, dt, f * ldx + k);
+}
+
+/* potentials: POT_LANES strided partial sums (lane t sums i = t, t+L, ... ascending, fma-free),
+ * then the partials are added in lane order.  (sklearn: `@` via BLAS, order unspecified.) */
+static double pot_sum(const double *d, const double *w, int64_t n) {
+  double part[POT_LANES];
+  for (int t = 0; t < POT_LANES; t++) {
+    double a = 0.0;
+    for (int64_t i = t; i < n; i += POT_LANES) a = a + d[i] * w[i];
+    part[t] = a;
+  }
+  double s = 0.0;
+  for (int t = 0; t < POT_LANES; t++) s = s + part[t];
+  return s;
+}
+
+/* --- a6: sklearn _kmeans.py:214-276 */
+int hamsm_kmeans_seed(hamsm_ctx *c, int s, const void *X, int dt, int64_t ldx, const int32_t *rows, int64_t n_b,
+                      const double *wf, const int64_t *sub, int64_t n_sub, int K, int64_t first, const double *u,
+                      int L, int64_t *chosen) {
+  if (!c->st || s < 0 || s >= c->S) return fail(c, HAMSM_EINVAL, "bad stratum");
+  int D = c->D;
+  int64_t n = sub ? n_sub : n_b;
+  if (K < 1 || n < 1 || first < 0 || first >= n || L < 1 || L > 64) return fail(c, HAMSM_EINVAL, "bad seed args");
+  double *Xb = (double *)malloc(sizeof(double) * (size_t)n * D);
+  double *w = (double *)malloc(sizeof(double) * (size_t)n);
+  double *xsq = (double *)malloc(sizeof(double) * (size_t)n);
+  double *closest = (double *)malloc(sizeof(double) * (size_t)n);
+  double *cand = (double *)malloc(sizeof(double) * (size_t)n * L);
+  double *cum = (double *)malloc(sizeof(double) * (size_t)n);
+  double *C = (double *)malloc(sizeof(double) * (size_t)K * D);
+  for (int64_t i = 0; i < n; i++) {
+    int64_t f = frame_of(rows, sub, i);
+    load_row(Xb + i * D, X, dt, ldx, f, D);
+    w[i] = wf ? wf[f] : 1.0;
+    xsq[i] = sqnorm_chain(Xb + i * D, D); /* partial_fit: row_norms(X, squared=True), _kmeans.py:2246 */
+  }
+  /* :225-232 first centre; :235-238 closest = ||x_first - x||^2, pot */
+  memcpy(C, Xb + first * D, sizeof(double) * D);
+  if (chosen) chosen[0] = first;
+#define DIST(ci, i)                                                                  \
+  ({                                                                                 \
+    double acc_ = 0.0;                                                               \
+    const double *a_ = Xb + (ci)*D, *b_ = Xb + (i)*D;                                \
+    for (int k_ = 0; k_ < D; k_++) acc_ = __builtin_fma(a_[k_], b_[k_], acc_);      \
+    double v_ = ((-2.0 * acc_) + xsq[ci]) + xsq[i]; /* euclidean_distances order */ \
+    v_ > 0.0 ? v_ : 0.0;                           /* np.maximum(d, 0); NaN -> 0 is not reproduced: inputs are finite */ \
+  })
+  for (int64_t i = 0; i < n; i++) closest[i] = DIST(first, i);
+  double pot = pot_sum(closest, w, n);
+  for (int cc = 1; cc < K; cc++) {
+    /* :243-247 stable_cumsum(w * closest): chunked scan -- chunk totals first (sequential inside a
+     * chunk of SCAN_CHUNK), bases by sequential sum over chunks, then base + running local sum. */
+    int64_t nch = (n + SCAN_CHUNK - 1) / SCAN_CHUNK;
+    double base = 0.0;
+    for (int64_t q = 0; q < nch; q++) {
+      double loc = 0.0;
+      int64_t e = (q + 1) * SCAN_CHUNK < n ? (q + 1) * SCAN_CHUNK : n;
+      for (int64_t i = q * SCAN_CHUNK; i < e; i++) {
+        loc = loc + w[i] * closest[i];
+        cum[i] = base + loc;
+      }
+      base = base + loc;
+    }
+    int64_t cid[64];
+    for (int l = 0; l < L; l++) {
+      double v = u[(size_t)(cc - 1) * L + l] * pot; /* :243 */
+      int64_t lo = 0, hi = n;                       /* searchsorted side='left' */
+      while (lo < hi) {
+        int64_t mid = (lo + hi) / 2;
+        if (cum[mid] < v) lo = mid + 1;
+        else hi = mid;
+      }
+      if (lo > n - 1) lo = n - 1; /* :249 clip */
+      cid[l] = lo;
+    }
+    int best = 0;
+    double bestpot = 0.0;
+    for (int l = 0; l < L; l++) {
+      double *dl = cand + (size_t)l * n;
+      for (int64_t i = 0; i < n; i++) {
+        double d = DIST(cid[l], i); /* :252-254 */
+        dl[i] = d < closest[i] ? d : closest[i]; /* :257 np.minimum */
+      }
+      double p = pot_sum(dl, w, n); /* :258 */
+      if (l == 0 || p < bestpot) {  /* :261 argmin */
+        bestpot = p;
+        best = l;
+      }
+    }
+    pot = bestpot;
+    memcpy(closest, cand + (size_t)best * n, sizeof(double) * (size_t)n);
+    memcpy(C + (size_t)cc * D, Xb + cid[best] * D, sizeof(double) * D);
+    if (chosen) chosen[cc] = cid[best];
+  }
+#undef DIST
+  int rc = hamsm_set_centroids(c, s, K, C, NULL, NULL); /* counts = 0, _kmeans.py:2271 */
+  free(Xb);
+  free(w);
+  free(xsq);
+  free(closest);
+  free(cand);
+  free(cum);
+  free(C);
+  return rc;
+}
+
+/* --- a7: _kmeans.py:1620-1642 + _k_means_minibatch.pyx:59-108 */
+int hamsm_minibatch_step(hamsm_ctx *c, int s, const void *X, int dt, int64_t ldx, const int32_t *rows, int64_t n_b,
+                         const double *wf, int32_t *labels_out) {
+  if (!c->st || s < 0 || s >= c->S) return fail(c, HAMSM_EINVAL, "bad stratum");
+  stratum_t *t = &c->st[s];
+  if (t->K == 0) return fail(c, HAMSM_EUNFIT, "stratum %d has no centroids", s);
+  int D = c->D;
+  int32_t *lab = (int32_t *)malloc(sizeof(int32_t) * (size_t)(n_b > 0 ? n_b : 1));
+  double *x = (double *)malloc(sizeof(double) * (size_t)D);
+  for (int64_t i = 0; i < n_b; i++) {
+    load_row(x, X, dt, ldx, frame_of(rows, NULL, i), D);
+    lab[i] = argmin_row(x, t, D);
+  }
+  for (int j = 0; j < t->K; j++) {
+    double wsum = 0.0;
+    for (int64_t i = 0; i < n_b; i++)
+      if (lab[i] == j) wsum = wsum + (wf ? wf[frame_of(rows, NULL, i)] : 1.0); /* pyx:80-85 */
+    if (wsum > 0) {
+      double *cj = t->C + (size_t)j * D;
+      for (int k = 0; k < D; k++) cj[k] = cj[k] * t->counts[j]; /* pyx:89-91 */
+      for (int64_t i = 0; i < n_b; i++)
+        if (lab[i] == j) {
+          int64_t f = frame_of(rows, NULL, i);
+          double wi = wf ? wf[f] : 1.0;
+          for (int k = 0; k < D; k++) cj[k] = cj[k] + xval(X, dt, f * ldx + k) * wi; /* pyx:94-97 */
+        }
+      t->counts[j] = t->counts[j] + wsum; /* pyx:100 */
+      double alpha = 1.0 / t->counts[j];  /* pyx:103 */
+      for (int k = 0; k < D; k++) cj[k] = cj[k] * alpha;
+      t->csq[j] = sqnorm_chain(cj, D);
+    }
+  }
+  if (labels_out) memcpy(labels_out, lab, sizeof(int32_t) * (size_t)n_b);
+  free(lab);
+  free(x);
+  return HAMSM_OK;
+}
+
+int hamsm_get_counts(hamsm_ctx *c, int s, double *counts) {
+  if (!c->st || s < 0 || s >= c->S) return fail(c, HAMSM_EINVAL, "bad stratum");
+  memcpy(counts, c->st[s].counts, sizeof(double) * (size_t)c->st[s].K);
+  return HAMSM_OK;
+}
+
+/* --- _kmeans.py:1652-1673 */
+int hamsm_reassign(hamsm_ctx *c, int s, const void *X, int dt, int64_t ldx, const int32_t *rows, const int32_t *cl,
+                   const int64_t *brow, int n_re, double new_count) {
+  if (!c->st || s < 0 || s >= c->S) return fail(c, HAMSM_EINVAL, "bad stratum");
+  stratum_t *t = &c->st[s];
+  for (int i = 0; i < n_re; i++) {
+    if (cl[i] < 0 || cl[i] >= t->K) return fail(c, HAMSM_EINVAL, "reassign cluster out of range");
+    double *cj = t->C + (size_t)cl[i] * c->D;
+    if (brow) {
+      load_row(cj, X, dt, ldx, frame_of(rows, NULL, brow[i]), c->D); /* :1667 centers_new[to_reassign] = X[new_centers] */
+      t->csq[cl[i]] = sqnorm_chain(cj, c->D);
+    }
+    t->counts[cl[i]] = new_count; /* :1672 */
+  }
+  return HAMSM_OK;
+}
+
+/* --- single-process stand-ins for the exchange step (tests drive N>1 through gloo on the host) */
+int hamsm_comm_unique_id(char *id) {
+  memset(id, 0, 128);
+  return HAMSM_OK;
+}
+int hamsm_comm_init(hamsm_ctx *c, int nranks, int rank, const char *id) {
+  (void)id;
+  (void)rank;
+  return nranks == 1 ? HAMSM_OK : fail(c, HAMSM_ENOTSUP, "cpu-oracle has no collective backend");
+}
+int hamsm_comm_destroy(hamsm_ctx *c) {
+  (void)c;
+  return HAMSM_OK;
+}
+int hamsm_allreduce_sum_f64(hamsm_ctx *c, double *b, int64_t n) {
+  (void)c, (void)b, (void)n;
+  return HAMSM_OK;
+}
+int hamsm_allreduce_min_f64(hamsm_ctx *c, double *b, int64_t n) {
+  (void)c, (void)b, (void)n;
+  return HAMSM_OK;
+}
+int hamsm_allreduce_max_f64(hamsm_ctx *c, double *b, int64_t n) {
+  (void)c, (void)b, (void)n;
+  return HAMSM_OK;
+}
+int hamsm_allreduce_sum_i64(hamsm_ctx *c, int64_t *b, int64_t n) {
+  (void)c, (void)b, (void)n;
+  return HAMSM_OK;
+}
+int hamsm_bcast(hamsm_ctx *c, void *b, size_t n, int root) {
+  (void)c, (void)b, (void)n, (void)root;
+  return HAMSM_OK;
+}
+int hamsm_bcast_model(hamsm_ctx *c, int root) {
+  (void)c, (void)root;
+  return HAMSM_OK;
+}
+int hamsm_timers(hamsm_ctx *c, double *out, int reset) {
+  (void)c, (void)reset;
+  memset(out, 0, sizeof(double) * 8);
+  return HAMSM_OK;
+}
+int hamsm_last_kernel_ms(hamsm_ctx *c, int stage, double *ms) {
+  (void)c, (void)stage;
+  *ms = 0.0;
+  return HAMSM_OK;
+}

@@ -1,0 +1,119 @@
+"""Shared fixtures.  `-m "not gpu"`: oracle vs golden vectors, host logic, ABI export checks.
+`-m gpu`: parity tests proper, HIP library vs oracle, all through the C ABI."""
+import ctypes
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run by the driver with -m gpu)")
+
+
+def _build_oracle():
+    so = os.path.join(ROOT, "oracle", "_build", "libhamsm_oracle.so")
+    src = os.path.join(ROOT, "oracle", "hamsm_oracle.c")
+    if not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle")])
+    return so
+
+
+@pytest.fixture(scope="session")
+def oracle_lib():
+    """The CPU oracle (test infrastructure): same C ABI as the product, plain C."""
+    return ctypes.CDLL(_build_oracle())
+
+
+@pytest.fixture()
+def oracle_h(oracle_lib):
+    from msm_we_amd import _abi
+
+    h = _abi.Hamsm(lib=oracle_lib)
+    yield h
+    h.close()
+
+
+@pytest.fixture(scope="session")
+def hip_lib():
+    from msm_we_amd import _abi
+
+    return _abi.load()  # raises if the HIP library is missing: no fallback
+
+
+@pytest.fixture()
+def hip_h(hip_lib):
+    from msm_we_amd import _abi
+
+    h = _abi.Hamsm(lib=hip_lib, device=0)
+    assert h.backend == "hip-gfx950"
+    yield h
+    h.close()
+
+
+class RectilinearBinMapper:
+    """Test-side stand-in for westpa.core.binning.RectilinearBinMapper (attributes only: the
+    library does the assignment)."""
+
+    def __init__(self, boundaries):
+        self.boundaries = [np.asarray(b, dtype=np.float32) for b in boundaries]
+        self.nbins = int(np.prod([len(b) - 1 for b in self.boundaries]))
+
+
+def load_golden(case):
+    g = np.load(os.path.join(GOLDEN, f"{case}.npz"))
+    meta = json.loads(str(g["meta"]))
+    return g, meta
+
+
+def golden_iterations(g):
+    offs = g["in_offsets"]
+    return {i + 1: {k: g["in_" + k][offs[i]: offs[i + 1]] for k in ("Xp", "Xc", "p0", "p1", "w")}
+            for i in range(len(offs) - 1)}
+
+
+def build_model(h, g, meta, seed_forcing=True):
+    """modelWE on golden inputs, up to (and including) cluster_coordinates.  Returns (model, forced)
+    where forced counts k-means++ seedings replaced by the reference's (exact-tie flips)."""
+    from msm_we_amd.data import InMemorySource
+    from msm_we_amd.model import modelWE
+
+    m = modelWE(h=h)
+    m.set_iteration_source(InMemorySource(golden_iterations(g)))
+    m.initialize(["golden.h5"], {"coords": None, "nAtoms": meta["D"], "coord_ndim": 1}, "golden",
+                 basis_pcoord_bounds=meta["basis"], target_pcoord_bounds=meta["target"], tau=meta["tau"],
+                 pcoord_ndim=1, use_weights_in_clustering=meta["use_weights"])
+    m.get_iterations()
+    m.get_coordSet(m.maxIter)
+    m.dimReduce()
+    state = {"i": 0, "forced": 0, "chosen": []}
+    orig = h.kmeans_seed
+
+    def seed(stratum, d_X, x_dtype, ldx, d_rows, n_b, d_w, sub, K_s, first, u, L, want_chosen=False):
+        ch = orig(stratum, d_X, x_dtype, ldx, d_rows, n_b, d_w, sub, K_s, first, u, L, want_chosen=True)
+        ref = g["pp_indices"][state["i"]]
+        state["chosen"].append((ch.copy(), ref.copy()))
+        if seed_forcing and not np.array_equal(ch, ref):
+            state["forced"] += 1
+            h.set_centroids(stratum, g["pp_centers"][state["i"]])
+        state["i"] += 1
+        return ch
+
+    h.kmeans_seed = seed
+    bm = RectilinearBinMapper([np.array(meta["boundaries"], dtype=np.float32)])
+    try:
+        m.cluster_coordinates(meta["K_s"], streaming=True, use_ray=True, stratified=True, user_bin_mapper=bm,
+                              random_state=meta["seed"])
+    finally:
+        h.kmeans_seed = orig
+    return m, state
+
+
+GOLDEN_CASES = ["c1p_d10", "c1p_d30", "c1p_d10_weighted", "gap_d10", "sparse_d10"]
