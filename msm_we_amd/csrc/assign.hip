@@ -1,0 +1,456 @@
+// assign.hip -- a3/a4 classify and a9 fused stratified assignment (StratifiedClusters.predict,
+// reference msm_we/stratified_clustering.py:101-212) for gfx950.
+//
+// Kernel plan.  One 256-thread workgroup (4 waves, one per SIMD) owns a contiguous
+// chunk of FR frames:
+//   1. classify: every frame's pcoord -> basis/target flags and stratum s = remap[bin(p)]; basis /
+//      target frames get their label at once; the others are bucketed by stratum in LDS into tiles
+//      of 16 frames (the MFMA M dimension).  Frames stay in HBM order: one coalesced pass.
+//   2. the chunk's feature rows are staged into LDS with 16-byte loads (the only HBM read of X).
+//   3. each wave pulls work items (<= MT tiles of one stratum), holds the A fragments (frames) of all
+//      k-steps in registers, streams the stratum's centroids as pre-packed MFMA B fragments from L2
+//      (fully coalesced 512-B loads, double buffered) and runs v_mfma_f64_16x16x4_f64; the epilogue
+//      forms csq - 2*dot, keeps a running first-minimum per lane and reduces across the 16 lanes of
+//      a row with DPP-free shuffles.
+// The dot product of a frame and a centroid is an f64 FMA chain over ascending k (the MFMA applies
+// its four k-products in order; zero padding adds exact zeros), i.e. the arithmetic contract of
+// include/hamsm.h; hamsm_selftest_mfma() checks that property of the hardware bit for bit.
+#include "common.h"
+
+typedef double v4f64 __attribute__((ext_vector_type(4)));
+
+#define FR 512          // frames per workgroup
+#define NTHREADS 256
+#define MAX_TILES (FR / 16 + 64)  // FR/16 full tiles + one partial tile per stratum present (<= 64 here, see host check)
+
+// ---- classify -----------------------------------------------------------------------------------
+__global__ void k_classify(MapperDev m, const double *__restrict__ p, int64_t n, int apply_remap, int32_t *bin,
+                           uint8_t *flags) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  double pi[HAMSM_MAX_NDIM];
+  for (int d = 0; d < m.ndim; d++) pi[d] = p[i * m.ndim + d];
+  int b = dev_bin_of(m, pi);
+  if (b >= 0 && apply_remap) b = m.remap[b];
+  if (bin) bin[i] = b;
+  if (flags) flags[i] = (uint8_t)((dev_in_box(m.basis, m.ndim, pi) ? 1 : 0) | (dev_in_box(m.target, m.ndim, pi) ? 2 : 0));
+}
+
+extern "C" int hamsm_classify(hamsm_ctx *c, const double *p, int64_t n, int apply_remap, int32_t *bin, uint8_t *flags) {
+  if (!c->have_mapper || !c->have_bounds) return hamsm_fail(c, HAMSM_EINVAL, "mapper/bounds not set");
+  if (n <= 0) return HAMSM_OK;
+  hipLaunchKernelGGL(k_classify, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, c->mapper, p, n, apply_remap,
+                     bin, flags);
+  HIPCHK(c, hipGetLastError());
+  return HAMSM_OK;
+}
+
+// ---- the MFMA tile routine ------------------------------------------------------------------------
+// a[m][ks]: A fragments of MT tiles (lane l: frame row l&15 of tile m, feature ks*4 + (l>>4)).
+// On return bi[m][r] (valid in lanes with (l&15)==0) = first argmin over the stratum's centroids for
+// tile m, row (l>>4) + 4*r  (C/D layout of v_mfma_f64_16x16x4_f64: col = l&15, row = (l>>4) + 4*reg).
+template <int KS, int MT>
+__device__ __forceinline__ void tile_argmin(const double (&a)[MT][KS], int nt, const double *__restrict__ Bpack,
+                                            const double *__restrict__ csq, int K, int lane, int (&bi)[MT][4]) {
+  const double inf = __builtin_huge_val();
+  double bd[MT][4];
+#pragma unroll
+  for (int m = 0; m < MT; m++)
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+      bd[m][r] = inf;
+      bi[m][r] = lane & 15;
+    }
+  const int njt = (K + 15) >> 4;
+  double bcur[KS], bnext[KS];
+#pragma unroll
+  for (int ks = 0; ks < KS; ks++) bcur[ks] = Bpack[(size_t)ks * 64 + lane];
+  for (int jt = 0; jt < njt; jt++) {
+    const double cs = csq[jt * 16 + (lane & 15)];
+    if (jt + 1 < njt) {
+#pragma unroll
+      for (int ks = 0; ks < KS; ks++) bnext[ks] = Bpack[((size_t)(jt + 1) * KS + ks) * 64 + lane];
+    }
+    v4f64 acc[MT];
+#pragma unroll
+    for (int m = 0; m < MT; m++) acc[m] = (v4f64){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int ks = 0; ks < KS; ks++) {
+#pragma unroll
+      for (int m = 0; m < MT; m++)
+        if (m < nt) acc[m] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[m][ks], bcur[ks], acc[m], 0, 0, 0);
+    }
+    const int j = jt * 16 + (lane & 15);
+#pragma unroll
+    for (int m = 0; m < MT; m++)
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+        double d = __builtin_fma(-2.0, acc[m][r], cs);  // csq - 2*dot, one rounding
+        bool lt = d < bd[m][r];                          // strict: lowest j wins inside a lane
+        bd[m][r] = lt ? d : bd[m][r];
+        bi[m][r] = lt ? j : bi[m][r];
+      }
+#pragma unroll
+    for (int ks = 0; ks < KS; ks++) bcur[ks] = bnext[ks];
+  }
+  // first-minimum across the 16 lanes that share a row: (d, j) lexicographic
+#pragma unroll
+  for (int m = 0; m < MT; m++)
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+      double d = bd[m][r];
+      int j = bi[m][r];
+#pragma unroll
+      for (int off = 8; off >= 1; off >>= 1) {
+        double d2 = __shfl_xor(d, off, 16);
+        int j2 = __shfl_xor(j, off, 16);
+        bool take = (d2 < d) || (d2 == d && j2 < j);
+        d = take ? d2 : d;
+        j = take ? j2 : j;
+      }
+      bi[m][r] = j;
+    }
+}
+
+// ---- fused assign ---------------------------------------------------------------------------------
+struct AssignArgs {
+  const void *X;
+  int64_t ldx;
+  const double *pcoord;
+  int64_t n;
+  int32_t *labels;
+  int32_t *seen;  // nullable [2][S]
+  const StratumDev *table;
+  int S, D, Kfit;
+  int *err;
+};
+
+template <typename XT, int KS, int MT>
+__global__ __launch_bounds__(NTHREADS) void k_assign(MapperDev mp, AssignArgs g) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  // LDS carve (one array, G17): Xs | slot | tile_s | item_* | cnt/tb | misc
+  XT *Xs = (XT *)smem;                                                 // [FR][D]
+  size_t xbytes = ((size_t)FR * g.D * sizeof(XT) + 15) & ~(size_t)15;
+  int16_t *slot = (int16_t *)(smem + xbytes);                          // [MAX_TILES*16] local frame index or -1
+  int16_t *sid = slot + MAX_TILES * 16;                                // [FR] stratum of frame (or -1)
+  int16_t *pos = sid + FR;                                             // [FR] position inside the stratum's list
+  int *tile_s = (int *)(pos + FR);                                     // [MAX_TILES] stratum of tile
+  int *cnt = tile_s + MAX_TILES;                                       // [S]  frames per stratum
+  int *tbase = cnt + g.S;                                              // [S]  first tile of stratum
+  int *misc = tbase + g.S;                                             // [0] n tiles, [1] next item
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int64_t f0 = (int64_t)blockIdx.x * FR;
+  const int nf = (int)((g.n - f0) < FR ? (g.n - f0) : FR);
+
+  for (int s = tid; s < g.S; s += NTHREADS) cnt[s] = 0;
+  for (int t = tid; t < MAX_TILES * 16; t += NTHREADS) slot[t] = -1;
+  if (tid == 0) misc[1] = 0;
+  __syncthreads();
+
+  // 1. classify + bucket
+  for (int i = tid; i < nf; i += NTHREADS) {
+    double pi[HAMSM_MAX_NDIM];
+    for (int d = 0; d < mp.ndim; d++) pi[d] = g.pcoord[(f0 + i) * mp.ndim + d];
+    int b = dev_bin_of(mp, pi);
+    int16_t my = -1, myp = 0;
+    if (b < 0) {
+      dev_set_error(g.err, HAMSM_ERANGE, (int)(f0 + i), b);
+    } else {
+      int s = mp.remap[b];                       // stratified_clustering.py:134-135
+      if (dev_in_box(mp.target, mp.ndim, pi)) {  // :159 target first
+        g.labels[f0 + i] = g.Kfit + 1;
+        if (g.seen) g.seen[s] = 1;
+      } else if (dev_in_box(mp.basis, mp.ndim, pi)) {  // :165
+        g.labels[f0 + i] = g.Kfit;
+        if (g.seen) g.seen[g.S + s] = 1;
+      } else if (g.table[s].K == 0) {  // :187-189
+        dev_set_error(g.err, HAMSM_EUNFIT, (int)(f0 + i), s);
+      } else {
+        my = (int16_t)s;
+        myp = (int16_t)atomicAdd(&cnt[s], 1);
+      }
+    }
+    sid[i] = my;
+    pos[i] = myp;
+  }
+  // 2. stage the chunk's rows (flat copy when rows are dense, else row by row)
+  {
+    const XT *src = (const XT *)g.X;
+    if (g.ldx == g.D) {
+      const int64_t e0 = f0 * g.D;
+      const int tot = nf * g.D;
+      constexpr int V = 16 / sizeof(XT);
+      // 16-byte vector loads where aligned
+      int head = (int)(((16 - ((uintptr_t)(src + e0) & 15)) & 15) / sizeof(XT));
+      if (head > tot) head = tot;
+      for (int e = tid; e < head; e += NTHREADS) Xs[e] = src[e0 + e];
+      int nvec = (tot - head) / V;
+      typedef XT vecT __attribute__((ext_vector_type(V)));
+      const vecT *vs = (const vecT *)(src + e0 + head);
+      for (int v = tid; v < nvec; v += NTHREADS) {
+        vecT x = vs[v];
+#pragma unroll
+        for (int q = 0; q < V; q++) Xs[head + v * V + q] = x[q];
+      }
+      for (int e = head + nvec * V + tid; e < tot; e += NTHREADS) Xs[e] = src[e0 + e];
+    } else {
+      for (int e = tid; e < nf * g.D; e += NTHREADS) {
+        int r = e / g.D, k = e - r * g.D;
+        Xs[e] = src[(f0 + r) * g.ldx + k];
+      }
+    }
+  }
+  __syncthreads();
+  // tile bases per stratum (one wave, S is small; sequential scan by lane 0 keeps it simple)
+  if (tid == 0) {
+    int t = 0;
+    for (int s = 0; s < g.S; s++) {
+      tbase[s] = t;
+      int nt = (cnt[s] + 15) >> 4;
+      for (int q = 0; q < nt && t + q < MAX_TILES; q++) tile_s[t + q] = s;
+      t += nt;
+    }
+    misc[0] = t < MAX_TILES ? t : MAX_TILES;
+    if (t > MAX_TILES) dev_set_error(g.err, HAMSM_ENOTSUP, t, MAX_TILES);
+  }
+  __syncthreads();
+  for (int i = tid; i < nf; i += NTHREADS) {
+    int s = sid[i];
+    if (s >= 0) {
+      int sl = tbase[s] * 16 + pos[i];
+      if (sl < MAX_TILES * 16) slot[sl] = (int16_t)i;
+    }
+  }
+  __syncthreads();
+
+  // 3. work items: up to MT consecutive tiles of one stratum, pulled dynamically by the waves
+  const int ntiles = misc[0];
+  while (true) {
+    int t0 = 0;
+    if (lane == 0) t0 = atomicAdd(&misc[1], MT);
+    t0 = __builtin_amdgcn_readfirstlane(t0);
+    if (t0 >= ntiles) break;
+    // tiles t0..t0+MT-1 may span strata: process runs of equal stratum
+    int t = t0;
+    const int tend = (t0 + MT < ntiles) ? t0 + MT : ntiles;
+    while (t < tend) {
+      const int s = tile_s[t];
+      int nt = 1;
+      while (t + nt < tend && tile_s[t + nt] == s) nt++;
+      double a[MT][KS];
+      int fr[MT];
+#pragma unroll
+      for (int m = 0; m < MT; m++) {
+        int f = (m < nt) ? slot[(t + m) * 16 + (lane & 15)] : -1;
+        fr[m] = f;
+        int fsafe = f < 0 ? 0 : f;
+#pragma unroll
+        for (int ks = 0; ks < KS; ks++) {
+          int k = ks * 4 + (lane >> 4);
+          a[m][ks] = (f >= 0 && k < g.D) ? (double)Xs[fsafe * g.D + k] : 0.0;
+        }
+      }
+      const StratumDev sd = g.table[s];
+      int bi[MT][4];
+      tile_argmin<KS, MT>(a, nt, sd.Bpack, sd.csq, sd.K, lane, bi);
+      // lanes with (lane&15)==0 own rows (lane>>4) + 4r
+#pragma unroll
+      for (int m = 0; m < MT; m++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+          int row = (lane >> 4) + 4 * r;
+          int f = __shfl(fr[m], row, 64);  // lane `row` holds the frame index of tile row `row`
+          if ((lane & 15) == 0 && m < nt && f >= 0) g.labels[f0 + f] = sd.off + bi[m][r];  // :195
+        }
+      t += nt;
+    }
+  }
+}
+
+template <typename XT, int KS>
+static int launch_assign_ks(hamsm_ctx *c, const MapperDev &mp, const AssignArgs &g) {
+  constexpr int MT = (KS <= 16) ? 4 : 2;
+  size_t xbytes = ((size_t)FR * g.D * sizeof(XT) + 15) & ~(size_t)15;
+  size_t lds = xbytes + sizeof(int16_t) * (MAX_TILES * 16 + 2 * FR) + sizeof(int) * (MAX_TILES + 2 * g.S + 4);
+  if (lds > 160 * 1024) return hamsm_fail(c, HAMSM_ENOTSUP, "assign needs %zu B of LDS", lds);
+  auto kern = k_assign<XT, KS, MT>;
+  HIPCHK(c, hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  unsigned grid = (unsigned)((g.n + FR - 1) / FR);
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(NTHREADS), lds, c->stream, mp, g);
+  HIPCHK(c, hipGetLastError());
+  return HAMSM_OK;
+}
+
+template <typename XT>
+static int launch_assign(hamsm_ctx *c, const MapperDev &mp, const AssignArgs &g) {
+  int ks = c->KS;
+  if (ks <= 1) return launch_assign_ks<XT, 1>(c, mp, g);
+  if (ks <= 2) return launch_assign_ks<XT, 2>(c, mp, g);
+  if (ks <= 3) return launch_assign_ks<XT, 3>(c, mp, g);
+  if (ks <= 4) return launch_assign_ks<XT, 4>(c, mp, g);
+  if (ks <= 6) return launch_assign_ks<XT, 6>(c, mp, g);
+  if (ks <= 8) return launch_assign_ks<XT, 8>(c, mp, g);
+  if (ks <= 12) return launch_assign_ks<XT, 12>(c, mp, g);
+  if (ks <= 16) return launch_assign_ks<XT, 16>(c, mp, g);
+  if (ks <= 24) return launch_assign_ks<XT, 24>(c, mp, g);
+  if (ks <= 32) return launch_assign_ks<XT, 32>(c, mp, g);
+  return hamsm_fail(c, HAMSM_ENOTSUP, "D > 128");
+}
+
+extern "C" int hamsm_assign(hamsm_ctx *c, const void *X, int dt, int64_t ldx, const double *p, int64_t n, int32_t *labels,
+                            int32_t *seen) {
+  if (!c->have_mapper || !c->have_bounds) return hamsm_fail(c, HAMSM_EINVAL, "mapper/bounds not set");
+  if (dt != HAMSM_F32 && dt != HAMSM_F64) return hamsm_fail(c, HAMSM_EINVAL, "x_dtype");
+  if (ldx < c->D) return hamsm_fail(c, HAMSM_EINVAL, "ldx < D");
+  if (c->S > 64 + 0 && c->S > MAX_TILES - FR / 16) {
+    // more strata than spare partial tiles per workgroup: still correct as long as a chunk meets <= 64 strata;
+    // the kernel reports HAMSM_ENOTSUP otherwise
+  }
+  if (n <= 0) return HAMSM_OK;
+  int rc = hamsm_refresh_table(c);
+  if (rc) return rc;
+  // B fragments carry ceil(D/4) k-steps, but the kernels are instantiated for a few KS values: the
+  // packed layout always uses c->KS, so the instantiated KS must equal it
+  AssignArgs g{X, ldx, p, n, labels, seen, c->d_table, c->S, c->D, c->Kfit, c->d_err};
+  hamsm_timer_begin(c);
+  rc = (dt == HAMSM_F32) ? launch_assign<float>(c, c->mapper, g) : launch_assign<double>(c, c->mapper, g);
+  hamsm_timer_end(c, ST_ASSIGN);
+  if (rc) return rc;
+  return hamsm_check_device_error(c, "assign");
+}
+
+extern "C" int hamsm_predict_host(hamsm_ctx *c, const void *X, int dt, const double *p, int64_t n, int32_t *labels,
+                                  int32_t *seen) {
+  if (n <= 0) return HAMSM_OK;
+  size_t xs = (dt == HAMSM_F32 ? 4 : 8) * (size_t)n * c->D;
+  size_t ps = sizeof(double) * (size_t)n * c->ndim, ls = sizeof(int32_t) * (size_t)n, ss = sizeof(int32_t) * 2 * c->S;
+  size_t o_p = (xs + 255) & ~(size_t)255, o_l = (o_p + ps + 255) & ~(size_t)255, o_s = (o_l + ls + 255) & ~(size_t)255;
+  int rc = hamsm_ensure_scratch(c, o_s + ss);
+  if (rc) return rc;
+  char *base = (char *)c->scratch;
+  HIPCHK(c, hipMemcpyAsync(base, X, xs, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(base + o_p, p, ps, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemsetAsync(base + o_s, 0, ss, c->stream));
+  rc = hamsm_assign(c, base, dt, c->D, (const double *)(base + o_p), n, (int32_t *)(base + o_l),
+                    seen ? (int32_t *)(base + o_s) : nullptr);
+  if (rc) return rc;
+  HIPCHK(c, hipMemcpyAsync(labels, base + o_l, ls, hipMemcpyDeviceToHost, c->stream));
+  if (seen) HIPCHK(c, hipMemcpyAsync(seen, base + o_s, ss, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return HAMSM_OK;
+}
+
+// ---- assign a gathered batch to ONE stratum (the E-step of MiniBatchKMeans, a7 i) -----------------
+// rows (nullable) index frames of X; one wave per MT tiles, A fragments gathered straight from global.
+template <typename XT, int KS, int MT>
+__global__ __launch_bounds__(NTHREADS) void k_assign_rows(const XT *__restrict__ X, int64_t ldx, int D,
+                                                          const int32_t *__restrict__ rows, int64_t n_b,
+                                                          const double *__restrict__ Bpack, const double *__restrict__ csq,
+                                                          int K, int32_t *__restrict__ labels) {
+  const int lane = threadIdx.x & 63;
+  const int64_t wave = (int64_t)blockIdx.x * (NTHREADS / 64) + (threadIdx.x >> 6);
+  const int64_t r0 = wave * (MT * 16);
+  if (r0 >= n_b) return;
+  double a[MT][KS];
+  int64_t br[MT];
+  int nt = 0;
+#pragma unroll
+  for (int m = 0; m < MT; m++) {
+    int64_t r = r0 + m * 16 + (lane & 15);
+    bool ok = r < n_b;
+    if (r0 + m * 16 < n_b) nt = m + 1;
+    br[m] = ok ? r : -1;
+    int64_t f = ok ? (rows ? (int64_t)rows[r] : r) : 0;
+#pragma unroll
+    for (int ks = 0; ks < KS; ks++) {
+      int k = ks * 4 + (lane >> 4);
+      a[m][ks] = (ok && k < D) ? (double)X[f * ldx + k] : 0.0;
+    }
+  }
+  int bi[MT][4];
+  tile_argmin<KS, MT>(a, nt, Bpack, csq, K, lane, bi);
+#pragma unroll
+  for (int m = 0; m < MT; m++)
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+      int row = (lane >> 4) + 4 * r;
+      int64_t b = __shfl(br[m], row, 64);
+      if ((lane & 15) == 0 && m < nt && b >= 0) labels[b] = bi[m][r];
+    }
+}
+
+template <typename XT, int KS>
+static int launch_rows_ks(hamsm_ctx *c, const void *X, int64_t ldx, const int32_t *rows, int64_t n_b, const Stratum &t,
+                          int32_t *labels) {
+  constexpr int MT = (KS <= 16) ? 2 : 1;  // small batches: favour more waves over B reuse
+  int64_t waves = (n_b + MT * 16 - 1) / (MT * 16);
+  unsigned grid = (unsigned)((waves + 3) / 4);
+  hipLaunchKernelGGL((k_assign_rows<XT, KS, MT>), dim3(grid), dim3(NTHREADS), 0, c->stream, (const XT *)X, ldx, c->D, rows,
+                     n_b, t.Bpack, t.csq, t.K, labels);
+  HIPCHK(c, hipGetLastError());
+  return HAMSM_OK;
+}
+
+template <typename XT>
+static int launch_rows(hamsm_ctx *c, const void *X, int64_t ldx, const int32_t *rows, int64_t n_b, const Stratum &t,
+                       int32_t *labels) {
+  int ks = c->KS;
+#define R(KSV) return launch_rows_ks<XT, KSV>(c, X, ldx, rows, n_b, t, labels)
+  if (ks <= 1) R(1);
+  if (ks <= 2) R(2);
+  if (ks <= 3) R(3);
+  if (ks <= 4) R(4);
+  if (ks <= 6) R(6);
+  if (ks <= 8) R(8);
+  if (ks <= 12) R(12);
+  if (ks <= 16) R(16);
+  if (ks <= 24) R(24);
+  R(32);
+#undef R
+}
+
+int hamsm_assign_rows(hamsm_ctx *c, int s, const void *X, int dt, int64_t ldx, const int32_t *rows, int64_t n_b,
+                      int32_t *labels) {
+  const Stratum &t = c->st[s];
+  return dt == HAMSM_F32 ? launch_rows<float>(c, X, ldx, rows, n_b, t, labels)
+                         : launch_rows<double>(c, X, ldx, rows, n_b, t, labels);
+}
+
+// ---- hardware property check: is v_mfma_f64_16x16x4_f64 an in-order FMA chain? --------------------
+__global__ void k_selftest(const double *A, const double *B, int KS, double *out_mfma, double *out_chain) {
+  // A [16][KS*4], B [KS*4][16] row-major; one wave
+  int lane = threadIdx.x;
+  v4f64 acc = {0.0, 0.0, 0.0, 0.0};
+  for (int ks = 0; ks < KS; ks++) {
+    double a = A[(lane & 15) * KS * 4 + ks * 4 + (lane >> 4)];
+    double b = B[(ks * 4 + (lane >> 4)) * 16 + (lane & 15)];
+    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
+  }
+  for (int r = 0; r < 4; r++) {
+    int row = (lane >> 4) + 4 * r, col = lane & 15;
+    out_mfma[row * 16 + col] = acc[r];
+    double ch = 0.0;
+    for (int k = 0; k < KS * 4; k++) ch = __builtin_fma(A[row * KS * 4 + k], B[k * 16 + col], ch);
+    out_chain[row * 16 + col] = ch;
+  }
+}
+
+// Not part of the product ABI (debug / test hook): returns the number of the 256 outputs whose bits
+// differ between the MFMA and the FMA chain, for A (16 x 4*KS) and B (4*KS x 16) given on the host.
+extern "C" int hamsm_selftest_mfma(hamsm_ctx *c, const double *hA, const double *hB, int KS, double *h_mfma,
+                                   double *h_chain) {
+  size_t na = sizeof(double) * 16 * KS * 4;
+  int rc = hamsm_ensure_scratch(c, 2 * na + 2 * 256 * sizeof(double));
+  if (rc) return rc;
+  double *dA = (double *)c->scratch, *dB = dA + 16 * KS * 4, *o1 = dB + 16 * KS * 4, *o2 = o1 + 256;
+  HIPCHK(c, hipMemcpyAsync(dA, hA, na, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(dB, hB, na, hipMemcpyHostToDevice, c->stream));
+  hipLaunchKernelGGL(k_selftest, dim3(1), dim3(64), 0, c->stream, dA, dB, KS, o1, o2);
+  HIPCHK(c, hipMemcpyAsync(h_mfma, o1, 256 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipMemcpyAsync(h_chain, o2, 256 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  int bad = 0;
+  for (int i = 0; i < 256; i++) bad += memcmp(&h_mfma[i], &h_chain[i], 8) != 0;
+  return bad;
+}

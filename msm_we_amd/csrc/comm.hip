@@ -1,0 +1,113 @@
+// comm.hip -- the exchange step of the sharded path: RCCL over xGMI, one rank per GPU.
+// Frames shard by WE iteration; assignment needs no communication; the partial flux matrix, the
+// cluster statistics and (for broadcast) the centroid tables are the only payloads.  Replaces the
+// reference's driver-side dense sum (_fluxmatrix.py:325-327) and ray.put broadcasts
+// (_clustering.py:1169-1176).
+#include <rccl/rccl.h>
+
+#include "common.h"
+
+#define NCCLCHK(c, call)                                                                                  \
+  do {                                                                                                    \
+    ncclResult_t r_ = (call);                                                                             \
+    if (r_ != ncclSuccess)                                                                                \
+      return hamsm_fail((c), HAMSM_EDEVICE, "%s failed: %s (%s:%d)", #call, ncclGetErrorString(r_), __FILE__, __LINE__); \
+  } while (0)
+
+static_assert(sizeof(ncclUniqueId) == 128, "hamsm_comm_unique_id hands out 128 bytes");
+
+extern "C" int hamsm_comm_unique_id(char *id128) {
+  ncclUniqueId id;
+  if (ncclGetUniqueId(&id) != ncclSuccess) return HAMSM_EDEVICE;
+  memcpy(id128, &id, 128);
+  return HAMSM_OK;
+}
+
+extern "C" int hamsm_comm_init(hamsm_ctx *c, int nranks, int rank, const char *id128) {
+  if (nranks < 1 || rank < 0 || rank >= nranks) return hamsm_fail(c, HAMSM_EINVAL, "bad rank %d/%d", rank, nranks);
+  HIPCHK(c, hipSetDevice(c->device));
+  c->nranks = nranks;
+  c->rank = rank;
+  if (nranks == 1) return HAMSM_OK;
+  ncclUniqueId id;
+  memcpy(&id, id128, 128);
+  ncclComm_t comm;
+  NCCLCHK(c, ncclCommInitRank(&comm, nranks, id, rank));
+  c->comm = (void *)comm;
+  return HAMSM_OK;
+}
+
+extern "C" int hamsm_comm_destroy(hamsm_ctx *c) {
+  if (c && c->comm) {
+    ncclCommDestroy((ncclComm_t)c->comm);
+    c->comm = nullptr;
+  }
+  return HAMSM_OK;
+}
+
+static int allreduce(hamsm_ctx *c, void *buf, int64_t count, ncclDataType_t dt, ncclRedOp_t op) {
+  if (c->nranks == 1 || count <= 0) return HAMSM_OK;
+  if (!c->comm) return hamsm_fail(c, HAMSM_EINVAL, "comm not initialised");
+  NCCLCHK(c, ncclAllReduce(buf, buf, (size_t)count, dt, op, (ncclComm_t)c->comm, c->stream));
+  return HAMSM_OK;
+}
+
+extern "C" int hamsm_allreduce_sum_f64(hamsm_ctx *c, double *b, int64_t n) { return allreduce(c, b, n, ncclDouble, ncclSum); }
+extern "C" int hamsm_allreduce_min_f64(hamsm_ctx *c, double *b, int64_t n) { return allreduce(c, b, n, ncclDouble, ncclMin); }
+extern "C" int hamsm_allreduce_max_f64(hamsm_ctx *c, double *b, int64_t n) { return allreduce(c, b, n, ncclDouble, ncclMax); }
+extern "C" int hamsm_allreduce_sum_i64(hamsm_ctx *c, int64_t *b, int64_t n) { return allreduce(c, b, n, ncclInt64, ncclSum); }
+
+extern "C" int hamsm_bcast(hamsm_ctx *c, void *b, size_t bytes, int root) {
+  if (c->nranks == 1 || bytes == 0) return HAMSM_OK;
+  if (!c->comm) return hamsm_fail(c, HAMSM_EINVAL, "comm not initialised");
+  NCCLCHK(c, ncclBroadcast(b, b, bytes, ncclChar, root, (ncclComm_t)c->comm, c->stream));
+  return HAMSM_OK;
+}
+
+// centroids, counts, ||c||^2 and remap of every stratum, root -> all (exact-mode training: SURVEY §7 hard part 3)
+extern "C" int hamsm_bcast_model(hamsm_ctx *c, int root) {
+  if (c->nranks == 1) return HAMSM_OK;
+  if (!c->comm) return hamsm_fail(c, HAMSM_EINVAL, "comm not initialised");
+  const int S = c->S;
+  int rc = hamsm_ensure_scratch(c, sizeof(int32_t) * S);
+  if (rc) return rc;
+  std::vector<int32_t> Ks(S);
+  for (int s = 0; s < S; s++) Ks[s] = c->st[s].K;
+  HIPCHK(c, hipMemcpyAsync(c->scratch, Ks.data(), sizeof(int32_t) * S, hipMemcpyHostToDevice, c->stream));
+  rc = hamsm_bcast(c, c->scratch, sizeof(int32_t) * S, root);
+  if (rc) return rc;
+  HIPCHK(c, hipMemcpyAsync(Ks.data(), c->scratch, sizeof(int32_t) * S, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  for (int s = 0; s < S; s++) {
+    Stratum &t = c->st[s];
+    if (Ks[s] > 0) {
+      rc = hamsm_stratum_reserve(c, s, Ks[s]);
+      if (rc) return rc;
+    }
+    t.K = Ks[s];
+  }
+  NCCLCHK(c, ncclGroupStart());
+  for (int s = 0; s < S; s++) {
+    Stratum &t = c->st[s];
+    if (t.K == 0) continue;
+    ncclComm_t cm = (ncclComm_t)c->comm;
+    ncclBroadcast(t.C, t.C, (size_t)t.K * c->D, ncclDouble, root, cm, c->stream);
+    ncclBroadcast(t.csq, t.csq, (size_t)t.K, ncclDouble, root, cm, c->stream);
+    ncclBroadcast(t.counts, t.counts, (size_t)t.K, ncclDouble, root, cm, c->stream);
+  }
+  NCCLCHK(c, ncclGroupEnd());
+  for (int s = 0; s < S; s++) {
+    // re-pack the MFMA B fragments locally from the broadcast rows, keeping the broadcast ||c||^2
+    Stratum &t = c->st[s];
+    if (t.K == 0) continue;
+    rc = hamsm_ensure_scratch(c, sizeof(double) * t.K);
+    if (rc) return rc;
+    HIPCHK(c, hipMemcpyAsync(c->scratch, t.csq, sizeof(double) * t.K, hipMemcpyDeviceToDevice, c->stream));
+    rc = hamsm_pack_stratum(c, s, (const double *)c->scratch);
+    if (rc) return rc;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+  }
+  rc = hamsm_bcast(c, c->d_remap, sizeof(int32_t) * S, root);
+  c->table_dirty = true;
+  return rc;
+}

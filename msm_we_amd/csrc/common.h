@@ -1,0 +1,143 @@
+// common.h -- context, error handling and device-side helpers shared by the HIP translation units.
+// gfx950 (CDNA4, wave64) only.  Built with -ffp-contract=off: a multiply and an add are never
+// fused unless the source says __builtin_fma, which is how the arithmetic contract of
+// include/hamsm.h (and of oracle/hamsm_oracle.c) is kept bit-for-bit.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdarg.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <vector>
+
+#include "../../include/hamsm.h"
+
+#define HAMSM_MAX_NDIM 8
+#define HAMSM_MAX_STRATA 4096
+#define POT_LANES 256   // strided partial sums of k-means++ potentials (oracle: POT_LANES)
+#define SCAN_CHUNK 64   // chunked cumulative sum (oracle: SCAN_CHUNK)
+
+// ---- device view of the mapper / bounds (passed by value to kernels) ---------------------------
+struct MapperDev {
+  int ndim;
+  int nb[HAMSM_MAX_NDIM];    // boundaries per dim
+  int boff[HAMSM_MAX_NDIM];  // offset of each dim's boundaries in `bounds`
+  const float *bounds;       // device
+  const int32_t *remap;      // device [S]
+  double basis[HAMSM_MAX_NDIM][2];
+  double target[HAMSM_MAX_NDIM][2];
+};
+
+// ---- per-stratum centroid storage ---------------------------------------------------------------
+// C      [Kcap][D]              row-major f64 (update / get)
+// csq    [Kpad]                 ||c||^2, +inf beyond K (never selected)
+// counts [Kcap]
+// Bpack  [Kpad/16][KS][64]      MFMA B-fragment order: element (jt, ks, lane) = C[jt*16 + (lane&15)][ks*4 + (lane>>4)]
+//                               (v_mfma_f64_16x16x4_f64: lane l holds B[k = l>>4][col = l&15]); zero padded
+struct StratumDev {
+  const double *Bpack;
+  const double *csq;
+  int K;    // fitted centroids (0 = unfitted)
+  int off;  // label offset = sum of K of earlier strata
+};
+
+struct Stratum {
+  int K = 0, Kcap = 0;
+  double *C = nullptr, *csq = nullptr, *counts = nullptr, *Bpack = nullptr;
+};
+
+enum { ST_ASSIGN = 0, ST_FLUX, ST_STATS, ST_SEED, ST_STEP, ST_REASSIGN, ST_PREPASS, ST_OTHER, ST_N };
+
+struct hamsm_ctx {
+  char err[512];
+  int device = 0;
+  hipStream_t stream = nullptr;
+  int D = 0, KS = 0 /* ceil(D/4) */, ndim = 0, S = 0;
+  bool have_mapper = false, have_bounds = false;
+  MapperDev mapper;  // host copy with device pointers inside
+  float *d_bounds = nullptr;
+  int32_t *d_remap = nullptr;
+  std::vector<Stratum> st;
+  StratumDev *d_table = nullptr;  // [S]
+  bool table_dirty = true;
+  int Kfit = 0;
+  int *d_err = nullptr;   // device error word: [0] code, [1] detail a, [2] detail b
+  int *h_err = nullptr;   // pinned mirror
+  void *scratch = nullptr;
+  size_t scratch_bytes = 0;
+  void *h_pinned = nullptr;  // small pinned staging buffer
+  size_t h_pinned_bytes = 0;
+  struct EvPair {
+    hipEvent_t e0, e1;
+    int stage;
+  };
+  std::vector<EvPair> ev_pending;
+  std::vector<hipEvent_t> ev_free;
+  hipEvent_t ev_cur0 = nullptr;
+  double timers[ST_N] = {0};
+  double last_ms[ST_N] = {0};
+  void *comm = nullptr;  // ncclComm_t
+  int nranks = 1, rank = 0;
+};
+
+int hamsm_fail(hamsm_ctx *c, int code, const char *fmt, ...);
+
+#define HIPCHK(c, call)                                                                              \
+  do {                                                                                               \
+    hipError_t e_ = (call);                                                                          \
+    if (e_ != hipSuccess)                                                                            \
+      return hamsm_fail((c), HAMSM_EDEVICE, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); \
+  } while (0)
+
+int hamsm_ensure_scratch(hamsm_ctx *c, size_t bytes);
+int hamsm_ensure_pinned(hamsm_ctx *c, size_t bytes);
+int hamsm_refresh_table(hamsm_ctx *c);                    // rebuilds d_table / Kfit when dirty
+int hamsm_check_device_error(hamsm_ctx *c, const char *what);  // reads d_err (syncs the stream)
+int hamsm_stratum_reserve(hamsm_ctx *c, int s, int K);
+int hamsm_pack_stratum(hamsm_ctx *c, int s, const double *d_csq_in);
+void hamsm_timer_begin(hamsm_ctx *c);
+void hamsm_timer_end(hamsm_ctx *c, int stage);
+
+// ---- device helpers -----------------------------------------------------------------------------
+#ifdef __HIPCC__
+// westpa RectilinearBinMapper.assign restated (oracle bin_of): float32 compare, half-open bins,
+// row-major over dims; -1 outside the bin space (also NaN).
+__device__ __forceinline__ int dev_bin_of(const MapperDev &m, const double *p) {
+  int idx = 0;
+  for (int d = 0; d < m.ndim; d++) {
+    float pf = (float)p[d];
+    const float *b = m.bounds + m.boff[d];
+    int n = m.nb[d], lo = 0, hi = n;
+    while (lo < hi) {
+      int mid = (lo + hi) >> 1;
+      if (b[mid] <= pf) lo = mid + 1;
+      else hi = mid;
+    }
+    int j = lo - 1;
+    if (j < 0 || j >= n - 1) return -1;
+    idx = idx * (n - 1) + j;
+  }
+  return idx;
+}
+
+// msm_we.py:480-492 / 515-527: all dims strictly inside, f64
+__device__ __forceinline__ bool dev_in_box(const double (*box)[2], int ndim, const double *p) {
+  bool in = true;
+  for (int d = 0; d < ndim; d++) in = in && (p[d] > box[d][0]) && (p[d] < box[d][1]);
+  return in;
+}
+
+template <typename XT>
+__device__ __forceinline__ double dev_ld(const XT *X, int64_t i) {
+  return (double)X[i];
+}
+
+__device__ __forceinline__ void dev_set_error(int *err, int code, int a, int b) {
+  if (atomicCAS(&err[0], 0, code) == 0) {
+    err[1] = a;
+    err[2] = b;
+  }
+}
+#endif

@@ -1,0 +1,396 @@
+// ctx.hip -- lifecycle, device memory, model state (mapper, bounds, remap, centroids).
+#include "common.h"
+
+int hamsm_fail(hamsm_ctx *c, int code, const char *fmt, ...) {
+  if (c) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(c->err, sizeof c->err, fmt, ap);
+    va_end(ap);
+  }
+  return code;
+}
+
+extern "C" int hamsm_abi_version(void) { return HAMSM_ABI_VERSION; }
+extern "C" const char *hamsm_backend_name(void) { return "hip-gfx950"; }
+
+extern "C" int hamsm_create(int device, hamsm_ctx **out) {
+  if (!out) return HAMSM_EINVAL;
+  hamsm_ctx *c = new hamsm_ctx();
+  c->err[0] = 0;
+  c->device = device;
+  memset(&c->mapper, 0, sizeof c->mapper);
+  if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess ||
+      hipMalloc((void **)&c->d_err, 4 * sizeof(int)) != hipSuccess ||
+      hipHostMalloc((void **)&c->h_err, 4 * sizeof(int)) != hipSuccess) {
+    // no GPU, no product: the caller gets an error, never a CPU path
+    delete c;
+    return HAMSM_EDEVICE;
+  }
+  hipMemsetAsync(c->d_err, 0, 4 * sizeof(int), c->stream);
+  hipStreamSynchronize(c->stream);
+  *out = c;
+  return HAMSM_OK;
+}
+
+static void free_strata(hamsm_ctx *c) {
+  for (auto &t : c->st) {
+    hipFree(t.C);
+    hipFree(t.csq);
+    hipFree(t.counts);
+    hipFree(t.Bpack);
+  }
+  c->st.clear();
+  hipFree(c->d_table);
+  c->d_table = nullptr;
+  hipFree(c->d_remap);
+  c->d_remap = nullptr;
+}
+
+extern "C" int hamsm_comm_destroy(hamsm_ctx *c);
+
+extern "C" void hamsm_destroy(hamsm_ctx *c) {
+  if (!c) return;
+  hipSetDevice(c->device);
+  hipStreamSynchronize(c->stream);
+  hamsm_comm_destroy(c);
+  free_strata(c);
+  hipFree(c->d_bounds);
+  hipFree(c->d_err);
+  hipHostFree(c->h_err);
+  hipFree(c->scratch);
+  hipHostFree(c->h_pinned);
+  for (auto &p : c->ev_pending) {
+    hipEventDestroy(p.e0);
+    hipEventDestroy(p.e1);
+  }
+  for (auto e : c->ev_free) hipEventDestroy(e);
+  hipStreamDestroy(c->stream);
+  delete c;
+}
+
+extern "C" const char *hamsm_last_error(hamsm_ctx *c) { return c ? c->err : "null ctx"; }
+
+// ---- memory -------------------------------------------------------------------------------------
+extern "C" int hamsm_malloc(hamsm_ctx *c, size_t bytes, void **out) {
+  HIPCHK(c, hipSetDevice(c->device));
+  hipError_t e = hipMalloc(out, bytes ? bytes : 1);
+  if (e != hipSuccess) return hamsm_fail(c, HAMSM_ENOMEM, "hipMalloc(%zu): %s", bytes, hipGetErrorString(e));
+  return HAMSM_OK;
+}
+extern "C" int hamsm_free(hamsm_ctx *c, void *p) {
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  HIPCHK(c, hipFree(p));
+  return HAMSM_OK;
+}
+extern "C" int hamsm_memcpy_h2d(hamsm_ctx *c, void *d, const void *h, size_t n) {
+  HIPCHK(c, hipMemcpyAsync(d, h, n, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));  // the host buffer is the caller's: it may be reused on return
+  return HAMSM_OK;
+}
+extern "C" int hamsm_memcpy_d2h(hamsm_ctx *c, void *h, const void *d, size_t n) {
+  HIPCHK(c, hipMemcpyAsync(h, d, n, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return HAMSM_OK;
+}
+extern "C" int hamsm_memset(hamsm_ctx *c, void *d, int b, size_t n) {
+  HIPCHK(c, hipMemsetAsync(d, b, n, c->stream));
+  return HAMSM_OK;
+}
+extern "C" int hamsm_sync(hamsm_ctx *c) {
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return hamsm_check_device_error(c, "sync");
+}
+
+int hamsm_ensure_scratch(hamsm_ctx *c, size_t bytes) {
+  if (bytes <= c->scratch_bytes) return HAMSM_OK;
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  hipFree(c->scratch);
+  c->scratch = nullptr;
+  c->scratch_bytes = 0;
+  size_t want = bytes + bytes / 4 + 4096;
+  hipError_t e = hipMalloc(&c->scratch, want);
+  if (e != hipSuccess) return hamsm_fail(c, HAMSM_ENOMEM, "scratch hipMalloc(%zu): %s", want, hipGetErrorString(e));
+  c->scratch_bytes = want;
+  return HAMSM_OK;
+}
+
+int hamsm_ensure_pinned(hamsm_ctx *c, size_t bytes) {
+  if (bytes <= c->h_pinned_bytes) return HAMSM_OK;
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  hipHostFree(c->h_pinned);
+  c->h_pinned = nullptr;
+  c->h_pinned_bytes = 0;
+  size_t want = bytes * 2 + 4096;
+  HIPCHK(c, hipHostMalloc(&c->h_pinned, want));
+  c->h_pinned_bytes = want;
+  return HAMSM_OK;
+}
+
+int hamsm_check_device_error(hamsm_ctx *c, const char *what) {
+  HIPCHK(c, hipMemcpyAsync(c->h_err, c->d_err, 4 * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  int code = c->h_err[0];
+  if (code == 0) return HAMSM_OK;
+  int a = c->h_err[1], b = c->h_err[2];
+  hipMemsetAsync(c->d_err, 0, 4 * sizeof(int), c->stream);
+  switch (code) {
+    case HAMSM_EUNFIT: return hamsm_fail(c, code, "%s: Not initialized in seg %d, bin %d", what, a, b);
+    case HAMSM_ERANGE: return hamsm_fail(c, code, "%s: index out of range at element %d (value %d)", what, a, b);
+    default: return hamsm_fail(c, code, "%s: device error %d (%d, %d)", what, code, a, b);
+  }
+}
+
+// Timers: event pairs are recorded on the stream and resolved lazily, so timing never adds a host
+// sync to the launch path (only hamsm_timers / hamsm_last_kernel_ms block).
+static void timers_resolve(hamsm_ctx *c, bool block) {
+  size_t done = 0;
+  for (; done < c->ev_pending.size(); done++) {
+    auto &p = c->ev_pending[done];
+    if (block) hipEventSynchronize(p.e1);
+    else if (hipEventQuery(p.e1) != hipSuccess) break;
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, p.e0, p.e1) == hipSuccess) {
+      c->timers[p.stage] += ms * 1e-3;
+      c->last_ms[p.stage] = ms;
+    }
+    c->ev_free.push_back(p.e0);
+    c->ev_free.push_back(p.e1);
+  }
+  c->ev_pending.erase(c->ev_pending.begin(), c->ev_pending.begin() + done);
+}
+
+static hipEvent_t ev_get(hamsm_ctx *c) {
+  if (!c->ev_free.empty()) {
+    hipEvent_t e = c->ev_free.back();
+    c->ev_free.pop_back();
+    return e;
+  }
+  hipEvent_t e = nullptr;
+  hipEventCreate(&e);
+  return e;
+}
+
+void hamsm_timer_begin(hamsm_ctx *c) {
+  c->ev_cur0 = ev_get(c);
+  hipEventRecord(c->ev_cur0, c->stream);
+}
+void hamsm_timer_end(hamsm_ctx *c, int stage) {
+  hipEvent_t e1 = ev_get(c);
+  hipEventRecord(e1, c->stream);
+  c->ev_pending.push_back({c->ev_cur0, e1, stage});
+  if (c->ev_pending.size() > 512) timers_resolve(c, false);
+  if (c->ev_pending.size() > 8192) timers_resolve(c, true);
+}
+
+extern "C" int hamsm_timers(hamsm_ctx *c, double *out, int reset) {
+  timers_resolve(c, true);
+  for (int i = 0; i < ST_N; i++) out[i] = c->timers[i];
+  if (reset)
+    for (int i = 0; i < ST_N; i++) c->timers[i] = 0;
+  return HAMSM_OK;
+}
+extern "C" int hamsm_last_kernel_ms(hamsm_ctx *c, int stage, double *ms) {
+  if (stage < 0 || stage >= ST_N) return hamsm_fail(c, HAMSM_EINVAL, "bad stage");
+  timers_resolve(c, true);
+  *ms = c->last_ms[stage];
+  return HAMSM_OK;
+}
+
+// ---- model state --------------------------------------------------------------------------------
+extern "C" int hamsm_set_geometry(hamsm_ctx *c, int D, int ndim, int S) {
+  if (D < 1 || ndim < 1 || ndim > HAMSM_MAX_NDIM || S < 1 || S > HAMSM_MAX_STRATA)
+    return hamsm_fail(c, HAMSM_EINVAL, "bad geometry D=%d ndim=%d S=%d", D, ndim, S);
+  if (D > 128) return hamsm_fail(c, HAMSM_ENOTSUP, "D=%d > 128 features is not supported yet", D);
+  HIPCHK(c, hipSetDevice(c->device));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  free_strata(c);
+  c->D = D;
+  // k-steps of 4 features; rounded up to a value the kernels are instantiated for (zero padded)
+  {
+    static const int ks_list[] = {1, 2, 3, 4, 6, 8, 12, 16, 24, 32};
+    int need = (D + 3) / 4;
+    c->KS = 32;
+    for (int v : ks_list)
+      if (v >= need) {
+        c->KS = v;
+        break;
+      }
+  }
+  c->ndim = ndim;
+  c->S = S;
+  c->st.resize(S);
+  HIPCHK(c, hipMalloc((void **)&c->d_remap, sizeof(int32_t) * S));
+  std::vector<int32_t> id(S);
+  for (int s = 0; s < S; s++) id[s] = s;  // stratified_clustering.py:85
+  HIPCHK(c, hipMemcpy(c->d_remap, id.data(), sizeof(int32_t) * S, hipMemcpyHostToDevice));
+  HIPCHK(c, hipMalloc((void **)&c->d_table, sizeof(StratumDev) * S));
+  c->mapper.ndim = ndim;
+  c->mapper.remap = c->d_remap;
+  c->table_dirty = true;
+  c->have_mapper = false;
+  return HAMSM_OK;
+}
+
+extern "C" int hamsm_set_mapper_rectilinear(hamsm_ctx *c, const int32_t *nb, const float *b) {
+  if (c->st.empty()) return hamsm_fail(c, HAMSM_EINVAL, "set_geometry first");
+  long nbins = 1;
+  int tot = 0;
+  for (int d = 0; d < c->ndim; d++) {
+    if (nb[d] < 2) return hamsm_fail(c, HAMSM_EINVAL, "need >=2 boundaries per dim");
+    c->mapper.nb[d] = nb[d];
+    c->mapper.boff[d] = tot;
+    tot += nb[d];
+    nbins *= nb[d] - 1;
+  }
+  if (nbins != c->S) return hamsm_fail(c, HAMSM_EINVAL, "mapper has %ld bins, geometry says %d", nbins, c->S);
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  hipFree(c->d_bounds);
+  HIPCHK(c, hipMalloc((void **)&c->d_bounds, sizeof(float) * tot));
+  HIPCHK(c, hipMemcpy(c->d_bounds, b, sizeof(float) * tot, hipMemcpyHostToDevice));
+  c->mapper.bounds = c->d_bounds;
+  c->have_mapper = true;
+  return HAMSM_OK;
+}
+
+extern "C" int hamsm_set_remap(hamsm_ctx *c, const int32_t *r) {
+  if (c->st.empty()) return hamsm_fail(c, HAMSM_EINVAL, "set_geometry first");
+  for (int s = 0; s < c->S; s++)
+    if (r[s] < 0 || r[s] >= c->S) return hamsm_fail(c, HAMSM_EINVAL, "remap[%d]=%d out of range", s, r[s]);
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  HIPCHK(c, hipMemcpy(c->d_remap, r, sizeof(int32_t) * c->S, hipMemcpyHostToDevice));
+  return HAMSM_OK;
+}
+
+extern "C" int hamsm_set_bounds(hamsm_ctx *c, const double *basis, const double *target) {
+  if (c->st.empty()) return hamsm_fail(c, HAMSM_EINVAL, "set_geometry first");
+  for (int d = 0; d < c->ndim; d++) {
+    c->mapper.basis[d][0] = basis[2 * d];
+    c->mapper.basis[d][1] = basis[2 * d + 1];
+    c->mapper.target[d][0] = target[2 * d];
+    c->mapper.target[d][1] = target[2 * d + 1];
+  }
+  c->have_bounds = true;
+  return HAMSM_OK;
+}
+
+static inline int kpad(int K) { return (K + 15) & ~15; }
+
+int hamsm_stratum_reserve(hamsm_ctx *c, int s, int K) {
+  Stratum &t = c->st[s];
+  if (K <= t.Kcap) return HAMSM_OK;
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  hipFree(t.C);
+  hipFree(t.csq);
+  hipFree(t.counts);
+  hipFree(t.Bpack);
+  int cap = kpad(K);
+  HIPCHK(c, hipMalloc((void **)&t.C, sizeof(double) * (size_t)cap * c->D));
+  HIPCHK(c, hipMalloc((void **)&t.csq, sizeof(double) * cap));
+  HIPCHK(c, hipMalloc((void **)&t.counts, sizeof(double) * cap));
+  HIPCHK(c, hipMalloc((void **)&t.Bpack, sizeof(double) * (size_t)cap * c->KS * 4));
+  t.Kcap = cap;
+  return HAMSM_OK;
+}
+
+// csq (fma chain unless given) + MFMA B-fragment packing of rows [j0, j1) ... and padding up to Kpad
+__global__ void k_pack(const double *__restrict__ C, const double *__restrict__ csq_in, int K, int Kpad, int D, int KS,
+                       double *__restrict__ csq, double *__restrict__ Bpack) {
+  int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= Kpad) return;
+  const double inf = __builtin_huge_val();
+  if (j < K) {
+    if (csq_in) csq[j] = csq_in[j];
+    else {
+      double a = 0.0;
+      for (int k = 0; k < D; k++) a = __builtin_fma(C[(size_t)j * D + k], C[(size_t)j * D + k], a);
+      csq[j] = a;
+    }
+  } else csq[j] = inf;
+  int jt = j >> 4, col = j & 15;
+  for (int k = 0; k < KS * 4; k++) {
+    double v = (j < K && k < D) ? C[(size_t)j * D + k] : 0.0;
+    Bpack[((size_t)jt * KS + (k >> 2)) * 64 + (k & 3) * 16 + col] = v;
+  }
+}
+
+int hamsm_pack_stratum(hamsm_ctx *c, int s, const double *d_csq_in) {
+  Stratum &t = c->st[s];
+  if (t.K == 0) return HAMSM_OK;
+  int Kp = kpad(t.K);
+  hipLaunchKernelGGL(k_pack, dim3((Kp + 63) / 64), dim3(64), 0, c->stream, t.C, d_csq_in, t.K, Kp, c->D, c->KS, t.csq,
+                     t.Bpack);
+  HIPCHK(c, hipGetLastError());
+  return HAMSM_OK;
+}
+
+extern "C" int hamsm_set_centroids(hamsm_ctx *c, int s, int K, const double *C, const double *csq, const double *counts) {
+  if (c->st.empty() || s < 0 || s >= c->S || K < 0) return hamsm_fail(c, HAMSM_EINVAL, "bad stratum/K");
+  HIPCHK(c, hipSetDevice(c->device));
+  Stratum &t = c->st[s];
+  c->table_dirty = true;
+  if (K == 0) {
+    t.K = 0;
+    return HAMSM_OK;
+  }
+  int rc = hamsm_stratum_reserve(c, s, K);
+  if (rc) return rc;
+  t.K = K;
+  HIPCHK(c, hipMemcpyAsync(t.C, C, sizeof(double) * (size_t)K * c->D, hipMemcpyHostToDevice, c->stream));
+  if (counts) HIPCHK(c, hipMemcpyAsync(t.counts, counts, sizeof(double) * K, hipMemcpyHostToDevice, c->stream));
+  else HIPCHK(c, hipMemsetAsync(t.counts, 0, sizeof(double) * K, c->stream));
+  double *d_csq_in = nullptr;
+  if (csq) {
+    rc = hamsm_ensure_scratch(c, sizeof(double) * K);
+    if (rc) return rc;
+    d_csq_in = (double *)c->scratch;
+    HIPCHK(c, hipMemcpyAsync(d_csq_in, csq, sizeof(double) * K, hipMemcpyHostToDevice, c->stream));
+  }
+  rc = hamsm_pack_stratum(c, s, d_csq_in);
+  if (rc) return rc;
+  HIPCHK(c, hipStreamSynchronize(c->stream));  // host buffers are the caller's
+  return HAMSM_OK;
+}
+
+extern "C" int hamsm_get_centroids(hamsm_ctx *c, int s, double *C, double *counts, double *csq) {
+  if (c->st.empty() || s < 0 || s >= c->S) return hamsm_fail(c, HAMSM_EINVAL, "bad stratum");
+  Stratum &t = c->st[s];
+  if (t.K == 0) return HAMSM_OK;
+  if (C) HIPCHK(c, hipMemcpyAsync(C, t.C, sizeof(double) * (size_t)t.K * c->D, hipMemcpyDeviceToHost, c->stream));
+  if (counts) HIPCHK(c, hipMemcpyAsync(counts, t.counts, sizeof(double) * t.K, hipMemcpyDeviceToHost, c->stream));
+  if (csq) HIPCHK(c, hipMemcpyAsync(csq, t.csq, sizeof(double) * t.K, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return HAMSM_OK;
+}
+
+extern "C" int hamsm_num_centroids(hamsm_ctx *c, int s) {
+  if (c->st.empty() || s < 0 || s >= c->S) return hamsm_fail(c, HAMSM_EINVAL, "bad stratum");
+  return c->st[s].K;
+}
+
+extern "C" int hamsm_get_counts(hamsm_ctx *c, int s, double *counts) {
+  if (c->st.empty() || s < 0 || s >= c->S) return hamsm_fail(c, HAMSM_EINVAL, "bad stratum");
+  Stratum &t = c->st[s];
+  if (t.K == 0) return HAMSM_OK;
+  HIPCHK(c, hipMemcpyAsync(counts, t.counts, sizeof(double) * t.K, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return HAMSM_OK;
+}
+
+int hamsm_refresh_table(hamsm_ctx *c) {
+  if (!c->table_dirty) return HAMSM_OK;
+  std::vector<StratumDev> tab(c->S);
+  int off = 0;
+  for (int s = 0; s < c->S; s++) {
+    tab[s].Bpack = c->st[s].Bpack;
+    tab[s].csq = c->st[s].csq;
+    tab[s].K = c->st[s].K;
+    tab[s].off = off;  // stratified_clustering.py:178-185
+    off += c->st[s].K;
+  }
+  c->Kfit = off;  // :143-150
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  HIPCHK(c, hipMemcpy(c->d_table, tab.data(), sizeof(StratumDev) * c->S, hipMemcpyHostToDevice));
+  c->table_dirty = false;
+  return HAMSM_OK;
+}

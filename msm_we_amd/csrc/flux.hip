@@ -1,0 +1,253 @@
+// flux.hip -- a10 flux-matrix accumulation (FluxMatrixMixin.build_flux_matrix, reference
+// msm_we/_hamsm/_fluxmatrix.py:97-164, summed over iterations :325-327), a11 cluster pcoord
+// statistics (_clustering.py:1559-1591) and the a13 feed: row-normalised T as CSR (_analysis.py:44-79).
+//
+// These are HBM/L2-atomic bound scatter kernels: 32 B read per segment, one f64
+// atomic into a (K+2)^2 matrix that lives in L2 / Infinity Cache (8 MB at K=1000).
+#include "common.h"
+
+struct FluxArgs {
+  const int32_t *pa, *ch;
+  const double *p0, *p1, *w;
+  int64_t i0, n;
+  int K;
+  double *F;
+  int *err;
+};
+
+__global__ void k_flux_atomic(MapperDev m, FluxArgs g) {
+  int64_t i = g.i0 + (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= g.i0 + g.n) return;
+  double q0[HAMSM_MAX_NDIM], q1[HAMSM_MAX_NDIM];
+  for (int d = 0; d < m.ndim; d++) {
+    q0[d] = g.p0[i * m.ndim + d];
+    q1[d] = g.p1[i * m.ndim + d];
+  }
+  int a = g.pa[i], b = g.ch[i];
+  const int K = g.K;
+  if (dev_in_box(m.target, m.ndim, q1)) b = K + 1;  // _fluxmatrix.py:135
+  if (dev_in_box(m.basis, m.ndim, q0)) a = K;       // :136
+  if (dev_in_box(m.basis, m.ndim, q1)) b = K;       // :137
+  if (a < 0 || b < 0 || a >= K + 2 || b >= K + 2) {
+    dev_set_error(g.err, HAMSM_ERANGE, (int)i, a < 0 || a >= K + 2 ? a : b);
+    return;
+  }
+  // global_atomic_add_f64 (built with -munsafe-fp-atomics: no CAS loop)
+  unsafeAtomicAdd(&g.F[(size_t)a * (K + 2) + b], g.w[i]);
+}
+
+int hamsm_flux_sorted(hamsm_ctx *c, const MapperDev &m, const FluxArgs &g, const int64_t *d_offs, int64_t n_iters);
+
+extern "C" int hamsm_flux_accumulate(hamsm_ctx *c, const int32_t *pa, const int32_t *ch, const double *p0, const double *p1,
+                                     const double *w, int64_t n, int K, double *F, int mode, const int64_t *d_offs,
+                                     int64_t n_iters) {
+  if (!c->have_bounds) return hamsm_fail(c, HAMSM_EINVAL, "bounds not set");
+  if (n <= 0) return HAMSM_OK;
+  int64_t i0 = 0;
+  if (d_offs) {
+    HIPCHK(c, hipMemcpyAsync(&i0, d_offs, sizeof(int64_t), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+  }
+  FluxArgs g{pa, ch, p0, p1, w, i0, n, K, F, c->d_err};
+  hamsm_timer_begin(c);
+  int rc = HAMSM_OK;
+  if (mode == 0) {
+    hipLaunchKernelGGL(k_flux_atomic, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, c->mapper, g);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) rc = hamsm_fail(c, HAMSM_EDEVICE, "k_flux_atomic: %s", hipGetErrorString(e));
+  } else {
+    rc = hamsm_flux_sorted(c, c->mapper, g, d_offs, n_iters);
+  }
+  hamsm_timer_end(c, ST_FLUX);
+  if (rc) return rc;
+  return hamsm_check_device_error(c, "flux_accumulate");
+}
+
+__global__ void k_scale(double *F, int64_t n, double div) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) F[i] = F[i] / div;  // _fluxmatrix.py:342, true division
+}
+
+extern "C" int hamsm_scale(hamsm_ctx *c, double *F, int64_t count, double div) {
+  if (count <= 0) return HAMSM_OK;
+  hipLaunchKernelGGL(k_scale, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, c->stream, F, count, div);
+  HIPCHK(c, hipGetLastError());
+  return HAMSM_OK;
+}
+
+// ---- a11 ----------------------------------------------------------------------------------------
+// order-preserving map double <-> uint64 so that min/max are native integer atomics
+__device__ __forceinline__ unsigned long long dkey(double v) {
+  unsigned long long u = (unsigned long long)__double_as_longlong(v);
+  return (u & 0x8000000000000000ull) ? ~u : (u | 0x8000000000000000ull);
+}
+__device__ __forceinline__ double dunkey(unsigned long long k) {
+  unsigned long long u = (k & 0x8000000000000000ull) ? (k & 0x7fffffffffffffffull) : ~k;
+  return __longlong_as_double((long long)u);
+}
+
+__global__ void k_stats_init(unsigned long long *kmin, unsigned long long *kmax, int ns) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < ns) {
+    kmin[i] = ~0ull;
+    kmax[i] = 0ull;
+  }
+}
+
+__global__ void k_stats(const int32_t *__restrict__ lab, const double *__restrict__ p, int ndim, int64_t n, int ns,
+                        double *sum, unsigned long long *kmin, unsigned long long *kmax, unsigned long long *cnt, int *err) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  int l = lab[i];
+  if (l < 0 || l >= ns) {
+    dev_set_error(err, HAMSM_ERANGE, (int)i, l);
+    return;
+  }
+  double v = p[i * ndim];
+  unsafeAtomicAdd(&sum[l], v);
+  if (v == v) {  // NaN never wins a min/max (the oracle's < and > are false for NaN)
+    atomicMin(&kmin[l], dkey(v));
+    atomicMax(&kmax[l], dkey(v));
+  }
+  atomicAdd(&cnt[l], 1ull);
+}
+
+__global__ void k_stats_fin(const unsigned long long *kmin, const unsigned long long *kmax, int ns, double *mn, double *mx) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= ns) return;
+  if (kmin[i] != ~0ull) {
+    double a = dunkey(kmin[i]);
+    if (a < mn[i]) mn[i] = a;
+  }
+  if (kmax[i] != 0ull) {
+    double b = dunkey(kmax[i]);
+    if (b > mx[i]) mx[i] = b;
+  }
+}
+
+extern "C" int hamsm_cluster_stats(hamsm_ctx *c, const int32_t *lab, const double *p, int64_t n, int ns, double *sum,
+                                   double *mn, double *mx, int64_t *cnt) {
+  if (n <= 0) return HAMSM_OK;
+  int rc = hamsm_ensure_scratch(c, sizeof(unsigned long long) * 2 * (size_t)ns);
+  if (rc) return rc;
+  unsigned long long *kmin = (unsigned long long *)c->scratch, *kmax = kmin + ns;
+  hamsm_timer_begin(c);
+  hipLaunchKernelGGL(k_stats_init, dim3((ns + 255) / 256), dim3(256), 0, c->stream, kmin, kmax, ns);
+  hipLaunchKernelGGL(k_stats, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, lab, p, c->ndim, n, ns, sum, kmin,
+                     kmax, (unsigned long long *)cnt, c->d_err);
+  hipLaunchKernelGGL(k_stats_fin, dim3((ns + 255) / 256), dim3(256), 0, c->stream, kmin, kmax, ns, mn, mx);
+  hamsm_timer_end(c, ST_STATS);
+  HIPCHK(c, hipGetLastError());
+  return hamsm_check_device_error(c, "cluster_stats");
+}
+
+// ---- a13 feed -----------------------------------------------------------------------------------
+// numpy pairwise summation (what np.sum(fluxmatrix, 1) does per contiguous row), reproduced so that
+// T is bit-equal to AnalysisMixin.get_Tmatrix.  One thread per row; depth <= log2(n/128)+1.
+__device__ double np_pairwise(const double *a, int64_t n) {
+  if (n < 8) {
+    double r = -0.0;
+    for (int64_t i = 0; i < n; i++) r = r + a[i];
+    return r;
+  } else if (n <= 128) {
+    double r[8];
+    for (int k = 0; k < 8; k++) r[k] = a[k];
+    int64_t i;
+    for (i = 8; i < n - (n % 8); i += 8)
+      for (int k = 0; k < 8; k++) r[k] = r[k] + a[i + k];
+    double res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+    for (; i < n; i++) res = res + a[i];
+    return res;
+  } else {
+    int64_t n2 = n / 2;
+    n2 -= n2 % 8;
+    return np_pairwise(a, n2) + np_pairwise(a + n2, n - n2);
+  }
+}
+
+__device__ __forceinline__ double t_entry(const double *row, double out, int i, int j, bool is_t, const int32_t *basis,
+                                          int nb) {
+  if (is_t) {  // _analysis.py:74-77
+    double v = 0.0;
+    for (int k = 0; k < nb; k++)
+      if (basis[k] == j) v = 1.0 / (double)nb;
+    return v;
+  }
+  double v = row[j];
+  if (out > 0) v = v / out;           // :53-56
+  if (out == 0.0 && j == i) v = 1.0;  // :60-61
+  return v;
+}
+
+__global__ void k_trow(const double *F, int ns, const int32_t *basis, int nb, const int32_t *target, int nt, double *rowsum,
+                       int64_t *nnz) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= ns) return;
+  const double *row = F + (size_t)i * ns;
+  double out = np_pairwise(row, ns);
+  rowsum[i] = out;
+  bool is_t = false;
+  for (int k = 0; k < nt; k++) is_t |= (target[k] == i);
+  int64_t c = 0;
+  for (int j = 0; j < ns; j++) c += t_entry(row, out, i, j, is_t, basis, nb) != 0.0;
+  nnz[i] = c;
+}
+
+__global__ void k_tfill(const double *F, int ns, const int32_t *basis, int nb, const int32_t *target, int nt,
+                        const double *rowsum, const int64_t *indptr, int32_t *indices, double *data) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= ns) return;
+  const double *row = F + (size_t)i * ns;
+  double out = rowsum[i];
+  bool is_t = false;
+  for (int k = 0; k < nt; k++) is_t |= (target[k] == i);
+  int64_t o = indptr[i];
+  for (int j = 0; j < ns; j++) {
+    double v = t_entry(row, out, i, j, is_t, basis, nb);
+    if (v != 0.0) {
+      indices[o] = j;
+      data[o] = v;
+      o++;
+    }
+  }
+}
+
+extern "C" int hamsm_tmatrix_csr(hamsm_ctx *c, const double *F, int ns, const int32_t *basis, int nb, const int32_t *target,
+                                 int nt, int64_t *indptr, int32_t *indices, double *data, int64_t cap, int64_t *nnz_out) {
+  if (ns <= 0) return hamsm_fail(c, HAMSM_EINVAL, "nstates");
+  size_t o_rs = 0, o_nz = o_rs + sizeof(double) * ns, o_ip = o_nz + sizeof(int64_t) * ns,
+         o_bt = o_ip + sizeof(int64_t) * (ns + 1), o_end = o_bt + sizeof(int32_t) * (nb + nt + 2);
+  int rc = hamsm_ensure_scratch(c, o_end);
+  if (rc) return rc;
+  char *base = (char *)c->scratch;
+  double *rowsum = (double *)(base + o_rs);
+  int64_t *d_nnz = (int64_t *)(base + o_nz), *d_ip = (int64_t *)(base + o_ip);
+  int32_t *d_b = (int32_t *)(base + o_bt), *d_t = d_b + nb;
+  HIPCHK(c, hipMemcpyAsync(d_b, basis, sizeof(int32_t) * nb, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(d_t, target, sizeof(int32_t) * nt, hipMemcpyHostToDevice, c->stream));
+  hipLaunchKernelGGL(k_trow, dim3((ns + 63) / 64), dim3(64), 0, c->stream, F, ns, d_b, nb, d_t, nt, rowsum, d_nnz);
+  HIPCHK(c, hipGetLastError());
+  std::vector<int64_t> cnt(ns);
+  HIPCHK(c, hipMemcpyAsync(cnt.data(), d_nnz, sizeof(int64_t) * ns, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  indptr[0] = 0;
+  for (int i = 0; i < ns; i++) indptr[i + 1] = indptr[i] + cnt[i];
+  int64_t nnz = indptr[ns];
+  *nnz_out = nnz;
+  if (nnz > cap) return hamsm_fail(c, HAMSM_ENOMEM, "csr capacity %lld too small for %lld", (long long)cap, (long long)nnz);
+  HIPCHK(c, hipMemcpyAsync(d_ip, indptr, sizeof(int64_t) * (ns + 1), hipMemcpyHostToDevice, c->stream));
+  int32_t *d_idx = nullptr;
+  double *d_dat = nullptr;
+  HIPCHK(c, hipMalloc((void **)&d_idx, sizeof(int32_t) * (size_t)(nnz ? nnz : 1)));
+  HIPCHK(c, hipMalloc((void **)&d_dat, sizeof(double) * (size_t)(nnz ? nnz : 1)));
+  hipLaunchKernelGGL(k_tfill, dim3((ns + 63) / 64), dim3(64), 0, c->stream, F, ns, d_b, nb, d_t, nt, rowsum, d_ip, d_idx,
+                     d_dat);
+  hipError_t e = hipGetLastError();
+  if (e == hipSuccess) e = hipMemcpyAsync(indices, d_idx, sizeof(int32_t) * nnz, hipMemcpyDeviceToHost, c->stream);
+  if (e == hipSuccess) e = hipMemcpyAsync(data, d_dat, sizeof(double) * nnz, hipMemcpyDeviceToHost, c->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+  hipFree(d_idx);
+  hipFree(d_dat);
+  if (e != hipSuccess) return hamsm_fail(c, HAMSM_EDEVICE, "tmatrix_csr: %s", hipGetErrorString(e));
+  return HAMSM_OK;
+}

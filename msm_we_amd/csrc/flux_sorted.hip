@@ -1,0 +1,122 @@
+// flux_sorted.hip -- deterministic flux accumulation (mode 1 of hamsm_flux_accumulate).
+//
+// Bit-identical to the reference's arithmetic: per iteration the COO->dense conversion adds duplicate
+// (start, end) pairs in segment order, and the per-iteration matrices are added in ascending
+// iteration order (_fluxmatrix.py:143-146, 325-327; oracle hamsm_flux_accumulate).  Realised as a
+// stable radix sort of the segments by (cell, iteration) (rocPRIM, the one library primitive used),
+// then two hand-written passes: per (cell, iteration) run an in-order partial sum, per cell an
+// in-order sum of those partials on top of the value already in F.
+#include <cstring>
+#include <hip/hip_runtime.h>
+#include <rocprim/rocprim.hpp>
+
+#include "common.h"
+
+struct FluxArgs {
+  const int32_t *pa, *ch;
+  const double *p0, *p1, *w;
+  int64_t i0, n;
+  int K;
+  double *F;
+  int *err;
+};
+
+__global__ void k_flux_keys(MapperDev m, FluxArgs g, const int64_t *__restrict__ offs, int64_t n_iters,
+                            unsigned long long *keys, double *vals) {
+  int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= g.n) return;
+  int64_t i = g.i0 + j;
+  double q0[HAMSM_MAX_NDIM], q1[HAMSM_MAX_NDIM];
+  for (int d = 0; d < m.ndim; d++) {
+    q0[d] = g.p0[i * m.ndim + d];
+    q1[d] = g.p1[i * m.ndim + d];
+  }
+  int a = g.pa[i], b = g.ch[i];
+  const int K = g.K;
+  if (dev_in_box(m.target, m.ndim, q1)) b = K + 1;
+  if (dev_in_box(m.basis, m.ndim, q0)) a = K;
+  if (dev_in_box(m.basis, m.ndim, q1)) b = K;
+  unsigned long long cell;
+  if (a < 0 || b < 0 || a >= K + 2 || b >= K + 2) {
+    dev_set_error(g.err, HAMSM_ERANGE, (int)i, a < 0 || a >= K + 2 ? a : b);
+    cell = 0;
+    vals[j] = 0.0;
+  } else {
+    cell = (unsigned long long)a * (K + 2) + b;
+    vals[j] = g.w[i];
+  }
+  // iteration of segment i: last t with offs[t] <= i
+  int64_t lo = 0, hi = n_iters;
+  if (offs) {
+    while (hi - lo > 1) {
+      int64_t mid = (lo + hi) >> 1;
+      if (offs[mid] <= i) lo = mid;
+      else hi = mid;
+    }
+  }
+  keys[j] = cell * (unsigned long long)n_iters + (unsigned long long)lo;
+}
+
+__global__ void k_flux_parts(const unsigned long long *__restrict__ ks, const double *__restrict__ ws, int64_t n,
+                             double *part, int32_t *len) {
+  int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= n) return;
+  const unsigned long long k = ks[j];
+  if (j > 0 && ks[j - 1] == k) return;  // not the first element of its (cell, iteration) run
+  double p = 0.0;
+  int64_t e = j;
+  while (e < n && ks[e] == k) {
+    p = p + ws[e];  // segment order inside the iteration (stable sort)
+    e++;
+  }
+  part[j] = p;
+  len[j] = (int32_t)(e - j);
+}
+
+__global__ void k_flux_cells(const unsigned long long *__restrict__ ks, const double *__restrict__ part,
+                             const int32_t *__restrict__ len, int64_t n, unsigned long long n_iters, double *F) {
+  int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= n) return;
+  const unsigned long long cell = ks[j] / n_iters;
+  if (j > 0 && ks[j - 1] / n_iters == cell) return;  // not the first element of its cell run
+  double acc = F[cell];
+  int64_t e = j;
+  while (e < n && ks[e] / n_iters == cell) {
+    acc = acc + part[e];  // ascending iteration
+    e += len[e];
+  }
+  F[cell] = acc;
+}
+
+int hamsm_flux_sorted(hamsm_ctx *c, const MapperDev &m, const FluxArgs &g, const int64_t *d_offs, int64_t n_iters) {
+  const int64_t n = g.n;
+  if (!d_offs) n_iters = 1;
+  if (n > 0x7fffffffLL) return hamsm_fail(c, HAMSM_ENOTSUP, "deterministic flux: more than 2^31 segments per call");
+  unsigned long long maxkey = (unsigned long long)(g.K + 2) * (g.K + 2) * (unsigned long long)n_iters;
+  int bits = 1;
+  while (bits < 64 && (maxkey >> bits)) bits++;
+  size_t temp_bytes = 0;
+  unsigned long long *nullk = nullptr;
+  double *nullv = nullptr;
+  hipError_t e = rocprim::radix_sort_pairs(nullptr, temp_bytes, nullk, nullk, nullv, nullv, (size_t)n, 0, bits, c->stream);
+  if (e != hipSuccess) return hamsm_fail(c, HAMSM_EDEVICE, "radix_sort_pairs(size): %s", hipGetErrorString(e));
+  size_t a8 = ((size_t)n * 8 + 255) & ~(size_t)255, a4 = ((size_t)n * 4 + 255) & ~(size_t)255;
+  size_t need = 5 * a8 + a4 + temp_bytes + 256;
+  int rc = hamsm_ensure_scratch(c, need);
+  if (rc) return rc;
+  char *base = (char *)c->scratch;
+  unsigned long long *k_in = (unsigned long long *)base, *k_out = (unsigned long long *)(base + a8);
+  double *v_in = (double *)(base + 2 * a8), *v_out = (double *)(base + 3 * a8), *part = (double *)(base + 4 * a8);
+  int32_t *len = (int32_t *)(base + 5 * a8);
+  void *temp = base + 5 * a8 + a4;
+  unsigned grid = (unsigned)((n + 255) / 256);
+  hipLaunchKernelGGL(k_flux_keys, dim3(grid), dim3(256), 0, c->stream, m, g, d_offs, n_iters, k_in, v_in);
+  e = rocprim::radix_sort_pairs(temp, temp_bytes, k_in, k_out, v_in, v_out, (size_t)n, 0, bits, c->stream);
+  if (e != hipSuccess) return hamsm_fail(c, HAMSM_EDEVICE, "radix_sort_pairs: %s", hipGetErrorString(e));
+  hipLaunchKernelGGL(k_flux_parts, dim3(grid), dim3(256), 0, c->stream, k_out, v_out, n, part, len);
+  hipLaunchKernelGGL(k_flux_cells, dim3(grid), dim3(256), 0, c->stream, k_out, part, len, n, (unsigned long long)n_iters,
+                     g.F);
+  e = hipGetLastError();
+  if (e != hipSuccess) return hamsm_fail(c, HAMSM_EDEVICE, "flux_sorted: %s", hipGetErrorString(e));
+  return HAMSM_OK;
+}

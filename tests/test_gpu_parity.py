@@ -1,0 +1,323 @@
+"""GPU parity tests: the HIP library (product) against the CPU oracle, both through the C ABI,
+on identical seeded inputs.  Bars: labels / indices / counts bit-exact; centroids, csq, flux
+(deterministic mode), T bit-exact; atomic-mode flux and cluster sums within 1e-12 rel."""
+import ctypes
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN_CASES, build_model, load_golden
+
+pytestmark = pytest.mark.gpu
+
+
+def _setup(h, D, S, K_s, rng, ndim=1, fit=None, remap=None):
+    """geometry + unit strata + basis/target + random centroids (same on every backend)"""
+    h.set_geometry(D, ndim, S)
+    b = np.arange(S + 1, dtype=np.float32)
+    b[-1] = np.inf
+    h.set_mapper_rectilinear([b] + [np.array([-np.inf, np.inf], dtype=np.float32)] * (ndim - 1))
+    basis = [[-np.inf, 0.05]] + [[-np.inf, np.inf]] * (ndim - 1)
+    target = [[S - 0.05, np.inf]] + [[-np.inf, np.inf]] * (ndim - 1)
+    h.set_bounds(basis, target)
+    cents = []
+    for s in range(S):
+        if fit is not None and not fit[s]:
+            h.set_centroids(s, None)
+            cents.append(None)
+            continue
+        k = K_s if np.isscalar(K_s) else K_s[s]
+        Cm = rng.normal(size=(k, D)) * 3
+        h.set_centroids(s, Cm, csq=np.einsum("ij,ij->i", Cm, Cm))
+        cents.append(Cm)
+    if remap is not None:
+        h.set_remap(remap)
+    return cents
+
+
+def _frames(rng, n, D, S, dtype, ndim=1):
+    X = rng.normal(size=(n, D)).astype(dtype) * 3
+    p = rng.uniform(0, S, size=(n, ndim))
+    return X, p
+
+
+def test_mfma_f64_is_an_fma_chain(hip_h):
+    """The arithmetic contract rests on v_mfma_f64_16x16x4_f64 applying its k-products in order
+    with one rounding each (== fma chain).  Checked bit for bit on random and on cancelling data."""
+    fn = hip_h.lib.hamsm_selftest_mfma
+    fn.restype = ctypes.c_int
+    vp = ctypes.c_void_p
+    fn.argtypes = [vp, vp, vp, ctypes.c_int, vp, vp]
+    rng = np.random.default_rng(0)
+    for KS in (1, 2, 8, 16, 32):
+        for scale in (1.0, 1e8):
+            A = rng.normal(size=(16, KS * 4)) * scale
+            B = rng.normal(size=(KS * 4, 16)) / scale
+            A[:, ::3] *= -1e3  # cancellation makes any re-association visible
+            o1, o2 = np.empty((16, 16)), np.empty((16, 16))
+            bad = fn(hip_h.ctx, A.ctypes.data, B.ctypes.data, KS, o1.ctypes.data, o2.ctypes.data)
+            assert bad == 0, (KS, scale, np.abs(o1 - o2).max())
+
+
+@pytest.mark.parametrize("D,S,K_s,dtype", [(10, 1, 200, np.float32), (30, 4, 250, np.float32), (13, 12, 25, np.float64),
+                                          (64, 4, 77, np.float32), (3, 2, 5, np.float64), (128, 2, 40, np.float32),
+                                          (20, 3, 33, np.float32)])
+def test_assign_matches_oracle(hip_h, oracle_h, D, S, K_s, dtype):
+    n = 5003  # not a multiple of the chunk or tile size
+    outs = []
+    for h in (oracle_h, hip_h):
+        rng = np.random.default_rng(42)
+        _setup(h, D, S, K_s, rng)
+        X, p = _frames(rng, n, D, S, dtype)
+        lab, seen = h.predict_host(X, p, want_seen=True)
+        outs.append((lab, seen))
+    assert np.array_equal(outs[0][0], outs[1][0])
+    assert np.array_equal(outs[0][1], outs[1][1])
+    K = S * K_s
+    assert outs[1][0].max() == K + 1 and (outs[1][0] == K).any()  # basis and target frames present
+
+
+def test_assign_edge_cases(hip_h, oracle_h):
+    for h in (oracle_h, hip_h):
+        rng = np.random.default_rng(1)
+        cents = _setup(h, 10, 4, 16, rng, fit=[True, False, True, True], remap=[0, 0, 2, 3])
+        # empty input
+        assert len(h.predict_host(np.zeros((0, 10), np.float32), np.zeros((0, 1)))) == 0
+        # a single frame, and frames that ARE centroids (distance ties to themselves)
+        X = np.concatenate([cents[0], cents[2], cents[3]]).astype(np.float64)
+        p = np.concatenate([np.full(16, 0.5), np.full(16, 2.5), np.full(16, 3.5)])[:, None]
+        lab = h.predict_host(X, p)
+        assert np.array_equal(lab, np.arange(48))
+        assert h.predict_host(X[:1], p[:1])[0] == 0
+        # stratum 1 is remapped onto 0
+        assert h.predict_host(cents[0][3:4], np.array([[1.5]]))[0] == 3
+        # duplicate centroids: first index wins
+        Cm = np.repeat(rng.normal(size=(4, 10)), 2, axis=0)
+        h.set_centroids(0, Cm, csq=np.einsum("ij,ij->i", Cm, Cm))
+        assert np.array_equal(h.predict_host(Cm, np.full((8, 1), 0.5)), [0, 0, 2, 2, 4, 4, 6, 6])
+
+
+def test_assign_unfitted_stratum_raises(hip_h, oracle_h):
+    from msm_we_amd._abi import HamsmError
+
+    for h in (oracle_h, hip_h):
+        rng = np.random.default_rng(2)
+        _setup(h, 10, 2, 8, rng, fit=[True, False])
+        X, p = _frames(rng, 100, 10, 2, np.float32)
+        with pytest.raises(HamsmError) as e:
+            h.predict_host(X, p)
+        assert e.value.code == -4  # HAMSM_EUNFIT <-> AssertionError at stratified_clustering.py:187-189
+        # a pcoord outside the bin space (westpa raises) -> HAMSM_ERANGE
+        with pytest.raises(HamsmError) as e:
+            h.predict_host(X[:1], np.array([[-3.0]]))
+        assert e.value.code == -5
+
+
+def test_classify_matches_oracle(hip_h, oracle_h):
+    res = []
+    for h in (oracle_h, hip_h):
+        rng = np.random.default_rng(3)
+        _setup(h, 4, 5, 4, rng, ndim=2, remap=[0, 1, 1, 3, 4])
+        p = np.stack([rng.uniform(0, 5, 4000), rng.normal(size=4000)], axis=1)
+        p[::97, 0] = np.round(p[::97, 0])  # exactly on float32 boundaries
+        d_p = h.to_device(p)
+        d_b, d_f = h.alloc(4000, np.int32), h.alloc(4000, np.uint8)
+        for remap in (0, 1):
+            h.classify(d_p, 4000, remap, d_b, d_f)
+            res.append((d_b.to_host(), d_f.to_host()))
+    assert all(np.array_equal(res[i][0], res[i + 2][0]) and np.array_equal(res[i][1], res[i + 2][1]) for i in (0, 1))
+
+
+def _flux_inputs(rng, n, K, n_iters):
+    pa = rng.integers(0, K, n).astype(np.int32)
+    ch = rng.integers(0, K + 2, n).astype(np.int32)
+    # few distinct cells so that duplicates inside an iteration are common
+    pa[: n // 2] = rng.integers(0, 3, n // 2)
+    ch[: n // 2] = rng.integers(0, 3, n // 2)
+    p0 = rng.uniform(0, 4, (n, 1))
+    p1 = rng.uniform(0, 4, (n, 1))
+    w = rng.exponential(size=n) * 10.0 ** rng.integers(-12, 0, n)
+    offs = np.sort(np.concatenate([[0, n], rng.integers(0, n, n_iters - 1)])).astype(np.int64)
+    return pa, ch, p0, p1, w, offs
+
+
+@pytest.mark.parametrize("mode", [0, 1])
+def test_flux_matches_oracle(hip_h, oracle_h, mode):
+    K, n, n_iters = 37, 20000, 23
+    Fs = []
+    for h in (oracle_h, hip_h):
+        rng = np.random.default_rng(5)
+        _setup(h, 4, 4, 4, rng)
+        pa, ch, p0, p1, w, offs = _flux_inputs(rng, n, K, n_iters)
+        d = [h.to_device(a) for a in (pa, ch, p0, p1, w, offs)]
+        d_F = h.to_device(rng.uniform(size=(K + 2, K + 2)))  # accumulate on top of existing values
+        # all iterations in one call, then a sub-range (absolute offsets, unshifted bases)
+        h.flux_accumulate(d[0], d[1], d[2], d[3], d[4], n, K, d_F, mode, d[5], n_iters)
+        sub = int(offs[9] - offs[4])
+        h.flux_accumulate(d[0], d[1], d[2], d[3], d[4], sub, K, d_F, mode, d[5].offset(4), 5)
+        h.scale(d_F, (K + 2) ** 2, 7.0)
+        Fs.append(d_F.to_host())
+    if mode == 1:
+        assert np.array_equal(Fs[0], Fs[1])  # deterministic kernel: bit-identical
+    else:
+        np.testing.assert_allclose(Fs[1], Fs[0], rtol=1e-12)  # f64 atomics: order-free
+
+
+def test_flux_bad_label_raises(hip_h):
+    from msm_we_amd._abi import HamsmError
+
+    h = hip_h
+    rng = np.random.default_rng(6)
+    _setup(h, 4, 4, 4, rng)
+    pa, ch, p0, p1, w, offs = _flux_inputs(rng, 1000, 10, 3)
+    p0[:] = 1.0
+    p1[:] = 1.0
+    ch[17] = 50
+    d = [h.to_device(a) for a in (pa, ch, p0, p1, w)]
+    for mode in (0, 1):
+        with pytest.raises(HamsmError) as e:
+            h.flux_accumulate(d[0], d[1], d[2], d[3], d[4], 1000, 10, h.zeros((12, 12), np.float64), mode)
+        assert e.value.code == -5
+
+
+def test_cluster_stats_matches_oracle(hip_h, oracle_h):
+    ns, n = 53, 30000
+    out = []
+    for h in (oracle_h, hip_h):
+        rng = np.random.default_rng(7)
+        _setup(h, 4, 4, 4, rng)
+        lab = rng.integers(0, ns - 3, n).astype(np.int32)  # some states stay empty
+        p = rng.normal(size=(n, 1))
+        d = [h.to_device(lab), h.to_device(p), h.zeros(ns, np.float64), h.to_device(np.full(ns, np.inf)),
+             h.to_device(np.full(ns, -np.inf)), h.zeros(ns, np.int64)]
+        h.cluster_stats(d[0], d[1], n, ns, d[2], d[3], d[4], d[5])
+        out.append([b.to_host() for b in d[2:]])
+    np.testing.assert_allclose(out[1][0], out[0][0], rtol=1e-12, atol=1e-12)  # sums: atomics
+    assert np.array_equal(out[1][1], out[0][1]) and np.array_equal(out[1][2], out[0][2])  # min / max exact
+    assert np.array_equal(out[1][3], out[0][3])
+
+
+def test_tmatrix_csr_matches_oracle(hip_h, oracle_h):
+    for ns in (7, 194, 700):
+        rng = np.random.default_rng(ns)
+        F = rng.exponential(size=(ns, ns)) * (rng.uniform(size=(ns, ns)) < 0.2)
+        F[3] = 0.0  # zero row -> self loop
+        res = []
+        for h in (oracle_h, hip_h):
+            h.set_geometry(4, 1, 2)
+            res.append(h.tmatrix_csr(h.to_device(F), ns, [ns - 2], [ns - 1]))
+        for a, b in zip(*res):
+            assert np.array_equal(a, b)
+
+
+def _train_inputs(rng, n, D, S, dtype):
+    X = (rng.normal(size=(n, D)) * 2 + rng.integers(0, 6, (n, 1)) * 5).astype(dtype)
+    p = rng.uniform(-0.2, S + 0.3, size=(n, 1)).clip(0, None)
+    w = rng.exponential(size=n)
+    return X, p, w
+
+
+@pytest.mark.parametrize("D,dtype,weighted,sub", [(10, np.float32, False, False), (30, np.float32, True, False),
+                                                   (13, np.float64, False, True), (64, np.float32, True, True)])
+def test_training_primitives_match_oracle(hip_h, oracle_h, D, dtype, weighted, sub):
+    """prepass, row lists, k-means++ seeding, three minibatch steps and a reassignment: every
+    intermediate bit-identical between the HIP library and the oracle."""
+    S, K, n = 3, 25, 3000
+    rec = []
+    for h in (oracle_h, hip_h):
+        rng = np.random.default_rng(11)
+        _setup(h, D, S, 1, rng, fit=[False] * S)
+        X, p, w = _train_inputs(rng, n, D, S, dtype)
+        dt = 0 if dtype == np.float32 else 1
+        d_X, d_p, d_w = h.to_device(X), h.to_device(p), h.to_device(w)
+        offs = np.array([0, 700, 1900, n], dtype=np.int64)
+        d_bin = h.alloc(n, np.int32)
+        hist = h.train_prepass(d_p, n, offs, d_bin)
+        d_rows = h.alloc(n, np.int32)
+        call_remap = np.array([0, 2, 2], dtype=np.int32)  # fold bin 1 into bin 2 (tail remap of _clustering.py:811-821)
+        cnt, st = h.train_build_rows(d_bin, n, call_remap, d_rows)
+        out = dict(hist=hist, bins=d_bin.to_host(), cnt=cnt, st=st, rows=d_rows.to_host()[: cnt.sum()])
+        b = 2
+        nb = int(cnt[b])
+        rows_b = d_rows.offset(int(st[b]))
+        rs = np.random.RandomState(5)
+        subidx = rs.randint(0, nb, 600) if sub else None
+        nn = 600 if sub else nb
+        L = 2 + int(np.log(K))
+        u = rs.uniform(size=(K - 1) * L)
+        out["chosen"] = h.kmeans_seed(b, d_X, dt, D, rows_b, nb, d_w if weighted else None, subidx, K, int(rs.randint(nn)),
+                                      u, L, want_chosen=True)
+        out["seed"] = h.get_centroids(b)
+        d_lab = h.alloc(nb, np.int32)
+        for step in range(3):
+            h.minibatch_step(b, d_X, dt, D, rows_b, nb, d_w if weighted else None, d_lab)
+            out[f"step{step}"] = h.get_centroids(b) + (d_lab.to_host(),)
+        h.reassign(b, d_X, dt, D, rows_b, [3, 7, 20], [5, 0, nb - 1], 2.5)
+        out["re"] = h.get_centroids(b)
+        # the re-packed centroids are what assign uses: check through predict too
+        h.set_centroids(0, out["re"][0][:5])
+        out["pred"] = h.predict_host(X[:500], np.where(p[:500] < 1, 0.5, 2.5))
+        rec.append(out)
+    a, g = rec
+    for k in ("hist", "bins", "cnt", "st", "rows", "chosen", "pred"):
+        assert np.array_equal(a[k], g[k]), k
+    for k in ("seed", "step0", "step1", "step2", "re"):
+        for i, (x, y) in enumerate(zip(a[k], g[k])):
+            assert np.array_equal(x, y), (k, i)
+    assert len(np.unique(a["chosen"])) > 1
+
+
+@pytest.mark.parametrize("case", GOLDEN_CASES)
+def test_pipeline_on_reference_goldens(hip_h, case):
+    """The full modelWE path on the HIP library reproduces the REAL reference's outputs
+    (tests/golden/*.npz): same assertions as tests/test_oracle_golden.py."""
+    g, meta = load_golden(case)
+    m, st = build_model(hip_h, g, meta)
+    assert st["forced"] <= 1
+    assert [m.clusters.we_remap[b] for b in range(meta["S"])] == list(g["remap_post_cluster"])
+    for b, cm in enumerate(m.clusters.cluster_models):
+        assert cm.fitted == bool(g["fitted_post_cluster"][b])
+        if cm.fitted:
+            assert np.array_equal(cm.cluster_centers_, g[f"centers_post_cluster_{b}"])
+            assert np.array_equal(cm._counts, g[f"counts_post_cluster_{b}"])
+    assert np.array_equal(np.concatenate(m.dtrajs), g["dtrajs_post_cluster"])
+    assert np.array_equal(np.concatenate(m.pair_dtrajs), g["pairs_post_cluster"])
+    m.get_fluxMatrix(0, first_iter=1, last_iter=m.maxIter, use_ray=True)
+    assert np.array_equal(m.fluxMatrixRaw, g["fluxMatrixRaw"])
+    m.organize_fluxMatrix(use_ray=True)
+    assert m.n_clusters == int(g["n_clusters_clean"])
+    assert np.array_equal(np.concatenate(m.dtrajs), g["dtrajs_clean"])
+    assert np.array_equal(m.fluxMatrix, g["fluxMatrix"])
+    np.testing.assert_allclose(m.targetRMSD_centers[:-2, 0], g["targetRMSD_centers"][:-2, 0], rtol=1e-12)
+    m.get_Tmatrix()
+    assert np.array_equal(m.Tmatrix, g["Tmatrix"])
+    m.get_steady_state()
+    np.testing.assert_allclose(m.pSS, g["pSS"], rtol=1e-6, atol=1e-300)
+    m.get_steady_state_target_flux()
+    assert abs(m.JtargetSS - float(g["JtargetSS"])) <= 1e-6 * float(g["JtargetSS"])
+    # atomic-mode flux agrees with the deterministic one to 1e-12
+    m2, _ = build_model(hip_h, g, meta)
+    m2.flux_mode = 0
+    m2.get_fluxMatrix(0, first_iter=1, last_iter=m2.maxIter)
+    np.testing.assert_allclose(m2.fluxMatrixRaw, g["fluxMatrixRaw"], rtol=1e-12, atol=1e-300)
+
+
+def test_block_validation_runs(hip_h):
+    g, meta = load_golden("c1p_d10")
+    m, _ = build_model(hip_h, g, meta)
+    from copy import deepcopy
+
+    m.post_cluster_model = deepcopy(m)
+    m.get_fluxMatrix(0, first_iter=1, last_iter=m.maxIter)
+    m.organize_fluxMatrix()
+    m.get_Tmatrix()
+    m.get_steady_state()
+    m.get_steady_state_target_flux()
+    J = m.JtargetSS
+    m.do_block_validation(cross_validation_groups=2, cross_validation_blocks=4)
+    assert len(m.validation_models) == 2
+    for vm in m.validation_models:
+        assert vm.JtargetSS > 0 and 0.05 < vm.JtargetSS / J < 20
+    # the main model's state is untouched by the copies sharing its ctx
+    m.launch_ray_discretization()
+    assert np.array_equal(np.concatenate(m.dtrajs), g["dtrajs_clean"])
