@@ -1,0 +1,243 @@
+#!/usr/bin/env python3
+"""bench.py -- haMSM construction throughput on MI355X: frames/s clustered + flux-matrix built.
+
+    python bench.py --gpus N --steps K --warmup W          (N>1: launched by torch.distributed.run)
+
+Workload (default ``c3`` = BASELINE.json configs[2], the configuration the metric is quoted on):
+synthetic WE data, 1000 iterations x 10 000 segments, 30 float32 features per frame, 4 strata x 250
+clusters (K = 1000).  One *step* = one pass of the hot path over the resident shard:
+
+    stratified mini-batch k-means training (999 iterations, sklearn-exact control flow and draws)
+    -> assignment of the parent and child frame of every segment (2 x 10 M rows)
+    -> flux-matrix accumulation over the segments (+ D2H of the (K+2)^2 matrix)
+
+Inputs are generated on the host, uploaded once, and are resident in HBM when the timed region
+starts.  N > 1 (weak scaling): every rank holds its own 10 M-segment shard of an N x 10 M-segment
+run; rank 0 trains on its iterations (the reference's ``iters_to_use``), the model is broadcast with
+RCCL, every rank discretizes its shard and the partial flux matrices are all-reduced over xGMI.
+
+Rank 0 prints ONE JSON line (contract in the task statement) with ``roofline`` for the dominant
+kernel (k_assign: f64 MFMA) and ``cpu_baseline`` (the oracle = scalar C port, 1 core, bounded sample).
+"""
+from __future__ import annotations
+
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+from msm_we_amd import _abi, synthetic  # noqa: E402
+from msm_we_amd.data import DeviceStore  # noqa: E402
+from msm_we_amd.model import modelWE  # noqa: E402
+
+PEAK_F64_MFMA_TFLOPS = 78.6   # MI355X FP64 matrix (= vector) peak, dense (vendor figure)
+PEAK_HBM_GBS = 8000.0         # MI355X_MICROARCH.md: 8.0 TB/s spec
+
+
+class Mapper:
+    """attribute-only RectilinearBinMapper (the library does the assignment)"""
+
+    def __init__(self, boundaries):
+        self.boundaries = [np.asarray(b, dtype=np.float32) for b in boundaries]
+        self.nbins = int(np.prod([len(b) - 1 for b in self.boundaries]))
+
+
+Mapper.__name__ = "RectilinearBinMapper"
+
+
+def make_shard(cfg, it_first, n_iters, log=None):
+    """iterations it_first .. it_first+n_iters-1 as host arrays (float32 features)"""
+    lat = synthetic.latent_centres(cfg)
+    n = n_iters * cfg.segs_per_iter
+    Xp = np.empty((n, cfg.D), np.float32)
+    Xc = np.empty((n, cfg.D), np.float32)
+    p0 = np.empty((n, 1))
+    p1 = np.empty((n, 1))
+    w = np.empty(n)
+    t0 = time.time()
+    for k in range(n_iters):
+        d = synthetic.make_iteration(cfg, it_first + k, lat)
+        a, b = k * cfg.segs_per_iter, (k + 1) * cfg.segs_per_iter
+        Xp[a:b], Xc[a:b], p0[a:b], p1[a:b], w[a:b] = d["Xp"], d["Xc"], d["p0"], d["p1"], d["w"]
+        if log and k and k % 250 == 0:
+            log(f"generated {k}/{n_iters} iterations ({time.time() - t0:.1f}s)")
+    offs = np.arange(n_iters + 1, dtype=np.int64) * cfg.segs_per_iter
+    return Xp, Xc, p0, p1, w, offs
+
+
+def new_model(h, cfg, store, n_iters):
+    m = modelWE(h=h)
+    m.pcoord_ndim = 1
+    basis, target = synthetic.basis_target_bounds(cfg.S)
+    m.basis_pcoord_bounds = basis
+    m.target_pcoord_bounds = target
+    m.tau = 1.0
+    # n_iters iterations are resident and complete: the reference's maxIter counts iterations that have a
+    # successor (_data.py:860-866), and trains / discretizes range(1, maxIter)
+    m.attach_store(store, maxIter=None)
+    m.maxIter = n_iters + 1
+    m.numSegments = np.diff(store.offsets).astype(float)
+    return m
+
+
+def one_step(m, cfg, seed, flux_mode):
+    bm = Mapper([synthetic.strata_boundaries(cfg.S)])
+    m.flux_mode = flux_mode
+    m.cluster_coordinates(cfg.K_s, streaming=True, use_ray=True, stratified=True, user_bin_mapper=bm, random_state=seed)
+    m.get_fluxMatrix(0, first_iter=1, last_iter=m.maxIter)
+    return m
+
+
+def cpu_baseline(cfg, n_iters_sample, seed):
+    """The oracle (scalar C restatement, one core) on the first `n_iters_sample` iterations of the
+    same workload: same host logic, same ABI, CPU arithmetic."""
+    so = os.path.join(ROOT, "oracle", "_build", "libhamsm_oracle.so")
+    if not os.path.exists(so):
+        import subprocess
+
+        subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle")])
+    h = _abi.Hamsm(lib=ctypes.CDLL(so))
+    Xp, Xc, p0, p1, w, offs = make_shard(cfg, 1, n_iters_sample)
+    store = DeviceStore.from_host(h, Xp, Xc, p0, p1, w, offs)
+    m = new_model(h, cfg, store, n_iters_sample)
+    t0 = time.perf_counter()
+    one_step(m, cfg, seed, 1)
+    dt = time.perf_counter() - t0
+    frames = n_iters_sample * cfg.segs_per_iter
+    h.close()
+    return {"value": frames / dt, "unit": "frames/s", "cores": 1, "kind": "port",
+            "sample": f"first {n_iters_sample} of {cfg.n_iters} iterations ({frames} segments), same train+assign+flux "
+                      f"step, oracle/hamsm_oracle.c single thread, {dt:.1f} s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--workload", default="c3", choices=["c2", "c3", "c5s", "tiny"])
+    ap.add_argument("--iters", type=int, default=0, help="override iterations per rank (debug)")
+    ap.add_argument("--flux-mode", type=int, default=0, help="0 = f64 atomics, 1 = deterministic sort-based")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-iters", type=int, default=20)
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+
+    def log(msg):
+        if rank == 0:
+            print(f"[bench] {msg}", file=sys.stderr, flush=True)
+
+    dist = None
+    if world > 1:
+        import torch
+        import torch.distributed as dist
+
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", rank=rank, world_size=world)
+
+    cfgs = dict(synthetic.CONFIGS)
+    cfgs["c5s"] = synthetic.WEConfig("c5s", 5, 200, 50000, 64, 4, 1250)   # C5 shape, 10 M frames (single-GPU slice)
+    cfgs["tiny"] = synthetic.WEConfig("tiny", 9, 50, 2000, 30, 4, 50)
+    cfg = cfgs[args.workload]
+    n_iters = args.iters or cfg.n_iters
+    seed = 1337
+
+    h = _abi.Hamsm(device=local_rank)  # the HIP library; raises if it is not built
+    assert h.backend == "hip-gfx950"
+    if world > 1:
+        uid = [h.comm_unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(uid, src=0)
+        h.comm_init(world, rank, uid[0])
+
+    log(f"workload {cfg.name}: {n_iters} iterations x {cfg.segs_per_iter} segments x {cfg.D} features, "
+        f"{cfg.S} strata x {cfg.K_s} clusters, rank shard starts at iteration {1 + rank * n_iters}")
+    Xp, Xc, p0, p1, w, offs = make_shard(cfg, 1 + rank * n_iters, n_iters, log)
+    store = DeviceStore.from_host(h, Xp, Xc, p0, p1, w, offs)
+    del Xp, Xc
+    n_seg = int(offs[-1])
+    m = new_model(h, cfg, store, n_iters)
+
+    def barrier():
+        h.sync()
+        if dist is not None:
+            import torch
+
+            torch.cuda.synchronize()
+            dist.barrier()
+
+    for _ in range(args.warmup):
+        one_step(m, cfg, seed, args.flux_mode)
+    barrier()
+    h.timers(reset=True)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        one_step(m, cfg, seed, args.flux_mode)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        import torch
+
+        t = torch.tensor([elapsed], device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    timers = h.timers()
+    assign_ms = h.last_kernel_ms(0)
+    n_assign_launch = 2 * args.steps
+    assign_avg_ms = timers["assign"] * 1e3 / n_assign_launch
+    rows_per_launch = n_seg                                   # one launch = all parent (or child) frames
+    flops = 2.0 * cfg.K_s * cfg.D * rows_per_launch           # 2*K_s*D per frame
+    bytes_alg = (cfg.D * 4 + 8 + 4) * rows_per_launch         # D*s + 8*ndim + 4 per frame
+    tflops = flops / (assign_avg_ms * 1e-3) / 1e12
+    K = cfg.K_s * cfg.S
+    out = {
+        "metric": "frames/sec clustered + fluxmatrix-built",
+        "value": world * n_seg * args.steps / elapsed,
+        "unit": "frames/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": elapsed * 1e3 / args.steps,
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "f64",
+        "data": "synthetic",
+        "config": {"workload": f"{cfg.name}: {n_iters} WE iterations x {cfg.segs_per_iter} segments per GPU, "
+                               f"{cfg.D} f32 features, {cfg.S} strata x {cfg.K_s} clusters (K={K}); "
+                               f"train + assign(2N) + flux per step", "frames_per_gpu": n_seg,
+                   "flux_mode": "atomic" if args.flux_mode == 0 else "deterministic",
+                   "parallelism": f"iteration-sharded x{world}"},
+        "roofline": {"bound": "mfma", "achieved": tflops, "peak": PEAK_F64_MFMA_TFLOPS, "unit": "TFLOP/s",
+                     "frac": tflops / PEAK_F64_MFMA_TFLOPS, "traffic": None, "kernel": "k_assign (f64 MFMA 16x16x4)",
+                     "avg_launch_ms": assign_avg_ms, "last_launch_ms": assign_ms,
+                     "algorithmic_GBps": bytes_alg / (assign_avg_ms * 1e-3) / 1e9,
+                     "hbm_frac": bytes_alg / (assign_avg_ms * 1e-3) / 1e9 / PEAK_HBM_GBS},
+        "stage_seconds_per_step": {k: v / args.steps for k, v in timers.items()},
+    }
+    if rank == 0:
+        if not args.no_cpu_baseline:
+            log("timing the CPU oracle on a bounded sample ...")
+            out["cpu_baseline"] = cpu_baseline(cfg, min(args.cpu_iters, n_iters), seed)
+            out["cpu_baseline"]["gpu_over_cpu"] = out["value"] / out["cpu_baseline"]["value"]
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.barrier()
+        h.comm_destroy()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -84,7 +84,7 @@ def load() -> C.CDLL:
             f"{path} not found: build the HIP library first (python -c 'import __graft_entry__ as g; g.build()' "
             "or make -C msm_we_amd/csrc).  msm_we_amd has no CPU fallback."
         )
-    return C.CDLL(path, mode=C.RTLD_GLOBAL)
+    return C.CDLL(path)
 
 
 def bind(lib: C.CDLL) -> C.CDLL:
@@ -157,7 +157,7 @@ class Hamsm:
         self.ctx = ctx
         self.device = device
         self.D = self.ndim = self.S = None
-        self._bufs = []
+        self.nranks, self.rank = 1, 0
 
     # -- plumbing ---------------------------------------------------------------------------
     @property

@@ -94,6 +94,10 @@ class ClusteringMixin:
         S = bin_mapper.nbins
         pos = 0
         first_call = True
+        # sharded runs (SURVEY §8e "exact" mode): rank 0 trains on its iterations, the model is broadcast
+        trains_here = getattr(h, "rank", 0) == 0
+        if not trains_here:
+            pos = len(iters_to_use)
         while pos < len(iters_to_use):
             # ---- do_stratified_clustering (:748-918): pull iterations until every SEEN bin has >= k rows
             group, counts = [], np.zeros(S, dtype=np.int64)
@@ -165,8 +169,24 @@ class ClusteringMixin:
 
         # :718-731 never-trained bins are remapped to the nearest trained one
         true_unfilled = np.setdiff1d(range(S), list(all_filled))
-        for ub in true_unfilled:
-            clusters.we_remap[int(ub)] = int(self.find_nearest_bin(bin_mapper, ub, list(all_filled)))
+        if trains_here:
+            for ub in true_unfilled:
+                clusters.we_remap[int(ub)] = int(self.find_nearest_bin(bin_mapper, ub, list(all_filled)))
+        if getattr(h, "nranks", 1) > 1:
+            # exchange step 1: centroids / counts / ||c||^2 of every stratum and the remap table, rank 0 -> all
+            # (replaces ray.put(deepcopy(clusters)), _clustering.py:1171-1174)
+            if trains_here:
+                clusters._activate()
+            remap = np.array([clusters.we_remap[b] for b in range(S)], dtype=np.int32)
+            d_remap = h.to_device(remap)
+            h.bcast_model(0)
+            h.bcast(d_remap, remap.nbytes, 0)
+            remap = d_remap.to_host()
+            d_remap.free()
+            if not trains_here:
+                clusters._adopt_device_state()
+                for b in range(S):
+                    clusters.we_remap[b] = int(remap[b])
 
         self.clusters = clusters
         self.clusters.model = self

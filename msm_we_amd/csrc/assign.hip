@@ -19,9 +19,9 @@
 
 typedef double v4f64 __attribute__((ext_vector_type(4)));
 
-#define FR 512          // frames per workgroup
+#define FR_MAX 512       // frames per workgroup (fewer when a row is wide: the chunk must fit LDS)
 #define NTHREADS 256
-#define MAX_TILES (FR / 16 + 64)  // FR/16 full tiles + one partial tile per stratum present (<= 64 here, see host check)
+#define SPARE_TILES 64   // one partial tile per stratum present in a chunk (at most 64 distinct strata per chunk)
 
 // ---- classify -----------------------------------------------------------------------------------
 __global__ void k_classify(MapperDev m, const double *__restrict__ p, int64_t n, int apply_remap, int32_t *bin,
@@ -123,12 +123,14 @@ struct AssignArgs {
   const StratumDev *table;
   int S, D, Kfit;
   int *err;
+  int FR;  // frames per workgroup, multiple of 64
 };
 
 template <typename XT, int KS, int MT>
 __global__ __launch_bounds__(NTHREADS) void k_assign(MapperDev mp, AssignArgs g) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   // LDS carve (one array, G17): Xs | slot | tile_s | item_* | cnt/tb | misc
+  const int FR = g.FR, MAX_TILES = FR / 16 + SPARE_TILES;
   XT *Xs = (XT *)smem;                                                 // [FR][D]
   size_t xbytes = ((size_t)FR * g.D * sizeof(XT) + 15) & ~(size_t)15;
   int16_t *slot = (int16_t *)(smem + xbytes);                          // [MAX_TILES*16] local frame index or -1
@@ -269,8 +271,14 @@ __global__ __launch_bounds__(NTHREADS) void k_assign(MapperDev mp, AssignArgs g)
 }
 
 template <typename XT, int KS>
-static int launch_assign_ks(hamsm_ctx *c, const MapperDev &mp, const AssignArgs &g) {
+static int launch_assign_ks(hamsm_ctx *c, const MapperDev &mp, const AssignArgs &g_in) {
   constexpr int MT = (KS <= 16) ? 4 : 2;
+  AssignArgs g = g_in;
+  // chunk of frames per workgroup: as many as keep the staged rows within ~64 KB (2 workgroups per CU)
+  int FR = FR_MAX;
+  while (FR > 64 && (size_t)FR * g.D * sizeof(XT) > 64 * 1024) FR >>= 1;
+  g.FR = FR;
+  const int MAX_TILES = FR / 16 + SPARE_TILES;
   size_t xbytes = ((size_t)FR * g.D * sizeof(XT) + 15) & ~(size_t)15;
   size_t lds = xbytes + sizeof(int16_t) * (MAX_TILES * 16 + 2 * FR) + sizeof(int) * (MAX_TILES + 2 * g.S + 4);
   if (lds > 160 * 1024) return hamsm_fail(c, HAMSM_ENOTSUP, "assign needs %zu B of LDS", lds);
@@ -303,16 +311,13 @@ extern "C" int hamsm_assign(hamsm_ctx *c, const void *X, int dt, int64_t ldx, co
   if (!c->have_mapper || !c->have_bounds) return hamsm_fail(c, HAMSM_EINVAL, "mapper/bounds not set");
   if (dt != HAMSM_F32 && dt != HAMSM_F64) return hamsm_fail(c, HAMSM_EINVAL, "x_dtype");
   if (ldx < c->D) return hamsm_fail(c, HAMSM_EINVAL, "ldx < D");
-  if (c->S > 64 + 0 && c->S > MAX_TILES - FR / 16) {
-    // more strata than spare partial tiles per workgroup: still correct as long as a chunk meets <= 64 strata;
-    // the kernel reports HAMSM_ENOTSUP otherwise
-  }
+  // a chunk that meets more than SPARE_TILES distinct strata is reported as HAMSM_ENOTSUP by the kernel
   if (n <= 0) return HAMSM_OK;
   int rc = hamsm_refresh_table(c);
   if (rc) return rc;
   // B fragments carry ceil(D/4) k-steps, but the kernels are instantiated for a few KS values: the
   // packed layout always uses c->KS, so the instantiated KS must equal it
-  AssignArgs g{X, ldx, p, n, labels, seen, c->d_table, c->S, c->D, c->Kfit, c->d_err};
+  AssignArgs g{X, ldx, p, n, labels, seen, c->d_table, c->S, c->D, c->Kfit, c->d_err, FR_MAX};
   hamsm_timer_begin(c);
   rc = (dt == HAMSM_F32) ? launch_assign<float>(c, c->mapper, g) : launch_assign<double>(c, c->mapper, g);
   hamsm_timer_end(c, ST_ASSIGN);

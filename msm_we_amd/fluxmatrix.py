@@ -38,6 +38,14 @@ class FluxMatrixMixin:
         ns = K + 2
         d_F = self._flux_device(iters)
         nI = len(iters)
+        if getattr(h, "nranks", 1) > 1:
+            # exchange step 2: sum of the ranks' partial flux matrices (replaces the driver-side
+            # `fluxMatrix + _fmatrix.todense().A` over Ray results, :325-327) and of the iteration counts
+            h.allreduce_sum_f64(d_F, ns * ns)
+            d_n = h.to_device(np.array([nI], dtype=np.int64))
+            h.allreduce_sum_i64(d_n, 1)
+            nI = int(d_n.to_host()[0])
+            d_n.free()
         h.scale(d_F, ns * ns, float(nI))  # :342
         F = np.empty((ns, ns))
         h.d2h(F, d_F)

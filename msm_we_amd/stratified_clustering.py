@@ -289,6 +289,18 @@ class StratifiedClusters:
             h.set_remap([self._remap[b] for b in range(self.bin_mapper.nbins)])
             self._remap_dirty = False
 
+    def _adopt_device_state(self):
+        """After a model broadcast the ctx holds the authoritative centroids: become their owner."""
+        h = self._h
+        for m in self.cluster_models:
+            k = h.num_centroids(m.stratum)
+            m.__dict__["_host_centers"] = None
+            m.__dict__["_host_counts"] = None
+            m.__dict__["_device_newer"] = k > 0
+            m.__dict__["_host_newer"] = False
+        h._active_clusters = weakref.ref(self)
+        self._remap_dirty = True
+
     def attach(self, h: "_abi.Hamsm"):
         """Bind an unpickled / copied object to a context."""
         self._h = h

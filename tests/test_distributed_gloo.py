@@ -1,0 +1,130 @@
+"""N>1 path on CPU: world_size 2 over gloo.  The sharding logic of the mixins (rank 0 trains, model
+broadcast, per-rank discretization, flux all-reduce) runs on the oracle backend; the two exchange
+steps, which the product performs with RCCL inside the library (csrc/comm.hip), are served here by
+torch.distributed/gloo on host copies -- a test-side stand-in for the collective only."""
+import ctypes
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import ROOT, RectilinearBinMapper, _build_oracle, golden_iterations, load_golden
+
+torch = pytest.importorskip("torch")
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _gloo_comm(h, dist, rank, world):
+    """give a single-process ctx the collective entry points, implemented with gloo on host buffers"""
+    h.nranks, h.rank = world, rank
+
+    def allreduce(dtype):
+        def f(d_buf, count):
+            a = np.empty(count, dtype=dtype)
+            h.d2h(a, d_buf)
+            t = torch.from_numpy(a)
+            dist.all_reduce(t)
+            h.h2d(d_buf, t.numpy())
+        return f
+
+    h.allreduce_sum_f64 = allreduce(np.float64)
+    h.allreduce_sum_i64 = allreduce(np.int64)
+
+    def bcast(d_buf, nbytes, root=0):
+        a = np.empty(nbytes, dtype=np.uint8)
+        h.d2h(a, d_buf)
+        t = torch.from_numpy(a)
+        dist.broadcast(t, root)
+        h.h2d(d_buf, t.numpy())
+
+    h.bcast = bcast
+
+    def bcast_model(root=0):
+        state = [[h.get_centroids(s) for s in range(h.S)] if rank == root else None]
+        dist.broadcast_object_list(state, src=root)
+        if rank != root:
+            for s, (Cm, counts, csq) in enumerate(state[0]):
+                h.set_centroids(s, Cm if len(Cm) else None, csq=csq if len(Cm) else None, counts=counts if len(Cm) else None)
+
+    h.bcast_model = bcast_model
+
+
+def _shard_model(h, g, meta, first, last):
+    from msm_we_amd.data import InMemorySource
+    from msm_we_amd.model import modelWE
+
+    its = golden_iterations(g)
+    shard = {i - first + 1: its[i] for i in range(first, last + 2)}  # + the successor iteration
+    m = modelWE(h=h)
+    m.set_iteration_source(InMemorySource(shard))
+    m.initialize(["g"], {"coords": None, "nAtoms": meta["D"], "coord_ndim": 1}, "g", basis_pcoord_bounds=meta["basis"],
+                 target_pcoord_bounds=meta["target"], tau=meta["tau"], pcoord_ndim=1)
+    m.get_iterations()
+    m.dimReduce()
+    return m
+
+
+def _worker(rank, world, port, out):
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+
+    from msm_we_amd import _abi
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    g, meta = load_golden("c1p_d10")
+    h = _abi.Hamsm(lib=ctypes.CDLL(_build_oracle()))
+    _gloo_comm(h, dist, rank, world)
+    m = _shard_model(h, g, meta, 1 + rank * 19, 19 + rank * 19)  # iterations 1..19 and 20..38
+    bm = RectilinearBinMapper([np.array(meta["boundaries"], dtype=np.float32)])
+    m.cluster_coordinates(meta["K_s"], streaming=True, use_ray=True, stratified=True, user_bin_mapper=bm,
+                          random_state=meta["seed"])
+    m.get_fluxMatrix(0, first_iter=0, last_iter=m.maxIter)  # every local iteration with pairs
+    np.savez(out.format(rank), labels=np.concatenate(m.dtrajs), flux=m.fluxMatrixRaw,
+             centers0=m.clusters.cluster_models[0].cluster_centers_, remap=[m.clusters.we_remap[b] for b in range(2)])
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_ranks_match_single_process(tmp_path, oracle_lib):
+    import torch.multiprocessing as mp
+
+    from msm_we_amd import _abi
+
+    out = str(tmp_path / "rank{}.npz")
+    mp.spawn(_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    r0, r1 = np.load(out.format(0)), np.load(out.format(1))
+
+    # single process: train on shard 0, reuse its centroids for shard 1, combine the flux by hand
+    g, meta = load_golden("c1p_d10")
+    bm = RectilinearBinMapper([np.array(meta["boundaries"], dtype=np.float32)])
+    h = _abi.Hamsm(lib=oracle_lib)
+    a = _shard_model(h, g, meta, 1, 19)
+    a.cluster_coordinates(meta["K_s"], streaming=True, use_ray=True, stratified=True, user_bin_mapper=bm,
+                          random_state=meta["seed"])
+    a.get_fluxMatrix(0, first_iter=0, last_iter=a.maxIter)
+    la, Fa, na = np.concatenate(a.dtrajs), a.fluxMatrixRaw * (a.maxIter - 1), a.maxIter - 1
+    b = _shard_model(h, g, meta, 20, 38)
+    b.stage_iterations()
+    b.clusters, b.n_clusters, b.clustering_method = a.clusters, a.n_clusters, "stratified"
+    b.clusters.model = b
+    b.launch_ray_discretization()
+    b.get_fluxMatrix(0, first_iter=0, last_iter=b.maxIter)
+    lb, Fb, nb = np.concatenate(b.dtrajs), b.fluxMatrixRaw * (b.maxIter - 1), b.maxIter - 1
+
+    assert np.array_equal(r0["labels"], la) and np.array_equal(r1["labels"], lb)      # labels bit-exact
+    assert np.array_equal(r0["centers0"], r1["centers0"])                              # broadcast model
+    assert np.array_equal(r0["remap"], r1["remap"])
+    assert np.array_equal(r0["flux"], r1["flux"])                                      # all ranks hold the same sum
+    np.testing.assert_allclose(r0["flux"], (Fa + Fb) / (na + nb), rtol=1e-12, atol=1e-300)
+    assert abs(r0["flux"].sum() - 1.0) < 1e-12
