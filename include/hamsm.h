@@ -171,6 +171,49 @@ int hamsm_reassign(hamsm_ctx *ctx, int stratum, const void *d_X, int x_dtype, in
                    const int32_t *d_rows, const int32_t *h_cluster, const int64_t *h_batch_row,
                    int n_re, double new_count);
 
+/* ---- a5-a7 batched: the whole training pass without per-step host round trips ------------------
+ * The reference runs one partial_fit per WE bin per training call, each behind a fork and a pickle
+ * (_clustering.py:664-691).  The grouping of iterations into training calls depends only on the
+ * prepass histogram, so the host plans every call up front; these entry points then execute the plan.
+ *
+ * hamsm_train_build_rows_batched: hamsm_train_build_rows for n_groups calls in one launch.  Group g
+ * covers frames [h_group_range[2g], h_group_range[2g+1]) of d_bin (disjoint ranges) and uses
+ * h_call_remap[g*S .. g*S+S).  Its row lists are written to d_rows starting at h_group_range[2g]
+ * (ranks stay relative to the group's first frame); h_counts[g*S+s] rows of bin s start at
+ * d_rows + h_starts[g*S+s].                                                                        */
+int hamsm_train_build_rows_batched(hamsm_ctx *ctx, const int32_t *d_bin, int64_t n_groups,
+                                   const int64_t *h_group_range, const int32_t *h_call_remap,
+                                   int32_t *d_rows, int64_t *h_counts, int64_t *h_starts);
+
+/* k-means++ for several strata at once (they are independent; one workgroup each, concurrently).
+ * Arrays of length n_items; per item the arguments of hamsm_kmeans_seed, with batch rows
+ * d_rows + rows_off[i] indexing frames of d_X + x_off[i]*ldx.  h_u holds the items' uniform draws
+ * back to back ((K_s[i]-1)*L[i] each); h_sub likewise (n_sub[i] each, 0 = no subsample).           */
+int hamsm_kmeans_seed_multi(hamsm_ctx *ctx, int n_items, const int32_t *h_stratum, const void *d_X,
+                            int x_dtype, int64_t ldx, const int64_t *h_x_off, const int32_t *d_rows,
+                            const int64_t *h_rows_off, const int64_t *h_n_b, const double *d_w,
+                            const int64_t *h_sub, const int64_t *h_n_sub, const int32_t *h_K,
+                            const int64_t *h_first, const double *h_u, const int32_t *h_L);
+
+/* One planned minibatch step: batch rows d_rows[rows_off .. rows_off+n_b) (relative to frame x_off)
+ * update the centroids of `stratum`.  flags bit0: evaluate the low-count rule after the step.      */
+typedef struct hamsm_step {
+  int32_t stratum;
+  int32_t flags;
+  int64_t x_off;
+  int64_t rows_off;
+  int64_t n_b;
+} hamsm_step;
+
+/* Execute steps in order (steps of different strata may overlap; steps of one stratum never do)
+ * with no host involvement.  The host predicts that no random reassignment is needed; h_report lets
+ * it verify that: h_report[2*i] = 1 if some centroid count was 0 before step i (the
+ * `(self._counts == 0).any()` test, _kmeans.py:2037), h_report[2*i+1] = number of centroids with
+ * count < ratio * max(count) after step i when flags bit0 is set (_kmeans.py:1645), else 0.        */
+int hamsm_minibatch_run(hamsm_ctx *ctx, const void *d_X, int x_dtype, int64_t ldx,
+                        const int32_t *d_rows, const double *d_w, const hamsm_step *h_steps,
+                        int64_t n_steps, double reassignment_ratio, int32_t *h_report);
+
 /* ---- multi-GPU: frames shard by WE iteration; these are the only exchanges.
  *      Replaces the driver-side sum of per-task flux matrices (_fluxmatrix.py:325-327) and
  *      ray.put broadcasts (_clustering.py:1169-1176).  RCCL over xGMI in the product.           */

@@ -52,6 +52,9 @@ SYMBOLS = {
     "hamsm_minibatch_step": (_int, [_vp, _int, _vp, _int, _i64, _vp, _i64, _vp, _vp]),
     "hamsm_get_counts": (_int, [_vp, _int, _vp]),
     "hamsm_reassign": (_int, [_vp, _int, _vp, _int, _i64, _vp, _vp, _vp, _int, _f64]),
+    "hamsm_train_build_rows_batched": (_int, [_vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp]),
+    "hamsm_kmeans_seed_multi": (_int, [_vp, _int, _vp, _vp, _int, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "hamsm_minibatch_run": (_int, [_vp, _vp, _int, _i64, _vp, _vp, _vp, _i64, _f64, _vp]),
     "hamsm_comm_unique_id": (_int, [_vp]),
     "hamsm_comm_init": (_int, [_vp, _int, _int, _vp]),
     "hamsm_comm_destroy": (_int, [_vp]),
@@ -353,6 +356,40 @@ class Hamsm:
         br = None if batch_rows is None else np.ascontiguousarray(batch_rows, dtype=np.int64)
         self._ck(self.lib.hamsm_reassign(self.ctx, int(stratum), _dp(d_X), int(x_dtype), int(ldx), _dp(d_rows), _hp(cl),
                                          _hp(br), len(cl), float(new_count)))
+
+    # -- batched training plan ----------------------------------------------------------------
+    STEP_DTYPE = np.dtype([("stratum", "<i4"), ("flags", "<i4"), ("x_off", "<i8"), ("rows_off", "<i8"), ("n_b", "<i8")])
+
+    def train_build_rows_batched(self, d_bin, group_begin, group_end, call_remap, d_rows):
+        goff = np.ascontiguousarray(np.stack([group_begin, group_end], axis=1), dtype=np.int64)
+        G = len(goff)
+        cr = np.ascontiguousarray(call_remap, dtype=np.int32).reshape(G, self.S)
+        counts = np.zeros((G, self.S), dtype=np.int64)
+        starts = np.zeros((G, self.S), dtype=np.int64)
+        self._ck(self.lib.hamsm_train_build_rows_batched(self.ctx, _dp(d_bin), G, _hp(goff), _hp(cr), _dp(d_rows),
+                                                         _hp(counts), _hp(starts)))
+        return counts, starts
+
+    def kmeans_seed_multi(self, strata, d_X, x_dtype, ldx, x_off, d_rows, rows_off, n_b, d_w, subs, K, first, us, L):
+        n = len(strata)
+        a32 = lambda v: np.ascontiguousarray(v, dtype=np.int32)  # noqa: E731
+        a64 = lambda v: np.ascontiguousarray(v, dtype=np.int64)  # noqa: E731
+        n_sub = a64([0 if sb is None else len(sb) for sb in subs])
+        sub = a64(np.concatenate([np.asarray(sb, dtype=np.int64) for sb in subs if sb is not None])
+                  if any(sb is not None for sb in subs) else np.zeros(1, np.int64))
+        u = np.ascontiguousarray(np.concatenate([np.asarray(x, dtype=np.float64).ravel() for x in us] + [np.zeros(1)]))
+        st, xo, ro, nb, Ks, fs, Ls = a32(strata), a64(x_off), a64(rows_off), a64(n_b), a32(K), a64(first), a32(L)
+        self._ck(self.lib.hamsm_kmeans_seed_multi(self.ctx, n, _hp(st), _dp(d_X), int(x_dtype), int(ldx), _hp(xo), _dp(d_rows),
+                                                  _hp(ro), _hp(nb), _dp(d_w), _hp(sub), _hp(n_sub), _hp(Ks), _hp(fs), _hp(u),
+                                                  _hp(Ls)))
+
+    def minibatch_run(self, d_X, x_dtype, ldx, d_rows, d_w, steps, ratio):
+        steps = np.ascontiguousarray(steps, dtype=self.STEP_DTYPE)
+        report = np.zeros((len(steps), 2), dtype=np.int32)
+        if len(steps):
+            self._ck(self.lib.hamsm_minibatch_run(self.ctx, _dp(d_X), int(x_dtype), int(ldx), _dp(d_rows), _dp(d_w),
+                                                  _hp(steps), len(steps), float(ratio), _hp(report)))
+        return report
 
     # -- exchange step ----------------------------------------------------------------------
     def comm_unique_id(self) -> bytes:

@@ -90,80 +90,18 @@ class ClusteringMixin:
         d_rows = h.alloc(max(store.N, 1), np.int32)
 
         self.dtrajs = []
-        all_filled, all_unfilled = set(), set()
         S = bin_mapper.nbins
-        pos = 0
-        first_call = True
         # sharded runs (SURVEY §8e "exact" mode): rank 0 trains on its iterations, the model is broadcast
         trains_here = getattr(h, "rank", 0) == 0
-        if not trains_here:
-            pos = len(iters_to_use)
-        while pos < len(iters_to_use):
-            # ---- do_stratified_clustering (:748-918): pull iterations until every SEEN bin has >= k rows
-            group, counts = [], np.zeros(S, dtype=np.int64)
-            call_remap = np.arange(S, dtype=np.int32)
-            ran_out = False
-            while True:
-                if pos + len(group) >= len(iters_to_use):  # :798-826 IndexError branch
-                    ran_out = True
-                    break
-                it = iters_to_use[pos + len(group)]
-                if it > self.maxIter:  # :834-840
-                    break
-                group.append(it)
-                counts += hist[it - 1]
-                seen = counts > 0
-                if np.all(counts[seen] >= n_clusters):  # :885-886
-                    break
-            contiguous = all(b == a + 1 for a, b in zip(group, group[1:]))
-            if not contiguous:
-                raise NotImplementedError("non-contiguous iters_to_use within one training call")
-            unique_bins = np.nonzero(counts > 0)[0]
-            unfilled_ret = []
-            failed = False
-            if ran_out:
-                unfilled = unique_bins[counts[unique_bins] < n_clusters]
-                filled = np.setdiff1d(unique_bins, unfilled)
-                try:
-                    for ub in unfilled:
-                        call_remap[ub] = self.find_nearest_bin(bin_mapper, ub, list(filled))  # :811-821
-                except AssertionError:
-                    # :693-705: fatal on the very first call, swallowed afterwards
-                    if first_call:
-                        raise
-                    log.info("Clustering couldn't use last iteration, not all bins filled.")
-                    failed = True
-                unique_bins = filled
-                unfilled_ret = list(unfilled)
-            if not failed and len(group) and len(unique_bins):
-                f0, f1 = store.span(group[0], group[-1])
-                n = f1 - f0
-                cnt, starts = h.train_build_rows(d_bin.offset(f0), n, call_remap, d_rows)
-                X_base = store.Xc.offset(f0 * store.D)  # segment-END frames (_data.py:616)
-                w_base = store.w.offset(f0) if self.use_weights_in_clustering else None
-                w_host_all = None
-                if self.use_weights_in_clustering:
-                    w_host_all = np.empty(n)
-                    h.d2h(w_host_all, store.w.offset(f0))
-                rows_host = None
-                for b in unique_bins:  # :890 ascending (np.unique)
-                    nb = int(cnt[b])
-                    rows_b = d_rows.offset(int(starts[b]))
-                    w_rows = None
-                    if w_host_all is not None:
-                        if rows_host is None:
-                            rows_host = np.empty(int(cnt.sum()), dtype=np.int32)
-                            h.d2h(rows_host, d_rows, rows_host.nbytes)
-                        w_rows = w_host_all[rows_host[int(starts[b]): int(starts[b]) + nb]]
-                    clusters.cluster_models[b].partial_fit_device(X_base, store.x_dtype, store.D, rows_b, nb, w_base,
-                                                                  w_rows)
-            if not failed:
-                all_filled.update(int(b) for b in unique_bins)
-                all_unfilled.update(int(b) for b in unfilled_ret)
-            first_call = False
-            # :664-669,716: a call that consumed extra iterations skips them; a failed call only advances by one
-            pos += max(len(group), 1) if not failed else 1
-
+        all_filled = set()
+        if trains_here:
+            plan, all_filled = self._plan_training_calls(hist, iters_to_use, n_clusters, bin_mapper)
+            done = False
+            if getattr(self, "speculative_training", True):
+                done = self._train_planned(plan, clusters, store, d_bin, d_rows)
+            if not done:
+                self._train_stepwise(plan, clusters, store, d_bin, d_rows)
+            self.training_path = "planned" if done else "stepwise"
         d_bin.free()
         d_rows.free()
 
@@ -193,6 +131,200 @@ class ClusteringMixin:
         self.n_clusters = n_clusters * S  # :742 (quirk Q3)
         self.clusters.toggle = False
         self.launch_ray_discretization(progress_bar)
+
+    # ------------------------------------------------------------------------------------------
+    def _plan_training_calls(self, hist, iters_to_use, n_clusters, bin_mapper):
+        """The control flow of `cluster_stratified` / `do_stratified_clustering` (`_clustering.py:664-716,
+        794-886`): which iterations each training call consumes and which bins it fits.  It depends only
+        on the per-iteration bin histogram, so every call is known before any arithmetic runs."""
+        S = bin_mapper.nbins
+        plan, all_filled, all_unfilled = [], set(), set()
+        pos, first_call = 0, True
+        while pos < len(iters_to_use):
+            # pull iterations until every SEEN bin has >= k rows
+            group, counts = [], np.zeros(S, dtype=np.int64)
+            call_remap = np.arange(S, dtype=np.int32)
+            ran_out = False
+            while True:
+                if pos + len(group) >= len(iters_to_use):  # :798-826 IndexError branch
+                    ran_out = True
+                    break
+                it = iters_to_use[pos + len(group)]
+                if it > self.maxIter:  # :834-840
+                    break
+                group.append(it)
+                counts += hist[it - 1]
+                seen = counts > 0
+                if np.all(counts[seen] >= n_clusters):  # :885-886
+                    break
+            if not all(b == a + 1 for a, b in zip(group, group[1:])):
+                raise NotImplementedError("non-contiguous iters_to_use within one training call")
+            unique_bins = np.nonzero(counts > 0)[0]
+            unfilled_ret, failed = [], False
+            if ran_out:
+                unfilled = unique_bins[counts[unique_bins] < n_clusters]
+                filled = np.setdiff1d(unique_bins, unfilled)
+                try:
+                    for ub in unfilled:
+                        call_remap[ub] = self.find_nearest_bin(bin_mapper, ub, list(filled))  # :811-821
+                except AssertionError:
+                    # :693-705: fatal on the very first call, swallowed afterwards
+                    if first_call:
+                        raise
+                    log.info("Clustering couldn't use last iteration, not all bins filled.")
+                    failed = True
+                unique_bins = filled
+                unfilled_ret = list(unfilled)
+            if not failed and len(group) and len(unique_bins):
+                nrows = np.zeros(S, dtype=np.int64)
+                np.add.at(nrows, call_remap, counts)
+                plan.append(dict(group=group, call_remap=call_remap, bins=[int(b) for b in unique_bins], nrows=nrows))
+            if not failed:
+                all_filled.update(int(b) for b in unique_bins)
+                all_unfilled.update(int(b) for b in unfilled_ret)
+            first_call = False
+            # :664-669,716: a call that consumed extra iterations skips them; a failed call only advances by one
+            pos += max(len(group), 1) if not failed else 1
+        return plan, all_filled
+
+    def _train_stepwise(self, plan, clusters, store, d_bin, d_rows):
+        """One `partial_fit` at a time with the host in the loop (RandomState draws for reassignment)."""
+        h = self.h
+        for call in plan:
+            group = call["group"]
+            f0, f1 = store.span(group[0], group[-1])
+            n = f1 - f0
+            cnt, starts = h.train_build_rows(d_bin.offset(f0), n, call["call_remap"], d_rows)
+            X_base = store.Xc.offset(f0 * store.D)  # segment-END frames (_data.py:616)
+            w_base = store.w.offset(f0) if self.use_weights_in_clustering else None
+            w_host_all = rows_host = None
+            if self.use_weights_in_clustering:
+                w_host_all = np.empty(n)
+                h.d2h(w_host_all, store.w.offset(f0))
+            for b in call["bins"]:  # :890 ascending (np.unique)
+                nb = int(cnt[b])
+                rows_b = d_rows.offset(int(starts[b]))
+                w_rows = None
+                if w_host_all is not None:
+                    if rows_host is None:
+                        rows_host = np.empty(int(cnt.sum()), dtype=np.int32)
+                        h.d2h(rows_host, d_rows, rows_host.nbytes)
+                    w_rows = w_host_all[rows_host[int(starts[b]): int(starts[b]) + nb]]
+                clusters.cluster_models[b].partial_fit_device(X_base, store.x_dtype, store.D, rows_b, nb, w_base, w_rows)
+
+    def _train_planned(self, plan, clusters, store, d_bin, d_rows):
+        """Execute the whole plan on the device without per-step host round trips.
+
+        sklearn's step needs the host only when a low-count centroid must be re-seeded from a random
+        batch row (`_kmeans.py:1643-1673`).  The plan *predicts* that this never happens (it does not
+        on data whose strata hold at least as many modes as centroids), enqueues every seeding and every
+        step, and checks the prediction afterwards with what the device reported per step (was any count
+        zero before the step; how many counts fell under ratio*max after it).  A wrong prediction costs
+        a rerun through `_train_stepwise` from restored RandomState streams -- results are identical
+        either way.  Returns False when the rerun is needed."""
+        from .stratified_clustering import _check_random_state
+
+        h = self.h
+        if not plan:
+            return True
+        S = clusters.bin_mapper.nbins
+        gb = np.array([store.span(c["group"][0], c["group"][-1])[0] for c in plan], dtype=np.int64)
+        ge = np.array([store.span(c["group"][0], c["group"][-1])[1] for c in plan], dtype=np.int64)
+        counts, starts = h.train_build_rows_batched(d_bin, gb, ge, [c["call_remap"] for c in plan], d_rows)
+        use_w = self.use_weights_in_clustering
+        d_w = store.w if use_w else None
+        models = clusters.cluster_models
+        # RandomState streams as they were, for the rerun
+        rs_objs = {}
+        for m in models:
+            if "_random_state" not in m.__dict__:
+                m._random_state = _check_random_state(m.random_state)
+            rs_objs[id(m._random_state)] = m._random_state
+        saved = {k: r.get_state() for k, r in rs_objs.items()}
+        clusters._activate()
+        pred = {}  # stratum -> predicted MiniBatchKMeans bookkeeping
+        seeds, all_steps, all_first = [], [], []
+        for g, call in enumerate(plan):
+            for b in call["bins"]:
+                m = models[b]
+                nb = int(counts[g, b])
+                assert nb == int(call["nrows"][b]), "row lists disagree with the prepass histogram"
+                K = m.n_clusters
+                first = b not in pred
+                if first:
+                    if m.fitted:
+                        return False  # continuing a fitted model: take the stepwise path
+                    if nb < K:
+                        raise ValueError(f"n_samples={nb} should be >= n_clusters={K}.")
+                    rs = m._random_state
+                    bs = min(m.batch_size, nb)
+                    init_size = m.init_size
+                    if init_size is None:
+                        init_size = 3 * bs
+                        if init_size < K:
+                            init_size = 3 * K
+                    elif init_size < K:
+                        init_size = 3 * K
+                    init_size = min(init_size, nb)
+                    w_host = np.ones(nb)
+                    if use_w:
+                        rows_host = np.empty(nb, dtype=np.int32)
+                        h.d2h(rows_host, d_rows.offset(int(starts[g, b])), rows_host.nbytes)
+                        w_grp = np.empty(int(ge[g] - gb[g]))
+                        h.d2h(w_grp, store.w.offset(int(gb[g])))
+                        w_host = w_grp[rows_host]
+                    sub, n = None, nb
+                    if init_size < nb:
+                        sub = rs.randint(0, nb, init_size)
+                        n = init_size
+                        w_host = w_host[sub]
+                    fidx = rs.choice(n, p=w_host / w_host.sum())
+                    L = 2 + int(np.log(K))
+                    u = np.concatenate([rs.uniform(size=L) for _ in range(K - 1)]) if K > 1 else np.empty(0)
+                    seeds.append((b, int(gb[g]), int(starts[g, b]), nb, sub, K, int(fidx), u, L))
+                    pred[b] = dict(bs=bs, init=init_size, n_since=0, nsteps=0)
+                st = pred[b]
+                st["n_since"] += st["bs"]
+                do = first or st["n_since"] >= 10 * K
+                if do:
+                    st["n_since"] = 0
+                st["nsteps"] += 1
+                all_steps.append((b, 1 if (do and m.reassignment_ratio > 0) else 0, int(gb[g]), int(starts[g, b]), nb))
+                all_first.append(first)
+        ratios = {m.reassignment_ratio for m in models}
+        if len(ratios) != 1:
+            return False
+        # strata are independent and a seeding reads only its own first batch: every seeding can be issued
+        # before every step (the draws above were made in the stepwise order)
+        if seeds:
+            z = list(zip(*seeds))
+            h.kmeans_seed_multi(z[0], store.Xc, store.x_dtype, store.D, z[1], d_rows, z[2], z[3], d_w, z[4], z[5], z[6],
+                                z[7], z[8])
+        report = h.minibatch_run(store.Xc, store.x_dtype, store.D, d_rows, d_w,
+                                 np.array(all_steps, dtype=h.STEP_DTYPE), ratios.pop())
+        ok = True
+        for i, (stp, first) in enumerate(zip(all_steps, all_first)):
+            if report[i, 1] != 0 or (report[i, 0] != 0 and not first):
+                ok = False
+                break
+        if not ok:
+            log.info("training plan mispredicted a reassignment at step %d: rerunning stepwise", i)
+            for k, r in rs_objs.items():
+                r.set_state(saved[k])
+            for b in pred:
+                h.set_centroids(b, None)
+                m = models[b]
+                m.__dict__["_device_newer"] = False
+                m.__dict__["_host_centers"] = None
+            return False
+        for b, st in pred.items():
+            m = models[b]
+            m._batch_size, m._init_size = st["bs"], st["init"]
+            m._n_since_last_reassign = st["n_since"]
+            m._counts_cache = None
+            m.n_steps_ = m.__dict__.get("n_steps_", 0) + st["nsteps"]
+            m.__dict__["_device_newer"] = True
+        return True
 
     # ------------------------------------------------------------------------------------------
     def launch_ray_discretization(self, progress_bar=None):

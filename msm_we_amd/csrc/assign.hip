@@ -346,82 +346,6 @@ extern "C" int hamsm_predict_host(hamsm_ctx *c, const void *X, int dt, const dou
   return HAMSM_OK;
 }
 
-// ---- assign a gathered batch to ONE stratum (the E-step of MiniBatchKMeans, a7 i) -----------------
-// rows (nullable) index frames of X; one wave per MT tiles, A fragments gathered straight from global.
-template <typename XT, int KS, int MT>
-__global__ __launch_bounds__(NTHREADS) void k_assign_rows(const XT *__restrict__ X, int64_t ldx, int D,
-                                                          const int32_t *__restrict__ rows, int64_t n_b,
-                                                          const double *__restrict__ Bpack, const double *__restrict__ csq,
-                                                          int K, int32_t *__restrict__ labels) {
-  const int lane = threadIdx.x & 63;
-  const int64_t wave = (int64_t)blockIdx.x * (NTHREADS / 64) + (threadIdx.x >> 6);
-  const int64_t r0 = wave * (MT * 16);
-  if (r0 >= n_b) return;
-  double a[MT][KS];
-  int64_t br[MT];
-  int nt = 0;
-#pragma unroll
-  for (int m = 0; m < MT; m++) {
-    int64_t r = r0 + m * 16 + (lane & 15);
-    bool ok = r < n_b;
-    if (r0 + m * 16 < n_b) nt = m + 1;
-    br[m] = ok ? r : -1;
-    int64_t f = ok ? (rows ? (int64_t)rows[r] : r) : 0;
-#pragma unroll
-    for (int ks = 0; ks < KS; ks++) {
-      int k = ks * 4 + (lane >> 4);
-      a[m][ks] = (ok && k < D) ? (double)X[f * ldx + k] : 0.0;
-    }
-  }
-  int bi[MT][4];
-  tile_argmin<KS, MT>(a, nt, Bpack, csq, K, lane, bi);
-#pragma unroll
-  for (int m = 0; m < MT; m++)
-#pragma unroll
-    for (int r = 0; r < 4; r++) {
-      int row = (lane >> 4) + 4 * r;
-      int64_t b = __shfl(br[m], row, 64);
-      if ((lane & 15) == 0 && m < nt && b >= 0) labels[b] = bi[m][r];
-    }
-}
-
-template <typename XT, int KS>
-static int launch_rows_ks(hamsm_ctx *c, const void *X, int64_t ldx, const int32_t *rows, int64_t n_b, const Stratum &t,
-                          int32_t *labels) {
-  constexpr int MT = (KS <= 16) ? 2 : 1;  // small batches: favour more waves over B reuse
-  int64_t waves = (n_b + MT * 16 - 1) / (MT * 16);
-  unsigned grid = (unsigned)((waves + 3) / 4);
-  hipLaunchKernelGGL((k_assign_rows<XT, KS, MT>), dim3(grid), dim3(NTHREADS), 0, c->stream, (const XT *)X, ldx, c->D, rows,
-                     n_b, t.Bpack, t.csq, t.K, labels);
-  HIPCHK(c, hipGetLastError());
-  return HAMSM_OK;
-}
-
-template <typename XT>
-static int launch_rows(hamsm_ctx *c, const void *X, int64_t ldx, const int32_t *rows, int64_t n_b, const Stratum &t,
-                       int32_t *labels) {
-  int ks = c->KS;
-#define R(KSV) return launch_rows_ks<XT, KSV>(c, X, ldx, rows, n_b, t, labels)
-  if (ks <= 1) R(1);
-  if (ks <= 2) R(2);
-  if (ks <= 3) R(3);
-  if (ks <= 4) R(4);
-  if (ks <= 6) R(6);
-  if (ks <= 8) R(8);
-  if (ks <= 12) R(12);
-  if (ks <= 16) R(16);
-  if (ks <= 24) R(24);
-  R(32);
-#undef R
-}
-
-int hamsm_assign_rows(hamsm_ctx *c, int s, const void *X, int dt, int64_t ldx, const int32_t *rows, int64_t n_b,
-                      int32_t *labels) {
-  const Stratum &t = c->st[s];
-  return dt == HAMSM_F32 ? launch_rows<float>(c, X, ldx, rows, n_b, t, labels)
-                         : launch_rows<double>(c, X, ldx, rows, n_b, t, labels);
-}
-
 // ---- hardware property check: is v_mfma_f64_16x16x4_f64 an in-order FMA chain? --------------------
 __global__ void k_selftest(const double *A, const double *B, int KS, double *out_mfma, double *out_chain) {
   // A [16][KS*4], B [KS*4][16] row-major; one wave

@@ -16,7 +16,7 @@
 
 #define HAMSM_MAX_NDIM 8
 #define HAMSM_MAX_STRATA 4096
-#define POT_LANES 256   // strided partial sums of k-means++ potentials (oracle: POT_LANES)
+#define POT_LANES 1024  // strided partial sums of k-means++ potentials (oracle: POT_LANES, POT_GROUP = 32)
 #define SCAN_CHUNK 64   // chunked cumulative sum (oracle: SCAN_CHUNK)
 
 // ---- device view of the mapper / bounds (passed by value to kernels) ---------------------------
@@ -78,6 +78,7 @@ struct hamsm_ctx {
   hipEvent_t ev_cur0 = nullptr;
   double timers[ST_N] = {0};
   double last_ms[ST_N] = {0};
+  void *seed_chosen_dev = nullptr;  // chosen indices of the last seeding's first item (device)
   void *comm = nullptr;  // ncclComm_t
   int nranks = 1, rank = 0;
 };

@@ -1,15 +1,17 @@
 // train.hip -- a5/a6/a7: stratified mini-batch k-means training on device-resident frames.
-//   hamsm_train_prepass / hamsm_train_build_rows : planning support for do_stratified_clustering
-//                                                   (reference _clustering.py:843-899, quirks Q1/Q2)
-//   hamsm_kmeans_seed                             : k-means++ (sklearn _kmeans.py:214-276)
-//   hamsm_minibatch_step                          : _labels_inertia + _minibatch_update_dense
-//                                                   (_kmeans.py:1620-1642, _k_means_minibatch.pyx:59-108)
-//   hamsm_reassign                                : low-count reassignment (_kmeans.py:1652-1673)
-// Every reduction follows the order fixed in oracle/hamsm_oracle.c so that results are bit-identical.
+//   hamsm_train_prepass / hamsm_train_build_rows[_batched] : planning support for
+//       do_stratified_clustering (reference _clustering.py:843-899, quirks Q1/Q2)
+//   hamsm_kmeans_seed[_multi]  : k-means++ (sklearn _kmeans.py:214-276), one workgroup per stratum
+//   hamsm_minibatch_step / _run: _labels_inertia + _minibatch_update_dense
+//                                (_kmeans.py:1620-1642, _k_means_minibatch.pyx:59-108)
+//   hamsm_reassign             : low-count reassignment (_kmeans.py:1652-1673)
+// These kernels work on 10^3-row batches: they are latency-bound, so they are shaped for a single
+// round trip to L2 per phase (all operand loads issued before the first use) and for many small
+// workgroups, and several strata share one launch.  Every reduction follows the order fixed in
+// oracle/hamsm_oracle.c so that results are bit-identical.
 #include "common.h"
 
-int hamsm_assign_rows(hamsm_ctx *c, int s, const void *X, int dt, int64_t ldx, const int32_t *rows, int64_t n_b,
-                      int32_t *labels);
+typedef double v4f64 __attribute__((ext_vector_type(4)));
 
 // ---- prepass: raw bin or -1 (basis/target) per frame + per-iteration histogram --------------------
 __global__ void k_prepass(MapperDev m, const double *__restrict__ p, const int64_t *__restrict__ offs, int64_t n_iters,
@@ -59,7 +61,7 @@ extern "C" int hamsm_train_prepass(hamsm_ctx *c, const double *p, int64_t n, con
   return hamsm_check_device_error(c, "train_prepass");
 }
 
-// ---- row lists of one training call (single workgroup, stable) -------------------------------------
+// ---- row lists: one workgroup per training call, stable -------------------------------------------
 // rank = position in the basis/target-filtered list (:874), applied later to the unfiltered rows (Q1).
 #define BR_T 1024
 __device__ __forceinline__ int block_excl_scan(int v, int *sh /*[BR_T]*/, int *total) {
@@ -78,36 +80,73 @@ __device__ __forceinline__ int block_excl_scan(int v, int *sh /*[BR_T]*/, int *t
   return incl - v;
 }
 
-__global__ __launch_bounds__(BR_T) void k_build_rows(const int32_t *__restrict__ bin, int64_t n, const int32_t *__restrict__ cr,
-                                                     int S, int32_t *__restrict__ rank, int32_t *__restrict__ rows,
-                                                     long long *__restrict__ counts, long long *__restrict__ starts) {
+__global__ __launch_bounds__(BR_T) void k_build_rows(const int32_t *__restrict__ bin_all, const long long *__restrict__ range,
+                                                     const int32_t *__restrict__ cr_all, int S, int32_t *__restrict__ rank_all,
+                                                     int32_t *__restrict__ rows_all, long long *__restrict__ counts,
+                                                     long long *__restrict__ starts) {
   __shared__ int sh[BR_T];
-  const int tid = threadIdx.x;
-  const int64_t per = (n + BR_T - 1) / BR_T, a = tid * per, b = (a + per < n) ? a + per : n;
-  // ranks among valid frames
+  const int g = blockIdx.x, tid = threadIdx.x;
+  const long long g0 = range[2 * g], n = range[2 * g + 1] - g0;
+  const int32_t *bin = bin_all + g0, *cr = cr_all + (size_t)g * S;
+  int32_t *rank = rank_all + g0, *rows = rows_all + g0;
+  const long long per = (n + BR_T - 1) / BR_T, a = tid * per, b = (a + per < n) ? a + per : n;
   int v = 0;
-  for (int64_t i = a; i < b; i++) v += bin[i] >= 0;
+  for (long long i = a; i < b; i++) v += bin[i] >= 0;
   int tot;
   int base = block_excl_scan(v, sh, &tot);
-  for (int64_t i = a; i < b; i++)
+  for (long long i = a; i < b; i++)
     if (bin[i] >= 0) rank[i] = base++;
   __syncthreads();
   long long start = 0;
   for (int s = 0; s < S; s++) {
     int cnt = 0;
-    for (int64_t i = a; i < b; i++) cnt += (bin[i] >= 0 && cr[bin[i]] == s);
+    for (long long i = a; i < b; i++) cnt += (bin[i] >= 0 && cr[bin[i]] == s);
     int ts;
     int o = block_excl_scan(cnt, sh, &ts);
     if (ts) {
-      for (int64_t i = a; i < b; i++)
+      for (long long i = a; i < b; i++)
         if (bin[i] >= 0 && cr[bin[i]] == s) rows[start + o++] = rank[i];
     }
     if (tid == 0) {
-      counts[s] = ts;
-      starts[s] = start;
+      counts[(size_t)g * S + s] = ts;
+      starts[(size_t)g * S + s] = g0 + start;
     }
     start += ts;
   }
+}
+
+extern "C" int hamsm_train_build_rows_batched(hamsm_ctx *c, const int32_t *bin, int64_t G, const int64_t *h_range,
+                                              const int32_t *h_cr, int32_t *rows, int64_t *h_counts, int64_t *h_starts) {
+  if (G <= 0) return HAMSM_OK;
+  int64_t hi = 0;
+  for (int64_t g = 0; g < G; g++) {
+    if (h_range[2 * g + 1] < h_range[2 * g]) return hamsm_fail(c, HAMSM_EINVAL, "bad group range");
+    if (h_range[2 * g + 1] > hi) hi = h_range[2 * g + 1];
+  }
+  size_t off = 0;
+  auto take = [&](size_t bytes) {
+    size_t o = off;
+    off = (off + bytes + 255) & ~(size_t)255;
+    return o;
+  };
+  size_t o_rg = take(sizeof(long long) * 2 * G), o_cr = take(sizeof(int32_t) * G * c->S),
+         o_cnt = take(sizeof(long long) * G * c->S), o_st = take(sizeof(long long) * G * c->S),
+         o_rank = take(sizeof(int32_t) * (size_t)hi);
+  int rc = hamsm_ensure_scratch(c, off);
+  if (rc) return rc;
+  char *b = (char *)c->scratch;
+  HIPCHK(c, hipMemcpyAsync(b + o_rg, h_range, sizeof(long long) * 2 * G, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(b + o_cr, h_cr, sizeof(int32_t) * G * c->S, hipMemcpyHostToDevice, c->stream));
+  hamsm_timer_begin(c);
+  hipLaunchKernelGGL(k_build_rows, dim3((unsigned)G), dim3(BR_T), 0, c->stream, bin, (const long long *)(b + o_rg),
+                     (const int32_t *)(b + o_cr), c->S, (int32_t *)(b + o_rank), rows, (long long *)(b + o_cnt),
+                     (long long *)(b + o_st));
+  hamsm_timer_end(c, ST_PREPASS);
+  HIPCHK(c, hipGetLastError());
+  HIPCHK(c, hipMemcpyAsync(h_counts, b + o_cnt, sizeof(int64_t) * G * c->S, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipMemcpyAsync(h_starts, b + o_st, sizeof(int64_t) * G * c->S, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return HAMSM_OK;
 }
 
 extern "C" int hamsm_train_build_rows(hamsm_ctx *c, const int32_t *bin, int64_t n, const int32_t *h_cr, int32_t *rows,
@@ -116,155 +155,195 @@ extern "C" int hamsm_train_build_rows(hamsm_ctx *c, const int32_t *bin, int64_t 
     for (int s = 0; s < c->S; s++) h_counts[s] = h_starts[s] = 0;
     return HAMSM_OK;
   }
-  size_t o_cr = 0, o_cnt = (sizeof(int32_t) * c->S + 255) & ~(size_t)255, o_st = o_cnt + sizeof(long long) * c->S,
-         o_rank = (o_st + sizeof(long long) * c->S + 255) & ~(size_t)255;
-  int rc = hamsm_ensure_scratch(c, o_rank + sizeof(int32_t) * (size_t)n);
-  if (rc) return rc;
-  char *base = (char *)c->scratch;
-  HIPCHK(c, hipMemcpyAsync(base + o_cr, h_cr, sizeof(int32_t) * c->S, hipMemcpyHostToDevice, c->stream));
-  hamsm_timer_begin(c);
-  hipLaunchKernelGGL(k_build_rows, dim3(1), dim3(BR_T), 0, c->stream, bin, n, (const int32_t *)(base + o_cr), c->S,
-                     (int32_t *)(base + o_rank), rows, (long long *)(base + o_cnt), (long long *)(base + o_st));
-  hamsm_timer_end(c, ST_PREPASS);
-  HIPCHK(c, hipGetLastError());
-  HIPCHK(c, hipMemcpyAsync(h_counts, base + o_cnt, sizeof(int64_t) * c->S, hipMemcpyDeviceToHost, c->stream));
-  HIPCHK(c, hipMemcpyAsync(h_starts, base + o_st, sizeof(int64_t) * c->S, hipMemcpyDeviceToHost, c->stream));
-  HIPCHK(c, hipStreamSynchronize(c->stream));
-  return HAMSM_OK;
+  int64_t range[2] = {0, n};
+  return hamsm_train_build_rows_batched(c, bin, 1, range, h_cr, rows, h_counts, h_starts);
 }
 
 // ---- k-means++ ------------------------------------------------------------------------------------
+#define SEED_T 1024          // = POT_LANES of the oracle
+#define SEED_GROUP 32        // = POT_GROUP
+#define SEED_LMAX 16
+static_assert(SEED_T == POT_LANES, "potential partials are one per thread");
+
+struct SeedItem {
+  const void *X;        // frame 0 of this item
+  const int32_t *rows;  // nullable
+  const long long *sub; // nullable
+  const double *wf;     // nullable, indexed like X
+  const double *u;      // [(K-1)*L]
+  long long n, first;
+  int K, L;
+  double *XbT;          // [D][n]  feature-major copy of the batch (coalesced over rows)
+  double *w, *xsq, *closest, *cum, *cand /*[L][n]*/, *chunk_tot;
+  double *C;            // stratum centroids [K][D]
+  long long *chosen;    // [K]
+};
+
 template <typename XT>
-__global__ void k_seed_gather(const XT *__restrict__ X, int64_t ldx, int D, const int32_t *__restrict__ rows,
-                              const long long *__restrict__ sub, int64_t n, const double *__restrict__ wf, double *Xb,
-                              double *w, double *xsq) {
+__global__ void k_seed_gather(const SeedItem *__restrict__ items, int64_t ldx, int D) {
+  const SeedItem it = items[blockIdx.y];
   int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  int64_t r = sub ? sub[i] : i;
-  int64_t f = rows ? (int64_t)rows[r] : r;
+  if (i >= it.n) return;
+  const XT *X = (const XT *)it.X;
+  int64_t r = it.sub ? it.sub[i] : i;
+  int64_t f = it.rows ? (int64_t)it.rows[r] : r;
   double a = 0.0;
   for (int k = 0; k < D; k++) {
     double v = (double)X[f * ldx + k];
-    Xb[i * D + k] = v;
+    it.XbT[(size_t)k * it.n + i] = v;
     a = __builtin_fma(v, v, a);  // row_norms(X, squared=True) restated as an fma chain (oracle sqnorm_chain)
   }
-  xsq[i] = a;
-  w[i] = wf ? wf[f] : 1.0;
+  it.xsq[i] = a;
+  it.w[i] = it.wf ? it.wf[f] : 1.0;
 }
 
-#define SEED_T 256
-#define SEED_LMAX 16
-// one workgroup runs all K-1 greedy steps; every reduction order is the oracle's
-__global__ __launch_bounds__(SEED_T) void k_seed(const double *__restrict__ Xb, const double *__restrict__ w,
-                                                 const double *__restrict__ xsq, int64_t n, int D, int K, long long first,
-                                                 const double *__restrict__ u, int L, double *closest, double *cand,
-                                                 double *cum, double *chunk_tot, double *C, long long *chosen) {
+// sum of the 1024 per-thread partials in the oracle's order: 32 consecutive lanes in lane order, then the
+// 32 group sums in group order.  part: LDS [SEED_T]; result valid in every thread after the call.
+__device__ __forceinline__ double seed_reduce(double *part, double *grp, int tid) {
+  __syncthreads();
+  if (tid < SEED_T / SEED_GROUP) {
+    double gs = 0.0;
+    for (int t = 0; t < SEED_GROUP; t++) gs = gs + part[tid * SEED_GROUP + t];
+    grp[tid] = gs;
+  }
+  __syncthreads();
+  double s = 0.0;
+  for (int g = 0; g < SEED_T / SEED_GROUP; g++) s = s + grp[g];
+  return s;
+}
+
+// one workgroup per stratum runs all K-1 greedy steps
+__global__ __launch_bounds__(SEED_T) void k_seed(const SeedItem *__restrict__ items, int D) {
   extern __shared__ double sm[];
-  double *crow = sm;                       // [L][D] candidate rows
-  double *lpart = crow + SEED_LMAX * D;    // [L][SEED_T] strided partial potentials
-  double *pots = lpart + SEED_LMAX * SEED_T;  // [L]
+  const SeedItem it = items[blockIdx.x];
+  const long long n = it.n;
+  const int K = it.K, L = it.L;
+  double *crow = sm;                         // [LMAX][D] candidate rows
+  double *part = crow + SEED_LMAX * D;       // [LMAX][SEED_T] per-thread partial potentials
+  double *grp = part + SEED_LMAX * SEED_T;   // [LMAX][SEED_T/SEED_GROUP]
+  double *pots = grp + SEED_LMAX * (SEED_T / SEED_GROUP);  // [LMAX]
   __shared__ long long cid[SEED_LMAX];
   __shared__ double s_pot;
   __shared__ int s_best;
   const int tid = threadIdx.x;
+  const double *XbT = it.XbT;
 
   // first centre (_kmeans.py:225-238)
   for (int k = tid; k < D; k += SEED_T) {
-    crow[k] = Xb[first * D + k];
-    C[k] = crow[k];
+    double v = XbT[(size_t)k * n + it.first];
+    crow[k] = v;
+    it.C[k] = v;
   }
-  if (tid == 0) chosen[0] = first;
+  if (tid == 0) it.chosen[0] = it.first;
   __syncthreads();
   {
-    const double xs0 = xsq[first];
+    const double xs0 = it.xsq[it.first];
     double a = 0.0;
-    for (int64_t i = tid; i < n; i += SEED_T) {
+    for (long long i = tid; i < n; i += SEED_T) {
       double acc = 0.0;
-      for (int k = 0; k < D; k++) acc = __builtin_fma(crow[k], Xb[i * D + k], acc);
-      double v = ((-2.0 * acc) + xs0) + xsq[i];
+      for (int k = 0; k < D; k++) acc = __builtin_fma(crow[k], XbT[(size_t)k * n + i], acc);
+      double v = ((-2.0 * acc) + xs0) + it.xsq[i];
       v = v > 0.0 ? v : 0.0;
-      closest[i] = v;
-      a = a + v * w[i];
+      it.closest[i] = v;
+      a = a + v * it.w[i];
     }
-    lpart[tid] = a;
-    __syncthreads();
-    if (tid == 0) {
-      double s = 0.0;
-      for (int t = 0; t < SEED_T; t++) s = s + lpart[t];
-      s_pot = s;
-    }
+    part[tid] = a;
+    double s = seed_reduce(part, grp, tid);
+    if (tid == 0) s_pot = s;
     __syncthreads();
   }
-  const int64_t nch = (n + SCAN_CHUNK - 1) / SCAN_CHUNK;
+  const long long nch = (n + SCAN_CHUNK - 1) / SCAN_CHUNK;
   for (int cc = 1; cc < K; cc++) {
-    // chunked cumulative sum of w*closest (:243-247 stable_cumsum)
-    for (int64_t q = tid; q < nch; q += SEED_T) {
+    // chunked cumulative sum of w*closest (:243-247 stable_cumsum): chunk totals, then chunk bases
+    for (long long q = tid; q < nch; q += SEED_T) {
       double loc = 0.0;
-      int64_t e = (q + 1) * SCAN_CHUNK < n ? (q + 1) * SCAN_CHUNK : n;
-      for (int64_t i = q * SCAN_CHUNK; i < e; i++) loc = loc + w[i] * closest[i];
-      chunk_tot[q] = loc;
+      long long e = (q + 1) * SCAN_CHUNK < n ? (q + 1) * SCAN_CHUNK : n;
+      for (long long i = q * SCAN_CHUNK; i < e; i++) loc = loc + it.w[i] * it.closest[i];
+      it.chunk_tot[q] = loc;
     }
     __syncthreads();
     if (tid == 0) {
       double base = 0.0;
-      for (int64_t q = 0; q < nch; q++) {
-        double t = chunk_tot[q];
-        chunk_tot[q] = base;  // becomes the chunk's base
+      for (long long q = 0; q < nch; q++) {
+        double t = it.chunk_tot[q];
+        it.chunk_tot[q] = base;  // becomes the chunk's base
         base = base + t;
       }
     }
     __syncthreads();
-    for (int64_t q = tid; q < nch; q += SEED_T) {
-      double loc = 0.0, base = chunk_tot[q];
-      int64_t e = (q + 1) * SCAN_CHUNK < n ? (q + 1) * SCAN_CHUNK : n;
-      for (int64_t i = q * SCAN_CHUNK; i < e; i++) {
-        loc = loc + w[i] * closest[i];
-        cum[i] = base + loc;
-      }
-    }
-    __syncthreads();
+    // searchsorted(cum, u*pot, side='left') without materialising cum: last chunk whose base is < v, then
+    // the running sum inside it (cum[i] = base + loc, the oracle's values)
     if (tid < L) {
-      double v = u[(size_t)(cc - 1) * L + tid] * s_pot;  // :243
-      int64_t lo = 0, hi = n;                            // searchsorted side='left'
-      while (lo < hi) {
-        int64_t mid = (lo + hi) >> 1;
-        if (cum[mid] < v) lo = mid + 1;
+      const double v = it.u[(size_t)(cc - 1) * L + tid] * s_pot;  // :243
+      long long lo = 0, hi = nch;  // first chunk whose END value >= v  <=> first q with base[q+1] >= v
+      // chunk q ends with cum = base[q] + tot[q]; recompute per candidate chunk (monotone, so bisect on bases)
+      while (hi - lo > 1) {
+        long long mid = (lo + hi) >> 1;
+        if (it.chunk_tot[mid] < v) lo = mid;  // base[mid] < v: the answer is not before chunk mid-? (see below)
         else hi = mid;
       }
-      if (lo > n - 1) lo = n - 1;  // :249
-      cid[tid] = lo;
+      // candidates: chunk lo (base < v or lo == 0) -- the first index with cum >= v lies in chunk lo or is the
+      // first element of a later chunk; scan forward from the start of chunk lo
+      long long ans = n;
+      for (long long q = lo; q < nch && ans == n; q++) {
+        double loc = 0.0, base = it.chunk_tot[q];
+        long long e = (q + 1) * SCAN_CHUNK < n ? (q + 1) * SCAN_CHUNK : n;
+        for (long long i = q * SCAN_CHUNK; i < e; i++) {
+          loc = loc + it.w[i] * it.closest[i];
+          if (base + loc >= v) {
+            ans = i;
+            break;
+          }
+        }
+      }
+      if (ans > n - 1) ans = n - 1;  // :249 clip
+      cid[tid] = ans;
     }
     __syncthreads();
-    for (int e = tid; e < L * D; e += SEED_T) crow[e] = Xb[cid[e / D] * D + (e % D)];
+    for (int e = tid; e < L * D; e += SEED_T) crow[e] = XbT[(size_t)(e % D) * n + cid[e / D]];
     __syncthreads();
     {
       double a[SEED_LMAX];
+#pragma unroll
       for (int l = 0; l < SEED_LMAX; l++) a[l] = 0.0;
-      for (int64_t i = tid; i < n; i += SEED_T) {
+      for (long long i = tid; i < n; i += SEED_T) {
         double acc[SEED_LMAX];
+#pragma unroll
         for (int l = 0; l < SEED_LMAX; l++) acc[l] = 0.0;
         for (int k = 0; k < D; k++) {
-          double xi = Xb[i * D + k];
+          const double xi = XbT[(size_t)k * n + i];
+#pragma unroll
           for (int l = 0; l < SEED_LMAX; l++)
             if (l < L) acc[l] = __builtin_fma(crow[l * D + k], xi, acc[l]);
         }
-        const double ci = closest[i], xi2 = xsq[i], wi = w[i];
+        const double ci = it.closest[i], xi2 = it.xsq[i], wi = it.w[i];
+#pragma unroll
         for (int l = 0; l < SEED_LMAX; l++)
           if (l < L) {
-            double v = ((-2.0 * acc[l]) + xsq[cid[l]]) + xi2;  // euclidean_distances order (:252-254)
+            double v = ((-2.0 * acc[l]) + it.xsq[cid[l]]) + xi2;  // euclidean_distances order (:252-254)
             v = v > 0.0 ? v : 0.0;
             v = v < ci ? v : ci;  // :257 np.minimum
-            cand[(size_t)l * n + i] = v;
+            it.cand[(size_t)l * n + i] = v;
             a[l] = a[l] + v * wi;
           }
       }
-      for (int l = 0; l < L; l++) lpart[l * SEED_T + tid] = a[l];
+#pragma unroll
+      for (int l = 0; l < SEED_LMAX; l++)
+        if (l < L) part[l * SEED_T + tid] = a[l];
+    }
+    __syncthreads();
+    // potentials of the L candidates (:258), oracle order
+    for (int e = tid; e < L * (SEED_T / SEED_GROUP); e += SEED_T) {
+      int l = e / (SEED_T / SEED_GROUP), g = e % (SEED_T / SEED_GROUP);
+      double gs = 0.0;
+      for (int t = 0; t < SEED_GROUP; t++) gs = gs + part[l * SEED_T + g * SEED_GROUP + t];
+      grp[l * (SEED_T / SEED_GROUP) + g] = gs;
     }
     __syncthreads();
     if (tid < L) {
       double s = 0.0;
-      for (int t = 0; t < SEED_T; t++) s = s + lpart[tid * SEED_T + t];
-      pots[tid] = s;  // :258
+      for (int g = 0; g < SEED_T / SEED_GROUP; g++) s = s + grp[tid * (SEED_T / SEED_GROUP) + g];
+      pots[tid] = s;
     }
     __syncthreads();
     if (tid == 0) {
@@ -277,119 +356,351 @@ __global__ __launch_bounds__(SEED_T) void k_seed(const double *__restrict__ Xb, 
         }
       s_best = best;
       s_pot = bp;
-      chosen[cc] = cid[best];
+      it.chosen[cc] = cid[best];
     }
     __syncthreads();
     const int best = s_best;
-    for (int64_t i = tid; i < n; i += SEED_T) closest[i] = cand[(size_t)best * n + i];
-    for (int k = tid; k < D; k += SEED_T) C[(size_t)cc * D + k] = crow[best * D + k];
+    for (long long i = tid; i < n; i += SEED_T) it.closest[i] = it.cand[(size_t)best * n + i];
+    for (int k = tid; k < D; k += SEED_T) it.C[(size_t)cc * D + k] = crow[best * D + k];
     __syncthreads();
   }
 }
 
-extern "C" int hamsm_kmeans_seed(hamsm_ctx *c, int s, const void *X, int dt, int64_t ldx, const int32_t *rows, int64_t n_b,
-                                 const double *wf, const int64_t *h_sub, int64_t n_sub, int K, int64_t first,
-                                 const double *h_u, int L, int64_t *h_chosen) {
-  if (c->st.empty() || s < 0 || s >= c->S) return hamsm_fail(c, HAMSM_EINVAL, "bad stratum");
+extern "C" int hamsm_kmeans_seed_multi(hamsm_ctx *c, int n_items, const int32_t *h_stratum, const void *X, int dt, int64_t ldx,
+                                       const int64_t *h_x_off, const int32_t *d_rows, const int64_t *h_rows_off,
+                                       const int64_t *h_n_b, const double *d_w, const int64_t *h_sub, const int64_t *h_n_sub,
+                                       const int32_t *h_K, const int64_t *h_first, const double *h_u, const int32_t *h_L) {
+  if (n_items <= 0) return HAMSM_OK;
+  if (c->st.empty()) return hamsm_fail(c, HAMSM_EINVAL, "set_geometry first");
   const int D = c->D;
-  const int64_t n = h_sub ? n_sub : n_b;
-  if (K < 1 || n < 1 || first < 0 || first >= n || L < 1 || L > SEED_LMAX) return hamsm_fail(c, HAMSM_EINVAL, "bad seed args");
-  int rc = hamsm_stratum_reserve(c, s, K);
-  if (rc) return rc;
-  Stratum &t = c->st[s];
-  const int64_t nch = (n + SCAN_CHUNK - 1) / SCAN_CHUNK;
-  // scratch: Xb[n*D] w[n] xsq[n] closest[n] cum[n] cand[L*n] chunk_tot[nch] u[(K-1)*L] chosen[K] sub[n]
+  const size_t esz = dt == HAMSM_F32 ? 4 : 8;
   size_t off = 0;
   auto take = [&](size_t bytes) {
     size_t o = off;
     off = (off + bytes + 255) & ~(size_t)255;
     return o;
   };
-  size_t o_Xb = take(sizeof(double) * n * D), o_w = take(sizeof(double) * n), o_xs = take(sizeof(double) * n),
-         o_cl = take(sizeof(double) * n), o_cum = take(sizeof(double) * n), o_cand = take(sizeof(double) * n * L),
-         o_ct = take(sizeof(double) * nch), o_u = take(sizeof(double) * (size_t)(K > 1 ? (K - 1) * L : 1)),
-         o_ch = take(sizeof(long long) * K), o_sub = take(sizeof(long long) * (h_sub ? n : 1));
-  rc = hamsm_ensure_scratch(c, off);
+  struct Lay {
+    size_t XbT, w, xsq, cl, cum, cand, ct, u, ch, sub;
+    int64_t n;
+  };
+  std::vector<Lay> lay(n_items);
+  size_t o_items = take(sizeof(SeedItem) * n_items);
+  size_t tot_u = 0, tot_sub = 0;
+  int64_t nmax = 0;
+  for (int i = 0; i < n_items; i++) {
+    int s = h_stratum[i];
+    if (s < 0 || s >= c->S) return hamsm_fail(c, HAMSM_EINVAL, "bad stratum");
+    for (int j = 0; j < i; j++)
+      if (h_stratum[j] == s) return hamsm_fail(c, HAMSM_EINVAL, "stratum %d seeded twice in one call", s);
+    int64_t n = h_n_sub[i] ? h_n_sub[i] : h_n_b[i];
+    int K = h_K[i], L = h_L[i];
+    if (K < 1 || n < 1 || h_first[i] < 0 || h_first[i] >= n || L < 1 || L > SEED_LMAX)
+      return hamsm_fail(c, HAMSM_EINVAL, "bad seed args for stratum %d", s);
+    int rc = hamsm_stratum_reserve(c, s, K);
+    if (rc) return rc;
+    Lay &l = lay[i];
+    l.n = n;
+    if (n > nmax) nmax = n;
+    int64_t nch = (n + SCAN_CHUNK - 1) / SCAN_CHUNK;
+    l.XbT = take(sizeof(double) * n * D);
+    l.w = take(sizeof(double) * n);
+    l.xsq = take(sizeof(double) * n);
+    l.cl = take(sizeof(double) * n);
+    l.cum = take(sizeof(double) * 1);
+    l.cand = take(sizeof(double) * n * L);
+    l.ct = take(sizeof(double) * nch);
+    l.u = take(sizeof(double) * (size_t)(K > 1 ? (K - 1) * L : 1));
+    l.ch = take(sizeof(long long) * K);
+    l.sub = take(sizeof(long long) * (h_n_sub[i] ? h_n_sub[i] : 1));
+    tot_u += (size_t)(K - 1) * L;
+    tot_sub += h_n_sub[i];
+  }
+  int rc = hamsm_ensure_scratch(c, off);
   if (rc) return rc;
   char *b = (char *)c->scratch;
-  if (K > 1) HIPCHK(c, hipMemcpyAsync(b + o_u, h_u, sizeof(double) * (size_t)(K - 1) * L, hipMemcpyHostToDevice, c->stream));
-  if (h_sub) HIPCHK(c, hipMemcpyAsync(b + o_sub, h_sub, sizeof(long long) * n, hipMemcpyHostToDevice, c->stream));
+  std::vector<SeedItem> items(n_items);
+  const double *up = h_u;
+  const int64_t *sp = h_sub;
+  for (int i = 0; i < n_items; i++) {
+    const Lay &l = lay[i];
+    int K = h_K[i], L = h_L[i];
+    SeedItem &it = items[i];
+    it.X = (const char *)X + (size_t)h_x_off[i] * ldx * esz;
+    it.rows = d_rows ? d_rows + h_rows_off[i] : nullptr;
+    it.sub = h_n_sub[i] ? (const long long *)(b + l.sub) : nullptr;
+    it.wf = d_w ? d_w + h_x_off[i] : nullptr;
+    it.u = (const double *)(b + l.u);
+    it.n = l.n;
+    it.first = h_first[i];
+    it.K = K;
+    it.L = L;
+    it.XbT = (double *)(b + l.XbT);
+    it.w = (double *)(b + l.w);
+    it.xsq = (double *)(b + l.xsq);
+    it.closest = (double *)(b + l.cl);
+    it.cum = (double *)(b + l.cum);
+    it.cand = (double *)(b + l.cand);
+    it.chunk_tot = (double *)(b + l.ct);
+    it.C = c->st[h_stratum[i]].C;
+    it.chosen = (long long *)(b + l.ch);
+    if (K > 1) HIPCHK(c, hipMemcpyAsync(b + l.u, up, sizeof(double) * (size_t)(K - 1) * L, hipMemcpyHostToDevice, c->stream));
+    if (h_n_sub[i]) HIPCHK(c, hipMemcpyAsync(b + l.sub, sp, sizeof(long long) * h_n_sub[i], hipMemcpyHostToDevice, c->stream));
+    up += (size_t)(K - 1) * L;
+    sp += h_n_sub[i];
+  }
+  HIPCHK(c, hipMemcpyAsync(b + o_items, items.data(), sizeof(SeedItem) * n_items, hipMemcpyHostToDevice, c->stream));
   hamsm_timer_begin(c);
-  const long long *d_sub = h_sub ? (const long long *)(b + o_sub) : nullptr;
-  unsigned grid = (unsigned)((n + 255) / 256);
+  dim3 gg((unsigned)((nmax + 255) / 256), (unsigned)n_items);
   if (dt == HAMSM_F32)
-    hipLaunchKernelGGL(k_seed_gather<float>, dim3(grid), dim3(256), 0, c->stream, (const float *)X, ldx, D, rows, d_sub, n, wf,
-                       (double *)(b + o_Xb), (double *)(b + o_w), (double *)(b + o_xs));
+    hipLaunchKernelGGL(k_seed_gather<float>, gg, dim3(256), 0, c->stream, (const SeedItem *)(b + o_items), ldx, D);
   else
-    hipLaunchKernelGGL(k_seed_gather<double>, dim3(grid), dim3(256), 0, c->stream, (const double *)X, ldx, D, rows, d_sub, n,
-                       wf, (double *)(b + o_Xb), (double *)(b + o_w), (double *)(b + o_xs));
-  size_t lds = sizeof(double) * ((size_t)SEED_LMAX * D + (size_t)SEED_LMAX * SEED_T + SEED_LMAX);
+    hipLaunchKernelGGL(k_seed_gather<double>, gg, dim3(256), 0, c->stream, (const SeedItem *)(b + o_items), ldx, D);
+  size_t lds = sizeof(double) * ((size_t)SEED_LMAX * D + (size_t)SEED_LMAX * SEED_T + SEED_LMAX * (SEED_T / SEED_GROUP) + SEED_LMAX);
   HIPCHK(c, hipFuncSetAttribute((const void *)k_seed, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  hipLaunchKernelGGL(k_seed, dim3(1), dim3(SEED_T), lds, c->stream, (const double *)(b + o_Xb), (const double *)(b + o_w),
-                     (const double *)(b + o_xs), n, D, K, (long long)first, (const double *)(b + o_u), L,
-                     (double *)(b + o_cl), (double *)(b + o_cand), (double *)(b + o_cum), (double *)(b + o_ct), t.C,
-                     (long long *)(b + o_ch));
+  hipLaunchKernelGGL(k_seed, dim3((unsigned)n_items), dim3(SEED_T), lds, c->stream, (const SeedItem *)(b + o_items), D);
   HIPCHK(c, hipGetLastError());
-  t.K = K;
+  for (int i = 0; i < n_items; i++) {
+    int s = h_stratum[i];
+    Stratum &t = c->st[s];
+    t.K = h_K[i];
+    HIPCHK(c, hipMemsetAsync(t.counts, 0, sizeof(double) * t.K, c->stream));  // _kmeans.py:2271
+    rc = hamsm_pack_stratum(c, s, nullptr);
+    if (rc) return rc;
+  }
   c->table_dirty = true;
-  HIPCHK(c, hipMemsetAsync(t.counts, 0, sizeof(double) * K, c->stream));  // _kmeans.py:2271
-  rc = hamsm_pack_stratum(c, s, nullptr);
   hamsm_timer_end(c, ST_SEED);
-  if (rc) return rc;
-  if (h_chosen) HIPCHK(c, hipMemcpyAsync(h_chosen, b + o_ch, sizeof(long long) * K, hipMemcpyDeviceToHost, c->stream));
-  HIPCHK(c, hipStreamSynchronize(c->stream));  // host draw buffers are the caller's
+  // h_u / h_sub were pageable host memory: hipMemcpyAsync staged them before returning, no sync needed.
+  c->seed_chosen_dev = b + lay[0].ch;  // hamsm_kmeans_seed reads item 0's choices
   return HAMSM_OK;
 }
 
-// ---- minibatch update: one wave per cluster, lanes = features, samples in ascending order ---------
-// _k_means_minibatch.pyx:59-108
-template <typename XT>
-__global__ __launch_bounds__(256) void k_update(const XT *__restrict__ X, int64_t ldx, int D, int KS,
-                                                const int32_t *__restrict__ rows, int64_t n_b,
-                                                const double *__restrict__ wf, const int32_t *__restrict__ lab, int K,
-                                                double *C, double *counts, double *csq, double *Bpack) {
-  const int lane = threadIdx.x & 63;
-  const int j = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (j >= K) return;
-  // pass 1: wsum in sample order (pyx:80-85)
-  double wsum = 0.0;
-  bool any = false;
-  for (int64_t base = 0; base < n_b; base += 64) {
-    int64_t i = base + lane;
-    bool mt = (i < n_b) && (lab[i] == j);
-    unsigned long long mask = __ballot(mt);
-    any |= mask != 0;
-    while (mask) {
-      int bpos = __ffsll((long long)mask) - 1;
-      mask &= mask - 1;
-      int64_t ii = base + bpos;
-      int64_t f = rows ? (int64_t)rows[ii] : ii;
-      wsum = wsum + (wf ? wf[f] : 1.0);
+extern "C" int hamsm_kmeans_seed(hamsm_ctx *c, int s, const void *X, int dt, int64_t ldx, const int32_t *rows, int64_t n_b,
+                                 const double *wf, const int64_t *h_sub, int64_t n_sub, int K, int64_t first,
+                                 const double *h_u, int L, int64_t *h_chosen) {
+  int32_t st = s, k = K, l = L;
+  int64_t zero = 0, nb = n_b, ns = h_sub ? n_sub : 0, f = first;
+  int rc = hamsm_kmeans_seed_multi(c, 1, &st, X, dt, ldx, &zero, rows, &zero, &nb, wf, h_sub, &ns, &k, &f, h_u, &l);
+  if (rc) return rc;
+  if (h_chosen) HIPCHK(c, hipMemcpyAsync(h_chosen, c->seed_chosen_dev, sizeof(long long) * K, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return HAMSM_OK;
+}
+
+// ---- minibatch steps ------------------------------------------------------------------------------
+struct StepDev {
+  const void *X;         // frame 0 of the step's call
+  const int32_t *rows;   // batch row list (nullable = identity)
+  const double *wf;      // nullable, indexed like X
+  long long n_b;
+  int32_t *labels;       // [n_b] scratch
+  double *C, *counts, *csq, *Bpack;
+  int K, flags;
+  int32_t *report;       // [2]
+};
+
+// E-step: one workgroup per 16-row tile; the stratum's centroid tiles are split over the 4 waves, each wave
+// issues ALL of its B-fragment loads before the first MFMA (one L2 round trip), then the 4 partial
+// first-minima are combined through LDS.
+template <typename XT, int KS, int JB>
+__global__ __launch_bounds__(256) void k_step_assign(const StepDev *__restrict__ steps, int64_t ldx, int D) {
+  const StepDev st = steps[blockIdx.y];
+  const long long r0 = (long long)blockIdx.x * 16;
+  if (r0 >= st.n_b) return;
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  if (blockIdx.x == 0 && (st.flags & 2)) {
+    // `(self._counts == 0).any()` before the step (_kmeans.py:2037)
+    int z = 0;
+    for (int j = tid; j < st.K; j += 256) z |= (st.counts[j] == 0.0);
+    if (z) atomicOr(&st.report[0], 1);
+  }
+  const XT *X = (const XT *)st.X;
+  const long long r = r0 + (lane & 15);
+  const bool ok = r < st.n_b;
+  const long long f = ok ? (st.rows ? (long long)st.rows[r] : r) : 0;
+  double a[KS];
+#pragma unroll
+  for (int ks = 0; ks < KS; ks++) {
+    int k = ks * 4 + (lane >> 4);
+    a[ks] = (ok && k < D) ? (double)X[f * ldx + k] : 0.0;
+  }
+  const int njt = (st.K + 15) >> 4;
+  const double inf = __builtin_huge_val();
+  double bd[4];
+  int bi[4];
+#pragma unroll
+  for (int q = 0; q < 4; q++) {
+    bd[q] = inf;
+    bi[q] = 0x7fffffff;
+  }
+  for (int t0 = wv; t0 < njt; t0 += 4 * JB) {
+    double b[JB][KS], cs[JB];
+#pragma unroll
+    for (int u = 0; u < JB; u++) {
+      int jt = t0 + 4 * u;
+      bool live = jt < njt;
+      cs[u] = live ? st.csq[jt * 16 + (lane & 15)] : inf;
+#pragma unroll
+      for (int ks = 0; ks < KS; ks++) b[u][ks] = live ? st.Bpack[((size_t)jt * KS + ks) * 64 + lane] : 0.0;
+    }
+#pragma unroll
+    for (int u = 0; u < JB; u++) {
+      int jt = t0 + 4 * u;
+      if (jt < njt) {
+        v4f64 acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int ks = 0; ks < KS; ks++) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[ks], b[u][ks], acc, 0, 0, 0);
+        const int j = jt * 16 + (lane & 15);
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+          double d = __builtin_fma(-2.0, acc[q], cs[u]);
+          bool lt = d < bd[q];  // a wave's tiles ascend, so strict < keeps its lowest j
+          bd[q] = lt ? d : bd[q];
+          bi[q] = lt ? j : bi[q];
+        }
+      }
     }
   }
+  __shared__ double sd[4][16];
+  __shared__ int sj[4][16];
+#pragma unroll
+  for (int q = 0; q < 4; q++) {
+    double d = bd[q];
+    int j = bi[q];
+#pragma unroll
+    for (int off = 8; off >= 1; off >>= 1) {
+      double d2 = __shfl_xor(d, off, 16);
+      int j2 = __shfl_xor(j, off, 16);
+      bool take = (d2 < d) || (d2 == d && j2 < j);
+      d = take ? d2 : d;
+      j = take ? j2 : j;
+    }
+    if ((lane & 15) == 0) {
+      int row = (lane >> 4) + 4 * q;
+      sd[wv][row] = d;
+      sj[wv][row] = j;
+    }
+  }
+  __syncthreads();
+  if (tid < 16 && r0 + tid < st.n_b) {
+    double d = sd[0][tid];
+    int j = sj[0][tid];
+#pragma unroll
+    for (int w = 1; w < 4; w++) {
+      double d2 = sd[w][tid];
+      int j2 = sj[w][tid];
+      bool take = (d2 < d) || (d2 == d && j2 < j);
+      d = take ? d2 : d;
+      j = take ? j2 : j;
+    }
+    if (j == 0x7fffffff) j = 0;  // all-NaN row: label 0 like the oracle
+    st.labels[r0 + tid] = j;
+  }
+}
+
+// M-step: one wave per centroid; the step's labels are scanned from LDS, member rows are fetched 8 at a
+// time and added in ascending sample order (_k_means_minibatch.pyx:59-108).
+#define UPD_LABEL_CAP 16384
+#define UPD_LIST 512
+template <typename XT>
+__global__ __launch_bounds__(256) void k_step_update(const StepDev *__restrict__ steps, int64_t ldx, int D, int KS) {
+  const StepDev st = steps[blockIdx.y];
+  if (blockIdx.x * 4 >= st.K) return;
+  extern __shared__ int lds_i[];
+  int *slab = lds_i;                                        // [min(n_b, CAP)] labels
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const bool in_lds = st.n_b <= UPD_LABEL_CAP;
+  int *list = lds_i + (in_lds ? (int)st.n_b : 0) + wv * UPD_LIST;  // [UPD_LIST] member batch of this wave
+  if (in_lds) {
+    for (long long i = threadIdx.x; i < st.n_b; i += 256) slab[i] = st.labels[i];
+    __syncthreads();
+  }
+  const int *lab = in_lds ? slab : st.labels;
+  const int j = blockIdx.x * 4 + wv;
+  if (j >= st.K) return;
+  const XT *X = (const XT *)st.X;
+  const long long n_b = st.n_b;
+
+  // pass 1: wsum in sample order (pyx:80-85); unweighted: the sum of `cnt` ones is exactly cnt
+  double wsum = 0.0;
+  {
+    long long cnt = 0;
+    int fill = 0;
+    for (long long base = 0; base < n_b; base += 64) {
+      long long i = base + lane;
+      bool mt = (i < n_b) && (lab[i] == j);
+      unsigned long long mask = __ballot(mt);
+      if (!mask) continue;
+      if (!st.wf) {
+        cnt += __popcll(mask);
+        continue;
+      }
+      if (mt) list[fill + __popcll(mask & ((1ull << lane) - 1))] = (int)i;
+      fill += __popcll(mask);
+      if (fill > UPD_LIST - 64 || base + 64 >= n_b) {
+        for (int m0 = 0; m0 < fill; m0 += 64) {
+          int ii = (m0 + lane < fill) ? list[m0 + lane] : -1;
+          double wv_ = 0.0;
+          if (ii >= 0) wv_ = st.wf[st.rows ? (long long)st.rows[ii] : (long long)ii];
+          int lim = fill - m0 < 64 ? fill - m0 : 64;
+          for (int q = 0; q < lim; q++) wsum = wsum + __shfl(wv_, q, 64);
+        }
+        fill = 0;
+      }
+    }
+    if (st.wf && fill) {
+      for (int m0 = 0; m0 < fill; m0 += 64) {
+        int ii = (m0 + lane < fill) ? list[m0 + lane] : -1;
+        double wv_ = 0.0;
+        if (ii >= 0) wv_ = st.wf[st.rows ? (long long)st.rows[ii] : (long long)ii];
+        int lim = fill - m0 < 64 ? fill - m0 : 64;
+        for (int q = 0; q < lim; q++) wsum = wsum + __shfl(wv_, q, 64);
+      }
+    }
+    if (!st.wf) wsum = (double)cnt;
+  }
   if (!(wsum > 0)) return;  // pyx:87 / :105-108: centre unchanged
+
   // pass 2: c = c*count; c += x*w in sample order; count += wsum; c *= 1/count  (pyx:89-104)
-  const double cnt0 = counts[j];
+  const double cnt0 = st.counts[j];
   double acc[2];
 #pragma unroll
   for (int h = 0; h < 2; h++) {
     int k = lane + 64 * h;
-    acc[h] = (k < D) ? C[(size_t)j * D + k] * cnt0 : 0.0;
+    acc[h] = (k < D) ? st.C[(size_t)j * D + k] * cnt0 : 0.0;
   }
-  for (int64_t base = 0; base < n_b; base += 64) {
-    int64_t i = base + lane;
-    bool mt = (i < n_b) && (lab[i] == j);
-    unsigned long long mask = __ballot(mt);
-    while (mask) {
-      int bpos = __ffsll((long long)mask) - 1;
-      mask &= mask - 1;
-      int64_t ii = base + bpos;
-      int64_t f = rows ? (int64_t)rows[ii] : ii;
-      double wi = wf ? wf[f] : 1.0;
+  {
+    int fill = 0;
+    for (long long base = 0; base < n_b; base += 64) {
+      long long i = base + lane;
+      bool mt = (i < n_b) && (lab[i] == j);
+      unsigned long long mask = __ballot(mt);
+      if (mask) {
+        if (mt) list[fill + __popcll(mask & ((1ull << lane) - 1))] = (int)i;
+        fill += __popcll(mask);
+      }
+      if (fill && (fill > UPD_LIST - 64 || base + 64 >= n_b)) {
+        for (int m0 = 0; m0 < fill; m0 += 8) {
+          double xv[8][2], wq[8];
 #pragma unroll
-      for (int h = 0; h < 2; h++) {
-        int k = lane + 64 * h;
-        if (k < D) acc[h] = acc[h] + (double)X[f * ldx + k] * wi;
+          for (int q = 0; q < 8; q++) {
+            int ii = (m0 + q < fill) ? list[m0 + q] : -1;
+            long long f = ii >= 0 ? (st.rows ? (long long)st.rows[ii] : (long long)ii) : 0;
+            wq[q] = (ii >= 0) ? (st.wf ? st.wf[f] : 1.0) : 0.0;
+#pragma unroll
+            for (int h = 0; h < 2; h++) {
+              int k = lane + 64 * h;
+              xv[q][h] = (ii >= 0 && k < D) ? (double)X[f * ldx + k] : 0.0;
+            }
+          }
+#pragma unroll
+          for (int q = 0; q < 8; q++)
+            if (m0 + q < fill) {
+#pragma unroll
+              for (int h = 0; h < 2; h++) acc[h] = acc[h] + xv[q][h] * wq[q];
+            }
+        }
+        fill = 0;
       }
     }
   }
@@ -401,45 +712,169 @@ __global__ __launch_bounds__(256) void k_update(const XT *__restrict__ X, int64_
     int k = lane + 64 * h;
     v[h] = acc[h] * alpha;
     if (k < D) {
-      C[(size_t)j * D + k] = v[h];
-      Bpack[((size_t)(j >> 4) * KS + (k >> 2)) * 64 + (k & 3) * 16 + (j & 15)] = v[h];
+      st.C[(size_t)j * D + k] = v[h];
+      st.Bpack[((size_t)(j >> 4) * KS + (k >> 2)) * 64 + (k & 3) * 16 + (j & 15)] = v[h];
     }
   }
-  if (lane == 0) counts[j] = cnt1;
+  if (lane == 0) st.counts[j] = cnt1;
   // ||c||^2 as an fma chain over ascending k (oracle sqnorm_chain): lane values broadcast in order
   double a = 0.0;
   for (int k = 0; k < D; k++) {
     double vk = __shfl(k < 64 ? v[0] : v[1], k & 63, 64);
     a = __builtin_fma(vk, vk, a);
   }
-  if (lane == 0) csq[j] = a;
+  if (lane == 0) st.csq[j] = a;
+}
+
+// after the update: number of centroids with count < ratio * max(count)  (_kmeans.py:1645)
+__global__ __launch_bounds__(256) void k_step_check(const StepDev *__restrict__ steps, double ratio) {
+  const StepDev st = steps[blockIdx.x];
+  if (!(st.flags & 1)) return;
+  __shared__ double smax[256];
+  __shared__ int slow[256];
+  double mx = -__builtin_huge_val();
+  for (int j = threadIdx.x; j < st.K; j += 256) mx = st.counts[j] > mx ? st.counts[j] : mx;
+  smax[threadIdx.x] = mx;
+  __syncthreads();
+  for (int o = 128; o >= 1; o >>= 1) {
+    if (threadIdx.x < o) smax[threadIdx.x] = smax[threadIdx.x + o] > smax[threadIdx.x] ? smax[threadIdx.x + o] : smax[threadIdx.x];
+    __syncthreads();
+  }
+  const double thr = ratio * smax[0];
+  int low = 0;
+  for (int j = threadIdx.x; j < st.K; j += 256) low += st.counts[j] < thr;
+  slow[threadIdx.x] = low;
+  __syncthreads();
+  for (int o = 128; o >= 1; o >>= 1) {
+    if (threadIdx.x < o) slow[threadIdx.x] += slow[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) st.report[1] = slow[0];
+}
+
+template <typename XT, int KS>
+static void launch_step_kernels(hamsm_ctx *c, const StepDev *d_steps, int ny, long long max_nb, int maxK, int any_check,
+                                int64_t ldx, double ratio) {
+  constexpr int JB = KS <= 4 ? 8 : (KS <= 8 ? 4 : (KS <= 16 ? 2 : 1));
+  dim3 ga((unsigned)((max_nb + 15) / 16), (unsigned)ny);
+  hipLaunchKernelGGL((k_step_assign<XT, KS, JB>), ga, dim3(256), 0, c->stream, d_steps, ldx, c->D);
+  size_t lds = sizeof(int) * ((size_t)(max_nb <= UPD_LABEL_CAP ? max_nb : 0) + 4 * UPD_LIST);
+  dim3 gu((unsigned)((maxK + 3) / 4), (unsigned)ny);
+  hipLaunchKernelGGL(k_step_update<XT>, gu, dim3(256), lds, c->stream, d_steps, ldx, c->D, c->KS);
+  if (any_check) hipLaunchKernelGGL(k_step_check, dim3((unsigned)ny), dim3(256), 0, c->stream, d_steps, ratio);
+}
+
+template <typename XT>
+static int launch_steps(hamsm_ctx *c, const StepDev *d_steps, int ny, long long max_nb, int maxK, int any_check, int64_t ldx,
+                        double ratio) {
+  switch (c->KS) {
+#define CASE(KSV)                                                                      \
+  case KSV:                                                                            \
+    launch_step_kernels<XT, KSV>(c, d_steps, ny, max_nb, maxK, any_check, ldx, ratio); \
+    break;
+    CASE(1) CASE(2) CASE(3) CASE(4) CASE(6) CASE(8) CASE(12) CASE(16) CASE(24) CASE(32)
+#undef CASE
+    default: return hamsm_fail(c, HAMSM_ENOTSUP, "KS=%d", c->KS);
+  }
+  return HAMSM_OK;
+}
+
+// steps [0,n): consecutive steps of distinct strata share launches (grid.y)
+static int run_steps(hamsm_ctx *c, const void *X, int dt, int64_t ldx, const int32_t *d_rows, const double *d_w,
+                     const hamsm_step *h_steps, int64_t n_steps, double ratio, int32_t *h_report, int want_zero_flag,
+                     int32_t **labels_of_first) {
+  const size_t esz = dt == HAMSM_F32 ? 4 : 8;
+  int64_t lab_hi = 0;
+  for (int64_t i = 0; i < n_steps; i++) {
+    const hamsm_step &s = h_steps[i];
+    if (s.stratum < 0 || s.stratum >= c->S) return hamsm_fail(c, HAMSM_EINVAL, "bad stratum in step %lld", (long long)i);
+    if (c->st[s.stratum].K == 0) return hamsm_fail(c, HAMSM_EUNFIT, "stratum %d has no centroids", s.stratum);
+    if (s.n_b < 0 || s.rows_off < 0) return hamsm_fail(c, HAMSM_EINVAL, "bad step %lld", (long long)i);
+    int64_t hi = (d_rows ? s.rows_off : 0) + s.n_b;
+    if (hi > lab_hi) lab_hi = hi;
+  }
+  size_t off = 0;
+  auto take = [&](size_t bytes) {
+    size_t o = off;
+    off = (off + bytes + 255) & ~(size_t)255;
+    return o;
+  };
+  size_t o_steps = take(sizeof(StepDev) * n_steps), o_rep = take(sizeof(int32_t) * 2 * n_steps),
+         o_lab = take(sizeof(int32_t) * (size_t)lab_hi);
+  int rc = hamsm_ensure_scratch(c, off);
+  if (rc) return rc;
+  char *b = (char *)c->scratch;
+  std::vector<StepDev> sd(n_steps);
+  for (int64_t i = 0; i < n_steps; i++) {
+    const hamsm_step &s = h_steps[i];
+    Stratum &t = c->st[s.stratum];
+    StepDev &d = sd[i];
+    d.X = (const char *)X + (size_t)s.x_off * ldx * esz;
+    d.rows = d_rows ? d_rows + s.rows_off : nullptr;
+    d.wf = d_w ? d_w + s.x_off : nullptr;
+    d.n_b = s.n_b;
+    d.labels = (int32_t *)(b + o_lab) + (d_rows ? s.rows_off : 0);
+    d.C = t.C;
+    d.counts = t.counts;
+    d.csq = t.csq;
+    d.Bpack = t.Bpack;
+    d.K = t.K;
+    d.flags = (s.flags & 1) | (want_zero_flag ? 2 : 0);
+    d.report = (int32_t *)(b + o_rep) + 2 * i;
+  }
+  if (labels_of_first) *labels_of_first = sd[0].labels;
+  HIPCHK(c, hipMemcpyAsync(b + o_steps, sd.data(), sizeof(StepDev) * n_steps, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemsetAsync(b + o_rep, 0, sizeof(int32_t) * 2 * n_steps, c->stream));
+  const StepDev *d_steps = (const StepDev *)(b + o_steps);
+  hamsm_timer_begin(c);
+  std::vector<char> used(c->S);
+  int64_t i = 0;
+  while (i < n_steps) {
+    std::fill(used.begin(), used.end(), 0);
+    int64_t j = i;
+    long long max_nb = 0;
+    int maxK = 0, any_check = 0;
+    while (j < n_steps && !used[h_steps[j].stratum] && j - i < 65535) {
+      used[h_steps[j].stratum] = 1;
+      if (h_steps[j].n_b > max_nb) max_nb = h_steps[j].n_b;
+      if (c->st[h_steps[j].stratum].K > maxK) maxK = c->st[h_steps[j].stratum].K;
+      any_check |= h_steps[j].flags & 1;
+      j++;
+    }
+    if (max_nb > 0) {
+      rc = (dt == HAMSM_F32) ? launch_steps<float>(c, d_steps + i, (int)(j - i), max_nb, maxK, any_check, ldx, ratio)
+                             : launch_steps<double>(c, d_steps + i, (int)(j - i), max_nb, maxK, any_check, ldx, ratio);
+      if (rc) return rc;
+    }
+    i = j;
+  }
+  hamsm_timer_end(c, ST_STEP);
+  HIPCHK(c, hipGetLastError());
+  if (h_report) {
+    HIPCHK(c, hipMemcpyAsync(h_report, b + o_rep, sizeof(int32_t) * 2 * n_steps, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+  }
+  return HAMSM_OK;
+}
+
+extern "C" int hamsm_minibatch_run(hamsm_ctx *c, const void *X, int dt, int64_t ldx, const int32_t *d_rows, const double *d_w,
+                                   const hamsm_step *h_steps, int64_t n_steps, double ratio, int32_t *h_report) {
+  if (c->st.empty()) return hamsm_fail(c, HAMSM_EINVAL, "set_geometry first");
+  if (n_steps <= 0) return HAMSM_OK;
+  return run_steps(c, X, dt, ldx, d_rows, d_w, h_steps, n_steps, ratio, h_report, 1, nullptr);
 }
 
 extern "C" int hamsm_minibatch_step(hamsm_ctx *c, int s, const void *X, int dt, int64_t ldx, const int32_t *rows, int64_t n_b,
                                     const double *wf, int32_t *labels_out) {
   if (c->st.empty() || s < 0 || s >= c->S) return hamsm_fail(c, HAMSM_EINVAL, "bad stratum");
-  Stratum &t = c->st[s];
-  if (t.K == 0) return hamsm_fail(c, HAMSM_EUNFIT, "stratum %d has no centroids", s);
+  if (c->st[s].K == 0) return hamsm_fail(c, HAMSM_EUNFIT, "stratum %d has no centroids", s);
   if (n_b <= 0) return HAMSM_OK;
-  int32_t *lab = labels_out;
-  if (!lab) {
-    // labels scratch lives at the end of the scratch arena so that it does not alias seed buffers in flight
-    int rc = hamsm_ensure_scratch(c, sizeof(int32_t) * (size_t)n_b + 256);
-    if (rc) return rc;
-    lab = (int32_t *)c->scratch;
-  }
-  hamsm_timer_begin(c);
-  int rc = hamsm_assign_rows(c, s, X, dt, ldx, rows, n_b, lab);
+  // the row list becomes the step's d_rows (offset 0): labels scratch is indexed by batch position
+  hamsm_step st{s, 0, 0, 0, n_b};
+  int32_t *lab = nullptr;
+  int rc = run_steps(c, X, dt, ldx, rows, wf, &st, 1, 0.0, nullptr, 0, &lab);
   if (rc) return rc;
-  unsigned grid = (unsigned)((t.K + 3) / 4);
-  if (dt == HAMSM_F32)
-    hipLaunchKernelGGL(k_update<float>, dim3(grid), dim3(256), 0, c->stream, (const float *)X, ldx, c->D, c->KS, rows, n_b, wf,
-                       lab, t.K, t.C, t.counts, t.csq, t.Bpack);
-  else
-    hipLaunchKernelGGL(k_update<double>, dim3(grid), dim3(256), 0, c->stream, (const double *)X, ldx, c->D, c->KS, rows, n_b,
-                       wf, lab, t.K, t.C, t.counts, t.csq, t.Bpack);
-  hamsm_timer_end(c, ST_STEP);
-  HIPCHK(c, hipGetLastError());
+  if (labels_out) HIPCHK(c, hipMemcpyAsync(labels_out, lab, sizeof(int32_t) * n_b, hipMemcpyDeviceToDevice, c->stream));
   return HAMSM_OK;
 }
 

@@ -26,7 +26,8 @@
 #include <string.h>
 
 #define MAX_NDIM 8
-#define POT_LANES 256 /* strided partial sums for potentials */
+#define POT_LANES 1024 /* strided partial sums for potentials */
+#define POT_GROUP 32   /* lanes per second-level group        */
 #define SCAN_CHUNK 64 /* chunked cumulative sum              */
 
 typedef struct {
@@ -503,17 +504,23 @@ static void load_row(double *dst, const void *X, int dt, int64_t ldx, int64_t f,
   for (int k = 0; k < D; k++) dst[k] = xval(X, dt, f * ldx + k);
 }
 
-/* potentials: POT_LANES strided partial sums (lane t sums i = t, t+L, ... ascending, fma-free),
- * then the partials are added in lane order.  (sklearn: `@` via BLAS, order unspecified.) */
+/* potentials (sklearn: `@` via BLAS, order unspecified).  Fixed order, chosen so that a 1024-thread
+ * workgroup reproduces it without serial bottlenecks: POT_LANES strided partials (lane t sums
+ * d[i]*w[i] over i = t, t+POT_LANES, ... ascending, multiply then add), POT_GROUP consecutive lanes
+ * are added in lane order, and the group sums are added in group order. */
 static double pot_sum(const double *d, const double *w, int64_t n) {
-  double part[POT_LANES];
-  for (int t = 0; t < POT_LANES; t++) {
-    double a = 0.0;
-    for (int64_t i = t; i < n; i += POT_LANES) a = a + d[i] * w[i];
-    part[t] = a;
+  double grp[POT_LANES / POT_GROUP];
+  for (int g = 0; g < POT_LANES / POT_GROUP; g++) {
+    double gs = 0.0;
+    for (int t = g * POT_GROUP; t < (g + 1) * POT_GROUP; t++) {
+      double a = 0.0;
+      for (int64_t i = t; i < n; i += POT_LANES) a = a + d[i] * w[i];
+      gs = gs + a;
+    }
+    grp[g] = gs;
   }
   double s = 0.0;
-  for (int t = 0; t < POT_LANES; t++) s = s + part[t];
+  for (int g = 0; g < POT_LANES / POT_GROUP; g++) s = s + grp[g];
   return s;
 }
 
@@ -665,6 +672,60 @@ int hamsm_reassign(hamsm_ctx *c, int s, const void *X, int dt, int64_t ldx, cons
       t->csq[cl[i]] = sqnorm_chain(cj, c->D);
     }
     t->counts[cl[i]] = new_count; /* :1672 */
+  }
+  return HAMSM_OK;
+}
+
+/* --- batched forms: loops over the single-call restatements above ------------------------------- */
+int hamsm_train_build_rows_batched(hamsm_ctx *c, const int32_t *bin, int64_t n_groups, const int64_t *goff,
+                                   const int32_t *call_remap, int32_t *rows, int64_t *counts, int64_t *starts) {
+  for (int64_t g = 0; g < n_groups; g++) {
+    int64_t b = goff[2 * g], e = goff[2 * g + 1];
+    int rc = hamsm_train_build_rows(c, bin + b, e - b, call_remap + g * c->S, rows + b, counts + g * c->S, starts + g * c->S);
+    if (rc) return rc;
+    for (int s = 0; s < c->S; s++) starts[g * c->S + s] += b;
+  }
+  return HAMSM_OK;
+}
+
+int hamsm_kmeans_seed_multi(hamsm_ctx *c, int n_items, const int32_t *stratum, const void *X, int dt, int64_t ldx,
+                            const int64_t *x_off, const int32_t *rows, const int64_t *rows_off, const int64_t *n_b,
+                            const double *wf, const int64_t *sub, const int64_t *n_sub, const int32_t *K,
+                            const int64_t *first, const double *u, const int32_t *L) {
+  size_t esz = dt == HAMSM_F32 ? 4 : 8;
+  for (int i = 0; i < n_items; i++) {
+    const char *Xi = (const char *)X + (size_t)x_off[i] * ldx * esz;
+    const double *wi = wf ? wf + x_off[i] : NULL;
+    int rc = hamsm_kmeans_seed(c, stratum[i], Xi, dt, ldx, rows + rows_off[i], n_b[i], wi, n_sub[i] ? sub : NULL, n_sub[i],
+                               K[i], first[i], u, L[i], NULL);
+    if (rc) return rc;
+    u += (size_t)(K[i] - 1) * L[i];
+    sub += n_sub[i];
+  }
+  return HAMSM_OK;
+}
+
+int hamsm_minibatch_run(hamsm_ctx *c, const void *X, int dt, int64_t ldx, const int32_t *rows, const double *wf,
+                        const hamsm_step *steps, int64_t n_steps, double ratio, int32_t *report) {
+  size_t esz = dt == HAMSM_F32 ? 4 : 8;
+  for (int64_t i = 0; i < n_steps; i++) {
+    const hamsm_step *st = &steps[i];
+    if (st->stratum < 0 || st->stratum >= c->S) return fail(c, HAMSM_EINVAL, "bad stratum in step %lld", (long long)i);
+    stratum_t *t = &c->st[st->stratum];
+    int zero = 0;
+    for (int j = 0; j < t->K; j++) zero |= (t->counts[j] == 0.0); /* _kmeans.py:2037 */
+    report[2 * i] = zero;
+    int rc = hamsm_minibatch_step(c, st->stratum, (const char *)X + (size_t)st->x_off * ldx * esz, dt, ldx,
+                                  rows + st->rows_off, st->n_b, wf ? wf + st->x_off : NULL, NULL);
+    if (rc) return rc;
+    int low = 0;
+    if (st->flags & 1) { /* _kmeans.py:1645 */
+      double mx = t->counts[0];
+      for (int j = 1; j < t->K; j++)
+        if (t->counts[j] > mx) mx = t->counts[j];
+      for (int j = 0; j < t->K; j++) low += (t->counts[j] < ratio * mx);
+    }
+    report[2 * i + 1] = low;
   }
   return HAMSM_OK;
 }

@@ -79,7 +79,7 @@ def golden_iterations(g):
             for i in range(len(offs) - 1)}
 
 
-def build_model(h, g, meta, seed_forcing=True):
+def build_model(h, g, meta, seed_forcing=True, planned=True):
     """modelWE on golden inputs, up to (and including) cluster_coordinates.  Returns (model, forced)
     where forced counts k-means++ seedings replaced by the reference's (exact-tie flips)."""
     from msm_we_amd.data import InMemorySource
@@ -106,13 +106,32 @@ def build_model(h, g, meta, seed_forcing=True):
         state["i"] += 1
         return ch
 
+    orig_multi = h.kmeans_seed_multi
+
+    def seed_multi(strata, *a, **k):
+        # the planned training path seeds several strata in one call (same order as the reference's
+        # k-means++ calls); compare / teacher-force on the resulting centroids
+        orig_multi(strata, *a, **k)
+        for s in strata:
+            ref_c = g["pp_centers"][state["i"]]
+            mine = h.get_centroids(s)[0]
+            same = np.array_equal(mine, ref_c)
+            state["chosen"].append((np.zeros(1, int), np.zeros(1, int)) if same else (np.zeros(1, int), np.ones(1, int)))
+            if seed_forcing and not same:
+                state["forced"] += 1
+                h.set_centroids(s, ref_c)
+            state["i"] += 1
+
     h.kmeans_seed = seed
+    h.kmeans_seed_multi = seed_multi
+    m.speculative_training = planned
     bm = RectilinearBinMapper([np.array(meta["boundaries"], dtype=np.float32)])
     try:
         m.cluster_coordinates(meta["K_s"], streaming=True, use_ray=True, stratified=True, user_bin_mapper=bm,
                               random_state=meta["seed"])
     finally:
         h.kmeans_seed = orig
+        h.kmeans_seed_multi = orig_multi
     return m, state
 
 

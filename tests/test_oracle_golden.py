@@ -10,10 +10,13 @@ import pytest
 from conftest import GOLDEN_CASES, build_model, load_golden
 
 
+@pytest.mark.parametrize("planned", [True, False], ids=["planned", "stepwise"])
 @pytest.mark.parametrize("case", GOLDEN_CASES)
-def test_pipeline_matches_reference(oracle_h, case):
+def test_pipeline_matches_reference(oracle_h, case, planned):
+    """planned = the whole training pass enqueued at once (prediction: no random reassignment, verified
+    afterwards); stepwise = one partial_fit at a time with the host in the loop.  Same results."""
     g, meta = load_golden(case)
-    m, st = build_model(oracle_h, g, meta)
+    m, st = build_model(oracle_h, g, meta, planned=planned)
     # k-means++ seeds: identical except where the reference's argmin over candidate potentials is an
     # exact mathematical tie broken by BLAS rounding (DESIGN.md §4); at most one such flip per case
     assert st["forced"] <= 1
@@ -80,7 +83,7 @@ def test_every_partial_fit_matches_reference(oracle_h):
 
         StratumKMeans.partial_fit_device = rec
         try:
-            build_model(oracle_h, g, meta)
+            build_model(oracle_h, g, meta, planned=False)
         finally:
             StratumKMeans.partial_fit_device = orig
         assert len(log) == len(g["fit_bin"])

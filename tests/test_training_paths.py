@@ -1,0 +1,81 @@
+"""The planned (no host round trips) and stepwise training paths must agree, including when the plan's
+prediction "no random reassignment" is wrong and the run falls back (few modes, many centroids)."""
+import numpy as np
+import pytest
+
+from conftest import RectilinearBinMapper
+from msm_we_amd import synthetic
+from msm_we_amd.data import InMemorySource
+from msm_we_amd.model import modelWE
+
+
+def _run(h, cfg, n_clusters, planned, weights=False, random_state=7, outliers=False):
+    lat = synthetic.latent_centres(cfg)
+    iters = {i: synthetic.make_iteration(cfg, i, lat) for i in range(1, cfg.n_iters + 1)}
+    if outliers:
+        # one very tight mode plus a few far outliers per stratum: k-means++ seeds the outliers, whose
+        # counts stay ~1 while the mode's centroid collects hundreds -> count < 0.01*max -> reassignment
+        rng = np.random.default_rng(99)
+        for d in iters.values():
+            for key in ("Xp", "Xc"):
+                n = len(d[key])
+                X = (rng.normal(size=(n, cfg.D)) * 0.01).astype(np.float32)
+                far = rng.uniform(size=n) < 0.03
+                X[far] = (rng.normal(size=(int(far.sum()), cfg.D)) * 100).astype(np.float32)
+                d[key] = X
+    m = modelWE(h=h)
+    m.set_iteration_source(InMemorySource(iters))
+    basis, target = synthetic.basis_target_bounds(cfg.S)
+    m.initialize(["x"], {"coords": None, "nAtoms": cfg.D, "coord_ndim": 1}, "t", basis_pcoord_bounds=basis,
+                 target_pcoord_bounds=target, tau=1.0, use_weights_in_clustering=weights)
+    m.get_iterations()
+    m.dimReduce()
+    m.speculative_training = planned
+    bm = RectilinearBinMapper([synthetic.strata_boundaries(cfg.S)])
+    m.cluster_coordinates(n_clusters, streaming=True, use_ray=True, stratified=True, user_bin_mapper=bm,
+                          random_state=random_state)
+    cents = [cm.cluster_centers_.copy() for cm in m.clusters.cluster_models if cm.fitted]
+    counts = [cm._counts.copy() for cm in m.clusters.cluster_models if cm.fitted]
+    return m, np.concatenate(m.dtrajs), cents, counts
+
+
+def _compare(h, cfg, n_clusters, expect_path, **kw):
+    a, la, ca, na = _run(h, cfg, n_clusters, True, **kw)
+    b, lb, cb, nb = _run(h, cfg, n_clusters, False, **kw)
+    assert a.training_path == expect_path and b.training_path == "stepwise"
+    assert np.array_equal(la, lb)
+    for x, y in zip(ca + na, cb + nb):
+        assert np.array_equal(x, y)
+    # bookkeeping the next partial_fit would read
+    for ma, mb in zip(a.clusters.cluster_models, b.clusters.cluster_models):
+        if ma.fitted:
+            assert ma._n_since_last_reassign == mb._n_since_last_reassign and ma.n_steps_ == mb.n_steps_
+
+
+def test_planned_equals_stepwise_when_prediction_holds(oracle_h):
+    _compare(oracle_h, synthetic.WEConfig("t1", 3, 30, 300, 10, 3, 12), 12, "planned")
+    _compare(oracle_h, synthetic.WEConfig("t1w", 4, 30, 300, 10, 2, 12), 12, "planned", weights=True)
+
+
+def test_misprediction_falls_back_to_identical_result(oracle_h):
+    # 2 modes per stratum, 40 centroids requested: low-count centroids must be re-seeded (host RNG)
+    _compare(oracle_h, synthetic.WEConfig("t2", 5, 12, 2500, 6, 2, 2), 20, "stepwise", outliers=True)
+    # shared global RandomState (random_state=None -> np.random singleton, sklearn semantics)
+    np.random.seed(123)
+    a = _run(oracle_h, synthetic.WEConfig("t3", 6, 10, 2500, 6, 2, 2), 20, True, random_state=None, outliers=True)
+    np.random.seed(123)
+    b = _run(oracle_h, synthetic.WEConfig("t3", 6, 10, 2500, 6, 2, 2), 20, False, random_state=None, outliers=True)
+    assert a[0].training_path == "stepwise" and np.array_equal(a[1], b[1])
+
+
+@pytest.mark.gpu
+def test_planned_paths_on_gpu_match_oracle(hip_h, oracle_h):
+    for cfg, k, path in ((synthetic.WEConfig("t1", 3, 30, 300, 10, 3, 12), 12, "planned"),
+                         (synthetic.WEConfig("t2", 5, 12, 2500, 6, 2, 2), 40, "stepwise"),
+                         (synthetic.WEConfig("t4", 8, 12, 3000, 30, 4, 60), 60, "planned")):
+        g = _run(hip_h, cfg, k, True, outliers=(path == "stepwise"))
+        o = _run(oracle_h, cfg, k, True, outliers=(path == "stepwise"))
+        assert g[0].training_path == o[0].training_path == path
+        assert np.array_equal(g[1], o[1])
+        for x, y in zip(g[2] + g[3], o[2] + o[3]):
+            assert np.array_equal(x, y)
