@@ -366,6 +366,183 @@ __global__ __launch_bounds__(SEED_T) void k_seed(const SeedItem *__restrict__ it
   }
 }
 
+// Same algorithm for batches that fit on chip (n <= SEED_NLDS rows, L <= SEED_LFAST candidates): w, ||x||^2,
+// closest and the chunk bases live in LDS and every thread keeps the candidate distances of its own rows in
+// registers, so a greedy step touches global memory only to stream the (L2-resident) batch once.
+#define SEED_NLDS 3072
+#define SEED_RPT (SEED_NLDS / SEED_T)
+#define SEED_LFAST 8
+__global__ __launch_bounds__(SEED_T) void k_seed_lds(const SeedItem *__restrict__ items, int D) {
+  extern __shared__ double sm[];
+  const SeedItem it = items[blockIdx.x];
+  const int n = (int)it.n;
+  const int K = it.K, L = it.L;
+  double *crow = sm;                                   // [LFAST][D]
+  double *part = crow + SEED_LFAST * D;                // [LFAST][SEED_T]
+  double *grp = part + SEED_LFAST * SEED_T;            // [LFAST][32]
+  double *pots = grp + SEED_LFAST * (SEED_T / SEED_GROUP);  // [LFAST]
+  double *lw = pots + SEED_LFAST;                      // [n]
+  double *lxsq = lw + SEED_NLDS;                       // [n]
+  double *lcl = lxsq + SEED_NLDS;                      // [n] closest
+  double *lbase = lcl + SEED_NLDS;                     // [nch] chunk totals -> bases
+  __shared__ int cid[SEED_LFAST];
+  __shared__ double s_pot;
+  __shared__ int s_best;
+  const int tid = threadIdx.x;
+  const double *XbT = it.XbT;
+
+  for (int i = tid; i < n; i += SEED_T) {
+    lw[i] = it.w[i];
+    lxsq[i] = it.xsq[i];
+  }
+  for (int k = tid; k < D; k += SEED_T) {
+    double v = XbT[(size_t)k * n + it.first];
+    crow[k] = v;
+    it.C[k] = v;
+  }
+  if (tid == 0) it.chosen[0] = it.first;
+  __syncthreads();
+  {
+    const double xs0 = lxsq[it.first];
+    double a = 0.0;
+#pragma unroll
+    for (int r = 0; r < SEED_RPT; r++) {
+      int i = tid + r * SEED_T;
+      if (i < n) {
+        double acc = 0.0;
+        for (int k = 0; k < D; k++) acc = __builtin_fma(crow[k], XbT[(size_t)k * n + i], acc);
+        double v = ((-2.0 * acc) + xs0) + lxsq[i];
+        v = v > 0.0 ? v : 0.0;
+        lcl[i] = v;
+        a = a + v * lw[i];
+      }
+    }
+    part[tid] = a;
+    double s = seed_reduce(part, grp, tid);
+    if (tid == 0) s_pot = s;
+    __syncthreads();
+  }
+  const int nch = (n + SCAN_CHUNK - 1) / SCAN_CHUNK;
+  for (int cc = 1; cc < K; cc++) {
+    if (tid < nch) {
+      double loc = 0.0;
+      int e = (tid + 1) * SCAN_CHUNK < n ? (tid + 1) * SCAN_CHUNK : n;
+      for (int i = tid * SCAN_CHUNK; i < e; i++) loc = loc + lw[i] * lcl[i];
+      lbase[tid] = loc;
+    }
+    __syncthreads();
+    if (tid == 0) {
+      double base = 0.0;
+      for (int q = 0; q < nch; q++) {
+        double t = lbase[q];
+        lbase[q] = base;
+        base = base + t;
+      }
+    }
+    __syncthreads();
+    if (tid < L) {
+      const double v = it.u[(size_t)(cc - 1) * L + tid] * s_pot;  // :243
+      int lo = 0, hi = nch;
+      while (hi - lo > 1) {
+        int mid = (lo + hi) >> 1;
+        if (lbase[mid] < v) lo = mid;
+        else hi = mid;
+      }
+      int ans = n;
+      for (int q = lo; q < nch && ans == n; q++) {
+        double loc = 0.0, base = lbase[q];
+        int e = (q + 1) * SCAN_CHUNK < n ? (q + 1) * SCAN_CHUNK : n;
+        for (int i = q * SCAN_CHUNK; i < e; i++) {
+          loc = loc + lw[i] * lcl[i];
+          if (base + loc >= v) {
+            ans = i;
+            break;
+          }
+        }
+      }
+      if (ans > n - 1) ans = n - 1;  // :249
+      cid[tid] = ans;
+    }
+    __syncthreads();
+    for (int e = tid; e < L * D; e += SEED_T) crow[e] = XbT[(size_t)(e % D) * n + cid[e / D]];
+    __syncthreads();
+    double cnd[SEED_RPT][SEED_LFAST];
+    {
+      double a[SEED_LFAST];
+#pragma unroll
+      for (int l = 0; l < SEED_LFAST; l++) a[l] = 0.0;
+#pragma unroll
+      for (int r = 0; r < SEED_RPT; r++) {
+        int i = tid + r * SEED_T;
+        if (i < n) {
+          double acc[SEED_LFAST];
+#pragma unroll
+          for (int l = 0; l < SEED_LFAST; l++) acc[l] = 0.0;
+          for (int k = 0; k < D; k++) {
+            const double xi = XbT[(size_t)k * n + i];
+#pragma unroll
+            for (int l = 0; l < SEED_LFAST; l++)
+              if (l < L) acc[l] = __builtin_fma(crow[l * D + k], xi, acc[l]);
+          }
+          const double ci = lcl[i], xi2 = lxsq[i], wi = lw[i];
+#pragma unroll
+          for (int l = 0; l < SEED_LFAST; l++)
+            if (l < L) {
+              double v = ((-2.0 * acc[l]) + lxsq[cid[l]]) + xi2;  // :252-254
+              v = v > 0.0 ? v : 0.0;
+              v = v < ci ? v : ci;  // :257
+              cnd[r][l] = v;
+              a[l] = a[l] + v * wi;
+            }
+        }
+      }
+#pragma unroll
+      for (int l = 0; l < SEED_LFAST; l++)
+        if (l < L) part[l * SEED_T + tid] = a[l];
+    }
+    __syncthreads();
+    if (tid < L * (SEED_T / SEED_GROUP)) {
+      int l = tid / (SEED_T / SEED_GROUP), g = tid % (SEED_T / SEED_GROUP);
+      double gs = 0.0;
+      for (int t = 0; t < SEED_GROUP; t++) gs = gs + part[l * SEED_T + g * SEED_GROUP + t];
+      grp[l * (SEED_T / SEED_GROUP) + g] = gs;
+    }
+    __syncthreads();
+    if (tid < L) {
+      double s = 0.0;
+      for (int g = 0; g < SEED_T / SEED_GROUP; g++) s = s + grp[tid * (SEED_T / SEED_GROUP) + g];
+      pots[tid] = s;
+    }
+    __syncthreads();
+    if (tid == 0) {
+      int best = 0;
+      double bp = pots[0];
+      for (int l = 1; l < L; l++)
+        if (pots[l] < bp) {  // :261
+          bp = pots[l];
+          best = l;
+        }
+      s_best = best;
+      s_pot = bp;
+      it.chosen[cc] = cid[best];
+    }
+    __syncthreads();
+    const int best = s_best;
+#pragma unroll
+    for (int r = 0; r < SEED_RPT; r++) {
+      int i = tid + r * SEED_T;
+      if (i < n) {
+        double v = cnd[r][0];
+#pragma unroll
+        for (int l = 1; l < SEED_LFAST; l++) v = (l == best) ? cnd[r][l] : v;
+        lcl[i] = v;
+      }
+    }
+    for (int k = tid; k < D; k += SEED_T) it.C[(size_t)cc * D + k] = crow[best * D + k];
+    __syncthreads();
+  }
+}
+
 extern "C" int hamsm_kmeans_seed_multi(hamsm_ctx *c, int n_items, const int32_t *h_stratum, const void *X, int dt, int64_t ldx,
                                        const int64_t *h_x_off, const int32_t *d_rows, const int64_t *h_rows_off,
                                        const int64_t *h_n_b, const double *d_w, const int64_t *h_sub, const int64_t *h_n_sub,
@@ -456,9 +633,18 @@ extern "C" int hamsm_kmeans_seed_multi(hamsm_ctx *c, int n_items, const int32_t 
     hipLaunchKernelGGL(k_seed_gather<float>, gg, dim3(256), 0, c->stream, (const SeedItem *)(b + o_items), ldx, D);
   else
     hipLaunchKernelGGL(k_seed_gather<double>, gg, dim3(256), 0, c->stream, (const SeedItem *)(b + o_items), ldx, D);
-  size_t lds = sizeof(double) * ((size_t)SEED_LMAX * D + (size_t)SEED_LMAX * SEED_T + SEED_LMAX * (SEED_T / SEED_GROUP) + SEED_LMAX);
-  HIPCHK(c, hipFuncSetAttribute((const void *)k_seed, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  hipLaunchKernelGGL(k_seed, dim3((unsigned)n_items), dim3(SEED_T), lds, c->stream, (const SeedItem *)(b + o_items), D);
+  bool fast = true;
+  for (int i = 0; i < n_items; i++) fast = fast && lay[i].n <= SEED_NLDS && h_L[i] <= SEED_LFAST;
+  size_t lds_fast = sizeof(double) * ((size_t)SEED_LFAST * D + (size_t)SEED_LFAST * SEED_T + SEED_LFAST * (SEED_T / SEED_GROUP) +
+                                      SEED_LFAST + 3 * (size_t)SEED_NLDS + SEED_NLDS / SCAN_CHUNK + 8);
+  if (fast && lds_fast <= 160 * 1024) {
+    HIPCHK(c, hipFuncSetAttribute((const void *)k_seed_lds, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_fast));
+    hipLaunchKernelGGL(k_seed_lds, dim3((unsigned)n_items), dim3(SEED_T), lds_fast, c->stream, (const SeedItem *)(b + o_items), D);
+  } else {
+    size_t lds = sizeof(double) * ((size_t)SEED_LMAX * D + (size_t)SEED_LMAX * SEED_T + SEED_LMAX * (SEED_T / SEED_GROUP) + SEED_LMAX);
+    HIPCHK(c, hipFuncSetAttribute((const void *)k_seed, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(k_seed, dim3((unsigned)n_items), dim3(SEED_T), lds, c->stream, (const SeedItem *)(b + o_items), D);
+  }
   HIPCHK(c, hipGetLastError());
   for (int i = 0; i < n_items; i++) {
     int s = h_stratum[i];
@@ -494,6 +680,7 @@ struct StepDev {
   const double *wf;      // nullable, indexed like X
   long long n_b;
   int32_t *labels;       // [n_b] scratch
+  double *Xg;            // [n_b][D] the batch rows, gathered once by the E-step for the M-step (L2-resident)
   double *C, *counts, *csq, *Bpack;
   int K, flags;
   int32_t *report;       // [2]
@@ -523,6 +710,13 @@ __global__ __launch_bounds__(256) void k_step_assign(const StepDev *__restrict__
   for (int ks = 0; ks < KS; ks++) {
     int k = ks * 4 + (lane >> 4);
     a[ks] = (ok && k < D) ? (double)X[f * ldx + k] : 0.0;
+  }
+  if (wv == 0 && ok) {
+#pragma unroll
+    for (int ks = 0; ks < KS; ks++) {
+      int k = ks * 4 + (lane >> 4);
+      if (k < D) st.Xg[(size_t)r * D + k] = a[ks];
+    }
   }
   const int njt = (st.K + 15) >> 4;
   const double inf = __builtin_huge_val();
@@ -601,7 +795,7 @@ __global__ __launch_bounds__(256) void k_step_assign(const StepDev *__restrict__
 // M-step: one wave per centroid; the step's labels are scanned from LDS, member rows are fetched 8 at a
 // time and added in ascending sample order (_k_means_minibatch.pyx:59-108).
 #define UPD_LABEL_CAP 16384
-#define UPD_LIST 512
+#define UPD_LIST 1024
 template <typename XT>
 __global__ __launch_bounds__(256) void k_step_update(const StepDev *__restrict__ steps, int64_t ldx, int D, int KS) {
   const StepDev st = steps[blockIdx.y];
@@ -621,23 +815,42 @@ __global__ __launch_bounds__(256) void k_step_update(const StepDev *__restrict__
   const XT *X = (const XT *)st.X;
   const long long n_b = st.n_b;
 
+  // labels are scanned 256 at a time (4 consecutive per lane); members are appended in ascending sample order
+  auto scan4 = [&](long long base, int &fill, bool store) -> int {
+    int l4[4];
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+      long long i = base + 4 * lane + q;
+      l4[q] = (i < n_b) ? lab[i] : -1;
+    }
+    unsigned long long M[4];
+    int tot = 0, before = 0;
+    const unsigned long long lt = (1ull << lane) - 1;
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+      M[q] = __ballot(l4[q] == j);
+      tot += __popcll(M[q]);
+      before += __popcll(M[q] & lt);
+    }
+    if (store && tot) {
+      int o = fill + before;
+#pragma unroll
+      for (int q = 0; q < 4; q++)
+        if (l4[q] == j) list[o++] = (int)(base + 4 * lane + q);
+    }
+    fill += tot;
+    return tot;
+  };
+
   // pass 1: wsum in sample order (pyx:80-85); unweighted: the sum of `cnt` ones is exactly cnt
   double wsum = 0.0;
   {
-    long long cnt = 0;
     int fill = 0;
-    for (long long base = 0; base < n_b; base += 64) {
-      long long i = base + lane;
-      bool mt = (i < n_b) && (lab[i] == j);
-      unsigned long long mask = __ballot(mt);
-      if (!mask) continue;
-      if (!st.wf) {
-        cnt += __popcll(mask);
-        continue;
-      }
-      if (mt) list[fill + __popcll(mask & ((1ull << lane) - 1))] = (int)i;
-      fill += __popcll(mask);
-      if (fill > UPD_LIST - 64 || base + 64 >= n_b) {
+    long long cnt = 0;
+    for (long long base = 0; base < n_b; base += 256) {
+      int got = scan4(base, fill, st.wf != nullptr);
+      cnt += got;
+      if (st.wf && fill && (fill > UPD_LIST - 256 || base + 256 >= n_b)) {
         for (int m0 = 0; m0 < fill; m0 += 64) {
           int ii = (m0 + lane < fill) ? list[m0 + lane] : -1;
           double wv_ = 0.0;
@@ -647,15 +860,7 @@ __global__ __launch_bounds__(256) void k_step_update(const StepDev *__restrict__
         }
         fill = 0;
       }
-    }
-    if (st.wf && fill) {
-      for (int m0 = 0; m0 < fill; m0 += 64) {
-        int ii = (m0 + lane < fill) ? list[m0 + lane] : -1;
-        double wv_ = 0.0;
-        if (ii >= 0) wv_ = st.wf[st.rows ? (long long)st.rows[ii] : (long long)ii];
-        int lim = fill - m0 < 64 ? fill - m0 : 64;
-        for (int q = 0; q < lim; q++) wsum = wsum + __shfl(wv_, q, 64);
-      }
+      if (!st.wf) fill = 0;
     }
     if (!st.wf) wsum = (double)cnt;
   }
@@ -671,26 +876,19 @@ __global__ __launch_bounds__(256) void k_step_update(const StepDev *__restrict__
   }
   {
     int fill = 0;
-    for (long long base = 0; base < n_b; base += 64) {
-      long long i = base + lane;
-      bool mt = (i < n_b) && (lab[i] == j);
-      unsigned long long mask = __ballot(mt);
-      if (mask) {
-        if (mt) list[fill + __popcll(mask & ((1ull << lane) - 1))] = (int)i;
-        fill += __popcll(mask);
-      }
-      if (fill && (fill > UPD_LIST - 64 || base + 64 >= n_b)) {
+    for (long long base = 0; base < n_b; base += 256) {
+      scan4(base, fill, true);
+      if (fill && (fill > UPD_LIST - 256 || base + 256 >= n_b)) {
         for (int m0 = 0; m0 < fill; m0 += 8) {
           double xv[8][2], wq[8];
 #pragma unroll
           for (int q = 0; q < 8; q++) {
             int ii = (m0 + q < fill) ? list[m0 + q] : -1;
-            long long f = ii >= 0 ? (st.rows ? (long long)st.rows[ii] : (long long)ii) : 0;
-            wq[q] = (ii >= 0) ? (st.wf ? st.wf[f] : 1.0) : 0.0;
+            wq[q] = (ii >= 0) ? (st.wf ? st.wf[st.rows ? (long long)st.rows[ii] : (long long)ii] : 1.0) : 0.0;
 #pragma unroll
             for (int h = 0; h < 2; h++) {
               int k = lane + 64 * h;
-              xv[q][h] = (ii >= 0 && k < D) ? (double)X[f * ldx + k] : 0.0;
+              xv[q][h] = (ii >= 0 && k < D) ? st.Xg[(size_t)ii * D + k] : 0.0;
             }
           }
 #pragma unroll
@@ -784,8 +982,9 @@ static int run_steps(hamsm_ctx *c, const void *X, int dt, int64_t ldx, const int
                      const hamsm_step *h_steps, int64_t n_steps, double ratio, int32_t *h_report, int want_zero_flag,
                      int32_t **labels_of_first) {
   const size_t esz = dt == HAMSM_F32 ? 4 : 8;
-  int64_t lab_hi = 0;
+  int64_t lab_hi = 0, nb_max = 0;
   for (int64_t i = 0; i < n_steps; i++) {
+    if (h_steps[i].n_b > nb_max) nb_max = h_steps[i].n_b;
     const hamsm_step &s = h_steps[i];
     if (s.stratum < 0 || s.stratum >= c->S) return hamsm_fail(c, HAMSM_EINVAL, "bad stratum in step %lld", (long long)i);
     if (c->st[s.stratum].K == 0) return hamsm_fail(c, HAMSM_EUNFIT, "stratum %d has no centroids", s.stratum);
@@ -801,6 +1000,9 @@ static int run_steps(hamsm_ctx *c, const void *X, int dt, int64_t ldx, const int
   };
   size_t o_steps = take(sizeof(StepDev) * n_steps), o_rep = take(sizeof(int32_t) * 2 * n_steps),
          o_lab = take(sizeof(int32_t) * (size_t)lab_hi);
+  // the gathered batch copy is reused by every launch group: one slot per stratum position, stream-ordered
+  const int nslot = c->S < 65535 ? c->S : 65535;
+  size_t o_xg = take(sizeof(double) * (size_t)nslot * nb_max * c->D);
   int rc = hamsm_ensure_scratch(c, off);
   if (rc) return rc;
   char *b = (char *)c->scratch;
@@ -814,6 +1016,7 @@ static int run_steps(hamsm_ctx *c, const void *X, int dt, int64_t ldx, const int
     d.wf = d_w ? d_w + s.x_off : nullptr;
     d.n_b = s.n_b;
     d.labels = (int32_t *)(b + o_lab) + (d_rows ? s.rows_off : 0);
+    d.Xg = nullptr;  // slot assigned per launch group below
     d.C = t.C;
     d.counts = t.counts;
     d.csq = t.csq;
@@ -821,6 +1024,21 @@ static int run_steps(hamsm_ctx *c, const void *X, int dt, int64_t ldx, const int
     d.K = t.K;
     d.flags = (s.flags & 1) | (want_zero_flag ? 2 : 0);
     d.report = (int32_t *)(b + o_rep) + 2 * i;
+  }
+  {
+    // launch groups = maximal runs of distinct strata; slot = position inside the run
+    std::vector<char> used0(c->S);
+    int64_t i0 = 0;
+    while (i0 < n_steps) {
+      std::fill(used0.begin(), used0.end(), 0);
+      int64_t j0 = i0;
+      while (j0 < n_steps && !used0[h_steps[j0].stratum] && j0 - i0 < 65535) {
+        used0[h_steps[j0].stratum] = 1;
+        sd[j0].Xg = (double *)(b + o_xg) + (size_t)(j0 - i0) * nb_max * c->D;
+        j0++;
+      }
+      i0 = j0;
+    }
   }
   if (labels_of_first) *labels_of_first = sd[0].labels;
   HIPCHK(c, hipMemcpyAsync(b + o_steps, sd.data(), sizeof(StepDev) * n_steps, hipMemcpyHostToDevice, c->stream));

@@ -217,12 +217,17 @@ def _train_inputs(rng, n, D, S, dtype):
     return X, p, w
 
 
-@pytest.mark.parametrize("D,dtype,weighted,sub", [(10, np.float32, False, False), (30, np.float32, True, False),
-                                                   (13, np.float64, False, True), (64, np.float32, True, True)])
-def test_training_primitives_match_oracle(hip_h, oracle_h, D, dtype, weighted, sub):
+@pytest.mark.parametrize("D,dtype,weighted,sub,K,n", [(10, np.float32, False, False, 25, 3000),
+                                                       (30, np.float32, True, False, 25, 3000),
+                                                       (13, np.float64, False, True, 25, 3000),
+                                                       (64, np.float32, True, True, 25, 3000),
+                                                       # general (global-memory) seeding kernel: L = 9 candidates / > 3072 rows
+                                                       (10, np.float32, False, False, 1100, 4000),
+                                                       (30, np.float32, True, False, 40, 9000)])
+def test_training_primitives_match_oracle(hip_h, oracle_h, D, dtype, weighted, sub, K, n):
     """prepass, row lists, k-means++ seeding, three minibatch steps and a reassignment: every
     intermediate bit-identical between the HIP library and the oracle."""
-    S, K, n = 3, 25, 3000
+    S = 3
     rec = []
     for h in (oracle_h, hip_h):
         rng = np.random.default_rng(11)
