@@ -127,6 +127,7 @@ def main():
     ap.add_argument("--flux-mode", type=int, default=0, help="0 = f64 atomics, 1 = deterministic sort-based")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-iters", type=int, default=20)
+    ap.add_argument("--lib", default=None, help="(kernel A/B experiments) path of an alternative build of the HIP library")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -154,7 +155,7 @@ def main():
     n_iters = args.iters or cfg.n_iters
     seed = 1337
 
-    h = _abi.Hamsm(device=local_rank)  # the HIP library; raises if it is not built
+    h = _abi.Hamsm(lib=ctypes.CDLL(args.lib) if args.lib else None, device=local_rank)  # the HIP library; raises if not built
     assert h.backend == "hip-gfx950"
     if world > 1:
         uid = [h.comm_unique_id() if rank == 0 else None]

@@ -18,6 +18,45 @@
 #include "common.h"
 
 typedef double v4f64 __attribute__((ext_vector_type(4)));
+#ifndef V2_DPP
+#define V2_DPP 1
+#endif
+#ifndef V2_UNCOND
+#define V2_UNCOND 1
+#endif
+#ifndef V2_GLOBAL
+#define V2_GLOBAL 1
+#endif
+#if V2_GLOBAL
+typedef const double __attribute__((address_space(1))) *gcdp;  // global-address-space view: global_load, not flat_load
+#else
+typedef const double *gcdp;
+#endif
+
+// row_shr:N inside each 16-lane DPP row; lanes with no source keep their own value
+template <int N>
+__device__ __forceinline__ int dpp_shr_i(int v) {
+  return __builtin_amdgcn_update_dpp(v, v, 0x110 + N, 0xf, 0xf, false);
+}
+template <int N>
+__device__ __forceinline__ double dpp_shr_d(double v) {
+  long long b = __double_as_longlong(v);
+  int lo = dpp_shr_i<N>((int)(b & 0xffffffffll)), hi = dpp_shr_i<N>((int)(b >> 32));
+  return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
+// lexicographic (d, j) minimum over the 16 lanes of a DPP row; the result is valid in lane 15 of the row
+__device__ __forceinline__ void row_min16(double &d, int &j) {
+#define STEP(N)                                          \
+  {                                                      \
+    double d2 = dpp_shr_d<N>(d);                         \
+    int j2 = dpp_shr_i<N>(j);                            \
+    bool take = (d2 < d) || (d2 == d && j2 < j);         \
+    d = take ? d2 : d;                                   \
+    j = take ? j2 : j;                                   \
+  }
+  STEP(1) STEP(2) STEP(4) STEP(8)
+#undef STEP
+}
 
 #define FR_MAX 512       // frames per workgroup (fewer when a row is wide: the chunk must fit LDS)
 #define NTHREADS 256
@@ -124,10 +163,15 @@ struct AssignArgs {
   int S, D, Kfit;
   int *err;
   int FR;  // frames per workgroup, multiple of 64
+  int need_rb;  // VER 2: some stratum has more centroid tiles than one group (running best kept in LDS)
 };
 
-template <typename XT, int KS, int MT>
-__global__ __launch_bounds__(NTHREADS) void k_assign(MapperDev mp, AssignArgs g) {
+// VER 1: waves pull independent (stratum, <=MT tiles) items and stream B fragments from L2.
+// VER 2: the four waves sweep the same tiles; each wave keeps JW centroid tiles of the current stratum as B
+//        fragments in registers (loaded once per stratum and centroid group), reads A fragments from LDS only,
+//        and the four partial first-minima of a tile are merged through LDS.  No global load in the MFMA loop.
+template <typename XT, int KS, int MT, int VER>
+__global__ __launch_bounds__(NTHREADS, 2) void k_assign(MapperDev mp, AssignArgs g) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   // LDS carve (one array, G17): Xs | slot | tile_s | item_* | cnt/tb | misc
   const int FR = g.FR, MAX_TILES = FR / 16 + SPARE_TILES;
@@ -140,6 +184,11 @@ __global__ __launch_bounds__(NTHREADS) void k_assign(MapperDev mp, AssignArgs g)
   int *cnt = tile_s + MAX_TILES;                                       // [S]  frames per stratum
   int *tbase = cnt + g.S;                                              // [S]  first tile of stratum
   int *misc = tbase + g.S;                                             // [0] n tiles, [1] next item
+  // VER 2 extras (8-byte aligned): partial minima of the 4 waves, double buffered; running best per slot
+  double *part_d = (double *)(((uintptr_t)(misc + 4) + 7) & ~(uintptr_t)7);  // [2][4][MT*16]
+  int *part_j = (int *)(part_d + 2 * 4 * MT * 16);                        // [2][4][MT*16]
+  double *rb_d = (double *)(part_j + 2 * 4 * MT * 16);                    // [MAX_TILES*16] (only if g.need_rb)
+  int *rb_j = (int *)(rb_d + (g.need_rb ? MAX_TILES * 16 : 0));           // [MAX_TILES*16]
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int64_t f0 = (int64_t)blockIdx.x * FR;
@@ -226,6 +275,152 @@ __global__ __launch_bounds__(NTHREADS) void k_assign(MapperDev mp, AssignArgs g)
   }
   __syncthreads();
 
+  if constexpr (VER == 2) {
+    constexpr int JW = (KS <= 16) ? 4 : 2;  // centroid tiles per wave per group
+    const int wv = tid >> 6;
+    const double inf = __builtin_huge_val();
+    int batch = 0;
+    for (int s = 0; s < g.S; s++) {
+      const int nts = (cnt[s] + 15) >> 4;
+      if (!nts) continue;
+      const StratumDev sd = g.table[s];
+      const int njt = (sd.K + 15) >> 4;
+      const int ngrp = (njt + 4 * JW - 1) / (4 * JW);
+      for (int gi = 0; gi < ngrp; gi++) {
+        double b[JW][KS], cs[JW];
+#pragma unroll
+        for (int u = 0; u < JW; u++) {
+          const int jt = gi * 4 * JW + wv * JW + u;
+          const bool live = jt < njt;
+          const int jts = live ? jt : 0;
+          double c0 = ((gcdp)sd.csq)[jts * 16 + (lane & 15)];
+          cs[u] = live ? c0 : inf;
+#pragma unroll
+          for (int ks = 0; ks < KS; ks++) {
+            double v = ((gcdp)sd.Bpack)[((size_t)jts * KS + ks) * 64 + lane];
+            b[u][ks] = live ? v : 0.0;
+          }
+        }
+        for (int t = 0; t < nts; t += MT, batch++) {
+          const int nt = (nts - t) < MT ? (nts - t) : MT;
+          const int tb = tbase[s] + t;
+          double bd[MT][4];
+          int bj[MT][4];
+          // one tile at a time; the JW centroid tiles give JW independent accumulator chains.  Dead centroid
+          // tiles (beyond the stratum's K) carry zero B fragments and csq = +inf: they run unconditionally so
+          // that the MFMA stream has no branches, and can never win.
+#pragma unroll
+          for (int m = 0; m < MT; m++) {
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+              bd[m][r] = inf;
+              bj[m][r] = 0x7fffffff;
+            }
+            if (m >= nt) continue;  // block-uniform: a whole tile's MFMA stream is skipped, never a single MFMA
+            double a[KS];
+            {
+              int f = (m < nt) ? slot[(tb + m) * 16 + (lane & 15)] : -1;
+              const XT *xr = Xs + (f < 0 ? 0 : f) * g.D;
+#pragma unroll
+              for (int ks = 0; ks < KS; ks++) {
+                int k = ks * 4 + (lane >> 4);
+#if V2_UNCOND
+                double v = (double)xr[k < g.D ? k : 0];  // unconditional LDS read, then select: no exec-mask branches
+                a[ks] = (f >= 0 && k < g.D) ? v : 0.0;
+#else
+                a[ks] = (f >= 0 && k < g.D) ? (double)xr[k] : 0.0;
+#endif
+              }
+            }
+            v4f64 acc[JW];
+#pragma unroll
+            for (int u = 0; u < JW; u++) acc[u] = (v4f64){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int ks = 0; ks < KS; ks++)
+#pragma unroll
+              for (int u = 0; u < JW; u++) acc[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[ks], b[u][ks], acc[u], 0, 0, 0);
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+              bd[m][r] = inf;
+              bj[m][r] = 0x7fffffff;
+            }
+#pragma unroll
+            for (int u = 0; u < JW; u++) {
+              const int j = (gi * 4 * JW + wv * JW + u) * 16 + (lane & 15);
+#pragma unroll
+              for (int r = 0; r < 4; r++) {
+                double d = __builtin_fma(-2.0, acc[u][r], cs[u]);
+                bool lt = d < bd[m][r];  // this wave's tiles ascend: strict < keeps its lowest j
+                bd[m][r] = lt ? d : bd[m][r];
+                bj[m][r] = lt ? j : bj[m][r];
+              }
+            }
+          }
+          const int buf = batch & 1;
+#pragma unroll
+          for (int m = 0; m < MT; m++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+              double d = bd[m][r];
+              int j = bj[m][r];
+#if V2_DPP
+              row_min16(d, j);
+              const bool owner = (lane & 15) == 15;
+#else
+#pragma unroll
+              for (int off = 8; off >= 1; off >>= 1) {
+                double d2 = __shfl_xor(d, off, 16);
+                int j2 = __shfl_xor(j, off, 16);
+                bool take = (d2 < d) || (d2 == d && j2 < j);
+                d = take ? d2 : d;
+                j = take ? j2 : j;
+              }
+              const bool owner = (lane & 15) == 0;
+#endif
+              if (owner && m < nt) {
+                int row = (lane >> 4) + 4 * r;
+                part_d[(buf * 4 + wv) * MT * 16 + m * 16 + row] = d;
+                part_j[(buf * 4 + wv) * MT * 16 + m * 16 + row] = j;
+              }
+            }
+          __syncthreads();
+          if (tid < nt * 16) {
+            const int m = tid >> 4, row = tid & 15;
+            double d = part_d[(buf * 4 + 0) * MT * 16 + m * 16 + row];
+            int j = part_j[(buf * 4 + 0) * MT * 16 + m * 16 + row];
+#pragma unroll
+            for (int w = 1; w < 4; w++) {
+              double d2 = part_d[(buf * 4 + w) * MT * 16 + m * 16 + row];
+              int j2 = part_j[(buf * 4 + w) * MT * 16 + m * 16 + row];
+              bool take = (d2 < d) || (d2 == d && j2 < j);
+              d = take ? d2 : d;
+              j = take ? j2 : j;
+            }
+            const int sl = (tb + m) * 16 + row;
+            if (ngrp > 1) {
+              if (gi > 0) {  // earlier groups hold lower j: they win ties
+                double d0 = rb_d[sl];
+                int j0 = rb_j[sl];
+                bool keep = (d0 < d) || (d0 == d && j0 < j);
+                d = keep ? d0 : d;
+                j = keep ? j0 : j;
+              }
+              if (gi < ngrp - 1) {
+                rb_d[sl] = d;
+                rb_j[sl] = j;
+              }
+            }
+            if (gi == ngrp - 1) {
+              const int f = slot[sl];
+              if (j == 0x7fffffff) j = 0;  // all-NaN row: label 0 like the oracle
+              if (f >= 0) g.labels[f0 + f] = sd.off + j;  // stratified_clustering.py:195
+            }
+          }
+        }
+      }
+    }
+    return;
+  }
   // 3. work items: up to MT consecutive tiles of one stratum, pulled dynamically by the waves
   const int ntiles = misc[0];
   while (true) {
@@ -272,17 +467,24 @@ __global__ __launch_bounds__(NTHREADS) void k_assign(MapperDev mp, AssignArgs g)
 
 template <typename XT, int KS>
 static int launch_assign_ks(hamsm_ctx *c, const MapperDev &mp, const AssignArgs &g_in) {
-  constexpr int MT = (KS <= 16) ? 4 : 2;
+  constexpr int MT = (KS <= 8) ? 4 : (KS <= 16 ? 2 : 1);
   AssignArgs g = g_in;
   // chunk of frames per workgroup: as many as keep the staged rows within ~64 KB (2 workgroups per CU)
   int FR = FR_MAX;
   while (FR > 64 && (size_t)FR * g.D * sizeof(XT) > 64 * 1024) FR >>= 1;
   g.FR = FR;
   const int MAX_TILES = FR / 16 + SPARE_TILES;
+  constexpr int JW = (KS <= 16) ? 4 : 2;
+  g.need_rb = 0;
+  for (int s = 0; s < c->S; s++) g.need_rb |= ((c->st[s].K + 15) / 16 > 4 * JW);
   size_t xbytes = ((size_t)FR * g.D * sizeof(XT) + 15) & ~(size_t)15;
   size_t lds = xbytes + sizeof(int16_t) * (MAX_TILES * 16 + 2 * FR) + sizeof(int) * (MAX_TILES + 2 * g.S + 4);
+  const int ver = c->assign_version;
+  if (ver == 2)
+    lds += 16 + (sizeof(double) + sizeof(int)) * 2 * 4 * MT * 16 +
+           (g.need_rb ? (sizeof(double) + sizeof(int)) * MAX_TILES * 16 : 0);
   if (lds > 160 * 1024) return hamsm_fail(c, HAMSM_ENOTSUP, "assign needs %zu B of LDS", lds);
-  auto kern = k_assign<XT, KS, MT>;
+  auto kern = ver == 2 ? k_assign<XT, KS, MT, 2> : k_assign<XT, KS, MT, 1>;
   HIPCHK(c, hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   unsigned grid = (unsigned)((g.n + FR - 1) / FR);
   hipLaunchKernelGGL(kern, dim3(grid), dim3(NTHREADS), lds, c->stream, mp, g);
@@ -317,7 +519,7 @@ extern "C" int hamsm_assign(hamsm_ctx *c, const void *X, int dt, int64_t ldx, co
   if (rc) return rc;
   // B fragments carry ceil(D/4) k-steps, but the kernels are instantiated for a few KS values: the
   // packed layout always uses c->KS, so the instantiated KS must equal it
-  AssignArgs g{X, ldx, p, n, labels, seen, c->d_table, c->S, c->D, c->Kfit, c->d_err, FR_MAX};
+  AssignArgs g{X, ldx, p, n, labels, seen, c->d_table, c->S, c->D, c->Kfit, c->d_err, FR_MAX, 0};
   hamsm_timer_begin(c);
   rc = (dt == HAMSM_F32) ? launch_assign<float>(c, c->mapper, g) : launch_assign<double>(c, c->mapper, g);
   hamsm_timer_end(c, ST_ASSIGN);

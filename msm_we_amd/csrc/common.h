@@ -78,6 +78,7 @@ struct hamsm_ctx {
   hipEvent_t ev_cur0 = nullptr;
   double timers[ST_N] = {0};
   double last_ms[ST_N] = {0};
+  int assign_version = 2;  // k_assign variant (HAMSM_ASSIGN_V=1 selects the item-pulling variant)
   void *seed_chosen_dev = nullptr;  // chosen indices of the last seeding's first item (device)
   void *comm = nullptr;  // ncclComm_t
   int nranks = 1, rank = 0;

@@ -1,4 +1,6 @@
 // ctx.hip -- lifecycle, device memory, model state (mapper, bounds, remap, centroids).
+#include <stdlib.h>
+
 #include "common.h"
 
 int hamsm_fail(hamsm_ctx *c, int code, const char *fmt, ...) {
@@ -20,6 +22,7 @@ extern "C" int hamsm_create(int device, hamsm_ctx **out) {
   c->err[0] = 0;
   c->device = device;
   memset(&c->mapper, 0, sizeof c->mapper);
+  if (const char *v = getenv("HAMSM_ASSIGN_V")) c->assign_version = atoi(v) == 1 ? 1 : 2;
   if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess ||
       hipMalloc((void **)&c->d_err, 4 * sizeof(int)) != hipSuccess ||
       hipHostMalloc((void **)&c->h_err, 4 * sizeof(int)) != hipSuccess) {
