@@ -363,7 +363,7 @@ class Hamsm:
     def train_build_rows_batched(self, d_bin, group_begin, group_end, call_remap, d_rows):
         goff = np.ascontiguousarray(np.stack([group_begin, group_end], axis=1), dtype=np.int64)
         G = len(goff)
-        cr = np.ascontiguousarray(call_remap, dtype=np.int32).reshape(G, self.S)
+        cr = np.ascontiguousarray(np.asarray(call_remap), dtype=np.int32).reshape(G, self.S)
         counts = np.zeros((G, self.S), dtype=np.int64)
         starts = np.zeros((G, self.S), dtype=np.int64)
         self._ck(self.lib.hamsm_train_build_rows_batched(self.ctx, _dp(d_bin), G, _hp(goff), _hp(cr), _dp(d_rows),

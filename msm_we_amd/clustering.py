@@ -136,20 +136,45 @@ class ClusteringMixin:
     def _plan_training_calls(self, hist, iters_to_use, n_clusters, bin_mapper):
         """The control flow of `cluster_stratified` / `do_stratified_clustering` (`_clustering.py:664-716,
         794-886`): which iterations each training call consumes and which bins it fits.  It depends only
-        on the per-iteration bin histogram, so every call is known before any arithmetic runs."""
+        on the per-iteration bin histogram, so every call is known before any arithmetic runs.
+
+        Returns (plan, all_filled); plan = arrays over calls: first / last iteration, call_remap [G,S],
+        nrows [G,S] (rows per bin after the call's remap) and fit [G,S] (bins fitted by the call)."""
         S = bin_mapper.nbins
-        plan, all_filled, all_unfilled = [], set(), set()
+        its = np.asarray(iters_to_use, dtype=np.int64)
+        n = len(its)
+        ident = np.arange(S, dtype=np.int32)
+        valid = its <= self.maxIter
+        H = np.zeros((n, S), dtype=np.int64)
+        H[valid] = hist[its[valid] - 1]
+        # an iteration that fills every bin it touches is a training call by itself (:885-886)
+        alone = valid & np.all((H >= n_clusters) | (H == 0), axis=1)
+        stops = np.nonzero(~alone)[0]
+        firsts, lasts, remaps, nrows, fits = [], [], [], [], []
         pos, first_call = 0, True
-        while pos < len(iters_to_use):
+        while pos < n:
+            if alone[pos]:
+                k = np.searchsorted(stops, pos)
+                end = int(stops[k]) if k < len(stops) else n
+                sl = slice(pos, end)
+                fit = H[sl] > 0
+                keep = fit.any(axis=1)
+                firsts.append(its[sl][keep])
+                lasts.append(its[sl][keep])
+                remaps.append(np.broadcast_to(ident, (int(keep.sum()), S)))
+                nrows.append(H[sl][keep])
+                fits.append(fit[keep])
+                pos, first_call = end, False
+                continue
             # pull iterations until every SEEN bin has >= k rows
             group, counts = [], np.zeros(S, dtype=np.int64)
-            call_remap = np.arange(S, dtype=np.int32)
+            call_remap = ident.copy()
             ran_out = False
             while True:
-                if pos + len(group) >= len(iters_to_use):  # :798-826 IndexError branch
+                if pos + len(group) >= n:  # :798-826 IndexError branch
                     ran_out = True
                     break
-                it = iters_to_use[pos + len(group)]
+                it = int(its[pos + len(group)])
                 if it > self.maxIter:  # :834-840
                     break
                 group.append(it)
@@ -160,7 +185,7 @@ class ClusteringMixin:
             if not all(b == a + 1 for a, b in zip(group, group[1:])):
                 raise NotImplementedError("non-contiguous iters_to_use within one training call")
             unique_bins = np.nonzero(counts > 0)[0]
-            unfilled_ret, failed = [], False
+            failed = False
             if ran_out:
                 unfilled = unique_bins[counts[unique_bins] < n_clusters]
                 filled = np.setdiff1d(unique_bins, unfilled)
@@ -174,34 +199,43 @@ class ClusteringMixin:
                     log.info("Clustering couldn't use last iteration, not all bins filled.")
                     failed = True
                 unique_bins = filled
-                unfilled_ret = list(unfilled)
             if not failed and len(group) and len(unique_bins):
-                nrows = np.zeros(S, dtype=np.int64)
-                np.add.at(nrows, call_remap, counts)
-                plan.append(dict(group=group, call_remap=call_remap, bins=[int(b) for b in unique_bins], nrows=nrows))
-            if not failed:
-                all_filled.update(int(b) for b in unique_bins)
-                all_unfilled.update(int(b) for b in unfilled_ret)
+                nr = np.zeros(S, dtype=np.int64)
+                np.add.at(nr, call_remap, counts)
+                fit = np.zeros(S, dtype=bool)
+                fit[unique_bins] = True
+                firsts.append(np.array([group[0]]))
+                lasts.append(np.array([group[-1]]))
+                remaps.append(call_remap[None, :])
+                nrows.append(nr[None, :])
+                fits.append(fit[None, :])
             first_call = False
             # :664-669,716: a call that consumed extra iterations skips them; a failed call only advances by one
             pos += max(len(group), 1) if not failed else 1
+        if firsts:
+            plan = dict(first=np.concatenate(firsts), last=np.concatenate(lasts),
+                        call_remap=np.ascontiguousarray(np.concatenate(remaps), dtype=np.int32),
+                        nrows=np.concatenate(nrows), fit=np.concatenate(fits))
+        else:
+            plan = dict(first=np.zeros(0, np.int64), last=np.zeros(0, np.int64), call_remap=np.zeros((0, S), np.int32),
+                        nrows=np.zeros((0, S), np.int64), fit=np.zeros((0, S), bool))
+        all_filled = set(np.nonzero(plan["fit"].any(axis=0))[0].tolist())
         return plan, all_filled
 
     def _train_stepwise(self, plan, clusters, store, d_bin, d_rows):
         """One `partial_fit` at a time with the host in the loop (RandomState draws for reassignment)."""
         h = self.h
-        for call in plan:
-            group = call["group"]
-            f0, f1 = store.span(group[0], group[-1])
+        for g in range(len(plan["first"])):
+            f0, f1 = store.span(int(plan["first"][g]), int(plan["last"][g]))
             n = f1 - f0
-            cnt, starts = h.train_build_rows(d_bin.offset(f0), n, call["call_remap"], d_rows)
+            cnt, starts = h.train_build_rows(d_bin.offset(f0), n, plan["call_remap"][g], d_rows)
             X_base = store.Xc.offset(f0 * store.D)  # segment-END frames (_data.py:616)
             w_base = store.w.offset(f0) if self.use_weights_in_clustering else None
             w_host_all = rows_host = None
             if self.use_weights_in_clustering:
                 w_host_all = np.empty(n)
                 h.d2h(w_host_all, store.w.offset(f0))
-            for b in call["bins"]:  # :890 ascending (np.unique)
+            for b in np.nonzero(plan["fit"][g])[0]:  # :890 ascending (np.unique)
                 nb = int(cnt[b])
                 rows_b = d_rows.offset(int(starts[b]))
                 w_rows = None
@@ -210,7 +244,7 @@ class ClusteringMixin:
                         rows_host = np.empty(int(cnt.sum()), dtype=np.int32)
                         h.d2h(rows_host, d_rows, rows_host.nbytes)
                     w_rows = w_host_all[rows_host[int(starts[b]): int(starts[b]) + nb]]
-                clusters.cluster_models[b].partial_fit_device(X_base, store.x_dtype, store.D, rows_b, nb, w_base, w_rows)
+                clusters.cluster_models[int(b)].partial_fit_device(X_base, store.x_dtype, store.D, rows_b, nb, w_base, w_rows)
 
     def _train_planned(self, plan, clusters, store, d_bin, d_rows):
         """Execute the whole plan on the device without per-step host round trips.
@@ -225,15 +259,22 @@ class ClusteringMixin:
         from .stratified_clustering import _check_random_state
 
         h = self.h
-        if not plan:
+        G = len(plan["first"])
+        if G == 0:
             return True
-        S = clusters.bin_mapper.nbins
-        gb = np.array([store.span(c["group"][0], c["group"][-1])[0] for c in plan], dtype=np.int64)
-        ge = np.array([store.span(c["group"][0], c["group"][-1])[1] for c in plan], dtype=np.int64)
-        counts, starts = h.train_build_rows_batched(d_bin, gb, ge, [c["call_remap"] for c in plan], d_rows)
+        models = clusters.cluster_models
+        ratios = {m.reassignment_ratio for m in models}
+        if len(ratios) != 1:
+            return False
+        ratio = ratios.pop()
+        offs = store.offsets
+        gb = offs[plan["first"] - 1]
+        ge = offs[plan["last"]]
+        counts, starts = h.train_build_rows_batched(d_bin, gb, ge, plan["call_remap"], d_rows)
+        fit = plan["fit"]
+        assert np.array_equal(counts[fit], plan["nrows"][fit]), "row lists disagree with the prepass histogram"
         use_w = self.use_weights_in_clustering
         d_w = store.w if use_w else None
-        models = clusters.cluster_models
         # RandomState streams as they were, for the rerun
         rs_objs = {}
         for m in models:
@@ -242,73 +283,73 @@ class ClusteringMixin:
             rs_objs[id(m._random_state)] = m._random_state
         saved = {k: r.get_state() for k, r in rs_objs.items()}
         clusters._activate()
-        pred = {}  # stratum -> predicted MiniBatchKMeans bookkeeping
-        seeds, all_steps, all_first = [], [], []
-        for g, call in enumerate(plan):
-            for b in call["bins"]:
-                m = models[b]
-                nb = int(counts[g, b])
-                assert nb == int(call["nrows"][b]), "row lists disagree with the prepass histogram"
-                K = m.n_clusters
-                first = b not in pred
-                if first:
-                    if m.fitted:
-                        return False  # continuing a fitted model: take the stepwise path
-                    if nb < K:
-                        raise ValueError(f"n_samples={nb} should be >= n_clusters={K}.")
-                    rs = m._random_state
-                    bs = min(m.batch_size, nb)
-                    init_size = m.init_size
-                    if init_size is None:
-                        init_size = 3 * bs
-                        if init_size < K:
-                            init_size = 3 * K
-                    elif init_size < K:
-                        init_size = 3 * K
-                    init_size = min(init_size, nb)
-                    w_host = np.ones(nb)
-                    if use_w:
-                        rows_host = np.empty(nb, dtype=np.int32)
-                        h.d2h(rows_host, d_rows.offset(int(starts[g, b])), rows_host.nbytes)
-                        w_grp = np.empty(int(ge[g] - gb[g]))
-                        h.d2h(w_grp, store.w.offset(int(gb[g])))
-                        w_host = w_grp[rows_host]
-                    sub, n = None, nb
-                    if init_size < nb:
-                        sub = rs.randint(0, nb, init_size)
-                        n = init_size
-                        w_host = w_host[sub]
-                    fidx = rs.choice(n, p=w_host / w_host.sum())
-                    L = 2 + int(np.log(K))
-                    u = np.concatenate([rs.uniform(size=L) for _ in range(K - 1)]) if K > 1 else np.empty(0)
-                    seeds.append((b, int(gb[g]), int(starts[g, b]), nb, sub, K, int(fidx), u, L))
-                    pred[b] = dict(bs=bs, init=init_size, n_since=0, nsteps=0)
-                st = pred[b]
-                st["n_since"] += st["bs"]
-                do = first or st["n_since"] >= 10 * K
-                if do:
-                    st["n_since"] = 0
-                st["nsteps"] += 1
-                all_steps.append((b, 1 if (do and m.reassignment_ratio > 0) else 0, int(gb[g]), int(starts[g, b]), nb))
-                all_first.append(first)
-        ratios = {m.reassignment_ratio for m in models}
-        if len(ratios) != 1:
-            return False
+        # per bin: the calls that fit it, in order; bookkeeping of MiniBatchKMeans predicted in closed form
+        # (_kmeans.py:2029-2043: with no empty centroid, do_reassign fires every ceil(10K / batch_size) steps)
+        pred, parts = {}, []
+        first_g = np.full(len(models), G, dtype=np.int64)
+        for b in np.nonzero(fit.any(axis=0))[0]:
+            b = int(b)
+            m = models[b]
+            if m.fitted:
+                return False  # continuing a fitted model: take the stepwise path
+            gs = np.nonzero(fit[:, b])[0]
+            nb = counts[gs, b]
+            K = m.n_clusters
+            if nb[0] < K:
+                raise ValueError(f"n_samples={int(nb[0])} should be >= n_clusters={K}.")  # _kmeans.py:875-879
+            bs = int(min(m.batch_size, nb[0]))
+            init_size = m.init_size
+            if init_size is None:
+                init_size = 3 * bs
+                if init_size < K:
+                    init_size = 3 * K
+            elif init_size < K:
+                init_size = 3 * K
+            init_size = int(min(init_size, nb[0]))
+            period = max(1, -(-10 * K // bs))
+            t = np.arange(len(gs))
+            do = (t % period) == 0
+            st = np.zeros(len(gs), dtype=h.STEP_DTYPE)
+            st["stratum"], st["flags"] = b, (do & (ratio > 0)).astype(np.int32)
+            st["x_off"], st["rows_off"], st["n_b"] = gb[gs], starts[gs, b], nb
+            parts.append((gs, np.full(len(gs), b), st, t == 0))
+            pred[b] = dict(bs=bs, init=init_size, n_since=int((len(gs) - 1) % period) * bs, nsteps=len(gs))
+            first_g[b] = gs[0]
+        # seeding draws in the stepwise order: by first call, then bin (shared RandomState streams stay in sync)
+        seeds = []
+        for b in sorted(pred, key=lambda x: (first_g[x], x)):
+            m, g0 = models[b], int(first_g[b])
+            nb, K, rs = int(counts[g0, b]), m.n_clusters, m._random_state
+            w_host = np.ones(nb)
+            if use_w:
+                rows_host = np.empty(nb, dtype=np.int32)
+                h.d2h(rows_host, d_rows.offset(int(starts[g0, b])), rows_host.nbytes)
+                w_grp = np.empty(int(ge[g0] - gb[g0]))
+                h.d2h(w_grp, store.w.offset(int(gb[g0])))
+                w_host = w_grp[rows_host]
+            sub, n = None, nb
+            if pred[b]["init"] < nb:  # _kmeans.py:1003-1011
+                sub = rs.randint(0, nb, pred[b]["init"])
+                n = pred[b]["init"]
+                w_host = w_host[sub]
+            fidx = rs.choice(n, p=w_host / w_host.sum())  # :225
+            L = 2 + int(np.log(K))
+            u = np.concatenate([rs.uniform(size=L) for _ in range(K - 1)]) if K > 1 else np.empty(0)  # :243
+            seeds.append((b, int(gb[g0]), int(starts[g0, b]), nb, sub, K, int(fidx), u, L))
         # strata are independent and a seeding reads only its own first batch: every seeding can be issued
-        # before every step (the draws above were made in the stepwise order)
-        if seeds:
-            z = list(zip(*seeds))
-            h.kmeans_seed_multi(z[0], store.Xc, store.x_dtype, store.D, z[1], d_rows, z[2], z[3], d_w, z[4], z[5], z[6],
-                                z[7], z[8])
-        report = h.minibatch_run(store.Xc, store.x_dtype, store.D, d_rows, d_w,
-                                 np.array(all_steps, dtype=h.STEP_DTYPE), ratios.pop())
-        ok = True
-        for i, (stp, first) in enumerate(zip(all_steps, all_first)):
-            if report[i, 1] != 0 or (report[i, 0] != 0 and not first):
-                ok = False
-                break
-        if not ok:
-            log.info("training plan mispredicted a reassignment at step %d: rerunning stepwise", i)
+        # before every step
+        z = list(zip(*seeds))
+        h.kmeans_seed_multi(z[0], store.Xc, store.x_dtype, store.D, z[1], d_rows, z[2], z[3], d_w, z[4], z[5], z[6], z[7], z[8])
+        # steps in call order, bins ascending inside a call (:890)
+        gcat = np.concatenate([p[0] for p in parts])
+        bcat = np.concatenate([p[1] for p in parts])
+        order = np.lexsort((bcat, gcat))
+        steps = np.concatenate([p[2] for p in parts])[order]
+        is_first = np.concatenate([p[3] for p in parts])[order]
+        report = h.minibatch_run(store.Xc, store.x_dtype, store.D, d_rows, d_w, steps, ratio)
+        bad = (report[:, 1] != 0) | ((report[:, 0] != 0) & ~is_first)
+        if bad.any():
+            log.info("training plan mispredicted a reassignment at step %d: rerunning stepwise", int(np.argmax(bad)))
             for k, r in rs_objs.items():
                 r.set_state(saved[k])
             for b in pred:
