@@ -1,0 +1,181 @@
+"""Parity at BASELINE.json's full sizes through size-independent properties (the oracle cannot
+finish these sizes in seconds, so it checks bounded random samples and the properties do the rest):
+
+C2  1 M frames x 10 features, 200 clusters, 1 stratum   (assign only)
+C3 10 M frames x 30 features, 4 strata x 250 clusters   (train + assign + flux + stats)
+"""
+import numpy as np
+import pytest
+
+from conftest import RectilinearBinMapper
+from msm_we_amd import synthetic
+from msm_we_amd.data import DeviceStore
+from msm_we_amd.model import modelWE
+
+pytestmark = pytest.mark.gpu
+
+
+def _shard(cfg, n_iters):
+    lat = synthetic.latent_centres(cfg)
+    n = n_iters * cfg.segs_per_iter
+    out = dict(Xp=np.empty((n, cfg.D), np.float32), Xc=np.empty((n, cfg.D), np.float32), p0=np.empty((n, 1)),
+               p1=np.empty((n, 1)), w=np.empty(n))
+    for k in range(n_iters):
+        d = synthetic.make_iteration(cfg, k + 1, lat)
+        a, b = k * cfg.segs_per_iter, (k + 1) * cfg.segs_per_iter
+        for key in out:
+            out[key][a:b] = d[key]
+    out["offsets"] = np.arange(n_iters + 1, dtype=np.int64) * cfg.segs_per_iter
+    return out
+
+
+def _model(h, cfg, d):
+    store = DeviceStore.from_host(h, d["Xp"], d["Xc"], d["p0"], d["p1"], d["w"], d["offsets"])
+    m = modelWE(h=h)
+    m.pcoord_ndim = 1
+    basis, target = synthetic.basis_target_bounds(cfg.S)
+    m.basis_pcoord_bounds, m.target_pcoord_bounds, m.tau = basis, target, 1.0
+    m.attach_store(store)
+    m.maxIter = len(d["offsets"])  # every resident iteration is complete
+    m.numSegments = np.diff(d["offsets"]).astype(float)
+    return m, store
+
+
+def _check_assign_sample(oracle_h, h, cfg, X, p, labels, rng, n_sample=4000):
+    """the oracle on a random sample of the full-size launch: labels bit-identical"""
+    idx = np.sort(rng.choice(len(X), n_sample, replace=False))
+    oracle_h.set_geometry(cfg.D, 1, cfg.S)
+    oracle_h.set_mapper_rectilinear([synthetic.strata_boundaries(cfg.S)])
+    basis, target = synthetic.basis_target_bounds(cfg.S)
+    oracle_h.set_bounds(basis, target)
+    for s in range(cfg.S):
+        Cm, counts, csq = h.get_centroids(s)
+        oracle_h.set_centroids(s, Cm, csq=csq)
+    ref = oracle_h.predict_host(X[idx], p[idx])
+    assert np.array_equal(ref, labels[idx])
+
+
+def test_c2_assign_full_size(hip_h, oracle_h):
+    cfg = synthetic.CONFIGS["c2"]  # 1000 x 1000 x 10, 1 stratum x 200
+    d = _shard(cfg, cfg.n_iters)
+    h = hip_h
+    h.set_geometry(cfg.D, 1, cfg.S)
+    h.set_mapper_rectilinear([synthetic.strata_boundaries(cfg.S)])
+    basis, target = synthetic.basis_target_bounds(cfg.S)
+    h.set_bounds(basis, target)
+    rng = np.random.default_rng(0)
+    # centroids "from a 20 k-row partial_fit" (SURVEY §8d): seed + one step on the first 20 iterations
+    from msm_we_amd.stratified_clustering import StratifiedClusters
+
+    cl = StratifiedClusters(RectilinearBinMapper([synthetic.strata_boundaries(cfg.S)]), None, cfg.K_s, h=h, random_state=2)
+    cl.cluster_models[0].partial_fit(d["Xc"][:20000])
+    cl._activate()
+    n = len(d["Xc"])
+    d_X, d_p, d_l = h.to_device(d["Xc"]), h.to_device(d["p1"]), h.alloc(n, np.int32)
+    h.assign(d_X, 0, cfg.D, d_p, n, d_l)
+    lab = d_l.to_host()
+    K = cfg.K_s
+    tgt = d["p1"][:, 0] > cfg.S - 0.05
+    bas = d["p1"][:, 0] < 0.05
+    assert np.all(lab[tgt] == K + 1) and np.all(lab[bas & ~tgt] == K) and lab[~(tgt | bas)].max() < K
+    _check_assign_sample(oracle_h, h, cfg, d["Xc"], d["p1"], lab, rng)
+    # permutation equivariance and chunk independence (the kernel buckets frames per 512-frame chunk)
+    perm = rng.permutation(n)
+    h.h2d(d_X, d["Xc"][perm])
+    h.h2d(d_p, d["p1"][perm])
+    h.assign(d_X, 0, cfg.D, d_p, n, d_l)
+    assert np.array_equal(d_l.to_host(), lab[perm])
+    off = 123457
+    h.assign(d_X.offset(off * cfg.D), 0, cfg.D, d_p.offset(off), 300001, d_l)
+    assert np.array_equal(d_l.to_host()[:300001], lab[perm][off: off + 300001])
+    # every centroid is its own nearest centroid (distance 0 to itself; ties -> first index)
+    Cm = h.get_centroids(0)[0]
+    assert np.array_equal(h.predict_host(Cm, np.full((K, 1), 0.5)), np.arange(K))
+
+
+@pytest.fixture(scope="module")
+def c3_run(hip_lib):
+    from msm_we_amd import _abi
+
+    cfg = synthetic.CONFIGS["c3"]  # 1000 x 10000 x 30, 4 strata x 250
+    d = _shard(cfg, cfg.n_iters)
+    h = _abi.Hamsm(lib=hip_lib)
+    m, store = _model(h, cfg, d)
+    bm = RectilinearBinMapper([synthetic.strata_boundaries(cfg.S)])
+    m.cluster_coordinates(cfg.K_s, streaming=True, use_ray=True, stratified=True, user_bin_mapper=bm, random_state=1337)
+    yield cfg, d, h, m, store, bm
+    h.close()
+
+
+def test_c3_train_assign_full_size(c3_run, oracle_h):
+    cfg, d, h, m, store, bm = c3_run
+    assert m.training_path == "planned" and m.n_clusters == 1000
+    n = store.N  # maxIter = n_iters + 1: iterations 1..maxIter-1 (all resident ones) are trained on and discretized
+    child = np.concatenate(m.dtrajs)
+    parent = np.concatenate([p[:, 0] for p in m.pair_dtrajs])
+    assert len(child) == n
+    rng = np.random.default_rng(1)
+    _check_assign_sample(oracle_h, h, cfg, d["Xc"][:n], d["p1"][:n], child.astype(np.int32), rng)
+    _check_assign_sample(oracle_h, h, cfg, d["Xp"][:n], d["p0"][:n], parent.astype(np.int32), rng)
+    # strata never mix: a frame of stratum s gets a label in [250 s, 250 s + 250)
+    free = (d["p1"][:n, 0] >= 0.05) & (d["p1"][:n, 0] <= cfg.S - 0.05)
+    s_of = np.minimum(np.floor(d["p1"][:n, 0].astype(np.float32)), cfg.S - 1).astype(int)
+    assert np.array_equal(child[free] // cfg.K_s, s_of[free])
+    # training bookkeeping: counts sum to the rows each stratum's model saw (sample weights are 1)
+    for s, cm in enumerate(m.clusters.cluster_models):
+        p0f = d["p0"][:n, 0].astype(np.float32)  # the mapper compares in float32 (westpa), basis/target in float64
+        seen = ((np.floor(p0f) == s) | ((s == cfg.S - 1) & (p0f >= cfg.S))) \
+            & (d["p0"][:n, 0] >= 0.05) & (d["p0"][:n, 0] <= cfg.S - 0.05)
+        assert cm._counts.sum() == seen.sum()
+        assert cm.n_steps_ == cfg.n_iters
+    # determinism: a second full run gives bit-identical centroids and labels
+    m2, _ = _model(h, cfg, d)
+    m2._store = store
+    m2.cluster_coordinates(cfg.K_s, streaming=True, use_ray=True, stratified=True, user_bin_mapper=bm, random_state=1337)
+    for a, b in zip(m.clusters.cluster_models, m2.clusters.cluster_models):
+        assert np.array_equal(a.cluster_centers_, b.cluster_centers_)
+    assert np.array_equal(np.concatenate(m2.dtrajs), child)
+
+
+def test_c3_flux_and_stats_full_size(c3_run):
+    cfg, d, h, m, store, bm = c3_run
+    K = m.n_clusters
+    n = store.N
+    child = np.concatenate(m.dtrajs)
+    parent = np.concatenate([p[:, 0] for p in m.pair_dtrajs])
+    m.flux_mode = 1
+    m.get_fluxMatrix(0, first_iter=1, last_iter=m.maxIter)
+    F_det = m.fluxMatrixRaw.copy()
+    m.flux_mode = 0
+    m.get_fluxMatrix(0, first_iter=1, last_iter=m.maxIter)
+    F_at = m.fluxMatrixRaw.copy()
+    np.testing.assert_allclose(F_at, F_det, rtol=1e-11, atol=1e-300)
+    # every iteration's weights sum to 1 and the matrix is the mean over iterations 2..maxIter-1
+    assert abs(F_det.sum() - 1.0) < 1e-12
+    # independent host accumulation (np.add.at, same overrides: _fluxmatrix.py:135-137)
+    lo, hi = cfg.segs_per_iter, n  # iterations 2 .. maxIter-1
+    a, b = parent[lo:hi].copy(), child[lo:hi].copy()
+    p0, p1 = d["p0"][lo:hi, 0], d["p1"][lo:hi, 0]
+    b[p1 > cfg.S - 0.05] = K + 1
+    a[p0 < 0.05] = K
+    b[p1 < 0.05] = K
+    ref = np.zeros((K + 2) * (K + 2))
+    np.add.at(ref, a * (K + 2) + b, d["w"][lo:hi])
+    ref = ref.reshape(K + 2, K + 2) / (m.maxIter - 2)
+    np.testing.assert_allclose(F_det, ref, rtol=1e-11, atol=1e-18)
+    assert np.array_equal(F_det == 0, ref == 0)
+    # determinism of the sorted kernel
+    m.flux_mode = 1
+    m.get_fluxMatrix(0, first_iter=1, last_iter=m.maxIter)
+    assert np.array_equal(m.fluxMatrixRaw, F_det)
+    # cluster statistics: counts partition the frames, min <= mean <= max
+    order = m.get_cluster_centers()
+    cnt = m.cluster_pcoord_counts
+    assert cnt.sum() == np.sum(child < K)
+    c, mm = m.targetRMSD_centers[:, 0], m.targetRMSD_minmax[:, 0, :]
+    ok = ~np.isnan(c)
+    assert np.all(mm[ok, 0] <= c[ok] + 1e-12) and np.all(c[ok] <= mm[ok, 1] + 1e-12)
+    assert np.all(np.diff(c[ok]) >= 0)  # sorted by mean pcoord
+    href = np.bincount(child[child < K], weights=d["p1"][:n, 0][child < K], minlength=K) / np.maximum(
+        np.bincount(child[child < K], minlength=K), 1)
+    np.testing.assert_allclose(np.sort(href[np.bincount(child[child < K], minlength=K) > 0]), c[ok], rtol=1e-11)
