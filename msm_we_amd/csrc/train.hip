@@ -681,10 +681,14 @@ struct StepDev {
   long long n_b;
   int32_t *labels;       // [n_b] scratch
   double *Xg;            // [n_b][D] the batch rows, gathered once by the E-step for the M-step (L2-resident)
+  int32_t *mcnt;         // [K] members appended by the E-step (reset by the M-step)
+  int32_t *mlist;        // [K][MCAP] member batch rows, unordered (the M-step sorts them)
   double *C, *counts, *csq, *Bpack;
   int K, flags;
   int32_t *report;       // [2]
 };
+
+#define MCAP 64  // members per centroid kept in the unordered lists; larger clusters fall back to a label scan
 
 // E-step: one workgroup per 16-row tile; the stratum's centroid tiles are split over the 4 waves, each wave
 // issues ALL of its B-fragment loads before the first MFMA (one L2 round trip), then the 4 partial
@@ -789,6 +793,8 @@ __global__ __launch_bounds__(256) void k_step_assign(const StepDev *__restrict__
     }
     if (j == 0x7fffffff) j = 0;  // all-NaN row: label 0 like the oracle
     st.labels[r0 + tid] = j;
+    int pos = atomicAdd(&st.mcnt[j], 1);
+    if (pos < MCAP) st.mlist[(size_t)j * MCAP + pos] = (int)(r0 + tid);
   }
 }
 
@@ -801,20 +807,23 @@ __global__ __launch_bounds__(256) void k_step_update(const StepDev *__restrict__
   const StepDev st = steps[blockIdx.y];
   if (blockIdx.x * 4 >= st.K) return;
   extern __shared__ int lds_i[];
-  int *slab = lds_i;                                        // [min(n_b, CAP)] labels
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  const bool in_lds = st.n_b <= UPD_LABEL_CAP;
-  int *list = lds_i + (in_lds ? (int)st.n_b : 0) + wv * UPD_LIST;  // [UPD_LIST] member batch of this wave
-  if (in_lds) {
-    for (long long i = threadIdx.x; i < st.n_b; i += 256) slab[i] = st.labels[i];
-    __syncthreads();
-  }
-  const int *lab = in_lds ? slab : st.labels;
+  int *list = lds_i + wv * UPD_LIST;  // [UPD_LIST] member batch rows of this wave, ascending
+  const int *lab = st.labels;         // (global) only scanned by clusters with more than MCAP members
   const int j = blockIdx.x * 4 + wv;
   if (j >= st.K) return;
-  const XT *X = (const XT *)st.X;
   const long long n_b = st.n_b;
-
+  const int mc = st.mcnt[j];
+  if (mc == 0) return;  // no member: wsum = 0, centre unchanged (pyx:105-108)
+  if (lane == 0) st.mcnt[j] = 0;  // ready for the stratum's next step
+  const bool listed = mc <= MCAP;
+  if (listed) {
+    // the E-step appended the members in arrival order: sort by batch row (rank = number of smaller rows)
+    int mine = lane < mc ? st.mlist[(size_t)j * MCAP + lane] : 0x7fffffff;
+    int rank = 0;
+    for (int q = 0; q < mc; q++) rank += __shfl(mine, q, 64) < mine;
+    if (lane < mc) list[rank] = mine;
+  }
   // labels are scanned 256 at a time (4 consecutive per lane); members are appended in ascending sample order
   auto scan4 = [&](long long base, int &fill, bool store) -> int {
     int l4[4];
@@ -844,7 +853,13 @@ __global__ __launch_bounds__(256) void k_step_update(const StepDev *__restrict__
 
   // pass 1: wsum in sample order (pyx:80-85); unweighted: the sum of `cnt` ones is exactly cnt
   double wsum = 0.0;
-  {
+  if (listed) {
+    if (!st.wf) wsum = (double)mc;
+    else {
+      double wv_ = st.wf[st.rows ? (long long)st.rows[list[lane < mc ? lane : 0]] : (long long)list[lane < mc ? lane : 0]];
+      for (int q = 0; q < mc; q++) wsum = wsum + __shfl(wv_, q, 64);
+    }
+  } else {
     int fill = 0;
     long long cnt = 0;
     for (long long base = 0; base < n_b; base += 256) {
@@ -874,30 +889,34 @@ __global__ __launch_bounds__(256) void k_step_update(const StepDev *__restrict__
     int k = lane + 64 * h;
     acc[h] = (k < D) ? st.C[(size_t)j * D + k] * cnt0 : 0.0;
   }
-  {
+  auto add_members = [&](int fill) {
+    for (int m0 = 0; m0 < fill; m0 += 8) {
+      double xv[8][2], wq[8];
+#pragma unroll
+      for (int q = 0; q < 8; q++) {
+        int ii = (m0 + q < fill) ? list[m0 + q] : -1;
+        wq[q] = (ii >= 0) ? (st.wf ? st.wf[st.rows ? (long long)st.rows[ii] : (long long)ii] : 1.0) : 0.0;
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+          int k = lane + 64 * h;
+          xv[q][h] = (ii >= 0 && k < D) ? st.Xg[(size_t)ii * D + k] : 0.0;
+        }
+      }
+#pragma unroll
+      for (int q = 0; q < 8; q++)
+        if (m0 + q < fill) {
+#pragma unroll
+          for (int h = 0; h < 2; h++) acc[h] = acc[h] + xv[q][h] * wq[q];
+        }
+    }
+  };
+  if (listed) add_members(mc);
+  else {
     int fill = 0;
     for (long long base = 0; base < n_b; base += 256) {
       scan4(base, fill, true);
       if (fill && (fill > UPD_LIST - 256 || base + 256 >= n_b)) {
-        for (int m0 = 0; m0 < fill; m0 += 8) {
-          double xv[8][2], wq[8];
-#pragma unroll
-          for (int q = 0; q < 8; q++) {
-            int ii = (m0 + q < fill) ? list[m0 + q] : -1;
-            wq[q] = (ii >= 0) ? (st.wf ? st.wf[st.rows ? (long long)st.rows[ii] : (long long)ii] : 1.0) : 0.0;
-#pragma unroll
-            for (int h = 0; h < 2; h++) {
-              int k = lane + 64 * h;
-              xv[q][h] = (ii >= 0 && k < D) ? st.Xg[(size_t)ii * D + k] : 0.0;
-            }
-          }
-#pragma unroll
-          for (int q = 0; q < 8; q++)
-            if (m0 + q < fill) {
-#pragma unroll
-              for (int h = 0; h < 2; h++) acc[h] = acc[h] + xv[q][h] * wq[q];
-            }
-        }
+        add_members(fill);
         fill = 0;
       }
     }
@@ -956,7 +975,7 @@ static void launch_step_kernels(hamsm_ctx *c, const StepDev *d_steps, int ny, lo
   constexpr int JB = KS <= 4 ? 8 : (KS <= 8 ? 4 : (KS <= 16 ? 2 : 1));
   dim3 ga((unsigned)((max_nb + 15) / 16), (unsigned)ny);
   hipLaunchKernelGGL((k_step_assign<XT, KS, JB>), ga, dim3(256), 0, c->stream, d_steps, ldx, c->D);
-  size_t lds = sizeof(int) * ((size_t)(max_nb <= UPD_LABEL_CAP ? max_nb : 0) + 4 * UPD_LIST);
+  size_t lds = sizeof(int) * (4 * UPD_LIST);
   dim3 gu((unsigned)((maxK + 3) / 4), (unsigned)ny);
   hipLaunchKernelGGL(k_step_update<XT>, gu, dim3(256), lds, c->stream, d_steps, ldx, c->D, c->KS);
   if (any_check) hipLaunchKernelGGL(k_step_check, dim3((unsigned)ny), dim3(256), 0, c->stream, d_steps, ratio);
@@ -1003,6 +1022,9 @@ static int run_steps(hamsm_ctx *c, const void *X, int dt, int64_t ldx, const int
   // the gathered batch copy is reused by every launch group: one slot per stratum position, stream-ordered
   const int nslot = c->S < 65535 ? c->S : 65535;
   size_t o_xg = take(sizeof(double) * (size_t)nslot * nb_max * c->D);
+  int Kmax = 0;
+  for (int s = 0; s < c->S; s++) Kmax = c->st[s].K > Kmax ? c->st[s].K : Kmax;
+  size_t o_mc = take(sizeof(int32_t) * (size_t)nslot * Kmax), o_ml = take(sizeof(int32_t) * (size_t)nslot * Kmax * MCAP);
   int rc = hamsm_ensure_scratch(c, off);
   if (rc) return rc;
   char *b = (char *)c->scratch;
@@ -1035,6 +1057,8 @@ static int run_steps(hamsm_ctx *c, const void *X, int dt, int64_t ldx, const int
       while (j0 < n_steps && !used0[h_steps[j0].stratum] && j0 - i0 < 65535) {
         used0[h_steps[j0].stratum] = 1;
         sd[j0].Xg = (double *)(b + o_xg) + (size_t)(j0 - i0) * nb_max * c->D;
+        sd[j0].mcnt = (int32_t *)(b + o_mc) + (size_t)(j0 - i0) * Kmax;
+        sd[j0].mlist = (int32_t *)(b + o_ml) + (size_t)(j0 - i0) * Kmax * MCAP;
         j0++;
       }
       i0 = j0;
@@ -1043,6 +1067,7 @@ static int run_steps(hamsm_ctx *c, const void *X, int dt, int64_t ldx, const int
   if (labels_of_first) *labels_of_first = sd[0].labels;
   HIPCHK(c, hipMemcpyAsync(b + o_steps, sd.data(), sizeof(StepDev) * n_steps, hipMemcpyHostToDevice, c->stream));
   HIPCHK(c, hipMemsetAsync(b + o_rep, 0, sizeof(int32_t) * 2 * n_steps, c->stream));
+  HIPCHK(c, hipMemsetAsync(b + o_mc, 0, sizeof(int32_t) * (size_t)nslot * Kmax, c->stream));
   const StepDev *d_steps = (const StepDev *)(b + o_steps);
   hamsm_timer_begin(c);
   std::vector<char> used(c->S);
