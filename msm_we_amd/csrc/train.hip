@@ -310,11 +310,17 @@ __global__ __launch_bounds__(SEED_T) void k_seed(const SeedItem *__restrict__ it
         double acc[SEED_LMAX];
 #pragma unroll
         for (int l = 0; l < SEED_LMAX; l++) acc[l] = 0.0;
-        for (int k = 0; k < D; k++) {
-          const double xi = XbT[(size_t)k * n + i];
+        for (int k0 = 0; k0 < D; k0 += 8) {
+          double xk[8];
 #pragma unroll
-          for (int l = 0; l < SEED_LMAX; l++)
-            if (l < L) acc[l] = __builtin_fma(crow[l * D + k], xi, acc[l]);
+          for (int q = 0; q < 8; q++) xk[q] = XbT[(size_t)(k0 + q < D ? k0 + q : 0) * n + i];
+#pragma unroll
+          for (int q = 0; q < 8; q++)
+            if (k0 + q < D) {
+#pragma unroll
+              for (int l = 0; l < SEED_LMAX; l++)
+                if (l < L) acc[l] = __builtin_fma(crow[l * D + k0 + q], xk[q], acc[l]);
+            }
         }
         const double ci = it.closest[i], xi2 = it.xsq[i], wi = it.w[i];
 #pragma unroll
@@ -369,6 +375,17 @@ __global__ __launch_bounds__(SEED_T) void k_seed(const SeedItem *__restrict__ it
 // Same algorithm for batches that fit on chip (n <= SEED_NLDS rows, L <= SEED_LFAST candidates): w, ||x||^2,
 // closest and the chunk bases live in LDS and every thread keeps the candidate distances of its own rows in
 // registers, so a greedy step touches global memory only to stream the (L2-resident) batch once.
+#ifdef SEED_PROFILE
+__device__ unsigned long long g_seed_prof[16];
+#define PROF_T(idx)                                                        \
+  if (tid == 0 && blockIdx.x == 0) {                                       \
+    unsigned long long t_ = __builtin_amdgcn_s_memtime();                  \
+    g_seed_prof[idx] += t_ - t_last;                                       \
+    t_last = t_;                                                           \
+  }
+#else
+#define PROF_T(idx)
+#endif
 #define SEED_NLDS 3072
 #define SEED_RPT (SEED_NLDS / SEED_T)
 #define SEED_LFAST 8
@@ -397,7 +414,7 @@ __global__ __launch_bounds__(SEED_T) void k_seed_lds(const SeedItem *__restrict_
   }
   for (int k = tid; k < D; k += SEED_T) {
     double v = XbT[(size_t)k * n + it.first];
-    crow[k] = v;
+    crow[k * SEED_LFAST] = v;
     it.C[k] = v;
   }
   if (tid == 0) it.chosen[0] = it.first;
@@ -410,7 +427,14 @@ __global__ __launch_bounds__(SEED_T) void k_seed_lds(const SeedItem *__restrict_
       int i = tid + r * SEED_T;
       if (i < n) {
         double acc = 0.0;
-        for (int k = 0; k < D; k++) acc = __builtin_fma(crow[k], XbT[(size_t)k * n + i], acc);
+        for (int k0 = 0; k0 < D; k0 += 8) {
+          double xk[8];
+#pragma unroll
+          for (int q = 0; q < 8; q++) xk[q] = XbT[(size_t)(k0 + q < D ? k0 + q : 0) * n + i];
+#pragma unroll
+          for (int q = 0; q < 8; q++)
+            if (k0 + q < D) acc = __builtin_fma(crow[(k0 + q) * SEED_LFAST], xk[q], acc);
+        }
         double v = ((-2.0 * acc) + xs0) + lxsq[i];
         v = v > 0.0 ? v : 0.0;
         lcl[i] = v;
@@ -423,14 +447,29 @@ __global__ __launch_bounds__(SEED_T) void k_seed_lds(const SeedItem *__restrict_
     __syncthreads();
   }
   const int nch = (n + SCAN_CHUNK - 1) / SCAN_CHUNK;
+#ifdef SEED_PROFILE
+  unsigned long long t_last = __builtin_amdgcn_s_memtime();
+#endif
   for (int cc = 1; cc < K; cc++) {
     if (tid < nch) {
       double loc = 0.0;
       int e = (tid + 1) * SCAN_CHUNK < n ? (tid + 1) * SCAN_CHUNK : n;
-      for (int i = tid * SCAN_CHUNK; i < e; i++) loc = loc + lw[i] * lcl[i];
+      for (int i0 = tid * SCAN_CHUNK; i0 < e; i0 += 16) {
+        double pw[16], pc[16];
+#pragma unroll
+        for (int q = 0; q < 16; q++) {
+          int i = i0 + q < e ? i0 + q : i0;
+          pw[q] = lw[i];
+          pc[q] = lcl[i];
+        }
+#pragma unroll
+        for (int q = 0; q < 16; q++)
+          if (i0 + q < e) loc = loc + pw[q] * pc[q];
+      }
       lbase[tid] = loc;
     }
     __syncthreads();
+    PROF_T(0)
     if (tid == 0) {
       double base = 0.0;
       for (int q = 0; q < nch; q++) {
@@ -440,6 +479,7 @@ __global__ __launch_bounds__(SEED_T) void k_seed_lds(const SeedItem *__restrict_
       }
     }
     __syncthreads();
+    PROF_T(1)
     if (tid < L) {
       const double v = it.u[(size_t)(cc - 1) * L + tid] * s_pot;  // :243
       int lo = 0, hi = nch;
@@ -452,22 +492,59 @@ __global__ __launch_bounds__(SEED_T) void k_seed_lds(const SeedItem *__restrict_
       for (int q = lo; q < nch && ans == n; q++) {
         double loc = 0.0, base = lbase[q];
         int e = (q + 1) * SCAN_CHUNK < n ? (q + 1) * SCAN_CHUNK : n;
-        for (int i = q * SCAN_CHUNK; i < e; i++) {
-          loc = loc + lw[i] * lcl[i];
-          if (base + loc >= v) {
-            ans = i;
-            break;
+        for (int i0 = q * SCAN_CHUNK; i0 < e && ans == n; i0 += 16) {
+          double pw[16], pc[16];
+#pragma unroll
+          for (int z = 0; z < 16; z++) {
+            int i = i0 + z < e ? i0 + z : i0;
+            pw[z] = lw[i];
+            pc[z] = lcl[i];
           }
+#pragma unroll
+          for (int z = 0; z < 16; z++)
+            if (i0 + z < e && ans == n) {
+              loc = loc + pw[z] * pc[z];
+              if (base + loc >= v) ans = i0 + z;
+            }
         }
       }
       if (ans > n - 1) ans = n - 1;  // :249
       cid[tid] = ans;
     }
     __syncthreads();
-    for (int e = tid; e < L * D; e += SEED_T) crow[e] = XbT[(size_t)(e % D) * n + cid[e / D]];
+    PROF_T(2)
+    // candidate rows, feature-major [k][LFAST]: one k's L values are contiguous (128-bit LDS reads, each read once
+    // per k and reused for all of the thread's rows)
+    for (int e = tid; e < L * D; e += SEED_T) crow[(e % D) * SEED_LFAST + e / D] = XbT[(size_t)(e % D) * n + cid[e / D]];
     __syncthreads();
+    PROF_T(3)
     double cnd[SEED_RPT][SEED_LFAST];
     {
+#pragma unroll
+      for (int r = 0; r < SEED_RPT; r++)
+#pragma unroll
+        for (int l = 0; l < SEED_LFAST; l++) cnd[r][l] = 0.0;
+      // dot products: acc[r][l] = fma chain over k of crow[l][k] * x_r[k]
+      for (int k0 = 0; k0 < D; k0 += 4) {
+        double xk[SEED_RPT][4];
+#pragma unroll
+        for (int r = 0; r < SEED_RPT; r++) {
+          int i = tid + r * SEED_T;
+#pragma unroll
+          for (int q = 0; q < 4; q++) xk[r][q] = XbT[(size_t)(k0 + q < D ? k0 + q : 0) * n + (i < n ? i : 0)];
+        }
+#pragma unroll
+        for (int q = 0; q < 4; q++)
+          if (k0 + q < D) {
+            double cr[SEED_LFAST];
+#pragma unroll
+            for (int l = 0; l < SEED_LFAST; l++) cr[l] = crow[(k0 + q) * SEED_LFAST + l];
+#pragma unroll
+            for (int r = 0; r < SEED_RPT; r++)
+#pragma unroll
+              for (int l = 0; l < SEED_LFAST; l++) cnd[r][l] = __builtin_fma(cr[l], xk[r][q], cnd[r][l]);
+          }
+      }
       double a[SEED_LFAST];
 #pragma unroll
       for (int l = 0; l < SEED_LFAST; l++) a[l] = 0.0;
@@ -475,20 +552,11 @@ __global__ __launch_bounds__(SEED_T) void k_seed_lds(const SeedItem *__restrict_
       for (int r = 0; r < SEED_RPT; r++) {
         int i = tid + r * SEED_T;
         if (i < n) {
-          double acc[SEED_LFAST];
-#pragma unroll
-          for (int l = 0; l < SEED_LFAST; l++) acc[l] = 0.0;
-          for (int k = 0; k < D; k++) {
-            const double xi = XbT[(size_t)k * n + i];
-#pragma unroll
-            for (int l = 0; l < SEED_LFAST; l++)
-              if (l < L) acc[l] = __builtin_fma(crow[l * D + k], xi, acc[l]);
-          }
           const double ci = lcl[i], xi2 = lxsq[i], wi = lw[i];
 #pragma unroll
           for (int l = 0; l < SEED_LFAST; l++)
             if (l < L) {
-              double v = ((-2.0 * acc[l]) + lxsq[cid[l]]) + xi2;  // :252-254
+              double v = ((-2.0 * cnd[r][l]) + lxsq[cid[l]]) + xi2;  // :252-254
               v = v > 0.0 ? v : 0.0;
               v = v < ci ? v : ci;  // :257
               cnd[r][l] = v;
@@ -501,16 +569,25 @@ __global__ __launch_bounds__(SEED_T) void k_seed_lds(const SeedItem *__restrict_
         if (l < L) part[l * SEED_T + tid] = a[l];
     }
     __syncthreads();
+    PROF_T(4)
     if (tid < L * (SEED_T / SEED_GROUP)) {
       int l = tid / (SEED_T / SEED_GROUP), g = tid % (SEED_T / SEED_GROUP);
+      double pv[SEED_GROUP];
+#pragma unroll
+      for (int t = 0; t < SEED_GROUP; t++) pv[t] = part[l * SEED_T + g * SEED_GROUP + t];
       double gs = 0.0;
-      for (int t = 0; t < SEED_GROUP; t++) gs = gs + part[l * SEED_T + g * SEED_GROUP + t];
+#pragma unroll
+      for (int t = 0; t < SEED_GROUP; t++) gs = gs + pv[t];
       grp[l * (SEED_T / SEED_GROUP) + g] = gs;
     }
     __syncthreads();
     if (tid < L) {
+      double pv[SEED_T / SEED_GROUP];
+#pragma unroll
+      for (int g = 0; g < SEED_T / SEED_GROUP; g++) pv[g] = grp[tid * (SEED_T / SEED_GROUP) + g];
       double s = 0.0;
-      for (int g = 0; g < SEED_T / SEED_GROUP; g++) s = s + grp[tid * (SEED_T / SEED_GROUP) + g];
+#pragma unroll
+      for (int g = 0; g < SEED_T / SEED_GROUP; g++) s = s + pv[g];
       pots[tid] = s;
     }
     __syncthreads();
@@ -527,6 +604,7 @@ __global__ __launch_bounds__(SEED_T) void k_seed_lds(const SeedItem *__restrict_
       it.chosen[cc] = cid[best];
     }
     __syncthreads();
+    PROF_T(5)
     const int best = s_best;
 #pragma unroll
     for (int r = 0; r < SEED_RPT; r++) {
@@ -538,10 +616,17 @@ __global__ __launch_bounds__(SEED_T) void k_seed_lds(const SeedItem *__restrict_
         lcl[i] = v;
       }
     }
-    for (int k = tid; k < D; k += SEED_T) it.C[(size_t)cc * D + k] = crow[best * D + k];
+    for (int k = tid; k < D; k += SEED_T) it.C[(size_t)cc * D + k] = crow[k * SEED_LFAST + best];
     __syncthreads();
+    PROF_T(6)
   }
 }
+
+#ifdef SEED_PROFILE
+extern "C" int hamsm_debug_seed_profile(unsigned long long *h_out) {
+  return hipMemcpyFromSymbol(h_out, HIP_SYMBOL(g_seed_prof), sizeof(unsigned long long) * 16) == hipSuccess ? 0 : -1;
+}
+#endif
 
 extern "C" int hamsm_kmeans_seed_multi(hamsm_ctx *c, int n_items, const int32_t *h_stratum, const void *X, int dt, int64_t ldx,
                                        const int64_t *h_x_off, const int32_t *d_rows, const int64_t *h_rows_off,
