@@ -508,6 +508,311 @@ static int launch_assign(hamsm_ctx *c, const MapperDev &mp, const AssignArgs &g)
   return hamsm_fail(c, HAMSM_ENOTSUP, "D > 128");
 }
 
+// ---- VER 3: stratum-sorted assignment --------------------------------------------------------------
+// Three light passes bucket the frames by stratum (a permutation, 4 B per frame), then every workgroup of the
+// main kernel owns FRB frames of ONE stratum: the stratum's centroid fragments are loaded into registers once
+// per workgroup, there are no partial tiles except at a stratum's end and no stratum switches.  Rows are
+// gathered through the permutation (each 4*D-byte row is one contiguous read).
+#define FRB_MAX 512
+struct SortArgs {
+  const void *X;
+  int64_t ldx;
+  const double *pcoord;
+  int64_t n;
+  int32_t *labels;
+  int32_t *seen;
+  const StratumDev *table;
+  int S, D, Kfit;
+  int *err;
+  int32_t *code;                 // [n] stratum of frame, or -1 (basis / target / error: label already final)
+  int32_t *perm;                 // [n] frames grouped by stratum
+  unsigned long long *cnt;       // [S] frames per stratum
+  unsigned long long *cursor;    // [S] fill cursors
+  long long *base;               // [S+1] first position of stratum s in perm
+  long long *blkbase;            // [S+1] first workgroup of stratum s in the main kernel's grid
+  int need_rb;
+  int FRB;  // frames per workgroup of the main kernel (multiple of 16)
+};
+
+__global__ __launch_bounds__(256) void k_sort_count(MapperDev mp, SortArgs g) {
+  extern __shared__ unsigned int lh[];  // [S]
+  for (int s = threadIdx.x; s < g.S; s += 256) lh[s] = 0;
+  __syncthreads();
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < g.n; i += (int64_t)gridDim.x * 256) {
+    double pi[HAMSM_MAX_NDIM];
+    for (int d = 0; d < mp.ndim; d++) pi[d] = g.pcoord[i * mp.ndim + d];
+    int b = dev_bin_of(mp, pi);
+    int code = -1;
+    if (b < 0) {
+      dev_set_error(g.err, HAMSM_ERANGE, (int)i, b);
+    } else {
+      int s = mp.remap[b];                       // stratified_clustering.py:134-135
+      if (dev_in_box(mp.target, mp.ndim, pi)) {  // :159 target first
+        g.labels[i] = g.Kfit + 1;
+        if (g.seen) g.seen[s] = 1;
+      } else if (dev_in_box(mp.basis, mp.ndim, pi)) {  // :165
+        g.labels[i] = g.Kfit;
+        if (g.seen) g.seen[g.S + s] = 1;
+      } else if (g.table[s].K == 0) {  // :187-189
+        dev_set_error(g.err, HAMSM_EUNFIT, (int)i, s);
+      } else {
+        code = s;
+        atomicAdd(&lh[s], 1u);
+      }
+    }
+    g.code[i] = code;
+  }
+  __syncthreads();
+  for (int s = threadIdx.x; s < g.S; s += 256)
+    if (lh[s]) atomicAdd(&g.cnt[s], (unsigned long long)lh[s]);
+}
+
+__global__ void k_sort_offsets(SortArgs g) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    long long b = 0, k = 0;
+    for (int s = 0; s < g.S; s++) {
+      g.base[s] = b;
+      g.blkbase[s] = k;
+      b += (long long)g.cnt[s];
+      k += ((long long)g.cnt[s] + g.FRB - 1) / g.FRB;
+      g.cursor[s] = 0;
+    }
+    g.base[g.S] = b;
+    g.blkbase[g.S] = k;
+  }
+}
+
+__global__ __launch_bounds__(256) void k_sort_fill(SortArgs g) {
+  extern __shared__ unsigned int lh[];  // [S] local counts, then local cursors
+  unsigned long long *lbase = (unsigned long long *)(lh + ((g.S + 1) & ~1));  // [S] reserved range of this workgroup
+  const int64_t per = (g.n + gridDim.x - 1) / gridDim.x, a = blockIdx.x * per, b = (a + per < g.n) ? a + per : g.n;
+  for (int s = threadIdx.x; s < g.S; s += 256) lh[s] = 0;
+  __syncthreads();
+  for (int64_t i = a + threadIdx.x; i < b; i += 256) {
+    int c = g.code[i];
+    if (c >= 0) atomicAdd(&lh[c], 1u);
+  }
+  __syncthreads();
+  for (int s = threadIdx.x; s < g.S; s += 256) {
+    lbase[s] = lh[s] ? atomicAdd(&g.cursor[s], (unsigned long long)lh[s]) : 0ull;
+    lh[s] = 0;
+  }
+  __syncthreads();
+  for (int64_t i = a + threadIdx.x; i < b; i += 256) {
+    int c = g.code[i];
+    if (c >= 0) {
+      unsigned int r = atomicAdd(&lh[c], 1u);
+      g.perm[g.base[c] + (long long)lbase[c] + r] = (int32_t)i;
+    }
+  }
+}
+
+template <typename XT, int KS, int MT>
+__global__ __launch_bounds__(NTHREADS, 2) void k_assign_sorted(SortArgs g) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  constexpr int JW = (KS <= 16) ? 4 : 2;
+  const int FRB = g.FRB;
+  // which stratum does this workgroup serve?
+  int s = 0;
+  {
+    const long long blk = blockIdx.x;
+    if (blk >= g.blkbase[g.S]) return;
+    while (g.blkbase[s + 1] <= blk) s++;
+  }
+  const long long p0 = g.base[s] + (long long)(blockIdx.x - g.blkbase[s]) * FRB;
+  const long long pend = g.base[s + 1];
+  const int nf = (int)((pend - p0) < FRB ? (pend - p0) : FRB);
+  const int nts = (nf + 15) >> 4;
+  XT *Xs = (XT *)smem;                                                   // [FRB][D]
+  size_t xbytes = ((size_t)FRB * g.D * sizeof(XT) + 15) & ~(size_t)15;
+  int *fidx = (int *)(smem + xbytes);                                    // [FRB] frame index of local row
+  double *part_d = (double *)(fidx + FRB);                               // [2][4][MT*16]
+  int *part_j = (int *)(part_d + 2 * 4 * MT * 16);                       // [2][4][MT*16]
+  double *rb_d = (double *)(part_j + 2 * 4 * MT * 16);                   // [FRB] running best (need_rb)
+  int *rb_j = (int *)(rb_d + (g.need_rb ? FRB : 0));
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const double inf = __builtin_huge_val();
+  const StratumDev sd = g.table[s];
+  const int njt = (sd.K + 15) >> 4;
+  const int ngrp = (njt + 4 * JW - 1) / (4 * JW);
+
+  for (int i = tid; i < nf; i += NTHREADS) fidx[i] = g.perm[p0 + i];
+  __syncthreads();
+  {
+    const XT *src = (const XT *)g.X;
+    const int tot = nf * g.D;
+    for (int e = tid; e < tot; e += NTHREADS) {
+      int r = e / g.D, k = e - r * g.D;
+      Xs[e] = src[(int64_t)fidx[r] * g.ldx + k];
+    }
+  }
+  __syncthreads();
+  int batch = 0;
+  for (int gi = 0; gi < ngrp; gi++) {
+    double b[JW][KS], cs[JW];
+#pragma unroll
+    for (int u = 0; u < JW; u++) {
+      const int jt = gi * 4 * JW + wv * JW + u;
+      const bool live = jt < njt;
+      const int jts = live ? jt : 0;
+      double c0 = ((gcdp)sd.csq)[jts * 16 + (lane & 15)];
+      cs[u] = live ? c0 : inf;
+#pragma unroll
+      for (int ks = 0; ks < KS; ks++) {
+        double v = ((gcdp)sd.Bpack)[((size_t)jts * KS + ks) * 64 + lane];
+        b[u][ks] = live ? v : 0.0;
+      }
+    }
+    for (int t = 0; t < nts; t += MT, batch++) {
+      const int nt = (nts - t) < MT ? (nts - t) : MT;
+      double bd[MT][4];
+      int bj[MT][4];
+#pragma unroll
+      for (int m = 0; m < MT; m++) {
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+          bd[m][r] = inf;
+          bj[m][r] = 0x7fffffff;
+        }
+        if (m >= nt) continue;  // block-uniform
+        double a[KS];
+        {
+          const int lr = (t + m) * 16 + (lane & 15);
+          const bool ok = lr < nf;
+          const XT *xr = Xs + (ok ? lr : 0) * g.D;
+#pragma unroll
+          for (int ks = 0; ks < KS; ks++) {
+            int k = ks * 4 + (lane >> 4);
+            double v = (double)xr[k < g.D ? k : 0];
+            a[ks] = (ok && k < g.D) ? v : 0.0;
+          }
+        }
+        v4f64 acc[JW];
+#pragma unroll
+        for (int u = 0; u < JW; u++) acc[u] = (v4f64){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int ks = 0; ks < KS; ks++)
+#pragma unroll
+          for (int u = 0; u < JW; u++) acc[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[ks], b[u][ks], acc[u], 0, 0, 0);
+#pragma unroll
+        for (int u = 0; u < JW; u++) {
+          const int j = (gi * 4 * JW + wv * JW + u) * 16 + (lane & 15);
+#pragma unroll
+          for (int r = 0; r < 4; r++) {
+            double d = __builtin_fma(-2.0, acc[u][r], cs[u]);
+            bool lt = d < bd[m][r];
+            bd[m][r] = lt ? d : bd[m][r];
+            bj[m][r] = lt ? j : bj[m][r];
+          }
+        }
+      }
+      const int buf = batch & 1;
+#pragma unroll
+      for (int m = 0; m < MT; m++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+          double d = bd[m][r];
+          int j = bj[m][r];
+          row_min16(d, j);
+          if ((lane & 15) == 15 && m < nt) {
+            int row = (lane >> 4) + 4 * r;
+            part_d[(buf * 4 + wv) * MT * 16 + m * 16 + row] = d;
+            part_j[(buf * 4 + wv) * MT * 16 + m * 16 + row] = j;
+          }
+        }
+      __syncthreads();
+      if (tid < nt * 16) {
+        const int m = tid >> 4, row = tid & 15;
+        double d = part_d[(buf * 4 + 0) * MT * 16 + m * 16 + row];
+        int j = part_j[(buf * 4 + 0) * MT * 16 + m * 16 + row];
+#pragma unroll
+        for (int w = 1; w < 4; w++) {
+          double d2 = part_d[(buf * 4 + w) * MT * 16 + m * 16 + row];
+          int j2 = part_j[(buf * 4 + w) * MT * 16 + m * 16 + row];
+          bool take = (d2 < d) || (d2 == d && j2 < j);
+          d = take ? d2 : d;
+          j = take ? j2 : j;
+        }
+        const int lr = (t + m) * 16 + row;
+        if (ngrp > 1) {
+          if (gi > 0) {
+            double d0 = rb_d[lr];
+            int j0 = rb_j[lr];
+            bool keep = (d0 < d) || (d0 == d && j0 < j);
+            d = keep ? d0 : d;
+            j = keep ? j0 : j;
+          }
+          if (gi < ngrp - 1) {
+            rb_d[lr] = d;
+            rb_j[lr] = j;
+          }
+        }
+        if (gi == ngrp - 1 && lr < nf) {
+          if (j == 0x7fffffff) j = 0;
+          g.labels[fidx[lr]] = sd.off + j;  // stratified_clustering.py:195
+        }
+      }
+    }
+  }
+}
+
+int hamsm_ensure_scratch2(hamsm_ctx *c, size_t bytes);
+
+template <typename XT, int KS>
+static int launch_sorted_ks(hamsm_ctx *c, SortArgs g) {
+  constexpr int MT = (KS <= 8) ? 4 : (KS <= 16 ? 2 : 1);
+  constexpr int JW = (KS <= 16) ? 4 : 2;
+  g.need_rb = 0;
+  for (int s = 0; s < c->S; s++) g.need_rb |= ((c->st[s].K + 15) / 16 > 4 * JW);
+  const int FRB = g.FRB;
+  size_t xbytes = ((size_t)FRB * g.D * sizeof(XT) + 15) & ~(size_t)15;
+  size_t lds = xbytes + sizeof(int) * FRB + (sizeof(double) + sizeof(int)) * 2 * 4 * MT * 16 +
+               (g.need_rb ? (sizeof(double) + sizeof(int)) * FRB : 0) + 16;
+  if (lds > 160 * 1024) return hamsm_fail(c, HAMSM_ENOTSUP, "sorted assign needs %zu B of LDS", lds);
+  auto kern = k_assign_sorted<XT, KS, MT>;
+  HIPCHK(c, hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  unsigned grid = (unsigned)((g.n + FRB - 1) / FRB + c->S);  // upper bound; surplus workgroups exit at once
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(NTHREADS), lds, c->stream, g);
+  HIPCHK(c, hipGetLastError());
+  return HAMSM_OK;
+}
+
+template <typename XT>
+static int launch_sorted(hamsm_ctx *c, const AssignArgs &a) {
+  const int64_t n = a.n;
+  const int S = c->S;
+  size_t off = 0;
+  auto take = [&](size_t bytes) {
+    size_t o = off;
+    off = (off + bytes + 255) & ~(size_t)255;
+    return o;
+  };
+  size_t o_code = take(sizeof(int32_t) * n), o_perm = take(sizeof(int32_t) * n), o_cnt = take(sizeof(long long) * S),
+         o_cur = take(sizeof(long long) * S), o_base = take(sizeof(long long) * (S + 1)), o_blk = take(sizeof(long long) * (S + 1));
+  int rc = hamsm_ensure_scratch2(c, off);
+  if (rc) return rc;
+  char *b = (char *)c->scratch2;
+  SortArgs g{a.X, a.ldx, a.pcoord, n, a.labels, a.seen, a.table, S, a.D, a.Kfit, a.err, (int32_t *)(b + o_code),
+             (int32_t *)(b + o_perm), (unsigned long long *)(b + o_cnt), (unsigned long long *)(b + o_cur),
+             (long long *)(b + o_base), (long long *)(b + o_blk), 0, FRB_MAX};
+  // frames per workgroup: as many as keep the staged rows within ~64 KB (2 workgroups per CU)
+  while (g.FRB > 64 && (size_t)g.FRB * a.D * sizeof(XT) > 64 * 1024) g.FRB >>= 1;
+  HIPCHK(c, hipMemsetAsync(b + o_cnt, 0, sizeof(long long) * S, c->stream));
+  unsigned gridc = (unsigned)((n + 255) / 256 < 2048 ? (n + 255) / 256 : 2048);
+  hipLaunchKernelGGL(k_sort_count, dim3(gridc), dim3(256), sizeof(unsigned int) * S, c->stream, c->mapper, g);
+  hipLaunchKernelGGL(k_sort_offsets, dim3(1), dim3(64), 0, c->stream, g);
+  hipLaunchKernelGGL(k_sort_fill, dim3(gridc), dim3(256), sizeof(unsigned int) * ((S + 1) & ~1) + sizeof(long long) * S,
+                     c->stream, g);
+  HIPCHK(c, hipGetLastError());
+  switch (c->KS) {
+#define CASE(KSV) \
+  case KSV: return launch_sorted_ks<XT, KSV>(c, g);
+    CASE(1) CASE(2) CASE(3) CASE(4) CASE(6) CASE(8) CASE(12) CASE(16) CASE(24) CASE(32)
+#undef CASE
+  }
+  return hamsm_fail(c, HAMSM_ENOTSUP, "KS=%d", c->KS);
+}
+
 extern "C" int hamsm_assign(hamsm_ctx *c, const void *X, int dt, int64_t ldx, const double *p, int64_t n, int32_t *labels,
                             int32_t *seen) {
   if (!c->have_mapper || !c->have_bounds) return hamsm_fail(c, HAMSM_EINVAL, "mapper/bounds not set");
@@ -521,7 +826,8 @@ extern "C" int hamsm_assign(hamsm_ctx *c, const void *X, int dt, int64_t ldx, co
   // packed layout always uses c->KS, so the instantiated KS must equal it
   AssignArgs g{X, ldx, p, n, labels, seen, c->d_table, c->S, c->D, c->Kfit, c->d_err, FR_MAX, 0};
   hamsm_timer_begin(c);
-  rc = (dt == HAMSM_F32) ? launch_assign<float>(c, c->mapper, g) : launch_assign<double>(c, c->mapper, g);
+  if (c->assign_version == 3) rc = (dt == HAMSM_F32) ? launch_sorted<float>(c, g) : launch_sorted<double>(c, g);
+  else rc = (dt == HAMSM_F32) ? launch_assign<float>(c, c->mapper, g) : launch_assign<double>(c, c->mapper, g);
   hamsm_timer_end(c, ST_ASSIGN);
   if (rc) return rc;
   return hamsm_check_device_error(c, "assign");

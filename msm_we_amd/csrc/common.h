@@ -67,6 +67,8 @@ struct hamsm_ctx {
   int *h_err = nullptr;   // pinned mirror
   void *scratch = nullptr;
   size_t scratch_bytes = 0;
+  void *scratch2 = nullptr;  // second arena: internals of hamsm_assign (its caller may hold `scratch`)
+  size_t scratch2_bytes = 0;
   void *h_pinned = nullptr;  // small pinned staging buffer
   size_t h_pinned_bytes = 0;
   struct EvPair {
@@ -78,7 +80,7 @@ struct hamsm_ctx {
   hipEvent_t ev_cur0 = nullptr;
   double timers[ST_N] = {0};
   double last_ms[ST_N] = {0};
-  int assign_version = 2;  // k_assign variant (HAMSM_ASSIGN_V=1 selects the item-pulling variant)
+  int assign_version = 3;  // assign kernel: 3 = stratum-sorted (default), 2 = chunk-local buckets, 1 = item pulling (HAMSM_ASSIGN_V)
   void *seed_chosen_dev = nullptr;  // chosen indices of the last seeding's first item (device)
   void *comm = nullptr;  // ncclComm_t
   int nranks = 1, rank = 0;

@@ -22,7 +22,7 @@ extern "C" int hamsm_create(int device, hamsm_ctx **out) {
   c->err[0] = 0;
   c->device = device;
   memset(&c->mapper, 0, sizeof c->mapper);
-  if (const char *v = getenv("HAMSM_ASSIGN_V")) c->assign_version = atoi(v) == 1 ? 1 : 2;
+  if (const char *v = getenv("HAMSM_ASSIGN_V")) c->assign_version = (atoi(v) >= 1 && atoi(v) <= 3) ? atoi(v) : 3;
   if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess ||
       hipMalloc((void **)&c->d_err, 4 * sizeof(int)) != hipSuccess ||
       hipHostMalloc((void **)&c->h_err, 4 * sizeof(int)) != hipSuccess) {
@@ -62,6 +62,7 @@ extern "C" void hamsm_destroy(hamsm_ctx *c) {
   hipFree(c->d_err);
   hipHostFree(c->h_err);
   hipFree(c->scratch);
+  hipFree(c->scratch2);
   hipHostFree(c->h_pinned);
   for (auto &p : c->ev_pending) {
     hipEventDestroy(p.e0);
@@ -115,6 +116,19 @@ int hamsm_ensure_scratch(hamsm_ctx *c, size_t bytes) {
   hipError_t e = hipMalloc(&c->scratch, want);
   if (e != hipSuccess) return hamsm_fail(c, HAMSM_ENOMEM, "scratch hipMalloc(%zu): %s", want, hipGetErrorString(e));
   c->scratch_bytes = want;
+  return HAMSM_OK;
+}
+
+int hamsm_ensure_scratch2(hamsm_ctx *c, size_t bytes) {
+  if (bytes <= c->scratch2_bytes) return HAMSM_OK;
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  hipFree(c->scratch2);
+  c->scratch2 = nullptr;
+  c->scratch2_bytes = 0;
+  size_t want = bytes + bytes / 4 + 4096;
+  hipError_t e = hipMalloc(&c->scratch2, want);
+  if (e != hipSuccess) return hamsm_fail(c, HAMSM_ENOMEM, "scratch2 hipMalloc(%zu): %s", want, hipGetErrorString(e));
+  c->scratch2_bytes = want;
   return HAMSM_OK;
 }
 

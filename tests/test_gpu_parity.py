@@ -326,3 +326,24 @@ def test_block_validation_runs(hip_h):
     # the main model's state is untouched by the copies sharing its ctx
     m.launch_ray_discretization()
     assert np.array_equal(np.concatenate(m.dtrajs), g["dtrajs_clean"])
+
+
+@pytest.mark.parametrize("version", ["1", "2", "3"])
+def test_assign_kernel_variants_agree(hip_lib, oracle_h, version, monkeypatch):
+    """The three assign kernels (3 = stratum-sorted, the default; 2 = chunk-local buckets with register-resident
+    centroid fragments; 1 = item pulling) compute the same labels as the oracle."""
+    from msm_we_amd import _abi
+
+    monkeypatch.setenv("HAMSM_ASSIGN_V", version)
+    h = _abi.Hamsm(lib=hip_lib)
+    try:
+        for D, S, K_s, dtype in ((30, 4, 250, np.float32), (64, 3, 300, np.float64), (10, 12, 25, np.float32)):
+            outs = []
+            for hh in (oracle_h, h):
+                rng = np.random.default_rng(7)
+                _setup(hh, D, S, K_s, rng)
+                X, p = _frames(rng, 7001, D, S, dtype)
+                outs.append(hh.predict_host(X, p))
+            assert np.array_equal(outs[0], outs[1]), (version, D, S, K_s)
+    finally:
+        h.close()
