@@ -508,6 +508,29 @@ static int launch_assign(hamsm_ctx *c, const MapperDev &mp, const AssignArgs &g)
   return hamsm_fail(c, HAMSM_ENOTSUP, "D > 128");
 }
 
+#ifdef ASSIGN_PROFILE
+__device__ unsigned long long g_assign_prof[8];
+#define APROF_INIT unsigned long long t_last_ = __builtin_amdgcn_s_memtime(), t_acc_[6] = {0, 0, 0, 0, 0, 0};
+#define APROF(i)                                             \
+  {                                                          \
+    unsigned long long t_ = __builtin_amdgcn_s_memtime();    \
+    t_acc_[i] += t_ - t_last_;                               \
+    t_last_ = t_;                                            \
+  }
+#define APROF_END                                                                        \
+  if (threadIdx.x == 0) {                                                                \
+    for (int i_ = 0; i_ < 6; i_++) atomicAdd(&g_assign_prof[i_], t_acc_[i_]);            \
+    atomicAdd(&g_assign_prof[7], 1ull);                                                  \
+  }
+extern "C" int hamsm_debug_assign_profile(unsigned long long *h_out) {
+  return hipMemcpyFromSymbol(h_out, HIP_SYMBOL(g_assign_prof), sizeof(unsigned long long) * 8) == hipSuccess ? 0 : -1;
+}
+#else
+#define APROF_INIT
+#define APROF(i)
+#define APROF_END
+#endif
+
 // ---- VER 3: stratum-sorted assignment --------------------------------------------------------------
 // Three light passes bucket the frames by stratum (a permutation, 4 B per frame), then every workgroup of the
 // main kernel owns FRB frames of ONE stratum: the stratum's centroid fragments are loaded into registers once
@@ -607,10 +630,14 @@ __global__ __launch_bounds__(256) void k_sort_fill(SortArgs g) {
   }
 }
 
-template <typename XT, int KS, int MT>
-__global__ __launch_bounds__(NTHREADS, 2) void k_assign_sorted(SortArgs g) {
+// NW waves per workgroup share the staged rows; each wave owns JW = 16/NW... centroid tiles of the current group
+// (NW*JW tiles per group).  8 waves x 2 tiles needs half the B registers of 4 x 4, so that two workgroups per CU
+// give 4 waves per SIMD -- a single wave cannot keep the f64 MFMA pipe busy.
+template <typename XT, int KS, int MT, int NW, int JW>
+__global__ __launch_bounds__(NW * 64, NW / 2) void k_assign_sorted(SortArgs g) {
+  APROF_INIT
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  constexpr int JW = (KS <= 16) ? 4 : 2;
+  constexpr int NT = NW * 64;
   const int FRB = g.FRB;
   // which stratum does this workgroup serve?
   int s = 0;
@@ -626,54 +653,94 @@ __global__ __launch_bounds__(NTHREADS, 2) void k_assign_sorted(SortArgs g) {
   XT *Xs = (XT *)smem;                                                   // [FRB][D]
   size_t xbytes = ((size_t)FRB * g.D * sizeof(XT) + 15) & ~(size_t)15;
   int *fidx = (int *)(smem + xbytes);                                    // [FRB] frame index of local row
-  double *part_d = (double *)(fidx + FRB);                               // [2][4][MT*16]
-  int *part_j = (int *)(part_d + 2 * 4 * MT * 16);                       // [2][4][MT*16]
-  double *rb_d = (double *)(part_j + 2 * 4 * MT * 16);                   // [FRB] running best (need_rb)
+  double *part_d = (double *)(fidx + FRB);                               // [2][NW][MT*16]
+  int *part_j = (int *)(part_d + 2 * NW * MT * 16);                       // [2][NW][MT*16]
+  double *rb_d = (double *)(part_j + 2 * NW * MT * 16);                   // [FRB] running best (need_rb)
   int *rb_j = (int *)(rb_d + (g.need_rb ? FRB : 0));
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const double inf = __builtin_huge_val();
   const StratumDev sd = g.table[s];
   const int njt = (sd.K + 15) >> 4;
-  const int ngrp = (njt + 4 * JW - 1) / (4 * JW);
+  const int ngrp = (njt + NW * JW - 1) / (NW * JW);
 
-  for (int i = tid; i < nf; i += NTHREADS) fidx[i] = g.perm[p0 + i];
+  for (int i = tid; i < nf; i += NT) fidx[i] = g.perm[p0 + i];
   __syncthreads();
   {
     const XT *src = (const XT *)g.X;
     const int tot = nf * g.D;
-    for (int e = tid; e < tot; e += NTHREADS) {
-      int r = e / g.D, k = e - r * g.D;
-      Xs[e] = src[(int64_t)fidx[r] * g.ldx + k];
+    // gather through the permutation, 8 independent loads in flight per thread (a plain loop would expose one
+    // HBM round trip per element)
+    constexpr int U = 8;
+    typedef XT xt2 __attribute__((ext_vector_type(2)));
+    if ((g.D & 1) == 0 && (g.ldx & 1) == 0 && ((uintptr_t)src & (2 * sizeof(XT) - 1)) == 0) {
+      // rows start on 2-element boundaries: move pairs (half the load instructions, 16 elements in flight)
+      const int D2 = g.D >> 1, tot2 = nf * D2;
+      xt2 *Xs2 = (xt2 *)Xs;
+      for (int e0 = tid; e0 < tot2; e0 += NT * U) {
+        xt2 v[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+          int e = e0 + u * NT;
+          int ec = e < tot2 ? e : 0;
+          int r = ec / D2, k = ec - r * D2;
+          v[u] = *(const xt2 *)(src + (int64_t)fidx[r] * g.ldx + 2 * k);
+        }
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+          int e = e0 + u * NT;
+          if (e < tot2) Xs2[e] = v[u];
+        }
+      }
+    } else
+    for (int e0 = tid; e0 < tot; e0 += NT * U) {
+      XT v[U];
+#pragma unroll
+      for (int u = 0; u < U; u++) {
+        int e = e0 + u * NT;
+        int ec = e < tot ? e : 0;
+        int r = ec / g.D, k = ec - r * g.D;
+        v[u] = src[(int64_t)fidx[r] * g.ldx + k];
+      }
+#pragma unroll
+      for (int u = 0; u < U; u++) {
+        int e = e0 + u * NT;
+        if (e < tot) Xs[e] = v[u];
+      }
     }
   }
   __syncthreads();
+  APROF(0)
   int batch = 0;
   for (int gi = 0; gi < ngrp; gi++) {
-    double b[JW][KS], cs[JW];
+    // centroids are the MFMA's A operand (output rows), frames its B operand (output columns): lane l then holds,
+    // for frame l&15 of the tile, the dot products with centroids (l>>4) + 4r -- the first-minimum over a tile's
+    // centroids is a register-only reduction, and only the four lane groups have to be merged across lanes
+    double b[JW][KS], cs[JW][4];
 #pragma unroll
     for (int u = 0; u < JW; u++) {
-      const int jt = gi * 4 * JW + wv * JW + u;
+      const int jt = gi * NW * JW + wv * JW + u;
       const bool live = jt < njt;
       const int jts = live ? jt : 0;
-      double c0 = ((gcdp)sd.csq)[jts * 16 + (lane & 15)];
-      cs[u] = live ? c0 : inf;
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+        double c0 = ((gcdp)sd.csq)[jts * 16 + (lane >> 4) + 4 * r];
+        cs[u][r] = live ? c0 : inf;
+      }
 #pragma unroll
       for (int ks = 0; ks < KS; ks++) {
         double v = ((gcdp)sd.Bpack)[((size_t)jts * KS + ks) * 64 + lane];
         b[u][ks] = live ? v : 0.0;
       }
     }
+    APROF(1)
     for (int t = 0; t < nts; t += MT, batch++) {
       const int nt = (nts - t) < MT ? (nts - t) : MT;
-      double bd[MT][4];
-      int bj[MT][4];
+      double bd[MT];
+      int bj[MT];
 #pragma unroll
       for (int m = 0; m < MT; m++) {
-#pragma unroll
-        for (int r = 0; r < 4; r++) {
-          bd[m][r] = inf;
-          bj[m][r] = 0x7fffffff;
-        }
+        bd[m] = inf;
+        bj[m] = 0x7fffffff;
         if (m >= nt) continue;  // block-uniform
         double a[KS];
         {
@@ -693,42 +760,50 @@ __global__ __launch_bounds__(NTHREADS, 2) void k_assign_sorted(SortArgs g) {
 #pragma unroll
         for (int ks = 0; ks < KS; ks++)
 #pragma unroll
-          for (int u = 0; u < JW; u++) acc[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[ks], b[u][ks], acc[u], 0, 0, 0);
+          for (int u = 0; u < JW; u++) acc[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(b[u][ks], a[ks], acc[u], 0, 0, 0);
 #pragma unroll
         for (int u = 0; u < JW; u++) {
-          const int j = (gi * 4 * JW + wv * JW + u) * 16 + (lane & 15);
+          const int j0 = (gi * NW * JW + wv * JW + u) * 16 + (lane >> 4);
 #pragma unroll
-          for (int r = 0; r < 4; r++) {
-            double d = __builtin_fma(-2.0, acc[u][r], cs[u]);
-            bool lt = d < bd[m][r];
-            bd[m][r] = lt ? d : bd[m][r];
-            bj[m][r] = lt ? j : bj[m][r];
+          for (int r = 0; r < 4; r++) {  // centroid j0 + 4r: ascending, so strict < keeps the lowest index
+            double d = __builtin_fma(-2.0, acc[u][r], cs[u][r]);
+            bool lt = d < bd[m];
+            bd[m] = lt ? d : bd[m];
+            bj[m] = lt ? j0 + 4 * r : bj[m];
           }
         }
       }
+      APROF(2)
       const int buf = batch & 1;
 #pragma unroll
-      for (int m = 0; m < MT; m++)
+      for (int m = 0; m < MT; m++) {
+        // merge the four lane groups (lanes l, l^16, l^32, l^48 hold the same frame)
+        double d = bd[m];
+        int j = bj[m];
 #pragma unroll
-        for (int r = 0; r < 4; r++) {
-          double d = bd[m][r];
-          int j = bj[m][r];
-          row_min16(d, j);
-          if ((lane & 15) == 15 && m < nt) {
-            int row = (lane >> 4) + 4 * r;
-            part_d[(buf * 4 + wv) * MT * 16 + m * 16 + row] = d;
-            part_j[(buf * 4 + wv) * MT * 16 + m * 16 + row] = j;
-          }
+        for (int off = 16; off <= 32; off <<= 1) {
+          double d2 = __shfl_xor(d, off, 64);
+          int j2 = __shfl_xor(j, off, 64);
+          bool take = (d2 < d) || (d2 == d && j2 < j);
+          d = take ? d2 : d;
+          j = take ? j2 : j;
         }
+        if (lane < 16 && m < nt) {
+          part_d[(buf * NW + wv) * MT * 16 + m * 16 + lane] = d;
+          part_j[(buf * NW + wv) * MT * 16 + m * 16 + lane] = j;
+        }
+      }
+      APROF(3)
       __syncthreads();
+      APROF(4)
       if (tid < nt * 16) {
         const int m = tid >> 4, row = tid & 15;
-        double d = part_d[(buf * 4 + 0) * MT * 16 + m * 16 + row];
-        int j = part_j[(buf * 4 + 0) * MT * 16 + m * 16 + row];
+        double d = part_d[(buf * NW + 0) * MT * 16 + m * 16 + row];
+        int j = part_j[(buf * NW + 0) * MT * 16 + m * 16 + row];
 #pragma unroll
-        for (int w = 1; w < 4; w++) {
-          double d2 = part_d[(buf * 4 + w) * MT * 16 + m * 16 + row];
-          int j2 = part_j[(buf * 4 + w) * MT * 16 + m * 16 + row];
+        for (int w = 1; w < NW; w++) {
+          double d2 = part_d[(buf * NW + w) * MT * 16 + m * 16 + row];
+          int j2 = part_j[(buf * NW + w) * MT * 16 + m * 16 + row];
           bool take = (d2 < d) || (d2 == d && j2 < j);
           d = take ? d2 : d;
           j = take ? j2 : j;
@@ -752,29 +827,43 @@ __global__ __launch_bounds__(NTHREADS, 2) void k_assign_sorted(SortArgs g) {
           g.labels[fidx[lr]] = sd.off + j;  // stratified_clustering.py:195
         }
       }
+      APROF(5)
     }
   }
+  APROF_END
 }
 
 int hamsm_ensure_scratch2(hamsm_ctx *c, size_t bytes);
 
-template <typename XT, int KS>
-static int launch_sorted_ks(hamsm_ctx *c, SortArgs g) {
+template <typename XT, int KS, int NW, int JW>
+static int launch_sorted_cfg(hamsm_ctx *c, SortArgs g) {
   constexpr int MT = (KS <= 8) ? 4 : (KS <= 16 ? 2 : 1);
-  constexpr int JW = (KS <= 16) ? 4 : 2;
   g.need_rb = 0;
-  for (int s = 0; s < c->S; s++) g.need_rb |= ((c->st[s].K + 15) / 16 > 4 * JW);
+  for (int s = 0; s < c->S; s++) g.need_rb |= ((c->st[s].K + 15) / 16 > NW * JW);
   const int FRB = g.FRB;
   size_t xbytes = ((size_t)FRB * g.D * sizeof(XT) + 15) & ~(size_t)15;
-  size_t lds = xbytes + sizeof(int) * FRB + (sizeof(double) + sizeof(int)) * 2 * 4 * MT * 16 +
+  size_t lds = xbytes + sizeof(int) * FRB + (sizeof(double) + sizeof(int)) * 2 * NW * MT * 16 +
                (g.need_rb ? (sizeof(double) + sizeof(int)) * FRB : 0) + 16;
   if (lds > 160 * 1024) return hamsm_fail(c, HAMSM_ENOTSUP, "sorted assign needs %zu B of LDS", lds);
-  auto kern = k_assign_sorted<XT, KS, MT>;
+  auto kern = k_assign_sorted<XT, KS, MT, NW, JW>;
   HIPCHK(c, hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   unsigned grid = (unsigned)((g.n + FRB - 1) / FRB + c->S);  // upper bound; surplus workgroups exit at once
-  hipLaunchKernelGGL(kern, dim3(grid), dim3(NTHREADS), lds, c->stream, g);
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(NW * 64), lds, c->stream, g);
   HIPCHK(c, hipGetLastError());
   return HAMSM_OK;
+}
+
+template <typename XT, int KS>
+static int launch_sorted_ks(hamsm_ctx *c, SortArgs g) {
+  // 8 waves x 2 centroid tiles while the k-steps are few (<= 128 VGPRs: 4 waves per SIMD); else 4 waves x (4 or 2)
+  if constexpr (KS <= 8) {
+    if (c->assign_waves == 8) return launch_sorted_cfg<XT, KS, 8, 2>(c, g);
+    return launch_sorted_cfg<XT, KS, 4, 4>(c, g);
+  } else if constexpr (KS <= 16) {
+    return launch_sorted_cfg<XT, KS, 4, 4>(c, g);
+  } else {
+    return launch_sorted_cfg<XT, KS, 4, 2>(c, g);
+  }
 }
 
 template <typename XT>

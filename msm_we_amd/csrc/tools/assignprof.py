@@ -1,0 +1,28 @@
+import sys, ctypes, os, numpy as np
+sys.path.insert(0, '.')
+from msm_we_amd import _abi
+lib = ctypes.CDLL('msm_we_amd/csrc/_var/lib_assignprof.so')
+for waves in ('4', '8'):
+    os.environ['HAMSM_ASSIGN_W'] = waves
+    h = _abi.Hamsm(lib=lib)
+    D, S, K, n = 30, 4, 250, 2_000_000
+    h.set_geometry(D, 1, S)
+    b = np.arange(S + 1, dtype=np.float32); b[-1] = np.inf
+    h.set_mapper_rectilinear([b]); h.set_bounds([[-np.inf, 0.05]], [[S - 0.05, np.inf]])
+    rng = np.random.default_rng(0)
+    for s in range(S):
+        h.set_centroids(s, rng.normal(size=(K, D)))
+    X = rng.normal(size=(n, D)).astype(np.float32); p = rng.uniform(0, S, size=(n, 1))
+    dX, dp, dl = h.to_device(X), h.to_device(p), h.alloc(n, np.int32)
+    z = np.zeros(8, dtype=np.uint64)
+    h.assign(dX, 0, D, dp, n, dl); h.sync()
+    out0 = np.zeros(8, dtype=np.uint64); lib.hamsm_debug_assign_profile(out0.ctypes.data_as(ctypes.c_void_p))
+    h.assign(dX, 0, D, dp, n, dl); h.sync()
+    out = np.zeros(8, dtype=np.uint64); lib.hamsm_debug_assign_profile(out.ctypes.data_as(ctypes.c_void_p))
+    d = (out - out0).astype(float); nb = d[7]
+    names = ['stage rows', 'B frag load', 'A load+MFMA+epilogue', 'row reduce+LDS write', 'barrier wait', 'combine']
+    tot = d[:6].sum()
+    print(f'waves/block {waves}: {nb:.0f} workgroups, {tot/nb:.0f} cycles per workgroup (thread 0 view)')
+    for nm, v in zip(names, d[:6]):
+        print(f'  {nm:24s} {v/nb:9.0f}  {100*v/tot:5.1f}%')
+    h.close()
