@@ -117,6 +117,23 @@ def cpu_baseline(cfg, n_iters_sample, seed):
                       f"step, oracle/hamsm_oracle.c single thread, {dt:.1f} s"}
 
 
+def pmc_traffic(cfg, n_iters):
+    """HBM bytes per k_assign_sorted launch from the committed rocprofv3 PMC passes of this same workload
+    (profiles/r01_d_pmc_summary.csv: separate --pmc FETCH_SIZE / WRITE_SIZE runs; FETCH_SIZE doubled as
+    MI355X_MICROARCH.md prescribes for gfx950, calibrated here on k_sort_count's 80 MB pcoord read)."""
+    path = os.path.join(ROOT, "profiles", "r01_d_pmc_summary.csv")
+    if cfg.name != "c3" or n_iters != cfg.n_iters or not os.path.exists(path):
+        return None
+    vals = {}
+    for line in open(path).read().splitlines()[1:]:
+        k, c, _, v = line.rsplit(",", 3)
+        if "k_assign_sorted" in k:
+            vals[c] = float(v)
+    if "FETCH_SIZE" not in vals or "WRITE_SIZE" not in vals:
+        return None
+    return (2.0 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024.0
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -194,10 +211,10 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
-    timers = h.timers()
+    timers = h.timers()   # HIP events on the library's stream around every kernel (lazy: no sync on the launch path)
     assign_ms = h.last_kernel_ms(0)
     n_assign_launch = 2 * args.steps
-    assign_avg_ms = timers["assign"] * 1e3 / n_assign_launch
+    assign_avg_ms = timers["assign"] * 1e3 / n_assign_launch   # k_assign_sorted alone; its bucket passes are "other"
     rows_per_launch = n_seg                                   # one launch = all parent (or child) frames
     flops = 2.0 * cfg.K_s * cfg.D * rows_per_launch           # 2*K_s*D per frame
     bytes_alg = (cfg.D * 4 + 8 + 4) * rows_per_launch         # D*s + 8*ndim + 4 per frame
@@ -222,7 +239,8 @@ def main():
                    "flux_mode": "atomic" if args.flux_mode == 0 else "deterministic",
                    "parallelism": f"iteration-sharded x{world}"},
         "roofline": {"bound": "mfma", "achieved": tflops, "peak": PEAK_F64_MFMA_TFLOPS, "unit": "TFLOP/s",
-                     "frac": tflops / PEAK_F64_MFMA_TFLOPS, "traffic": None, "kernel": "k_assign (f64 MFMA 16x16x4)",
+                     "frac": tflops / PEAK_F64_MFMA_TFLOPS, "traffic": pmc_traffic(cfg, n_iters),
+                     "kernel": "k_assign_sorted (v_mfma_f64_16x16x4_f64)",
                      "avg_launch_ms": assign_avg_ms, "last_launch_ms": assign_ms,
                      "algorithmic_GBps": bytes_alg / (assign_avg_ms * 1e-3) / 1e9,
                      "hbm_frac": bytes_alg / (assign_avg_ms * 1e-3) / 1e9 / PEAK_HBM_GBS},

@@ -1,66 +1,42 @@
-// assign.hip -- a3/a4 classify and a9 fused stratified assignment (StratifiedClusters.predict,
-// reference msm_we/stratified_clustering.py:101-212) for gfx950.
+// assign.hip -- a3/a4 classify and a9 stratified assignment (StratifiedClusters.predict, reference
+// msm_we/stratified_clustering.py:101-212) for gfx950.
 //
-// Kernel plan.  One 256-thread workgroup (4 waves, one per SIMD) owns a contiguous
-// chunk of FR frames:
-//   1. classify: every frame's pcoord -> basis/target flags and stratum s = remap[bin(p)]; basis /
-//      target frames get their label at once; the others are bucketed by stratum in LDS into tiles
-//      of 16 frames (the MFMA M dimension).  Frames stay in HBM order: one coalesced pass.
-//   2. the chunk's feature rows are staged into LDS with 16-byte loads (the only HBM read of X).
-//   3. each wave pulls work items (<= MT tiles of one stratum), holds the A fragments (frames) of all
-//      k-steps in registers, streams the stratum's centroids as pre-packed MFMA B fragments from L2
-//      (fully coalesced 512-B loads, double buffered) and runs v_mfma_f64_16x16x4_f64; the epilogue
-//      forms csq - 2*dot, keeps a running first-minimum per lane and reduces across the 16 lanes of
-//      a row with DPP-free shuffles.
-// The dot product of a frame and a centroid is an f64 FMA chain over ascending k (the MFMA applies
-// its four k-products in order; zero padding adds exact zeros), i.e. the arithmetic contract of
-// include/hamsm.h; hamsm_selftest_mfma() checks that property of the hardware bit for bit.
+// Kernel plan.
+//   k_sort_count / k_sort_offsets / k_sort_fill : three light passes bucket the frames by stratum
+//       s = remap[bin(pcoord)] into a permutation (4 B per frame); basis / target frames receive their label
+//       here and never reach the distance kernel.
+//   k_assign_sorted : every workgroup owns <= 512 frames of ONE stratum.  The stratum's centroids, pre-packed as
+//       MFMA fragments, are loaded into registers once per workgroup (each wave keeps JW centroid tiles); the
+//       rows are gathered through the permutation into LDS (each 4*D-byte row is one contiguous read); the waves
+//       sweep the 16-frame tiles with v_mfma_f64_16x16x4_f64, centroids as the A operand (output rows) and
+//       frames as the B operand (output columns), so that a lane holds, for ONE frame, its distances to the
+//       centroids (l>>4)+4r of each tile: csq - 2*dot and the running first-minimum are register-local, only the
+//       four lane groups and then the waves are merged (2 shuffles + one LDS round per batch of tiles).
+// The dot product of a frame and a centroid is an f64 FMA chain over ascending k (the MFMA applies its four
+// k-products in order; zero padding adds exact zeros), i.e. the arithmetic contract of include/hamsm.h;
+// hamsm_selftest_mfma() checks that property of the hardware bit for bit.
+//
+// Measured on MI355X (C3: 10 M rows x 30 features, 4 strata x 250 centroids): 3.5 ms = 42 TFLOP/s; earlier
+// forms of this kernel are in the history (chunk-local buckets with L2-streamed fragments: 7.1 ms; 16-lane DPP
+// argmin: 4.8 ms) -- see DESIGN.md §5.1 for what each step bought.
 #include "common.h"
 
 typedef double v4f64 __attribute__((ext_vector_type(4)));
-#ifndef V2_DPP
-#define V2_DPP 1
-#endif
-#ifndef V2_UNCOND
-#define V2_UNCOND 1
-#endif
-#ifndef V2_GLOBAL
-#define V2_GLOBAL 1
-#endif
-#if V2_GLOBAL
 typedef const double __attribute__((address_space(1))) *gcdp;  // global-address-space view: global_load, not flat_load
-#else
-typedef const double *gcdp;
-#endif
 
-// row_shr:N inside each 16-lane DPP row; lanes with no source keep their own value
-template <int N>
-__device__ __forceinline__ int dpp_shr_i(int v) {
-  return __builtin_amdgcn_update_dpp(v, v, 0x110 + N, 0xf, 0xf, false);
-}
-template <int N>
-__device__ __forceinline__ double dpp_shr_d(double v) {
-  long long b = __double_as_longlong(v);
-  int lo = dpp_shr_i<N>((int)(b & 0xffffffffll)), hi = dpp_shr_i<N>((int)(b >> 32));
-  return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
-}
-// lexicographic (d, j) minimum over the 16 lanes of a DPP row; the result is valid in lane 15 of the row
-__device__ __forceinline__ void row_min16(double &d, int &j) {
-#define STEP(N)                                          \
-  {                                                      \
-    double d2 = dpp_shr_d<N>(d);                         \
-    int j2 = dpp_shr_i<N>(j);                            \
-    bool take = (d2 < d) || (d2 == d && j2 < j);         \
-    d = take ? d2 : d;                                   \
-    j = take ? j2 : j;                                   \
-  }
-  STEP(1) STEP(2) STEP(4) STEP(8)
-#undef STEP
-}
-
-#define FR_MAX 512       // frames per workgroup (fewer when a row is wide: the chunk must fit LDS)
 #define NTHREADS 256
-#define SPARE_TILES 64   // one partial tile per stratum present in a chunk (at most 64 distinct strata per chunk)
+
+struct AssignArgs {
+  const void *X;
+  int64_t ldx;
+  const double *pcoord;
+  int64_t n;
+  int32_t *labels;
+  int32_t *seen;  // nullable [2][S]
+  const StratumDev *table;
+  int S, D, Kfit;
+  int *err;
+};
 
 // ---- classify -----------------------------------------------------------------------------------
 __global__ void k_classify(MapperDev m, const double *__restrict__ p, int64_t n, int apply_remap, int32_t *bin,
@@ -82,430 +58,6 @@ extern "C" int hamsm_classify(hamsm_ctx *c, const double *p, int64_t n, int appl
                      bin, flags);
   HIPCHK(c, hipGetLastError());
   return HAMSM_OK;
-}
-
-// ---- the MFMA tile routine ------------------------------------------------------------------------
-// a[m][ks]: A fragments of MT tiles (lane l: frame row l&15 of tile m, feature ks*4 + (l>>4)).
-// On return bi[m][r] (valid in lanes with (l&15)==0) = first argmin over the stratum's centroids for
-// tile m, row (l>>4) + 4*r  (C/D layout of v_mfma_f64_16x16x4_f64: col = l&15, row = (l>>4) + 4*reg).
-template <int KS, int MT>
-__device__ __forceinline__ void tile_argmin(const double (&a)[MT][KS], int nt, const double *__restrict__ Bpack,
-                                            const double *__restrict__ csq, int K, int lane, int (&bi)[MT][4]) {
-  const double inf = __builtin_huge_val();
-  double bd[MT][4];
-#pragma unroll
-  for (int m = 0; m < MT; m++)
-#pragma unroll
-    for (int r = 0; r < 4; r++) {
-      bd[m][r] = inf;
-      bi[m][r] = lane & 15;
-    }
-  const int njt = (K + 15) >> 4;
-  double bcur[KS], bnext[KS];
-#pragma unroll
-  for (int ks = 0; ks < KS; ks++) bcur[ks] = Bpack[(size_t)ks * 64 + lane];
-  for (int jt = 0; jt < njt; jt++) {
-    const double cs = csq[jt * 16 + (lane & 15)];
-    if (jt + 1 < njt) {
-#pragma unroll
-      for (int ks = 0; ks < KS; ks++) bnext[ks] = Bpack[((size_t)(jt + 1) * KS + ks) * 64 + lane];
-    }
-    v4f64 acc[MT];
-#pragma unroll
-    for (int m = 0; m < MT; m++) acc[m] = (v4f64){0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-    for (int ks = 0; ks < KS; ks++) {
-#pragma unroll
-      for (int m = 0; m < MT; m++)
-        if (m < nt) acc[m] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[m][ks], bcur[ks], acc[m], 0, 0, 0);
-    }
-    const int j = jt * 16 + (lane & 15);
-#pragma unroll
-    for (int m = 0; m < MT; m++)
-#pragma unroll
-      for (int r = 0; r < 4; r++) {
-        double d = __builtin_fma(-2.0, acc[m][r], cs);  // csq - 2*dot, one rounding
-        bool lt = d < bd[m][r];                          // strict: lowest j wins inside a lane
-        bd[m][r] = lt ? d : bd[m][r];
-        bi[m][r] = lt ? j : bi[m][r];
-      }
-#pragma unroll
-    for (int ks = 0; ks < KS; ks++) bcur[ks] = bnext[ks];
-  }
-  // first-minimum across the 16 lanes that share a row: (d, j) lexicographic
-#pragma unroll
-  for (int m = 0; m < MT; m++)
-#pragma unroll
-    for (int r = 0; r < 4; r++) {
-      double d = bd[m][r];
-      int j = bi[m][r];
-#pragma unroll
-      for (int off = 8; off >= 1; off >>= 1) {
-        double d2 = __shfl_xor(d, off, 16);
-        int j2 = __shfl_xor(j, off, 16);
-        bool take = (d2 < d) || (d2 == d && j2 < j);
-        d = take ? d2 : d;
-        j = take ? j2 : j;
-      }
-      bi[m][r] = j;
-    }
-}
-
-// ---- fused assign ---------------------------------------------------------------------------------
-struct AssignArgs {
-  const void *X;
-  int64_t ldx;
-  const double *pcoord;
-  int64_t n;
-  int32_t *labels;
-  int32_t *seen;  // nullable [2][S]
-  const StratumDev *table;
-  int S, D, Kfit;
-  int *err;
-  int FR;  // frames per workgroup, multiple of 64
-  int need_rb;  // VER 2: some stratum has more centroid tiles than one group (running best kept in LDS)
-};
-
-// VER 1: waves pull independent (stratum, <=MT tiles) items and stream B fragments from L2.
-// VER 2: the four waves sweep the same tiles; each wave keeps JW centroid tiles of the current stratum as B
-//        fragments in registers (loaded once per stratum and centroid group), reads A fragments from LDS only,
-//        and the four partial first-minima of a tile are merged through LDS.  No global load in the MFMA loop.
-template <typename XT, int KS, int MT, int VER>
-__global__ __launch_bounds__(NTHREADS, 2) void k_assign(MapperDev mp, AssignArgs g) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  // LDS carve (one array, G17): Xs | slot | tile_s | item_* | cnt/tb | misc
-  const int FR = g.FR, MAX_TILES = FR / 16 + SPARE_TILES;
-  XT *Xs = (XT *)smem;                                                 // [FR][D]
-  size_t xbytes = ((size_t)FR * g.D * sizeof(XT) + 15) & ~(size_t)15;
-  int16_t *slot = (int16_t *)(smem + xbytes);                          // [MAX_TILES*16] local frame index or -1
-  int16_t *sid = slot + MAX_TILES * 16;                                // [FR] stratum of frame (or -1)
-  int16_t *pos = sid + FR;                                             // [FR] position inside the stratum's list
-  int *tile_s = (int *)(pos + FR);                                     // [MAX_TILES] stratum of tile
-  int *cnt = tile_s + MAX_TILES;                                       // [S]  frames per stratum
-  int *tbase = cnt + g.S;                                              // [S]  first tile of stratum
-  int *misc = tbase + g.S;                                             // [0] n tiles, [1] next item
-  // VER 2 extras (8-byte aligned): partial minima of the 4 waves, double buffered; running best per slot
-  double *part_d = (double *)(((uintptr_t)(misc + 4) + 7) & ~(uintptr_t)7);  // [2][4][MT*16]
-  int *part_j = (int *)(part_d + 2 * 4 * MT * 16);                        // [2][4][MT*16]
-  double *rb_d = (double *)(part_j + 2 * 4 * MT * 16);                    // [MAX_TILES*16] (only if g.need_rb)
-  int *rb_j = (int *)(rb_d + (g.need_rb ? MAX_TILES * 16 : 0));           // [MAX_TILES*16]
-
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int64_t f0 = (int64_t)blockIdx.x * FR;
-  const int nf = (int)((g.n - f0) < FR ? (g.n - f0) : FR);
-
-  for (int s = tid; s < g.S; s += NTHREADS) cnt[s] = 0;
-  for (int t = tid; t < MAX_TILES * 16; t += NTHREADS) slot[t] = -1;
-  if (tid == 0) misc[1] = 0;
-  __syncthreads();
-
-  // 1. classify + bucket
-  for (int i = tid; i < nf; i += NTHREADS) {
-    double pi[HAMSM_MAX_NDIM];
-    for (int d = 0; d < mp.ndim; d++) pi[d] = g.pcoord[(f0 + i) * mp.ndim + d];
-    int b = dev_bin_of(mp, pi);
-    int16_t my = -1, myp = 0;
-    if (b < 0) {
-      dev_set_error(g.err, HAMSM_ERANGE, (int)(f0 + i), b);
-    } else {
-      int s = mp.remap[b];                       // stratified_clustering.py:134-135
-      if (dev_in_box(mp.target, mp.ndim, pi)) {  // :159 target first
-        g.labels[f0 + i] = g.Kfit + 1;
-        if (g.seen) g.seen[s] = 1;
-      } else if (dev_in_box(mp.basis, mp.ndim, pi)) {  // :165
-        g.labels[f0 + i] = g.Kfit;
-        if (g.seen) g.seen[g.S + s] = 1;
-      } else if (g.table[s].K == 0) {  // :187-189
-        dev_set_error(g.err, HAMSM_EUNFIT, (int)(f0 + i), s);
-      } else {
-        my = (int16_t)s;
-        myp = (int16_t)atomicAdd(&cnt[s], 1);
-      }
-    }
-    sid[i] = my;
-    pos[i] = myp;
-  }
-  // 2. stage the chunk's rows (flat copy when rows are dense, else row by row)
-  {
-    const XT *src = (const XT *)g.X;
-    if (g.ldx == g.D) {
-      const int64_t e0 = f0 * g.D;
-      const int tot = nf * g.D;
-      constexpr int V = 16 / sizeof(XT);
-      // 16-byte vector loads where aligned
-      int head = (int)(((16 - ((uintptr_t)(src + e0) & 15)) & 15) / sizeof(XT));
-      if (head > tot) head = tot;
-      for (int e = tid; e < head; e += NTHREADS) Xs[e] = src[e0 + e];
-      int nvec = (tot - head) / V;
-      typedef XT vecT __attribute__((ext_vector_type(V)));
-      const vecT *vs = (const vecT *)(src + e0 + head);
-      for (int v = tid; v < nvec; v += NTHREADS) {
-        vecT x = vs[v];
-#pragma unroll
-        for (int q = 0; q < V; q++) Xs[head + v * V + q] = x[q];
-      }
-      for (int e = head + nvec * V + tid; e < tot; e += NTHREADS) Xs[e] = src[e0 + e];
-    } else {
-      for (int e = tid; e < nf * g.D; e += NTHREADS) {
-        int r = e / g.D, k = e - r * g.D;
-        Xs[e] = src[(f0 + r) * g.ldx + k];
-      }
-    }
-  }
-  __syncthreads();
-  // tile bases per stratum (one wave, S is small; sequential scan by lane 0 keeps it simple)
-  if (tid == 0) {
-    int t = 0;
-    for (int s = 0; s < g.S; s++) {
-      tbase[s] = t;
-      int nt = (cnt[s] + 15) >> 4;
-      for (int q = 0; q < nt && t + q < MAX_TILES; q++) tile_s[t + q] = s;
-      t += nt;
-    }
-    misc[0] = t < MAX_TILES ? t : MAX_TILES;
-    if (t > MAX_TILES) dev_set_error(g.err, HAMSM_ENOTSUP, t, MAX_TILES);
-  }
-  __syncthreads();
-  for (int i = tid; i < nf; i += NTHREADS) {
-    int s = sid[i];
-    if (s >= 0) {
-      int sl = tbase[s] * 16 + pos[i];
-      if (sl < MAX_TILES * 16) slot[sl] = (int16_t)i;
-    }
-  }
-  __syncthreads();
-
-  if constexpr (VER == 2) {
-    constexpr int JW = (KS <= 16) ? 4 : 2;  // centroid tiles per wave per group
-    const int wv = tid >> 6;
-    const double inf = __builtin_huge_val();
-    int batch = 0;
-    for (int s = 0; s < g.S; s++) {
-      const int nts = (cnt[s] + 15) >> 4;
-      if (!nts) continue;
-      const StratumDev sd = g.table[s];
-      const int njt = (sd.K + 15) >> 4;
-      const int ngrp = (njt + 4 * JW - 1) / (4 * JW);
-      for (int gi = 0; gi < ngrp; gi++) {
-        double b[JW][KS], cs[JW];
-#pragma unroll
-        for (int u = 0; u < JW; u++) {
-          const int jt = gi * 4 * JW + wv * JW + u;
-          const bool live = jt < njt;
-          const int jts = live ? jt : 0;
-          double c0 = ((gcdp)sd.csq)[jts * 16 + (lane & 15)];
-          cs[u] = live ? c0 : inf;
-#pragma unroll
-          for (int ks = 0; ks < KS; ks++) {
-            double v = ((gcdp)sd.Bpack)[((size_t)jts * KS + ks) * 64 + lane];
-            b[u][ks] = live ? v : 0.0;
-          }
-        }
-        for (int t = 0; t < nts; t += MT, batch++) {
-          const int nt = (nts - t) < MT ? (nts - t) : MT;
-          const int tb = tbase[s] + t;
-          double bd[MT][4];
-          int bj[MT][4];
-          // one tile at a time; the JW centroid tiles give JW independent accumulator chains.  Dead centroid
-          // tiles (beyond the stratum's K) carry zero B fragments and csq = +inf: they run unconditionally so
-          // that the MFMA stream has no branches, and can never win.
-#pragma unroll
-          for (int m = 0; m < MT; m++) {
-#pragma unroll
-            for (int r = 0; r < 4; r++) {
-              bd[m][r] = inf;
-              bj[m][r] = 0x7fffffff;
-            }
-            if (m >= nt) continue;  // block-uniform: a whole tile's MFMA stream is skipped, never a single MFMA
-            double a[KS];
-            {
-              int f = (m < nt) ? slot[(tb + m) * 16 + (lane & 15)] : -1;
-              const XT *xr = Xs + (f < 0 ? 0 : f) * g.D;
-#pragma unroll
-              for (int ks = 0; ks < KS; ks++) {
-                int k = ks * 4 + (lane >> 4);
-#if V2_UNCOND
-                double v = (double)xr[k < g.D ? k : 0];  // unconditional LDS read, then select: no exec-mask branches
-                a[ks] = (f >= 0 && k < g.D) ? v : 0.0;
-#else
-                a[ks] = (f >= 0 && k < g.D) ? (double)xr[k] : 0.0;
-#endif
-              }
-            }
-            v4f64 acc[JW];
-#pragma unroll
-            for (int u = 0; u < JW; u++) acc[u] = (v4f64){0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-            for (int ks = 0; ks < KS; ks++)
-#pragma unroll
-              for (int u = 0; u < JW; u++) acc[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[ks], b[u][ks], acc[u], 0, 0, 0);
-#pragma unroll
-            for (int r = 0; r < 4; r++) {
-              bd[m][r] = inf;
-              bj[m][r] = 0x7fffffff;
-            }
-#pragma unroll
-            for (int u = 0; u < JW; u++) {
-              const int j = (gi * 4 * JW + wv * JW + u) * 16 + (lane & 15);
-#pragma unroll
-              for (int r = 0; r < 4; r++) {
-                double d = __builtin_fma(-2.0, acc[u][r], cs[u]);
-                bool lt = d < bd[m][r];  // this wave's tiles ascend: strict < keeps its lowest j
-                bd[m][r] = lt ? d : bd[m][r];
-                bj[m][r] = lt ? j : bj[m][r];
-              }
-            }
-          }
-          const int buf = batch & 1;
-#pragma unroll
-          for (int m = 0; m < MT; m++)
-#pragma unroll
-            for (int r = 0; r < 4; r++) {
-              double d = bd[m][r];
-              int j = bj[m][r];
-#if V2_DPP
-              row_min16(d, j);
-              const bool owner = (lane & 15) == 15;
-#else
-#pragma unroll
-              for (int off = 8; off >= 1; off >>= 1) {
-                double d2 = __shfl_xor(d, off, 16);
-                int j2 = __shfl_xor(j, off, 16);
-                bool take = (d2 < d) || (d2 == d && j2 < j);
-                d = take ? d2 : d;
-                j = take ? j2 : j;
-              }
-              const bool owner = (lane & 15) == 0;
-#endif
-              if (owner && m < nt) {
-                int row = (lane >> 4) + 4 * r;
-                part_d[(buf * 4 + wv) * MT * 16 + m * 16 + row] = d;
-                part_j[(buf * 4 + wv) * MT * 16 + m * 16 + row] = j;
-              }
-            }
-          __syncthreads();
-          if (tid < nt * 16) {
-            const int m = tid >> 4, row = tid & 15;
-            double d = part_d[(buf * 4 + 0) * MT * 16 + m * 16 + row];
-            int j = part_j[(buf * 4 + 0) * MT * 16 + m * 16 + row];
-#pragma unroll
-            for (int w = 1; w < 4; w++) {
-              double d2 = part_d[(buf * 4 + w) * MT * 16 + m * 16 + row];
-              int j2 = part_j[(buf * 4 + w) * MT * 16 + m * 16 + row];
-              bool take = (d2 < d) || (d2 == d && j2 < j);
-              d = take ? d2 : d;
-              j = take ? j2 : j;
-            }
-            const int sl = (tb + m) * 16 + row;
-            if (ngrp > 1) {
-              if (gi > 0) {  // earlier groups hold lower j: they win ties
-                double d0 = rb_d[sl];
-                int j0 = rb_j[sl];
-                bool keep = (d0 < d) || (d0 == d && j0 < j);
-                d = keep ? d0 : d;
-                j = keep ? j0 : j;
-              }
-              if (gi < ngrp - 1) {
-                rb_d[sl] = d;
-                rb_j[sl] = j;
-              }
-            }
-            if (gi == ngrp - 1) {
-              const int f = slot[sl];
-              if (j == 0x7fffffff) j = 0;  // all-NaN row: label 0 like the oracle
-              if (f >= 0) g.labels[f0 + f] = sd.off + j;  // stratified_clustering.py:195
-            }
-          }
-        }
-      }
-    }
-    return;
-  }
-  // 3. work items: up to MT consecutive tiles of one stratum, pulled dynamically by the waves
-  const int ntiles = misc[0];
-  while (true) {
-    int t0 = 0;
-    if (lane == 0) t0 = atomicAdd(&misc[1], MT);
-    t0 = __builtin_amdgcn_readfirstlane(t0);
-    if (t0 >= ntiles) break;
-    // tiles t0..t0+MT-1 may span strata: process runs of equal stratum
-    int t = t0;
-    const int tend = (t0 + MT < ntiles) ? t0 + MT : ntiles;
-    while (t < tend) {
-      const int s = tile_s[t];
-      int nt = 1;
-      while (t + nt < tend && tile_s[t + nt] == s) nt++;
-      double a[MT][KS];
-      int fr[MT];
-#pragma unroll
-      for (int m = 0; m < MT; m++) {
-        int f = (m < nt) ? slot[(t + m) * 16 + (lane & 15)] : -1;
-        fr[m] = f;
-        int fsafe = f < 0 ? 0 : f;
-#pragma unroll
-        for (int ks = 0; ks < KS; ks++) {
-          int k = ks * 4 + (lane >> 4);
-          a[m][ks] = (f >= 0 && k < g.D) ? (double)Xs[fsafe * g.D + k] : 0.0;
-        }
-      }
-      const StratumDev sd = g.table[s];
-      int bi[MT][4];
-      tile_argmin<KS, MT>(a, nt, sd.Bpack, sd.csq, sd.K, lane, bi);
-      // lanes with (lane&15)==0 own rows (lane>>4) + 4r
-#pragma unroll
-      for (int m = 0; m < MT; m++)
-#pragma unroll
-        for (int r = 0; r < 4; r++) {
-          int row = (lane >> 4) + 4 * r;
-          int f = __shfl(fr[m], row, 64);  // lane `row` holds the frame index of tile row `row`
-          if ((lane & 15) == 0 && m < nt && f >= 0) g.labels[f0 + f] = sd.off + bi[m][r];  // :195
-        }
-      t += nt;
-    }
-  }
-}
-
-template <typename XT, int KS>
-static int launch_assign_ks(hamsm_ctx *c, const MapperDev &mp, const AssignArgs &g_in) {
-  constexpr int MT = (KS <= 8) ? 4 : (KS <= 16 ? 2 : 1);
-  AssignArgs g = g_in;
-  // chunk of frames per workgroup: as many as keep the staged rows within ~64 KB (2 workgroups per CU)
-  int FR = FR_MAX;
-  while (FR > 64 && (size_t)FR * g.D * sizeof(XT) > 64 * 1024) FR >>= 1;
-  g.FR = FR;
-  const int MAX_TILES = FR / 16 + SPARE_TILES;
-  constexpr int JW = (KS <= 16) ? 4 : 2;
-  g.need_rb = 0;
-  for (int s = 0; s < c->S; s++) g.need_rb |= ((c->st[s].K + 15) / 16 > 4 * JW);
-  size_t xbytes = ((size_t)FR * g.D * sizeof(XT) + 15) & ~(size_t)15;
-  size_t lds = xbytes + sizeof(int16_t) * (MAX_TILES * 16 + 2 * FR) + sizeof(int) * (MAX_TILES + 2 * g.S + 4);
-  const int ver = c->assign_version;
-  if (ver == 2)
-    lds += 16 + (sizeof(double) + sizeof(int)) * 2 * 4 * MT * 16 +
-           (g.need_rb ? (sizeof(double) + sizeof(int)) * MAX_TILES * 16 : 0);
-  if (lds > 160 * 1024) return hamsm_fail(c, HAMSM_ENOTSUP, "assign needs %zu B of LDS", lds);
-  auto kern = ver == 2 ? k_assign<XT, KS, MT, 2> : k_assign<XT, KS, MT, 1>;
-  HIPCHK(c, hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  unsigned grid = (unsigned)((g.n + FR - 1) / FR);
-  hipLaunchKernelGGL(kern, dim3(grid), dim3(NTHREADS), lds, c->stream, mp, g);
-  HIPCHK(c, hipGetLastError());
-  return HAMSM_OK;
-}
-
-template <typename XT>
-static int launch_assign(hamsm_ctx *c, const MapperDev &mp, const AssignArgs &g) {
-  int ks = c->KS;
-  if (ks <= 1) return launch_assign_ks<XT, 1>(c, mp, g);
-  if (ks <= 2) return launch_assign_ks<XT, 2>(c, mp, g);
-  if (ks <= 3) return launch_assign_ks<XT, 3>(c, mp, g);
-  if (ks <= 4) return launch_assign_ks<XT, 4>(c, mp, g);
-  if (ks <= 6) return launch_assign_ks<XT, 6>(c, mp, g);
-  if (ks <= 8) return launch_assign_ks<XT, 8>(c, mp, g);
-  if (ks <= 12) return launch_assign_ks<XT, 12>(c, mp, g);
-  if (ks <= 16) return launch_assign_ks<XT, 16>(c, mp, g);
-  if (ks <= 24) return launch_assign_ks<XT, 24>(c, mp, g);
-  if (ks <= 32) return launch_assign_ks<XT, 32>(c, mp, g);
-  return hamsm_fail(c, HAMSM_ENOTSUP, "D > 128");
 }
 
 #ifdef ASSIGN_PROFILE
@@ -531,11 +83,7 @@ extern "C" int hamsm_debug_assign_profile(unsigned long long *h_out) {
 #define APROF_END
 #endif
 
-// ---- VER 3: stratum-sorted assignment --------------------------------------------------------------
-// Three light passes bucket the frames by stratum (a permutation, 4 B per frame), then every workgroup of the
-// main kernel owns FRB frames of ONE stratum: the stratum's centroid fragments are loaded into registers once
-// per workgroup, there are no partial tiles except at a stratum's end and no stratum switches.  Rows are
-// gathered through the permutation (each 4*D-byte row is one contiguous read).
+// ---- stratum-sorted assignment -------------------------------------------------------------------
 #define FRB_MAX 512
 struct SortArgs {
   const void *X;
@@ -893,6 +441,8 @@ static int launch_sorted(hamsm_ctx *c, const AssignArgs &a) {
   hipLaunchKernelGGL(k_sort_fill, dim3(gridc), dim3(256), sizeof(unsigned int) * ((S + 1) & ~1) + sizeof(long long) * S,
                      c->stream, g);
   HIPCHK(c, hipGetLastError());
+  hamsm_timer_end(c, ST_OTHER);   // the three bucket passes
+  hamsm_timer_begin(c);           // ... and the distance kernel proper (ST_ASSIGN, ended by the caller)
   switch (c->KS) {
 #define CASE(KSV) \
   case KSV: return launch_sorted_ks<XT, KSV>(c, g);
@@ -907,16 +457,12 @@ extern "C" int hamsm_assign(hamsm_ctx *c, const void *X, int dt, int64_t ldx, co
   if (!c->have_mapper || !c->have_bounds) return hamsm_fail(c, HAMSM_EINVAL, "mapper/bounds not set");
   if (dt != HAMSM_F32 && dt != HAMSM_F64) return hamsm_fail(c, HAMSM_EINVAL, "x_dtype");
   if (ldx < c->D) return hamsm_fail(c, HAMSM_EINVAL, "ldx < D");
-  // a chunk that meets more than SPARE_TILES distinct strata is reported as HAMSM_ENOTSUP by the kernel
   if (n <= 0) return HAMSM_OK;
   int rc = hamsm_refresh_table(c);
   if (rc) return rc;
-  // B fragments carry ceil(D/4) k-steps, but the kernels are instantiated for a few KS values: the
-  // packed layout always uses c->KS, so the instantiated KS must equal it
-  AssignArgs g{X, ldx, p, n, labels, seen, c->d_table, c->S, c->D, c->Kfit, c->d_err, FR_MAX, 0};
-  hamsm_timer_begin(c);
-  if (c->assign_version == 3) rc = (dt == HAMSM_F32) ? launch_sorted<float>(c, g) : launch_sorted<double>(c, g);
-  else rc = (dt == HAMSM_F32) ? launch_assign<float>(c, c->mapper, g) : launch_assign<double>(c, c->mapper, g);
+  AssignArgs g{X, ldx, p, n, labels, seen, c->d_table, c->S, c->D, c->Kfit, c->d_err};
+  hamsm_timer_begin(c);  // bucket passes -> ST_OTHER (ended inside launch_sorted), distance kernel -> ST_ASSIGN
+  rc = (dt == HAMSM_F32) ? launch_sorted<float>(c, g) : launch_sorted<double>(c, g);
   hamsm_timer_end(c, ST_ASSIGN);
   if (rc) return rc;
   return hamsm_check_device_error(c, "assign");

@@ -80,7 +80,6 @@ struct hamsm_ctx {
   hipEvent_t ev_cur0 = nullptr;
   double timers[ST_N] = {0};
   double last_ms[ST_N] = {0};
-  int assign_version = 3;  // assign kernel: 3 = stratum-sorted (default), 2 = chunk-local buckets, 1 = item pulling (HAMSM_ASSIGN_V)
   int assign_waves = 4;    // waves per workgroup of the sorted assign kernel (HAMSM_ASSIGN_W=8: 8 waves x 2 centroid tiles)
   void *seed_chosen_dev = nullptr;  // chosen indices of the last seeding's first item (device)
   void *comm = nullptr;  // ncclComm_t

@@ -23,7 +23,6 @@ extern "C" int hamsm_create(int device, hamsm_ctx **out) {
   c->device = device;
   memset(&c->mapper, 0, sizeof c->mapper);
   if (const char *v = getenv("HAMSM_ASSIGN_W")) c->assign_waves = atoi(v) == 8 ? 8 : 4;
-  if (const char *v = getenv("HAMSM_ASSIGN_V")) c->assign_version = (atoi(v) >= 1 && atoi(v) <= 3) ? atoi(v) : 3;
   if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess ||
       hipMalloc((void **)&c->d_err, 4 * sizeof(int)) != hipSuccess ||
       hipHostMalloc((void **)&c->h_err, 4 * sizeof(int)) != hipSuccess) {

@@ -809,20 +809,18 @@ __global__ __launch_bounds__(256) void k_step_assign(const StepDev *__restrict__
   }
   const int njt = (st.K + 15) >> 4;
   const double inf = __builtin_huge_val();
-  double bd[4];
-  int bi[4];
-#pragma unroll
-  for (int q = 0; q < 4; q++) {
-    bd[q] = inf;
-    bi[q] = 0x7fffffff;
-  }
+  // centroids are the MFMA's A operand (rows), the 16 batch rows its B operand (columns): lane l accumulates, for
+  // batch row l&15, the centroids (l>>4) + 4q of each tile -- the first-minimum is register-local
+  double bd = inf;
+  int bi = 0x7fffffff;
   for (int t0 = wv; t0 < njt; t0 += 4 * JB) {
-    double b[JB][KS], cs[JB];
+    double b[JB][KS], cs[JB][4];
 #pragma unroll
     for (int u = 0; u < JB; u++) {
       int jt = t0 + 4 * u;
       bool live = jt < njt;
-      cs[u] = live ? st.csq[jt * 16 + (lane & 15)] : inf;
+#pragma unroll
+      for (int q = 0; q < 4; q++) cs[u][q] = live ? st.csq[jt * 16 + (lane >> 4) + 4 * q] : inf;
 #pragma unroll
       for (int ks = 0; ks < KS; ks++) b[u][ks] = live ? st.Bpack[((size_t)jt * KS + ks) * 64 + lane] : 0.0;
     }
@@ -832,36 +830,34 @@ __global__ __launch_bounds__(256) void k_step_assign(const StepDev *__restrict__
       if (jt < njt) {
         v4f64 acc = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-        for (int ks = 0; ks < KS; ks++) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[ks], b[u][ks], acc, 0, 0, 0);
-        const int j = jt * 16 + (lane & 15);
+        for (int ks = 0; ks < KS; ks++) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(b[u][ks], a[ks], acc, 0, 0, 0);
+        const int j0 = jt * 16 + (lane >> 4);
 #pragma unroll
         for (int q = 0; q < 4; q++) {
-          double d = __builtin_fma(-2.0, acc[q], cs[u]);
-          bool lt = d < bd[q];  // a wave's tiles ascend, so strict < keeps its lowest j
-          bd[q] = lt ? d : bd[q];
-          bi[q] = lt ? j : bi[q];
+          double d = __builtin_fma(-2.0, acc[q], cs[u][q]);
+          bool lt = d < bd;  // a lane's centroids ascend (q, then tile), so strict < keeps its lowest j
+          bd = lt ? d : bd;
+          bi = lt ? j0 + 4 * q : bi;
         }
       }
     }
   }
   __shared__ double sd[4][16];
   __shared__ int sj[4][16];
+  {
+    double d = bd;
+    int j = bi;
 #pragma unroll
-  for (int q = 0; q < 4; q++) {
-    double d = bd[q];
-    int j = bi[q];
-#pragma unroll
-    for (int off = 8; off >= 1; off >>= 1) {
-      double d2 = __shfl_xor(d, off, 16);
-      int j2 = __shfl_xor(j, off, 16);
+    for (int off = 16; off <= 32; off <<= 1) {  // lanes l, l^16, l^32, l^48 hold the same batch row
+      double d2 = __shfl_xor(d, off, 64);
+      int j2 = __shfl_xor(j, off, 64);
       bool take = (d2 < d) || (d2 == d && j2 < j);
       d = take ? d2 : d;
       j = take ? j2 : j;
     }
-    if ((lane & 15) == 0) {
-      int row = (lane >> 4) + 4 * q;
-      sd[wv][row] = d;
-      sj[wv][row] = j;
+    if (lane < 16) {
+      sd[wv][lane] = d;
+      sj[wv][lane] = j;
     }
   }
   __syncthreads();

@@ -328,22 +328,23 @@ def test_block_validation_runs(hip_h):
     assert np.array_equal(np.concatenate(m.dtrajs), g["dtrajs_clean"])
 
 
-@pytest.mark.parametrize("version", ["1", "2", "3"])
-def test_assign_kernel_variants_agree(hip_lib, oracle_h, version, monkeypatch):
-    """The three assign kernels (3 = stratum-sorted, the default; 2 = chunk-local buckets with register-resident
-    centroid fragments; 1 = item pulling) compute the same labels as the oracle."""
+@pytest.mark.parametrize("waves", ["4", "8"])
+def test_assign_kernel_variants_agree(hip_lib, oracle_h, waves, monkeypatch):
+    """Both workgroup shapes of the sorted assign kernel (4 waves x 4 centroid tiles, 8 waves x 2) compute the
+    oracle's labels, including strata with more centroids than one register-resident group (K_s = 300 > 256)."""
     from msm_we_amd import _abi
 
-    monkeypatch.setenv("HAMSM_ASSIGN_V", version)
+    monkeypatch.setenv("HAMSM_ASSIGN_W", waves)
     h = _abi.Hamsm(lib=hip_lib)
     try:
-        for D, S, K_s, dtype in ((30, 4, 250, np.float32), (64, 3, 300, np.float64), (10, 12, 25, np.float32)):
+        for D, S, K_s, dtype in ((30, 4, 250, np.float32), (64, 3, 300, np.float64), (10, 12, 25, np.float32),
+                                 (30, 2, 1250, np.float32)):
             outs = []
             for hh in (oracle_h, h):
                 rng = np.random.default_rng(7)
                 _setup(hh, D, S, K_s, rng)
                 X, p = _frames(rng, 7001, D, S, dtype)
                 outs.append(hh.predict_host(X, p))
-            assert np.array_equal(outs[0], outs[1]), (version, D, S, K_s)
+            assert np.array_equal(outs[0], outs[1]), (waves, D, S, K_s)
     finally:
         h.close()
