@@ -117,6 +117,34 @@ def cpu_baseline(cfg, n_iters_sample, seed):
                       f"step, oracle/hamsm_oracle.c single thread, {dt:.1f} s"}
 
 
+def full_pipeline(m, cfg, seed, flux_mode):
+    """The reference's ``build_analyze_model`` sequence from clustering onwards (msm_we.py:588-882): train + discretize,
+    flux matrix, cleaning (re-discretize + re-flux), T as CSR on the device, steady state + target flux on the host,
+    then 2-group / 4-block validation (per group: flux, clean, T, solve).  Timed once, outside the timed steps."""
+    bm = Mapper([synthetic.strata_boundaries(cfg.S)])
+    m.flux_mode = flux_mode
+    t = {}
+
+    def lap(name, fn):
+        t0 = time.perf_counter()
+        fn()
+        m.h.sync()
+        t[name] = time.perf_counter() - t0
+
+    lap("cluster", lambda: m.cluster_coordinates(cfg.K_s, streaming=True, use_ray=True, stratified=True, user_bin_mapper=bm,
+                                                  random_state=seed, store_validation_model=True))
+    lap("fluxmatrix", lambda: m.get_fluxMatrix(0, first_iter=1, last_iter=m.maxIter, use_ray=True))
+    lap("organize", lambda: m.organize_fluxMatrix(use_ray=True))
+    lap("tmatrix_csr", m.get_Tmatrix)
+    lap("steady_state", m.get_steady_state)
+    lap("target_flux", m.get_steady_state_target_flux)
+    lap("block_validation", lambda: m.do_block_validation(cross_validation_groups=2, cross_validation_blocks=4, use_ray=True))
+    total = sum(t.values())
+    return {"seconds": {k: round(v, 5) for k, v in t.items()}, "total_seconds": total, "states": int(m.Tmatrix.shape[0]),
+            "tmatrix_nnz": int(m.Tmatrix_csr.nnz), "JtargetSS": float(m.JtargetSS),
+            "validation_JtargetSS": [float(v.JtargetSS) for v in m.validation_models]}
+
+
 def pmc_traffic(cfg, n_iters):
     """HBM bytes per k_assign_sorted launch from the committed rocprofv3 PMC passes of this same workload
     (profiles/r01_d_pmc_summary.csv: separate --pmc FETCH_SIZE / WRITE_SIZE runs; FETCH_SIZE doubled as
@@ -144,6 +172,7 @@ def main():
     ap.add_argument("--flux-mode", type=int, default=0, help="0 = f64 atomics, 1 = deterministic sort-based")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-iters", type=int, default=20)
+    ap.add_argument("--no-full-pipeline", action="store_true")
     ap.add_argument("--lib", default=None, help="(kernel A/B experiments) path of an alternative build of the HIP library")
     args = ap.parse_args()
 
@@ -173,7 +202,7 @@ def main():
     seed = 1337
 
     h = _abi.Hamsm(lib=ctypes.CDLL(args.lib) if args.lib else None, device=local_rank)  # the HIP library; raises if not built
-    assert h.backend == "hip-gfx950"
+    assert args.lib or h.backend == "hip-gfx950"
     if world > 1:
         uid = [h.comm_unique_id() if rank == 0 else None]
         dist.broadcast_object_list(uid, src=0)
@@ -246,8 +275,16 @@ def main():
                      "hbm_frac": bytes_alg / (assign_avg_ms * 1e-3) / 1e9 / PEAK_HBM_GBS},
         "stage_seconds_per_step": {k: v / args.steps for k, v in timers.items()},
     }
+    if world == 1 and not args.no_full_pipeline:
+        # BASELINE.json's second figure (steady-state solve wall-time) and SURVEY §8d's build_analyze_model-equivalent
+        log("timing the full build_analyze_model sequence (clean, T, solve, block validation) ...")
+        fp = full_pipeline(m, cfg, seed, args.flux_mode)
+        fp["frames_per_s"] = n_seg / fp["total_seconds"]
+        out["full_pipeline"] = fp
+        out["solve"] = {"states": fp["states"], "tmatrix_csr_s": fp["seconds"]["tmatrix_csr"],
+                        "steady_state_s": fp["seconds"]["steady_state"], "where": "T built as CSR on the GPU; scipy solve on host"}
     if rank == 0:
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:
             log("timing the CPU oracle on a bounded sample ...")
             out["cpu_baseline"] = cpu_baseline(cfg, min(args.cpu_iters, n_iters), seed)
             out["cpu_baseline"]["gpu_over_cpu"] = out["value"] / out["cpu_baseline"]["value"]

@@ -218,6 +218,8 @@ int hamsm_minibatch_run(hamsm_ctx *ctx, const void *d_X, int x_dtype, int64_t ld
  *      Replaces the driver-side sum of per-task flux matrices (_fluxmatrix.py:325-327) and
  *      ray.put broadcasts (_clustering.py:1169-1176).  RCCL over xGMI in the product.           */
 int hamsm_comm_unique_id(char *h_id128);
+/* nranks == 1 with h_id128 == NULL: no communicator, the collectives below are no-ops.  With an id a communicator is
+ * created even for one rank (the collectives then run through RCCL and are the identity). */
 int hamsm_comm_init(hamsm_ctx *ctx, int nranks, int rank, const char *h_id128);
 int hamsm_comm_destroy(hamsm_ctx *ctx);
 int hamsm_allreduce_sum_f64(hamsm_ctx *ctx, double *d_buf, int64_t count);

@@ -6,13 +6,17 @@ GPU-built CSR transition matrix (``hamsm_tmatrix_csr``).  Semantics follow the r
 eigenvector refined by inverse iteration, convergence on the target flux.  Where the reference forms
 an explicit sparse inverse (``utils.py:138``) this factorises once and solves (same SuperLU
 factorisation, no inverse); above ``dense_eig_max`` states the dense ``eig`` seed (``:222``) is
-replaced by ARPACK on the CSR matrix.
+replaced by ARPACK on the CSR matrix, and matrices denser
+than 10 % are factorised with LAPACK instead of SuperLU.
 """
 from __future__ import annotations
 
 import logging
 
+import warnings
+
 import numpy as np
+import scipy.linalg as sla
 import scipy.sparse as sp
 import scipy.sparse.csgraph as csgraph
 import scipy.sparse.linalg as spla
@@ -20,6 +24,8 @@ import scipy.sparse.linalg as spla
 log = logging.getLogger("msm_we_amd")
 
 __all__ = ["AnalysisMixin", "inverse_iteration", "is_connected"]
+
+DENSE_LU_DENSITY = 0.10
 
 
 def is_connected(matrix, source_states, target_states, directed=True):
@@ -33,15 +39,28 @@ def inverse_iteration(guess, matrix, mu=1):
     `utils.py:116-161`): solve (T^T - mu I) x = guess, normalise; fall back to mu=0.999 when the
     shifted matrix is exactly singular."""
     n = guess.shape[0]
-    A = (matrix.T - mu * sp.eye(n)).tocsc()
-    try:
-        lu = spla.splu(A)
-    except RuntimeError:
+    guess = np.asarray(guess, dtype=np.float64)
+    matrix = sp.csr_matrix(matrix)
+    x = None
+    if matrix.nnz > DENSE_LU_DENSITY * n * n:
+        # cleaned haMSM matrices are often 30-50 % dense: LAPACK getrf beats SuperLU there by 2-4x
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore", sla.LinAlgWarning)
+            A = matrix.toarray().T
+            A[np.diag_indices(n)] -= mu
+            lu = sla.lu_factor(A, overwrite_a=True, check_finite=False)
+            if np.all(np.diagonal(lu[0]) != 0):
+                x = sla.lu_solve(lu, guess, check_finite=False)
+    else:
+        try:
+            x = spla.splu((matrix.T - mu * sp.eye(n)).tocsc()).solve(guess)
+        except RuntimeError:
+            x = None
+    if x is None or not np.all(np.isfinite(x)):
         if mu != 1:
-            raise
+            raise RuntimeError("inverse iteration failed: shifted matrix is singular")
         log.error("When solving steady-state, failed to perform inverse iteration! Trying again with mu=0.999.")
         return inverse_iteration(guess, matrix, mu=0.999)
-    x = lu.solve(np.asarray(guess, dtype=np.float64))
     x = x / sum(x)
     return x
 
@@ -51,7 +70,7 @@ class AnalysisMixin:
     pSS = None
     lagtime = None
     JtargetSS = None
-    dense_eig_max = 2500
+    dense_eig_max = 256  # states; above this the eigenvector seed comes from ARPACK on the CSR matrix
 
     def get_Tmatrix(self):
         """`_analysis.py:23-79` on the device: row-normalise, zero rows -> self loop, target rows ->
@@ -74,12 +93,21 @@ class AnalysisMixin:
     def get_steady_state_algebraic(self, max_iters=1000, check_negative=True, set=True):
         """`_analysis.py:193-282`"""
         n = self.Tmatrix.shape[0]
-        if n <= self.dense_eig_max:
+        pSS = None
+        if n > self.dense_eig_max:
+            # dense eig is O(n^3) with a large constant (1 s at 670 states, 5 s at 2600); ARPACK on the device-built CSR
+            # needs a handful of mat-vecs.  Deterministic start vector; dense fallback when it does not converge.
+            try:
+                vals, vecs = spla.eigs(self._T_csr().T.tocsc(), k=1, which="LR", v0=np.full(n, 1.0 / n), tol=1e-13,
+                                       maxiter=max(20 * n, 2000))
+                pSS = np.real(vecs[:, 0]).squeeze()
+                if np.isclose(np.sum(pSS), 0):
+                    pSS = None
+            except (spla.ArpackNoConvergence, spla.ArpackError) as e:
+                log.warning(f"ARPACK did not converge ({e}); falling back to dense eig")
+        if pSS is None:
             vals, vecs = np.linalg.eig(np.transpose(self.Tmatrix))
             pSS = np.real(vecs[:, np.argmax(np.real(vals))]).squeeze()
-        else:
-            vals, vecs = spla.eigs(self._T_csr().T.tocsc(), k=1, which="LR")
-            pSS = np.real(vecs[:, 0]).squeeze()
         assert not np.isclose(np.sum(pSS), 0), "Steady-state distribution sums to 0!"
         pSS = pSS / np.sum(pSS)
         if sum(pSS < 0) > 0 and max_iters > 0:

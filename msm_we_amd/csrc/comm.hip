@@ -28,7 +28,9 @@ extern "C" int hamsm_comm_init(hamsm_ctx *c, int nranks, int rank, const char *i
   HIPCHK(c, hipSetDevice(c->device));
   c->nranks = nranks;
   c->rank = rank;
-  if (nranks == 1) return HAMSM_OK;
+  if (nranks == 1 && !id128) return HAMSM_OK;
+  if (!id128) return hamsm_fail(c, HAMSM_EINVAL, "comm_init: unique id missing");
+  // a 1-rank communicator is legal and keeps every collective below on the RCCL path (used by the GPU tests)
   ncclUniqueId id;
   memcpy(&id, id128, 128);
   ncclComm_t comm;
@@ -46,7 +48,7 @@ extern "C" int hamsm_comm_destroy(hamsm_ctx *c) {
 }
 
 static int allreduce(hamsm_ctx *c, void *buf, int64_t count, ncclDataType_t dt, ncclRedOp_t op) {
-  if (c->nranks == 1 || count <= 0) return HAMSM_OK;
+  if (count <= 0 || (c->nranks == 1 && !c->comm)) return HAMSM_OK;
   if (!c->comm) return hamsm_fail(c, HAMSM_EINVAL, "comm not initialised");
   NCCLCHK(c, ncclAllReduce(buf, buf, (size_t)count, dt, op, (ncclComm_t)c->comm, c->stream));
   return HAMSM_OK;
@@ -58,7 +60,7 @@ extern "C" int hamsm_allreduce_max_f64(hamsm_ctx *c, double *b, int64_t n) { ret
 extern "C" int hamsm_allreduce_sum_i64(hamsm_ctx *c, int64_t *b, int64_t n) { return allreduce(c, b, n, ncclInt64, ncclSum); }
 
 extern "C" int hamsm_bcast(hamsm_ctx *c, void *b, size_t bytes, int root) {
-  if (c->nranks == 1 || bytes == 0) return HAMSM_OK;
+  if (bytes == 0 || (c->nranks == 1 && !c->comm)) return HAMSM_OK;
   if (!c->comm) return hamsm_fail(c, HAMSM_EINVAL, "comm not initialised");
   NCCLCHK(c, ncclBroadcast(b, b, bytes, ncclChar, root, (ncclComm_t)c->comm, c->stream));
   return HAMSM_OK;
@@ -66,7 +68,7 @@ extern "C" int hamsm_bcast(hamsm_ctx *c, void *b, size_t bytes, int root) {
 
 // centroids, counts, ||c||^2 and remap of every stratum, root -> all (exact-mode training: SURVEY §7 hard part 3)
 extern "C" int hamsm_bcast_model(hamsm_ctx *c, int root) {
-  if (c->nranks == 1) return HAMSM_OK;
+  if (c->nranks == 1 && !c->comm) return HAMSM_OK;
   if (!c->comm) return hamsm_fail(c, HAMSM_EINVAL, "comm not initialised");
   const int S = c->S;
   int rc = hamsm_ensure_scratch(c, sizeof(int32_t) * S);

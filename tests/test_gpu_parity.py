@@ -348,3 +348,40 @@ def test_assign_kernel_variants_agree(hip_lib, oracle_h, waves, monkeypatch):
             assert np.array_equal(outs[0], outs[1]), (waves, D, S, K_s)
     finally:
         h.close()
+
+
+def test_rccl_collectives_on_one_rank_communicator(hip_lib):
+    """Only one GPU is visible to the tests, so the RCCL calls of the sharded path are exercised on a real 1-rank
+    communicator (ncclCommInitRank, AllReduce, Broadcast, the grouped model broadcast + re-pack): every collective
+    must be the identity and leave the model usable.  (world_size 2 logic: tests/test_distributed_gloo.py.)"""
+    from msm_we_amd import _abi
+
+    h = _abi.Hamsm(lib=hip_lib)
+    try:
+        h.comm_init(1, 0, h.comm_unique_id())
+        rng = np.random.default_rng(5)
+        D, S, K_s = 30, 4, 250
+        _setup(h, D, S, K_s, rng, fit=[True, True, False, True], remap=np.array([0, 1, 1, 3], dtype=np.int32))
+        X, p = _frames(rng, 4001, D, S, np.float32)
+        before = h.predict_host(X, p)
+        cents = [h.get_centroids(s) for s in (0, 1, 3)]
+        v = rng.normal(size=100003)
+        d_v = h.to_device(v)
+        for fn in (h.allreduce_sum_f64, h.allreduce_min_f64, h.allreduce_max_f64):
+            fn(d_v, v.size)
+            assert np.array_equal(d_v.to_host(), v)
+        iv = rng.integers(-2 ** 40, 2 ** 40, size=1001)
+        d_i = h.to_device(iv)
+        h.allreduce_sum_i64(d_i, iv.size)
+        assert np.array_equal(d_i.to_host(), iv)
+        h.bcast(d_v, v.nbytes, 0)
+        assert np.array_equal(d_v.to_host(), v)
+        h.bcast_model(0)
+        for s, (Cm, cnt, csq) in zip((0, 1, 3), cents):
+            C2, cnt2, csq2 = h.get_centroids(s)
+            assert np.array_equal(Cm, C2) and np.array_equal(csq, csq2) and np.array_equal(cnt, cnt2)
+        assert h.num_centroids(2) == 0
+        assert np.array_equal(h.predict_host(X, p), before)
+        h.comm_destroy()
+    finally:
+        h.close()

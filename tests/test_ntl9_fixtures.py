@@ -4,6 +4,7 @@ strongly-connected-set size implied by fluxmatrix_raw.npy -> 192 kept clusters (
 import os
 
 import numpy as np
+import pytest
 
 from conftest import GOLDEN
 
@@ -27,8 +28,16 @@ def test_get_tmatrix(oracle_h):
     assert m.Tmatrix_csr.nnz == np.count_nonzero(ref)
 
 
-def test_get_steady_state_and_target_flux(oracle_h):
+@pytest.mark.parametrize("dense_eig_max, dense_lu_density", [(10 ** 9, 0.10), (0, 0.10), (0, 2.0), (10 ** 9, 2.0)],
+                         ids=["eig+lapack", "arpack+lapack", "arpack+superlu", "eig+superlu"])
+def test_get_steady_state_and_target_flux(oracle_h, monkeypatch, dense_eig_max, dense_lu_density):
+    """every solver combination the host solve can pick (dense eig = the reference's chain; ARPACK seed above
+    `dense_eig_max` states; LAPACK or SuperLU inverse iteration by matrix density) lands on the reference's numbers"""
+    from msm_we_amd import analysis
+
+    monkeypatch.setattr(analysis, "DENSE_LU_DENSITY", dense_lu_density)
     m = _model(oracle_h)
+    m.dense_eig_max = dense_eig_max
     m.get_Tmatrix()
     m.get_steady_state()
     ref = np.load(os.path.join(NTL9, "pSS.npy"))
