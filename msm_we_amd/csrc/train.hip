@@ -765,56 +765,136 @@ struct StepDev {
   const double *wf;      // nullable, indexed like X
   long long n_b;
   int32_t *labels;       // [n_b] scratch
-  double *Xg;            // [n_b][D] the batch rows, gathered once by the E-step for the M-step (L2-resident)
+  double *Xg;            // [n_b][D] the batch rows as f64, written by the E-step for the M-step: a small buffer that is
+                         // TLB- and cache-warm on every CU, unlike the call's span of the frame array
   int32_t *mcnt;         // [K] members appended by the E-step (reset by the M-step)
-  int32_t *mlist;        // [K][MCAP] member batch rows, unordered (the M-step sorts them)
+  unsigned long long *mlist;  // [K][MCAP] members, unordered: (batch row << 32 | frame); the M-step sorts them
   double *C, *counts, *csq, *Bpack;
   int K, flags;
   int32_t *report;       // [2]
 };
+// what the next call's E-step will gather: its lines are pulled towards this XCD's L2 while this call computes
+struct StepNext {
+  const void *X;
+  const int32_t *rows;
+  long long n_b;
+};
+// launch groups of at most PACK_NY strata travel in the kernel arguments: no dependent load of the descriptor
+#define PACK_NY 4
+struct StepPack {
+  StepDev s[PACK_NY];
+  StepNext nx[PACK_NY];
+  int n_next;
+};
 
 #define MCAP 64  // members per centroid kept in the unordered lists; larger clusters fall back to a label scan
+#define PF_MAX 3 // prefetch loads per lane (4 lanes per row): rows of up to 12 cache lines
+
+// STEP_PROFILE=1: entry/exit stamps only; =2: a stamp after every phase, each behind a full s_waitcnt (perturbs overlap)
+#ifdef STEP_PROFILE
+#define SPROF_WG 4096
+__device__ unsigned long long g_step_prof[2][SPROF_WG][8];
+#define SPROF_ID                                        \
+  const unsigned wg_ = blockIdx.y * gridDim.x + blockIdx.x; \
+  unsigned long long sp_[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#define SPROF(k, slot) sp_[slot] = wall_clock64();
+#define SPROF_FLUSH(k)                            \
+  if (threadIdx.x == 0 && wg_ < SPROF_WG)         \
+    for (int i_ = 0; i_ < 8; i_++) g_step_prof[k][wg_][i_] = sp_[i_];
+#if STEP_PROFILE >= 2
+#define SPROF_W(k, slot)             \
+  {                                  \
+    __builtin_amdgcn_s_waitcnt(0);   \
+    SPROF(k, slot)                   \
+  }
+#else
+#define SPROF_W(k, slot)
+#endif
+extern "C" int hamsm_debug_step_profile(unsigned long long *h_out) {
+  return hipMemcpyFromSymbol(h_out, HIP_SYMBOL(g_step_prof), sizeof(unsigned long long) * 2 * SPROF_WG * 8) == hipSuccess ? 0 : -1;
+}
+#else
+#define SPROF_ID
+#define SPROF(k, slot)
+#define SPROF_W(k, slot)
+#define SPROF_FLUSH(k)
+#endif
+
+__device__ __forceinline__ double readlane_f64(double v, int l) {
+  unsigned lo = __builtin_amdgcn_readlane((int)(__double_as_longlong(v) & 0xffffffffll), l);
+  unsigned hi = __builtin_amdgcn_readlane((int)(__double_as_longlong(v) >> 32), l);
+  return __longlong_as_double(((long long)hi << 32) | lo);
+}
+
+// Pointers that arrive inside a descriptor are generic to the compiler (flat_load/flat_atomic, which tie up both
+// memory counters); every one of them is device memory, so the kernels address them as such.
+#define GAS __attribute__((address_space(1)))
+template <typename T>
+__device__ __forceinline__ GAS T *gp(T *p) {
+  return (GAS T *)p;
+}
+struct StepG {  // a StepDev with its pointers in the global address space
+  const GAS char *X;
+  const GAS int32_t *rows;
+  const GAS double *wf;
+  long long n_b;
+  GAS int32_t *labels;
+  GAS double *Xg;
+  GAS int32_t *mcnt;
+  GAS unsigned long long *mlist;
+  GAS double *C, *counts, *csq, *Bpack;
+  int K, flags;
+  GAS int32_t *report;
+  __device__ __forceinline__ explicit StepG(const StepDev &d)
+      : X(gp((const char *)d.X)), rows(gp(d.rows)), wf(gp(d.wf)), n_b(d.n_b), labels(gp(d.labels)), Xg(gp(d.Xg)),
+        mcnt(gp(d.mcnt)), mlist(gp(d.mlist)), C(gp(d.C)), counts(gp(d.counts)), csq(gp(d.csq)), Bpack(gp(d.Bpack)), K(d.K),
+        flags(d.flags), report(gp(d.report)) {}
+};
+
+template <bool BYVAL>
+__device__ __forceinline__ StepDev load_step(const StepDev *steps, const StepPack &pk, unsigned i) {
+  if constexpr (BYVAL) return pk.s[i];  // scalar loads from the kernel-argument segment
+  static_assert(sizeof(StepDev) % 8 == 0, "StepDev is copied as 64-bit words");
+  union {
+    StepDev d;
+    unsigned long long w[sizeof(StepDev) / 8];
+  } u;
+  const GAS unsigned long long *src = (const GAS unsigned long long *)(steps + i);
+#pragma unroll
+  for (unsigned q = 0; q < sizeof(StepDev) / 8; q++) u.w[q] = src[q];
+  return u.d;
+}
 
 // E-step: one workgroup per 16-row tile; the stratum's centroid tiles are split over the 4 waves, each wave
-// issues ALL of its B-fragment loads before the first MFMA (one L2 round trip), then the 4 partial
-// first-minima are combined through LDS.
-template <typename XT, int KS, int JB>
-__global__ __launch_bounds__(256) void k_step_assign(const StepDev *__restrict__ steps, int64_t ldx, int D) {
-  const StepDev st = steps[blockIdx.y];
+// issues ALL of its operand loads before the first MFMA (one round trip), then the 4 partial first-minima are
+// combined through LDS.  Wave 3 also touches the lines the same tile of the NEXT call will gather.
+template <typename XT, int KS, int JB, bool BYVAL>
+__global__ __launch_bounds__(256) void k_step_assign(const StepDev *__restrict__ steps, const StepPack pk, int64_t ldx, int D) {
+  SPROF_ID
+  SPROF(0, 0)
+  const StepG st(load_step<BYVAL>(steps, pk, blockIdx.y));
   const long long r0 = (long long)blockIdx.x * 16;
   if (r0 >= st.n_b) return;
+  SPROF_W(0, 1)
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-  if (blockIdx.x == 0 && (st.flags & 2)) {
-    // `(self._counts == 0).any()` before the step (_kmeans.py:2037)
-    int z = 0;
-    for (int j = tid; j < st.K; j += 256) z |= (st.counts[j] == 0.0);
-    if (z) atomicOr(&st.report[0], 1);
-  }
-  const XT *X = (const XT *)st.X;
+  const GAS XT *X = (const GAS XT *)st.X;
   const long long r = r0 + (lane & 15);
   const bool ok = r < st.n_b;
+  // prefetch, part 1 (wave 3): the next call's row index, requested before anything else of this wave so that
+  // the in-order return of this wave's loads never waits for it alone
+  const bool pf_on = BYVAL && wv == 3 && (int)blockIdx.y < pk.n_next && r < pk.nx[blockIdx.y < PACK_NY ? blockIdx.y : 0].n_b;
+  long long fn = 0;
+  if (pf_on) {
+    const GAS int32_t *nrows = gp(pk.nx[blockIdx.y].rows);
+    fn = nrows ? (long long)nrows[r] : r;
+  }
   const long long f = ok ? (st.rows ? (long long)st.rows[r] : r) : 0;
-  double a[KS];
-#pragma unroll
-  for (int ks = 0; ks < KS; ks++) {
-    int k = ks * 4 + (lane >> 4);
-    a[ks] = (ok && k < D) ? (double)X[f * ldx + k] : 0.0;
-  }
-  if (wv == 0 && ok) {
-#pragma unroll
-    for (int ks = 0; ks < KS; ks++) {
-      int k = ks * 4 + (lane >> 4);
-      if (k < D) st.Xg[(size_t)r * D + k] = a[ks];
-    }
-  }
+  SPROF_W(0, 2)
+  // the first group of centroid operands does not depend on the row index: requested before the gather waits for it
   const int njt = (st.K + 15) >> 4;
   const double inf = __builtin_huge_val();
-  // centroids are the MFMA's A operand (rows), the 16 batch rows its B operand (columns): lane l accumulates, for
-  // batch row l&15, the centroids (l>>4) + 4q of each tile -- the first-minimum is register-local (DESIGN.md §5.1)
-  double bd = inf;
-  int bi = 0x7fffffff;
-  for (int t0 = wv; t0 < njt; t0 += 4 * JB) {
-    double b[JB][KS], cs[JB][4];
+  double b[JB][KS], cs[JB][4];
+  auto load_group = [&](int t0) {
 #pragma unroll
     for (int u = 0; u < JB; u++) {
       int jt = t0 + 4 * u;
@@ -824,6 +904,44 @@ __global__ __launch_bounds__(256) void k_step_assign(const StepDev *__restrict__
 #pragma unroll
       for (int ks = 0; ks < KS; ks++) b[u][ks] = live ? st.Bpack[((size_t)jt * KS + ks) * 64 + lane] : 0.0;
     }
+  };
+  load_group(wv);
+  double a[KS];
+#pragma unroll
+  for (int ks = 0; ks < KS; ks++) {
+    int k = ks * 4 + (lane >> 4);
+    a[ks] = (ok && k < D) ? (double)X[f * ldx + k] : 0.0;
+  }
+  SPROF_W(0, 3)
+  if (blockIdx.x == 0 && (st.flags & 2)) {
+    // `(self._counts == 0).any()` before the step (_kmeans.py:2037)
+    int z = 0;
+    for (int j = tid; j < st.K; j += 256) z |= (st.counts[j] == 0.0);
+    if (z) __hip_atomic_fetch_or(&st.report[0], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  // centroids are the MFMA's A operand (rows), the 16 batch rows its B operand (columns): lane l accumulates, for
+  // batch row l&15, the centroids (l>>4) + 4q of each tile -- the first-minimum is register-local (DESIGN.md §5.1)
+  double bd = inf;
+  int bi = 0x7fffffff;
+  XT pfv[PF_MAX];
+#pragma unroll
+  for (int i = 0; i < PF_MAX; i++) pfv[i] = (XT)0;
+  bool pf_todo = pf_on;
+  for (int t0 = wv; t0 < njt; t0 += 4 * JB) {
+    if (t0 != wv) load_group(t0);
+    if (pf_todo) {
+      // prefetch, part 2: one dword per 128-byte line of the next call's row, behind this wave's last operand loads
+      pf_todo = false;
+      const GAS XT *Xn = gp((const XT *)pk.nx[blockIdx.y].X) + fn * ldx;
+      const int per = 128 / (int)sizeof(XT);
+#pragma unroll
+      for (int i = 0; i < PF_MAX; i++) {
+        int k = ((lane >> 4) + 4 * i) * per;
+        k = k < D ? k : D - 1;  // the last element covers a row end that straddles into one more line
+        if ((lane >> 4) + 4 * i <= (D - 1) / per + 1) pfv[i] = Xn[k];
+      }
+    }
+    SPROF_W(0, 4)
 #pragma unroll
     for (int u = 0; u < JB; u++) {
       int jt = t0 + 4 * u;
@@ -842,6 +960,14 @@ __global__ __launch_bounds__(256) void k_step_assign(const StepDev *__restrict__
       }
     }
   }
+  if (wv == 1 && ok) {
+#pragma unroll
+    for (int ks = 0; ks < KS; ks++) {
+      int k = ks * 4 + (lane >> 4);
+      if (k < D) st.Xg[(size_t)r * D + k] = a[ks];
+    }
+  }
+  SPROF_W(0, 5)
   __shared__ double sd[4][16];
   __shared__ int sj[4][16];
   {
@@ -861,6 +987,7 @@ __global__ __launch_bounds__(256) void k_step_assign(const StepDev *__restrict__
     }
   }
   __syncthreads();
+  SPROF_W(0, 6)
   if (tid < 16 && r0 + tid < st.n_b) {
     double d = sd[0][tid];
     int j = sj[0][tid];
@@ -874,38 +1001,77 @@ __global__ __launch_bounds__(256) void k_step_assign(const StepDev *__restrict__
     }
     if (j == 0x7fffffff) j = 0;  // all-NaN row: label 0 like the oracle
     st.labels[r0 + tid] = j;
-    int pos = atomicAdd(&st.mcnt[j], 1);
-    if (pos < MCAP) st.mlist[(size_t)j * MCAP + pos] = (int)(r0 + tid);
+    int pos = __hip_atomic_fetch_add(&st.mcnt[j], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (pos < MCAP) st.mlist[(size_t)j * MCAP + pos] = ((unsigned long long)(r0 + tid) << 32) | (unsigned)f;
   }
+  if (pf_on) {
+#pragma unroll
+    for (int i = 0; i < PF_MAX; i++) asm volatile("" ::"v"(pfv[i]));  // the touched lines are only wanted in L2
+  }
+  SPROF_W(0, 7)
+#if defined(STEP_PROFILE) && STEP_PROFILE < 2
+  SPROF(0, 7)
+#endif
+  SPROF_FLUSH(0)
 }
 
-// M-step: one wave per centroid; the step's labels are scanned from LDS, member rows are fetched 8 at a
-// time and added in ascending sample order (_k_means_minibatch.pyx:59-108).
-#define UPD_LABEL_CAP 16384
+// M-step: one wave per centroid.  Round trip 1 fetches everything that does not depend on the member list (count,
+// list, centre); the list is sorted by batch row in registers; round trip 2 fetches up to UB member rows at once
+// (lane = feature); they are added in ascending sample order (_k_means_minibatch.pyx:59-108).  Clusters with more
+// than MCAP members scan the labels instead.
 #define UPD_LIST 1024
-template <typename XT>
-__global__ __launch_bounds__(256) void k_step_update(const StepDev *__restrict__ steps, int64_t ldx, int D, int KS) {
-  const StepDev st = steps[blockIdx.y];
+template <typename XT, int H, bool BYVAL>
+__global__ __launch_bounds__(256) void k_step_update(const StepDev *__restrict__ steps, const StepPack pk, int64_t ldx, int D,
+                                                     int KS) {
+  SPROF_ID
+  SPROF(1, 0)
+#ifndef UPD_UB
+#define UPD_UB 32
+#endif
+  constexpr int UB = UPD_UB / H;
+  const StepG st(load_step<BYVAL>(steps, pk, blockIdx.y));
   if (blockIdx.x * 4 >= st.K) return;
   extern __shared__ int lds_i[];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  int *list = lds_i + wv * UPD_LIST;  // [UPD_LIST] member batch rows of this wave, ascending
-  const int *lab = st.labels;         // (global) only scanned by clusters with more than MCAP members
+  int *list = lds_i + wv * UPD_LIST;  // [UPD_LIST] member batch rows of this wave, ascending (label-scan path only)
+  const GAS int *lab = st.labels;
   const int j = blockIdx.x * 4 + wv;
   if (j >= st.K) return;
   const long long n_b = st.n_b;
   const int mc = st.mcnt[j];
+  unsigned long long mine = st.mlist[(size_t)j * MCAP + lane];  // entries past mc are stale: masked below
+  const double cnt0 = st.counts[j];
+  double c0[H];
+#pragma unroll
+  for (int h = 0; h < H; h++) {
+    int k = lane + 64 * h;
+    c0[h] = (k < D) ? st.C[(size_t)j * D + k] : 0.0;
+  }
+  SPROF_W(1, 1)
   if (mc == 0) return;  // no member: wsum = 0, centre unchanged (pyx:105-108)
   if (lane == 0) st.mcnt[j] = 0;  // ready for the stratum's next step
   const bool listed = mc <= MCAP;
+  unsigned fm = 0, rm = 0;  // frame / batch row of this lane's member after sorting
+  double wl = 1.0;    // its weight
+  double wsum = 0.0;
   if (listed) {
-    // the E-step appended the members in arrival order: sort by batch row (rank = number of smaller rows)
-    int mine = lane < mc ? st.mlist[(size_t)j * MCAP + lane] : 0x7fffffff;
+    // the E-step appended the members in arrival order: rank = number of smaller keys (keys are distinct)
+    if (lane >= mc) mine = ~0ull;
+    const unsigned lo = (unsigned)mine, hi = (unsigned)(mine >> 32);
     int rank = 0;
-    for (int q = 0; q < mc; q++) rank += __shfl(mine, q, 64) < mine;
-    if (lane < mc) list[rank] = mine;
+    for (int q = 0; q < mc; q++) {
+      unsigned ql = __builtin_amdgcn_readlane((int)lo, q), qh = __builtin_amdgcn_readlane((int)hi, q);
+      rank += (((unsigned long long)qh << 32) | ql) < mine;
+    }
+    fm = (unsigned)__builtin_amdgcn_ds_permute(rank << 2, (int)lo);  // lane `rank` receives this member
+    rm = (unsigned)__builtin_amdgcn_ds_permute(rank << 2, (int)hi);
+    if (st.wf) {
+      if (lane < mc) wl = st.wf[fm];
+      for (int q = 0; q < mc; q++) wsum = wsum + readlane_f64(wl, q);  // sample order (pyx:80-85)
+    } else wsum = (double)mc;  // the sum of mc ones is exactly mc
   }
-  // labels are scanned 256 at a time (4 consecutive per lane); members are appended in ascending sample order
+  SPROF_W(1, 2)
+  // label scan, 256 at a time (4 consecutive per lane); members are appended in ascending sample order
   auto scan4 = [&](long long base, int &fill, bool store) -> int {
     int l4[4];
 #pragma unroll
@@ -931,16 +1097,8 @@ __global__ __launch_bounds__(256) void k_step_update(const StepDev *__restrict__
     fill += tot;
     return tot;
   };
-
-  // pass 1: wsum in sample order (pyx:80-85); unweighted: the sum of `cnt` ones is exactly cnt
-  double wsum = 0.0;
-  if (listed) {
-    if (!st.wf) wsum = (double)mc;
-    else {
-      double wv_ = st.wf[st.rows ? (long long)st.rows[list[lane < mc ? lane : 0]] : (long long)list[lane < mc ? lane : 0]];
-      for (int q = 0; q < mc; q++) wsum = wsum + __shfl(wv_, q, 64);
-    }
-  } else {
+  auto frame_of = [&](int ii) -> long long { return st.rows ? (long long)st.rows[ii] : (long long)ii; };
+  if (!listed) {
     int fill = 0;
     long long cnt = 0;
     for (long long base = 0; base < n_b; base += 256) {
@@ -950,9 +1108,9 @@ __global__ __launch_bounds__(256) void k_step_update(const StepDev *__restrict__
         for (int m0 = 0; m0 < fill; m0 += 64) {
           int ii = (m0 + lane < fill) ? list[m0 + lane] : -1;
           double wv_ = 0.0;
-          if (ii >= 0) wv_ = st.wf[st.rows ? (long long)st.rows[ii] : (long long)ii];
+          if (ii >= 0) wv_ = st.wf[frame_of(ii)];
           int lim = fill - m0 < 64 ? fill - m0 : 64;
-          for (int q = 0; q < lim; q++) wsum = wsum + __shfl(wv_, q, 64);
+          for (int q = 0; q < lim; q++) wsum = wsum + readlane_f64(wv_, q);
         }
         fill = 0;
       }
@@ -962,37 +1120,58 @@ __global__ __launch_bounds__(256) void k_step_update(const StepDev *__restrict__
   }
   if (!(wsum > 0)) return;  // pyx:87 / :105-108: centre unchanged
 
-  // pass 2: c = c*count; c += x*w in sample order; count += wsum; c *= 1/count  (pyx:89-104)
-  const double cnt0 = st.counts[j];
-  double acc[2];
+  // c = c*count; c += x*w in sample order; count += wsum; c *= 1/count  (pyx:89-104)
+  double acc[H];
 #pragma unroll
-  for (int h = 0; h < 2; h++) {
-    int k = lane + 64 * h;
-    acc[h] = (k < D) ? st.C[(size_t)j * D + k] * cnt0 : 0.0;
-  }
-  auto add_members = [&](int fill) {
-    for (int m0 = 0; m0 < fill; m0 += 8) {
-      double xv[8][2], wq[8];
+  for (int h = 0; h < H; h++) acc[h] = c0[h] * cnt0;
+  SPROF_W(1, 3)
+  if (listed) {
+    for (int m0 = 0; m0 < mc; m0 += UB) {
+      // branch-free: past the end the last member is fetched again (same lines) and its add is deselected
+      double xv[UB][H];
 #pragma unroll
-      for (int q = 0; q < 8; q++) {
-        int ii = (m0 + q < fill) ? list[m0 + q] : -1;
-        wq[q] = (ii >= 0) ? (st.wf ? st.wf[st.rows ? (long long)st.rows[ii] : (long long)ii] : 1.0) : 0.0;
+      for (int q = 0; q < UB; q++) {
+        const int mq = m0 + q < mc ? m0 + q : mc - 1;
+        const size_t rq = (size_t)(unsigned)__builtin_amdgcn_readlane((int)rm, mq);
 #pragma unroll
-        for (int h = 0; h < 2; h++) {
+        for (int h = 0; h < H; h++) {
           int k = lane + 64 * h;
-          xv[q][h] = (ii >= 0 && k < D) ? st.Xg[(size_t)ii * D + k] : 0.0;
+          xv[q][h] = (k < D) ? st.Xg[rq * D + k] : 0.0;
         }
       }
 #pragma unroll
-      for (int q = 0; q < 8; q++)
-        if (m0 + q < fill) {
+      for (int q = 0; q < UB; q++) {
+        const int mq = m0 + q < mc ? m0 + q : mc - 1;
+        const double wq = st.wf ? readlane_f64(wl, mq) : 1.0;
 #pragma unroll
-          for (int h = 0; h < 2; h++) acc[h] = acc[h] + xv[q][h] * wq[q];
+        for (int h = 0; h < H; h++) {
+          double nv = acc[h] + xv[q][h] * wq;
+          acc[h] = (m0 + q < mc) ? nv : acc[h];
         }
+      }
     }
-  };
-  if (listed) add_members(mc);
-  else {
+  } else {
+    auto add_members = [&](int fill) {
+      for (int m0 = 0; m0 < fill; m0 += 8) {
+        double xv[8][H], wq[8];
+#pragma unroll
+        for (int q = 0; q < 8; q++) {
+          int ii = (m0 + q < fill) ? list[m0 + q] : -1;
+          wq[q] = (ii >= 0) ? (st.wf ? st.wf[frame_of(ii)] : 1.0) : 0.0;
+#pragma unroll
+          for (int h = 0; h < H; h++) {
+            int k = lane + 64 * h;
+            xv[q][h] = (ii >= 0 && k < D) ? st.Xg[(size_t)ii * D + k] : 0.0;
+          }
+        }
+#pragma unroll
+        for (int q = 0; q < 8; q++)
+          if (m0 + q < fill) {
+#pragma unroll
+            for (int h = 0; h < H; h++) acc[h] = acc[h] + xv[q][h] * wq[q];
+          }
+      }
+    };
     int fill = 0;
     for (long long base = 0; base < n_b; base += 256) {
       scan4(base, fill, true);
@@ -1002,11 +1181,12 @@ __global__ __launch_bounds__(256) void k_step_update(const StepDev *__restrict__
       }
     }
   }
+  SPROF_W(1, 4)
   const double cnt1 = cnt0 + wsum;
   const double alpha = 1.0 / cnt1;
-  double v[2];
+  double v[H];
 #pragma unroll
-  for (int h = 0; h < 2; h++) {
+  for (int h = 0; h < H; h++) {
     int k = lane + 64 * h;
     v[h] = acc[h] * alpha;
     if (k < D) {
@@ -1018,15 +1198,21 @@ __global__ __launch_bounds__(256) void k_step_update(const StepDev *__restrict__
   // ||c||^2 as an fma chain over ascending k (oracle sqnorm_chain): lane values broadcast in order
   double a = 0.0;
   for (int k = 0; k < D; k++) {
-    double vk = __shfl(k < 64 ? v[0] : v[1], k & 63, 64);
+    double vk = readlane_f64(v[k < 64 ? 0 : H - 1], k & 63);
     a = __builtin_fma(vk, vk, a);
   }
   if (lane == 0) st.csq[j] = a;
+  SPROF_W(1, 5)
+#if defined(STEP_PROFILE) && STEP_PROFILE < 2
+  SPROF(1, 5)
+#endif
+  SPROF_FLUSH(1)
 }
 
 // after the update: number of centroids with count < ratio * max(count)  (_kmeans.py:1645)
-__global__ __launch_bounds__(256) void k_step_check(const StepDev *__restrict__ steps, double ratio) {
-  const StepDev st = steps[blockIdx.x];
+template <bool BYVAL>
+__global__ __launch_bounds__(256) void k_step_check(const StepDev *__restrict__ steps, const StepPack pk, double ratio) {
+  const StepG st(load_step<BYVAL>(steps, pk, blockIdx.x));
   if (!(st.flags & 1)) return;
   __shared__ double smax[256];
   __shared__ int slow[256];
@@ -1050,25 +1236,29 @@ __global__ __launch_bounds__(256) void k_step_check(const StepDev *__restrict__ 
   if (threadIdx.x == 0) st.report[1] = slow[0];
 }
 
-template <typename XT, int KS>
-static void launch_step_kernels(hamsm_ctx *c, const StepDev *d_steps, int ny, long long max_nb, int maxK, int any_check,
-                                int64_t ldx, double ratio) {
+template <typename XT, int KS, bool BYVAL>
+static void launch_step_kernels(hamsm_ctx *c, const StepDev *d_steps, const StepPack &pk, int ny, long long max_nb, int maxK,
+                                int any_check, int64_t ldx, double ratio) {
   constexpr int JB = KS <= 4 ? 8 : (KS <= 8 ? 4 : (KS <= 16 ? 2 : 1));
   dim3 ga((unsigned)((max_nb + 15) / 16), (unsigned)ny);
-  hipLaunchKernelGGL((k_step_assign<XT, KS, JB>), ga, dim3(256), 0, c->stream, d_steps, ldx, c->D);
+  hipLaunchKernelGGL((k_step_assign<XT, KS, JB, BYVAL>), ga, dim3(256), 0, c->stream, d_steps, pk, ldx, c->D);
   size_t lds = sizeof(int) * (4 * UPD_LIST);
   dim3 gu((unsigned)((maxK + 3) / 4), (unsigned)ny);
-  hipLaunchKernelGGL(k_step_update<XT>, gu, dim3(256), lds, c->stream, d_steps, ldx, c->D, c->KS);
-  if (any_check) hipLaunchKernelGGL(k_step_check, dim3((unsigned)ny), dim3(256), 0, c->stream, d_steps, ratio);
+  if (c->D <= 64)
+    hipLaunchKernelGGL((k_step_update<XT, 1, BYVAL>), gu, dim3(256), lds, c->stream, d_steps, pk, ldx, c->D, c->KS);
+  else
+    hipLaunchKernelGGL((k_step_update<XT, 2, BYVAL>), gu, dim3(256), lds, c->stream, d_steps, pk, ldx, c->D, c->KS);
+  if (any_check) hipLaunchKernelGGL(k_step_check<BYVAL>, dim3((unsigned)ny), dim3(256), 0, c->stream, d_steps, pk, ratio);
 }
 
 template <typename XT>
-static int launch_steps(hamsm_ctx *c, const StepDev *d_steps, int ny, long long max_nb, int maxK, int any_check, int64_t ldx,
-                        double ratio) {
+static int launch_steps(hamsm_ctx *c, const StepDev *d_steps, const StepPack &pk, int ny, long long max_nb, int maxK,
+                        int any_check, int64_t ldx, double ratio) {
   switch (c->KS) {
-#define CASE(KSV)                                                                      \
-  case KSV:                                                                            \
-    launch_step_kernels<XT, KSV>(c, d_steps, ny, max_nb, maxK, any_check, ldx, ratio); \
+#define CASE(KSV)                                                                                       \
+  case KSV:                                                                                             \
+    if (d_steps) launch_step_kernels<XT, KSV, false>(c, d_steps, pk, ny, max_nb, maxK, any_check, ldx, ratio); \
+    else launch_step_kernels<XT, KSV, true>(c, d_steps, pk, ny, max_nb, maxK, any_check, ldx, ratio);   \
     break;
     CASE(1) CASE(2) CASE(3) CASE(4) CASE(6) CASE(8) CASE(12) CASE(16) CASE(24) CASE(32)
 #undef CASE
@@ -1082,10 +1272,11 @@ static int run_steps(hamsm_ctx *c, const void *X, int dt, int64_t ldx, const int
                      const hamsm_step *h_steps, int64_t n_steps, double ratio, int32_t *h_report, int want_zero_flag,
                      int32_t **labels_of_first) {
   const size_t esz = dt == HAMSM_F32 ? 4 : 8;
+  if (c->D > 128) return hamsm_fail(c, HAMSM_ENOTSUP, "training supports at most 128 features (D=%d)", c->D);
   int64_t lab_hi = 0, nb_max = 0;
   for (int64_t i = 0; i < n_steps; i++) {
-    if (h_steps[i].n_b > nb_max) nb_max = h_steps[i].n_b;
     const hamsm_step &s = h_steps[i];
+    if (s.n_b > nb_max) nb_max = s.n_b;
     if (s.stratum < 0 || s.stratum >= c->S) return hamsm_fail(c, HAMSM_EINVAL, "bad stratum in step %lld", (long long)i);
     if (c->st[s.stratum].K == 0) return hamsm_fail(c, HAMSM_EUNFIT, "stratum %d has no centroids", s.stratum);
     if (s.n_b < 0 || s.rows_off < 0) return hamsm_fail(c, HAMSM_EINVAL, "bad step %lld", (long long)i);
@@ -1100,12 +1291,14 @@ static int run_steps(hamsm_ctx *c, const void *X, int dt, int64_t ldx, const int
   };
   size_t o_steps = take(sizeof(StepDev) * n_steps), o_rep = take(sizeof(int32_t) * 2 * n_steps),
          o_lab = take(sizeof(int32_t) * (size_t)lab_hi);
-  // the gathered batch copy is reused by every launch group: one slot per stratum position, stream-ordered
+  // the gathered batch copy and the member lists are reused by every launch group: one slot per stratum position,
+  // stream-ordered
   const int nslot = c->S < 65535 ? c->S : 65535;
   size_t o_xg = take(sizeof(double) * (size_t)nslot * nb_max * c->D);
   int Kmax = 0;
   for (int s = 0; s < c->S; s++) Kmax = c->st[s].K > Kmax ? c->st[s].K : Kmax;
-  size_t o_mc = take(sizeof(int32_t) * (size_t)nslot * Kmax), o_ml = take(sizeof(int32_t) * (size_t)nslot * Kmax * MCAP);
+  size_t o_mc = take(sizeof(int32_t) * (size_t)nslot * Kmax),
+         o_ml = take(sizeof(unsigned long long) * (size_t)nslot * Kmax * MCAP);
   int rc = hamsm_ensure_scratch(c, off);
   if (rc) return rc;
   char *b = (char *)c->scratch;
@@ -1119,7 +1312,6 @@ static int run_steps(hamsm_ctx *c, const void *X, int dt, int64_t ldx, const int
     d.wf = d_w ? d_w + s.x_off : nullptr;
     d.n_b = s.n_b;
     d.labels = (int32_t *)(b + o_lab) + (d_rows ? s.rows_off : 0);
-    d.Xg = nullptr;  // slot assigned per launch group below
     d.C = t.C;
     d.counts = t.counts;
     d.csq = t.csq;
@@ -1128,22 +1320,25 @@ static int run_steps(hamsm_ctx *c, const void *X, int dt, int64_t ldx, const int
     d.flags = (s.flags & 1) | (want_zero_flag ? 2 : 0);
     d.report = (int32_t *)(b + o_rep) + 2 * i;
   }
+  // launch groups = maximal runs of distinct strata; member-list slot = position inside the run
+  std::vector<int64_t> gstart;
   {
-    // launch groups = maximal runs of distinct strata; slot = position inside the run
-    std::vector<char> used0(c->S);
+    std::vector<char> used(c->S);
     int64_t i0 = 0;
     while (i0 < n_steps) {
-      std::fill(used0.begin(), used0.end(), 0);
+      std::fill(used.begin(), used.end(), 0);
       int64_t j0 = i0;
-      while (j0 < n_steps && !used0[h_steps[j0].stratum] && j0 - i0 < 65535) {
-        used0[h_steps[j0].stratum] = 1;
+      while (j0 < n_steps && !used[h_steps[j0].stratum] && j0 - i0 < 65535) {
+        used[h_steps[j0].stratum] = 1;
         sd[j0].Xg = (double *)(b + o_xg) + (size_t)(j0 - i0) * nb_max * c->D;
         sd[j0].mcnt = (int32_t *)(b + o_mc) + (size_t)(j0 - i0) * Kmax;
-        sd[j0].mlist = (int32_t *)(b + o_ml) + (size_t)(j0 - i0) * Kmax * MCAP;
+        sd[j0].mlist = (unsigned long long *)(b + o_ml) + (size_t)(j0 - i0) * Kmax * MCAP;
         j0++;
       }
+      gstart.push_back(i0);
       i0 = j0;
     }
+    gstart.push_back(n_steps);
   }
   if (labels_of_first) *labels_of_first = sd[0].labels;
   HIPCHK(c, hipMemcpyAsync(b + o_steps, sd.data(), sizeof(StepDev) * n_steps, hipMemcpyHostToDevice, c->stream));
@@ -1151,26 +1346,34 @@ static int run_steps(hamsm_ctx *c, const void *X, int dt, int64_t ldx, const int
   HIPCHK(c, hipMemsetAsync(b + o_mc, 0, sizeof(int32_t) * (size_t)nslot * Kmax, c->stream));
   const StepDev *d_steps = (const StepDev *)(b + o_steps);
   hamsm_timer_begin(c);
-  std::vector<char> used(c->S);
-  int64_t i = 0;
-  while (i < n_steps) {
-    std::fill(used.begin(), used.end(), 0);
-    int64_t j = i;
+  StepPack pk;
+  memset(&pk, 0, sizeof(pk));
+  for (size_t g = 0; g + 1 < gstart.size(); g++) {
+    const int64_t i = gstart[g], j = gstart[g + 1];
     long long max_nb = 0;
     int maxK = 0, any_check = 0;
-    while (j < n_steps && !used[h_steps[j].stratum] && j - i < 65535) {
-      used[h_steps[j].stratum] = 1;
-      if (h_steps[j].n_b > max_nb) max_nb = h_steps[j].n_b;
-      if (c->st[h_steps[j].stratum].K > maxK) maxK = c->st[h_steps[j].stratum].K;
-      any_check |= h_steps[j].flags & 1;
-      j++;
+    for (int64_t q = i; q < j; q++) {
+      if (h_steps[q].n_b > max_nb) max_nb = h_steps[q].n_b;
+      if (c->st[h_steps[q].stratum].K > maxK) maxK = c->st[h_steps[q].stratum].K;
+      any_check |= h_steps[q].flags & 1;
     }
-    if (max_nb > 0) {
-      rc = (dt == HAMSM_F32) ? launch_steps<float>(c, d_steps + i, (int)(j - i), max_nb, maxK, any_check, ldx, ratio)
-                             : launch_steps<double>(c, d_steps + i, (int)(j - i), max_nb, maxK, any_check, ldx, ratio);
-      if (rc) return rc;
+    if (max_nb <= 0) continue;
+    const int ny = (int)(j - i);
+    const StepDev *dptr = d_steps + i;
+    if (ny <= PACK_NY) {
+      dptr = nullptr;  // descriptors by value
+      for (int q = 0; q < ny; q++) pk.s[q] = sd[i + q];
+      pk.n_next = 0;
+      if (g + 2 < gstart.size()) {
+        const int64_t jn = gstart[g + 2];
+        const int nn = (int)(jn - j) < ny ? (int)(jn - j) : ny;
+        for (int q = 0; q < nn; q++) pk.nx[q] = StepNext{sd[j + q].X, sd[j + q].rows, sd[j + q].n_b};
+        pk.n_next = nn;
+      }
     }
-    i = j;
+    rc = (dt == HAMSM_F32) ? launch_steps<float>(c, dptr, pk, ny, max_nb, maxK, any_check, ldx, ratio)
+                           : launch_steps<double>(c, dptr, pk, ny, max_nb, maxK, any_check, ldx, ratio);
+    if (rc) return rc;
   }
   hamsm_timer_end(c, ST_STEP);
   HIPCHK(c, hipGetLastError());
