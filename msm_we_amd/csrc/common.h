@@ -10,6 +10,8 @@
 #include <stdio.h>
 #include <string.h>
 
+#include <map>
+#include <unordered_map>
 #include <vector>
 
 #include "../../include/hamsm.h"
@@ -54,6 +56,11 @@ struct hamsm_ctx {
   char err[512];
   int device = 0;
   hipStream_t stream = nullptr;
+  // hamsm_malloc / hamsm_free keep released blocks for reuse (hipMalloc costs ~1 ms per 40 MB block and hipFree
+  // synchronises the device; every use of a block is ordered on `stream`, so reuse needs no synchronisation)
+  std::unordered_map<void *, size_t> blk_live;
+  std::multimap<size_t, void *> blk_cache;
+  size_t blk_cached_bytes = 0;
   int D = 0, KS = 0 /* ceil(D/4) */, ndim = 0, S = 0;
   bool have_mapper = false, have_bounds = false;
   MapperDev mapper;  // host copy with device pointers inside

@@ -51,12 +51,14 @@ static void free_strata(hamsm_ctx *c) {
 }
 
 extern "C" int hamsm_comm_destroy(hamsm_ctx *c);
+static void blk_cache_flush(hamsm_ctx *c);
 
 extern "C" void hamsm_destroy(hamsm_ctx *c) {
   if (!c) return;
   hipSetDevice(c->device);
   hipStreamSynchronize(c->stream);
   hamsm_comm_destroy(c);
+  blk_cache_flush(c);
   free_strata(c);
   hipFree(c->d_bounds);
   hipFree(c->d_err);
@@ -76,13 +78,47 @@ extern "C" void hamsm_destroy(hamsm_ctx *c) {
 extern "C" const char *hamsm_last_error(hamsm_ctx *c) { return c ? c->err : "null ctx"; }
 
 // ---- memory -------------------------------------------------------------------------------------
+static const size_t BLK_CACHE_MAX = (size_t)8 << 30;  // bytes kept for reuse (of 288 GB)
+
+static void blk_cache_flush(hamsm_ctx *c) {
+  if (c->blk_cache.empty()) return;
+  hipStreamSynchronize(c->stream);
+  for (auto &kv : c->blk_cache) hipFree(kv.second);
+  c->blk_cache.clear();
+  c->blk_cached_bytes = 0;
+}
+
 extern "C" int hamsm_malloc(hamsm_ctx *c, size_t bytes, void **out) {
   HIPCHK(c, hipSetDevice(c->device));
-  hipError_t e = hipMalloc(out, bytes ? bytes : 1);
+  const size_t want = ((bytes ? bytes : 1) + 255) & ~(size_t)255;
+  auto it = c->blk_cache.lower_bound(want);
+  if (it != c->blk_cache.end() && it->first <= want + want / 2 + (1 << 20)) {  // close enough in size: reuse
+    *out = it->second;
+    c->blk_live[it->second] = it->first;
+    c->blk_cached_bytes -= it->first;
+    c->blk_cache.erase(it);
+    return HAMSM_OK;
+  }
+  hipError_t e = hipMalloc(out, want);
+  if (e != hipSuccess) {
+    blk_cache_flush(c);
+    e = hipMalloc(out, want);
+  }
   if (e != hipSuccess) return hamsm_fail(c, HAMSM_ENOMEM, "hipMalloc(%zu): %s", bytes, hipGetErrorString(e));
+  c->blk_live[*out] = want;
   return HAMSM_OK;
 }
 extern "C" int hamsm_free(hamsm_ctx *c, void *p) {
+  if (!p) return HAMSM_OK;
+  auto it = c->blk_live.find(p);
+  if (it == c->blk_live.end()) return hamsm_fail(c, HAMSM_EINVAL, "hamsm_free: %p was not returned by hamsm_malloc", p);
+  const size_t sz = it->second;
+  c->blk_live.erase(it);
+  if (sz <= BLK_CACHE_MAX / 4 && c->blk_cached_bytes + sz <= BLK_CACHE_MAX) {
+    c->blk_cache.emplace(sz, p);
+    c->blk_cached_bytes += sz;
+    return HAMSM_OK;
+  }
   HIPCHK(c, hipStreamSynchronize(c->stream));
   HIPCHK(c, hipFree(p));
   return HAMSM_OK;

@@ -34,6 +34,7 @@ for level in (1, 2):
         print(f"{name}: {live.sum()} workgroups reached the end; starts {start.min():.2f}..{start.max():.2f} us "
               f"(median {np.median(start):.2f}); ends {end.min():.2f}..{end.max():.2f} (median {np.median(end):.2f}); "
               f"in-WG duration median {np.median(end - start):.2f} max {(end - start).max():.2f}")
+        np.save(os.path.join(ROOT, "gpurun_out", f"stepprof_l{level}_k{k}.npy"), prof[k])
         if level == 2:
             d = np.diff(p[:, :nslot], axis=1) * 0.01
             print("   phase medians (us):", np.round(np.median(d, axis=0), 2), " p95:", np.round(np.percentile(d, 95, axis=0), 2))

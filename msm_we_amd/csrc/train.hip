@@ -765,13 +765,16 @@ struct StepDev {
   const double *wf;      // nullable, indexed like X
   long long n_b;
   int32_t *labels;       // [n_b] scratch
-  double *Xg;            // [n_b][D] the batch rows as f64, written by the E-step for the M-step: a small buffer that is
+  double *Xg;            // [n_b][D] the batch rows as f64, written by the E-step for the M-step (measured: an f32 copy,
+                         // packed or one row per 128-byte line, makes the M-step's fetch 3x slower): a small buffer that is
                          // TLB- and cache-warm on every CU, unlike the call's span of the frame array
   int32_t *mcnt;         // [K] members appended by the E-step (reset by the M-step)
   unsigned long long *mlist;  // [K][MCAP] members, unordered: (batch row << 32 | frame); the M-step sorts them
   double *C, *counts, *csq, *Bpack;
-  int K, flags;
+  int K, flags;          // flags: 1 = low-count test wanted after this step, 2 = zero-count test before it,
+                         //        4 = this step's E-step evaluates the low-count test of the stratum's previous step
   int32_t *report;       // [2]
+  int32_t *prev_report;  // report of the stratum's previous step (flags & 4)
 };
 // what the next call's E-step will gather: its lines are pulled towards this XCD's L2 while this call computes
 struct StepNext {
@@ -865,30 +868,44 @@ __device__ __forceinline__ StepDev load_step(const StepDev *steps, const StepPac
   return u.d;
 }
 
-// E-step: one workgroup per 16-row tile; the stratum's centroid tiles are split over the 4 waves, each wave
-// issues ALL of its operand loads before the first MFMA (one round trip), then the 4 partial first-minima are
-// combined through LDS.  Wave 3 also touches the lines the same tile of the NEXT call will gather.
-template <typename XT, int KS, int JB, bool BYVAL>
-__global__ __launch_bounds__(256) void k_step_assign(const StepDev *__restrict__ steps, const StepPack pk, int64_t ldx, int D) {
+// E-step: one workgroup per RT 16-row tiles.  The stratum's centroid tiles are split over the 4 waves and stay in
+// registers while the wave sweeps the workgroup's row tiles, so a workgroup pulls the centroid operands through L2
+// once per 16*RT rows (with RT = 1 a call of 10^4 rows moved 40 MB of operands and the kernel was L2-bound).  All
+// operand loads of a wave are issued before its first MFMA; the 4 partial first-minima are combined through LDS.
+// Wave 3 also touches the lines the same rows of the NEXT call will gather; workgroup 0 of each stratum evaluates
+// the low-count test of the stratum's previous step (the counts are final since that step's M-step).
+template <typename XT, int KS, int JB, int RT, bool BYVAL>
+__global__ __launch_bounds__(256) void k_step_assign(const StepDev *__restrict__ steps, const StepPack pk, int64_t ldx, int D,
+                                                     double ratio) {
   SPROF_ID
   SPROF(0, 0)
-  const StepG st(load_step<BYVAL>(steps, pk, blockIdx.y));
-  const long long r0 = (long long)blockIdx.x * 16;
+  constexpr int RW = 16 * RT;  // rows per workgroup
+  const StepDev sdesc = load_step<BYVAL>(steps, pk, blockIdx.y);
+  const StepG st(sdesc);
+  const long long r0 = (long long)blockIdx.x * RW;
   if (r0 >= st.n_b) return;
   SPROF_W(0, 1)
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const GAS XT *X = (const GAS XT *)st.X;
-  const long long r = r0 + (lane & 15);
-  const bool ok = r < st.n_b;
   // prefetch, part 1 (wave 3): the next call's row index, requested before anything else of this wave so that
   // the in-order return of this wave's loads never waits for it alone
-  const bool pf_on = BYVAL && wv == 3 && (int)blockIdx.y < pk.n_next && r < pk.nx[blockIdx.y < PACK_NY ? blockIdx.y : 0].n_b;
+  const int prow = lane % RW, pslot = lane / RW;
+  constexpr int PSTRIDE = 64 / RW;
+  const int ynx = blockIdx.y < PACK_NY ? blockIdx.y : 0;
+  const bool pf_on = BYVAL && wv == 3 && (int)blockIdx.y < pk.n_next && r0 + prow < pk.nx[ynx].n_b;
   long long fn = 0;
   if (pf_on) {
-    const GAS int32_t *nrows = gp(pk.nx[blockIdx.y].rows);
-    fn = nrows ? (long long)nrows[r] : r;
+    const GAS int32_t *nrows = gp(pk.nx[ynx].rows);
+    fn = nrows ? (long long)nrows[r0 + prow] : r0 + prow;
   }
-  const long long f = ok ? (st.rows ? (long long)st.rows[r] : r) : 0;
+  long long f[RT];
+  bool ok[RT];
+#pragma unroll
+  for (int rt = 0; rt < RT; rt++) {
+    const long long r = r0 + rt * 16 + (lane & 15);
+    ok[rt] = r < st.n_b;
+    f[rt] = ok[rt] ? (st.rows ? (long long)st.rows[r] : r) : 0;
+  }
   SPROF_W(0, 2)
   // the first group of centroid operands does not depend on the row index: requested before the gather waits for it
   const int njt = (st.K + 15) >> 4;
@@ -905,24 +922,70 @@ __global__ __launch_bounds__(256) void k_step_assign(const StepDev *__restrict__
       for (int ks = 0; ks < KS; ks++) b[u][ks] = live ? st.Bpack[((size_t)jt * KS + ks) * 64 + lane] : 0.0;
     }
   };
-  load_group(wv);
-  double a[KS];
-#pragma unroll
-  for (int ks = 0; ks < KS; ks++) {
-    int k = ks * 4 + (lane >> 4);
-    a[ks] = (ok && k < D) ? (double)X[f * ldx + k] : 0.0;
+#ifdef STEP_TOUCH
+  // cooperative warm-up: the stratum's operand lines were rewritten by the previous M-step (on other XCDs) and every
+  // workgroup walks them in the same order, so the misses serialise; here each wave of an XCD first touches its own
+  // share of the lines (one load instruction, one line per lane)
+  double tv = 0.0;
+  {
+    const int nl_b = njt * KS * 4, nl_c = (st.K + 15) >> 4;  // 128-byte lines of Bpack and csq
+    const int wpx = (((int)gridDim.x + 7) / 8) * 4;            // waves of this stratum on one XCD (round-robin dispatch)
+    const int line = ((int)blockIdx.x / 8) * 4 + wv + lane * wpx;
+    if (line < nl_b) tv = st.Bpack[(size_t)line * 16];
+    else if (line < nl_b + nl_c) tv = st.csq[(line - nl_b) * 16];
   }
+#endif
+  load_group(wv);
+  double a[RT][KS];
+#pragma unroll
+  for (int rt = 0; rt < RT; rt++)
+#pragma unroll
+    for (int ks = 0; ks < KS; ks++) {
+      int k = ks * 4 + (lane >> 4);
+      a[rt][ks] = (ok[rt] && k < D) ? (double)X[f[rt] * ldx + k] : 0.0;
+    }
   SPROF_W(0, 3)
-  if (blockIdx.x == 0 && (st.flags & 2)) {
-    // `(self._counts == 0).any()` before the step (_kmeans.py:2037)
+  __shared__ double sd[4][RW];
+  __shared__ int sj[4][RW];
+  if (blockIdx.x == 0 && (st.flags & 6)) {
+    // one pass over the counts: `(self._counts == 0).any()` before this step (_kmeans.py:2037), and for the
+    // previous step of the stratum `counts < ratio * max(counts)` (:1645)
+    const GAS int32_t *prev = gp(sdesc.prev_report);
     int z = 0;
-    for (int j = tid; j < st.K; j += 256) z |= (st.counts[j] == 0.0);
-    if (z) __hip_atomic_fetch_or(&st.report[0], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    double mx = -inf;
+    for (int j = tid; j < st.K; j += 256) {
+      double cj = st.counts[j];
+      z |= (cj == 0.0);
+      mx = cj > mx ? cj : mx;
+    }
+    if ((st.flags & 2) && z) __hip_atomic_fetch_or(&st.report[0], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (st.flags & 4) {
+#pragma unroll
+      for (int off = 32; off >= 1; off >>= 1) {
+        double o = __shfl_xor(mx, off, 64);
+        mx = o > mx ? o : mx;
+      }
+      if (lane == 0) sd[0][wv] = mx;
+      __syncthreads();
+      mx = sd[0][0];
+#pragma unroll
+      for (int w = 1; w < 4; w++) mx = sd[0][w] > mx ? sd[0][w] : mx;
+      const double thr = ratio * mx;
+      int low = 0;
+      for (int j = tid; j < st.K; j += 256) low += st.counts[j] < thr;
+      if (low) __hip_atomic_fetch_add((GAS int32_t *)prev + 1, low, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __syncthreads();  // sd is reused below
+    }
   }
   // centroids are the MFMA's A operand (rows), the 16 batch rows its B operand (columns): lane l accumulates, for
   // batch row l&15, the centroids (l>>4) + 4q of each tile -- the first-minimum is register-local
-  double bd = inf;
-  int bi = 0x7fffffff;
+  double bd[RT];
+  int bi[RT];
+#pragma unroll
+  for (int rt = 0; rt < RT; rt++) {
+    bd[rt] = inf;
+    bi[rt] = 0x7fffffff;
+  }
   XT pfv[PF_MAX];
 #pragma unroll
   for (int i = 0; i < PF_MAX; i++) pfv[i] = (XT)0;
@@ -932,13 +995,14 @@ __global__ __launch_bounds__(256) void k_step_assign(const StepDev *__restrict__
     if (pf_todo) {
       // prefetch, part 2: one dword per 128-byte line of the next call's row, behind this wave's last operand loads
       pf_todo = false;
-      const GAS XT *Xn = gp((const XT *)pk.nx[blockIdx.y].X) + fn * ldx;
+      const GAS XT *Xn = gp((const XT *)pk.nx[ynx].X) + fn * ldx;
       const int per = 128 / (int)sizeof(XT);
 #pragma unroll
       for (int i = 0; i < PF_MAX; i++) {
-        int k = ((lane >> 4) + 4 * i) * per;
+        const int slot = pslot + PSTRIDE * i;
+        int k = slot * per;
         k = k < D ? k : D - 1;  // the last element covers a row end that straddles into one more line
-        if ((lane >> 4) + 4 * i <= (D - 1) / per + 1) pfv[i] = Xn[k];
+        if (slot <= (D - 1) / per + 1) pfv[i] = Xn[k];
       }
     }
     SPROF_W(0, 4)
@@ -946,33 +1010,42 @@ __global__ __launch_bounds__(256) void k_step_assign(const StepDev *__restrict__
     for (int u = 0; u < JB; u++) {
       int jt = t0 + 4 * u;
       if (jt < njt) {
-        v4f64 acc = {0.0, 0.0, 0.0, 0.0};
+        v4f64 acc[RT];
 #pragma unroll
-        for (int ks = 0; ks < KS; ks++) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(b[u][ks], a[ks], acc, 0, 0, 0);
+        for (int rt = 0; rt < RT; rt++) acc[rt] = (v4f64){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int ks = 0; ks < KS; ks++)
+#pragma unroll
+          for (int rt = 0; rt < RT; rt++) acc[rt] = __builtin_amdgcn_mfma_f64_16x16x4f64(b[u][ks], a[rt][ks], acc[rt], 0, 0, 0);
         const int j0 = jt * 16 + (lane >> 4);
 #pragma unroll
-        for (int q = 0; q < 4; q++) {
-          double d = __builtin_fma(-2.0, acc[q], cs[u][q]);
-          bool lt = d < bd;  // a lane's centroids ascend (q, then tile), so strict < keeps its lowest j
-          bd = lt ? d : bd;
-          bi = lt ? j0 + 4 * q : bi;
-        }
+        for (int rt = 0; rt < RT; rt++)
+#pragma unroll
+          for (int q = 0; q < 4; q++) {
+            double d = __builtin_fma(-2.0, acc[rt][q], cs[u][q]);
+            bool lt = d < bd[rt];  // a lane's centroids ascend (q, then tile), so strict < keeps its lowest j
+            bd[rt] = lt ? d : bd[rt];
+            bi[rt] = lt ? j0 + 4 * q : bi[rt];
+          }
       }
     }
   }
-  if (wv == 1 && ok) {
+  // the batch rows as f64 for the M-step: row tile rt is written by wave (rt + 1) & 3
 #pragma unroll
-    for (int ks = 0; ks < KS; ks++) {
-      int k = ks * 4 + (lane >> 4);
-      if (k < D) st.Xg[(size_t)r * D + k] = a[ks];
+  for (int rt = 0; rt < RT; rt++)
+    if (((rt + 1) & 3) == wv && ok[rt]) {
+      const long long r = r0 + rt * 16 + (lane & 15);
+#pragma unroll
+      for (int ks = 0; ks < KS; ks++) {
+        int k = ks * 4 + (lane >> 4);
+        if (k < D) st.Xg[(size_t)r * D + k] = a[rt][ks];
+      }
     }
-  }
   SPROF_W(0, 5)
-  __shared__ double sd[4][16];
-  __shared__ int sj[4][16];
-  {
-    double d = bd;
-    int j = bi;
+#pragma unroll
+  for (int rt = 0; rt < RT; rt++) {
+    double d = bd[rt];
+    int j = bi[rt];
 #pragma unroll
     for (int off = 16; off <= 32; off <<= 1) {  // lanes l, l^16, l^32, l^48 hold the same batch row
       double d2 = __shfl_xor(d, off, 64);
@@ -982,13 +1055,13 @@ __global__ __launch_bounds__(256) void k_step_assign(const StepDev *__restrict__
       j = take ? j2 : j;
     }
     if (lane < 16) {
-      sd[wv][lane] = d;
-      sj[wv][lane] = j;
+      sd[wv][rt * 16 + lane] = d;
+      sj[wv][rt * 16 + lane] = j;
     }
   }
   __syncthreads();
   SPROF_W(0, 6)
-  if (tid < 16 && r0 + tid < st.n_b) {
+  if (tid < RW && r0 + tid < st.n_b) {
     double d = sd[0][tid];
     int j = sj[0][tid];
 #pragma unroll
@@ -1001,18 +1074,53 @@ __global__ __launch_bounds__(256) void k_step_assign(const StepDev *__restrict__
     }
     if (j == 0x7fffffff) j = 0;  // all-NaN row: label 0 like the oracle
     st.labels[r0 + tid] = j;
+    long long fr = f[0];  // lane tid (wave 0) holds the frames of rows (tid & 15) + 16 rt: pick rt = tid >> 4
+#pragma unroll
+    for (int rt = 1; rt < RT; rt++) fr = (tid >> 4) == rt ? f[rt] : fr;
     int pos = __hip_atomic_fetch_add(&st.mcnt[j], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (pos < MCAP) st.mlist[(size_t)j * MCAP + pos] = ((unsigned long long)(r0 + tid) << 32) | (unsigned)f;
+    if (pos < MCAP) st.mlist[(size_t)j * MCAP + pos] = ((unsigned long long)(r0 + tid) << 32) | (unsigned)fr;
   }
   if (pf_on) {
 #pragma unroll
     for (int i = 0; i < PF_MAX; i++) asm volatile("" ::"v"(pfv[i]));  // the touched lines are only wanted in L2
   }
+#ifdef STEP_TOUCH
+  asm volatile("" ::"v"(tv));
+#endif
   SPROF_W(0, 7)
 #if defined(STEP_PROFILE) && STEP_PROFILE < 2
   SPROF(0, 7)
 #endif
   SPROF_FLUSH(0)
+}
+
+// members m0 .. m0+W-1 of a sorted member list (lane q holds member q's batch row `rm` and weight `wl`): all W rows
+// are requested before the first add; branch-free -- past the end the last member is fetched again (same lines) and
+// its add is deselected
+template <int W, int H>
+__device__ __forceinline__ void upd_add_listed(double (&acc)[H], const GAS double *Xg, int ldg, unsigned rm, double wl, bool weighted,
+                                               int m0, int mc, int D, int lane) {
+  double xv[W][H];
+#pragma unroll
+  for (int q = 0; q < W; q++) {
+    const int mq = m0 + q < mc ? m0 + q : mc - 1;
+    const size_t rq = (size_t)(unsigned)__builtin_amdgcn_readlane((int)rm, mq);
+#pragma unroll
+    for (int h = 0; h < H; h++) {
+      int k = lane + 64 * h;
+      xv[q][h] = (k < D) ? Xg[rq * ldg + k] : 0.0;
+    }
+  }
+#pragma unroll
+  for (int q = 0; q < W; q++) {
+    const int mq = m0 + q < mc ? m0 + q : mc - 1;
+    const double wq = weighted ? readlane_f64(wl, mq) : 1.0;
+#pragma unroll
+    for (int h = 0; h < H; h++) {
+      double nv = acc[h] + xv[q][h] * wq;
+      acc[h] = (m0 + q < mc) ? nv : acc[h];
+    }
+  }
 }
 
 // M-step: one wave per centroid.  Round trip 1 fetches everything that does not depend on the member list (count,
@@ -1025,16 +1133,14 @@ __global__ __launch_bounds__(256) void k_step_update(const StepDev *__restrict__
                                                      int KS) {
   SPROF_ID
   SPROF(1, 0)
-#ifndef UPD_UB
-#define UPD_UB 32
-#endif
-  constexpr int UB = UPD_UB / H;
   const StepG st(load_step<BYVAL>(steps, pk, blockIdx.y));
   if (blockIdx.x * 4 >= st.K) return;
   extern __shared__ int lds_i[];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   int *list = lds_i + wv * UPD_LIST;  // [UPD_LIST] member batch rows of this wave, ascending (label-scan path only)
   const GAS int *lab = st.labels;
+  const GAS double *Xg = st.Xg;
+  const int ldg = D;
   const int j = blockIdx.x * 4 + wv;
   if (j >= st.K) return;
   const long long n_b = st.n_b;
@@ -1057,12 +1163,9 @@ __global__ __launch_bounds__(256) void k_step_update(const StepDev *__restrict__
   if (listed) {
     // the E-step appended the members in arrival order: rank = number of smaller keys (keys are distinct)
     if (lane >= mc) mine = ~0ull;
-    const unsigned lo = (unsigned)mine, hi = (unsigned)(mine >> 32);
+    const unsigned lo = (unsigned)mine, hi = (unsigned)(mine >> 32);  // hi = batch row: distinct, so it alone orders
     int rank = 0;
-    for (int q = 0; q < mc; q++) {
-      unsigned ql = __builtin_amdgcn_readlane((int)lo, q), qh = __builtin_amdgcn_readlane((int)hi, q);
-      rank += (((unsigned long long)qh << 32) | ql) < mine;
-    }
+    for (int q = 0; q < mc; q++) rank += (unsigned)__builtin_amdgcn_readlane((int)hi, q) < hi;
     fm = (unsigned)__builtin_amdgcn_ds_permute(rank << 2, (int)lo);  // lane `rank` receives this member
     rm = (unsigned)__builtin_amdgcn_ds_permute(rank << 2, (int)hi);
     if (st.wf) {
@@ -1126,30 +1229,11 @@ __global__ __launch_bounds__(256) void k_step_update(const StepDev *__restrict__
   for (int h = 0; h < H; h++) acc[h] = c0[h] * cnt0;
   SPROF_W(1, 3)
   if (listed) {
-    for (int m0 = 0; m0 < mc; m0 += UB) {
-      // branch-free: past the end the last member is fetched again (same lines) and its add is deselected
-      double xv[UB][H];
-#pragma unroll
-      for (int q = 0; q < UB; q++) {
-        const int mq = m0 + q < mc ? m0 + q : mc - 1;
-        const size_t rq = (size_t)(unsigned)__builtin_amdgcn_readlane((int)rm, mq);
-#pragma unroll
-        for (int h = 0; h < H; h++) {
-          int k = lane + 64 * h;
-          xv[q][h] = (k < D) ? st.Xg[rq * D + k] : 0.0;
-        }
-      }
-#pragma unroll
-      for (int q = 0; q < UB; q++) {
-        const int mq = m0 + q < mc ? m0 + q : mc - 1;
-        const double wq = st.wf ? readlane_f64(wl, mq) : 1.0;
-#pragma unroll
-        for (int h = 0; h < H; h++) {
-          double nv = acc[h] + xv[q][h] * wq;
-          acc[h] = (m0 + q < mc) ? nv : acc[h];
-        }
-      }
-    }
+    // one round trip for clusters of up to 64 / H members; the width follows the member count
+    if (mc <= 16 / H) upd_add_listed<16 / H, H>(acc, Xg, ldg, rm, wl, st.wf != nullptr, 0, mc, D, lane);
+    else if (mc <= 32 / H) upd_add_listed<32 / H, H>(acc, Xg, ldg, rm, wl, st.wf != nullptr, 0, mc, D, lane);
+    else
+      for (int m0 = 0; m0 < mc; m0 += 64 / H) upd_add_listed<64 / H, H>(acc, Xg, ldg, rm, wl, st.wf != nullptr, m0, mc, D, lane);
   } else {
     auto add_members = [&](int fill) {
       for (int m0 = 0; m0 < fill; m0 += 8) {
@@ -1161,7 +1245,7 @@ __global__ __launch_bounds__(256) void k_step_update(const StepDev *__restrict__
 #pragma unroll
           for (int h = 0; h < H; h++) {
             int k = lane + 64 * h;
-            xv[q][h] = (ii >= 0 && k < D) ? st.Xg[(size_t)ii * D + k] : 0.0;
+            xv[q][h] = (ii >= 0 && k < D) ? Xg[(size_t)ii * ldg + k] : 0.0;
           }
         }
 #pragma unroll
@@ -1210,9 +1294,8 @@ __global__ __launch_bounds__(256) void k_step_update(const StepDev *__restrict__
 }
 
 // after the update: number of centroids with count < ratio * max(count)  (_kmeans.py:1645)
-template <bool BYVAL>
-__global__ __launch_bounds__(256) void k_step_check(const StepDev *__restrict__ steps, const StepPack pk, double ratio) {
-  const StepG st(load_step<BYVAL>(steps, pk, blockIdx.x));
+__global__ __launch_bounds__(256) void k_step_check(const StepDev *__restrict__ steps, double ratio) {
+  const StepG st(load_step<false>(steps, StepPack{}, blockIdx.x));
   if (!(st.flags & 1)) return;
   __shared__ double smax[256];
   __shared__ int slow[256];
@@ -1236,29 +1319,45 @@ __global__ __launch_bounds__(256) void k_step_check(const StepDev *__restrict__ 
   if (threadIdx.x == 0) st.report[1] = slow[0];
 }
 
-template <typename XT, int KS, bool BYVAL>
+template <typename XT, int KS, int RT, bool BYVAL>
 static void launch_step_kernels(hamsm_ctx *c, const StepDev *d_steps, const StepPack &pk, int ny, long long max_nb, int maxK,
-                                int any_check, int64_t ldx, double ratio) {
+                                int64_t ldx, double ratio) {
   constexpr int JB = KS <= 4 ? 8 : (KS <= 8 ? 4 : (KS <= 16 ? 2 : 1));
-  dim3 ga((unsigned)((max_nb + 15) / 16), (unsigned)ny);
-  hipLaunchKernelGGL((k_step_assign<XT, KS, JB, BYVAL>), ga, dim3(256), 0, c->stream, d_steps, pk, ldx, c->D);
+  dim3 ga((unsigned)((max_nb + 16 * RT - 1) / (16 * RT)), (unsigned)ny);
+  hipLaunchKernelGGL((k_step_assign<XT, KS, JB, RT, BYVAL>), ga, dim3(256), 0, c->stream, d_steps, pk, ldx, c->D, ratio);
   size_t lds = sizeof(int) * (4 * UPD_LIST);
   dim3 gu((unsigned)((maxK + 3) / 4), (unsigned)ny);
   if (c->D <= 64)
     hipLaunchKernelGGL((k_step_update<XT, 1, BYVAL>), gu, dim3(256), lds, c->stream, d_steps, pk, ldx, c->D, c->KS);
   else
     hipLaunchKernelGGL((k_step_update<XT, 2, BYVAL>), gu, dim3(256), lds, c->stream, d_steps, pk, ldx, c->D, c->KS);
-  if (any_check) hipLaunchKernelGGL(k_step_check<BYVAL>, dim3((unsigned)ny), dim3(256), 0, c->stream, d_steps, pk, ratio);
+}
+
+// row tiles per E-step workgroup: as many as the registers allow (RT * KS <= 32) while the launch keeps >= 128 workgroups
+template <typename XT, int KS, bool BYVAL>
+static void launch_step_rt(hamsm_ctx *c, const StepDev *d_steps, const StepPack &pk, int ny, long long max_nb, int maxK,
+                           int64_t ldx, double ratio) {
+  const long long tiles = (max_nb + 15) / 16 * ny;
+  // measured on C3 (10^4 rows, 4 x 250 centroids per call): RT = 1 / 2 / 4 -> 25.0 / 26.5 / 29.0 us per call; fatter
+  // workgroups lose more latency hiding than they save in operand traffic, so RT > 1 is opt-in
+  static const int rt_cap = getenv("HAMSM_STEP_RT") ? atoi(getenv("HAMSM_STEP_RT")) : 1;
+  if constexpr (KS <= 8) {
+    if (tiles >= 4 * 128 && rt_cap >= 4) return launch_step_kernels<XT, KS, 4, BYVAL>(c, d_steps, pk, ny, max_nb, maxK, ldx, ratio);
+  }
+  if constexpr (KS <= 16) {
+    if (tiles >= 2 * 128 && rt_cap >= 2) return launch_step_kernels<XT, KS, 2, BYVAL>(c, d_steps, pk, ny, max_nb, maxK, ldx, ratio);
+  }
+  launch_step_kernels<XT, KS, 1, BYVAL>(c, d_steps, pk, ny, max_nb, maxK, ldx, ratio);
 }
 
 template <typename XT>
 static int launch_steps(hamsm_ctx *c, const StepDev *d_steps, const StepPack &pk, int ny, long long max_nb, int maxK,
-                        int any_check, int64_t ldx, double ratio) {
+                        int64_t ldx, double ratio) {
   switch (c->KS) {
-#define CASE(KSV)                                                                                       \
-  case KSV:                                                                                             \
-    if (d_steps) launch_step_kernels<XT, KSV, false>(c, d_steps, pk, ny, max_nb, maxK, any_check, ldx, ratio); \
-    else launch_step_kernels<XT, KSV, true>(c, d_steps, pk, ny, max_nb, maxK, any_check, ldx, ratio);   \
+#define CASE(KSV)                                                                               \
+  case KSV:                                                                                     \
+    if (d_steps) launch_step_rt<XT, KSV, false>(c, d_steps, pk, ny, max_nb, maxK, ldx, ratio);  \
+    else launch_step_rt<XT, KSV, true>(c, d_steps, pk, ny, max_nb, maxK, ldx, ratio);           \
     break;
     CASE(1) CASE(2) CASE(3) CASE(4) CASE(6) CASE(8) CASE(12) CASE(16) CASE(24) CASE(32)
 #undef CASE
@@ -1294,7 +1393,8 @@ static int run_steps(hamsm_ctx *c, const void *X, int dt, int64_t ldx, const int
   // the gathered batch copy and the member lists are reused by every launch group: one slot per stratum position,
   // stream-ordered
   const int nslot = c->S < 65535 ? c->S : 65535;
-  size_t o_xg = take(sizeof(double) * (size_t)nslot * nb_max * c->D);
+  const size_t xg_row = sizeof(double) * (size_t)c->D;
+  size_t o_xg = take(xg_row * (size_t)nslot * nb_max);
   int Kmax = 0;
   for (int s = 0; s < c->S; s++) Kmax = c->st[s].K > Kmax ? c->st[s].K : Kmax;
   size_t o_mc = take(sizeof(int32_t) * (size_t)nslot * Kmax),
@@ -1319,7 +1419,23 @@ static int run_steps(hamsm_ctx *c, const void *X, int dt, int64_t ldx, const int
     d.K = t.K;
     d.flags = (s.flags & 1) | (want_zero_flag ? 2 : 0);
     d.report = (int32_t *)(b + o_rep) + 2 * i;
+    d.prev_report = nullptr;
   }
+  // the low-count test of a step is evaluated by the E-step of the stratum's next step (the counts do not change in
+  // between); only a stratum's last step needs a launch of its own
+  std::vector<int64_t> last_of(c->S, -1), tail_checks;
+  for (int64_t i = 0; i < n_steps; i++) {
+    if (h_steps[i].n_b <= 0) continue;  // launches nothing: cannot evaluate anything either
+    const int s = h_steps[i].stratum;
+    const int64_t p = last_of[s];
+    if (p >= 0 && (sd[p].flags & 1)) {
+      sd[i].flags |= 4;
+      sd[i].prev_report = sd[p].report;
+    }
+    last_of[s] = i;
+  }
+  for (int s = 0; s < c->S; s++)
+    if (last_of[s] >= 0 && (sd[last_of[s]].flags & 1)) tail_checks.push_back(last_of[s]);
   // launch groups = maximal runs of distinct strata; member-list slot = position inside the run
   std::vector<int64_t> gstart;
   {
@@ -1330,7 +1446,7 @@ static int run_steps(hamsm_ctx *c, const void *X, int dt, int64_t ldx, const int
       int64_t j0 = i0;
       while (j0 < n_steps && !used[h_steps[j0].stratum] && j0 - i0 < 65535) {
         used[h_steps[j0].stratum] = 1;
-        sd[j0].Xg = (double *)(b + o_xg) + (size_t)(j0 - i0) * nb_max * c->D;
+        sd[j0].Xg = (double *)(b + o_xg + (size_t)(j0 - i0) * nb_max * xg_row);
         sd[j0].mcnt = (int32_t *)(b + o_mc) + (size_t)(j0 - i0) * Kmax;
         sd[j0].mlist = (unsigned long long *)(b + o_ml) + (size_t)(j0 - i0) * Kmax * MCAP;
         j0++;
@@ -1351,11 +1467,10 @@ static int run_steps(hamsm_ctx *c, const void *X, int dt, int64_t ldx, const int
   for (size_t g = 0; g + 1 < gstart.size(); g++) {
     const int64_t i = gstart[g], j = gstart[g + 1];
     long long max_nb = 0;
-    int maxK = 0, any_check = 0;
+    int maxK = 0;
     for (int64_t q = i; q < j; q++) {
       if (h_steps[q].n_b > max_nb) max_nb = h_steps[q].n_b;
       if (c->st[h_steps[q].stratum].K > maxK) maxK = c->st[h_steps[q].stratum].K;
-      any_check |= h_steps[q].flags & 1;
     }
     if (max_nb <= 0) continue;
     const int ny = (int)(j - i);
@@ -1371,10 +1486,11 @@ static int run_steps(hamsm_ctx *c, const void *X, int dt, int64_t ldx, const int
         pk.n_next = nn;
       }
     }
-    rc = (dt == HAMSM_F32) ? launch_steps<float>(c, dptr, pk, ny, max_nb, maxK, any_check, ldx, ratio)
-                           : launch_steps<double>(c, dptr, pk, ny, max_nb, maxK, any_check, ldx, ratio);
+    rc = (dt == HAMSM_F32) ? launch_steps<float>(c, dptr, pk, ny, max_nb, maxK, ldx, ratio)
+                           : launch_steps<double>(c, dptr, pk, ny, max_nb, maxK, ldx, ratio);
     if (rc) return rc;
   }
+  for (int64_t i : tail_checks) hipLaunchKernelGGL(k_step_check, dim3(1), dim3(256), 0, c->stream, d_steps + i, ratio);
   hamsm_timer_end(c, ST_STEP);
   HIPCHK(c, hipGetLastError());
   if (h_report) {
