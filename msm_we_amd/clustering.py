@@ -9,6 +9,7 @@ are HBM-resident and one launch covers every segment.
 from __future__ import annotations
 
 import logging
+import os
 from copy import deepcopy
 
 import numpy as np
@@ -340,16 +341,8 @@ class ClusteringMixin:
         # before every step
         z = list(zip(*seeds))
         h.kmeans_seed_multi(z[0], store.Xc, store.x_dtype, store.D, z[1], d_rows, z[2], z[3], d_w, z[4], z[5], z[6], z[7], z[8])
-        # steps in call order, bins ascending inside a call (:890)
-        gcat = np.concatenate([p[0] for p in parts])
-        bcat = np.concatenate([p[1] for p in parts])
-        order = np.lexsort((bcat, gcat))
-        steps = np.concatenate([p[2] for p in parts])[order]
-        is_first = np.concatenate([p[3] for p in parts])[order]
-        report = h.minibatch_run(store.Xc, store.x_dtype, store.D, d_rows, d_w, steps, ratio)
-        bad = (report[:, 1] != 0) | ((report[:, 0] != 0) & ~is_first)
-        if bad.any():
-            log.info("training plan mispredicted a reassignment at step %d: rerunning stepwise", int(np.argmax(bad)))
+
+        def undo():
             for k, r in rs_objs.items():
                 r.set_state(saved[k])
             for b in pred:
@@ -357,13 +350,53 @@ class ClusteringMixin:
                 m = models[b]
                 m.__dict__["_device_newer"] = False
                 m.__dict__["_host_centers"] = None
+                m.__dict__.pop("n_steps_", None)
             return False
+
+        # A stratum's FIRST step regularly needs the host: when the seeding batch is a subsample drawn with
+        # replacement (init_size < batch rows, `_kmeans.py:1003-1011`) duplicate seeds end the step with no member and
+        # are re-seeded at once (`:1652-1673`).  It is taken with the host in the loop; everything after it is fused.
+        if len(rs_objs) < len(pred):
+            shared_rng = True   # models share a RandomState: draws interleave in call order, keep the strict order
+        else:
+            shared_rng = False
+        for b in sorted(pred, key=lambda x: (first_g[x], x)):
+            m, g0 = models[b], int(first_g[b])
+            m._batch_size, m._init_size = pred[b]["bs"], pred[b]["init"]
+            m._counts_cache = np.zeros(m.n_clusters)
+            m._n_since_last_reassign = 0
+            m.__dict__["_device_newer"] = True
+            m.__dict__["n_steps_"] = 0
+            state_before = {k: (r.get_state()[1].tobytes(), r.get_state()[2]) for k, r in rs_objs.items()}
+            m._host_step(store.Xc.offset(int(gb[g0]) * store.D), store.x_dtype, store.D, d_rows.offset(int(starts[g0, b])),
+                         int(counts[g0, b]), d_w.offset(int(gb[g0])) if d_w is not None else None)
+            if shared_rng and any((r.get_state()[1].tobytes(), r.get_state()[2]) != state_before[k] for k, r in rs_objs.items()):
+                log.info("first step of stratum %d drew from a shared RandomState: rerunning stepwise", b)
+                return undo()
+            assert m._n_since_last_reassign == 0  # counts were all zero: the reassignment test fired
+        # steps in call order, bins ascending inside a call (:890); the first step of every stratum is done
+        gcat = np.concatenate([p[0] for p in parts])
+        bcat = np.concatenate([p[1] for p in parts])
+        order = np.lexsort((bcat, gcat))
+        steps = np.concatenate([p[2] for p in parts])[order]
+        is_first = np.concatenate([p[3] for p in parts])[order]
+        steps = steps[~is_first]
+        if len(steps):
+            report = h.minibatch_run(store.Xc, store.x_dtype, store.D, d_rows, d_w, steps, ratio)
+            bad = (report[:, 1] != 0) | (report[:, 0] != 0)
+            if os.environ.get("HAMSM_DEBUG_REPORT"):
+                print(f"[plan] {len(steps)} fused steps, {int((steps['flags'] & 1).sum())} reassign checks, "
+                      f"{int((report[:, 1] != 0).sum())} with low counts, {int((report[:, 0] != 0).sum())} zero-count flags",
+                      flush=True)
+            if bad.any():
+                log.info("training plan mispredicted a reassignment at step %d: rerunning stepwise", int(np.argmax(bad)))
+                return undo()
         for b, st in pred.items():
             m = models[b]
             m._batch_size, m._init_size = st["bs"], st["init"]
             m._n_since_last_reassign = st["n_since"]
             m._counts_cache = None
-            m.n_steps_ = m.__dict__.get("n_steps_", 0) + st["nsteps"]
+            m.n_steps_ = st["nsteps"]  # (the model was unfitted before this pass)
             m.__dict__["_device_newer"] = True
         return True
 

@@ -56,6 +56,11 @@ struct hamsm_ctx {
   char err[512];
   int device = 0;
   hipStream_t stream = nullptr;
+  // training steps of different strata are independent chains of small latency-bound kernels: strata alternate
+  // between `stream` and these side queues so that the chains overlap (fork/join with events inside run_steps)
+  hipStream_t side_stream[3] = {nullptr, nullptr, nullptr};
+  hipEvent_t ev_fork = nullptr, ev_join[3] = {nullptr, nullptr, nullptr};
+  int step_lanes = 2;  // queues used by the training steps (HAMSM_STEP_LANES = 1..4)
   // hamsm_malloc / hamsm_free keep released blocks for reuse (hipMalloc costs ~1 ms per 40 MB block and hipFree
   // synchronises the device; every use of a block is ordered on `stream`, so reuse needs no synchronisation)
   std::unordered_map<void *, size_t> blk_live;

@@ -23,6 +23,7 @@ extern "C" int hamsm_create(int device, hamsm_ctx **out) {
   c->device = device;
   memset(&c->mapper, 0, sizeof c->mapper);
   if (const char *v = getenv("HAMSM_ASSIGN_W")) c->assign_waves = atoi(v) == 8 ? 8 : 4;
+  if (const char *v = getenv("HAMSM_STEP_LANES")) c->step_lanes = atoi(v) < 1 ? 1 : (atoi(v) > 4 ? 4 : atoi(v));
   if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess ||
       hipMalloc((void **)&c->d_err, 4 * sizeof(int)) != hipSuccess ||
       hipHostMalloc((void **)&c->h_err, 4 * sizeof(int)) != hipSuccess) {
@@ -71,6 +72,11 @@ extern "C" void hamsm_destroy(hamsm_ctx *c) {
     hipEventDestroy(p.e1);
   }
   for (auto e : c->ev_free) hipEventDestroy(e);
+  for (int i = 0; i < 3; i++) {
+    if (c->side_stream[i]) hipStreamDestroy(c->side_stream[i]);
+    if (c->ev_join[i]) hipEventDestroy(c->ev_join[i]);
+  }
+  if (c->ev_fork) hipEventDestroy(c->ev_fork);
   hipStreamDestroy(c->stream);
   delete c;
 }

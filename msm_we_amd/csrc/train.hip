@@ -1320,44 +1320,44 @@ __global__ __launch_bounds__(256) void k_step_check(const StepDev *__restrict__ 
 }
 
 template <typename XT, int KS, int RT, bool BYVAL>
-static void launch_step_kernels(hamsm_ctx *c, const StepDev *d_steps, const StepPack &pk, int ny, long long max_nb, int maxK,
-                                int64_t ldx, double ratio) {
+static void launch_step_kernels(hamsm_ctx *c, hipStream_t q, const StepDev *d_steps, const StepPack &pk, int ny,
+                                long long max_nb, int maxK, int64_t ldx, double ratio) {
   constexpr int JB = KS <= 4 ? 8 : (KS <= 8 ? 4 : (KS <= 16 ? 2 : 1));
   dim3 ga((unsigned)((max_nb + 16 * RT - 1) / (16 * RT)), (unsigned)ny);
-  hipLaunchKernelGGL((k_step_assign<XT, KS, JB, RT, BYVAL>), ga, dim3(256), 0, c->stream, d_steps, pk, ldx, c->D, ratio);
+  hipLaunchKernelGGL((k_step_assign<XT, KS, JB, RT, BYVAL>), ga, dim3(256), 0, q, d_steps, pk, ldx, c->D, ratio);
   size_t lds = sizeof(int) * (4 * UPD_LIST);
   dim3 gu((unsigned)((maxK + 3) / 4), (unsigned)ny);
   if (c->D <= 64)
-    hipLaunchKernelGGL((k_step_update<XT, 1, BYVAL>), gu, dim3(256), lds, c->stream, d_steps, pk, ldx, c->D, c->KS);
+    hipLaunchKernelGGL((k_step_update<XT, 1, BYVAL>), gu, dim3(256), lds, q, d_steps, pk, ldx, c->D, c->KS);
   else
-    hipLaunchKernelGGL((k_step_update<XT, 2, BYVAL>), gu, dim3(256), lds, c->stream, d_steps, pk, ldx, c->D, c->KS);
+    hipLaunchKernelGGL((k_step_update<XT, 2, BYVAL>), gu, dim3(256), lds, q, d_steps, pk, ldx, c->D, c->KS);
 }
 
 // row tiles per E-step workgroup: as many as the registers allow (RT * KS <= 32) while the launch keeps >= 128 workgroups
 template <typename XT, int KS, bool BYVAL>
-static void launch_step_rt(hamsm_ctx *c, const StepDev *d_steps, const StepPack &pk, int ny, long long max_nb, int maxK,
-                           int64_t ldx, double ratio) {
+static void launch_step_rt(hamsm_ctx *c, hipStream_t q, const StepDev *d_steps, const StepPack &pk, int ny, long long max_nb,
+                           int maxK, int64_t ldx, double ratio) {
   const long long tiles = (max_nb + 15) / 16 * ny;
   // measured on C3 (10^4 rows, 4 x 250 centroids per call): RT = 1 / 2 / 4 -> 25.0 / 26.5 / 29.0 us per call; fatter
   // workgroups lose more latency hiding than they save in operand traffic, so RT > 1 is opt-in
   static const int rt_cap = getenv("HAMSM_STEP_RT") ? atoi(getenv("HAMSM_STEP_RT")) : 1;
   if constexpr (KS <= 8) {
-    if (tiles >= 4 * 128 && rt_cap >= 4) return launch_step_kernels<XT, KS, 4, BYVAL>(c, d_steps, pk, ny, max_nb, maxK, ldx, ratio);
+    if (tiles >= 4 * 128 && rt_cap >= 4) return launch_step_kernels<XT, KS, 4, BYVAL>(c, q, d_steps, pk, ny, max_nb, maxK, ldx, ratio);
   }
   if constexpr (KS <= 16) {
-    if (tiles >= 2 * 128 && rt_cap >= 2) return launch_step_kernels<XT, KS, 2, BYVAL>(c, d_steps, pk, ny, max_nb, maxK, ldx, ratio);
+    if (tiles >= 2 * 128 && rt_cap >= 2) return launch_step_kernels<XT, KS, 2, BYVAL>(c, q, d_steps, pk, ny, max_nb, maxK, ldx, ratio);
   }
-  launch_step_kernels<XT, KS, 1, BYVAL>(c, d_steps, pk, ny, max_nb, maxK, ldx, ratio);
+  launch_step_kernels<XT, KS, 1, BYVAL>(c, q, d_steps, pk, ny, max_nb, maxK, ldx, ratio);
 }
 
 template <typename XT>
-static int launch_steps(hamsm_ctx *c, const StepDev *d_steps, const StepPack &pk, int ny, long long max_nb, int maxK,
-                        int64_t ldx, double ratio) {
+static int launch_steps(hamsm_ctx *c, hipStream_t q, const StepDev *d_steps, const StepPack &pk, int ny, long long max_nb,
+                        int maxK, int64_t ldx, double ratio) {
   switch (c->KS) {
 #define CASE(KSV)                                                                               \
   case KSV:                                                                                     \
-    if (d_steps) launch_step_rt<XT, KSV, false>(c, d_steps, pk, ny, max_nb, maxK, ldx, ratio);  \
-    else launch_step_rt<XT, KSV, true>(c, d_steps, pk, ny, max_nb, maxK, ldx, ratio);           \
+    if (d_steps) launch_step_rt<XT, KSV, false>(c, q, d_steps, pk, ny, max_nb, maxK, ldx, ratio); \
+    else launch_step_rt<XT, KSV, true>(c, q, d_steps, pk, ny, max_nb, maxK, ldx, ratio);          \
     break;
     CASE(1) CASE(2) CASE(3) CASE(4) CASE(6) CASE(8) CASE(12) CASE(16) CASE(24) CASE(32)
 #undef CASE
@@ -1446,9 +1446,11 @@ static int run_steps(hamsm_ctx *c, const void *X, int dt, int64_t ldx, const int
       int64_t j0 = i0;
       while (j0 < n_steps && !used[h_steps[j0].stratum] && j0 - i0 < 65535) {
         used[h_steps[j0].stratum] = 1;
-        sd[j0].Xg = (double *)(b + o_xg + (size_t)(j0 - i0) * nb_max * xg_row);
-        sd[j0].mcnt = (int32_t *)(b + o_mc) + (size_t)(j0 - i0) * Kmax;
-        sd[j0].mlist = (unsigned long long *)(b + o_ml) + (size_t)(j0 - i0) * Kmax * MCAP;
+        // scratch slot = the stratum itself: chains of different strata run concurrently on different queues
+        const size_t slot = nslot == c->S ? (size_t)h_steps[j0].stratum : (size_t)(j0 - i0);
+        sd[j0].Xg = (double *)(b + o_xg + slot * nb_max * xg_row);
+        sd[j0].mcnt = (int32_t *)(b + o_mc) + slot * Kmax;
+        sd[j0].mlist = (unsigned long long *)(b + o_ml) + slot * Kmax * MCAP;
         j0++;
       }
       gstart.push_back(i0);
@@ -1462,33 +1464,67 @@ static int run_steps(hamsm_ctx *c, const void *X, int dt, int64_t ldx, const int
   HIPCHK(c, hipMemsetAsync(b + o_mc, 0, sizeof(int32_t) * (size_t)nslot * Kmax, c->stream));
   const StepDev *d_steps = (const StepDev *)(b + o_steps);
   hamsm_timer_begin(c);
+  // lanes: stratum s always runs on queue s % n_lanes, so every stratum's chain stays ordered; a lane's part of a
+  // launch group travels by value (<= PACK_NY strata) -- otherwise one queue and descriptors in memory
+  int n_lanes = c->step_lanes;
+  for (size_t g = 0; g + 1 < gstart.size() && n_lanes > 1; g++) {
+    std::vector<int> cnt(n_lanes, 0);
+    for (int64_t q = gstart[g]; q < gstart[g + 1]; q++)
+      if (++cnt[h_steps[q].stratum % n_lanes] > PACK_NY) n_lanes = 1;
+  }
+  if (gstart.size() <= 2 || c->S < 2 || nslot != c->S || !d_rows) n_lanes = 1;  // (labels scratch is per step only with row lists)
+  hipStream_t lanes[4] = {c->stream, nullptr, nullptr, nullptr};
+  if (n_lanes > 1) {
+    if (!c->ev_fork) HIPCHK(c, hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
+    HIPCHK(c, hipEventRecord(c->ev_fork, c->stream));
+    for (int l = 1; l < n_lanes; l++) {
+      if (!c->side_stream[l - 1]) {
+        HIPCHK(c, hipStreamCreateWithFlags(&c->side_stream[l - 1], hipStreamNonBlocking));
+        HIPCHK(c, hipEventCreateWithFlags(&c->ev_join[l - 1], hipEventDisableTiming));
+      }
+      lanes[l] = c->side_stream[l - 1];
+      HIPCHK(c, hipStreamWaitEvent(lanes[l], c->ev_fork, 0));
+    }
+  }
   StepPack pk;
   memset(&pk, 0, sizeof(pk));
   for (size_t g = 0; g + 1 < gstart.size(); g++) {
     const int64_t i = gstart[g], j = gstart[g + 1];
-    long long max_nb = 0;
-    int maxK = 0;
-    for (int64_t q = i; q < j; q++) {
-      if (h_steps[q].n_b > max_nb) max_nb = h_steps[q].n_b;
-      if (c->st[h_steps[q].stratum].K > maxK) maxK = c->st[h_steps[q].stratum].K;
-    }
-    if (max_nb <= 0) continue;
-    const int ny = (int)(j - i);
-    const StepDev *dptr = d_steps + i;
-    if (ny <= PACK_NY) {
-      dptr = nullptr;  // descriptors by value
-      for (int q = 0; q < ny; q++) pk.s[q] = sd[i + q];
-      pk.n_next = 0;
-      if (g + 2 < gstart.size()) {
-        const int64_t jn = gstart[g + 2];
-        const int nn = (int)(jn - j) < ny ? (int)(jn - j) : ny;
-        for (int q = 0; q < nn; q++) pk.nx[q] = StepNext{sd[j + q].X, sd[j + q].rows, sd[j + q].n_b};
-        pk.n_next = nn;
+    for (int l = 0; l < n_lanes; l++) {
+      long long max_nb = 0;
+      int maxK = 0, ny = 0;
+      std::vector<int64_t> mine;
+      for (int64_t q = i; q < j; q++) {
+        if (n_lanes > 1 && h_steps[q].stratum % n_lanes != l) continue;
+        mine.push_back(q);
+        if (h_steps[q].n_b > max_nb) max_nb = h_steps[q].n_b;
+        if (c->st[h_steps[q].stratum].K > maxK) maxK = c->st[h_steps[q].stratum].K;
       }
+      ny = (int)mine.size();
+      if (ny == 0 || max_nb <= 0) continue;
+      const StepDev *dptr = d_steps + i;
+      if (ny <= PACK_NY) {
+        dptr = nullptr;  // descriptors by value
+        for (int q = 0; q < ny; q++) pk.s[q] = sd[mine[q]];
+        pk.n_next = 0;
+        if (g + 2 < gstart.size()) {
+          // the same strata of the next group, in the same positions
+          int nn = 0;
+          for (int64_t q = j; q < gstart[g + 2] && nn < ny; q++) {
+            if (n_lanes > 1 && h_steps[q].stratum % n_lanes != l) continue;
+            pk.nx[nn++] = StepNext{sd[q].X, sd[q].rows, sd[q].n_b};
+          }
+          pk.n_next = nn;
+        }
+      }
+      rc = (dt == HAMSM_F32) ? launch_steps<float>(c, lanes[l], dptr, pk, ny, max_nb, maxK, ldx, ratio)
+                             : launch_steps<double>(c, lanes[l], dptr, pk, ny, max_nb, maxK, ldx, ratio);
+      if (rc) return rc;
     }
-    rc = (dt == HAMSM_F32) ? launch_steps<float>(c, dptr, pk, ny, max_nb, maxK, ldx, ratio)
-                           : launch_steps<double>(c, dptr, pk, ny, max_nb, maxK, ldx, ratio);
-    if (rc) return rc;
+  }
+  for (int l = 1; l < n_lanes; l++) {
+    HIPCHK(c, hipEventRecord(c->ev_join[l - 1], lanes[l]));
+    HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_join[l - 1], 0));
   }
   for (int64_t i : tail_checks) hipLaunchKernelGGL(k_step_check, dim3(1), dim3(256), 0, c->stream, d_steps + i, ratio);
   hamsm_timer_end(c, ST_STEP);

@@ -165,6 +165,14 @@ class StratumKMeans:
             self._counts_cache = np.zeros(K)  # _kmeans.py:2271
             self._n_since_last_reassign = 0   # :2274
             self.__dict__["_device_newer"] = True
+        return self._host_step(d_X, x_dtype, ldx, d_rows, n_b, d_w)
+
+    def _host_step(self, d_X, x_dtype, ldx, d_rows, n_b, d_w=None):
+        """One `_mini_batch_step` with the host in the loop: the reassignment decision and its RandomState draw
+        (`_kmeans.py:1643-1673`) need the counts on the host."""
+        h = self._h
+        K = self.n_clusters
+        rs = self._random_state
         # _random_reassign, _kmeans.py:2029-2043 (evaluated before the step)
         self._n_since_last_reassign += self._batch_size
         counts = self._counts_cache if self._counts_cache is not None else h.get_counts(self.stratum)
