@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define HAMSM_ABI_VERSION 1
+#define HAMSM_ABI_VERSION 2
 
 #define HAMSM_OK 0
 #define HAMSM_EINVAL (-1)   /* bad argument / call order                                         */
@@ -196,23 +196,43 @@ int hamsm_kmeans_seed_multi(hamsm_ctx *ctx, int n_items, const int32_t *h_stratu
                             const int64_t *h_first, const double *h_u, const int32_t *h_L);
 
 /* One planned minibatch step: batch rows d_rows[rows_off .. rows_off+n_b) (relative to frame x_off)
- * update the centroids of `stratum`.  flags bit0: evaluate the low-count rule after the step.      */
+ * update the centroids of `stratum`.
+ * flags bit0: the low-count rule (_kmeans.py:1643-1673) is evaluated after the step (the host's closed-form
+ * `_random_reassign` schedule, :2029-2043).  The rule needs `random_state.choice(n_b, replace=False,
+ * size=n_low)`, i.e. the first n_low entries of `random_state.permutation(n_b)` -- random numbers are consumed
+ * only when n_low > 0, so the host PREDICTS per step whether they will be:
+ *   perm_off <  0 : predicted n_low == 0, nothing drawn;
+ *   perm_off >= 0 : predicted n_low > 0: h_perm[perm_off .. perm_off+n_perm) holds the head of the permutation
+ *                   the host drew; the device re-seeds the low centroids from it (ascending centroid index
+ *                   <-> permutation order, counts := min over the others), exactly as :1652-1673.            */
 typedef struct hamsm_step {
   int32_t stratum;
   int32_t flags;
   int64_t x_off;
   int64_t rows_off;
   int64_t n_b;
+  int64_t perm_off;
+  int32_t n_perm;
+  int32_t reserved;
 } hamsm_step;
 
+/* why a stratum's chain of steps stopped (h_reason of hamsm_minibatch_run) */
+#define HAMSM_STOP_NONE 0   /* every step applied, every prediction held                                   */
+#define HAMSM_STOP_LOW 1    /* last applied step: n_low > 0 but no permutation (host must re-seed, then resume) */
+#define HAMSM_STOP_UNUSED 2 /* last applied step: a permutation was supplied but n_low == 0 (host rewinds its RNG) */
+#define HAMSM_STOP_CAP 3    /* last applied step: n_low > n_perm or n_low > 0.5 n_b (:1647-1651): host handles it  */
+#define HAMSM_STOP_ZERO 4   /* a count was zero before step h_resume[s] (`(self._counts == 0).any()`, :2037):
+                               the host's schedule does not hold from here                                     */
+
 /* Execute steps in order (steps of different strata may overlap; steps of one stratum never do)
- * with no host involvement.  The host predicts that no random reassignment is needed; h_report lets
- * it verify that: h_report[2*i] = 1 if some centroid count was 0 before step i (the
- * `(self._counts == 0).any()` test, _kmeans.py:2037), h_report[2*i+1] = number of centroids with
- * count < ratio * max(count) after step i when flags bit0 is set (_kmeans.py:1645), else 0.        */
+ * with no host involvement, each stratum until one of its predictions fails.  h_resume[s] = index of
+ * the first step of stratum s that was NOT applied (n_steps when all were), h_reason[s] = HAMSM_STOP_*.
+ * h_report[2*i] = 1 if some count was 0 before step i; h_report[2*i+1] = n_low after step i (flags bit0),
+ * whether or not it was acted upon.                                                                   */
 int hamsm_minibatch_run(hamsm_ctx *ctx, const void *d_X, int x_dtype, int64_t ldx,
                         const int32_t *d_rows, const double *d_w, const hamsm_step *h_steps,
-                        int64_t n_steps, double reassignment_ratio, int32_t *h_report);
+                        int64_t n_steps, double reassignment_ratio, const int32_t *h_perm,
+                        int64_t n_perm_total, int32_t *h_report, int64_t *h_resume, int32_t *h_reason);
 
 /* ---- multi-GPU: frames shard by WE iteration; these are the only exchanges.
  *      Replaces the driver-side sum of per-task flux matrices (_fluxmatrix.py:325-327) and

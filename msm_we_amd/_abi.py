@@ -54,7 +54,7 @@ SYMBOLS = {
     "hamsm_reassign": (_int, [_vp, _int, _vp, _int, _i64, _vp, _vp, _vp, _int, _f64]),
     "hamsm_train_build_rows_batched": (_int, [_vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp]),
     "hamsm_kmeans_seed_multi": (_int, [_vp, _int, _vp, _vp, _int, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
-    "hamsm_minibatch_run": (_int, [_vp, _vp, _int, _i64, _vp, _vp, _vp, _i64, _f64, _vp]),
+    "hamsm_minibatch_run": (_int, [_vp, _vp, _int, _i64, _vp, _vp, _vp, _i64, _f64, _vp, _i64, _vp, _vp, _vp]),
     "hamsm_comm_unique_id": (_int, [_vp]),
     "hamsm_comm_init": (_int, [_vp, _int, _int, _vp]),
     "hamsm_comm_destroy": (_int, [_vp]),
@@ -151,7 +151,7 @@ class Hamsm:
 
     def __init__(self, lib: C.CDLL | None = None, device: int = 0):
         self.lib = bind(lib if lib is not None else load())
-        if self.lib.hamsm_abi_version() != 1:
+        if self.lib.hamsm_abi_version() != 2:
             raise ImportError("hamsm ABI version mismatch")
         ctx = _vp()
         rc = self.lib.hamsm_create(int(device), C.byref(ctx))
@@ -358,7 +358,9 @@ class Hamsm:
                                          _hp(br), len(cl), float(new_count)))
 
     # -- batched training plan ----------------------------------------------------------------
-    STEP_DTYPE = np.dtype([("stratum", "<i4"), ("flags", "<i4"), ("x_off", "<i8"), ("rows_off", "<i8"), ("n_b", "<i8")])
+    STEP_DTYPE = np.dtype([("stratum", "<i4"), ("flags", "<i4"), ("x_off", "<i8"), ("rows_off", "<i8"), ("n_b", "<i8"),
+                           ("perm_off", "<i8"), ("n_perm", "<i4"), ("reserved", "<i4")])
+    STOP_NONE, STOP_LOW, STOP_UNUSED, STOP_CAP, STOP_ZERO = 0, 1, 2, 3, 4
 
     def train_build_rows_batched(self, d_bin, group_begin, group_end, call_remap, d_rows):
         goff = np.ascontiguousarray(np.stack([group_begin, group_end], axis=1), dtype=np.int64)
@@ -383,13 +385,18 @@ class Hamsm:
                                                   _hp(ro), _hp(nb), _dp(d_w), _hp(sub), _hp(n_sub), _hp(Ks), _hp(fs), _hp(u),
                                                   _hp(Ls)))
 
-    def minibatch_run(self, d_X, x_dtype, ldx, d_rows, d_w, steps, ratio):
+    def minibatch_run(self, d_X, x_dtype, ldx, d_rows, d_w, steps, ratio, perm=None):
+        """-> (report[n_steps, 2], resume[S], reason[S]); steps without a permutation carry perm_off = -1"""
         steps = np.ascontiguousarray(steps, dtype=self.STEP_DTYPE)
         report = np.zeros((len(steps), 2), dtype=np.int32)
+        resume = np.full(self.S, len(steps), dtype=np.int64)
+        reason = np.zeros(self.S, dtype=np.int32)
+        perm = np.zeros(0, dtype=np.int32) if perm is None else np.ascontiguousarray(perm, dtype=np.int32)
         if len(steps):
             self._ck(self.lib.hamsm_minibatch_run(self.ctx, _dp(d_X), int(x_dtype), int(ldx), _dp(d_rows), _dp(d_w),
-                                                  _hp(steps), len(steps), float(ratio), _hp(report)))
-        return report
+                                                  _hp(steps), len(steps), float(ratio), _hp(perm) if len(perm) else None,
+                                                  len(perm), _hp(report), _hp(resume), _hp(reason)))
+        return report, resume, reason
 
     # -- exchange step ----------------------------------------------------------------------
     def comm_unique_id(self) -> bytes:

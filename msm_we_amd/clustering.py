@@ -10,6 +10,7 @@ from __future__ import annotations
 
 import logging
 import os
+import sys
 from copy import deepcopy
 
 import numpy as np
@@ -374,22 +375,89 @@ class ClusteringMixin:
                 log.info("first step of stratum %d drew from a shared RandomState: rerunning stepwise", b)
                 return undo()
             assert m._n_since_last_reassign == 0  # counts were all zero: the reassignment test fired
-        # steps in call order, bins ascending inside a call (:890); the first step of every stratum is done
-        gcat = np.concatenate([p[0] for p in parts])
-        bcat = np.concatenate([p[1] for p in parts])
-        order = np.lexsort((bcat, gcat))
-        steps = np.concatenate([p[2] for p in parts])[order]
-        is_first = np.concatenate([p[3] for p in parts])[order]
-        steps = steps[~is_first]
-        if len(steps):
-            report = h.minibatch_run(store.Xc, store.x_dtype, store.D, d_rows, d_w, steps, ratio)
-            bad = (report[:, 1] != 0) | (report[:, 0] != 0)
+        # Everything after the first steps is fused.  The low-count rule (`_kmeans.py:1643-1673`) consumes
+        # `random_state.permutation(n_b)` only when some count IS low, so the host predicts per stratum whether it
+        # will be ("as at the last test": the outcome is persistent -- never on balanced data, at every test once a
+        # stratum holds more centroids than populated modes) and hands the permutation heads over; the device
+        # re-seeds from them and stops a stratum's chain at the first wrong prediction, which is then settled here
+        # (RandomState rewound or the re-seeding done on the host) before the chain resumes.
+        chain = {}
+        for gs, bb, st, first in parts:
+            chain[int(bb[0])] = dict(g=gs[~first], st=st[~first], pos=0)
+        predict = {b: models[b]._last_n_re > 0 for b in chain}
+        total_calls = int(max((len(c["g"]) for c in chain.values()), default=0))
+        span = G  # calls per fused run; halved after a stop, doubled after a clean run
+        g_lo = 0
+        n_runs = 0
+        while any(c["pos"] < len(c["g"]) for c in chain.values()):
+            live = [b for b, c in chain.items() if c["pos"] < len(c["g"])]
+            g_lo = min(int(chain[b]["g"][chain[b]["pos"]]) for b in live)
+            g_hi = g_lo + span
+            sel = {}
+            for b in live:
+                c = chain[b]
+                n_take = int(np.searchsorted(c["g"], g_hi, side="left")) - c["pos"]
+                if n_take > 0:
+                    sel[b] = (c["pos"], c["pos"] + n_take)
+            gcat = np.concatenate([chain[b]["g"][a:e] for b, (a, e) in sel.items()])
+            bcat = np.concatenate([np.full(e - a, b) for b, (a, e) in sel.items()])
+            scat = np.concatenate([chain[b]["st"][a:e] for b, (a, e) in sel.items()])
+            order = np.lexsort((bcat, gcat))  # call order, bins ascending inside a call (:890)
+            steps = scat[order].copy()
+            steps["perm_off"], steps["n_perm"] = -1, 0
+            # speculative draws, per model in step order (models own their RandomState here; shared ones never predict)
+            perms, off, drawn = [], 0, {b: [] for b in sel}
+            for i in np.nonzero(steps["flags"] & 1)[0]:
+                b = int(steps["stratum"][i])
+                if not predict[b] or shared_rng:
+                    continue
+                m = models[b]
+                nb_i = int(steps["n_b"][i])
+                drawn[b].append((int(i), m._random_state.get_state()))
+                head = m._random_state.permutation(nb_i)[: min(m.n_clusters, nb_i)]
+                steps["perm_off"][i], steps["n_perm"][i] = off, len(head)
+                perms.append(head)
+                off += len(head)
+            report, resume, reason = h.minibatch_run(store.Xc, store.x_dtype, store.D, d_rows, d_w, steps, ratio,
+                                                     np.concatenate(perms) if perms else None)
+            n_runs += 1
             if os.environ.get("HAMSM_DEBUG_REPORT"):
-                print(f"[plan] {len(steps)} fused steps, {int((steps['flags'] & 1).sum())} reassign checks, "
-                      f"{int((report[:, 1] != 0).sum())} with low counts, {int((report[:, 0] != 0).sum())} zero-count flags",
-                      flush=True)
-            if bad.any():
-                log.info("training plan mispredicted a reassignment at step %d: rerunning stepwise", int(np.argmax(bad)))
+                print(f"[plan] run {n_runs}: calls {g_lo}..{g_hi}, {len(steps)} steps, {int((steps['flags'] & 1).sum())} tests "
+                      f"({len(perms)} with a permutation), stops {dict((b, int(reason[b])) for b in sel if reason[b])}", flush=True,
+                      file=sys.stderr)
+            stopped = False
+            for b, (a, e) in sel.items():
+                m = models[b]
+                mine = np.nonzero(steps["stratum"] == b)[0]
+                n_applied = int(np.searchsorted(mine, resume[b], side="left"))
+                why = int(reason[b])
+                last = int(mine[n_applied - 1]) if n_applied else -1  # the last applied step of this stratum
+                # permutations drawn for steps that were not applied (and, when its prediction failed, for the last
+                # applied one) were never consumed by the reference: rewind to the earliest of them
+                undo_from = last if why in (h.STOP_UNUSED, h.STOP_CAP) else last + 1
+                for i, state in drawn[b]:
+                    if i >= undo_from:
+                        m._random_state.set_state(state)
+                        break
+                chain[b]["pos"] = a + n_applied
+                if why == h.STOP_NONE:
+                    continue
+                stopped = True
+                if why == h.STOP_ZERO or shared_rng or last < 0:
+                    log.info("training plan of stratum %d does not hold (stop %d): rerunning stepwise", b, why)
+                    return undo()
+                if why == h.STOP_UNUSED:
+                    predict[b] = False
+                else:  # the step is applied, its re-seeding is still due: on the host, with the model's RandomState
+                    st_l = steps[last]
+                    m.__dict__["_device_newer"] = True
+                    m._host_reassign(store.Xc.offset(int(st_l["x_off"]) * store.D), store.x_dtype, store.D,
+                                     d_rows.offset(int(st_l["rows_off"])), int(st_l["n_b"]))
+                    m._counts_cache = None
+                    predict[b] = True
+            span = max(span // 2, 16) if stopped else min(span * 2, G)
+            if n_runs > 64 + total_calls // 8:
+                log.info("training plan keeps mispredicting: rerunning stepwise")
                 return undo()
         for b, st in pred.items():
             m = models[b]

@@ -775,6 +775,10 @@ struct StepDev {
                          //        4 = this step's E-step evaluates the low-count test of the stratum's previous step
   int32_t *report;       // [2]
   int32_t *prev_report;  // report of the stratum's previous step (flags & 4)
+  const int32_t *perm;   // flags & 1: head of the permutation the host drew for this step's re-seeding (nullable)
+  int n_perm, idx;       // idx = position of the step in the run
+  int32_t *halt;         // the stratum's stop word: steps with idx >= *halt are not applied
+  int32_t *reason;       // HAMSM_STOP_* of the stratum
 };
 // what the next call's E-step will gather: its lines are pulled towards this XCD's L2 while this call computes
 struct StepNext {
@@ -846,12 +850,12 @@ struct StepG {  // a StepDev with its pointers in the global address space
   GAS int32_t *mcnt;
   GAS unsigned long long *mlist;
   GAS double *C, *counts, *csq, *Bpack;
-  int K, flags;
+  int K, flags, idx;
   GAS int32_t *report;
   __device__ __forceinline__ explicit StepG(const StepDev &d)
       : X(gp((const char *)d.X)), rows(gp(d.rows)), wf(gp(d.wf)), n_b(d.n_b), labels(gp(d.labels)), Xg(gp(d.Xg)),
         mcnt(gp(d.mcnt)), mlist(gp(d.mlist)), C(gp(d.C)), counts(gp(d.counts)), csq(gp(d.csq)), Bpack(gp(d.Bpack)), K(d.K),
-        flags(d.flags), report(gp(d.report)) {}
+        flags(d.flags), idx(d.idx), report(gp(d.report)) {}
 };
 
 template <bool BYVAL>
@@ -947,9 +951,11 @@ __global__ __launch_bounds__(256) void k_step_assign(const StepDev *__restrict__
   SPROF_W(0, 3)
   __shared__ double sd[4][RW];
   __shared__ int sj[4][RW];
-  if (blockIdx.x == 0 && (st.flags & 6)) {
-    // one pass over the counts: `(self._counts == 0).any()` before this step (_kmeans.py:2037), and for the
-    // previous step of the stratum `counts < ratio * max(counts)` (:1645)
+  if (blockIdx.x == 0 && (st.flags & 6) && st.idx < *gp(sdesc.halt)) {
+    // (the stratum's chain is live.)  One pass over the counts: for the previous step of the stratum
+    // `counts < ratio * max(counts)` when the host predicted that none would be (_kmeans.py:1645), else
+    // `(self._counts == 0).any()` before this step (:2037).  Either finding stops the chain HERE: this step's
+    // M-step and everything after it see idx >= *halt.
     const GAS int32_t *prev = gp(sdesc.prev_report);
     int z = 0;
     double mx = -inf;
@@ -958,7 +964,7 @@ __global__ __launch_bounds__(256) void k_step_assign(const StepDev *__restrict__
       z |= (cj == 0.0);
       mx = cj > mx ? cj : mx;
     }
-    if ((st.flags & 2) && z) __hip_atomic_fetch_or(&st.report[0], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    int any_low = 0;
     if (st.flags & 4) {
 #pragma unroll
       for (int off = 32; off >= 1; off >>= 1) {
@@ -974,7 +980,18 @@ __global__ __launch_bounds__(256) void k_step_assign(const StepDev *__restrict__
       int low = 0;
       for (int j = tid; j < st.K; j += 256) low += st.counts[j] < thr;
       if (low) __hip_atomic_fetch_add((GAS int32_t *)prev + 1, low, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      __syncthreads();  // sd is reused below
+      any_low = __syncthreads_or(low);
+    }
+    const int any_z = __syncthreads_or((st.flags & 2) ? z : 0);  // (also: sd is reused below)
+    if (tid == 0) {
+      if (any_low) {
+        *gp(sdesc.halt) = st.idx;
+        *gp(sdesc.reason) = HAMSM_STOP_LOW;
+      } else if (any_z) {
+        st.report[0] = 1;
+        *gp(sdesc.halt) = st.idx;
+        *gp(sdesc.reason) = HAMSM_STOP_ZERO;
+      }
     }
   }
   // centroids are the MFMA's A operand (rows), the 16 batch rows its B operand (columns): lane l accumulates, for
@@ -1133,7 +1150,8 @@ __global__ __launch_bounds__(256) void k_step_update(const StepDev *__restrict__
                                                      int KS) {
   SPROF_ID
   SPROF(1, 0)
-  const StepG st(load_step<BYVAL>(steps, pk, blockIdx.y));
+  const StepDev sdesc = load_step<BYVAL>(steps, pk, blockIdx.y);
+  const StepG st(sdesc);
   if (blockIdx.x * 4 >= st.K) return;
   extern __shared__ int lds_i[];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -1144,6 +1162,7 @@ __global__ __launch_bounds__(256) void k_step_update(const StepDev *__restrict__
   const int j = blockIdx.x * 4 + wv;
   if (j >= st.K) return;
   const long long n_b = st.n_b;
+  const int hv = *gp(sdesc.halt);
   const int mc = st.mcnt[j];
   unsigned long long mine = st.mlist[(size_t)j * MCAP + lane];  // entries past mc are stale: masked below
   const double cnt0 = st.counts[j];
@@ -1154,6 +1173,7 @@ __global__ __launch_bounds__(256) void k_step_update(const StepDev *__restrict__
     c0[h] = (k < D) ? st.C[(size_t)j * D + k] : 0.0;
   }
   SPROF_W(1, 1)
+  if (st.idx >= hv) return;  // the stratum's chain stopped before this step
   if (mc == 0) return;  // no member: wsum = 0, centre unchanged (pyx:105-108)
   if (lane == 0) st.mcnt[j] = 0;  // ready for the stratum's next step
   const bool listed = mc <= MCAP;
@@ -1293,35 +1313,146 @@ __global__ __launch_bounds__(256) void k_step_update(const StepDev *__restrict__
   SPROF_FLUSH(1)
 }
 
-// after the update: number of centroids with count < ratio * max(count)  (_kmeans.py:1645)
-__global__ __launch_bounds__(256) void k_step_check(const StepDev *__restrict__ steps, double ratio) {
-  const StepG st(load_step<false>(steps, StepPack{}, blockIdx.x));
-  if (!(st.flags & 1)) return;
-  __shared__ double smax[256];
-  __shared__ int slow[256];
+// block-wide reductions over 256 threads (4 waves); every thread gets the result
+__device__ __forceinline__ double block_max_f64(double v, double *sh /*[4]*/) {
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) {
+    double o = __shfl_xor(v, off, 64);
+    v = o > v ? o : v;
+  }
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+  __syncthreads();
+  v = sh[0];
+#pragma unroll
+  for (int w = 1; w < 4; w++) v = sh[w] > v ? sh[w] : v;
+  return v;
+}
+__device__ __forceinline__ int block_sum_i32(int v, int *sh /*[4]*/) {
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+  __syncthreads();
+  return sh[0] + sh[1] + sh[2] + sh[3];
+}
+
+// the low-count test of a stratum's LAST step when the host predicted that no count would be low (every other step's
+// test rides on the next E-step): count < ratio * max(count)  (_kmeans.py:1645)
+__global__ __launch_bounds__(256) void k_step_check(const StepDev *__restrict__ steps, double ratio, int n_steps) {
+  const StepDev sdesc = load_step<false>(steps, StepPack{}, blockIdx.x);
+  const StepG st(sdesc);
+  if (!(st.flags & 1) || sdesc.perm || st.idx >= *gp(sdesc.halt)) return;
+  __shared__ double shd[4];
+  __shared__ int shi[4];
   double mx = -__builtin_huge_val();
   for (int j = threadIdx.x; j < st.K; j += 256) mx = st.counts[j] > mx ? st.counts[j] : mx;
-  smax[threadIdx.x] = mx;
-  __syncthreads();
-  for (int o = 128; o >= 1; o >>= 1) {
-    if (threadIdx.x < o) smax[threadIdx.x] = smax[threadIdx.x + o] > smax[threadIdx.x] ? smax[threadIdx.x + o] : smax[threadIdx.x];
-    __syncthreads();
-  }
-  const double thr = ratio * smax[0];
+  mx = block_max_f64(mx, shd);
+  const double thr = ratio * mx;
   int low = 0;
   for (int j = threadIdx.x; j < st.K; j += 256) low += st.counts[j] < thr;
-  slow[threadIdx.x] = low;
-  __syncthreads();
-  for (int o = 128; o >= 1; o >>= 1) {
-    if (threadIdx.x < o) slow[threadIdx.x] += slow[threadIdx.x + o];
+  low = block_sum_i32(low, shi);
+  if (threadIdx.x == 0 && low) {
+    st.report[1] = low;
+    *gp(sdesc.halt) = n_steps;  // nothing left to skip; the reason tells the host to finish the step
+    *gp(sdesc.reason) = HAMSM_STOP_LOW;
+  }
+}
+
+// Re-seeding of low-count centroids on the device (_kmeans.py:1643-1673), for steps that carry the head of the host's
+// `permutation(n_b)`: to_reassign = counts < ratio * max; the i-th of them (ascending centroid index) becomes batch
+// row perm[i]; their counts become min(counts[~to_reassign]).  One workgroup per step.  When the prediction behind
+// the permutation fails (nothing low, or more than the rule / the supplied head allows) the stratum's chain stops.
+template <typename XT, bool BYVAL>
+__global__ __launch_bounds__(256) void k_step_reassign(const StepDev *__restrict__ steps, const StepPack pk, int64_t ldx, int D,
+                                                       int KS, double ratio) {
+  const StepDev sdesc = load_step<BYVAL>(steps, pk, blockIdx.x);
+  const StepG st(sdesc);
+  if (!(st.flags & 1) || !sdesc.perm || st.idx >= *gp(sdesc.halt)) return;
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const double inf = __builtin_huge_val();
+  __shared__ double shd[4];
+  __shared__ int shi[4];
+  __shared__ int lj[256], lr[256];
+  double mx = -inf;
+  for (int j = tid; j < st.K; j += 256) mx = st.counts[j] > mx ? st.counts[j] : mx;
+  mx = block_max_f64(mx, shd);
+  const double thr = ratio * mx;
+  int low = 0;
+  double mn = -inf;  // max of the negated = min over the centroids that stay
+  for (int j = tid; j < st.K; j += 256) {
+    double cj = st.counts[j];
+    if (cj < thr) low++;
+    else mn = -cj > mn ? -cj : mn;
+  }
+  low = block_sum_i32(low, shi);
+  const double new_count = -block_max_f64(mn, shd);  // :1672 np.min(weight_sums[~to_reassign])
+  if (tid == 0) st.report[1] = low;
+  int why = 0;
+  if (low == 0) why = HAMSM_STOP_UNUSED;
+  else if (low > sdesc.n_perm || (double)low > 0.5 * (double)st.n_b) why = HAMSM_STOP_CAP;  // :1647
+  if (why) {
+    if (tid == 0) {
+      *gp(sdesc.halt) = st.idx + 1;
+      *gp(sdesc.reason) = why;
+    }
+    return;
+  }
+  const GAS int32_t *perm = gp(sdesc.perm);
+  const GAS XT *X = (const GAS XT *)st.X;
+  int base = 0;
+  for (int j0 = 0; j0 < st.K; j0 += 256) {
+    const int j = j0 + tid;
+    const bool flag = j < st.K && st.counts[j] < thr;
+    const unsigned long long bal = __ballot(flag);
+    const int in_wave = __popcll(bal & ((1ull << lane) - 1));
+    __syncthreads();
+    if (lane == 0) shi[wv] = __popcll(bal);
+    __syncthreads();
+    int before = 0, total = 0;
+#pragma unroll
+    for (int w = 0; w < 4; w++) {
+      before += w < wv ? shi[w] : 0;
+      total += shi[w];
+    }
+    if (flag) {
+      const int e = before + in_wave;
+      lj[e] = j;
+      lr[e] = perm[base + e];  // :1655 choice(n_b, replace=False, size=n) == permutation(n_b)[:n]
+    }
+    __syncthreads();
+    for (int e = wv; e < total; e += 4) {  // one wave per re-seeded centroid
+      const int jc = lj[e];
+      const long long r = lr[e];
+      const long long f = st.rows ? (long long)st.rows[r] : r;
+      double v[2];
+#pragma unroll
+      for (int h = 0; h < 2; h++) {
+        const int k = lane + 64 * h;
+        v[h] = (k < D) ? (double)X[f * ldx + k] : 0.0;
+        if (k < D) {
+          st.C[(size_t)jc * D + k] = v[h];  // :1667
+          st.Bpack[((size_t)(jc >> 4) * KS + (k >> 2)) * 64 + (k & 3) * 16 + (jc & 15)] = v[h];
+        }
+      }
+      double a = 0.0;
+      for (int k = 0; k < D; k++) {
+        double vk = readlane_f64(v[k < 64 ? 0 : 1], k & 63);
+        a = __builtin_fma(vk, vk, a);
+      }
+      if (lane == 0) {
+        st.csq[jc] = a;
+        st.counts[jc] = new_count;
+      }
+    }
+    base += total;
     __syncthreads();
   }
-  if (threadIdx.x == 0) st.report[1] = slow[0];
 }
 
 template <typename XT, int KS, int RT, bool BYVAL>
 static void launch_step_kernels(hamsm_ctx *c, hipStream_t q, const StepDev *d_steps, const StepPack &pk, int ny,
-                                long long max_nb, int maxK, int64_t ldx, double ratio) {
+                                long long max_nb, int maxK, int64_t ldx, double ratio, bool any_perm) {
   constexpr int JB = KS <= 4 ? 8 : (KS <= 8 ? 4 : (KS <= 16 ? 2 : 1));
   dim3 ga((unsigned)((max_nb + 16 * RT - 1) / (16 * RT)), (unsigned)ny);
   hipLaunchKernelGGL((k_step_assign<XT, KS, JB, RT, BYVAL>), ga, dim3(256), 0, q, d_steps, pk, ldx, c->D, ratio);
@@ -1331,33 +1462,35 @@ static void launch_step_kernels(hamsm_ctx *c, hipStream_t q, const StepDev *d_st
     hipLaunchKernelGGL((k_step_update<XT, 1, BYVAL>), gu, dim3(256), lds, q, d_steps, pk, ldx, c->D, c->KS);
   else
     hipLaunchKernelGGL((k_step_update<XT, 2, BYVAL>), gu, dim3(256), lds, q, d_steps, pk, ldx, c->D, c->KS);
+  if (any_perm)
+    hipLaunchKernelGGL((k_step_reassign<XT, BYVAL>), dim3((unsigned)ny), dim3(256), 0, q, d_steps, pk, ldx, c->D, c->KS, ratio);
 }
 
 // row tiles per E-step workgroup: as many as the registers allow (RT * KS <= 32) while the launch keeps >= 128 workgroups
 template <typename XT, int KS, bool BYVAL>
 static void launch_step_rt(hamsm_ctx *c, hipStream_t q, const StepDev *d_steps, const StepPack &pk, int ny, long long max_nb,
-                           int maxK, int64_t ldx, double ratio) {
+                           int maxK, int64_t ldx, double ratio, bool any_perm) {
   const long long tiles = (max_nb + 15) / 16 * ny;
   // measured on C3 (10^4 rows, 4 x 250 centroids per call): RT = 1 / 2 / 4 -> 25.0 / 26.5 / 29.0 us per call; fatter
   // workgroups lose more latency hiding than they save in operand traffic, so RT > 1 is opt-in
   static const int rt_cap = getenv("HAMSM_STEP_RT") ? atoi(getenv("HAMSM_STEP_RT")) : 1;
   if constexpr (KS <= 8) {
-    if (tiles >= 4 * 128 && rt_cap >= 4) return launch_step_kernels<XT, KS, 4, BYVAL>(c, q, d_steps, pk, ny, max_nb, maxK, ldx, ratio);
+    if (tiles >= 4 * 128 && rt_cap >= 4) return launch_step_kernels<XT, KS, 4, BYVAL>(c, q, d_steps, pk, ny, max_nb, maxK, ldx, ratio, any_perm);
   }
   if constexpr (KS <= 16) {
-    if (tiles >= 2 * 128 && rt_cap >= 2) return launch_step_kernels<XT, KS, 2, BYVAL>(c, q, d_steps, pk, ny, max_nb, maxK, ldx, ratio);
+    if (tiles >= 2 * 128 && rt_cap >= 2) return launch_step_kernels<XT, KS, 2, BYVAL>(c, q, d_steps, pk, ny, max_nb, maxK, ldx, ratio, any_perm);
   }
-  launch_step_kernels<XT, KS, 1, BYVAL>(c, q, d_steps, pk, ny, max_nb, maxK, ldx, ratio);
+  launch_step_kernels<XT, KS, 1, BYVAL>(c, q, d_steps, pk, ny, max_nb, maxK, ldx, ratio, any_perm);
 }
 
 template <typename XT>
 static int launch_steps(hamsm_ctx *c, hipStream_t q, const StepDev *d_steps, const StepPack &pk, int ny, long long max_nb,
-                        int maxK, int64_t ldx, double ratio) {
+                        int maxK, int64_t ldx, double ratio, bool any_perm) {
   switch (c->KS) {
 #define CASE(KSV)                                                                               \
   case KSV:                                                                                     \
-    if (d_steps) launch_step_rt<XT, KSV, false>(c, q, d_steps, pk, ny, max_nb, maxK, ldx, ratio); \
-    else launch_step_rt<XT, KSV, true>(c, q, d_steps, pk, ny, max_nb, maxK, ldx, ratio);          \
+    if (d_steps) launch_step_rt<XT, KSV, false>(c, q, d_steps, pk, ny, max_nb, maxK, ldx, ratio, any_perm); \
+    else launch_step_rt<XT, KSV, true>(c, q, d_steps, pk, ny, max_nb, maxK, ldx, ratio, any_perm);          \
     break;
     CASE(1) CASE(2) CASE(3) CASE(4) CASE(6) CASE(8) CASE(12) CASE(16) CASE(24) CASE(32)
 #undef CASE
@@ -1368,7 +1501,8 @@ static int launch_steps(hamsm_ctx *c, hipStream_t q, const StepDev *d_steps, con
 
 // steps [0,n): consecutive steps of distinct strata share launches (grid.y)
 static int run_steps(hamsm_ctx *c, const void *X, int dt, int64_t ldx, const int32_t *d_rows, const double *d_w,
-                     const hamsm_step *h_steps, int64_t n_steps, double ratio, int32_t *h_report, int want_zero_flag,
+                     const hamsm_step *h_steps, int64_t n_steps, double ratio, const int32_t *h_perm, int64_t n_perm_total,
+                     int32_t *h_report, int64_t *h_resume, int32_t *h_reason, int want_zero_flag,
                      int32_t **labels_of_first) {
   const size_t esz = dt == HAMSM_F32 ? 4 : 8;
   if (c->D > 128) return hamsm_fail(c, HAMSM_ENOTSUP, "training supports at most 128 features (D=%d)", c->D);
@@ -1379,6 +1513,8 @@ static int run_steps(hamsm_ctx *c, const void *X, int dt, int64_t ldx, const int
     if (s.stratum < 0 || s.stratum >= c->S) return hamsm_fail(c, HAMSM_EINVAL, "bad stratum in step %lld", (long long)i);
     if (c->st[s.stratum].K == 0) return hamsm_fail(c, HAMSM_EUNFIT, "stratum %d has no centroids", s.stratum);
     if (s.n_b < 0 || s.rows_off < 0) return hamsm_fail(c, HAMSM_EINVAL, "bad step %lld", (long long)i);
+    if (s.perm_off >= 0 && (!h_perm || s.n_perm < 0 || s.perm_off + s.n_perm > n_perm_total))
+      return hamsm_fail(c, HAMSM_EINVAL, "step %lld: permutation outside h_perm", (long long)i);
     int64_t hi = (d_rows ? s.rows_off : 0) + s.n_b;
     if (hi > lab_hi) lab_hi = hi;
   }
@@ -1389,7 +1525,8 @@ static int run_steps(hamsm_ctx *c, const void *X, int dt, int64_t ldx, const int
     return o;
   };
   size_t o_steps = take(sizeof(StepDev) * n_steps), o_rep = take(sizeof(int32_t) * 2 * n_steps),
-         o_lab = take(sizeof(int32_t) * (size_t)lab_hi);
+         o_lab = take(sizeof(int32_t) * (size_t)lab_hi), o_halt = take(sizeof(int32_t) * 2 * (size_t)c->S),
+         o_perm = take(sizeof(int32_t) * (size_t)(n_perm_total > 0 ? n_perm_total : 1));
   // the gathered batch copy and the member lists are reused by every launch group: one slot per stratum position,
   // stream-ordered
   const int nslot = c->S < 65535 ? c->S : 65535;
@@ -1420,7 +1557,13 @@ static int run_steps(hamsm_ctx *c, const void *X, int dt, int64_t ldx, const int
     d.flags = (s.flags & 1) | (want_zero_flag ? 2 : 0);
     d.report = (int32_t *)(b + o_rep) + 2 * i;
     d.prev_report = nullptr;
+    d.perm = ((s.flags & 1) && s.perm_off >= 0) ? (const int32_t *)(b + o_perm) + s.perm_off : nullptr;
+    d.n_perm = s.n_perm;
+    d.idx = (int)i;
+    d.halt = (int32_t *)(b + o_halt) + s.stratum;
+    d.reason = (int32_t *)(b + o_halt) + c->S + s.stratum;
   }
+  if (n_steps >= 0x7f000000) return hamsm_fail(c, HAMSM_EINVAL, "too many steps");
   // the low-count test of a step is evaluated by the E-step of the stratum's next step (the counts do not change in
   // between); only a stratum's last step needs a launch of its own
   std::vector<int64_t> last_of(c->S, -1), tail_checks;
@@ -1428,14 +1571,14 @@ static int run_steps(hamsm_ctx *c, const void *X, int dt, int64_t ldx, const int
     if (h_steps[i].n_b <= 0) continue;  // launches nothing: cannot evaluate anything either
     const int s = h_steps[i].stratum;
     const int64_t p = last_of[s];
-    if (p >= 0 && (sd[p].flags & 1)) {
+    if (p >= 0 && (sd[p].flags & 1) && !sd[p].perm) {
       sd[i].flags |= 4;
       sd[i].prev_report = sd[p].report;
     }
     last_of[s] = i;
   }
   for (int s = 0; s < c->S; s++)
-    if (last_of[s] >= 0 && (sd[last_of[s]].flags & 1)) tail_checks.push_back(last_of[s]);
+    if (last_of[s] >= 0 && (sd[last_of[s]].flags & 1) && !sd[last_of[s]].perm) tail_checks.push_back(last_of[s]);
   // launch groups = maximal runs of distinct strata; member-list slot = position inside the run
   std::vector<int64_t> gstart;
   {
@@ -1461,6 +1604,10 @@ static int run_steps(hamsm_ctx *c, const void *X, int dt, int64_t ldx, const int
   if (labels_of_first) *labels_of_first = sd[0].labels;
   HIPCHK(c, hipMemcpyAsync(b + o_steps, sd.data(), sizeof(StepDev) * n_steps, hipMemcpyHostToDevice, c->stream));
   HIPCHK(c, hipMemsetAsync(b + o_rep, 0, sizeof(int32_t) * 2 * n_steps, c->stream));
+  HIPCHK(c, hipMemsetAsync(b + o_halt, 0x7f, sizeof(int32_t) * c->S, c->stream));  // stop words: 0x7f7f7f7f = never
+  HIPCHK(c, hipMemsetAsync(b + o_halt + sizeof(int32_t) * c->S, 0, sizeof(int32_t) * c->S, c->stream));
+  if (n_perm_total > 0)
+    HIPCHK(c, hipMemcpyAsync(b + o_perm, h_perm, sizeof(int32_t) * (size_t)n_perm_total, hipMemcpyHostToDevice, c->stream));
   HIPCHK(c, hipMemsetAsync(b + o_mc, 0, sizeof(int32_t) * (size_t)nslot * Kmax, c->stream));
   const StepDev *d_steps = (const StepDev *)(b + o_steps);
   hamsm_timer_begin(c);
@@ -1493,10 +1640,12 @@ static int run_steps(hamsm_ctx *c, const void *X, int dt, int64_t ldx, const int
     for (int l = 0; l < n_lanes; l++) {
       long long max_nb = 0;
       int maxK = 0, ny = 0;
+      bool any_perm = false;
       std::vector<int64_t> mine;
       for (int64_t q = i; q < j; q++) {
         if (n_lanes > 1 && h_steps[q].stratum % n_lanes != l) continue;
         mine.push_back(q);
+        any_perm = any_perm || sd[q].perm;
         if (h_steps[q].n_b > max_nb) max_nb = h_steps[q].n_b;
         if (c->st[h_steps[q].stratum].K > maxK) maxK = c->st[h_steps[q].stratum].K;
       }
@@ -1517,8 +1666,8 @@ static int run_steps(hamsm_ctx *c, const void *X, int dt, int64_t ldx, const int
           pk.n_next = nn;
         }
       }
-      rc = (dt == HAMSM_F32) ? launch_steps<float>(c, lanes[l], dptr, pk, ny, max_nb, maxK, ldx, ratio)
-                             : launch_steps<double>(c, lanes[l], dptr, pk, ny, max_nb, maxK, ldx, ratio);
+      rc = (dt == HAMSM_F32) ? launch_steps<float>(c, lanes[l], dptr, pk, ny, max_nb, maxK, ldx, ratio, any_perm)
+                             : launch_steps<double>(c, lanes[l], dptr, pk, ny, max_nb, maxK, ldx, ratio, any_perm);
       if (rc) return rc;
     }
   }
@@ -1526,21 +1675,42 @@ static int run_steps(hamsm_ctx *c, const void *X, int dt, int64_t ldx, const int
     HIPCHK(c, hipEventRecord(c->ev_join[l - 1], lanes[l]));
     HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_join[l - 1], 0));
   }
-  for (int64_t i : tail_checks) hipLaunchKernelGGL(k_step_check, dim3(1), dim3(256), 0, c->stream, d_steps + i, ratio);
+  for (int64_t i : tail_checks)
+    hipLaunchKernelGGL(k_step_check, dim3(1), dim3(256), 0, c->stream, d_steps + i, ratio, (int)n_steps);
   hamsm_timer_end(c, ST_STEP);
   HIPCHK(c, hipGetLastError());
   if (h_report) {
+    std::vector<int32_t> hw(2 * (size_t)c->S);
     HIPCHK(c, hipMemcpyAsync(h_report, b + o_rep, sizeof(int32_t) * 2 * n_steps, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(hw.data(), b + o_halt, sizeof(int32_t) * 2 * c->S, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (h_resume && h_reason) {
+      // stop word -> first step of the stratum that was not applied
+      for (int s = 0; s < c->S; s++) {
+        h_reason[s] = hw[c->S + s];
+        h_resume[s] = n_steps;
+      }
+      for (int64_t i = n_steps - 1; i >= 0; i--) {
+        const int s = h_steps[i].stratum;
+        if (i >= hw[s]) h_resume[s] = i;
+      }
+    }
   }
   return HAMSM_OK;
 }
 
 extern "C" int hamsm_minibatch_run(hamsm_ctx *c, const void *X, int dt, int64_t ldx, const int32_t *d_rows, const double *d_w,
-                                   const hamsm_step *h_steps, int64_t n_steps, double ratio, int32_t *h_report) {
+                                   const hamsm_step *h_steps, int64_t n_steps, double ratio, const int32_t *h_perm,
+                                   int64_t n_perm_total, int32_t *h_report, int64_t *h_resume, int32_t *h_reason) {
   if (c->st.empty()) return hamsm_fail(c, HAMSM_EINVAL, "set_geometry first");
+  if (!h_report || !h_resume || !h_reason) return hamsm_fail(c, HAMSM_EINVAL, "h_report / h_resume / h_reason missing");
+  for (int s = 0; s < c->S; s++) {
+    h_resume[s] = n_steps;
+    h_reason[s] = HAMSM_STOP_NONE;
+  }
   if (n_steps <= 0) return HAMSM_OK;
-  return run_steps(c, X, dt, ldx, d_rows, d_w, h_steps, n_steps, ratio, h_report, 1, nullptr);
+  return run_steps(c, X, dt, ldx, d_rows, d_w, h_steps, n_steps, ratio, h_perm, n_perm_total, h_report, h_resume, h_reason, 1,
+                   nullptr);
 }
 
 extern "C" int hamsm_minibatch_step(hamsm_ctx *c, int s, const void *X, int dt, int64_t ldx, const int32_t *rows, int64_t n_b,
@@ -1549,9 +1719,9 @@ extern "C" int hamsm_minibatch_step(hamsm_ctx *c, int s, const void *X, int dt, 
   if (c->st[s].K == 0) return hamsm_fail(c, HAMSM_EUNFIT, "stratum %d has no centroids", s);
   if (n_b <= 0) return HAMSM_OK;
   // the row list becomes the step's d_rows (offset 0): labels scratch is indexed by batch position
-  hamsm_step st{s, 0, 0, 0, n_b};
+  hamsm_step st{s, 0, 0, 0, n_b, -1, 0, 0};
   int32_t *lab = nullptr;
-  int rc = run_steps(c, X, dt, ldx, rows, wf, &st, 1, 0.0, nullptr, 0, &lab);
+  int rc = run_steps(c, X, dt, ldx, rows, wf, &st, 1, 0.0, nullptr, 0, nullptr, nullptr, nullptr, 0, &lab);
   if (rc) return rc;
   if (labels_out) HIPCHK(c, hipMemcpyAsync(labels_out, lab, sizeof(int32_t) * n_b, hipMemcpyDeviceToDevice, c->stream));
   return HAMSM_OK;

@@ -182,22 +182,29 @@ class StratumKMeans:
         h.minibatch_step(self.stratum, d_X, x_dtype, ldx, d_rows, n_b, d_w)
         self.__dict__["_device_newer"] = True
         self._counts_cache = None  # fetched lazily (one small D2H per step)
+        self._last_n_re = 0
         if do_reassign and self.reassignment_ratio > 0:
-            # _mini_batch_step, _kmeans.py:1643-1673
-            weight_sums = h.get_counts(self.stratum)
-            to_reassign = weight_sums < self.reassignment_ratio * weight_sums.max()
-            if to_reassign.sum() > 0.5 * n_b:
-                keep = np.argsort(weight_sums)[int(0.5 * n_b):]
-                to_reassign[keep] = False
-            n_re = int(to_reassign.sum())
-            if n_re:
-                new_rows = rs.choice(n_b, replace=False, size=n_re)
-                new_count = float(np.min(weight_sums[~to_reassign]))
-                h.reassign(self.stratum, d_X, x_dtype, ldx, d_rows, np.where(to_reassign)[0], new_rows, new_count)
-                weight_sums[to_reassign] = new_count
-            self._counts_cache = weight_sums
+            self._host_reassign(d_X, x_dtype, ldx, d_rows, n_b)
         self.n_steps_ = self.__dict__.get("n_steps_", 0) + 1
         return self
+
+    def _host_reassign(self, d_X, x_dtype, ldx, d_rows, n_b):
+        """`_mini_batch_step`, `_kmeans.py:1643-1673`, for the step just applied on the device."""
+        h = self._h
+        weight_sums = h.get_counts(self.stratum)
+        to_reassign = weight_sums < self.reassignment_ratio * weight_sums.max()
+        if to_reassign.sum() > 0.5 * n_b:
+            keep = np.argsort(weight_sums)[int(0.5 * n_b):]
+            to_reassign[keep] = False
+        n_re = int(to_reassign.sum())
+        if n_re:
+            new_rows = self._random_state.choice(n_b, replace=False, size=n_re)
+            new_count = float(np.min(weight_sums[~to_reassign]))
+            h.reassign(self.stratum, d_X, x_dtype, ldx, d_rows, np.where(to_reassign)[0], new_rows, new_count)
+            weight_sums[to_reassign] = new_count
+        self._counts_cache = weight_sums
+        self._last_n_re = n_re
+        return n_re
 
     # -- host-array entry point used by the reference's training loop (_clustering.py:909-911) ---
     def partial_fit(self, X, y=None, sample_weight=None):

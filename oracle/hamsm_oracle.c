@@ -706,28 +706,90 @@ int hamsm_kmeans_seed_multi(hamsm_ctx *c, int n_items, const int32_t *stratum, c
 }
 
 int hamsm_minibatch_run(hamsm_ctx *c, const void *X, int dt, int64_t ldx, const int32_t *rows, const double *wf,
-                        const hamsm_step *steps, int64_t n_steps, double ratio, int32_t *report) {
+                        const hamsm_step *steps, int64_t n_steps, double ratio, const int32_t *perm, int64_t n_perm_total,
+                        int32_t *report, int64_t *resume, int32_t *reason) {
   size_t esz = dt == HAMSM_F32 ? 4 : 8;
-  for (int64_t i = 0; i < n_steps; i++) {
+  char *stopped = (char *)calloc((size_t)c->S, 1);
+  for (int s = 0; s < c->S; s++) {
+    resume[s] = n_steps;
+    reason[s] = HAMSM_STOP_NONE;
+  }
+  memset(report, 0, sizeof(int32_t) * 2 * (size_t)n_steps);
+  int rc = HAMSM_OK;
+  for (int64_t i = 0; i < n_steps && rc == HAMSM_OK; i++) {
     const hamsm_step *st = &steps[i];
-    if (st->stratum < 0 || st->stratum >= c->S) return fail(c, HAMSM_EINVAL, "bad stratum in step %lld", (long long)i);
-    stratum_t *t = &c->st[st->stratum];
+    const int s = st->stratum;
+    if (s < 0 || s >= c->S) {
+      rc = fail(c, HAMSM_EINVAL, "bad stratum in step %lld", (long long)i);
+      break;
+    }
+    if (st->perm_off >= 0 && (st->n_perm < 0 || st->perm_off + st->n_perm > n_perm_total)) {
+      rc = fail(c, HAMSM_EINVAL, "step %lld: permutation outside h_perm", (long long)i);
+      break;
+    }
+    if (stopped[s]) { /* the chain of this stratum ended at an earlier step */
+      if (resume[s] == n_steps) resume[s] = i;
+      continue;
+    }
+    stratum_t *t = &c->st[s];
+    const char *Xs = (const char *)X + (size_t)st->x_off * ldx * esz;
+    const int32_t *rs = rows ? rows + st->rows_off : NULL;
     int zero = 0;
     for (int j = 0; j < t->K; j++) zero |= (t->counts[j] == 0.0); /* _kmeans.py:2037 */
     report[2 * i] = zero;
-    int rc = hamsm_minibatch_step(c, st->stratum, (const char *)X + (size_t)st->x_off * ldx * esz, dt, ldx,
-                                  rows + st->rows_off, st->n_b, wf ? wf + st->x_off : NULL, NULL);
-    if (rc) return rc;
-    int low = 0;
-    if (st->flags & 1) { /* _kmeans.py:1645 */
-      double mx = t->counts[0];
-      for (int j = 1; j < t->K; j++)
-        if (t->counts[j] > mx) mx = t->counts[j];
-      for (int j = 0; j < t->K; j++) low += (t->counts[j] < ratio * mx);
+    if (zero) {
+      stopped[s] = 1;
+      resume[s] = i;
+      reason[s] = HAMSM_STOP_ZERO;
+      continue;
     }
+    rc = hamsm_minibatch_step(c, s, Xs, dt, ldx, rs, st->n_b, wf ? wf + st->x_off : NULL, NULL);
+    if (rc) break;
+    if (!(st->flags & 1)) continue;
+    /* _kmeans.py:1643-1673 */
+    double mx = t->counts[0];
+    for (int j = 1; j < t->K; j++)
+      if (t->counts[j] > mx) mx = t->counts[j];
+    int low = 0;
+    for (int j = 0; j < t->K; j++) low += (t->counts[j] < ratio * mx);
     report[2 * i + 1] = low;
+    if (st->perm_off < 0) {
+      if (low) {
+        stopped[s] = 1;
+        reason[s] = HAMSM_STOP_LOW;
+      }
+      continue;
+    }
+    if (low == 0) {
+      stopped[s] = 1;
+      reason[s] = HAMSM_STOP_UNUSED;
+      continue;
+    }
+    if (low > st->n_perm || (double)low > 0.5 * (double)st->n_b) { /* :1647 */
+      stopped[s] = 1;
+      reason[s] = HAMSM_STOP_CAP;
+      continue;
+    }
+    int32_t *cl = (int32_t *)malloc(sizeof(int32_t) * (size_t)low);
+    int64_t *br = (int64_t *)malloc(sizeof(int64_t) * (size_t)low);
+    double new_count = 0.0;
+    int k = 0, have = 0;
+    for (int j = 0; j < t->K; j++) {
+      if (t->counts[j] < ratio * mx) {
+        cl[k] = j;
+        br[k] = perm[st->perm_off + k]; /* :1655 choice(n_b, replace=False, size=n) == permutation(n_b)[:n] */
+        k++;
+      } else if (!have || t->counts[j] < new_count) { /* :1672 np.min(weight_sums[~to_reassign]) */
+        new_count = t->counts[j];
+        have = 1;
+      }
+    }
+    rc = hamsm_reassign(c, s, Xs, dt, ldx, rs, cl, br, low, new_count);
+    free(cl);
+    free(br);
   }
-  return HAMSM_OK;
+  free(stopped);
+  return rc;
 }
 
 /* --- single-process stand-ins for the exchange step (tests drive N>1 through gloo on the host) */
