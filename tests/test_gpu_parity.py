@@ -272,6 +272,89 @@ def test_training_primitives_match_oracle(hip_h, oracle_h, D, dtype, weighted, s
     assert len(np.unique(a["chosen"])) > 1
 
 
+@pytest.mark.parametrize("D,dtype,weighted,K", [(30, np.float32, False, 250), (70, np.float64, True, 600),
+                                                (10, np.float32, True, 40)])
+def test_fused_run_with_reseeding_matches_oracle(hip_h, oracle_h, D, dtype, weighted, K):
+    """hamsm_minibatch_run with the low-count rule on the device: re-seeding from permutation heads (K spanning several
+    256-centroid chunks, rows of more than 64 features, weights), and every way a stratum's chain can stop --
+    HAMSM_STOP_LOW / UNUSED / CAP / ZERO -- with the same resume index, report and centroids as the oracle."""
+    S, n, ncall = 5, 6000, 6
+    rec = []
+    for h in (oracle_h, hip_h):
+        rng = np.random.default_rng(21)
+        _setup(h, D, S, 1, rng, fit=[False] * S)
+        X = (rng.normal(size=(n * ncall, D)) * 2 + rng.integers(0, 6, (n * ncall, 1)) * 5).astype(dtype)
+        w = rng.exponential(size=n * ncall)
+        dt = 0 if dtype == np.float32 else 1
+        d_X, d_w = h.to_device(X), h.to_device(w)
+        # every call: its own ascending row list per stratum (strata share the frames of a call)
+        rows, steps = [], []
+        cents = {}
+        for s in range(S):
+            Cm = X[rng.choice(n, K, replace=False)].astype(np.float64) + rng.normal(size=(K, D)) * 0.1
+            counts = rng.integers(50, 400, K).astype(np.float64)
+            if s in (0, 4):
+                counts[rng.choice(K, K // 3, replace=False)] = 0.01  # low at the first test: re-seeded from the permutation
+            if s == 1:
+                counts[5] = 0.5                                     # low, but the host predicted "none": STOP_LOW
+            if s == 3:
+                counts[7] = 0.0                                     # zero before its second step: STOP_ZERO
+            h.set_centroids(s, Cm, counts=counts)
+            cents[s] = (Cm, counts)
+        perm, off = [], 0
+        prng = np.random.RandomState(3)
+        for g in range(ncall):
+            for s in range(S):
+                nb = 900 + 37 * s + 11 * g
+                r = np.sort(rng.choice(n, nb, replace=False)).astype(np.int32)
+                st = np.zeros(1, dtype=h.STEP_DTYPE)
+                st["stratum"], st["flags"] = s, int(g % 2 == 0)
+                st["x_off"], st["rows_off"], st["n_b"] = g * n, sum(len(x) for x in rows), nb
+                st["perm_off"], st["n_perm"] = -1, 0
+                give = (s in (0, 4) and g == 0) or (s == 2 and g == 2)
+                if st["flags"][0] and give:
+                    head = prng.permutation(nb)[: (K if s != 4 else 1)].astype(np.int32)  # s == 4: head too short -> CAP
+                    st["perm_off"], st["n_perm"] = off, len(head)
+                    perm.append(head)
+                    off += len(head)
+                if s == 3 and g == 0:
+                    st["flags"] = 0
+                rows.append(r)
+                steps.append(st)
+        d_rows = h.to_device(np.concatenate(rows))
+        steps = np.concatenate(steps)
+        report, resume, reason = h.minibatch_run(d_X, dt, D, d_rows, d_w if weighted else None, steps, 0.01, np.concatenate(perm))
+        out = dict(report=report, resume=resume, reason=reason)
+        for s in range(S):
+            out[f"c{s}"] = h.get_centroids(s)
+        # stratum 1 stopped with STOP_LOW: settle it like the host does and resume its chain with a long enough head
+        if reason[1] == h.STOP_LOW:
+            cnt = h.get_counts(1)
+            to = cnt < 0.01 * cnt.max()
+            h.reassign(1, d_X, dt, D, d_rows.offset(int(steps[1]["rows_off"])), np.where(to)[0], [11] * int(to.sum()),
+                       float(cnt[~to].min()))
+            rest = steps[int(resume[1]):][steps[int(resume[1]):]["stratum"] == 1].copy()
+            rest["perm_off"], rest["n_perm"] = -1, 0
+            r2 = h.minibatch_run(d_X, dt, D, d_rows, d_w if weighted else None, rest, 0.01)
+            out["resumed"] = r2 + h.get_centroids(1)
+        rec.append(out)
+    a, g = rec
+    # which stop each stratum meets depends on the data (weights move counts across the threshold); these two do not
+    assert a["reason"][3] == oracle_h.STOP_ZERO and a["resume"][3] == 3
+    assert a["reason"][4] == oracle_h.STOP_CAP and a["resume"][4] == 4 + S
+    if (D, K) == (30, 250):
+        assert list(a["reason"]) == [0, oracle_h.STOP_LOW, oracle_h.STOP_UNUSED, oracle_h.STOP_ZERO, oracle_h.STOP_CAP]
+    for k in ("report", "resume", "reason"):
+        assert np.array_equal(a[k], g[k]), (k, a[k], g[k])
+    assert a["report"][0, 1] > 1  # stratum 0: re-seeded on the device (more low counts than stratum 4's head held)
+    for s in range(S):
+        for i, (x, y) in enumerate(zip(a[f"c{s}"], g[f"c{s}"])):
+            assert np.array_equal(x, y), (s, i)
+    assert ("resumed" in a) == ("resumed" in g)
+    for i, (x, y) in enumerate(zip(a.get("resumed", ()), g.get("resumed", ()))):
+        assert np.array_equal(x, y), ("resumed", i)
+
+
 @pytest.mark.parametrize("case", GOLDEN_CASES)
 def test_pipeline_on_reference_goldens(hip_h, case):
     """The full modelWE path on the HIP library reproduces the REAL reference's outputs
