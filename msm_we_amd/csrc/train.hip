@@ -13,6 +13,14 @@
 
 typedef double v4f64 __attribute__((ext_vector_type(4)));
 
+// Pointers that arrive inside a descriptor are generic to the compiler (flat_load/flat_atomic, which tie up both
+// memory counters); every one of them is device memory, so the kernels address them as such.
+#define GAS __attribute__((address_space(1)))
+template <typename T>
+__device__ __forceinline__ GAS T *gp(T *p) {
+  return (GAS T *)p;
+}
+
 // ---- prepass: raw bin or -1 (basis/target) per frame + per-iteration histogram --------------------
 __global__ void k_prepass(MapperDev m, const double *__restrict__ p, const int64_t *__restrict__ offs, int64_t n_iters,
                           int S, int32_t *__restrict__ bin, unsigned long long *__restrict__ hist, int *err) {
@@ -173,13 +181,14 @@ struct SeedItem {
   const double *u;      // [(K-1)*L]
   long long n, first;
   int K, L;
-  double *XbT;          // [D][n]  feature-major copy of the batch (coalesced over rows)
+  void *XbT;            // [D][n]  feature-major copy of the batch (coalesced over rows): double, or the frames' type
   double *w, *xsq, *closest, *cum, *cand /*[L][n]*/, *chunk_tot;
   double *C;            // stratum centroids [K][D]
   long long *chosen;    // [K]
 };
 
-template <typename XT>
+// BT: element type of the feature-major copy (XT for the on-chip kernel, double for the general one)
+template <typename XT, typename BT>
 __global__ void k_seed_gather(const SeedItem *__restrict__ items, int64_t ldx, int D) {
   const SeedItem it = items[blockIdx.y];
   int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -190,7 +199,7 @@ __global__ void k_seed_gather(const SeedItem *__restrict__ items, int64_t ldx, i
   double a = 0.0;
   for (int k = 0; k < D; k++) {
     double v = (double)X[f * ldx + k];
-    it.XbT[(size_t)k * it.n + i] = v;
+    ((BT *)it.XbT)[(size_t)k * it.n + i] = (BT)v;  // (exact: BT is double or the type v came from)
     a = __builtin_fma(v, v, a);  // row_norms(X, squared=True) restated as an fma chain (oracle sqnorm_chain)
   }
   it.xsq[i] = a;
@@ -216,6 +225,7 @@ __device__ __forceinline__ double seed_reduce(double *part, double *grp, int tid
 __global__ __launch_bounds__(SEED_T) void k_seed(const SeedItem *__restrict__ items, int D) {
   extern __shared__ double sm[];
   const SeedItem it = items[blockIdx.x];
+  const GAS double *itu = gp(it.u);
   const long long n = it.n;
   const int K = it.K, L = it.L;
   double *crow = sm;                         // [LMAX][D] candidate rows
@@ -226,7 +236,7 @@ __global__ __launch_bounds__(SEED_T) void k_seed(const SeedItem *__restrict__ it
   __shared__ double s_pot;
   __shared__ int s_best;
   const int tid = threadIdx.x;
-  const double *XbT = it.XbT;
+  const double *XbT = (const double *)it.XbT;
 
   // first centre (_kmeans.py:225-238)
   for (int k = tid; k < D; k += SEED_T) {
@@ -274,7 +284,7 @@ __global__ __launch_bounds__(SEED_T) void k_seed(const SeedItem *__restrict__ it
     // searchsorted(cum, u*pot, side='left') without materialising cum: last chunk whose base is < v, then
     // the running sum inside it (cum[i] = base + loc, the oracle's values)
     if (tid < L) {
-      const double v = it.u[(size_t)(cc - 1) * L + tid] * s_pot;  // :243
+      const double v = itu[(size_t)(cc - 1) * L + tid] * s_pot;  // :243
       long long lo = 0, hi = nch;  // first chunk whose END value >= v  <=> first q with base[q+1] >= v
       // chunk q ends with cum = base[q] + tot[q]; recompute per candidate chunk (monotone, so bisect on bases)
       while (hi - lo > 1) {
@@ -387,15 +397,23 @@ __device__ unsigned long long g_seed_prof[16];
 #define PROF_T(idx)
 #endif
 #define SEED_NLDS 3072
-#define SEED_RPT (SEED_NLDS / SEED_T)
+#define SEED_TL 512                       // threads: 2 waves per SIMD, 256 VGPRs each (1024 threads spilled the accumulators)
+#define SEED_LPT (SEED_T / SEED_TL)       // canonical lanes (of the oracle's POT_LANES) per thread
+#define SEED_RPL (SEED_NLDS / SEED_T)     // rows per lane: lane t owns rows t, t + 1024, t + 2048
+#define SEED_RPT (SEED_LPT * SEED_RPL)    // rows per thread
 #define SEED_LFAST 8
-__global__ __launch_bounds__(SEED_T) void k_seed_lds(const SeedItem *__restrict__ items, int D) {
+// XT: element type of the feature-major batch copy (the frames' own type: exact, half the stream for f32);
+// LF: number of candidates per greedy step (2 + int(log K)) -- the accumulators of unused candidates cost 1/8 of the FMAs
+template <typename XT, int LF>
+__global__ __launch_bounds__(SEED_TL) void k_seed_lds(const SeedItem *__restrict__ items, int D) {
   extern __shared__ double sm[];
   const SeedItem it = items[blockIdx.x];
   const int n = (int)it.n;
-  const int K = it.K, L = it.L;
-  double *crow = sm;                                   // [LFAST][D]
-  double *part = crow + SEED_LFAST * D;                // [LFAST][SEED_T]
+  const int K = it.K;
+  constexpr int L = LF;  // (== it.L, checked by the host)
+  const int Dp = (D + 7) & ~7;                         // features padded with zero candidate rows: branch-free k loop
+  double *crow = sm;                                   // [Dp][LFAST]
+  double *part = crow + SEED_LFAST * Dp;               // [LFAST][SEED_T]
   double *grp = part + SEED_LFAST * SEED_T;            // [LFAST][32]
   double *pots = grp + SEED_LFAST * (SEED_T / SEED_GROUP);  // [LFAST]
   double *lw = pots + SEED_LFAST;                      // [n]
@@ -406,42 +424,53 @@ __global__ __launch_bounds__(SEED_T) void k_seed_lds(const SeedItem *__restrict_
   __shared__ double s_pot;
   __shared__ int s_best;
   const int tid = threadIdx.x;
-  const double *XbT = it.XbT;
+  // (generic pointers would make every batch load a flat_load, which shares lgkmcnt with the LDS reads of the loop)
+  const GAS XT *XbT = (const GAS XT *)gp(it.XbT);
+  const GAS double *itu = gp(it.u);
+  GAS double *itC = gp(it.C);
+  GAS long long *itchosen = gp(it.chosen);
+  // row rr of this thread: lane tid + (rr / RPL) * TL, row lane + (rr % RPL) * 1024
+  auto row_of = [&](int rr) { return tid + (rr / SEED_RPL) * SEED_TL + (rr % SEED_RPL) * SEED_T; };
 
-  for (int i = tid; i < n; i += SEED_T) {
-    lw[i] = it.w[i];
-    lxsq[i] = it.xsq[i];
+  for (int i = tid; i < n; i += SEED_TL) {
+    lw[i] = gp(it.w)[i];
+    lxsq[i] = gp(it.xsq)[i];
   }
-  for (int k = tid; k < D; k += SEED_T) {
-    double v = XbT[(size_t)k * n + it.first];
+  for (int e = tid; e < SEED_LFAST * Dp; e += SEED_TL) crow[e] = 0.0;  // (rows D..Dp-1 stay zero: fma(0, x, acc) == acc)
+  __syncthreads();
+  for (int k = tid; k < D; k += SEED_TL) {
+    double v = (double)XbT[(size_t)k * n + it.first];
     crow[k * SEED_LFAST] = v;
-    it.C[k] = v;
+    itC[k] = v;
   }
-  if (tid == 0) it.chosen[0] = it.first;
+  if (tid == 0) itchosen[0] = it.first;
   __syncthreads();
   {
     const double xs0 = lxsq[it.first];
-    double a = 0.0;
 #pragma unroll
-    for (int r = 0; r < SEED_RPT; r++) {
-      int i = tid + r * SEED_T;
-      if (i < n) {
-        double acc = 0.0;
-        for (int k0 = 0; k0 < D; k0 += 8) {
-          double xk[8];
+    for (int lp = 0; lp < SEED_LPT; lp++) {
+      double a = 0.0;
 #pragma unroll
-          for (int q = 0; q < 8; q++) xk[q] = XbT[(size_t)(k0 + q < D ? k0 + q : 0) * n + i];
+      for (int r = 0; r < SEED_RPL; r++) {
+        int i = row_of(lp * SEED_RPL + r);
+        if (i < n) {
+          double acc = 0.0;
+          for (int k0 = 0; k0 < D; k0 += 8) {
+            XT xk[8];
 #pragma unroll
-          for (int q = 0; q < 8; q++)
-            if (k0 + q < D) acc = __builtin_fma(crow[(k0 + q) * SEED_LFAST], xk[q], acc);
+            for (int q = 0; q < 8; q++) xk[q] = XbT[(size_t)(k0 + q < D ? k0 + q : 0) * n + i];
+#pragma unroll
+            for (int q = 0; q < 8; q++)
+              if (k0 + q < D) acc = __builtin_fma(crow[(k0 + q) * SEED_LFAST], (double)xk[q], acc);
+          }
+          double v = ((-2.0 * acc) + xs0) + lxsq[i];
+          v = v > 0.0 ? v : 0.0;
+          lcl[i] = v;
+          a = a + v * lw[i];
         }
-        double v = ((-2.0 * acc) + xs0) + lxsq[i];
-        v = v > 0.0 ? v : 0.0;
-        lcl[i] = v;
-        a = a + v * lw[i];
       }
+      part[tid + lp * SEED_TL] = a;
     }
-    part[tid] = a;
     double s = seed_reduce(part, grp, tid);
     if (tid == 0) s_pot = s;
     __syncthreads();
@@ -481,7 +510,7 @@ __global__ __launch_bounds__(SEED_T) void k_seed_lds(const SeedItem *__restrict_
     __syncthreads();
     PROF_T(1)
     if (tid < L) {
-      const double v = it.u[(size_t)(cc - 1) * L + tid] * s_pot;  // :243
+      const double v = itu[(size_t)(cc - 1) * L + tid] * s_pot;  // :243
       int lo = 0, hi = nch;
       while (hi - lo > 1) {
         int mid = (lo + hi) >> 1;
@@ -515,58 +544,74 @@ __global__ __launch_bounds__(SEED_T) void k_seed_lds(const SeedItem *__restrict_
     PROF_T(2)
     // candidate rows, feature-major [k][LFAST]: one k's L values are contiguous (128-bit LDS reads, each read once
     // per k and reused for all of the thread's rows)
-    for (int e = tid; e < L * D; e += SEED_T) crow[(e % D) * SEED_LFAST + e / D] = XbT[(size_t)(e % D) * n + cid[e / D]];
+    for (int e = tid; e < L * D; e += SEED_TL) crow[(e % D) * SEED_LFAST + e / D] = (double)XbT[(size_t)(e % D) * n + cid[e / D]];
     __syncthreads();
     PROF_T(3)
-    double cnd[SEED_RPT][SEED_LFAST];
+    double cnd[SEED_RPT][LF];
     {
 #pragma unroll
       for (int r = 0; r < SEED_RPT; r++)
 #pragma unroll
-        for (int l = 0; l < SEED_LFAST; l++) cnd[r][l] = 0.0;
-      // dot products: acc[r][l] = fma chain over k of crow[l][k] * x_r[k]
-      for (int k0 = 0; k0 < D; k0 += 4) {
-        double xk[SEED_RPT][4];
-#pragma unroll
-        for (int r = 0; r < SEED_RPT; r++) {
-          int i = tid + r * SEED_T;
-#pragma unroll
-          for (int q = 0; q < 4; q++) xk[r][q] = XbT[(size_t)(k0 + q < D ? k0 + q : 0) * n + (i < n ? i : 0)];
-        }
-#pragma unroll
-        for (int q = 0; q < 4; q++)
-          if (k0 + q < D) {
-            double cr[SEED_LFAST];
-#pragma unroll
-            for (int l = 0; l < SEED_LFAST; l++) cr[l] = crow[(k0 + q) * SEED_LFAST + l];
-#pragma unroll
-            for (int r = 0; r < SEED_RPT; r++)
-#pragma unroll
-              for (int l = 0; l < SEED_LFAST; l++) cnd[r][l] = __builtin_fma(cr[l], xk[r][q], cnd[r][l]);
-          }
-      }
-      double a[SEED_LFAST];
-#pragma unroll
-      for (int l = 0; l < SEED_LFAST; l++) a[l] = 0.0;
+        for (int l = 0; l < LF; l++) cnd[r][l] = 0.0;
+      // dot products: cnd[r][l] = fma chain over k of crow[l][k] * x_r[k]; the batch copy streams from L2 in chunks of
+      // KC features, the next chunk requested before the current one is used
+      constexpr int KC = sizeof(XT) == 4 ? 4 : 2;
+      int ii[SEED_RPT];
 #pragma unroll
       for (int r = 0; r < SEED_RPT; r++) {
-        int i = tid + r * SEED_T;
-        if (i < n) {
-          const double ci = lcl[i], xi2 = lxsq[i], wi = lw[i];
+        int i = row_of(r);
+        ii[r] = i < n ? i : 0;
+      }
+      XT xa[SEED_RPT][KC], xb[SEED_RPT][KC];
+      auto load = [&](XT (&x)[SEED_RPT][KC], int k0) {
 #pragma unroll
-          for (int l = 0; l < SEED_LFAST; l++)
-            if (l < L) {
-              double v = ((-2.0 * cnd[r][l]) + lxsq[cid[l]]) + xi2;  // :252-254
-              v = v > 0.0 ? v : 0.0;
-              v = v < ci ? v : ci;  // :257
-              cnd[r][l] = v;
-              a[l] = a[l] + v * wi;
-            }
+        for (int r = 0; r < SEED_RPT; r++)
+#pragma unroll
+          for (int q = 0; q < KC; q++) x[r][q] = XbT[(size_t)(k0 + q < D ? k0 + q : D - 1) * n + ii[r]];
+      };
+      auto comp = [&](XT (&x)[SEED_RPT][KC], int k0) {
+#pragma unroll
+        for (int q = 0; q < KC; q++) {
+          double cr[LF];
+#pragma unroll
+          for (int l = 0; l < LF; l++) cr[l] = crow[(k0 + q) * SEED_LFAST + l];
+#pragma unroll
+          for (int r = 0; r < SEED_RPT; r++)
+#pragma unroll
+            for (int l = 0; l < LF; l++) cnd[r][l] = __builtin_fma(cr[l], (double)x[r][q], cnd[r][l]);
         }
+      };
+      load(xa, 0);
+      for (int k0 = 0; k0 < Dp; k0 += 2 * KC) {  // Dp is a multiple of 8 >= 2 KC
+        load(xb, k0 + KC);
+        comp(xa, k0);
+        load(xa, k0 + 2 * KC);
+        comp(xb, k0 + KC);
       }
 #pragma unroll
-      for (int l = 0; l < SEED_LFAST; l++)
-        if (l < L) part[l * SEED_T + tid] = a[l];
+      for (int lp = 0; lp < SEED_LPT; lp++) {
+        double a[LF];
+#pragma unroll
+        for (int l = 0; l < LF; l++) a[l] = 0.0;
+#pragma unroll
+        for (int r = 0; r < SEED_RPL; r++) {
+          const int rr = lp * SEED_RPL + r;
+          int i = row_of(rr);
+          if (i < n) {
+            const double ci = lcl[i], xi2 = lxsq[i], wi = lw[i];
+#pragma unroll
+            for (int l = 0; l < LF; l++) {
+              double v = ((-2.0 * cnd[rr][l]) + lxsq[cid[l]]) + xi2;  // :252-254
+              v = v > 0.0 ? v : 0.0;
+              v = v < ci ? v : ci;  // :257
+              cnd[rr][l] = v;
+              a[l] = a[l] + v * wi;
+            }
+          }
+        }
+#pragma unroll
+        for (int l = 0; l < LF; l++) part[l * SEED_T + tid + lp * SEED_TL] = a[l];
+      }
     }
     __syncthreads();
     PROF_T(4)
@@ -601,22 +646,22 @@ __global__ __launch_bounds__(SEED_T) void k_seed_lds(const SeedItem *__restrict_
         }
       s_best = best;
       s_pot = bp;
-      it.chosen[cc] = cid[best];
+      itchosen[cc] = cid[best];
     }
     __syncthreads();
     PROF_T(5)
     const int best = s_best;
 #pragma unroll
     for (int r = 0; r < SEED_RPT; r++) {
-      int i = tid + r * SEED_T;
+      int i = row_of(r);
       if (i < n) {
         double v = cnd[r][0];
 #pragma unroll
-        for (int l = 1; l < SEED_LFAST; l++) v = (l == best) ? cnd[r][l] : v;
+        for (int l = 1; l < LF; l++) v = (l == best) ? cnd[r][l] : v;
         lcl[i] = v;
       }
     }
-    for (int k = tid; k < D; k += SEED_T) it.C[(size_t)cc * D + k] = crow[k * SEED_LFAST + best];
+    for (int k = tid; k < D; k += SEED_TL) itC[(size_t)cc * D + k] = crow[k * SEED_LFAST + best];
     __syncthreads();
     PROF_T(6)
   }
@@ -714,17 +759,29 @@ extern "C" int hamsm_kmeans_seed_multi(hamsm_ctx *c, int n_items, const int32_t 
   HIPCHK(c, hipMemcpyAsync(b + o_items, items.data(), sizeof(SeedItem) * n_items, hipMemcpyHostToDevice, c->stream));
   hamsm_timer_begin(c);
   dim3 gg((unsigned)((nmax + 255) / 256), (unsigned)n_items);
-  if (dt == HAMSM_F32)
-    hipLaunchKernelGGL(k_seed_gather<float>, gg, dim3(256), 0, c->stream, (const SeedItem *)(b + o_items), ldx, D);
-  else
-    hipLaunchKernelGGL(k_seed_gather<double>, gg, dim3(256), 0, c->stream, (const SeedItem *)(b + o_items), ldx, D);
   bool fast = true;
   for (int i = 0; i < n_items; i++) fast = fast && lay[i].n <= SEED_NLDS && h_L[i] <= SEED_LFAST;
-  size_t lds_fast = sizeof(double) * ((size_t)SEED_LFAST * D + (size_t)SEED_LFAST * SEED_T + SEED_LFAST * (SEED_T / SEED_GROUP) +
+  size_t lds_fast = sizeof(double) * ((size_t)SEED_LFAST * ((D + 7) & ~7) + (size_t)SEED_LFAST * SEED_T + SEED_LFAST * (SEED_T / SEED_GROUP) +
                                       SEED_LFAST + 3 * (size_t)SEED_NLDS + SEED_NLDS / SCAN_CHUNK + 8);
-  if (fast && lds_fast <= 160 * 1024) {
-    HIPCHK(c, hipFuncSetAttribute((const void *)k_seed_lds, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_fast));
-    hipLaunchKernelGGL(k_seed_lds, dim3((unsigned)n_items), dim3(SEED_T), lds_fast, c->stream, (const SeedItem *)(b + o_items), D);
+  fast = fast && lds_fast <= 160 * 1024;
+  const SeedItem *d_items = (const SeedItem *)(b + o_items);
+  if (dt == HAMSM_F32 && fast) hipLaunchKernelGGL((k_seed_gather<float, float>), gg, dim3(256), 0, c->stream, d_items, ldx, D);
+  else if (dt == HAMSM_F32) hipLaunchKernelGGL((k_seed_gather<float, double>), gg, dim3(256), 0, c->stream, d_items, ldx, D);
+  else hipLaunchKernelGGL((k_seed_gather<double, double>), gg, dim3(256), 0, c->stream, d_items, ldx, D);
+  for (int i = 1; i < n_items; i++) fast = fast && h_L[i] == h_L[0];  // one candidate count per launch
+  if (fast) {
+    const void *fn = nullptr;
+#define SEED_CASE(LV)                                                                              \
+  case LV:                                                                                         \
+    fn = dt == HAMSM_F32 ? (const void *)k_seed_lds<float, LV> : (const void *)k_seed_lds<double, LV>; \
+    break;
+    switch (h_L[0]) {
+      SEED_CASE(1) SEED_CASE(2) SEED_CASE(3) SEED_CASE(4) SEED_CASE(5) SEED_CASE(6) SEED_CASE(7) SEED_CASE(8)
+    }
+#undef SEED_CASE
+    HIPCHK(c, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_fast));
+    void *args[] = {(void *)&d_items, (void *)&D};
+    HIPCHK(c, hipLaunchKernel(fn, dim3((unsigned)n_items), dim3(SEED_TL), args, lds_fast, c->stream));
   } else {
     size_t lds = sizeof(double) * ((size_t)SEED_LMAX * D + (size_t)SEED_LMAX * SEED_T + SEED_LMAX * (SEED_T / SEED_GROUP) + SEED_LMAX);
     HIPCHK(c, hipFuncSetAttribute((const void *)k_seed, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -833,13 +890,6 @@ __device__ __forceinline__ double readlane_f64(double v, int l) {
   return __longlong_as_double(((long long)hi << 32) | lo);
 }
 
-// Pointers that arrive inside a descriptor are generic to the compiler (flat_load/flat_atomic, which tie up both
-// memory counters); every one of them is device memory, so the kernels address them as such.
-#define GAS __attribute__((address_space(1)))
-template <typename T>
-__device__ __forceinline__ GAS T *gp(T *p) {
-  return (GAS T *)p;
-}
 struct StepG {  // a StepDev with its pointers in the global address space
   const GAS char *X;
   const GAS int32_t *rows;
