@@ -485,6 +485,11 @@ class ClusteringMixin:
             h.assign(store.Xc, store.x_dtype, store.D, store.p1, nseg, d_child, d_seen)   # :1315-1316
         seen = d_seen.to_host()
         d_seen.free()
+        if getattr(h, "nranks", 1) > 1:  # which bins held target / basis frames: union over the shards
+            d_any = h.to_device(seen.astype(np.int64).ravel())
+            h.allreduce_sum_i64(d_any, seen.size)
+            seen = d_any.to_host().reshape(seen.shape)
+            d_any.free()
         self.clusters.target_bins.update(np.nonzero(seen[0])[0].tolist())  # :1223-1224
         self.clusters.basis_bins.update(np.nonzero(seen[1])[0].tolist())
         self._d_parent, self._d_child, self._n_labelled = d_parent, d_child, nseg
@@ -565,6 +570,12 @@ class ClusteringMixin:
         d_max = h.to_device(np.full(ns, -np.inf))
         d_cnt = h.zeros(ns, np.int64)
         h.cluster_stats(self._d_child, store.p1, n, ns, d_sum, d_min, d_max, d_cnt)
+        if getattr(h, "nranks", 1) > 1:
+            # exchange step: per-cluster pcoord sums, extrema and counts of the iteration shards
+            h.allreduce_sum_f64(d_sum, ns)
+            h.allreduce_min_f64(d_min, ns)
+            h.allreduce_max_f64(d_max, ns)
+            h.allreduce_sum_i64(d_cnt, ns)
         s, mn, mx, cnt = d_sum.to_host(), d_min.to_host(), d_max.to_host(), d_cnt.to_host()
         for b in (d_sum, d_min, d_max, d_cnt):
             b.free()

@@ -27,17 +27,19 @@ def _gloo_comm(h, dist, rank, world):
     """give a single-process ctx the collective entry points, implemented with gloo on host buffers"""
     h.nranks, h.rank = world, rank
 
-    def allreduce(dtype):
+    def allreduce(dtype, op=dist.ReduceOp.SUM):
         def f(d_buf, count):
             a = np.empty(count, dtype=dtype)
             h.d2h(a, d_buf)
             t = torch.from_numpy(a)
-            dist.all_reduce(t)
+            dist.all_reduce(t, op=op)
             h.h2d(d_buf, t.numpy())
         return f
 
     h.allreduce_sum_f64 = allreduce(np.float64)
     h.allreduce_sum_i64 = allreduce(np.int64)
+    h.allreduce_min_f64 = allreduce(np.float64, dist.ReduceOp.MIN)
+    h.allreduce_max_f64 = allreduce(np.float64, dist.ReduceOp.MAX)
 
     def bcast(d_buf, nbytes, root=0):
         a = np.empty(nbytes, dtype=np.uint8)
@@ -85,13 +87,23 @@ def _worker(rank, world, port, out):
     g, meta = load_golden("c1p_d10")
     h = _abi.Hamsm(lib=ctypes.CDLL(_build_oracle()))
     _gloo_comm(h, dist, rank, world)
-    m = _shard_model(h, g, meta, 1 + rank * 19, 19 + rank * 19)  # iterations 1..19 and 20..38
+    # loaded iterations 1..21 and 20..39: the reference's maxIter bookkeeping discretizes all but the last two loaded
+    # ones (_data.py:860-866), i.e. 1..19 and 20..37 -- disjoint, and together what one process makes of 1..39
+    m = _shard_model(h, g, meta, (1, 20)[rank], (20, 38)[rank])
     bm = RectilinearBinMapper([np.array(meta["boundaries"], dtype=np.float32)])
     m.cluster_coordinates(meta["K_s"], streaming=True, use_ray=True, stratified=True, user_bin_mapper=bm,
                           random_state=meta["seed"])
     m.get_fluxMatrix(0, first_iter=0, last_iter=m.maxIter)  # every local iteration with pairs
-    np.savez(out.format(rank), labels=np.concatenate(m.dtrajs), flux=m.fluxMatrixRaw,
-             centers0=m.clusters.cluster_models[0].cluster_centers_, remap=[m.clusters.we_remap[b] for b in range(2)])
+    res = dict(labels=np.concatenate(m.dtrajs), flux=m.fluxMatrixRaw, centers0=m.clusters.cluster_models[0].cluster_centers_,
+               remap=[m.clusters.we_remap[b] for b in range(2)])
+    # the rest of build_analyze_model on the shards: cleaning (re-discretize + re-flux), cluster statistics, T, solve
+    m.organize_fluxMatrix(use_ray=True)
+    m.get_Tmatrix()
+    m.get_steady_state()
+    m.get_steady_state_target_flux()
+    res.update(fluxMatrix=m.fluxMatrix, T=m.Tmatrix, pSS=m.pSS, J=m.JtargetSS, centers=m.targetRMSD_centers,
+               minmax=m.targetRMSD_minmax, counts=m.cluster_pcoord_counts, labels2=np.concatenate(m.dtrajs))
+    np.savez(out.format(rank), **res)
     dist.barrier()
     dist.destroy_process_group()
 
@@ -109,7 +121,7 @@ def test_two_ranks_match_single_process(tmp_path, oracle_lib):
     g, meta = load_golden("c1p_d10")
     bm = RectilinearBinMapper([np.array(meta["boundaries"], dtype=np.float32)])
     h = _abi.Hamsm(lib=oracle_lib)
-    a = _shard_model(h, g, meta, 1, 19)
+    a = _shard_model(h, g, meta, 1, 20)
     a.cluster_coordinates(meta["K_s"], streaming=True, use_ray=True, stratified=True, user_bin_mapper=bm,
                           random_state=meta["seed"])
     a.get_fluxMatrix(0, first_iter=0, last_iter=a.maxIter)
@@ -128,3 +140,24 @@ def test_two_ranks_match_single_process(tmp_path, oracle_lib):
     assert np.array_equal(r0["flux"], r1["flux"])                                      # all ranks hold the same sum
     np.testing.assert_allclose(r0["flux"], (Fa + Fb) / (na + nb), rtol=1e-12, atol=1e-300)
     assert abs(r0["flux"].sum() - 1.0) < 1e-12
+
+    # cleaned model: every rank ends with the same matrix, statistics and solution ...
+    for k in ("fluxMatrix", "T", "pSS", "J", "centers", "minmax", "counts"):
+        assert np.array_equal(r0[k], r1[k], equal_nan=True), k
+    # ... and it is the single-process model of all 38 iterations trained on the first 19 (`iters_to_use`)
+    c = _shard_model(h, g, meta, 1, 38)
+    c.cluster_coordinates(meta["K_s"], streaming=True, use_ray=True, stratified=True, user_bin_mapper=bm,
+                          random_state=meta["seed"], iters_to_use=range(1, 20))
+    c.get_fluxMatrix(0, first_iter=0, last_iter=c.maxIter)
+    c.organize_fluxMatrix(use_ray=True)
+    c.get_Tmatrix()
+    c.get_steady_state()
+    c.get_steady_state_target_flux()
+    assert np.array_equal(np.concatenate([r0["labels2"], r1["labels2"]]), np.concatenate(c.dtrajs))
+    assert np.array_equal(r0["counts"], c.cluster_pcoord_counts)
+    np.testing.assert_allclose(r0["minmax"], c.targetRMSD_minmax, rtol=0, atol=0, equal_nan=True)
+    np.testing.assert_allclose(r0["centers"], c.targetRMSD_centers, rtol=1e-12, equal_nan=True)
+    np.testing.assert_allclose(r0["fluxMatrix"], c.fluxMatrix, rtol=1e-11, atol=1e-300)
+    np.testing.assert_allclose(r0["T"], c.Tmatrix, rtol=1e-11, atol=1e-300)
+    np.testing.assert_allclose(r0["pSS"], c.pSS, rtol=1e-8, atol=1e-300)
+    assert abs(float(r0["J"]) - c.JtargetSS) <= 1e-8 * c.JtargetSS
