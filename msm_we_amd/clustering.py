@@ -336,7 +336,7 @@ class ClusteringMixin:
                 w_host = w_host[sub]
             fidx = rs.choice(n, p=w_host / w_host.sum())  # :225
             L = 2 + int(np.log(K))
-            u = np.concatenate([rs.uniform(size=L) for _ in range(K - 1)]) if K > 1 else np.empty(0)  # :243
+            u = rs.uniform(size=(K - 1) * L)  # :243, K-1 calls of uniform(size=L): the same stream as one call
             seeds.append((b, int(gb[g0]), int(starts[g0, b]), nb, sub, K, int(fidx), u, L))
         # strata are independent and a seeding reads only its own first batch: every seeding can be issued
         # before every step

@@ -160,7 +160,7 @@ class StratumKMeans:
             # _kmeans_plusplus, _kmeans.py:225,243
             first = rs.choice(n, p=w_host / w_host.sum())
             L = 2 + int(np.log(K))
-            u = np.concatenate([rs.uniform(size=L) for _ in range(K - 1)]) if K > 1 else np.empty(0)
+            u = rs.uniform(size=(K - 1) * L)  # K-1 calls of uniform(size=L): the same stream as one call
             h.kmeans_seed(self.stratum, d_X, x_dtype, ldx, d_rows, n_b, d_w, sub, K, first, u, L)
             self._counts_cache = np.zeros(K)  # _kmeans.py:2271
             self._n_since_last_reassign = 0   # :2274
