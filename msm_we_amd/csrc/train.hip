@@ -401,7 +401,8 @@ __device__ unsigned long long g_seed_prof[16];
 #define SEED_LPT (SEED_T / SEED_TL)       // canonical lanes (of the oracle's POT_LANES) per thread
 #define SEED_RPL (SEED_NLDS / SEED_T)     // rows per lane: lane t owns rows t, t + 1024, t + 2048
 #define SEED_RPT (SEED_LPT * SEED_RPL)    // rows per thread
-#define SEED_LFAST 8
+#define SEED_LFAST 9                      // most candidates the on-chip kernel takes (K < 2981)
+#define SEED_LS(LF) ((LF) <= 8 ? 8 : 10)
 // XT: element type of the feature-major batch copy (the frames' own type: exact, half the stream for f32);
 // LF: number of candidates per greedy step (2 + int(log K)) -- the accumulators of unused candidates cost 1/8 of the FMAs
 template <typename XT, int LF>
@@ -412,15 +413,16 @@ __global__ __launch_bounds__(SEED_TL) void k_seed_lds(const SeedItem *__restrict
   const int K = it.K;
   constexpr int L = LF;  // (== it.L, checked by the host)
   const int Dp = (D + 7) & ~7;                         // features padded with zero candidate rows: branch-free k loop
-  double *crow = sm;                                   // [Dp][LFAST]
-  double *part = crow + SEED_LFAST * Dp;               // [LFAST][SEED_T]
-  double *grp = part + SEED_LFAST * SEED_T;            // [LFAST][32]
-  double *pots = grp + SEED_LFAST * (SEED_T / SEED_GROUP);  // [LFAST]
-  double *lw = pots + SEED_LFAST;                      // [n]
+  double *crow = sm;                                   // [Dp][LS]
+  constexpr int LS = SEED_LS(LF);                      // candidate stride of crow (even: 16-byte LDS reads)
+  double *part = crow + LS * Dp;                       // [LF][SEED_T]
+  double *grp = part + LF * SEED_T;                    // [LF][32]
+  double *pots = grp + LF * (SEED_T / SEED_GROUP);     // [LF]
+  double *lw = pots + LF;                              // [n]
   double *lxsq = lw + SEED_NLDS;                       // [n]
   double *lcl = lxsq + SEED_NLDS;                      // [n] closest
   double *lbase = lcl + SEED_NLDS;                     // [nch] chunk totals -> bases
-  __shared__ int cid[SEED_LFAST];
+  __shared__ int cid[SEED_LFAST];  // (SEED_LFAST = largest LF)
   __shared__ double s_pot;
   __shared__ int s_best;
   const int tid = threadIdx.x;
@@ -436,11 +438,11 @@ __global__ __launch_bounds__(SEED_TL) void k_seed_lds(const SeedItem *__restrict
     lw[i] = gp(it.w)[i];
     lxsq[i] = gp(it.xsq)[i];
   }
-  for (int e = tid; e < SEED_LFAST * Dp; e += SEED_TL) crow[e] = 0.0;  // (rows D..Dp-1 stay zero: fma(0, x, acc) == acc)
+  for (int e = tid; e < LS * Dp; e += SEED_TL) crow[e] = 0.0;  // (rows D..Dp-1 stay zero: fma(0, x, acc) == acc)
   __syncthreads();
   for (int k = tid; k < D; k += SEED_TL) {
     double v = (double)XbT[(size_t)k * n + it.first];
-    crow[k * SEED_LFAST] = v;
+    crow[k * LS] = v;
     itC[k] = v;
   }
   if (tid == 0) itchosen[0] = it.first;
@@ -461,7 +463,7 @@ __global__ __launch_bounds__(SEED_TL) void k_seed_lds(const SeedItem *__restrict
             for (int q = 0; q < 8; q++) xk[q] = XbT[(size_t)(k0 + q < D ? k0 + q : 0) * n + i];
 #pragma unroll
             for (int q = 0; q < 8; q++)
-              if (k0 + q < D) acc = __builtin_fma(crow[(k0 + q) * SEED_LFAST], (double)xk[q], acc);
+              if (k0 + q < D) acc = __builtin_fma(crow[(k0 + q) * LS], (double)xk[q], acc);
           }
           double v = ((-2.0 * acc) + xs0) + lxsq[i];
           v = v > 0.0 ? v : 0.0;
@@ -544,7 +546,7 @@ __global__ __launch_bounds__(SEED_TL) void k_seed_lds(const SeedItem *__restrict
     PROF_T(2)
     // candidate rows, feature-major [k][LFAST]: one k's L values are contiguous (128-bit LDS reads, each read once
     // per k and reused for all of the thread's rows)
-    for (int e = tid; e < L * D; e += SEED_TL) crow[(e % D) * SEED_LFAST + e / D] = (double)XbT[(size_t)(e % D) * n + cid[e / D]];
+    for (int e = tid; e < L * D; e += SEED_TL) crow[(e % D) * LS + e / D] = (double)XbT[(size_t)(e % D) * n + cid[e / D]];
     __syncthreads();
     PROF_T(3)
     double cnd[SEED_RPT][LF];
@@ -555,7 +557,7 @@ __global__ __launch_bounds__(SEED_TL) void k_seed_lds(const SeedItem *__restrict
         for (int l = 0; l < LF; l++) cnd[r][l] = 0.0;
       // dot products: cnd[r][l] = fma chain over k of crow[l][k] * x_r[k]; the batch copy streams from L2 in chunks of
       // KC features, the next chunk requested before the current one is used
-      constexpr int KC = sizeof(XT) == 4 ? 4 : 2;
+      constexpr int KC = (sizeof(XT) == 4 && LF <= 8) ? 4 : 2;  // (4 spills the 54 accumulators of LF = 9)
       int ii[SEED_RPT];
 #pragma unroll
       for (int r = 0; r < SEED_RPT; r++) {
@@ -574,7 +576,7 @@ __global__ __launch_bounds__(SEED_TL) void k_seed_lds(const SeedItem *__restrict
         for (int q = 0; q < KC; q++) {
           double cr[LF];
 #pragma unroll
-          for (int l = 0; l < LF; l++) cr[l] = crow[(k0 + q) * SEED_LFAST + l];
+          for (int l = 0; l < LF; l++) cr[l] = crow[(k0 + q) * LS + l];
 #pragma unroll
           for (int r = 0; r < SEED_RPT; r++)
 #pragma unroll
@@ -661,7 +663,7 @@ __global__ __launch_bounds__(SEED_TL) void k_seed_lds(const SeedItem *__restrict
         lcl[i] = v;
       }
     }
-    for (int k = tid; k < D; k += SEED_TL) itC[(size_t)cc * D + k] = crow[k * SEED_LFAST + best];
+    for (int k = tid; k < D; k += SEED_TL) itC[(size_t)cc * D + k] = crow[k * LS + best];
     __syncthreads();
     PROF_T(6)
   }
@@ -761,8 +763,9 @@ extern "C" int hamsm_kmeans_seed_multi(hamsm_ctx *c, int n_items, const int32_t 
   dim3 gg((unsigned)((nmax + 255) / 256), (unsigned)n_items);
   bool fast = true;
   for (int i = 0; i < n_items; i++) fast = fast && lay[i].n <= SEED_NLDS && h_L[i] <= SEED_LFAST;
-  size_t lds_fast = sizeof(double) * ((size_t)SEED_LFAST * ((D + 7) & ~7) + (size_t)SEED_LFAST * SEED_T + SEED_LFAST * (SEED_T / SEED_GROUP) +
-                                      SEED_LFAST + 3 * (size_t)SEED_NLDS + SEED_NLDS / SCAN_CHUNK + 8);
+  const int LF0 = h_L[0];
+  size_t lds_fast = sizeof(double) * ((size_t)SEED_LS(LF0) * ((D + 7) & ~7) + (size_t)LF0 * SEED_T + LF0 * (SEED_T / SEED_GROUP) +
+                                      LF0 + 3 * (size_t)SEED_NLDS + SEED_NLDS / SCAN_CHUNK + 8);
   fast = fast && lds_fast <= 160 * 1024;
   const SeedItem *d_items = (const SeedItem *)(b + o_items);
   if (dt == HAMSM_F32 && fast) hipLaunchKernelGGL((k_seed_gather<float, float>), gg, dim3(256), 0, c->stream, d_items, ldx, D);
@@ -776,7 +779,7 @@ extern "C" int hamsm_kmeans_seed_multi(hamsm_ctx *c, int n_items, const int32_t 
     fn = dt == HAMSM_F32 ? (const void *)k_seed_lds<float, LV> : (const void *)k_seed_lds<double, LV>; \
     break;
     switch (h_L[0]) {
-      SEED_CASE(1) SEED_CASE(2) SEED_CASE(3) SEED_CASE(4) SEED_CASE(5) SEED_CASE(6) SEED_CASE(7) SEED_CASE(8)
+      SEED_CASE(1) SEED_CASE(2) SEED_CASE(3) SEED_CASE(4) SEED_CASE(5) SEED_CASE(6) SEED_CASE(7) SEED_CASE(8) SEED_CASE(9)
     }
 #undef SEED_CASE
     HIPCHK(c, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_fast));
