@@ -1524,9 +1524,13 @@ template <typename XT, int KS, bool BYVAL>
 static void launch_step_rt(hamsm_ctx *c, hipStream_t q, const StepDev *d_steps, const StepPack &pk, int ny, long long max_nb,
                            int maxK, int64_t ldx, double ratio, bool any_perm) {
   const long long tiles = (max_nb + 15) / 16 * ny;
-  // measured on C3 (10^4 rows, 4 x 250 centroids per call): RT = 1 / 2 / 4 -> 25.0 / 26.5 / 29.0 us per call; fatter
-  // workgroups lose more latency hiding than they save in operand traffic, so RT > 1 is opt-in
-  static const int rt_cap = getenv("HAMSM_STEP_RT") ? atoi(getenv("HAMSM_STEP_RT")) : 1;
+  // measured: C3 (10^4 rows, 4 x 250 centroids, 64 KB of operands per stratum) RT = 1 / 2 / 4 -> 25.0 / 26.5 / 29.0 us
+  // per call -- fatter workgroups lose more latency hiding than they save in operand traffic; C5-shaped (5 x 10^4
+  // rows, 4 x 1250 centroids x 64 features, 647 KB per stratum) RT = 1 / 2 -> 468 / 420 us -- there the operand
+  // stream through L2 binds.  Hence two row tiles once a stratum's operands exceed 256 KB.
+  static const int rt_env = getenv("HAMSM_STEP_RT") ? atoi(getenv("HAMSM_STEP_RT")) : 0;
+  const size_t operand_bytes = (size_t)((maxK + 15) / 16) * KS * 512;
+  const int rt_cap = rt_env ? rt_env : (operand_bytes >= (256u << 10) ? 2 : 1);
   if constexpr (KS <= 8) {
     if (tiles >= 4 * 128 && rt_cap >= 4) return launch_step_kernels<XT, KS, 4, BYVAL>(c, q, d_steps, pk, ny, max_nb, maxK, ldx, ratio, any_perm);
   }
