@@ -1528,7 +1528,8 @@ static void launch_step_rt(hamsm_ctx *c, hipStream_t q, const StepDev *d_steps, 
   // per call -- fatter workgroups lose more latency hiding than they save in operand traffic; C5-shaped (5 x 10^4
   // rows, 4 x 1250 centroids x 64 features, 647 KB per stratum) RT = 1 / 2 -> 468 / 420 us -- there the operand
   // stream through L2 binds.  Hence two row tiles once a stratum's operands exceed 256 KB.
-  static const int rt_env = getenv("HAMSM_STEP_RT") ? atoi(getenv("HAMSM_STEP_RT")) : 0;
+  const char *rt_s = getenv("HAMSM_STEP_RT");  // (tests / experiments force a tile count)
+  const int rt_env = rt_s ? atoi(rt_s) : 0;
   const size_t operand_bytes = (size_t)((maxK + 15) / 16) * KS * 512;
   const int rt_cap = rt_env ? rt_env : (operand_bytes >= (256u << 10) ? 2 : 1);
   if constexpr (KS <= 8) {

@@ -105,3 +105,17 @@ def test_planned_paths_on_gpu_match_oracle(hip_h, oracle_h):
         assert np.array_equal(g[1], o[1])
         for x, y in zip(g[2] + g[3], o[2] + o[3]):
             assert np.array_equal(x, y)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("rt", ["2", "4"])
+def test_row_tile_variants_of_the_e_step_match_oracle(hip_h, oracle_h, rt, monkeypatch):
+    """2 and 4 row tiles per E-step workgroup (chosen by operand size in production, forced here)"""
+    monkeypatch.setenv("HAMSM_STEP_RT", rt)
+    cfg = synthetic.WEConfig("t5", 8, 5, 12000, 30, 4, 60)
+    g = _run(hip_h, cfg, 60, True)
+    o = _run(oracle_h, cfg, 60, True)
+    assert g[0].training_path == o[0].training_path == "planned"
+    assert np.array_equal(g[1], o[1])
+    for x, y in zip(g[2] + g[3], o[2] + o[3]):
+        assert np.array_equal(x, y)
