@@ -20,6 +20,8 @@ _vp, _i32, _i64, _f64, _sz = C.c_void_p, C.c_int32, C.c_int64, C.c_double, C.c_s
 _int = C.c_int
 
 # name -> (restype, argtypes); kept in the order of include/hamsm.h
+ABI_VERSION = 2  # HAMSM_ABI_VERSION of include/hamsm.h
+
 SYMBOLS = {
     "hamsm_abi_version": (_int, []),
     "hamsm_backend_name": (C.c_char_p, []),
@@ -151,7 +153,7 @@ class Hamsm:
 
     def __init__(self, lib: C.CDLL | None = None, device: int = 0):
         self.lib = bind(lib if lib is not None else load())
-        if self.lib.hamsm_abi_version() != 2:
+        if self.lib.hamsm_abi_version() != ABI_VERSION:
             raise ImportError("hamsm ABI version mismatch")
         ctx = _vp()
         rc = self.lib.hamsm_create(int(device), C.byref(ctx))

@@ -6,6 +6,7 @@ import os
 import re
 import subprocess
 
+import numpy as np
 import pytest
 
 from conftest import ROOT
@@ -23,6 +24,17 @@ def test_binding_table_covers_header():
     from msm_we_amd import _abi
 
     assert sorted(_abi.SYMBOLS) == _declared()
+
+
+def test_abi_version_is_one_number(oracle_lib):
+    """header, binding table, both libraries and the driver's build() check agree on the ABI version"""
+    from msm_we_amd import _abi
+
+    v = int(re.search(r"#define\s+HAMSM_ABI_VERSION\s+(\d+)", open(HEADER).read()).group(1))
+    assert _abi.ABI_VERSION == v and oracle_lib.hamsm_abi_version() == v
+    assert _abi.bind(_abi.load()).hamsm_abi_version() == v
+    assert "_abi.ABI_VERSION" in open(os.path.join(ROOT, "__graft_entry__.py")).read()
+    assert np.dtype(_abi.Hamsm.STEP_DTYPE).itemsize == 48  # sizeof(hamsm_step)
 
 
 def test_oracle_exports_abi(oracle_lib):
