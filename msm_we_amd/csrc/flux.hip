@@ -94,22 +94,61 @@ __global__ void k_stats_init(unsigned long long *kmin, unsigned long long *kmax,
   }
 }
 
-__global__ void k_stats(const int32_t *__restrict__ lab, const double *__restrict__ p, int ndim, int64_t n, int ns,
-                        double *sum, unsigned long long *kmin, unsigned long long *kmax, unsigned long long *cnt, int *err) {
-  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  int l = lab[i];
-  if (l < 0 || l >= ns) {
-    dev_set_error(err, HAMSM_ERANGE, (int)i, l);
-    return;
+// Per-cluster pcoord sum / min / max / count.  Ten million frames fall on ~10^3 clusters, so global atomics collide
+// ~10^4-fold per address (14 ms per pass); each workgroup therefore accumulates in LDS (ds_add_f64 / ds_min_u64 /
+// ds_max_u64, 28 bytes per cluster) and flushes its touched entries once.  ns too large for LDS: global atomics.
+#define STATS_LDS_MAX 2048  // 56 KB of LDS
+#define STATS_PER_WG 16384
+__global__ __launch_bounds__(256) void k_stats(const int32_t *__restrict__ lab, const double *__restrict__ p, int ndim, int64_t n,
+                                               int ns, double *sum, unsigned long long *kmin, unsigned long long *kmax,
+                                               unsigned long long *cnt, int *err, int use_lds) {
+  extern __shared__ unsigned long long sh[];
+  double *lsum = (double *)sh;
+  unsigned long long *lmin = sh + ns, *lmax = sh + 2 * (size_t)ns;
+  unsigned int *lcnt = (unsigned int *)(sh + 3 * (size_t)ns);
+  if (use_lds) {
+    for (int j = threadIdx.x; j < ns; j += 256) {
+      lsum[j] = 0.0;
+      lmin[j] = ~0ull;
+      lmax[j] = 0ull;
+      lcnt[j] = 0u;
+    }
+    __syncthreads();
   }
-  double v = p[i * ndim];
-  unsafeAtomicAdd(&sum[l], v);
-  if (v == v) {  // NaN never wins a min/max (the oracle's < and > are false for NaN)
-    atomicMin(&kmin[l], dkey(v));
-    atomicMax(&kmax[l], dkey(v));
+  const int64_t i0 = (int64_t)blockIdx.x * STATS_PER_WG, i1 = i0 + STATS_PER_WG < n ? i0 + STATS_PER_WG : n;
+  for (int64_t i = i0 + threadIdx.x; i < i1; i += 256) {
+    int l = lab[i];
+    if (l < 0 || l >= ns) {
+      dev_set_error(err, HAMSM_ERANGE, (int)i, l);
+      continue;
+    }
+    double v = p[i * ndim];
+    if (use_lds) {
+      unsafeAtomicAdd(&lsum[l], v);
+      if (v == v) {  // NaN never wins a min/max (the oracle's < and > are false for NaN)
+        atomicMin(&lmin[l], dkey(v));
+        atomicMax(&lmax[l], dkey(v));
+      }
+      atomicAdd(&lcnt[l], 1u);
+    } else {
+      unsafeAtomicAdd(&sum[l], v);
+      if (v == v) {
+        atomicMin(&kmin[l], dkey(v));
+        atomicMax(&kmax[l], dkey(v));
+      }
+      atomicAdd(&cnt[l], 1ull);
+    }
   }
-  atomicAdd(&cnt[l], 1ull);
+  if (use_lds) {
+    __syncthreads();
+    for (int j = threadIdx.x; j < ns; j += 256)
+      if (lcnt[j]) {
+        unsafeAtomicAdd(&sum[j], lsum[j]);
+        if (lmin[j] != ~0ull) atomicMin(&kmin[j], lmin[j]);
+        if (lmax[j] != 0ull) atomicMax(&kmax[j], lmax[j]);
+        atomicAdd(&cnt[j], (unsigned long long)lcnt[j]);
+      }
+  }
 }
 
 __global__ void k_stats_fin(const unsigned long long *kmin, const unsigned long long *kmax, int ns, double *mn, double *mx) {
@@ -133,8 +172,10 @@ extern "C" int hamsm_cluster_stats(hamsm_ctx *c, const int32_t *lab, const doubl
   unsigned long long *kmin = (unsigned long long *)c->scratch, *kmax = kmin + ns;
   hamsm_timer_begin(c);
   hipLaunchKernelGGL(k_stats_init, dim3((ns + 255) / 256), dim3(256), 0, c->stream, kmin, kmax, ns);
-  hipLaunchKernelGGL(k_stats, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, lab, p, c->ndim, n, ns, sum, kmin,
-                     kmax, (unsigned long long *)cnt, c->d_err);
+  const int use_lds = ns <= STATS_LDS_MAX;
+  const size_t lds = use_lds ? (size_t)ns * 28 + 8 : 0;
+  hipLaunchKernelGGL(k_stats, dim3((unsigned)((n + STATS_PER_WG - 1) / STATS_PER_WG)), dim3(256), lds, c->stream, lab, p, c->ndim,
+                     n, ns, sum, kmin, kmax, (unsigned long long *)cnt, c->d_err, use_lds);
   hipLaunchKernelGGL(k_stats_fin, dim3((ns + 255) / 256), dim3(256), 0, c->stream, kmin, kmax, ns, mn, mx);
   hamsm_timer_end(c, ST_STATS);
   HIPCHK(c, hipGetLastError());

@@ -78,6 +78,8 @@ class modelWE(DataMixin, ClusteringMixin, FluxMatrixMixin, AnalysisMixin):
         for k, v in self.__dict__.items():
             if k in ("_h", "_store", "_source", "_d_parent", "_d_child"):
                 new.__dict__[k] = v  # shared, read-only: discretization allocates fresh label buffers
+            elif k in ("_dtrajs_cache", "_pairs_cache"):
+                new.__dict__[k] = None  # host views of the shared device labels: rebuilt on first access
             else:
                 new.__dict__[k] = deepcopy(v, memo)
         return new
