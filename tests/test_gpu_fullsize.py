@@ -179,3 +179,34 @@ def test_c3_flux_and_stats_full_size(c3_run):
     href = np.bincount(child[child < K], weights=d["p1"][:n, 0][child < K], minlength=K) / np.maximum(
         np.bincount(child[child < K], minlength=K), 1)
     np.testing.assert_allclose(np.sort(href[np.bincount(child[child < K], minlength=K) > 0]), c[ok], rtol=1e-11)
+
+
+def test_c5_shaped_plan_with_reseeding_equals_stepwise(hip_lib):
+    """C5-shaped strata (more centroids than a 1024-row seeding subsample resolves: duplicate seeds, low counts):
+    the fused plan -- first steps with the host in the loop, permutation heads shipped with the plan, re-seeding on the
+    device, stops settled on the host -- must end bit-identical to the pass that takes every step with the host."""
+    from msm_we_amd import _abi
+
+    cfg = synthetic.WEConfig("c5m", 5, 60, 20000, 64, 4, 600)
+    d = _shard(cfg, cfg.n_iters)
+    h = _abi.Hamsm(lib=hip_lib)
+    try:
+        bm = RectilinearBinMapper([synthetic.strata_boundaries(cfg.S)])
+        out = []
+        for planned in (True, False):
+            m, store = _model(h, cfg, d)
+            m.speculative_training = planned
+            m.cluster_coordinates(cfg.K_s, streaming=True, use_ray=True, stratified=True, user_bin_mapper=bm, random_state=11)
+            out.append((m.training_path, [cm.cluster_centers_.copy() for cm in m.clusters.cluster_models],
+                        [cm._counts.copy() for cm in m.clusters.cluster_models], np.concatenate(m.dtrajs),
+                        [cm._n_since_last_reassign for cm in m.clusters.cluster_models]))
+        assert out[0][0] == "planned" and out[1][0] == "stepwise"
+        for a, b in zip(out[0][1] + out[0][2], out[1][1] + out[1][2]):
+            assert np.array_equal(a, b)
+        assert np.array_equal(out[0][3], out[1][3]) and out[0][4] == out[1][4]
+        # the scenario is the one intended: some centroid was re-seeded (counts are no longer the member totals)
+        p0f = d["p0"][:, 0].astype(np.float32)
+        seen0 = ((np.floor(p0f) == 0) & (d["p0"][:, 0] >= 0.05)).sum()
+        assert out[0][2][0].sum() != seen0
+    finally:
+        h.close()
