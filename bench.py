@@ -52,6 +52,13 @@ class Mapper:
 Mapper.__name__ = "RectilinearBinMapper"
 
 
+def bench_configs():
+    cfgs = dict(synthetic.CONFIGS)
+    cfgs["c5s"] = synthetic.WEConfig("c5s", 5, 200, 50000, 64, 4, 1250)   # C5 shape, 10 M frames (single-GPU slice)
+    cfgs["tiny"] = synthetic.WEConfig("tiny", 9, 50, 2000, 30, 4, 50)
+    return cfgs
+
+
 def make_shard(cfg, it_first, n_iters, log=None):
     """iterations it_first .. it_first+n_iters-1 as host arrays (float32 features)"""
     lat = synthetic.latent_centres(cfg)
@@ -95,26 +102,102 @@ def one_step(m, cfg, seed, flux_mode):
     return m
 
 
-def cpu_baseline(cfg, n_iters_sample, seed):
-    """The oracle (scalar C restatement, one core) on the first `n_iters_sample` iterations of the
-    same workload: same host logic, same ABI, CPU arithmetic."""
-    so = os.path.join(ROOT, "oracle", "_build", "libhamsm_oracle.so")
-    if not os.path.exists(so):
-        import subprocess
+ORACLE_SO = os.path.join(ROOT, "oracle", "_build", "libhamsm_oracle.so")
+_W = {}  # per-process state of the CPU pool workers
 
-        subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle")])
-    h = _abi.Hamsm(lib=ctypes.CDLL(so))
+
+def _cpu_pool_init(cfg_tuple, it_first, n_it, cents, remap):
+    """pool worker, untimed: an oracle context with the trained model and this worker's block of iterations"""
+    cfg = synthetic.WEConfig(*cfg_tuple)
+    h = _abi.Hamsm(lib=ctypes.CDLL(ORACLE_SO))
+    h.set_geometry(cfg.D, 1, cfg.S)
+    h.set_mapper_rectilinear([synthetic.strata_boundaries(cfg.S)])
+    basis, target = synthetic.basis_target_bounds(cfg.S)
+    h.set_bounds(basis, target)
+    for s, (Cm, csq) in enumerate(cents):
+        h.set_centroids(s, Cm, csq=csq)
+    h.set_remap(np.asarray(remap, dtype=np.int32))
+    Xp, Xc, p0, p1, w, offs = make_shard(cfg, it_first, n_it)
+    _W.update(h=h, cfg=cfg, d=(h.to_device(Xp), h.to_device(Xc), h.to_device(p0), h.to_device(p1), h.to_device(w)), n=len(w))
+    return n_it
+
+
+def _cpu_pool_run(_):
+    """pool worker, timed: discretize the parent and child frames of the block and accumulate its flux matrix"""
+    h, cfg, (dXp, dXc, dp0, dp1, dw), n = _W["h"], _W["cfg"], _W["d"], _W["n"]
+    K = cfg.K_s * cfg.S
+    t0 = time.perf_counter()
+    la, lb = h.alloc(n, np.int32), h.alloc(n, np.int32)
+    h.assign(dXp, 0, cfg.D, dp0, n, la)
+    h.assign(dXc, 0, cfg.D, dp1, n, lb)
+    dF = h.zeros((K + 2) * (K + 2), np.float64)
+    h.flux_accumulate(la, lb, dp0, dp1, dw, n, K, dF, 0)
+    F = dF.to_host()
+    return time.perf_counter() - t0, float(F.sum())
+
+
+def cpu_baseline_worker(workload, n_iters_sample, seed, cores):
+    """Runs in a child process that never touches the GPU (it forks a pool).  (i) the oracle = scalar C restatement on
+    one core over the first `n_iters_sample` iterations; (ii) the same with the reference's parallel structure:
+    training sequential in the driver (it is, _clustering.py:664-716), discretization and flux matrix over `cores`
+    worker processes by iteration block (the Ray tasks of _clustering.py:1183 / _fluxmatrix.py:275)."""
+    import multiprocessing as mp
+
+    cfg = bench_configs()[workload]
+    h = _abi.Hamsm(lib=ctypes.CDLL(ORACLE_SO))
     Xp, Xc, p0, p1, w, offs = make_shard(cfg, 1, n_iters_sample)
     store = DeviceStore.from_host(h, Xp, Xc, p0, p1, w, offs)
     m = new_model(h, cfg, store, n_iters_sample)
+    t_disc = [0.0]
+    inner = m.launch_ray_discretization
+
+    def timed_disc(*a, **k):
+        t = time.perf_counter()
+        r = inner(*a, **k)
+        t_disc[0] += time.perf_counter() - t
+        return r
+
+    m.launch_ray_discretization = timed_disc
     t0 = time.perf_counter()
     one_step(m, cfg, seed, 1)
     dt = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    m.get_fluxMatrix(0, first_iter=1, last_iter=m.maxIter)
+    t_flux = time.perf_counter() - t0
+    t_train = dt - t_disc[0] - t_flux
     frames = n_iters_sample * cfg.segs_per_iter
-    h.close()
-    return {"value": frames / dt, "unit": "frames/s", "cores": 1, "kind": "port",
-            "sample": f"first {n_iters_sample} of {cfg.n_iters} iterations ({frames} segments), same train+assign+flux "
-                      f"step, oracle/hamsm_oracle.c single thread, {dt:.1f} s"}
+    out = {"value": frames / dt, "unit": "frames/s", "cores": 1, "kind": "port",
+           "sample": f"first {n_iters_sample} of {cfg.n_iters} iterations ({frames} segments), same train+assign+flux "
+                     f"step, oracle/hamsm_oracle.c single thread, {dt:.1f} s"}
+    if cores > 1:
+        cents = [h.get_centroids(s) for s in range(cfg.S)]
+        cents = [(c[0], c[2]) for c in cents]
+        remap = [m.clusters.we_remap[b] for b in range(cfg.S)]
+        per = -(-n_iters_sample // cores)
+        blocks = [(1 + k * per, min(per, n_iters_sample - k * per)) for k in range(cores) if k * per < n_iters_sample]
+        cfg_t = (cfg.name, cfg.seed, cfg.n_iters, cfg.segs_per_iter, cfg.D, cfg.S, cfg.K_s)
+        with mp.get_context("fork").Pool(len(blocks)) as pool:
+            # one task per worker: chunksize 1 and as many tasks as processes
+            res = [pool.apply_async(_cpu_pool_init, (cfg_t, a, n, cents, remap)) for a, n in blocks]
+            [r.get() for r in res]
+            t0 = time.perf_counter()
+            res = pool.map(_cpu_pool_run, range(len(blocks)), chunksize=1)
+            t_par = time.perf_counter() - t0
+        out["all_cores"] = {"value": frames / (t_train + t_par), "cores": len(blocks),
+                            "how": f"training on one core ({t_train:.2f} s, sequential in the reference too) + discretization "
+                                   f"and flux over {len(blocks)} processes by iteration block ({t_par:.2f} s wall)"}
+    print(json.dumps(out), flush=True)
+
+
+def cpu_baseline(workload, n_iters_sample, seed, cores):
+    """child process: the CPU legs fork a process pool, which must not happen in a process that holds a GPU context"""
+    import subprocess
+
+    if not os.path.exists(ORACLE_SO):
+        subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle")])
+    r = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-worker", workload, str(n_iters_sample), str(seed),
+                        str(cores)], capture_output=True, text=True, check=True, env=dict(os.environ, HIP_VISIBLE_DEVICES=""))
+    return json.loads(r.stdout.strip().splitlines()[-1])
 
 
 def full_pipeline(m, cfg, seed, flux_mode):
@@ -163,6 +246,8 @@ def pmc_traffic(cfg, n_iters):
 
 
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "--cpu-worker":
+        return cpu_baseline_worker(sys.argv[2], int(sys.argv[3]), int(sys.argv[4]), int(sys.argv[5]))
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
@@ -171,7 +256,8 @@ def main():
     ap.add_argument("--iters", type=int, default=0, help="override iterations per rank (debug)")
     ap.add_argument("--flux-mode", type=int, default=0, help="0 = f64 atomics, 1 = deterministic sort-based")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-iters", type=int, default=20)
+    ap.add_argument("--cpu-iters", type=int, default=32)
+    ap.add_argument("--cpu-cores", type=int, default=min(16, os.cpu_count() or 1), help="processes of the all-cores CPU leg")
     ap.add_argument("--no-full-pipeline", action="store_true")
     ap.add_argument("--lib", default=None, help="(kernel A/B experiments) path of an alternative build of the HIP library")
     args = ap.parse_args()
@@ -194,10 +280,7 @@ def main():
         torch.cuda.set_device(local_rank)
         dist.init_process_group("nccl", rank=rank, world_size=world)
 
-    cfgs = dict(synthetic.CONFIGS)
-    cfgs["c5s"] = synthetic.WEConfig("c5s", 5, 200, 50000, 64, 4, 1250)   # C5 shape, 10 M frames (single-GPU slice)
-    cfgs["tiny"] = synthetic.WEConfig("tiny", 9, 50, 2000, 30, 4, 50)
-    cfg = cfgs[args.workload]
+    cfg = bench_configs()[args.workload]
     n_iters = args.iters or cfg.n_iters
     seed = 1337
 
@@ -286,7 +369,7 @@ def main():
     if rank == 0:
         if not args.no_cpu_baseline and world == 1:
             log("timing the CPU oracle on a bounded sample ...")
-            out["cpu_baseline"] = cpu_baseline(cfg, min(args.cpu_iters, n_iters), seed)
+            out["cpu_baseline"] = cpu_baseline(args.workload, min(args.cpu_iters, n_iters), seed, args.cpu_cores)
             out["cpu_baseline"]["gpu_over_cpu"] = out["value"] / out["cpu_baseline"]["value"]
         print(json.dumps(out), flush=True)
     if dist is not None:
