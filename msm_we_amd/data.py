@@ -20,7 +20,7 @@ import numpy as np
 
 from . import _abi
 
-__all__ = ["DataMixin", "InMemorySource", "WestpaH5Source", "DeviceStore"]
+__all__ = ["DataMixin", "InMemorySource", "NpzDirectorySource", "WestpaH5Source", "DeviceStore"]
 
 
 class InMemorySource:
@@ -34,6 +34,43 @@ class InMemorySource:
 
     def load(self, n):
         return self._iters[int(n)]
+
+
+class NpzDirectorySource:
+    """Iterations as ``<dir>/iter_%08d.npz`` files holding the arrays of the source contract above -- the raw fallback
+    for hosts without h5py: export once where the WESTPA run lives (`export`), analyse anywhere.
+    Files are memory-mapped lazily, one iteration at a time."""
+
+    PATTERN = "iter_%08d.npz"
+
+    def __init__(self, directory):
+        import os
+        import re
+
+        self.dir = str(directory)
+        found = [re.fullmatch(r"iter_(\d{8})\.npz", f) for f in os.listdir(self.dir)]
+        self._its = sorted(int(m.group(1)) for m in found if m)
+        if not self._its:
+            raise FileNotFoundError(f"no iter_XXXXXXXX.npz files in {self.dir}")
+
+    def iterations(self):
+        return list(self._its)
+
+    def load(self, n):
+        import os
+
+        with np.load(os.path.join(self.dir, self.PATTERN % int(n))) as z:
+            return {k: z[k] for k in z.files}
+
+    @classmethod
+    def export(cls, source, directory, iterations=None):
+        """write any source (e.g. a WestpaH5Source) in this layout"""
+        import os
+
+        os.makedirs(str(directory), exist_ok=True)
+        for n in (source.iterations() if iterations is None else iterations):
+            np.savez(os.path.join(str(directory), cls.PATTERN % int(n)), **{k: np.asarray(v) for k, v in source.load(n).items()})
+        return cls(directory)
 
 
 class WestpaH5Source:

@@ -79,14 +79,14 @@ def golden_iterations(g):
             for i in range(len(offs) - 1)}
 
 
-def build_model(h, g, meta, seed_forcing=True, planned=True):
+def build_model(h, g, meta, seed_forcing=True, planned=True, source=None):
     """modelWE on golden inputs, up to (and including) cluster_coordinates.  Returns (model, forced)
     where forced counts k-means++ seedings replaced by the reference's (exact-tie flips)."""
     from msm_we_amd.data import InMemorySource
     from msm_we_amd.model import modelWE
 
     m = modelWE(h=h)
-    m.set_iteration_source(InMemorySource(golden_iterations(g)))
+    m.set_iteration_source(source if source is not None else InMemorySource(golden_iterations(g)))
     m.initialize(["golden.h5"], {"coords": None, "nAtoms": meta["D"], "coord_ndim": 1}, "golden",
                  basis_pcoord_bounds=meta["basis"], target_pcoord_bounds=meta["target"], tau=meta["tau"],
                  pcoord_ndim=1, use_weights_in_clustering=meta["use_weights"])

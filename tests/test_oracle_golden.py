@@ -101,3 +101,15 @@ def test_unforced_seeding_is_deterministic(oracle_h):
     la = np.concatenate(a.dtrajs)
     b, _ = build_model(oracle_h, g, meta, seed_forcing=False)
     assert np.array_equal(la, np.concatenate(b.dtrajs))
+
+
+def test_npz_directory_source_round_trip(oracle_h, tmp_path):
+    """the h5py-free ingest path: a golden case exported as per-iteration .npz files gives the same model"""
+    from conftest import golden_iterations
+    from msm_we_amd.data import InMemorySource, NpzDirectorySource
+
+    g, meta = load_golden("c1p_d10")
+    src = NpzDirectorySource.export(InMemorySource(golden_iterations(g)), tmp_path / "iters")
+    assert src.iterations() == sorted(golden_iterations(g))
+    m, _ = build_model(oracle_h, g, meta, source=src)
+    assert np.array_equal(np.concatenate(m.dtrajs), g["dtrajs_post_cluster"])
