@@ -88,6 +88,14 @@ int hamsm_num_centroids(hamsm_ctx *ctx, int stratum); /* >=0, or negative error 
 int hamsm_classify(hamsm_ctx *ctx, const double *d_pcoord, int64_t n, int apply_remap,
                    int32_t *d_bin, uint8_t *d_flags);
 
+/* ---- a2: the linear map of the dimensionality reduction (reduceCoordinates, _dimensionality.py:37-66, called per
+ * iteration at _clustering.py:894-896 and 1291-1296): what sklearn's PCA / IncrementalPCA .transform computes,
+ *   d_Y[i][j] = (sum_k x[i][k] W[j][k]) - (sum_k mean[k] W[j][k])   ( / h_scale[j] when whitening ),
+ * every sum an in-order fma chain over k.  h_W is components_ [d][Draw]; h_mean [Draw] and h_scale [d] are nullable;
+ * d_X holds n rows of Draw raw features (x_dtype, row stride ldx); d_Y is [n][d] float64.  Needs no geometry.      */
+int hamsm_project(hamsm_ctx *ctx, const void *d_X, int x_dtype, int64_t ldx, int64_t n, int Draw,
+                  const double *h_mean, const double *h_W, int d, const double *h_scale, double *d_Y);
+
 /* ---- a9: StratifiedClusters.predict (stratified_clustering.py:101-212) fused with a3/a4 -------
  * label = Kfit+1 if target(p) else Kfit if basis(p) else off(s) + argmin_j ||x - c_j||^2 over
  * the centroids of s = remap[bin(p)].  d_seen (nullable): int32[2][n_strata], [0][s]=1 when a

@@ -42,6 +42,7 @@ SYMBOLS = {
     "hamsm_get_centroids": (_int, [_vp, _int, _vp, _vp, _vp]),
     "hamsm_num_centroids": (_int, [_vp, _int]),
     "hamsm_classify": (_int, [_vp, _vp, _i64, _int, _vp, _vp]),
+    "hamsm_project": (_int, [_vp, _vp, _int, _i64, _i64, _int, _vp, _vp, _int, _vp, _vp]),
     "hamsm_assign": (_int, [_vp, _vp, _int, _i64, _vp, _i64, _vp, _vp]),
     "hamsm_predict_host": (_int, [_vp, _vp, _int, _vp, _i64, _vp, _vp]),
     "hamsm_flux_accumulate": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _int, _vp, _int, _vp, _i64]),
@@ -274,6 +275,20 @@ class Hamsm:
     # -- ops --------------------------------------------------------------------------------
     def classify(self, d_pcoord, n, apply_remap, d_bin, d_flags):
         self._ck(self.lib.hamsm_classify(self.ctx, _dp(d_pcoord), int(n), int(apply_remap), _dp(d_bin), _dp(d_flags)))
+
+    def project(self, d_X, x_dtype, ldx, n, W, mean=None, scale=None, d_Y=None):
+        """sklearn's PCA.transform on device rows: -> DevBuf [n][d] float64"""
+        W = np.ascontiguousarray(W, dtype=np.float64)
+        d, Draw = W.shape
+        mean = None if mean is None else np.ascontiguousarray(mean, dtype=np.float64)
+        scale = None if scale is None else np.ascontiguousarray(scale, dtype=np.float64)
+        assert mean is None or mean.shape == (Draw,)
+        assert scale is None or scale.shape == (d,)
+        if d_Y is None:
+            d_Y = self.alloc(max(int(n), 1) * d, np.float64)
+        self._ck(self.lib.hamsm_project(self.ctx, _dp(d_X), int(x_dtype), int(ldx), int(n), int(Draw), _hp(mean), _hp(W), int(d),
+                                        _hp(scale), _dp(d_Y)))
+        return d_Y
 
     def assign(self, d_X, x_dtype, ldx, d_pcoord, n, d_labels, d_seen=None):
         self._ck(self.lib.hamsm_assign(self.ctx, _dp(d_X), int(x_dtype), int(ldx), _dp(d_pcoord), int(n),

@@ -108,6 +108,7 @@ int hamsm_fail(hamsm_ctx *c, int code, const char *fmt, ...);
   } while (0)
 
 int hamsm_ensure_scratch(hamsm_ctx *c, size_t bytes);
+int hamsm_ensure_scratch2(hamsm_ctx *c, size_t bytes);
 int hamsm_ensure_pinned(hamsm_ctx *c, size_t bytes);
 int hamsm_refresh_table(hamsm_ctx *c);                    // rebuilds d_table / Kfit when dirty
 int hamsm_check_device_error(hamsm_ctx *c, const char *what);  // reads d_err (syncs the stream)

@@ -451,6 +451,31 @@ int hamsm_tmatrix_csr(hamsm_ctx *c, const double *F, int ns, const int32_t *basi
   return HAMSM_OK;
 }
 
+/* --- a2: sklearn _BasePCA._transform (X @ components_.T, then -= mean_ @ components_.T, then /= scale) with every
+ *     dot product an fma chain over ascending k */
+int hamsm_project(hamsm_ctx *c, const void *X, int dt, int64_t ldx, int64_t n, int Draw, const double *mean, const double *W,
+                  int d, const double *scale, double *Y) {
+  if (Draw < 1 || d < 1 || !W || ldx < Draw) return fail(c, HAMSM_EINVAL, "bad projection shape");
+  if (dt != HAMSM_F32 && dt != HAMSM_F64) return fail(c, HAMSM_EINVAL, "bad x_dtype");
+  double *m = (double *)calloc((size_t)d, sizeof(double));
+  if (mean)
+    for (int j = 0; j < d; j++) {
+      double a = 0.0;
+      for (int k = 0; k < Draw; k++) a = __builtin_fma(W[(size_t)j * Draw + k], mean[k], a);
+      m[j] = a;
+    }
+  for (int64_t i = 0; i < n; i++)
+    for (int j = 0; j < d; j++) {
+      double a = 0.0;
+      for (int k = 0; k < Draw; k++) a = __builtin_fma(W[(size_t)j * Draw + k], xval(X, dt, i * ldx + k), a);
+      if (mean) a = a - m[j];
+      if (scale) a = a / scale[j];
+      Y[i * d + j] = a;
+    }
+  free(m);
+  return HAMSM_OK;
+}
+
 /* --- a5 support: _clustering.py:872-886 */
 int hamsm_train_prepass(hamsm_ctx *c, const double *p, int64_t n, const int64_t *offs, int64_t n_iters, int32_t *bin,
                         int64_t *hist) {
