@@ -224,11 +224,27 @@ class DataMixin:
         self.last_iter = last_iter
 
     # -- staging ----------------------------------------------------------------------------
+    def _linear_map(self):
+        """(components [d, Draw], mean [Draw] | None, scale [d] | None) when `self.coordinates` is a fitted
+        scikit-learn PCA / IncrementalPCA (`_base.py` transform), else None"""
+        c = self.coordinates
+        W = getattr(c, "components_", None)
+        if W is None or not hasattr(c, "mean_"):
+            return None
+        scale = None
+        if getattr(c, "whiten", False):
+            scale = np.sqrt(np.asarray(c.explained_variance_, dtype=np.float64))
+            scale[scale < np.finfo(scale.dtype).eps] = np.finfo(scale.dtype).eps
+        return np.asarray(W, dtype=np.float64), (None if c.mean_ is None else np.asarray(c.mean_, dtype=np.float64)), scale
+
     def stage_iterations(self):
-        """Featurize (host) and upload iterations 1..maxIter once.  Idempotent."""
+        """Featurize and upload iterations 1..maxIter once.  Idempotent.  `processCoordinates` (user code) runs on the
+        host; a PCA transform (`reduceCoordinates`, _dimensionality.py:37-66) runs on the device over the uploaded raw
+        features; any other `coordinates.transform` runs on the host."""
         if getattr(self, "_store", None) is not None:
             return self._store
         h = self.h
+        lin = self._linear_map()
         parts = {k: [] for k in ("Xp", "Xc", "p0", "p1", "w")}
         sizes = []
         for it in range(1, self.maxIter + 1):
@@ -237,8 +253,10 @@ class DataMixin:
             for which, key in (("parent", "Xp"), ("child", "Xc")):
                 if key in d and which not in d:
                     X = np.asarray(d[key])
-                    if self.coordinates is not None and type(self.coordinates).__name__ != "Coordinates":
+                    if lin is None and self.coordinates is not None and type(self.coordinates).__name__ != "Coordinates":
                         X = self.coordinates.transform(np.asarray(X, dtype=np.float64))
+                elif lin is not None:
+                    X = self.processCoordinates(np.asarray(d[which], dtype=np.float64))
                 else:
                     X = self._featurize(d[which])
                 if np.isnan(X).any():
@@ -258,8 +276,20 @@ class DataMixin:
             else:
                 Xp, Xc = Xp.astype(np.float64), Xc.astype(np.float64)
         offsets = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)
-        self._store = DeviceStore.from_host(h, Xp, Xc, np.concatenate(parts["p0"]), np.concatenate(parts["p1"]),
-                                            np.concatenate(parts["w"]), offsets)
+        p0, p1, w = np.concatenate(parts["p0"]), np.concatenate(parts["p1"]), np.concatenate(parts["w"])
+        if lin is None:
+            self._store = DeviceStore.from_host(h, Xp, Xc, p0, p1, w, offsets)
+            return self._store
+        W, mean, scale = lin
+        dt = _abi.F32 if Xp.dtype == np.float32 else _abi.F64
+        n, Draw = Xp.shape
+        proj = []
+        for X in (Xp, Xc):  # raw features up, reduced features stay: the raw copy is released at once
+            d_raw = h.to_device(X)
+            proj.append(h.project(d_raw, dt, Draw, n, W, mean, scale))
+            d_raw.free()
+        self._store = DeviceStore(h, W.shape[0], p0.shape[1], _abi.F64, offsets, proj[0], proj[1], h.to_device(p0), h.to_device(p1),
+                                  h.to_device(w))
         return self._store
 
     def attach_store(self, store: DeviceStore, maxIter=None):

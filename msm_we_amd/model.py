@@ -180,11 +180,54 @@ class modelWE(DataMixin, ClusteringMixin, FluxMatrixMixin, AnalysisMixin):
         def transform(self, coords):
             return coords
 
-    def dimReduce(self, **_):
-        if self.dimReduceMethod != "none":
-            raise NotImplementedError("dimReduceMethod other than 'none' is not built yet (SURVEY §8f-3)")
-        self.ndim = int(3 * self.nAtoms)
-        self.coordinates = self.Coordinates()
+    def dimReduce(self, first_iter=1, first_rough_iter=None, last_iter=None, rough_stride=10, fine_stride=1,
+                  variance_cutoff=0.95, use_weights=True, progress_bar=None):
+        """`_dimensionality.py:110-241`.  "none": identity.  "pca": the reference's streaming scheme with the same
+        estimator (scikit-learn's IncrementalPCA) -- a rough pass over every `rough_stride`-th iteration to find the
+        number of components that explain `variance_cutoff`, then the fit with that many components over all
+        iterations -- on the host; the fitted map is applied to every frame on the device at staging time
+        (`hamsm_project`).  TICA / VAMP need deeptime (not in the image)."""
+        if self.dimReduceMethod == "none":
+            self.ndim = int(3 * self.nAtoms)
+            self.coordinates = self.Coordinates()
+            return
+        if self.dimReduceMethod != "pca":
+            raise NotImplementedError(f"dimReduceMethod {self.dimReduceMethod!r} is not built (needs deeptime; SURVEY §8f-3)")
+        from sklearn.decomposition import IncrementalPCA as iPCA
+
+        if last_iter is None:
+            last_iter = self.maxIter
+        rough_ipca = iPCA()
+        if first_rough_iter is None:
+            total = last_iter
+            rough_iters = range(1, total, rough_stride) if total > 100 else range(total // 2, total)  # :150-158
+        else:
+            rough_iters = range(first_rough_iter, last_iter, rough_stride)
+        for iteration in rough_iters:  # do_pca, :69-82
+            iter_coords = self.get_iter_coordinates(iteration)
+            if iter_coords.shape[0] == 0:
+                continue
+            rough_ipca.partial_fit(self.processCoordinates(iter_coords))
+        components_for_var = int(np.argmax(np.cumsum(rough_ipca.explained_variance_ratio_) > variance_cutoff) + 1)  # :192-197
+        components_for_var = min(components_for_var, (last_iter - first_iter) // fine_stride - 1)
+        ipca = iPCA(n_components=components_for_var)
+        extra = 0
+        for iteration in range(first_iter, last_iter, fine_stride):  # do_full_pca, :84-108 / :206-235
+            if extra > 0:
+                extra -= 1
+                continue
+            iter_coords = self.get_iter_coordinates(iteration)
+            used = 0
+            while iter_coords.shape[0] <= components_for_var:  # keep adding iterations until there are enough frames
+                used += 1
+                more = self.get_iter_coordinates(iteration + used)
+                if more.shape[0] == 0:
+                    continue
+                iter_coords = np.append(iter_coords, more, axis=0)
+            ipca.partial_fit(self.processCoordinates(iter_coords))
+            extra = used
+        self.coordinates = ipca
+        self.ndim = components_for_var
 
     # msm_we.py:588-882, without the rich table / Ray bootstrap
     def build_analyze_model(self, file_paths, ref_struct, modelName, basis_pcoord_bounds, target_pcoord_bounds,

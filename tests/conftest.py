@@ -89,7 +89,8 @@ def build_model(h, g, meta, seed_forcing=True, planned=True, source=None):
     m.set_iteration_source(source if source is not None else InMemorySource(golden_iterations(g)))
     m.initialize(["golden.h5"], {"coords": None, "nAtoms": meta["D"], "coord_ndim": 1}, "golden",
                  basis_pcoord_bounds=meta["basis"], target_pcoord_bounds=meta["target"], tau=meta["tau"],
-                 pcoord_ndim=1, use_weights_in_clustering=meta["use_weights"])
+                 pcoord_ndim=1, use_weights_in_clustering=meta["use_weights"],
+                 dim_reduce_method=meta.get("dim_reduce", "none"))
     m.get_iterations()
     m.get_coordSet(m.maxIter)
     m.dimReduce()

@@ -36,6 +36,9 @@ CASES = {
     "gap_d10": dict(cfg=synthetic.WEConfig("gap_d10", 77, 30, 160, 10, 4, 12), drop_stratum=2),
     # multi-iteration accumulation: too few segments per iteration to fill a stratum at once (`:794-886`)
     "sparse_d10": dict(cfg=synthetic.WEConfig("sparse_d10", 5, 60, 24, 10, 2, 20)),
+    # dimensionality reduction: IncrementalPCA fitted by the reference's two-pass scheme (`_dimensionality.py:139-241`),
+    # every frame transformed before clustering (`reduceCoordinates`)
+    "c1p_d30_pca": dict(cfg="c1p_d30", dim_reduce="pca"),
 }
 
 
@@ -123,7 +126,7 @@ def run_case(case):
         "golden",
         basis_pcoord_bounds=basis,
         target_pcoord_bounds=target,
-        dim_reduce_method="none",
+        dim_reduce_method=spec.get("dim_reduce", "none"),
         tau=1e-9,
         pcoord_ndim=1,
         use_weights_in_clustering=bool(spec.get("use_weights", False)),
@@ -131,12 +134,17 @@ def run_case(case):
     model.get_iterations()
     model.get_coordSet(last_iter=model.maxIter)
     model.dimReduce()
+    out = {}
+    if spec.get("dim_reduce") == "pca":
+        out["pca_components"] = np.asarray(model.coordinates.components_, dtype=np.float64)
+        out["pca_mean"] = np.asarray(model.coordinates.mean_, dtype=np.float64)
+        out["pca_ndim"] = np.int64(model.ndim)
+        out["pca_n_samples_seen"] = np.int64(model.coordinates.n_samples_seen_)
     bm = ref_harness.RectilinearBinMapper([synthetic.strata_boundaries(cfg.S)])
     model.cluster_coordinates(
         n_clusters=cfg.K_s, streaming=True, use_ray=True, stratified=True,
         user_bin_mapper=bm, random_state=seed,
     )
-    out = {}
     out["remap_post_cluster"] = np.array([model.clusters.we_remap[b] for b in range(bm.nbins)], dtype=np.int64)
     out["n_clusters_post_cluster"] = np.int64(model.n_clusters)
     fitted = [hasattr(m, "cluster_centers_") for m in model.clusters.cluster_models]
@@ -197,7 +205,7 @@ def run_case(case):
     out["in_offsets"] = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)
     meta = dict(
         case=case, seed=seed, D=cfg.D, S=cfg.S, K_s=cfg.K_s, n_iters=cfg.n_iters, maxIter=int(model.maxIter),
-        tau=1e-9, use_weights=bool(spec.get("use_weights", False)),
+        tau=1e-9, use_weights=bool(spec.get("use_weights", False)), dim_reduce=spec.get("dim_reduce", "none"),
         boundaries=[float(x) for x in synthetic.strata_boundaries(cfg.S)],
         basis=basis.tolist(), target=target.tolist(),
         numpy=np.__version__, scipy=scipy.__version__, sklearn=sklearn.__version__,

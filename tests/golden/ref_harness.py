@@ -178,9 +178,12 @@ def load_reference(inline_pool=True):
 
     cl.np = _NpProxy()
     if inline_pool:
+        import msm_we._hamsm._dimensionality as dm
+
         ns = types.SimpleNamespace(futures=types.SimpleNamespace(ProcessPoolExecutor=_InlineExecutor))
         cl.concurrent = ns
         fm.concurrent = ns
+        dm.concurrent = ns  # the fork-per-iteration iPCA loop (_dimensionality.py:176-235)
     return msm_we
 
 

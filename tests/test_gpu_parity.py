@@ -390,6 +390,24 @@ def test_pipeline_on_reference_goldens(hip_h, case):
     np.testing.assert_allclose(m2.fluxMatrixRaw, g["fluxMatrixRaw"], rtol=1e-12, atol=1e-300)
 
 
+def test_pca_pipeline_on_reference_golden(hip_h, oracle_h):
+    """dim_reduce_method='pca': IncrementalPCA fitted on the host like the reference, every frame projected on the
+    device (hamsm_project).  HIP == oracle bit for bit; against the real reference every discrete result is identical
+    and the centroids agree to the ulp-level difference between BLAS and plain chains (tests/test_oracle_golden.py)."""
+    g, meta = load_golden("c1p_d30_pca")
+    res = []
+    for h in (oracle_h, hip_h):
+        m, st = build_model(h, g, meta)
+        m.get_fluxMatrix(0, first_iter=1, last_iter=m.maxIter, use_ray=True)
+        res.append((m._store.Xc.to_host(), [cm.cluster_centers_.copy() for cm in m.clusters.cluster_models],
+                    np.concatenate(m.dtrajs), m.fluxMatrixRaw.copy(), st["forced"]))
+    assert np.array_equal(res[0][0], res[1][0])  # projected features
+    for a, b in zip(res[0][1], res[1][1]):
+        assert np.array_equal(a, b)
+    assert np.array_equal(res[0][2], res[1][2]) and np.array_equal(res[0][3], res[1][3]) and res[0][4] == res[1][4]
+    assert np.array_equal(res[1][2], g["dtrajs_post_cluster"]) and np.array_equal(res[1][3], g["fluxMatrixRaw"])
+
+
 def test_block_validation_runs(hip_h):
     g, meta = load_golden("c1p_d10")
     m, _ = build_model(hip_h, g, meta)
