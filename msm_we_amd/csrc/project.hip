@@ -17,40 +17,95 @@ __global__ void k_pack_w(const double *__restrict__ W, int d, int Draw, int KS, 
   Wp[e] = (j < d && k < Draw) ? W[(size_t)j * Draw + k] : 0.0;
 }
 
+// One workgroup = 128 frames (4 waves x 2 tiles of 16).  The raw features stream through LDS in chunks of 32 (8 k-steps):
+// coalesced global loads (a wave reads two rows' 128-byte pieces), row stride 34 elements so that both the staging
+// writes and the fragment reads (16 frames x 2 features per half-wave) hit 32 distinct banks; the component fragments
+// of the chunk are staged once per workgroup instead of being fetched from L2 by every wave and k-step.  Chunk c+1 is
+// requested before chunk c is consumed.  Up to four component tiles per sweep over the features.
+#define PJ_FR 128
+#define PJ_KB 32
+#define PJ_XS 34
 template <typename XT>
 __global__ __launch_bounds__(256) void k_project(const XT *__restrict__ X, int64_t ldx, int64_t n, int Draw, int KS,
                                                  const double *__restrict__ Wp, int njt, const double *__restrict__ m,
                                                  const double *__restrict__ scale, int d, double *__restrict__ Y) {
-  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  const int64_t f = ((int64_t)blockIdx.x * 4 + wv) * 16 + (lane & 15);
-  const bool ok = f < n;
-  const XT *x = X + (ok ? f : 0) * ldx;
-  for (int j0 = 0; j0 < njt; j0 += 4) {  // four component tiles per sweep over the features
-    v4f64 acc[4];
+  __shared__ XT xs[2][PJ_FR * PJ_XS];
+  __shared__ double ws[2][4 * 8 * 64];
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int64_t f0 = (int64_t)blockIdx.x * PJ_FR;
+  const int nch = (Draw + PJ_KB - 1) / PJ_KB;
+  for (int j0 = 0; j0 < njt; j0 += 4) {
+    const int nj = njt - j0 < 4 ? njt - j0 : 4;
+    v4f64 acc[4][2];
 #pragma unroll
-    for (int u = 0; u < 4; u++) acc[u] = (v4f64){0.0, 0.0, 0.0, 0.0};
-#pragma unroll 4
-    for (int ks = 0; ks < KS; ks++) {
-      const int k = 4 * ks + (lane >> 4);
-      const double b = (ok && k < Draw) ? (double)x[k] : 0.0;
+    for (int u = 0; u < 4; u++)
 #pragma unroll
-      for (int u = 0; u < 4; u++)
-        if (j0 + u < njt) acc[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(Wp[((size_t)(j0 + u) * KS + ks) * 64 + lane], b, acc[u], 0, 0, 0);
-    }
-    if (ok) {
+      for (int t = 0; t < 2; t++) acc[u][t] = (v4f64){0.0, 0.0, 0.0, 0.0};
+    XT xr[PJ_FR * PJ_KB / 256];
+    double wr[4 * 8 * 64 / 256];
+    auto fetch = [&](int c) {  // chunk c: features [32 c, 32 c + 32) of the 128 rows, k-steps [8 c, 8 c + 8) of nj tiles
 #pragma unroll
-      for (int u = 0; u < 4; u++)
+      for (int i = 0; i < PJ_FR * PJ_KB / 256; i++) {
+        const int e = tid + 256 * i, r = e / PJ_KB, k = c * PJ_KB + e % PJ_KB;
+        const int64_t f = f0 + r;
+        xr[i] = (f < n && k < Draw) ? X[f * ldx + k] : (XT)0;
+      }
 #pragma unroll
-        for (int q = 0; q < 4; q++) {
-          const int j = (j0 + u) * 16 + (lane >> 4) + 4 * q;
-          if (j < d) {
-            double v = acc[u][q];
-            if (m) v = v - m[j];          // X_transformed -= mean_ @ components_.T
-            if (scale) v = v / scale[j];  // whiten
-            Y[(size_t)f * d + j] = v;
+      for (int i = 0; i < 4 * 8 * 64 / 256; i++) {
+        const int e = tid + 256 * i, u = e / 512, ks = c * 8 + (e % 512) / 64;
+        wr[i] = (u < nj && ks < KS) ? Wp[((size_t)(j0 + u) * KS + ks) * 64 + (e & 63)] : 0.0;
+      }
+    };
+    auto stash = [&](int buf) {
+#pragma unroll
+      for (int i = 0; i < PJ_FR * PJ_KB / 256; i++) {
+        const int e = tid + 256 * i;
+        xs[buf][(e / PJ_KB) * PJ_XS + e % PJ_KB] = xr[i];
+      }
+#pragma unroll
+      for (int i = 0; i < 4 * 8 * 64 / 256; i++) ws[buf][tid + 256 * i] = wr[i];
+    };
+    fetch(0);
+    stash(0);
+    __syncthreads();
+    for (int c = 0; c < nch; c++) {
+      const int buf = c & 1;
+      if (c + 1 < nch) fetch(c + 1);
+#pragma unroll
+      for (int ks = 0; ks < 8; ks++) {
+        double b[2];
+#pragma unroll
+        for (int t = 0; t < 2; t++) b[t] = (double)xs[buf][(wv * 32 + t * 16 + (lane & 15)) * PJ_XS + 4 * ks + (lane >> 4)];
+#pragma unroll
+        for (int u = 0; u < 4; u++)
+          if (u < nj) {
+            const double a = ws[buf][(u * 8 + ks) * 64 + lane];
+#pragma unroll
+            for (int t = 0; t < 2; t++) acc[u][t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b[t], acc[u][t], 0, 0, 0);
           }
-        }
+      }
+      if (c + 1 < nch) stash(buf ^ 1);
+      __syncthreads();
     }
+#pragma unroll
+    for (int t = 0; t < 2; t++) {
+      const int64_t f = f0 + wv * 32 + t * 16 + (lane & 15);
+      if (f < n) {
+#pragma unroll
+        for (int u = 0; u < 4; u++)
+#pragma unroll
+          for (int q = 0; q < 4; q++) {
+            const int j = (j0 + u) * 16 + (lane >> 4) + 4 * q;
+            if (u < nj && j < d) {
+              double v = acc[u][t][q];
+              if (m) v = v - m[j];          // X_transformed -= mean_ @ components_.T
+              if (scale) v = v / scale[j];  // whiten
+              Y[(size_t)f * d + j] = v;
+            }
+          }
+      }
+    }
+    __syncthreads();  // (the next sweep re-stages buffer 0)
   }
 }
 
@@ -87,7 +142,7 @@ extern "C" int hamsm_project(hamsm_ctx *c, const void *X, int dt, int64_t ldx, i
     m = (const double *)(b + o_m);
   }
   const double *sc = h_scale ? (const double *)(b + o_s) : nullptr;
-  const unsigned grid = (unsigned)((n + 63) / 64);
+  const unsigned grid = (unsigned)((n + PJ_FR - 1) / PJ_FR);
   if (dt == HAMSM_F32)
     hipLaunchKernelGGL(k_project<float>, dim3(grid), dim3(256), 0, c->stream, (const float *)X, ldx, n, Draw, KS, Wp, njt, m, sc, d, Y);
   else
