@@ -119,3 +119,22 @@ def test_row_tile_variants_of_the_e_step_match_oracle(hip_h, oracle_h, rt, monke
     assert np.array_equal(g[1], o[1])
     for x, y in zip(g[2] + g[3], o[2] + o[3]):
         assert np.array_equal(x, y)
+
+
+@pytest.mark.gpu
+def test_many_strata_take_the_descriptor_table_path(hip_h, oracle_h):
+    """10 strata: more steps per launch group than travel in the kernel arguments (PACK_NY = 4 per queue), so the step
+    kernels read their descriptors from the table in memory and run on one queue"""
+    cfg = synthetic.WEConfig("t10", 12, 8, 6000, 12, 10, 9)
+    g = _run(hip_h, cfg, 9, True)
+    o = _run(oracle_h, cfg, 9, True)
+    assert g[0].training_path == o[0].training_path == "planned"
+    assert np.array_equal(g[1], o[1])
+    for x, y in zip(g[2] + g[3], o[2] + o[3]):
+        assert np.array_equal(x, y)
+    # and with the low-count rule firing (outliers): device-side re-seeding through the table path
+    g = _run(hip_h, cfg, 9, True, outliers=True)
+    o = _run(oracle_h, cfg, 9, True, outliers=True)
+    assert np.array_equal(g[1], o[1])
+    for x, y in zip(g[2] + g[3], o[2] + o[3]):
+        assert np.array_equal(x, y)
