@@ -221,6 +221,8 @@ def _train_inputs(rng, n, D, S, dtype):
                                                        (30, np.float32, True, False, 25, 3000),
                                                        (13, np.float64, False, True, 25, 3000),
                                                        (64, np.float32, True, True, 25, 3000),
+                                                       (128, np.float32, False, False, 25, 3000),  # KS = 32, two feature halves
+                                                       (3, np.float64, True, False, 25, 3000),     # KS = 1
                                                        # general (global-memory) seeding kernel: L = 9 candidates / > 3072 rows
                                                        (10, np.float32, False, False, 1100, 4000),
                                                        (30, np.float32, True, False, 40, 9000)])
