@@ -128,6 +128,47 @@ def test_classify_matches_oracle(hip_h, oracle_h):
     assert all(np.array_equal(res[i][0], res[i + 2][0]) and np.array_equal(res[i][1], res[i + 2][1]) for i in (0, 1))
 
 
+def test_two_dimensional_bin_grid(hip_h, oracle_h):
+    """a true 3 x 2 rectilinear grid over two progress coordinates (westpa: C-order bin index, float32 half-open
+    digitize per dimension), 2-D basis / target boxes: bins, flags and labels against a NumPy restatement and
+    between the two libraries"""
+    bx = np.array([0.0, 1.0, 2.0, np.inf], dtype=np.float32)
+    by = np.array([-np.inf, 0.25, np.inf], dtype=np.float32)
+    basis = [[-np.inf, 0.3], [-np.inf, 0.0]]
+    target = [[2.5, np.inf], [0.5, np.inf]]
+    rng = np.random.default_rng(8)
+    n, D, K_s = 6000, 7, 9
+    p = np.stack([rng.uniform(-0.0, 3.5, n), rng.normal(size=n)], axis=1)
+    p[::53, 0] = np.round(p[::53, 0])
+    p[::71, 1] = 0.25
+    X = rng.normal(size=(n, D)).astype(np.float32) * 3
+    cents = [rng.normal(size=(K_s, D)) * 3 for _ in range(6)]
+    out = []
+    for h in (oracle_h, hip_h):
+        h.set_geometry(D, 2, 6)
+        h.set_mapper_rectilinear([bx, by])
+        h.set_bounds(basis, target)
+        for s in range(6):
+            h.set_centroids(s, cents[s], csq=np.einsum("ij,ij->i", cents[s], cents[s]))
+        d_p = h.to_device(p)
+        d_b, d_f = h.alloc(n, np.int32), h.alloc(n, np.uint8)
+        h.classify(d_p, n, 0, d_b, d_f)
+        out.append((d_b.to_host(), d_f.to_host(), h.predict_host(X, p)))
+    for a, b in zip(out[0], out[1]):
+        assert np.array_equal(a, b)
+    p32 = p.astype(np.float32)
+    ix = np.digitize(p32[:, 0], bx) - 1
+    iy = np.digitize(p32[:, 1], by) - 1
+    assert np.array_equal(out[1][0], ix * 2 + iy)
+    in_b = (p[:, 0] >= -np.inf) & (p[:, 0] < 0.3) & (p[:, 1] < 0.0)
+    in_t = (p[:, 0] > 2.5) & (p[:, 1] > 0.5)
+    lab = out[1][2]
+    K = 6 * K_s
+    assert np.array_equal(lab == K + 1, in_t) and np.array_equal(lab == K, in_b & ~in_t)
+    free = ~(in_t | in_b)
+    assert np.array_equal(lab[free] // K_s, (ix * 2 + iy)[free])
+
+
 def _flux_inputs(rng, n, K, n_iters):
     pa = rng.integers(0, K, n).astype(np.int32)
     ch = rng.integers(0, K + 2, n).astype(np.int32)
