@@ -1164,17 +1164,18 @@ __global__ __launch_bounds__(256) void k_step_assign(const StepDev *__restrict__
   SPROF_FLUSH(0)
 }
 
-// members m0 .. m0+W-1 of a sorted member list (lane q holds member q's batch row `rm` and weight `wl`): all W rows
-// are requested before the first add; branch-free -- past the end the last member is fetched again (same lines) and
-// its add is deselected
+// members m0 .. m0+W-1 of a sorted member list held in the wave's LDS strip (srow[q] = batch row, swl[q] = weight of
+// member q; broadcast reads -- v_readlane into an address or an operand costs ~100 cycles each here): all W rows are
+// requested before the first add; branch-free -- past the end the last member is fetched again (same lines) and its
+// add is deselected
 template <int W, int H>
-__device__ __forceinline__ void upd_add_listed(double (&acc)[H], const GAS double *Xg, int ldg, unsigned rm, double wl, bool weighted,
-                                               int m0, int mc, int D, int lane) {
+__device__ __forceinline__ void upd_add_listed(double (&acc)[H], const GAS double *Xg, int ldg, const unsigned *srow,
+                                               const double *swl, bool weighted, int m0, int mc, int D, int lane) {
   double xv[W][H];
 #pragma unroll
   for (int q = 0; q < W; q++) {
     const int mq = m0 + q < mc ? m0 + q : mc - 1;
-    const size_t rq = (size_t)(unsigned)__builtin_amdgcn_readlane((int)rm, mq);
+    const size_t rq = (size_t)srow[mq];
 #pragma unroll
     for (int h = 0; h < H; h++) {
       int k = lane + 64 * h;
@@ -1184,7 +1185,7 @@ __device__ __forceinline__ void upd_add_listed(double (&acc)[H], const GAS doubl
 #pragma unroll
   for (int q = 0; q < W; q++) {
     const int mq = m0 + q < mc ? m0 + q : mc - 1;
-    const double wq = weighted ? readlane_f64(wl, mq) : 1.0;
+    const double wq = weighted ? swl[mq] : 1.0;
 #pragma unroll
     for (int h = 0; h < H; h++) {
       double nv = acc[h] + xv[q][h] * wq;
@@ -1230,20 +1231,26 @@ __global__ __launch_bounds__(256) void k_step_update(const StepDev *__restrict__
   if (mc == 0) return;  // no member: wsum = 0, centre unchanged (pyx:105-108)
   if (lane == 0) st.mcnt[j] = 0;  // ready for the stratum's next step
   const bool listed = mc <= MCAP;
-  unsigned fm = 0, rm = 0;  // frame / batch row of this lane's member after sorting
-  double wl = 1.0;    // its weight
   double wsum = 0.0;
+  // the wave's LDS strip (UPD_LIST ints): [0,64) keys, [64,128) sorted batch rows, [128,256) sorted weights (doubles)
+  unsigned *kb = (unsigned *)list, *srow = kb + 64;
+  double *swl = (double *)(list + 128);
   if (listed) {
     // the E-step appended the members in arrival order: rank = number of smaller keys (keys are distinct)
     if (lane >= mc) mine = ~0ull;
     const unsigned lo = (unsigned)mine, hi = (unsigned)(mine >> 32);  // hi = batch row: distinct, so it alone orders
+    // every lane compares its key with all mc keys: the keys go through LDS and come back four at a time as broadcast
+    // reads (a v_readlane loop costs ~100 cycles per key here: 2 us for a 50-member cluster)
+    kb[lane] = hi;
     int rank = 0;
-    for (int q = 0; q < mc; q++) rank += (unsigned)__builtin_amdgcn_readlane((int)hi, q) < hi;
-    fm = (unsigned)__builtin_amdgcn_ds_permute(rank << 2, (int)lo);  // lane `rank` receives this member
-    rm = (unsigned)__builtin_amdgcn_ds_permute(rank << 2, (int)hi);
+    for (int q0 = 0; q0 < mc; q0 += 4) {
+      const uint4 k4 = *(const uint4 *)&kb[q0];  // (entries past mc hold 0xffffffff: never smaller)
+      rank += (k4.x < hi) + (k4.y < hi) + (k4.z < hi) + (k4.w < hi);
+    }
+    if (lane < mc) srow[rank] = hi;
     if (st.wf) {
-      if (lane < mc) wl = st.wf[fm];
-      for (int q = 0; q < mc; q++) wsum = wsum + readlane_f64(wl, q);  // sample order (pyx:80-85)
+      if (lane < mc) swl[rank] = st.wf[lo];  // lo = frame of this member
+      for (int q = 0; q < mc; q++) wsum = wsum + swl[q];  // sample order (pyx:80-85)
     } else wsum = (double)mc;  // the sum of mc ones is exactly mc
   }
   SPROF_W(1, 2)
@@ -1303,10 +1310,10 @@ __global__ __launch_bounds__(256) void k_step_update(const StepDev *__restrict__
   SPROF_W(1, 3)
   if (listed) {
     // one round trip for clusters of up to 64 / H members; the width follows the member count
-    if (mc <= 16 / H) upd_add_listed<16 / H, H>(acc, Xg, ldg, rm, wl, st.wf != nullptr, 0, mc, D, lane);
-    else if (mc <= 32 / H) upd_add_listed<32 / H, H>(acc, Xg, ldg, rm, wl, st.wf != nullptr, 0, mc, D, lane);
+    if (mc <= 16 / H) upd_add_listed<16 / H, H>(acc, Xg, ldg, srow, swl, st.wf != nullptr, 0, mc, D, lane);
+    else if (mc <= 32 / H) upd_add_listed<32 / H, H>(acc, Xg, ldg, srow, swl, st.wf != nullptr, 0, mc, D, lane);
     else
-      for (int m0 = 0; m0 < mc; m0 += 64 / H) upd_add_listed<64 / H, H>(acc, Xg, ldg, rm, wl, st.wf != nullptr, m0, mc, D, lane);
+      for (int m0 = 0; m0 < mc; m0 += 64 / H) upd_add_listed<64 / H, H>(acc, Xg, ldg, srow, swl, st.wf != nullptr, m0, mc, D, lane);
   } else {
     auto add_members = [&](int fill) {
       for (int m0 = 0; m0 < fill; m0 += 8) {
@@ -1352,12 +1359,18 @@ __global__ __launch_bounds__(256) void k_step_update(const StepDev *__restrict__
     }
   }
   if (lane == 0) st.counts[j] = cnt1;
-  // ||c||^2 as an fma chain over ascending k (oracle sqnorm_chain): lane values broadcast in order
+  // ||c||^2 as an fma chain over ascending k (oracle sqnorm_chain): the new row goes through the wave's LDS strip and
+  // comes back as broadcast reads, two features at a time (a v_readlane loop costs ~100 cycles per feature here)
+  double *vb = (double *)list;
+#pragma unroll
+  for (int h = 0; h < H; h++) vb[lane + 64 * h] = v[h];  // (lanes past D hold 0.0)
   double a = 0.0;
-  for (int k = 0; k < D; k++) {
-    double vk = readlane_f64(v[k < 64 ? 0 : H - 1], k & 63);
-    a = __builtin_fma(vk, vk, a);
+  for (int k = 0; k + 1 < D; k += 2) {
+    const double2 t = *(const double2 *)&vb[k];
+    a = __builtin_fma(t.x, t.x, a);
+    a = __builtin_fma(t.y, t.y, a);
   }
+  if (D & 1) a = __builtin_fma(vb[D - 1], vb[D - 1], a);
   if (lane == 0) st.csq[j] = a;
   SPROF_W(1, 5)
 #if defined(STEP_PROFILE) && STEP_PROFILE < 2
