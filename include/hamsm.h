@@ -205,6 +205,8 @@ int hamsm_kmeans_seed_multi(hamsm_ctx *ctx, int n_items, const int32_t *h_stratu
 
 /* One planned minibatch step: batch rows d_rows[rows_off .. rows_off+n_b) (relative to frame x_off)
  * update the centroids of `stratum`.
+ * flags bit1 (HAMSM_STEP_FIRST): the first step after seeding -- every count is zero by construction (_kmeans.py:2271),
+ * which is what makes `_random_reassign` fire on it (:2037); the zero-count stop (HAMSM_STOP_ZERO) is not applied.
  * flags bit0: the low-count rule (_kmeans.py:1643-1673) is evaluated after the step (the host's closed-form
  * `_random_reassign` schedule, :2029-2043).  The rule needs `random_state.choice(n_b, replace=False,
  * size=n_low)`, i.e. the first n_low entries of `random_state.permutation(n_b)` -- random numbers are consumed
@@ -213,6 +215,8 @@ int hamsm_kmeans_seed_multi(hamsm_ctx *ctx, int n_items, const int32_t *h_stratu
  *   perm_off >= 0 : predicted n_low > 0: h_perm[perm_off .. perm_off+n_perm) holds the head of the permutation
  *                   the host drew; the device re-seeds the low centroids from it (ascending centroid index
  *                   <-> permutation order, counts := min over the others), exactly as :1652-1673.            */
+#define HAMSM_STEP_TEST 1
+#define HAMSM_STEP_FIRST 2
 typedef struct hamsm_step {
   int32_t stratum;
   int32_t flags;

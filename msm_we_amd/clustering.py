@@ -359,37 +359,22 @@ class ClusteringMixin:
                 m.__dict__.pop("n_steps_", None)
             return False
 
-        # A stratum's FIRST step regularly needs the host: when the seeding batch is a subsample drawn with
-        # replacement (init_size < batch rows, `_kmeans.py:1003-1011`) duplicate seeds end the step with no member and
-        # are re-seeded at once (`:1652-1673`).  It is taken with the host in the loop; everything after it is fused.
-        if len(rs_objs) < len(pred):
-            shared_rng = True   # models share a RandomState: draws interleave in call order, keep the strict order
-        else:
-            shared_rng = False
-        for b in sorted(pred, key=lambda x: (first_g[x], x)):
-            m, g0 = models[b], int(first_g[b])
-            m._batch_size, m._init_size = pred[b]["bs"], pred[b]["init"]
-            m._counts_cache = np.zeros(m.n_clusters)
-            m._n_since_last_reassign = 0
-            m.__dict__["_device_newer"] = True
-            m.__dict__["n_steps_"] = 0
-            state_before = {k: (r.get_state()[1].tobytes(), r.get_state()[2]) for k, r in rs_objs.items()}
-            m._host_step(store.Xc.offset(int(gb[g0]) * store.D), store.x_dtype, store.D, d_rows.offset(int(starts[g0, b])),
-                         int(counts[g0, b]), d_w.offset(int(gb[g0])) if d_w is not None else None)
-            if shared_rng and any((r.get_state()[1].tobytes(), r.get_state()[2]) != state_before[k] for k, r in rs_objs.items()):
-                log.info("first step of stratum %d drew from a shared RandomState: rerunning stepwise", b)
-                return undo()
-            assert m._n_since_last_reassign == 0  # counts were all zero: the reassignment test fired
-        # Everything after the first steps is fused.  The low-count rule (`_kmeans.py:1643-1673`) consumes
-        # `random_state.permutation(n_b)` only when some count IS low, so the host predicts per stratum whether it
+        shared_rng = len(rs_objs) < len(pred)  # models share a RandomState: draws interleave in call order
+        # Everything is fused, first steps included (flag FIRST: their counts are zero by construction, which is what
+        # makes the low-count test fire on them; with a seeding subsample drawn with replacement, duplicate seeds end
+        # that step with no member and are re-seeded at once -- the usual stop / settle / resume).  The low-count rule
+        # (`_kmeans.py:1643-1673`) consumes `random_state.permutation(n_b)` only when some count IS low, so the host predicts per stratum whether it
         # will be ("as at the last test": the outcome is persistent -- never on balanced data, at every test once a
         # stratum holds more centroids than populated modes) and hands the permutation heads over; the device
         # re-seeds from them and stops a stratum's chain at the first wrong prediction, which is then settled here
         # (RandomState rewound or the re-seeding done on the host) before the chain resumes.
         chain = {}
         for gs, bb, st, first in parts:
-            chain[int(bb[0])] = dict(g=gs[~first], st=st[~first], pos=0)
-        predict = {b: models[b]._last_n_re > 0 for b in chain}
+            st = st.copy()
+            st["flags"] |= np.where(first, 2, 0).astype(np.int32)
+            chain[int(bb[0])] = dict(g=gs, st=st, pos=0)
+            models[int(bb[0])].__dict__["_device_newer"] = True
+        predict = {b: False for b in chain}
         total_calls = int(max((len(c["g"]) for c in chain.values()), default=0))
         span = G  # calls per fused run; halved after a stop, doubled after a clean run
         g_lo = 0

@@ -1625,7 +1625,7 @@ static int run_steps(hamsm_ctx *c, const void *X, int dt, int64_t ldx, const int
     d.csq = t.csq;
     d.Bpack = t.Bpack;
     d.K = t.K;
-    d.flags = (s.flags & 1) | (want_zero_flag ? 2 : 0);
+    d.flags = (s.flags & 1) | ((want_zero_flag && !(s.flags & HAMSM_STEP_FIRST)) ? 2 : 0);
     d.report = (int32_t *)(b + o_rep) + 2 * i;
     d.prev_report = nullptr;
     d.perm = ((s.flags & 1) && s.perm_off >= 0) ? (const int32_t *)(b + o_perm) + s.perm_off : nullptr;

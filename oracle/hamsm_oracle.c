@@ -761,6 +761,7 @@ int hamsm_minibatch_run(hamsm_ctx *c, const void *X, int dt, int64_t ldx, const 
     const int32_t *rs = rows ? rows + st->rows_off : NULL;
     int zero = 0;
     for (int j = 0; j < t->K; j++) zero |= (t->counts[j] == 0.0); /* _kmeans.py:2037 */
+    if (st->flags & HAMSM_STEP_FIRST) zero = 0; /* all counts are zero by construction: not a finding */
     report[2 * i] = zero;
     if (zero) {
       stopped[s] = 1;
