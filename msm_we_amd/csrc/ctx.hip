@@ -263,6 +263,18 @@ extern "C" int hamsm_set_geometry(hamsm_ctx *c, int D, int ndim, int S) {
   if (D > 128) return hamsm_fail(c, HAMSM_ENOTSUP, "D=%d > 128 features is not supported yet", D);
   HIPCHK(c, hipSetDevice(c->device));
   HIPCHK(c, hipStreamSynchronize(c->stream));
+  if (D == c->D && ndim == c->ndim && S == c->S && (int)c->st.size() == S && c->d_remap && c->d_table) {
+    // same geometry again (every cluster_coordinates call configures the context): keep the allocations, forget the
+    // model -- unfitted strata, identity remap, mapper to be set anew
+    for (auto &t : c->st) t.K = 0;
+    std::vector<int32_t> id(S);
+    for (int s = 0; s < S; s++) id[s] = s;
+    HIPCHK(c, hipMemcpy(c->d_remap, id.data(), sizeof(int32_t) * S, hipMemcpyHostToDevice));
+    c->Kfit = 0;
+    c->table_dirty = true;
+    c->have_mapper = false;
+    return HAMSM_OK;
+  }
   free_strata(c);
   c->D = D;
   // k-steps of 4 features; rounded up to a value the kernels are instantiated for (zero padded)
