@@ -138,3 +138,31 @@ def test_many_strata_take_the_descriptor_table_path(hip_h, oracle_h):
     assert np.array_equal(g[1], o[1])
     for x, y in zip(g[2] + g[3], o[2] + o[3]):
         assert np.array_equal(x, y)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", range(24))
+def test_random_configurations_hip_equals_oracle(hip_h, oracle_h, seed):
+    """seeded fuzz over the shape space (strata, clusters, features, batch sizes, weights, skewed data): the whole
+    training pass and the discretization on the HIP library equal the oracle's bit for bit"""
+    rng = np.random.default_rng(1000 + seed)
+    S = int(rng.integers(1, 7))
+    K = int(rng.integers(2, 40))
+    D = int(rng.choice([1, 2, 3, 5, 8, 13, 17, 30, 33, 48, 64, 70]))
+    segs = int(rng.integers(max(40, 3 * K * S), 6 * K * S + 400))
+    n_it = int(rng.integers(4, 14))
+    cfg = synthetic.WEConfig(f"fz{seed}", 500 + seed, n_it, segs, D, S, max(2, K // 2))
+    kw = dict(weights=bool(rng.integers(2)), outliers=bool(rng.integers(3) == 0), shift=False)
+    if not kw["outliers"] and rng.integers(3) == 0 and K <= 20:
+        kw["shift"] = True
+    try:
+        o = _run(oracle_h, cfg, K, True, **kw)
+    except (ValueError, AssertionError) as e:  # configurations the reference rejects too (n_samples < n_clusters, ...)
+        with pytest.raises(type(e)):
+            _run(hip_h, cfg, K, True, **kw)
+        return
+    g = _run(hip_h, cfg, K, True, **kw)
+    assert g[0].training_path == o[0].training_path
+    assert np.array_equal(g[1], o[1]), (cfg, K, kw)
+    for x, y in zip(g[2] + g[3], o[2] + o[3]):
+        assert np.array_equal(x, y), (cfg, K, kw)
