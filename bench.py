@@ -200,6 +200,43 @@ def cpu_baseline(workload, n_iters_sample, seed, cores):
     return json.loads(r.stdout.strip().splitlines()[-1])
 
 
+def torch_exchange(h, dist, torch, rank, world):
+    """Stand-in for the library's RCCL entry points (only used when its communicator cannot be created): the same
+    collectives on the same device buffers through torch.distributed's NCCL(=RCCL) process group, staged via the host."""
+    h.nranks, h.rank = world, rank
+
+    def allreduce(dtype, op):
+        def f(d_buf, count):
+            a = np.empty(count, dtype=dtype)
+            h.d2h(a, d_buf)
+            t = torch.from_numpy(a).cuda()
+            dist.all_reduce(t, op=op)
+            h.h2d(d_buf, t.cpu().numpy())
+        return f
+
+    h.allreduce_sum_f64 = allreduce(np.float64, dist.ReduceOp.SUM)
+    h.allreduce_sum_i64 = allreduce(np.int64, dist.ReduceOp.SUM)
+    h.allreduce_min_f64 = allreduce(np.float64, dist.ReduceOp.MIN)
+    h.allreduce_max_f64 = allreduce(np.float64, dist.ReduceOp.MAX)
+
+    def bcast(d_buf, nbytes, root=0):
+        a = np.empty(nbytes, dtype=np.uint8)
+        h.d2h(a, d_buf)
+        t = torch.from_numpy(a).cuda()
+        dist.broadcast(t, root)
+        h.h2d(d_buf, t.cpu().numpy())
+
+    def bcast_model(root=0):
+        state = [[h.get_centroids(s) for s in range(h.S)] if rank == root else None]
+        dist.broadcast_object_list(state, src=root)
+        if rank != root:
+            for s, (Cm, counts, csq) in enumerate(state[0]):
+                h.set_centroids(s, Cm if len(Cm) else None, csq=csq if len(Cm) else None, counts=counts if len(Cm) else None)
+
+    h.bcast, h.bcast_model = bcast, bcast_model
+    h.comm_destroy = lambda: None
+
+
 def full_pipeline(m, cfg, seed, flux_mode):
     """The reference's ``build_analyze_model`` sequence from clustering onwards (msm_we.py:588-882): train + discretize,
     flux matrix, cleaning (re-discretize + re-flux), T as CSR on the device, steady state + target flux on the host,
@@ -289,7 +326,19 @@ def main():
     if world > 1:
         uid = [h.comm_unique_id() if rank == 0 else None]
         dist.broadcast_object_list(uid, src=0)
-        h.comm_init(world, rank, uid[0])
+        try:
+            h.comm_init(world, rank, uid[0])   # RCCL communicator inside the library (csrc/comm.hip)
+            ok = 1
+        except Exception as e:  # noqa: BLE001
+            print(f"[bench] rank {rank}: in-library RCCL init failed ({e}); exchange steps go through torch.distributed",
+                  file=sys.stderr, flush=True)
+            ok = 0
+        flag = torch.tensor([ok], device="cuda")
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if int(flag.item()) == 0:
+            if ok:
+                h.comm_destroy()
+            torch_exchange(h, dist, torch, rank, world)
 
     log(f"workload {cfg.name}: {n_iters} iterations x {cfg.segs_per_iter} segments x {cfg.D} features, "
         f"{cfg.S} strata x {cfg.K_s} clusters, rank shard starts at iteration {1 + rank * n_iters}")
