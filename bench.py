@@ -200,7 +200,7 @@ def cpu_baseline(workload, n_iters_sample, seed, cores):
     return json.loads(r.stdout.strip().splitlines()[-1])
 
 
-def torch_exchange(h, dist, torch, rank, world):
+def torch_exchange(h, dist, torch, rank, world, dev="cuda"):
     """Stand-in for the library's RCCL entry points (only used when its communicator cannot be created): the same
     collectives on the same device buffers through torch.distributed's NCCL(=RCCL) process group, staged via the host."""
     h.nranks, h.rank = world, rank
@@ -209,7 +209,7 @@ def torch_exchange(h, dist, torch, rank, world):
         def f(d_buf, count):
             a = np.empty(count, dtype=dtype)
             h.d2h(a, d_buf)
-            t = torch.from_numpy(a).cuda()
+            t = torch.from_numpy(a).to(dev)
             dist.all_reduce(t, op=op)
             h.h2d(d_buf, t.cpu().numpy())
         return f
@@ -222,7 +222,7 @@ def torch_exchange(h, dist, torch, rank, world):
     def bcast(d_buf, nbytes, root=0):
         a = np.empty(nbytes, dtype=np.uint8)
         h.d2h(a, d_buf)
-        t = torch.from_numpy(a).cuda()
+        t = torch.from_numpy(a).to(dev)
         dist.broadcast(t, root)
         h.h2d(d_buf, t.cpu().numpy())
 
@@ -314,8 +314,12 @@ def main():
         import torch
         import torch.distributed as dist
 
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", rank=rank, world_size=world)
+        # (HAMSM_BENCH_BACKEND=gloo: CPU rehearsal of the N > 1 flow, tests/test_distributed_gloo.py)
+        backend = os.environ.get("HAMSM_BENCH_BACKEND", "nccl")
+        dev = "cuda" if backend == "nccl" else "cpu"
+        if dev == "cuda":
+            torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend, rank=rank, world_size=world)
 
     cfg = bench_configs()[args.workload]
     n_iters = args.iters or cfg.n_iters
@@ -333,12 +337,12 @@ def main():
             print(f"[bench] rank {rank}: in-library RCCL init failed ({e}); exchange steps go through torch.distributed",
                   file=sys.stderr, flush=True)
             ok = 0
-        flag = torch.tensor([ok], device="cuda")
+        flag = torch.tensor([ok], device=dev)
         dist.all_reduce(flag, op=dist.ReduceOp.MIN)
         if int(flag.item()) == 0:
             if ok:
                 h.comm_destroy()
-            torch_exchange(h, dist, torch, rank, world)
+            torch_exchange(h, dist, torch, rank, world, dev)
 
     log(f"workload {cfg.name}: {n_iters} iterations x {cfg.segs_per_iter} segments x {cfg.D} features, "
         f"{cfg.S} strata x {cfg.K_s} clusters, rank shard starts at iteration {1 + rank * n_iters}")
@@ -353,7 +357,8 @@ def main():
         if dist is not None:
             import torch
 
-            torch.cuda.synchronize()
+            if dev == "cuda":
+                torch.cuda.synchronize()
             dist.barrier()
 
     for _ in range(args.warmup):
@@ -368,7 +373,7 @@ def main():
     if dist is not None:
         import torch
 
-        t = torch.tensor([elapsed], device="cuda")
+        t = torch.tensor([elapsed], device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 

@@ -161,3 +161,24 @@ def test_two_ranks_match_single_process(tmp_path, oracle_lib):
     np.testing.assert_allclose(r0["T"], c.Tmatrix, rtol=1e-11, atol=1e-300)
     np.testing.assert_allclose(r0["pSS"], c.pSS, rtol=1e-8, atol=1e-300)
     assert abs(float(r0["J"]) - c.JtargetSS) <= 1e-8 * c.JtargetSS
+
+
+def test_bench_two_rank_flow_on_cpu(tmp_path, oracle_lib):
+    """bench.py launched the way the driver launches it for N > 1 (torch.distributed.run, one rank per "GPU"), rehearsed
+    on the CPU: gloo process group, oracle library, and -- because the oracle has no collective backend -- the
+    torch.distributed stand-in for the exchange steps.  Checks the contract line of rank 0."""
+    import json
+    import subprocess
+
+    env = dict(os.environ, HAMSM_BENCH_BACKEND="gloo", OMP_NUM_THREADS="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1",
+           "--workload", "tiny", "--lib", _build_oracle()]
+    r = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1  # ONE line, from rank 0
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["scaling"] == "weak" and out["unit"] == "frames/s" and out["value"] > 0
+    assert "cpu_baseline" not in out and out["config"]["parallelism"] == "iteration-sharded x2"
+    assert "torch.distributed" in r.stderr  # the stand-in was used (the oracle cannot create a communicator)
