@@ -325,7 +325,9 @@ def main():
     n_iters = args.iters or cfg.n_iters
     seed = 1337
 
-    h = _abi.Hamsm(lib=ctypes.CDLL(args.lib) if args.lib else None, device=local_rank)  # the HIP library; raises if not built
+    # (HAMSM_BENCH_DEVICE: rehearsals of the N > 1 flow on a box with fewer GPUs than ranks)
+    device = int(os.environ.get("HAMSM_BENCH_DEVICE", local_rank))
+    h = _abi.Hamsm(lib=ctypes.CDLL(args.lib) if args.lib else None, device=device)  # the HIP library; raises if not built
     assert args.lib or h.backend == "hip-gfx950"
     if world > 1:
         uid = [h.comm_unique_id() if rank == 0 else None]
