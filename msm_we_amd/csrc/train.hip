@@ -695,7 +695,6 @@ extern "C" int hamsm_kmeans_seed_multi(hamsm_ctx *c, int n_items, const int32_t 
   };
   std::vector<Lay> lay(n_items);
   size_t o_items = take(sizeof(SeedItem) * n_items);
-  size_t tot_u = 0, tot_sub = 0;
   int64_t nmax = 0;
   for (int i = 0; i < n_items; i++) {
     int s = h_stratum[i];
@@ -722,8 +721,6 @@ extern "C" int hamsm_kmeans_seed_multi(hamsm_ctx *c, int n_items, const int32_t 
     l.u = take(sizeof(double) * (size_t)(K > 1 ? (K - 1) * L : 1));
     l.ch = take(sizeof(long long) * K);
     l.sub = take(sizeof(long long) * (h_n_sub[i] ? h_n_sub[i] : 1));
-    tot_u += (size_t)(K - 1) * L;
-    tot_sub += h_n_sub[i];
   }
   int rc = hamsm_ensure_scratch(c, off);
   if (rc) return rc;
