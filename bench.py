@@ -386,6 +386,7 @@ def main():
     rows_per_launch = n_seg                                   # one launch = all parent (or child) frames
     flops = 2.0 * cfg.K_s * cfg.D * rows_per_launch           # 2*K_s*D per frame
     bytes_alg = (cfg.D * 4 + 8 + 4) * rows_per_launch         # D*s + 8*ndim + 4 per frame
+    assign_avg_ms = assign_avg_ms or float("nan")  # (the CPU rehearsal has no kernel timers)
     tflops = flops / (assign_avg_ms * 1e-3) / 1e12
     K = cfg.K_s * cfg.S
     out = {

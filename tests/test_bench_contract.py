@@ -1,0 +1,28 @@
+"""bench.py prints ONE JSON line with the keys the driver reads (task contract) plus `roofline` and `cpu_baseline`.
+Rehearsed on the CPU with the oracle library standing in for the device (`--lib`): the numbers mean nothing here,
+the shape of the line does."""
+import json
+import os
+import subprocess
+import sys
+
+from conftest import ROOT, _build_oracle
+
+
+def test_bench_line_has_the_contract_keys():
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--workload", "tiny", "--lib", _build_oracle(), "--steps", "1",
+                        "--warmup", "0", "--cpu-iters", "4", "--cpu-cores", "2"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1
+    out = json.loads(lines[0])
+    for k, t in (("metric", str), ("value", float), ("unit", str), ("n_gpus", int), ("steps", int), ("warmup", int),
+                 ("ms_per_step", float), ("higher_is_better", bool), ("scaling", str), ("dtype", str), ("data", str),
+                 ("config", dict), ("roofline", dict), ("cpu_baseline", dict)):
+        assert isinstance(out[k], t), k
+    assert out["vs_baseline"] is None and out["n_gpus"] == 1 and out["steps"] == 1 and out["scaling"] == "weak"
+    assert out["unit"] == "frames/s" and out["data"] == "synthetic" and out["dtype"] == "f64" and "workload" in out["config"]
+    assert set(out["roofline"]) >= {"bound", "achieved", "peak", "unit", "frac", "traffic"} and out["roofline"]["bound"] == "mfma"
+    assert set(out["cpu_baseline"]) >= {"value", "unit", "cores", "kind", "sample"} and out["cpu_baseline"]["kind"] == "port"
+    assert out["cpu_baseline"]["cores"] == 1 and out["cpu_baseline"]["all_cores"]["cores"] == 2
+    assert "solve" in out and "full_pipeline" in out
