@@ -17,72 +17,83 @@ __global__ void k_pack_w(const double *__restrict__ W, int d, int Draw, int KS, 
   Wp[e] = (j < d && k < Draw) ? W[(size_t)j * Draw + k] : 0.0;
 }
 
-// One workgroup = 128 frames (4 waves x 2 tiles of 16).  The raw features stream through LDS in chunks of 32 (8 k-steps):
-// coalesced global loads (a wave reads two rows' 128-byte pieces), row stride 34 elements so that both the staging
-// writes and the fragment reads (16 frames x 2 features per half-wave) hit 32 distinct banks; the component fragments
-// of the chunk are staged once per workgroup instead of being fetched from L2 by every wave and k-step.  Chunk c+1 is
-// requested before chunk c is consumed.  Up to four component tiles per sweep over the features.
+// One workgroup = 128 frames (4 waves x 2 tiles of 16).  The raw features stream through LDS in chunks of KB = 32 (64
+// was tried: one workgroup per CU, slower): coalesced global loads (thread t always reads column t % KB of rows t / KB + 256/KB i
+// -- one base pointer, constant stride), row stride KB + 2 elements so that the staging writes and the fragment reads
+// (16 frames x 2 features per half-wave) hit 32 distinct banks; the component fragments of a chunk are staged once per
+// workgroup.  Chunk c+1 is requested before chunk c is consumed.  NJ component tiles per sweep over the features is a
+// template parameter and every load is unconditional at a clamped address, so the k-step loop has no branches:
+// columns >= Draw meet zero fragments (the rows are finite), rows >= n are computed and not stored.
 #define PJ_FR 128
-#define PJ_KB 32
-#define PJ_XS 34
-template <typename XT>
+#define PJ_KB_OF(XT) 32
+template <typename XT, int NJ>
 __global__ __launch_bounds__(256) void k_project(const XT *__restrict__ X, int64_t ldx, int64_t n, int Draw, int KS,
                                                  const double *__restrict__ Wp, int njt, const double *__restrict__ m,
                                                  const double *__restrict__ scale, int d, double *__restrict__ Y) {
-  __shared__ XT xs[2][PJ_FR * PJ_XS];
-  __shared__ double ws[2][4 * 8 * 64];
+  constexpr int KB = PJ_KB_OF(XT), XS = KB + 2, KSC = KB / 4, RP = 256 / KB;  // RP rows per staging pass
+  constexpr int NX = PJ_FR / RP, NWR = NJ * KSC * 64 / 256;
+  // LDS: ws[2][NJ][KSC][64] doubles, then xs[2][128][XS] XT
+  extern __shared__ double pj_lds[];
+  double *ws0 = pj_lds, *ws1 = pj_lds + (size_t)NJ * KSC * 64;
+  XT *xs0 = (XT *)(pj_lds + (size_t)NJ * KSC * 128), *xs1 = xs0 + PJ_FR * XS;
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int64_t f0 = (int64_t)blockIdx.x * PJ_FR;
-  const int nch = (Draw + PJ_KB - 1) / PJ_KB;
-  for (int j0 = 0; j0 < njt; j0 += 4) {
-    const int nj = njt - j0 < 4 ? njt - j0 : 4;
-    v4f64 acc[4][2];
+  const int nch = (Draw + KB - 1) / KB;
+  const int xr_row = tid / KB, xr_col = tid % KB;
+  const bool full = f0 + PJ_FR <= n;
+  for (int j0 = 0; j0 < njt; j0 += NJ) {
+    v4f64 acc[NJ][2];
 #pragma unroll
-    for (int u = 0; u < 4; u++)
+    for (int u = 0; u < NJ; u++)
 #pragma unroll
       for (int t = 0; t < 2; t++) acc[u][t] = (v4f64){0.0, 0.0, 0.0, 0.0};
-    XT xr[PJ_FR * PJ_KB / 256];
-    double wr[4 * 8 * 64 / 256];
-    auto fetch = [&](int c) {  // chunk c: features [32 c, 32 c + 32) of the 128 rows, k-steps [8 c, 8 c + 8) of nj tiles
+    XT xr[NX];
+    double wr[NWR];
+    auto fetch = [&](int c) {
+      const int kc = c * KB + xr_col;
+      const XT *p = X + (f0 + xr_row) * ldx + (kc < Draw ? kc : Draw - 1);
+      if (full) {
 #pragma unroll
-      for (int i = 0; i < PJ_FR * PJ_KB / 256; i++) {
-        const int e = tid + 256 * i, r = e / PJ_KB, k = c * PJ_KB + e % PJ_KB;
-        const int64_t f = f0 + r;
-        xr[i] = (f < n && k < Draw) ? X[f * ldx + k] : (XT)0;
+        for (int i = 0; i < NX; i++) xr[i] = p[(int64_t)(RP * i) * ldx];
+      } else {
+#pragma unroll
+        for (int i = 0; i < NX; i++) {
+          const int64_t f = f0 + xr_row + RP * i;
+          xr[i] = p[((f < n ? f : n - 1) - (f0 + xr_row)) * ldx];
+        }
       }
 #pragma unroll
-      for (int i = 0; i < 4 * 8 * 64 / 256; i++) {
-        const int e = tid + 256 * i, u = e / 512, ks = c * 8 + (e % 512) / 64;
-        wr[i] = (u < nj && ks < KS) ? Wp[((size_t)(j0 + u) * KS + ks) * 64 + (e & 63)] : 0.0;
+      for (int i = 0; i < NWR; i++) {
+        const int e = tid + 256 * i, jt = j0 + e / (KSC * 64), ks = c * KSC + (e % (KSC * 64)) / 64;
+        const double v = Wp[((size_t)(jt < njt ? jt : njt - 1) * KS + (ks < KS ? ks : KS - 1)) * 64 + lane];
+        wr[i] = (jt < njt && ks < KS) ? v : 0.0;
       }
     };
     auto stash = [&](int buf) {
+      XT *xs = buf ? xs1 : xs0;
+      double *ws = buf ? ws1 : ws0;
 #pragma unroll
-      for (int i = 0; i < PJ_FR * PJ_KB / 256; i++) {
-        const int e = tid + 256 * i;
-        xs[buf][(e / PJ_KB) * PJ_XS + e % PJ_KB] = xr[i];
-      }
+      for (int i = 0; i < NX; i++) xs[(xr_row + RP * i) * XS + xr_col] = xr[i];
 #pragma unroll
-      for (int i = 0; i < 4 * 8 * 64 / 256; i++) ws[buf][tid + 256 * i] = wr[i];
+      for (int i = 0; i < NWR; i++) ws[tid + 256 * i] = wr[i];
     };
     fetch(0);
     stash(0);
     __syncthreads();
     for (int c = 0; c < nch; c++) {
       const int buf = c & 1;
+      const XT *xs = (buf ? xs1 : xs0) + (wv * 32 + (lane & 15)) * XS + (lane >> 4);
+      const double *ws = (buf ? ws1 : ws0) + lane;
       if (c + 1 < nch) fetch(c + 1);
+#pragma unroll 2
+      for (int ks = 0; ks < KSC; ks++) {
+        const double b0 = (double)xs[4 * ks], b1 = (double)xs[16 * XS + 4 * ks];
 #pragma unroll
-      for (int ks = 0; ks < 8; ks++) {
-        double b[2];
-#pragma unroll
-        for (int t = 0; t < 2; t++) b[t] = (double)xs[buf][(wv * 32 + t * 16 + (lane & 15)) * PJ_XS + 4 * ks + (lane >> 4)];
-#pragma unroll
-        for (int u = 0; u < 4; u++)
-          if (u < nj) {
-            const double a = ws[buf][(u * 8 + ks) * 64 + lane];
-#pragma unroll
-            for (int t = 0; t < 2; t++) acc[u][t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b[t], acc[u][t], 0, 0, 0);
-          }
+        for (int u = 0; u < NJ; u++) {
+          const double a = ws[(u * KSC + ks) * 64];
+          acc[u][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b0, acc[u][0], 0, 0, 0);
+          acc[u][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b1, acc[u][1], 0, 0, 0);
+        }
       }
       if (c + 1 < nch) stash(buf ^ 1);
       __syncthreads();
@@ -92,11 +103,11 @@ __global__ __launch_bounds__(256) void k_project(const XT *__restrict__ X, int64
       const int64_t f = f0 + wv * 32 + t * 16 + (lane & 15);
       if (f < n) {
 #pragma unroll
-        for (int u = 0; u < 4; u++)
+        for (int u = 0; u < NJ; u++)
 #pragma unroll
           for (int q = 0; q < 4; q++) {
             const int j = (j0 + u) * 16 + (lane >> 4) + 4 * q;
-            if (u < nj && j < d) {
+            if (j < d) {
               double v = acc[u][t][q];
               if (m) v = v - m[j];          // X_transformed -= mean_ @ components_.T
               if (scale) v = v / scale[j];  // whiten
@@ -107,6 +118,20 @@ __global__ __launch_bounds__(256) void k_project(const XT *__restrict__ X, int64
     }
     __syncthreads();  // (the next sweep re-stages buffer 0)
   }
+}
+
+template <typename XT>
+static int launch_project(hamsm_ctx *c, const XT *X, int64_t ldx, int64_t n, int Draw, int KS, const double *Wp, int njt,
+                          const double *m, const double *sc, int d, double *Y) {
+  const int nj = njt < 4 ? njt : 4;
+  const size_t lds = sizeof(double) * nj * (PJ_KB_OF(XT) / 4) * 128 + sizeof(XT) * 2 * PJ_FR * (PJ_KB_OF(XT) + 2);
+  const void *fn = nj == 1 ? (const void *)k_project<XT, 1> : nj == 2 ? (const void *)k_project<XT, 2>
+                 : nj == 3 ? (const void *)k_project<XT, 3> : (const void *)k_project<XT, 4>;
+  HIPCHK(c, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  void *args[] = {(void *)&X, (void *)&ldx, (void *)&n, (void *)&Draw, (void *)&KS, (void *)&Wp, (void *)&njt, (void *)&m,
+                  (void *)&sc, (void *)&d, (void *)&Y};
+  HIPCHK(c, hipLaunchKernel(fn, dim3((unsigned)((n + PJ_FR - 1) / PJ_FR)), dim3(256), args, lds, c->stream));
+  return HAMSM_OK;
 }
 
 extern "C" int hamsm_project(hamsm_ctx *c, const void *X, int dt, int64_t ldx, int64_t n, int Draw, const double *h_mean,
@@ -137,16 +162,15 @@ extern "C" int hamsm_project(hamsm_ctx *c, const void *X, int dt, int64_t ldx, i
   const double *Wp = (const double *)(b + o_wp);
   const double *m = nullptr;
   if (h_mean) {  // mean_ @ components_.T by the same chains
-    hipLaunchKernelGGL(k_project<double>, dim3(1), dim3(256), 0, c->stream, (const double *)(b + o_mean), (int64_t)Draw, (int64_t)1,
-                       Draw, KS, Wp, njt, (const double *)nullptr, (const double *)nullptr, d, (double *)(b + o_m));
+    rc = launch_project<double>(c, (const double *)(b + o_mean), (int64_t)Draw, (int64_t)1, Draw, KS, Wp, njt, nullptr, nullptr, d,
+                                (double *)(b + o_m));
+    if (rc) return rc;
     m = (const double *)(b + o_m);
   }
   const double *sc = h_scale ? (const double *)(b + o_s) : nullptr;
-  const unsigned grid = (unsigned)((n + PJ_FR - 1) / PJ_FR);
-  if (dt == HAMSM_F32)
-    hipLaunchKernelGGL(k_project<float>, dim3(grid), dim3(256), 0, c->stream, (const float *)X, ldx, n, Draw, KS, Wp, njt, m, sc, d, Y);
-  else
-    hipLaunchKernelGGL(k_project<double>, dim3(grid), dim3(256), 0, c->stream, (const double *)X, ldx, n, Draw, KS, Wp, njt, m, sc, d, Y);
+  rc = dt == HAMSM_F32 ? launch_project<float>(c, (const float *)X, ldx, n, Draw, KS, Wp, njt, m, sc, d, Y)
+                       : launch_project<double>(c, (const double *)X, ldx, n, Draw, KS, Wp, njt, m, sc, d, Y);
+  if (rc) return rc;
   hamsm_timer_end(c, ST_OTHER);
   HIPCHK(c, hipGetLastError());
   HIPCHK(c, hipStreamSynchronize(c->stream));  // h_W / h_mean / h_scale are the caller's
