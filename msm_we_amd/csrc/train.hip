@@ -968,12 +968,12 @@ __global__ __launch_bounds__(256) void k_step_assign(const StepDev *__restrict__
   auto load_group = [&](int t0) {
 #pragma unroll
     for (int u = 0; u < JB; u++) {
-      int jt = t0 + 4 * u;
-      bool live = jt < njt;
+      // unconditional loads at a clamped tile (tiles past the last one are never multiplied: see the MFMA loop)
+      const int jt = t0 + 4 * u < njt ? t0 + 4 * u : njt - 1;
 #pragma unroll
-      for (int q = 0; q < 4; q++) cs[u][q] = live ? st.csq[jt * 16 + (lane >> 4) + 4 * q] : inf;
+      for (int q = 0; q < 4; q++) cs[u][q] = st.csq[jt * 16 + (lane >> 4) + 4 * q];
 #pragma unroll
-      for (int ks = 0; ks < KS; ks++) b[u][ks] = live ? st.Bpack[((size_t)jt * KS + ks) * 64 + lane] : 0.0;
+      for (int ks = 0; ks < KS; ks++) b[u][ks] = st.Bpack[((size_t)jt * KS + ks) * 64 + lane];
     }
   };
 #ifdef STEP_TOUCH
@@ -995,8 +995,9 @@ __global__ __launch_bounds__(256) void k_step_assign(const StepDev *__restrict__
   for (int rt = 0; rt < RT; rt++)
 #pragma unroll
     for (int ks = 0; ks < KS; ks++) {
-      int k = ks * 4 + (lane >> 4);
-      a[rt][ks] = (ok[rt] && k < D) ? (double)X[f[rt] * ldx + k] : 0.0;
+      // unconditional: rows past n_b read frame 0 and are not stored; features past D meet zero centroid fragments
+      const int k = ks * 4 + (lane >> 4);
+      a[rt][ks] = (double)X[f[rt] * ldx + (k < D ? k : D - 1)];
     }
   SPROF_W(0, 3)
   __shared__ double sd[4][RW];
