@@ -822,7 +822,8 @@ struct StepDev {
   const double *wf;      // nullable, indexed like X
   long long n_b;
   int32_t *labels;       // [n_b] scratch
-  double *Xg;            // [n_b][D] the batch rows as f64, written by the E-step for the M-step (measured: an f32 copy,
+  double *Xg;            // [n_b padded to 64][4 KS] the batch rows as f64 (rows = whole 128-byte lines), written by the
+                         // E-step for the M-step (measured: an f32 copy,
                          // packed or one row per 128-byte line, makes the M-step's fetch 3x slower): a small buffer that is
                          // TLB- and cache-warm on every CU, unlike the call's span of the frame array
   int32_t *mcnt;         // [K] members appended by the E-step (reset by the M-step)
@@ -1101,13 +1102,11 @@ __global__ __launch_bounds__(256) void k_step_assign(const StepDev *__restrict__
   // the batch rows as f64 for the M-step: row tile rt is written by wave (rt + 1) & 3
 #pragma unroll
   for (int rt = 0; rt < RT; rt++)
-    if (((rt + 1) & 3) == wv && ok[rt]) {
+    if (((rt + 1) & 3) == wv) {
+      // rows of 4 KS doubles (whole 128-byte lines), the batch padded to whole tiles: unconditional stores
       const long long r = r0 + rt * 16 + (lane & 15);
 #pragma unroll
-      for (int ks = 0; ks < KS; ks++) {
-        int k = ks * 4 + (lane >> 4);
-        if (k < D) st.Xg[(size_t)r * D + k] = a[rt][ks];
-      }
+      for (int ks = 0; ks < KS; ks++) st.Xg[(size_t)r * (4 * KS) + ks * 4 + (lane >> 4)] = a[rt][ks];
     }
   SPROF_W(0, 5)
 #pragma unroll
@@ -1210,7 +1209,7 @@ __global__ __launch_bounds__(256) void k_step_update(const StepDev *__restrict__
   int *list = lds_i + wv * UPD_LIST;  // [UPD_LIST] member batch rows of this wave, ascending (label-scan path only)
   const GAS int *lab = st.labels;
   const GAS double *Xg = st.Xg;
-  const int ldg = D;
+  const int ldg = 4 * KS;  // rows of the batch copy are padded to whole k-steps
   const int j = blockIdx.x * 4 + wv;
   if (j >= st.K) return;
   const long long n_b = st.n_b;
@@ -1599,8 +1598,9 @@ static int run_steps(hamsm_ctx *c, const void *X, int dt, int64_t ldx, const int
   // the gathered batch copy and the member lists are reused by every launch group: one slot per stratum position,
   // stream-ordered
   const int nslot = c->S < 65535 ? c->S : 65535;
-  const size_t xg_row = sizeof(double) * (size_t)c->D;
-  size_t o_xg = take(xg_row * (size_t)nslot * nb_max);
+  const size_t xg_row = sizeof(double) * 4 * (size_t)c->KS;
+  const size_t nb_pad = ((size_t)nb_max + 63) & ~(size_t)63;  // whole E-step tiles (up to 4 x 16 rows)
+  size_t o_xg = take(xg_row * (size_t)nslot * nb_pad);
   int Kmax = 0;
   for (int s = 0; s < c->S; s++) Kmax = c->st[s].K > Kmax ? c->st[s].K : Kmax;
   size_t o_mc = take(sizeof(int32_t) * (size_t)nslot * Kmax),
@@ -1660,7 +1660,7 @@ static int run_steps(hamsm_ctx *c, const void *X, int dt, int64_t ldx, const int
         used[h_steps[j0].stratum] = 1;
         // scratch slot = the stratum itself: chains of different strata run concurrently on different queues
         const size_t slot = nslot == c->S ? (size_t)h_steps[j0].stratum : (size_t)(j0 - i0);
-        sd[j0].Xg = (double *)(b + o_xg + slot * nb_max * xg_row);
+        sd[j0].Xg = (double *)(b + o_xg + slot * nb_pad * xg_row);
         sd[j0].mcnt = (int32_t *)(b + o_mc) + slot * Kmax;
         sd[j0].mlist = (unsigned long long *)(b + o_ml) + slot * Kmax * MCAP;
         j0++;
