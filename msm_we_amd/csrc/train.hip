@@ -1175,8 +1175,8 @@ __device__ __forceinline__ void upd_add_listed(double (&acc)[H], const GAS doubl
     const size_t rq = (size_t)srow[mq];
 #pragma unroll
     for (int h = 0; h < H; h++) {
-      int k = lane + 64 * h;
-      xv[q][h] = (k < D) ? Xg[rq * ldg + k] : 0.0;
+      const int k = lane + 64 * h;
+      xv[q][h] = Xg[rq * ldg + (k < D ? k : D - 1)];  // unconditional; lanes past D carry a copy that is never stored
     }
   }
 #pragma unroll
@@ -1220,8 +1220,8 @@ __global__ __launch_bounds__(256) void k_step_update(const StepDev *__restrict__
   double c0[H];
 #pragma unroll
   for (int h = 0; h < H; h++) {
-    int k = lane + 64 * h;
-    c0[h] = (k < D) ? st.C[(size_t)j * D + k] : 0.0;
+    const int k = lane + 64 * h;
+    c0[h] = st.C[(size_t)j * D + (k < D ? k : D - 1)];
   }
   SPROF_W(1, 1)
   if (st.idx >= hv) return;  // the stratum's chain stopped before this step
