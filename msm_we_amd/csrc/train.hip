@@ -959,7 +959,8 @@ __global__ __launch_bounds__(256) void k_step_assign(const StepDev *__restrict__
   for (int rt = 0; rt < RT; rt++) {
     const long long r = r0 + rt * 16 + (lane & 15);
     ok[rt] = r < st.n_b;
-    f[rt] = ok[rt] ? (st.rows ? (long long)st.rows[r] : r) : 0;
+    const long long rc = ok[rt] ? r : st.n_b - 1;  // (rows past the batch repeat its last row; nothing of them is kept)
+    f[rt] = st.rows ? (long long)st.rows[rc] : rc;
   }
   SPROF_W(0, 2)
   // the first group of centroid operands does not depend on the row index: requested before the gather waits for it
