@@ -592,23 +592,25 @@ __global__ __launch_bounds__(SEED_TL) void k_seed_lds(const SeedItem *__restrict
       }
 #pragma unroll
       for (int lp = 0; lp < SEED_LPT; lp++) {
-        double a[LF];
+        double a[LF], xc[LF];
 #pragma unroll
-        for (int l = 0; l < LF; l++) a[l] = 0.0;
+        for (int l = 0; l < LF; l++) {
+          a[l] = 0.0;
+          xc[l] = lxsq[cid[l]];
+        }
 #pragma unroll
         for (int r = 0; r < SEED_RPL; r++) {
+          // branch-free: a row past the batch repeats the last one with weight +0.0 (a + v * 0.0 == a: a >= +0, v finite)
           const int rr = lp * SEED_RPL + r;
-          int i = row_of(rr);
-          if (i < n) {
-            const double ci = lcl[i], xi2 = lxsq[i], wi = lw[i];
+          const int i = row_of(rr), ic = i < n ? i : n - 1;
+          const double ci = lcl[ic], xi2 = lxsq[ic], wi = i < n ? lw[ic] : 0.0;
 #pragma unroll
-            for (int l = 0; l < LF; l++) {
-              double v = ((-2.0 * cnd[rr][l]) + lxsq[cid[l]]) + xi2;  // :252-254
-              v = v > 0.0 ? v : 0.0;
-              v = v < ci ? v : ci;  // :257
-              cnd[rr][l] = v;
-              a[l] = a[l] + v * wi;
-            }
+          for (int l = 0; l < LF; l++) {
+            double v = ((-2.0 * cnd[rr][l]) + xc[l]) + xi2;  // :252-254
+            v = v > 0.0 ? v : 0.0;
+            v = v < ci ? v : ci;  // :257
+            cnd[rr][l] = v;
+            a[l] = a[l] + v * wi;
           }
         }
 #pragma unroll
