@@ -521,22 +521,27 @@ __global__ __launch_bounds__(SEED_TL) void k_seed_lds(const SeedItem *__restrict
       }
       int ans = n;
       for (int q = lo; q < nch && ans == n; q++) {
+        // the chunk's running sum, all of it, without data-dependent branches: the first position where the
+        // cumulative value reaches v is kept by a select (entries past the chunk end never qualify)
         double loc = 0.0, base = lbase[q];
-        int e = (q + 1) * SCAN_CHUNK < n ? (q + 1) * SCAN_CHUNK : n;
-        for (int i0 = q * SCAN_CHUNK; i0 < e && ans == n; i0 += 16) {
+        const int e = (q + 1) * SCAN_CHUNK < n ? (q + 1) * SCAN_CHUNK : n;
+#pragma unroll
+        for (int b0 = 0; b0 < SCAN_CHUNK; b0 += 16) {
+          const int i0 = q * SCAN_CHUNK + b0;
           double pw[16], pc[16];
 #pragma unroll
           for (int z = 0; z < 16; z++) {
-            int i = i0 + z < e ? i0 + z : i0;
+            const int i = i0 + z < e ? i0 + z : e - 1;
             pw[z] = lw[i];
             pc[z] = lcl[i];
           }
 #pragma unroll
-          for (int z = 0; z < 16; z++)
-            if (i0 + z < e && ans == n) {
-              loc = loc + pw[z] * pc[z];
-              if (base + loc >= v) ans = i0 + z;
-            }
+          for (int z = 0; z < 16; z++) {
+            const bool in = i0 + z < e;
+            const double nl = loc + pw[z] * pc[z];
+            loc = in ? nl : loc;
+            ans = (in && ans == n && base + loc >= v) ? i0 + z : ans;
+          }
         }
       }
       if (ans > n - 1) ans = n - 1;  // :249
