@@ -1079,7 +1079,7 @@ __global__ __launch_bounds__(256) void k_step_assign(const StepDev *__restrict__
         const int slot = pslot + PSTRIDE * i;
         int k = slot * per;
         k = k < D ? k : D - 1;  // the last element covers a row end that straddles into one more line
-        if (slot <= (D - 1) / per + 1) pfv[i] = Xn[k];
+        pfv[i] = Xn[k];         // (unconditional: slots past the row touch its last element again)
       }
     }
     SPROF_W(0, 4)
