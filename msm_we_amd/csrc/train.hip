@@ -833,8 +833,10 @@ struct StepDev {
                          // E-step for the M-step (measured: an f32 copy,
                          // packed or one row per 128-byte line, makes the M-step's fetch 3x slower): a small buffer that is
                          // TLB- and cache-warm on every CU, unlike the call's span of the frame array
-  int32_t *mcnt;         // [K] members appended by the E-step (reset by the M-step)
-  unsigned long long *mlist;  // [K][MCAP] members, unordered: (batch row << 32 | frame); the M-step sorts them
+  unsigned long long *mbits;  // [K][wstride] membership bitmaps: bit b of word w of row j <=> batch row 64 w + b is nearest
+                              // to centroid j.  Set by the E-step with fire-and-forget atomic ORs, read (in sample
+                              // order by construction) and cleared by the M-step.
+  int wstride;                // words per centroid (a multiple of 64, >= ceil(n_b / 64))
   double *C, *counts, *csq, *Bpack;
   int K, flags;          // flags: 1 = low-count test wanted after this step, 2 = zero-count test before it,
                          //        4 = this step's E-step evaluates the low-count test of the stratum's previous step
@@ -859,7 +861,6 @@ struct StepPack {
   int n_next;
 };
 
-#define MCAP 64  // members per centroid kept in the unordered lists; larger clusters fall back to a label scan
 #define PF_MAX 3 // prefetch loads per lane (4 lanes per row): rows of up to 12 cache lines
 
 // STEP_PROFILE=1: entry/exit stamps only; =2: a stamp after every phase, each behind a full s_waitcnt (perturbs overlap)
@@ -905,14 +906,13 @@ struct StepG {  // a StepDev with its pointers in the global address space
   long long n_b;
   GAS int32_t *labels;
   GAS double *Xg;
-  GAS int32_t *mcnt;
-  GAS unsigned long long *mlist;
+  GAS unsigned long long *mbits;
   GAS double *C, *counts, *csq, *Bpack;
   int K, flags, idx;
   GAS int32_t *report;
   __device__ __forceinline__ explicit StepG(const StepDev &d)
       : X(gp((const char *)d.X)), rows(gp(d.rows)), wf(gp(d.wf)), n_b(d.n_b), labels(gp(d.labels)), Xg(gp(d.Xg)),
-        mcnt(gp(d.mcnt)), mlist(gp(d.mlist)), C(gp(d.C)), counts(gp(d.counts)), csq(gp(d.csq)), Bpack(gp(d.Bpack)), K(d.K),
+        mbits(gp(d.mbits)), C(gp(d.C)), counts(gp(d.counts)), csq(gp(d.csq)), Bpack(gp(d.Bpack)), K(d.K),
         flags(d.flags), idx(d.idx), report(gp(d.report)) {}
 };
 
@@ -1149,11 +1149,10 @@ __global__ __launch_bounds__(256) void k_step_assign(const StepDev *__restrict__
     }
     if (j == 0x7fffffff) j = 0;  // all-NaN row: label 0 like the oracle
     st.labels[r0 + tid] = j;
-    long long fr = f[0];  // lane tid (wave 0) holds the frames of rows (tid & 15) + 16 rt: pick rt = tid >> 4
-#pragma unroll
-    for (int rt = 1; rt < RT; rt++) fr = (tid >> 4) == rt ? f[rt] : fr;
-    int pos = __hip_atomic_fetch_add(&st.mcnt[j], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (pos < MCAP) st.mlist[(size_t)j * MCAP + pos] = ((unsigned long long)(r0 + tid) << 32) | (unsigned)fr;
+    const long long r = r0 + tid;
+    // (result unused: a non-returning atomic -- the workgroup does not wait for it)
+    __hip_atomic_fetch_or(&st.mbits[(size_t)j * sdesc.wstride + (r >> 6)], 1ull << (r & 63), __ATOMIC_RELAXED,
+                          __HIP_MEMORY_SCOPE_AGENT);
   }
   if (pf_on) {
 #pragma unroll
@@ -1199,11 +1198,13 @@ __device__ __forceinline__ void upd_add_listed(double (&acc)[H], const GAS doubl
   }
 }
 
-// M-step: one wave per centroid.  Round trip 1 fetches everything that does not depend on the member list (count,
-// list, centre); the list is sorted by batch row in registers; round trip 2 fetches up to UB member rows at once
-// (lane = feature); they are added in ascending sample order (_k_means_minibatch.pyx:59-108).  Clusters with more
-// than MCAP members scan the labels instead.
+// M-step: one wave per centroid.  Round trip 1 fetches the centroid's membership bitmap (one word per lane), its count
+// and its row; the set bits ARE the members in ascending sample order (no list to sort, no cap on the cluster size):
+// each lane expands its word into the wave's LDS strip at the position given by a prefix sum of the popcounts.
+// Round trip 2 fetches up to 64 member rows at once (lane = feature); they are added in sample order
+// (_k_means_minibatch.pyx:59-108).
 #define UPD_LIST 1024
+#define UPD_SC 768  // member rows the strip holds per pass: ints [0, 768); weights of a 64-member chunk: ints [768, 896)
 template <typename XT, int H, bool BYVAL>
 __global__ __launch_bounds__(256) void k_step_update(const StepDev *__restrict__ steps, const StepPack pk, int64_t ldx, int D,
                                                      int KS) {
@@ -1214,16 +1215,17 @@ __global__ __launch_bounds__(256) void k_step_update(const StepDev *__restrict__
   if (blockIdx.x * 4 >= st.K) return;
   extern __shared__ int lds_i[];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  int *list = lds_i + wv * UPD_LIST;  // [UPD_LIST] member batch rows of this wave, ascending (label-scan path only)
-  const GAS int *lab = st.labels;
+  int *list = lds_i + wv * UPD_LIST;
+  unsigned *srow = (unsigned *)list;
+  double *swl = (double *)(list + UPD_SC);
   const GAS double *Xg = st.Xg;
   const int ldg = 4 * KS;  // rows of the batch copy are padded to whole k-steps
   const int j = blockIdx.x * 4 + wv;
   if (j >= st.K) return;
-  const long long n_b = st.n_b;
+  const int nw = (int)((st.n_b + 63) >> 6);
+  GAS unsigned long long *mb = st.mbits + (size_t)j * sdesc.wstride;
   const int hv = *gp(sdesc.halt);
-  const int mc = st.mcnt[j];
-  unsigned long long mine = st.mlist[(size_t)j * MCAP + lane];  // entries past mc are stale: masked below
+  const unsigned long long w0 = mb[lane];  // (wstride is a multiple of 64: always inside the centroid's row)
   const double cnt0 = st.counts[j];
   double c0[H];
 #pragma unroll
@@ -1233,123 +1235,57 @@ __global__ __launch_bounds__(256) void k_step_update(const StepDev *__restrict__
   }
   SPROF_W(1, 1)
   if (st.idx >= hv) return;  // the stratum's chain stopped before this step
-  if (mc == 0) return;  // no member: wsum = 0, centre unchanged (pyx:105-108)
-  if (lane == 0) st.mcnt[j] = 0;  // ready for the stratum's next step
-  const bool listed = mc <= MCAP;
-  double wsum = 0.0;
-  // the wave's LDS strip (UPD_LIST ints): [0,64) keys, [64,128) sorted batch rows, [128,256) sorted weights (doubles)
-  unsigned *kb = (unsigned *)list, *srow = kb + 64;
-  double *swl = (double *)(list + 128);
-  if (listed) {
-    // the E-step appended the members in arrival order: rank = number of smaller keys (keys are distinct)
-    if (lane >= mc) mine = ~0ull;
-    const unsigned lo = (unsigned)mine, hi = (unsigned)(mine >> 32);  // hi = batch row: distinct, so it alone orders
-    // every lane compares its key with all mc keys: the keys go through LDS and come back four at a time as broadcast
-    // reads (a v_readlane loop costs ~100 cycles per key here: 2 us for a 50-member cluster)
-    kb[lane] = hi;
-    int rank = 0;
-    for (int q0 = 0; q0 < mc; q0 += 4) {
-      const uint4 k4 = *(const uint4 *)&kb[q0];  // (entries past mc hold 0xffffffff: never smaller)
-      rank += (k4.x < hi) + (k4.y < hi) + (k4.z < hi) + (k4.w < hi);
-    }
-    if (lane < mc) srow[rank] = hi;
-    if (st.wf) {
-      if (lane < mc) swl[rank] = st.wf[lo];  // lo = frame of this member
-      for (int q = 0; q < mc; q++) wsum = wsum + swl[q];  // sample order (pyx:80-85)
-    } else wsum = (double)mc;  // the sum of mc ones is exactly mc
-  }
-  SPROF_W(1, 2)
-  // label scan, 256 at a time (4 consecutive per lane); members are appended in ascending sample order
-  auto scan4 = [&](long long base, int &fill, bool store) -> int {
-    int l4[4];
-#pragma unroll
-    for (int q = 0; q < 4; q++) {
-      long long i = base + 4 * lane + q;
-      l4[q] = (i < n_b) ? lab[i] : -1;
-    }
-    unsigned long long M[4];
-    int tot = 0, before = 0;
-    const unsigned long long lt = (1ull << lane) - 1;
-#pragma unroll
-    for (int q = 0; q < 4; q++) {
-      M[q] = __ballot(l4[q] == j);
-      tot += __popcll(M[q]);
-      before += __popcll(M[q] & lt);
-    }
-    if (store && tot) {
-      int o = fill + before;
-#pragma unroll
-      for (int q = 0; q < 4; q++)
-        if (l4[q] == j) list[o++] = (int)(base + 4 * lane + q);
-    }
-    fill += tot;
-    return tot;
-  };
-  auto frame_of = [&](int ii) -> long long { return st.rows ? (long long)st.rows[ii] : (long long)ii; };
-  if (!listed) {
-    int fill = 0;
-    long long cnt = 0;
-    for (long long base = 0; base < n_b; base += 256) {
-      int got = scan4(base, fill, st.wf != nullptr);
-      cnt += got;
-      if (st.wf && fill && (fill > UPD_LIST - 256 || base + 256 >= n_b)) {
-        for (int m0 = 0; m0 < fill; m0 += 64) {
-          int ii = (m0 + lane < fill) ? list[m0 + lane] : -1;
-          double wv_ = 0.0;
-          if (ii >= 0) wv_ = st.wf[frame_of(ii)];
-          int lim = fill - m0 < 64 ? fill - m0 : 64;
-          for (int q = 0; q < lim; q++) wsum = wsum + readlane_f64(wv_, q);
-        }
-        fill = 0;
-      }
-      if (!st.wf) fill = 0;
-    }
-    if (!st.wf) wsum = (double)cnt;
-  }
-  if (!(wsum > 0)) return;  // pyx:87 / :105-108: centre unchanged
-
-  // c = c*count; c += x*w in sample order; count += wsum; c *= 1/count  (pyx:89-104)
+  const bool weighted = st.wf != nullptr;
+  // c = c*count; c += x*w in sample order; count += wsum; c *= 1/count  (pyx:80-104)
   double acc[H];
 #pragma unroll
   for (int h = 0; h < H; h++) acc[h] = c0[h] * cnt0;
-  SPROF_W(1, 3)
-  if (listed) {
-    // one round trip for clusters of up to 64 / H members; the width follows the member count
-    if (mc <= 16 / H) upd_add_listed<16 / H, H>(acc, Xg, ldg, srow, swl, st.wf != nullptr, 0, mc, D, lane);
-    else if (mc <= 32 / H) upd_add_listed<32 / H, H>(acc, Xg, ldg, srow, swl, st.wf != nullptr, 0, mc, D, lane);
-    else
-      for (int m0 = 0; m0 < mc; m0 += 64 / H) upd_add_listed<64 / H, H>(acc, Xg, ldg, srow, swl, st.wf != nullptr, m0, mc, D, lane);
-  } else {
-    auto add_members = [&](int fill) {
-      for (int m0 = 0; m0 < fill; m0 += 8) {
-        double xv[8][H], wq[8];
+  double wsum = 0.0;
+  long long total = 0;
+  for (int wb = 0; wb < nw; wb += 64) {  // 4096 batch rows per block of words (one block for batches up to 4096 rows)
+    const unsigned long long w = wb == 0 ? w0 : mb[wb + lane];
+    if (w) mb[wb + lane] = 0ull;  // ready for the stratum's next step
+    const int pc = __popcll(w);
+    int inc = pc;  // inclusive prefix sum over the lanes
 #pragma unroll
-        for (int q = 0; q < 8; q++) {
-          int ii = (m0 + q < fill) ? list[m0 + q] : -1;
-          wq[q] = (ii >= 0) ? (st.wf ? st.wf[frame_of(ii)] : 1.0) : 0.0;
-#pragma unroll
-          for (int h = 0; h < H; h++) {
-            int k = lane + 64 * h;
-            xv[q][h] = (ii >= 0 && k < D) ? Xg[(size_t)ii * ldg + k] : 0.0;
-          }
+    for (int off = 1; off < 64; off <<= 1) {
+      const int t = __shfl_up(inc, off, 64);
+      inc += lane >= off ? t : 0;
+    }
+    const int excl = inc - pc, blk = __shfl(inc, 63, 64);
+    SPROF_W(1, 2)
+    for (int p0 = 0; p0 < blk; p0 += UPD_SC) {
+      {  // this lane's members with index in [p0, p0 + SC) go to the strip, in order
+        unsigned long long t = w;
+        int idx = excl - p0;
+        while (t) {
+          const int bit = __builtin_ctzll(t);
+          t &= t - 1;
+          if (idx >= 0 && idx < UPD_SC) srow[idx] = (unsigned)((wb + lane) * 64 + bit);
+          idx++;
         }
-#pragma unroll
-        for (int q = 0; q < 8; q++)
-          if (m0 + q < fill) {
-#pragma unroll
-            for (int h = 0; h < H; h++) acc[h] = acc[h] + xv[q][h] * wq[q];
-          }
       }
-    };
-    int fill = 0;
-    for (long long base = 0; base < n_b; base += 256) {
-      scan4(base, fill, true);
-      if (fill && (fill > UPD_LIST - 256 || base + 256 >= n_b)) {
-        add_members(fill);
-        fill = 0;
+      const int np = blk - p0 < UPD_SC ? blk - p0 : UPD_SC;
+      for (int m0 = 0; m0 < np; m0 += 64 / H) {
+        const int cm = np - m0 < 64 / H ? np - m0 : 64 / H;
+        if (weighted) {
+          if (lane < cm) {
+            const long long r = srow[m0 + lane];
+            swl[lane] = st.wf[st.rows ? (long long)st.rows[r] : r];
+          }
+          for (int q = 0; q < cm; q++) wsum = wsum + swl[q];  // sample order (pyx:80-85)
+        }
+        if (cm <= 16 / H) upd_add_listed<16 / H, H>(acc, Xg, ldg, srow + m0, swl, weighted, 0, cm, D, lane);
+        else if (cm <= 32 / H) upd_add_listed<32 / H, H>(acc, Xg, ldg, srow + m0, swl, weighted, 0, cm, D, lane);
+        else upd_add_listed<64 / H, H>(acc, Xg, ldg, srow + m0, swl, weighted, 0, cm, D, lane);
       }
     }
+    total += blk;
   }
+  SPROF_W(1, 3)
+  if (total == 0) return;  // no member: wsum = 0, centre unchanged (pyx:105-108)
+  if (!weighted) wsum = (double)total;  // the sum of `total` ones is exactly that
+  if (!(wsum > 0)) return;  // pyx:87 / :105-108: centre unchanged
   SPROF_W(1, 4)
   const double cnt1 = cnt0 + wsum;
   const double alpha = 1.0 / cnt1;
@@ -1611,8 +1547,8 @@ static int run_steps(hamsm_ctx *c, const void *X, int dt, int64_t ldx, const int
   size_t o_xg = take(xg_row * (size_t)nslot * nb_pad);
   int Kmax = 0;
   for (int s = 0; s < c->S; s++) Kmax = c->st[s].K > Kmax ? c->st[s].K : Kmax;
-  size_t o_mc = take(sizeof(int32_t) * (size_t)nslot * Kmax),
-         o_ml = take(sizeof(unsigned long long) * (size_t)nslot * Kmax * MCAP);
+  const int wstride = (int)((((nb_max + 63) >> 6) + 63) & ~(int64_t)63);  // bitmap words per centroid
+  size_t o_mb = take(sizeof(unsigned long long) * (size_t)nslot * Kmax * wstride);
   int rc = hamsm_ensure_scratch(c, off);
   if (rc) return rc;
   char *b = (char *)c->scratch;
@@ -1669,8 +1605,8 @@ static int run_steps(hamsm_ctx *c, const void *X, int dt, int64_t ldx, const int
         // scratch slot = the stratum itself: chains of different strata run concurrently on different queues
         const size_t slot = nslot == c->S ? (size_t)h_steps[j0].stratum : (size_t)(j0 - i0);
         sd[j0].Xg = (double *)(b + o_xg + slot * nb_pad * xg_row);
-        sd[j0].mcnt = (int32_t *)(b + o_mc) + slot * Kmax;
-        sd[j0].mlist = (unsigned long long *)(b + o_ml) + slot * Kmax * MCAP;
+        sd[j0].mbits = (unsigned long long *)(b + o_mb) + slot * Kmax * wstride;
+        sd[j0].wstride = wstride;
         j0++;
       }
       gstart.push_back(i0);
@@ -1685,7 +1621,7 @@ static int run_steps(hamsm_ctx *c, const void *X, int dt, int64_t ldx, const int
   HIPCHK(c, hipMemsetAsync(b + o_halt + sizeof(int32_t) * c->S, 0, sizeof(int32_t) * c->S, c->stream));
   if (n_perm_total > 0)
     HIPCHK(c, hipMemcpyAsync(b + o_perm, h_perm, sizeof(int32_t) * (size_t)n_perm_total, hipMemcpyHostToDevice, c->stream));
-  HIPCHK(c, hipMemsetAsync(b + o_mc, 0, sizeof(int32_t) * (size_t)nslot * Kmax, c->stream));
+  HIPCHK(c, hipMemsetAsync(b + o_mb, 0, sizeof(unsigned long long) * (size_t)nslot * Kmax * wstride, c->stream));
   const StepDev *d_steps = (const StepDev *)(b + o_steps);
   hamsm_timer_begin(c);
   // lanes: stratum s always runs on queue s % n_lanes, so every stratum's chain stays ordered; a lane's part of a

@@ -166,3 +166,16 @@ def test_random_configurations_hip_equals_oracle(hip_h, oracle_h, seed):
     assert np.array_equal(g[1], o[1]), (cfg, K, kw)
     for x, y in zip(g[2] + g[3], o[2] + o[3]):
         assert np.array_equal(x, y), (cfg, K, kw)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("weights", [False, True])
+def test_huge_clusters_span_word_blocks_and_strip_passes(hip_h, oracle_h, weights):
+    """2 centroids per stratum on 4 500-row batches: ~2 250 members each -- more than one 4096-row block of bitmap
+    words per centroid and several 768-member passes of the M-step's LDS strip"""
+    cfg = synthetic.WEConfig("big", 21, 6, 9000, 8, 2, 2)
+    g = _run(hip_h, cfg, 2, True, weights=weights)
+    o = _run(oracle_h, cfg, 2, True, weights=weights)
+    assert np.array_equal(g[1], o[1])
+    for x, y in zip(g[2] + g[3], o[2] + o[3]):
+        assert np.array_equal(x, y)
