@@ -11,6 +11,8 @@
 // oracle/hamsm_oracle.c so that results are bit-identical.
 #include "common.h"
 
+#include <time.h>
+
 typedef double v4f64 __attribute__((ext_vector_type(4)));
 
 // Pointers that arrive inside a descriptor are generic to the compiler (flat_load/flat_atomic, which tie up both
@@ -1648,6 +1650,9 @@ static int run_steps(hamsm_ctx *c, const void *X, int dt, int64_t ldx, const int
   }
   StepPack pk;
   memset(&pk, 0, sizeof(pk));
+  const bool dbg_enq = getenv("HAMSM_DEBUG_ENQUEUE") != nullptr;
+  timespec ts0, ts1;
+  if (dbg_enq) clock_gettime(CLOCK_MONOTONIC, &ts0);
   for (size_t g = 0; g + 1 < gstart.size(); g++) {
     const int64_t i = gstart[g], j = gstart[g + 1];
     for (int l = 0; l < n_lanes; l++) {
@@ -1683,6 +1688,11 @@ static int run_steps(hamsm_ctx *c, const void *X, int dt, int64_t ldx, const int
                              : launch_steps<double>(c, lanes[l], dptr, pk, ny, max_nb, maxK, ldx, ratio, any_perm);
       if (rc) return rc;
     }
+  }
+  if (dbg_enq) {
+    clock_gettime(CLOCK_MONOTONIC, &ts1);
+    fprintf(stderr, "[hamsm] enqueued %zu launch groups on %d queue(s) in %.3f ms\n", gstart.size() - 1, n_lanes,
+            (ts1.tv_sec - ts0.tv_sec) * 1e3 + (ts1.tv_nsec - ts0.tv_nsec) * 1e-6);
   }
   for (int l = 1; l < n_lanes; l++) {
     HIPCHK(c, hipEventRecord(c->ev_join[l - 1], lanes[l]));
