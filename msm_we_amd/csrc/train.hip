@@ -1541,7 +1541,7 @@ static int run_steps(hamsm_ctx *c, const void *X, int dt, int64_t ldx, const int
   size_t o_steps = take(sizeof(StepDev) * n_steps), o_rep = take(sizeof(int32_t) * 2 * n_steps),
          o_lab = take(sizeof(int32_t) * (size_t)lab_hi), o_halt = take(sizeof(int32_t) * 2 * (size_t)c->S),
          o_perm = take(sizeof(int32_t) * (size_t)(n_perm_total > 0 ? n_perm_total : 1));
-  // the gathered batch copy and the member lists are reused by every launch group: one slot per stratum position,
+  // the gathered batch copy and the membership bitmaps are reused by every launch group: one slot per stratum position,
   // stream-ordered
   const int nslot = c->S < 65535 ? c->S : 65535;
   const size_t xg_row = sizeof(double) * 4 * (size_t)c->KS;
