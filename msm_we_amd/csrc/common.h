@@ -70,6 +70,7 @@ struct hamsm_ctx {
   bool have_mapper = false, have_bounds = false;
   MapperDev mapper;  // host copy with device pointers inside
   float *d_bounds = nullptr;
+  std::vector<float> h_bounds;  // host copy of what d_bounds holds
   int32_t *d_remap = nullptr;
   std::vector<Stratum> st;
   StratumDev *d_table = nullptr;  // [S]

@@ -315,10 +315,17 @@ extern "C" int hamsm_set_mapper_rectilinear(hamsm_ctx *c, const int32_t *nb, con
     nbins *= nb[d] - 1;
   }
   if (nbins != c->S) return hamsm_fail(c, HAMSM_EINVAL, "mapper has %ld bins, geometry says %d", nbins, c->S);
+  // the same boundaries again (every cluster_coordinates call sets the mapper): nothing to upload
+  if (c->d_bounds && (int)c->h_bounds.size() == tot && memcmp(c->h_bounds.data(), b, sizeof(float) * tot) == 0) {
+    c->mapper.bounds = c->d_bounds;
+    c->have_mapper = true;
+    return HAMSM_OK;
+  }
   HIPCHK(c, hipStreamSynchronize(c->stream));
   hipFree(c->d_bounds);
   HIPCHK(c, hipMalloc((void **)&c->d_bounds, sizeof(float) * tot));
   HIPCHK(c, hipMemcpy(c->d_bounds, b, sizeof(float) * tot, hipMemcpyHostToDevice));
+  c->h_bounds.assign(b, b + tot);
   c->mapper.bounds = c->d_bounds;
   c->have_mapper = true;
   return HAMSM_OK;
