@@ -136,6 +136,65 @@ def _cpu_pool_run(_):
     return time.perf_counter() - t0, float(F.sum())
 
 
+def reference_shaped_leg(cfg, seed, n_train=4):
+    """The reference's CALL PATTERN with its own estimator (scikit-learn), on one core: one MiniBatchKMeans.partial_fit
+    per WE bin per iteration (_clustering.py:843-899), then for ONE iteration the per-frame loop of
+    StratifiedClusters.predict -- offsets recomputed and a single-row `predict([coord])` for every parent and child frame
+    (stratified_clustering.py:152-196) -- and the per-iteration flux accumulation (_fluxmatrix.py:97-164).  Returns frames/s
+    per core or None without scikit-learn."""
+    try:
+        from sklearn.cluster import MiniBatchKMeans
+    except Exception:  # noqa: BLE001
+        return None
+    lat = synthetic.latent_centres(cfg)
+    its = [synthetic.make_iteration(cfg, it, lat) for it in range(1, n_train + 1)]
+    S, K_s = cfg.S, cfg.K_s
+    basis, target = synthetic.basis_target_bounds(S)
+    edges = np.asarray(synthetic.strata_boundaries(S), dtype=np.float32)
+
+    def bins(p):
+        return np.digitize(p[:, 0].astype(np.float32), edges) - 1
+
+    def in_box(p, box):
+        return (p[:, 0] > box[0][0]) & (p[:, 0] < box[0][1])
+
+    models = [MiniBatchKMeans(n_clusters=K_s, random_state=seed, n_init=1) for _ in range(S)]
+    t0 = time.perf_counter()
+    for d in its:
+        ok = ~(in_box(d["p0"], basis) | in_box(d["p0"], target))
+        b = bins(d["p0"])
+        for s in range(S):
+            rows = np.nonzero(ok & (b == s))[0]
+            if len(rows) >= K_s:
+                models[s].partial_fit(d["Xc"][rows].astype(np.float64))
+    t_train = (time.perf_counter() - t0) / n_train
+    d = its[-1]
+    K = S * K_s
+    t0 = time.perf_counter()
+    lab = []
+    for X, p in ((d["Xp"], d["p0"]), (d["Xc"], d["p1"])):
+        b = bins(p)
+        tgt, bas = in_box(p, target), in_box(p, basis)
+        out = np.empty(len(X), dtype=np.int64)
+        Xd = X.astype(np.float64)
+        for i in range(len(X)):
+            if tgt[i]:
+                out[i] = K + 1
+            elif bas[i]:
+                out[i] = K
+            else:
+                off = sum(len(models[q].cluster_centers_) for q in range(b[i]))
+                out[i] = models[b[i]].predict([Xd[i]])[0] + off
+        lab.append(out)
+    F = np.zeros((K + 2, K + 2))
+    np.add.at(F, (lab[0], lab[1]), d["w"])
+    t_iter = time.perf_counter() - t0
+    n = len(d["w"])
+    return {"value": n / (t_train + t_iter), "cores": 1,
+            "how": f"scikit-learn, the reference's call pattern: {n_train} iterations of per-bin partial_fit ({t_train:.2f} s per "
+                   f"iteration) + one iteration of per-frame single-row predict for {2 * n} frames and its flux ({t_iter:.1f} s)"}
+
+
 def cpu_baseline_worker(workload, n_iters_sample, seed, cores):
     """Runs in a child process that never touches the GPU (it forks a pool).  (i) the oracle = scalar C restatement on
     one core over the first `n_iters_sample` iterations; (ii) the same with the reference's parallel structure:
@@ -186,6 +245,10 @@ def cpu_baseline_worker(workload, n_iters_sample, seed, cores):
         out["all_cores"] = {"value": frames / (t_train + t_par), "cores": len(blocks),
                             "how": f"training on one core ({t_train:.2f} s, sequential in the reference too) + discretization "
                                    f"and flux over {len(blocks)} processes by iteration block ({t_par:.2f} s wall)"}
+    if os.environ.get("HAMSM_BENCH_REFERENCE_SHAPED", "1") != "0" and cfg.segs_per_iter * 2 <= 40000:
+        rs = reference_shaped_leg(cfg, seed)
+        if rs is not None:
+            out["reference_shaped"] = rs
     print(json.dumps(out), flush=True)
 
 
@@ -196,7 +259,8 @@ def cpu_baseline(workload, n_iters_sample, seed, cores):
     if not os.path.exists(ORACLE_SO):
         subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle")])
     r = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-worker", workload, str(n_iters_sample), str(seed),
-                        str(cores)], capture_output=True, text=True, check=True, env=dict(os.environ, HIP_VISIBLE_DEVICES=""))
+                        str(cores)], capture_output=True, text=True, check=True,
+                       env=dict(os.environ, HIP_VISIBLE_DEVICES="", OMP_NUM_THREADS="1", OPENBLAS_NUM_THREADS="1"))
     return json.loads(r.stdout.strip().splitlines()[-1])
 
 
