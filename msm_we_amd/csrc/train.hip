@@ -185,6 +185,7 @@ struct SeedItem {
   int K, L;
   void *XbT;            // [D][n]  feature-major copy of the batch (coalesced over rows): double, or the frames' type
   double *w, *xsq, *closest, *cum, *cand /*[L][n]*/, *chunk_tot;
+  double *G;            // [n][n] Gram matrix of the batch (k_seed_g only)
   double *C;            // stratum centroids [K][D]
   long long *chosen;    // [K]
 };
@@ -384,9 +385,6 @@ __global__ __launch_bounds__(SEED_T) void k_seed(const SeedItem *__restrict__ it
   }
 }
 
-// Same algorithm for batches that fit on chip (n <= SEED_NLDS rows, L <= SEED_LFAST candidates): w, ||x||^2,
-// closest and the chunk bases live in LDS and every thread keeps the candidate distances of its own rows in
-// registers, so a greedy step touches global memory only to stream the (L2-resident) batch once.
 #ifdef SEED_PROFILE
 __device__ unsigned long long g_seed_prof[16];
 #define PROF_T(idx)                                                        \
@@ -399,280 +397,307 @@ __device__ unsigned long long g_seed_prof[16];
 #define PROF_T(idx)
 #endif
 #define SEED_NLDS 3072
-#define SEED_TL 512                       // threads: 2 waves per SIMD, 256 VGPRs each (1024 threads spilled the accumulators)
+#define SEED_TL 512                       // threads of the on-chip kernel: 8 waves, 6 rows each lane
 #define SEED_LPT (SEED_T / SEED_TL)       // canonical lanes (of the oracle's POT_LANES) per thread
 #define SEED_RPL (SEED_NLDS / SEED_T)     // rows per lane: lane t owns rows t, t + 1024, t + 2048
 #define SEED_RPT (SEED_LPT * SEED_RPL)    // rows per thread
 #define SEED_LFAST 9                      // most candidates the on-chip kernel takes (K < 2981)
-#define SEED_LS(LF) ((LF) <= 8 ? 8 : 10)
-// XT: element type of the feature-major batch copy (the frames' own type: exact, half the stream for f32);
-// LF: number of candidates per greedy step (2 + int(log K)) -- the accumulators of unused candidates cost 1/8 of the FMAs
+
+// ---- k-means++ from the batch's Gram matrix ---------------------------------------------------------
+// Every distance a greedy step needs is between two ROWS OF THE BATCH, and the dot product inside it is the in-order fma
+// chain over the features -- exactly what v_mfma_f64_16x16x4_f64 accumulates.  So the whole chip computes G = Xb Xb^T once
+// (n <= 3072: 75 MB, a fraction of a millisecond), and the K-1 serial greedy steps of the one workgroup that owns the
+// stratum shrink from L n D fmas each to L n loads of finished dot products.  Bit-identical to k_seed / the oracle.
+template <typename XT>
+__global__ __launch_bounds__(256) void k_seed_gram(const SeedItem *__restrict__ items, int D) {
+  const SeedItem it = items[blockIdx.z];
+  const int n = (int)it.n;
+  const int i0 = blockIdx.y * 128, j0 = blockIdx.x * 128;
+  if (i0 >= n || j0 >= n) return;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int wi = i0 + (wv >> 1) * 64, wj = j0 + (wv & 1) * 64;
+  const GAS XT *X = (const GAS XT *)gp(it.XbT);
+  GAS double *G = gp(it.G);
+  v4f64 acc[4][4];
+#pragma unroll
+  for (int a = 0; a < 4; a++)
+#pragma unroll
+    for (int b = 0; b < 4; b++) acc[a][b] = (v4f64){0.0, 0.0, 0.0, 0.0};
+  int ia[4], jb[4];
+#pragma unroll
+  for (int t = 0; t < 4; t++) {
+    int i = wi + t * 16 + (lane & 15), j = wj + t * 16 + (lane & 15);
+    ia[t] = i < n ? i : n - 1;
+    jb[t] = j < n ? j : n - 1;
+  }
+  const int kq = lane >> 4;
+  for (int k0 = 0; k0 < D; k0 += 4) {
+    const int k = k0 + kq;
+    const size_t ko = (size_t)(k < D ? k : D - 1) * n;
+    double a[4], b[4];
+#pragma unroll
+    for (int t = 0; t < 4; t++) {
+      a[t] = (double)X[ko + ia[t]];
+      b[t] = (double)X[ko + jb[t]];
+    }
+#pragma unroll
+    for (int t = 0; t < 4; t++) {  // features past D: fma(0, 0, acc) == acc
+      a[t] = k < D ? a[t] : 0.0;
+      b[t] = k < D ? b[t] : 0.0;
+    }
+#pragma unroll
+    for (int ti = 0; ti < 4; ti++)
+#pragma unroll
+      for (int tj = 0; tj < 4; tj++) acc[ti][tj] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[ti], b[tj], acc[ti][tj], 0, 0, 0);
+  }
+#pragma unroll
+  for (int ti = 0; ti < 4; ti++)
+#pragma unroll
+    for (int tj = 0; tj < 4; tj++)
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+        const int row = wi + ti * 16 + kq + 4 * r, col = wj + tj * 16 + (lane & 15);
+        if (row < n && col < n) G[(size_t)row * n + col] = acc[ti][tj][r];
+      }
+}
+
+__device__ __forceinline__ double readlane_f64(double v, int l) {
+  unsigned lo = __builtin_amdgcn_readlane((int)(__double_as_longlong(v) & 0xffffffffll), l);
+  unsigned hi = __builtin_amdgcn_readlane((int)(__double_as_longlong(v) >> 32), l);
+  return __longlong_as_double(((long long)hi << 32) | lo);
+}
+
+#define SEED_G_BUDGET ((size_t)4 << 30)      // bytes of Gram matrices resident at once (56 strata of 3072 rows)
+#define SEED_NCH (SEED_NLDS / SCAN_CHUNK)   // 48 chunks of the cumulative sum
+#define SEED_PST (SEED_NCH + 1)             // stride of the transposed product array: lanes = chunks, conflict-free
+#define SEED_PL (32 * 33)                   // one candidate's 1024 partial potentials, groups of 32 padded to 33
+// LDS of k_seed_g in doubles
+#define SEED_G_LDS(LF) ((size_t)(LF) * SEED_PL + (LF) * 32 + 16 + SEED_NLDS + 2 * 64 * SEED_PST + SEED_NCH)
 template <typename XT, int LF>
-__global__ __launch_bounds__(SEED_TL) void k_seed_lds(const SeedItem *__restrict__ items, int D) {
+__global__ __launch_bounds__(SEED_TL) void k_seed_g(const SeedItem *__restrict__ items, int D) {
   extern __shared__ double sm[];
   const SeedItem it = items[blockIdx.x];
   const int n = (int)it.n;
   const int K = it.K;
-  constexpr int L = LF;  // (== it.L, checked by the host)
-  const int Dp = (D + 7) & ~7;                         // features padded with zero candidate rows: branch-free k loop
-  double *crow = sm;                                   // [Dp][LS]
-  constexpr int LS = SEED_LS(LF);                      // candidate stride of crow (even: 16-byte LDS reads)
-  double *part = crow + LS * Dp;                       // [LF][SEED_T]
-  double *grp = part + LF * SEED_T;                    // [LF][32]
-  double *pots = grp + LF * (SEED_T / SEED_GROUP);     // [LF]
-  double *lw = pots + LF;                              // [n]
-  double *lxsq = lw + SEED_NLDS;                       // [n]
-  double *lcl = lxsq + SEED_NLDS;                      // [n] closest
-  double *lbase = lcl + SEED_NLDS;                     // [nch] chunk totals -> bases
-  __shared__ int cid[SEED_LFAST];  // (SEED_LFAST = largest LF)
+  constexpr int L = LF;                 // (== it.L, checked by the host)
+  double *part = sm;                    // [LF][SEED_PL] per-lane partial potentials (oracle lane t -> (t / 32) * 33 + t % 32)
+  double *grp = part + LF * SEED_PL;    // [LF][32]
+  double *pots = grp + LF * 32;         // [16]
+  double *lxsq = pots + 16;             // [SEED_NLDS] ||x||^2
+  double *pT = lxsq + SEED_NLDS;        // [64][SEED_PST] w_i * closest_i, row i at (i % 64, i / 64); 0 past the batch
+  double *lbase = pT + 64 * SEED_PST;   // [SEED_NCH] chunk totals
+  double *pC = lbase + SEED_NCH;        // [64][SEED_PST] running sum of the products inside each chunk
+  __shared__ int cid[SEED_LFAST];
   __shared__ double s_pot;
   __shared__ int s_best;
   const int tid = threadIdx.x;
-  // (generic pointers would make every batch load a flat_load, which shares lgkmcnt with the LDS reads of the loop)
   const GAS XT *XbT = (const GAS XT *)gp(it.XbT);
+  const GAS double *G = gp(it.G);
   const GAS double *itu = gp(it.u);
   GAS double *itC = gp(it.C);
   GAS long long *itchosen = gp(it.chosen);
-  // row rr of this thread: lane tid + (rr / RPL) * TL, row lane + (rr % RPL) * 1024
+  // row rr of this thread: oracle lane tid + (rr / RPL) * TL, row lane + (rr % RPL) * 1024
   auto row_of = [&](int rr) { return tid + (rr / SEED_RPL) * SEED_TL + (rr % SEED_RPL) * SEED_T; };
-
-  for (int i = tid; i < n; i += SEED_TL) {
-    lw[i] = gp(it.w)[i];
-    lxsq[i] = gp(it.xsq)[i];
+  auto pidx = [&](int i) { return (i & (SCAN_CHUNK - 1)) * SEED_PST + (i >> 6); };
+  static_assert(SCAN_CHUNK == 64, "pidx");
+  // this thread's rows stay in registers for the whole seeding: index (clamped), weight (+0 past the batch: a partial sum
+  // plus v * 0.0 is the partial sum), ||x||^2, closest
+  int ii[SEED_RPT];
+  double wr[SEED_RPT], x2[SEED_RPT], cl[SEED_RPT];
+#pragma unroll
+  for (int r = 0; r < SEED_RPT; r++) {
+    const int i = row_of(r);
+    ii[r] = i < n ? i : n - 1;
+    wr[r] = i < n ? gp(it.w)[ii[r]] : 0.0;
+    x2[r] = gp(it.xsq)[ii[r]];
   }
-  for (int e = tid; e < LS * Dp; e += SEED_TL) crow[e] = 0.0;  // (rows D..Dp-1 stay zero: fma(0, x, acc) == acc)
-  __syncthreads();
-  for (int k = tid; k < D; k += SEED_TL) {
-    double v = (double)XbT[(size_t)k * n + it.first];
-    crow[k * LS] = v;
-    itC[k] = v;
-  }
+  for (int i = tid; i < SEED_NLDS; i += SEED_TL) lxsq[i] = i < n ? gp(it.xsq)[i] : 0.0;
+  for (int e = tid; e < 64 * SEED_PST + SEED_NCH; e += SEED_TL) pT[e] = 0.0;  // (and lbase)
+  for (int k = tid; k < D; k += SEED_TL) itC[k] = (double)XbT[(size_t)k * n + it.first];
   if (tid == 0) itchosen[0] = it.first;
   __syncthreads();
+  // sum of nl candidates' 1024 partials in the oracle's order: 32 consecutive lanes, then the 32 group sums
+  auto reduce1 = [&](int nl) {
+    __syncthreads();
+    if (tid < nl * 32) {
+      const int l = tid >> 5, g = tid & 31;
+      double pv[32];
+#pragma unroll
+      for (int t = 0; t < 32; t++) pv[t] = part[l * SEED_PL + g * 33 + t];
+      double gs = 0.0;
+#pragma unroll
+      for (int t = 0; t < 32; t++) gs = gs + pv[t];
+      grp[l * 32 + g] = gs;
+    }
+    __syncthreads();
+  };
   {
     const double xs0 = lxsq[it.first];
+    double g0[SEED_RPT];
+#pragma unroll
+    for (int r = 0; r < SEED_RPT; r++) g0[r] = G[(size_t)it.first * n + ii[r]];
 #pragma unroll
     for (int lp = 0; lp < SEED_LPT; lp++) {
       double a = 0.0;
 #pragma unroll
       for (int r = 0; r < SEED_RPL; r++) {
-        int i = row_of(lp * SEED_RPL + r);
-        if (i < n) {
-          double acc = 0.0;
-          for (int k0 = 0; k0 < D; k0 += 8) {
-            XT xk[8];
-#pragma unroll
-            for (int q = 0; q < 8; q++) xk[q] = XbT[(size_t)(k0 + q < D ? k0 + q : 0) * n + i];
-#pragma unroll
-            for (int q = 0; q < 8; q++)
-              if (k0 + q < D) acc = __builtin_fma(crow[(k0 + q) * LS], (double)xk[q], acc);
-          }
-          double v = ((-2.0 * acc) + xs0) + lxsq[i];
-          v = v > 0.0 ? v : 0.0;
-          lcl[i] = v;
-          a = a + v * lw[i];
-        }
+        const int rr = lp * SEED_RPL + r;
+        double v = ((-2.0 * g0[rr]) + xs0) + x2[rr];
+        v = v > 0.0 ? v : 0.0;
+        cl[rr] = v;
+        const double pr = v * wr[rr];
+        if (row_of(rr) < n) pT[pidx(row_of(rr))] = pr;
+        a = a + pr;
       }
-      part[tid + lp * SEED_TL] = a;
+      const int ln = tid + lp * SEED_TL;
+      part[(ln >> 5) * 33 + (ln & 31)] = a;
     }
-    double s = seed_reduce(part, grp, tid);
-    if (tid == 0) s_pot = s;
+    reduce1(1);
+    if (tid == 0) {
+      double s = 0.0;
+      for (int g = 0; g < 32; g++) s = s + grp[g];
+      s_pot = s;
+    }
     __syncthreads();
   }
   const int nch = (n + SCAN_CHUNK - 1) / SCAN_CHUNK;
+  const int lane = tid & 63, wv = tid >> 6;
+  static_assert(SEED_LFAST <= 2 * (SEED_TL / 64), "two candidates per wave");
+  double un0 = (K > 1 && wv < L) ? itu[wv] : 0.0, un1 = (K > 1 && wv + SEED_TL / 64 < L) ? itu[wv + SEED_TL / 64] : 0.0;
 #ifdef SEED_PROFILE
   unsigned long long t_last = __builtin_amdgcn_s_memtime();
 #endif
   for (int cc = 1; cc < K; cc++) {
-    if (tid < nch) {
+    if (tid < SEED_NCH) {  // per chunk: the running sum of its 64 products in row order (zeros past the batch)
+      double pv[SCAN_CHUNK];
+#pragma unroll
+      for (int z = 0; z < SCAN_CHUNK; z++) pv[z] = pT[z * SEED_PST + tid];
       double loc = 0.0;
-      int e = (tid + 1) * SCAN_CHUNK < n ? (tid + 1) * SCAN_CHUNK : n;
-      for (int i0 = tid * SCAN_CHUNK; i0 < e; i0 += 16) {
-        double pw[16], pc[16];
 #pragma unroll
-        for (int q = 0; q < 16; q++) {
-          int i = i0 + q < e ? i0 + q : i0;
-          pw[q] = lw[i];
-          pc[q] = lcl[i];
-        }
-#pragma unroll
-        for (int q = 0; q < 16; q++)
-          if (i0 + q < e) loc = loc + pw[q] * pc[q];
+      for (int z = 0; z < SCAN_CHUNK; z++) {
+        loc = loc + pv[z];
+        pC[z * SEED_PST + tid] = loc;
       }
       lbase[tid] = loc;
     }
     __syncthreads();
     PROF_T(0)
-    if (tid == 0) {
-      double base = 0.0;
-      for (int q = 0; q < nch; q++) {
-        double t = lbase[q];
-        lbase[q] = base;
-        base = base + t;
-      }
-    }
-    __syncthreads();
     PROF_T(1)
-    if (tid < L) {
-      const double v = itu[(size_t)(cc - 1) * L + tid] * s_pot;  // :243
-      int lo = 0, hi = nch;
-      while (hi - lo > 1) {
-        int mid = (lo + hi) >> 1;
-        if (lbase[mid] < v) lo = mid;
-        else hi = mid;
+    if (wv < L) {  // wave wv draws candidates wv and wv + 8
+      const double u0 = un0, u1 = un1;
+      if (cc + 1 < K) {  // next step's draws: their latency hides behind this step
+        un0 = itu[(size_t)cc * L + wv];
+        if (wv + SEED_TL / 64 < L) un1 = itu[(size_t)cc * L + wv + SEED_TL / 64];
       }
-      int ans = n;
-      for (int q = lo; q < nch && ans == n; q++) {
-        // the chunk's running sum, all of it, without data-dependent branches: the first position where the
-        // cumulative value reaches v is kept by a select (entries past the chunk end never qualify)
-        double loc = 0.0, base = lbase[q];
-        const int e = (q + 1) * SCAN_CHUNK < n ? (q + 1) * SCAN_CHUNK : n;
+      // exclusive running sum of the chunk totals, formed by every lane (the reads are LDS broadcasts); lane q keeps base q
+      double tv[SEED_NCH];
 #pragma unroll
-        for (int b0 = 0; b0 < SCAN_CHUNK; b0 += 16) {
-          const int i0 = q * SCAN_CHUNK + b0;
-          double pw[16], pc[16];
+      for (int q = 0; q < SEED_NCH; q++) tv[q] = lbase[q];
+      double run = 0.0, mybase = 0.0;
 #pragma unroll
-          for (int z = 0; z < 16; z++) {
-            const int i = i0 + z < e ? i0 + z : e - 1;
-            pw[z] = lw[i];
-            pc[z] = lcl[i];
-          }
-#pragma unroll
-          for (int z = 0; z < 16; z++) {
-            const bool in = i0 + z < e;
-            const double nl = loc + pw[z] * pc[z];
-            loc = in ? nl : loc;
-            ans = (in && ans == n && base + loc >= v) ? i0 + z : ans;
-          }
+      for (int q = 0; q < SEED_NCH; q++) {
+        mybase = lane == q ? run : mybase;
+        run = run + tv[q];
+      }
+      for (int l = wv; l < L; l += SEED_TL / 64) {
+        const double v = (l == wv ? u0 : u1) * s_pot;  // :243
+        // searchsorted over the cumulative sum: the last chunk whose base is below v (what a bisection of the
+        // non-decreasing bases returns), then the first row of it whose cumulative value reaches v
+        const unsigned long long below = __ballot(lane < nch && mybase < v);
+        const int lo = below ? 63 - __builtin_clzll(below) : 0;
+        double base = readlane_f64(mybase, lo);
+        int ans = n;
+        for (int q = lo; q < nch && ans == n; q++) {
+          const int e = n - q * SCAN_CHUNK;  // rows of this chunk (>= 64 except in the last one)
+          const double loc = pC[lane * SEED_PST + q];
+          const unsigned long long hit = __ballot(lane < e && base + loc >= v);
+          if (hit) ans = q * SCAN_CHUNK + __builtin_ctzll(hit);
+          base = base + pC[(SCAN_CHUNK - 1) * SEED_PST + q];  // the chunk's total: the next chunk's base
         }
+        if (ans > n - 1) ans = n - 1;  // :249
+        if (lane == 0) cid[l] = ans;
       }
-      if (ans > n - 1) ans = n - 1;  // :249
-      cid[tid] = ans;
     }
     __syncthreads();
     PROF_T(2)
-    // candidate rows, feature-major [k][LFAST]: one k's L values are contiguous (128-bit LDS reads, each read once
-    // per k and reused for all of the thread's rows)
-    for (int e = tid; e < L * D; e += SEED_TL) crow[(e % D) * LS + e / D] = (double)XbT[(size_t)(e % D) * n + cid[e / D]];
-    __syncthreads();
-    PROF_T(3)
     double cnd[SEED_RPT][LF];
     {
+      size_t go[LF];
+      double xc[LF];
+#pragma unroll
+      for (int l = 0; l < LF; l++) {
+        go[l] = (size_t)cid[l] * n;
+        xc[l] = lxsq[cid[l]];
+      }
 #pragma unroll
       for (int r = 0; r < SEED_RPT; r++)
 #pragma unroll
-        for (int l = 0; l < LF; l++) cnd[r][l] = 0.0;
-      // dot products: cnd[r][l] = fma chain over k of crow[l][k] * x_r[k]; the batch copy streams from L2 in chunks of
-      // KC features, the next chunk requested before the current one is used
-      constexpr int KC = (sizeof(XT) == 4 && LF <= 8) ? 4 : 2;  // (4 spills the 54 accumulators of LF = 9)
-      int ii[SEED_RPT];
-#pragma unroll
-      for (int r = 0; r < SEED_RPT; r++) {
-        int i = row_of(r);
-        ii[r] = i < n ? i : 0;
-      }
-      XT xa[SEED_RPT][KC], xb[SEED_RPT][KC];
-      auto load = [&](XT (&x)[SEED_RPT][KC], int k0) {
-#pragma unroll
-        for (int r = 0; r < SEED_RPT; r++)
-#pragma unroll
-          for (int q = 0; q < KC; q++) x[r][q] = XbT[(size_t)(k0 + q < D ? k0 + q : D - 1) * n + ii[r]];
-      };
-      auto comp = [&](XT (&x)[SEED_RPT][KC], int k0) {
-#pragma unroll
-        for (int q = 0; q < KC; q++) {
-          double cr[LF];
-#pragma unroll
-          for (int l = 0; l < LF; l++) cr[l] = crow[(k0 + q) * LS + l];
-#pragma unroll
-          for (int r = 0; r < SEED_RPT; r++)
-#pragma unroll
-            for (int l = 0; l < LF; l++) cnd[r][l] = __builtin_fma(cr[l], (double)x[r][q], cnd[r][l]);
-        }
-      };
-      load(xa, 0);
-      for (int k0 = 0; k0 < Dp; k0 += 2 * KC) {  // Dp is a multiple of 8 >= 2 KC
-        load(xb, k0 + KC);
-        comp(xa, k0);
-        load(xa, k0 + 2 * KC);
-        comp(xb, k0 + KC);
-      }
+        for (int l = 0; l < LF; l++) cnd[r][l] = G[go[l] + ii[r]];
+      PROF_T(3)
 #pragma unroll
       for (int lp = 0; lp < SEED_LPT; lp++) {
-        double a[LF], xc[LF];
+        double a[LF];
 #pragma unroll
-        for (int l = 0; l < LF; l++) {
-          a[l] = 0.0;
-          xc[l] = lxsq[cid[l]];
-        }
+        for (int l = 0; l < LF; l++) a[l] = 0.0;
 #pragma unroll
         for (int r = 0; r < SEED_RPL; r++) {
-          // branch-free: a row past the batch repeats the last one with weight +0.0 (a + v * 0.0 == a: a >= +0, v finite)
           const int rr = lp * SEED_RPL + r;
-          const int i = row_of(rr), ic = i < n ? i : n - 1;
-          const double ci = lcl[ic], xi2 = lxsq[ic], wi = i < n ? lw[ic] : 0.0;
 #pragma unroll
           for (int l = 0; l < LF; l++) {
-            double v = ((-2.0 * cnd[rr][l]) + xc[l]) + xi2;  // :252-254
+            double v = ((-2.0 * cnd[rr][l]) + xc[l]) + x2[rr];  // :252-254
             v = v > 0.0 ? v : 0.0;
-            v = v < ci ? v : ci;  // :257
+            v = v < cl[rr] ? v : cl[rr];  // :257
             cnd[rr][l] = v;
-            a[l] = a[l] + v * wi;
+            a[l] = a[l] + v * wr[rr];
           }
         }
+        const int ln = tid + lp * SEED_TL;
 #pragma unroll
-        for (int l = 0; l < LF; l++) part[l * SEED_T + tid + lp * SEED_TL] = a[l];
+        for (int l = 0; l < LF; l++) part[l * SEED_PL + (ln >> 5) * 33 + (ln & 31)] = a[l];
       }
     }
-    __syncthreads();
     PROF_T(4)
-    if (tid < L * (SEED_T / SEED_GROUP)) {
-      int l = tid / (SEED_T / SEED_GROUP), g = tid % (SEED_T / SEED_GROUP);
-      double pv[SEED_GROUP];
+    reduce1(L);
+    if (wv == 0) {  // the 32 group sums of candidate `lane` in group order, then the first minimum (:261)
+      double sp = 0.0;
+      if (lane < L) {
+        double pv[32];
 #pragma unroll
-      for (int t = 0; t < SEED_GROUP; t++) pv[t] = part[l * SEED_T + g * SEED_GROUP + t];
-      double gs = 0.0;
+        for (int g = 0; g < 32; g++) pv[g] = grp[lane * 32 + g];
 #pragma unroll
-      for (int t = 0; t < SEED_GROUP; t++) gs = gs + pv[t];
-      grp[l * (SEED_T / SEED_GROUP) + g] = gs;
-    }
-    __syncthreads();
-    if (tid < L) {
-      double pv[SEED_T / SEED_GROUP];
-#pragma unroll
-      for (int g = 0; g < SEED_T / SEED_GROUP; g++) pv[g] = grp[tid * (SEED_T / SEED_GROUP) + g];
-      double s = 0.0;
-#pragma unroll
-      for (int g = 0; g < SEED_T / SEED_GROUP; g++) s = s + pv[g];
-      pots[tid] = s;
-    }
-    __syncthreads();
-    if (tid == 0) {
+        for (int g = 0; g < 32; g++) sp = sp + pv[g];
+      }
       int best = 0;
-      double bp = pots[0];
-      for (int l = 1; l < L; l++)
-        if (pots[l] < bp) {  // :261
-          bp = pots[l];
+      double bp = readlane_f64(sp, 0);
+#pragma unroll
+      for (int l = 1; l < LF; l++) {
+        const double pl = readlane_f64(sp, l);
+        if (pl < bp) {
+          bp = pl;
           best = l;
         }
-      s_best = best;
-      s_pot = bp;
-      itchosen[cc] = cid[best];
+      }
+      if (lane == 0) {
+        s_best = best;
+        s_pot = bp;
+        itchosen[cc] = cid[best];
+      }
     }
     __syncthreads();
     PROF_T(5)
     const int best = s_best;
 #pragma unroll
     for (int r = 0; r < SEED_RPT; r++) {
-      int i = row_of(r);
-      if (i < n) {
-        double v = cnd[r][0];
+      double v = cnd[r][0];
 #pragma unroll
-        for (int l = 1; l < LF; l++) v = (l == best) ? cnd[r][l] : v;
-        lcl[i] = v;
-      }
+      for (int l = 1; l < LF; l++) v = (l == best) ? cnd[r][l] : v;
+      cl[r] = v;
+      if (row_of(r) < n) pT[pidx(row_of(r))] = v * wr[r];
     }
-    for (int k = tid; k < D; k += SEED_TL) itC[(size_t)cc * D + k] = crow[k * LS + best];
+    {
+      const size_t bo = (size_t)cid[best];
+      for (int k = tid; k < D; k += SEED_TL) itC[(size_t)cc * D + k] = (double)XbT[(size_t)k * n + bo];
+    }
     __syncthreads();
     PROF_T(6)
   }
@@ -731,6 +756,18 @@ extern "C" int hamsm_kmeans_seed_multi(hamsm_ctx *c, int n_items, const int32_t 
     l.ch = take(sizeof(long long) * K);
     l.sub = take(sizeof(long long) * (h_n_sub[i] ? h_n_sub[i] : 1));
   }
+  // batches that fit on chip, one candidate count per launch: Gram-matrix seeding (k_seed_gram + k_seed_g)
+  bool fast = true;
+  for (int i = 0; i < n_items; i++) fast = fast && lay[i].n <= SEED_NLDS && h_L[i] <= SEED_LFAST && h_L[i] == h_L[0];
+  const size_t lds_fast = sizeof(double) * SEED_G_LDS(h_L[0]);
+  const size_t g_bytes = (sizeof(double) * (size_t)nmax * nmax + 255) & ~(size_t)255;
+  int g_slots = 1;  // strata whose Gram matrices are resident at once (<= SEED_G_BUDGET bytes)
+  size_t o_G = 0;
+  if (fast) {
+    g_slots = (int)(SEED_G_BUDGET / g_bytes);
+    g_slots = g_slots < 1 ? 1 : (g_slots > n_items ? n_items : g_slots);
+    o_G = take(g_bytes * g_slots);
+  }
   int rc = hamsm_ensure_scratch(c, off);
   if (rc) return rc;
   char *b = (char *)c->scratch;
@@ -757,6 +794,7 @@ extern "C" int hamsm_kmeans_seed_multi(hamsm_ctx *c, int n_items, const int32_t 
     it.cum = (double *)(b + l.cum);
     it.cand = (double *)(b + l.cand);
     it.chunk_tot = (double *)(b + l.ct);
+    it.G = fast ? (double *)(b + o_G + g_bytes * (size_t)(i % g_slots)) : nullptr;
     it.C = c->st[h_stratum[i]].C;
     it.chosen = (long long *)(b + l.ch);
     if (K > 1) HIPCHK(c, hipMemcpyAsync(b + l.u, up, sizeof(double) * (size_t)(K - 1) * L, hipMemcpyHostToDevice, c->stream));
@@ -767,30 +805,31 @@ extern "C" int hamsm_kmeans_seed_multi(hamsm_ctx *c, int n_items, const int32_t 
   HIPCHK(c, hipMemcpyAsync(b + o_items, items.data(), sizeof(SeedItem) * n_items, hipMemcpyHostToDevice, c->stream));
   hamsm_timer_begin(c);
   dim3 gg((unsigned)((nmax + 255) / 256), (unsigned)n_items);
-  bool fast = true;
-  for (int i = 0; i < n_items; i++) fast = fast && lay[i].n <= SEED_NLDS && h_L[i] <= SEED_LFAST;
-  const int LF0 = h_L[0];
-  size_t lds_fast = sizeof(double) * ((size_t)SEED_LS(LF0) * ((D + 7) & ~7) + (size_t)LF0 * SEED_T + LF0 * (SEED_T / SEED_GROUP) +
-                                      LF0 + 3 * (size_t)SEED_NLDS + SEED_NLDS / SCAN_CHUNK + 8);
-  fast = fast && lds_fast <= 160 * 1024;
   const SeedItem *d_items = (const SeedItem *)(b + o_items);
   if (dt == HAMSM_F32 && fast) hipLaunchKernelGGL((k_seed_gather<float, float>), gg, dim3(256), 0, c->stream, d_items, ldx, D);
   else if (dt == HAMSM_F32) hipLaunchKernelGGL((k_seed_gather<float, double>), gg, dim3(256), 0, c->stream, d_items, ldx, D);
   else hipLaunchKernelGGL((k_seed_gather<double, double>), gg, dim3(256), 0, c->stream, d_items, ldx, D);
-  for (int i = 1; i < n_items; i++) fast = fast && h_L[i] == h_L[0];  // one candidate count per launch
   if (fast) {
     const void *fn = nullptr;
-#define SEED_CASE(LV)                                                                              \
-  case LV:                                                                                         \
-    fn = dt == HAMSM_F32 ? (const void *)k_seed_lds<float, LV> : (const void *)k_seed_lds<double, LV>; \
+#define SEED_CASE(LV)                                                                            \
+  case LV:                                                                                       \
+    fn = dt == HAMSM_F32 ? (const void *)k_seed_g<float, LV> : (const void *)k_seed_g<double, LV>; \
     break;
     switch (h_L[0]) {
       SEED_CASE(1) SEED_CASE(2) SEED_CASE(3) SEED_CASE(4) SEED_CASE(5) SEED_CASE(6) SEED_CASE(7) SEED_CASE(8) SEED_CASE(9)
     }
 #undef SEED_CASE
     HIPCHK(c, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_fast));
-    void *args[] = {(void *)&d_items, (void *)&D};
-    HIPCHK(c, hipLaunchKernel(fn, dim3((unsigned)n_items), dim3(SEED_TL), args, lds_fast, c->stream));
+    // groups of strata share the Gram slots: the stream orders a group's Gram + greedy kernels before the next group's
+    for (int g0 = 0; g0 < n_items; g0 += g_slots) {
+      const int ng = n_items - g0 < g_slots ? n_items - g0 : g_slots;
+      const SeedItem *gi = d_items + g0;
+      dim3 gm((unsigned)((nmax + 127) / 128), (unsigned)((nmax + 127) / 128), (unsigned)ng);
+      if (dt == HAMSM_F32) hipLaunchKernelGGL((k_seed_gram<float>), gm, dim3(256), 0, c->stream, gi, D);
+      else hipLaunchKernelGGL((k_seed_gram<double>), gm, dim3(256), 0, c->stream, gi, D);
+      void *args[] = {(void *)&gi, (void *)&D};
+      HIPCHK(c, hipLaunchKernel(fn, dim3((unsigned)ng), dim3(SEED_TL), args, lds_fast, c->stream));
+    }
   } else {
     size_t lds = sizeof(double) * ((size_t)SEED_LMAX * D + (size_t)SEED_LMAX * SEED_T + SEED_LMAX * (SEED_T / SEED_GROUP) + SEED_LMAX);
     HIPCHK(c, hipFuncSetAttribute((const void *)k_seed, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -895,11 +934,6 @@ extern "C" int hamsm_debug_step_profile(unsigned long long *h_out) {
 #define SPROF_FLUSH(k)
 #endif
 
-__device__ __forceinline__ double readlane_f64(double v, int l) {
-  unsigned lo = __builtin_amdgcn_readlane((int)(__double_as_longlong(v) & 0xffffffffll), l);
-  unsigned hi = __builtin_amdgcn_readlane((int)(__double_as_longlong(v) >> 32), l);
-  return __longlong_as_double(((long long)hi << 32) | lo);
-}
 
 struct StepG {  // a StepDev with its pointers in the global address space
   const GAS char *X;
