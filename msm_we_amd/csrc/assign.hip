@@ -20,6 +20,7 @@
 // forms of this kernel are in the history (chunk-local buckets with L2-streamed fragments: 7.1 ms; 16-lane DPP
 // argmin: 4.8 ms) -- see DESIGN.md §5.1 for what each step bought.
 #include "common.h"
+#include <vector>
 
 typedef double v4f64 __attribute__((ext_vector_type(4)));
 typedef const double __attribute__((address_space(1))) *gcdp;  // global-address-space view: global_load, not flat_load
@@ -103,6 +104,7 @@ struct SortArgs {
   long long *blkbase;            // [S+1] first workgroup of stratum s in the main kernel's grid
   int need_rb;
   int FRB;  // frames per workgroup of the main kernel (multiple of 16)
+  const long long *end;  // nullable: [S] one past the stratum's last position in perm (default base[s + 1])
 };
 
 __global__ __launch_bounds__(256) void k_sort_count(MapperDev mp, SortArgs g) {
@@ -195,7 +197,7 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void k_assign_sorted(SortArgs g) {
     while (g.blkbase[s + 1] <= blk) s++;
   }
   const long long p0 = g.base[s] + (long long)(blockIdx.x - g.blkbase[s]) * FRB;
-  const long long pend = g.base[s + 1];
+  const long long pend = g.end ? g.end[s] : g.base[s + 1];
   const int nf = (int)((pend - p0) < FRB ? (pend - p0) : FRB);
   const int nts = (nf + 15) >> 4;
   XT *Xs = (XT *)smem;                                                   // [FRB][D]
@@ -381,6 +383,234 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void k_assign_sorted(SortArgs g) {
   APROF_END
 }
 
+// ---- f32 filter in front of the exact kernel ---------------------------------------------------------
+// The label is an argmin: it needs the ORDER of the distances, not their values.  v_mfma_f32_32x32x2_f32 sustains
+// 3x the rate of the f64 MFMA on this part (tools/mfma_f32_rate.hip: 145 vs 47.5 TFLOP/s), so the first pass ranks
+// the centroids in f32.  With one extra feature slot (frame side 1, centroid side -csq / 2) the matrix unit itself
+// accumulates  s_j = x . c_j - csq_j / 2 = -d_j / 2 ; per frame the pass keeps the largest s, its centroid and the
+// largest s among the OTHER centroids (v_max / v_med3).  Each s_j is within E / 2 of the f64 contract value, where
+//     E = 2^-22 ((2 D + 8) ||x|| max_j ||c_j|| + (D + 5) max_j |csq_j|)
+// bounds: rounding the centroids, csq (and f64 frames) to f32; the D + 2 roundings of the accumulation under the
+// standard model, with unit roundoff 2^-22 instead of 2^-24 so that truncating or reordered accumulation inside the
+// matrix unit is covered; and the (2^-53-scale) rounding of the f64 chain itself.  If the two distances differ by more
+// than 2 E (x 1.01), the f64 argmin is that centroid, ties included, and the label is final.  Otherwise -- near ties,
+// NaN / inf anywhere, overflow of the f32 range -- the frame goes to a list and the exact f64 kernel decides, as
+// before.  Labels are bit-identical to the exact kernel's by construction; the tests compare both with the oracle.
+//
+// Layout: a workgroup stages 32 NW frames of one stratum in LDS; wave w owns frame tile w (B operand, kept in
+// registers) and sweeps ALL centroid tiles, whose A fragments stream through LDS in groups -- no merge across waves,
+// no barrier inside a group.  Lane l holds, for frame l % 32, the centroids 8 (r / 4) + 4 (l / 32) + r % 4 of a tile.
+typedef float v16f32 __attribute__((ext_vector_type(16)));
+typedef const float __attribute__((address_space(1))) *gcfp;
+struct FiltDev {
+  const float *A;  // [tiles32][KH][64] f32 MFMA fragments: lane l = centroid l % 32, slot 2 ks + l / 32; slot D = -csq / 2
+};
+struct FiltArgs {
+  const FiltDev *ft;        // [S]
+  const unsigned *bnd;      // [S][2] bit patterns of upper bounds of max ||c||^2 and max |csq| (f32)
+  int32_t *perm2;           // [n] undecided frames; stratum s fills from base[s]
+  unsigned long long *cnt2; // [S]
+  float c1, c2;             // 2.02 * 2^-22 * (2 D + 8), 2.02 * 2^-22 * (D + 5)
+  int DS;                   // row stride of the staged frames in floats (>= D, == 2 mod 4: conflict-free operand reads)
+  int G;                    // centroid tiles per LDS group
+};
+
+__global__ __launch_bounds__(64) void k_pack_f32(const StratumDev *__restrict__ table, const FiltDev *__restrict__ ft,
+                                                 unsigned *__restrict__ bnd, int KS, int KH, int D) {
+  const int s = blockIdx.y, jt = blockIdx.x;
+  const StratumDev sd = table[s];
+  if (jt * 32 >= sd.K) return;
+  const int lane = threadIdx.x, row = lane & 31, h = lane >> 5;
+  const int j = jt * 32 + row;
+  const bool live = j < sd.K;
+  float *A = (float *)ft[s].A;
+  const double cs = live ? sd.csq[j] : (double)__builtin_huge_valf();
+  double n2 = 0.0;
+  for (int ks = 0; ks < KH; ks++) {
+    const int k = 2 * ks + h;  // C[j][k] from the f64 fragments
+    double v = 0.0;
+    if (live && k < D) v = sd.Bpack[((size_t)(j >> 4) * KS + (k >> 2)) * 64 + (k & 3) * 16 + (j & 15)];
+    n2 += v * v;
+    if (k == D) v = -0.5 * cs;  // (-inf past K: such a row never ranks first)
+    A[((size_t)jt * KH + ks) * 64 + lane] = (float)v;
+  }
+  n2 += __shfl_xor(n2, 32, 64);
+  if (h == 0 && live) {  // (non-negative floats order like their bit patterns; NaN patterns sort above +inf and poison the bound)
+    atomicMax(&bnd[2 * s], __float_as_uint((float)n2 * 1.000001f));
+    atomicMax(&bnd[2 * s + 1], __float_as_uint(__builtin_fabsf((float)cs) * 1.000001f));
+  }
+}
+
+__global__ void k_sort_offsets2(SortArgs g, const unsigned long long *cnt2, long long *end2, long long *blkbase2) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    long long k = 0;
+    for (int s = 0; s < g.S; s++) {
+      blkbase2[s] = k;
+      end2[s] = g.base[s] + (long long)cnt2[s];
+      k += ((long long)cnt2[s] + g.FRB - 1) / g.FRB;
+    }
+    blkbase2[g.S] = k;
+  }
+}
+
+#define FILT_NW(KS) ((KS) <= 8 ? 8 : ((KS) <= 16 ? 4 : 2))
+template <typename XT, int KS, int AUGX>
+__global__ __launch_bounds__(FILT_NW(KS) * 64, 2) void k_assign_filter(SortArgs g, FiltArgs f) {
+  constexpr int NW = FILT_NW(KS), NT = NW * 64, KH = 2 * KS + AUGX, FRB = 32 * NW;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int DS = f.DS, D = g.D, G = f.G;
+  int s = 0;
+  {
+    const long long blk = blockIdx.x;
+    if (blk >= g.blkbase[g.S]) return;
+    while (g.blkbase[s + 1] <= blk) s++;
+  }
+  const long long p0 = g.base[s] + (long long)(blockIdx.x - g.blkbase[s]) * FRB;
+  const long long pend = g.base[s + 1];
+  const int nf = (int)((pend - p0) < FRB ? (pend - p0) : FRB);
+  float *Xs = (float *)smem;                      // [FRB][DS]
+  int *fidx = (int *)(Xs + (size_t)FRB * DS);     // [FRB]
+  float *As = (float *)(fidx + FRB);              // [G][KH][64]
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const float ninf = -__builtin_huge_valf();
+  const StratumDev sd = g.table[s];
+  const gcfp Ag = (gcfp)f.ft[s].A;
+  const int njt = (sd.K + 31) >> 5;
+
+  for (int i = tid; i < nf; i += NT) fidx[i] = g.perm[p0 + i];
+  __syncthreads();
+  {
+    const XT *src = (const XT *)g.X;
+    constexpr int U = 8;
+    typedef XT xt2 __attribute__((ext_vector_type(2)));
+    if ((D & 1) == 0 && (g.ldx & 1) == 0 && ((uintptr_t)src & (2 * sizeof(XT) - 1)) == 0) {
+      const int D2 = D >> 1, tot2 = nf * D2;
+      for (int e0 = tid; e0 < tot2; e0 += NT * U) {
+        xt2 v[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+          int e = e0 + u * NT;
+          int ec = e < tot2 ? e : 0;
+          int r = ec / D2, k = ec - r * D2;
+          v[u] = *(const xt2 *)(src + (int64_t)fidx[r] * g.ldx + 2 * k);
+        }
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+          int e = e0 + u * NT;
+          if (e < tot2) {
+            int r = e / D2, k = e - r * D2;
+            *(float2 *)(Xs + (size_t)r * DS + 2 * k) = make_float2((float)v[u][0], (float)v[u][1]);
+          }
+        }
+      }
+    } else {
+      const int tot = nf * D;
+      for (int e0 = tid; e0 < tot; e0 += NT * U) {
+        XT v[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+          int e = e0 + u * NT;
+          int ec = e < tot ? e : 0;
+          int r = ec / D, k = ec - r * D;
+          v[u] = src[(int64_t)fidx[r] * g.ldx + k];
+        }
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+          int e = e0 + u * NT;
+          if (e < tot) {
+            int r = e / D, k = e - r * D;
+            Xs[(size_t)r * DS + k] = (float)v[u];
+          }
+        }
+      }
+    }
+  }
+  __syncthreads();
+  // this wave's frame tile as the B operand: lane l carries frame l % 32, slots 2 ks + l / 32 (slot D = 1: the csq term)
+  const int lr = wv * 32 + (lane & 31);
+  const bool ok = lr < nf;
+  float bx[KH];
+  float xn2 = 0.f;
+  {
+    const float *xr = Xs + (size_t)(ok ? lr : 0) * DS;
+#pragma unroll
+    for (int ks = 0; ks < KH; ks++) {
+      const int k = 2 * ks + (lane >> 5);
+      float v = xr[k < D ? k : 0];
+      v = (ok && k < D) ? v : 0.f;
+      xn2 = __builtin_fmaf(v, v, xn2);
+      bx[ks] = k == D ? 1.f : v;
+    }
+    xn2 += __shfl_xor(xn2, 32, 64);
+  }
+  float M1 = ninf, M2 = ninf;
+  int J = 0;
+  for (int g0 = 0; g0 < njt; g0 += G) {
+    const int gc = (njt - g0) < G ? (njt - g0) : G;
+    if (g0) __syncthreads();  // the previous group's fragments are no longer read
+    {
+      const gcfp srcA = Ag + (size_t)g0 * KH * 64;
+      const int tot = gc * KH * 64;
+      typedef float v4f32 __attribute__((ext_vector_type(4)));
+      for (int e = tid * 4; e < tot; e += NT * 4) *(v4f32 *)(As + e) = *(const v4f32 __attribute__((address_space(1))) *)(srcA + e);
+    }
+    __syncthreads();
+    for (int jt = 0; jt < gc; jt += 2) {
+      const bool two = jt + 1 < gc;  // wave-uniform
+      const float *a0 = As + (size_t)jt * KH * 64 + lane, *a1 = As + (size_t)(two ? jt + 1 : jt) * KH * 64 + lane;
+      v16f32 acc0, acc1;
+#pragma unroll
+      for (int r = 0; r < 16; r++) {
+        acc0[r] = 0.f;
+        acc1[r] = 0.f;
+      }
+#pragma unroll
+      for (int ks = 0; ks < KH; ks++) {
+        acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[ks * 64], bx[ks], acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[ks * 64], bx[ks], acc1, 0, 0, 0);
+      }
+      const int code0 = (g0 + jt) * 16;
+#pragma unroll
+      for (int r = 0; r < 16; r++) {  // ascending centroid index: strict > keeps the lowest
+        const float v = acc0[r];
+        J = v > M1 ? code0 + r : J;
+        M2 = __builtin_amdgcn_fmed3f(M1, M2, v);
+        M1 = __builtin_fmaxf(M1, v);
+      }
+      if (two) {
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+          const float v = acc1[r];
+          J = v > M1 ? code0 + 16 + r : J;
+          M2 = __builtin_amdgcn_fmed3f(M1, M2, v);
+          M1 = __builtin_fmaxf(M1, v);
+        }
+      }
+    }
+  }
+  // code -> centroid index; then lanes l and l ^ 32 (same frame, the other half of each tile's centroids) are merged
+  int j = (J >> 4) * 32 + 8 * ((J & 15) >> 2) + 4 * (lane >> 5) + (J & 3);
+  {
+    const float M1o = __shfl_xor(M1, 32, 64), M2o = __shfl_xor(M2, 32, 64);
+    const int jo = __shfl_xor(j, 32, 64);
+    const bool take = (M1o > M1) || (M1o == M1 && jo < j);
+    M2 = take ? __builtin_fmaxf(M2o, M1) : __builtin_fmaxf(M2, M1o);
+    j = take ? jo : j;
+    M1 = take ? M1o : M1;
+  }
+  if (lane < 32 && ok) {
+    const float cmax = __builtin_sqrtf(__uint_as_float(f.bnd[2 * s])) * 1.000001f, csqmax = __uint_as_float(f.bnd[2 * s + 1]);
+    const float thr = f.c1 * __builtin_sqrtf(xn2) * 1.000001f * cmax + f.c2 * csqmax + 1e-30f;
+    const int fr = fidx[lr];
+    if (2.f * (M1 - M2) > thr) {  // d = -2 s
+      g.labels[fr] = sd.off + j;  // stratified_clustering.py:195
+    } else {  // (also every NaN: the comparison is false)
+      const unsigned long long pos = atomicAdd(&f.cnt2[s], 1ull);
+      f.perm2[g.base[s] + (long long)pos] = fr;
+    }
+  }
+}
+
 int hamsm_ensure_scratch2(hamsm_ctx *c, size_t bytes);
 
 template <typename XT, int KS, int NW, int JW>
@@ -414,10 +644,24 @@ static int launch_sorted_ks(hamsm_ctx *c, SortArgs g) {
   }
 }
 
+template <typename XT, int KS>
+static int launch_filter_ks(hamsm_ctx *c, SortArgs g, FiltArgs f, int KH) {
+  constexpr int NW = FILT_NW(KS), FRB = 32 * NW;
+  size_t lds = sizeof(float) * (size_t)FRB * f.DS + sizeof(int) * FRB + sizeof(float) * (size_t)f.G * KH * 64 + 16;
+  if (lds > 160 * 1024) return hamsm_fail(c, HAMSM_ENOTSUP, "assign filter needs %zu B of LDS", lds);
+  const void *kern = KH == 2 * KS ? (const void *)k_assign_filter<XT, KS, 0> : (const void *)k_assign_filter<XT, KS, 1>;
+  HIPCHK(c, hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  unsigned grid = (unsigned)((g.n + FRB - 1) / FRB + c->S);  // upper bound; surplus workgroups exit at once
+  void *args[] = {(void *)&g, (void *)&f};
+  HIPCHK(c, hipLaunchKernel(kern, dim3(grid), dim3(NW * 64), args, lds, c->stream));
+  return HAMSM_OK;
+}
+
 template <typename XT>
 static int launch_sorted(hamsm_ctx *c, const AssignArgs &a) {
   const int64_t n = a.n;
-  const int S = c->S;
+  const int S = c->S, KS = c->KS;
+  const bool filt = c->assign_filter != 0;
   size_t off = 0;
   auto take = [&](size_t bytes) {
     size_t o = off;
@@ -426,14 +670,43 @@ static int launch_sorted(hamsm_ctx *c, const AssignArgs &a) {
   };
   size_t o_code = take(sizeof(int32_t) * n), o_perm = take(sizeof(int32_t) * n), o_cnt = take(sizeof(long long) * S),
          o_cur = take(sizeof(long long) * S), o_base = take(sizeof(long long) * (S + 1)), o_blk = take(sizeof(long long) * (S + 1));
+  // filter: f32 fragments of the centroids, undecided-frame lists and the second set of block offsets
+  size_t o_perm2 = 0, o_zero = 0, o_end2 = 0, o_blk2 = 0, o_ft = 0, o_A = 0;
+  const int KH = a.D == 4 * KS ? 2 * KS + 1 : 2 * KS;  // feature slots of the f32 fragments, in pairs: the features, the csq slot, padding
+  std::vector<size_t> tile0(S + 1, 0);
+  int tmax = 0;
+  if (filt) {
+    for (int s = 0; s < S; s++) {
+      int t = (c->st[s].K + 31) / 32;
+      tile0[s + 1] = tile0[s] + t;
+      tmax = t > tmax ? t : tmax;
+    }
+    o_perm2 = take(sizeof(int32_t) * n);
+    o_zero = take(sizeof(long long) * S + sizeof(unsigned) * 2 * S);  // cnt2 [S], bnd [S][2]: one memset
+    o_end2 = take(sizeof(long long) * S);
+    o_blk2 = take(sizeof(long long) * (S + 1));
+    o_ft = take(sizeof(FiltDev) * S);
+    o_A = take(sizeof(float) * tile0[S] * KH * 64);
+  }
   int rc = hamsm_ensure_scratch2(c, off);
   if (rc) return rc;
   char *b = (char *)c->scratch2;
   SortArgs g{a.X, a.ldx, a.pcoord, n, a.labels, a.seen, a.table, S, a.D, a.Kfit, a.err, (int32_t *)(b + o_code),
              (int32_t *)(b + o_perm), (unsigned long long *)(b + o_cnt), (unsigned long long *)(b + o_cur),
-             (long long *)(b + o_base), (long long *)(b + o_blk), 0, FRB_MAX};
+             (long long *)(b + o_base), (long long *)(b + o_blk), 0, FRB_MAX, nullptr};
   // frames per workgroup: as many as keep the staged rows within ~64 KB (2 workgroups per CU)
   while (g.FRB > 64 && (size_t)g.FRB * a.D * sizeof(XT) > 64 * 1024) g.FRB >>= 1;
+  const int FRB_exact = g.FRB;
+  FiltArgs f{};
+  c->filter_cnt2 = nullptr;
+  if (filt) {
+    f.DS = a.D + ((6 - (a.D & 3)) & 3);
+    g.FRB = 32 * FILT_NW(KS);
+    // centroid tiles per LDS group: frames + fragments within ~72 KB (two workgroups per CU)
+    size_t room = 72 * 1024 - (sizeof(float) * (size_t)g.FRB * f.DS + sizeof(int) * g.FRB);
+    f.G = (int)(room / (sizeof(float) * KH * 64));
+    f.G = f.G < 2 ? 2 : (f.G > tmax ? (tmax > 0 ? tmax : 1) : f.G & ~1);
+  }
   HIPCHK(c, hipMemsetAsync(b + o_cnt, 0, sizeof(long long) * S, c->stream));
   unsigned gridc = (unsigned)((n + 255) / 256 < 2048 ? (n + 255) / 256 : 2048);
   hipLaunchKernelGGL(k_sort_count, dim3(gridc), dim3(256), sizeof(unsigned int) * S, c->stream, c->mapper, g);
@@ -442,14 +715,58 @@ static int launch_sorted(hamsm_ctx *c, const AssignArgs &a) {
                      c->stream, g);
   HIPCHK(c, hipGetLastError());
   hamsm_timer_end(c, ST_OTHER);   // the three bucket passes
-  hamsm_timer_begin(c);           // ... and the distance kernel proper (ST_ASSIGN, ended by the caller)
-  switch (c->KS) {
+  hamsm_timer_begin(c);           // ... and the distance kernels proper (ST_ASSIGN, ended by the caller)
+  if (filt) {
+    std::vector<FiltDev> ft(S);
+    for (int s = 0; s < S; s++) {
+      ft[s].A = (const float *)(b + o_A) + tile0[s] * KH * 64;
+    }
+    HIPCHK(c, hipMemcpyAsync(b + o_ft, ft.data(), sizeof(FiltDev) * S, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemsetAsync(b + o_zero, 0, sizeof(long long) * S + sizeof(unsigned) * 2 * S, c->stream));
+    f.ft = (const FiltDev *)(b + o_ft);
+    f.cnt2 = (unsigned long long *)(b + o_zero);
+    f.bnd = (const unsigned *)(b + o_zero + sizeof(long long) * S);
+    f.perm2 = (int32_t *)(b + o_perm2);
+    f.c1 = 2.02f * (float)(2 * a.D + 8) / 4194304.0f;
+    f.c2 = 2.02f * (float)(a.D + 5) / 4194304.0f;
+    c->filter_cnt2 = f.cnt2;
+    if (tmax > 0)
+      hipLaunchKernelGGL(k_pack_f32, dim3((unsigned)tmax, (unsigned)S), dim3(64), 0, c->stream, a.table, f.ft, (unsigned *)f.bnd, KS, KH,
+                         a.D);
+    switch (KS) {
+#define CASE(KSV) \
+  case KSV: rc = launch_filter_ks<XT, KSV>(c, g, f, KH); break;
+      CASE(1) CASE(2) CASE(3) CASE(4) CASE(6) CASE(8) CASE(12) CASE(16) CASE(24) CASE(32)
+#undef CASE
+      default: return hamsm_fail(c, HAMSM_ENOTSUP, "KS=%d", KS);
+    }
+    if (rc) return rc;
+    // the undecided frames, by the exact kernel
+    g.FRB = FRB_exact;
+    g.perm = f.perm2;
+    g.end = (const long long *)(b + o_end2);
+    g.blkbase = (long long *)(b + o_blk2);
+    hipLaunchKernelGGL(k_sort_offsets2, dim3(1), dim3(64), 0, c->stream, g, f.cnt2, (long long *)(b + o_end2), (long long *)(b + o_blk2));
+    HIPCHK(c, hipGetLastError());
+  }
+  switch (KS) {
 #define CASE(KSV) \
   case KSV: return launch_sorted_ks<XT, KSV>(c, g);
     CASE(1) CASE(2) CASE(3) CASE(4) CASE(6) CASE(8) CASE(12) CASE(16) CASE(24) CASE(32)
 #undef CASE
   }
-  return hamsm_fail(c, HAMSM_ENOTSUP, "KS=%d", c->KS);
+  return hamsm_fail(c, HAMSM_ENOTSUP, "KS=%d", KS);
+}
+
+// Not part of the product ABI (test hook): frames the last filtered hamsm_assign handed to the exact kernel.
+extern "C" long long hamsm_debug_filter_undecided(hamsm_ctx *c) {
+  if (!c->filter_cnt2) return -1;
+  std::vector<unsigned long long> h(c->S);
+  if (hipStreamSynchronize(c->stream) != hipSuccess) return -1;
+  if (hipMemcpy(h.data(), c->filter_cnt2, sizeof(unsigned long long) * c->S, hipMemcpyDeviceToHost) != hipSuccess) return -1;
+  long long t = 0;
+  for (auto v : h) t += (long long)v;
+  return t;
 }
 
 extern "C" int hamsm_assign(hamsm_ctx *c, const void *X, int dt, int64_t ldx, const double *p, int64_t n, int32_t *labels,

@@ -23,6 +23,7 @@ extern "C" int hamsm_create(int device, hamsm_ctx **out) {
   c->device = device;
   memset(&c->mapper, 0, sizeof c->mapper);
   if (const char *v = getenv("HAMSM_ASSIGN_W")) c->assign_waves = atoi(v) == 8 ? 8 : 4;
+  if (const char *v = getenv("HAMSM_ASSIGN_FILTER")) c->assign_filter = atoi(v) != 0;
   if (const char *v = getenv("HAMSM_STEP_LANES")) c->step_lanes = atoi(v) < 1 ? 1 : (atoi(v) > 4 ? 4 : atoi(v));
   if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess ||
       hipMalloc((void **)&c->d_err, 4 * sizeof(int)) != hipSuccess ||
