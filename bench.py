@@ -38,6 +38,7 @@ from msm_we_amd.data import DeviceStore  # noqa: E402
 from msm_we_amd.model import modelWE  # noqa: E402
 
 PEAK_F64_MFMA_TFLOPS = 78.6   # MI355X FP64 matrix (= vector) peak, dense (vendor figure)
+PEAK_F32_MFMA_TFLOPS = 157.3  # MI355X FP32 matrix peak, dense (MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 155 TF measured)
 PEAK_HBM_GBS = 8000.0         # MI355X_MICROARCH.md: 8.0 TB/s spec
 
 
@@ -330,17 +331,18 @@ def full_pipeline(m, cfg, seed, flux_mode):
 
 
 def pmc_traffic(cfg, n_iters):
-    """HBM bytes per k_assign_sorted launch from the committed rocprofv3 PMC passes of this same workload
-    (profiles/r01_g_pmc_summary.csv: separate --pmc FETCH_SIZE / WRITE_SIZE runs; FETCH_SIZE doubled as
+    """HBM bytes per assign launch (ranking pass + exact pass) from the committed rocprofv3 PMC passes of this same workload
+    (profiles/r01_k_pmc_summary.csv: separate --pmc FETCH_SIZE / WRITE_SIZE runs; FETCH_SIZE doubled as
     MI355X_MICROARCH.md prescribes for gfx950, calibrated here on k_sort_count's 80 MB pcoord read)."""
-    path = os.path.join(ROOT, "profiles", "r01_g_pmc_summary.csv")
+    path = os.path.join(ROOT, "profiles", "r01_k_pmc_summary.csv")
     if cfg.name != "c3" or n_iters != cfg.n_iters or not os.path.exists(path):
         return None
+    filt = os.environ.get("HAMSM_ASSIGN_FILTER", "1") != "0"
     vals = {}
     for line in open(path).read().splitlines()[1:]:
         k, c, _, v = line.rsplit(",", 3)
-        if "k_assign_sorted" in k:
-            vals[c] = float(v)
+        if "k_assign_sorted" in k or (filt and "k_assign_filter" in k):
+            vals[c] = vals.get(c, 0.0) + float(v)
     if "FETCH_SIZE" not in vals or "WRITE_SIZE" not in vals:
         return None
     return (2.0 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024.0
@@ -446,13 +448,23 @@ def main():
     timers = h.timers()   # HIP events on the library's stream around every kernel (lazy: no sync on the launch path)
     assign_ms = h.last_kernel_ms(0)
     n_assign_launch = 2 * args.steps
-    assign_avg_ms = timers["assign"] * 1e3 / n_assign_launch   # k_assign_sorted alone; its bucket passes are "other"
+    assign_avg_ms = timers["assign"] * 1e3 / n_assign_launch   # the distance kernels alone (f32 ranking pass + exact f64 pass over
+                                                               # the undecided frames); the bucket passes are "other"
     rows_per_launch = n_seg                                   # one launch = all parent (or child) frames
     flops = 2.0 * cfg.K_s * cfg.D * rows_per_launch           # 2*K_s*D per frame
     bytes_alg = (cfg.D * 4 + 8 + 4) * rows_per_launch         # D*s + 8*ndim + 4 per frame
     assign_avg_ms = assign_avg_ms or float("nan")  # (the CPU rehearsal has no kernel timers)
     tflops = flops / (assign_avg_ms * 1e-3) / 1e12
     K = cfg.K_s * cfg.S
+    if os.environ.get("HAMSM_ASSIGN_FILTER", "1") != "0":
+        peak = PEAK_F32_MFMA_TFLOPS
+        kernel = "k_assign_filter (v_mfma_f32_32x32x2_f32) + k_assign_sorted (v_mfma_f64_16x16x4_f64) on the undecided frames"
+        arithmetic = ("centroids ranked in f32 on the matrix unit; a label is final only if the f32 gap exceeds a proven bound "
+                      "on the f32-vs-f64 difference, otherwise the exact f64 kernel decides: labels identical to the f64 contract")
+    else:
+        peak = PEAK_F64_MFMA_TFLOPS
+        kernel = "k_assign_sorted (v_mfma_f64_16x16x4_f64)"
+        arithmetic = "f64 in-order fma chains on the matrix unit"
     out = {
         "metric": "frames/sec clustered + fluxmatrix-built",
         "value": world * n_seg * args.steps / elapsed,
@@ -471,9 +483,10 @@ def main():
                                f"train + assign(2N) + flux per step", "frames_per_gpu": n_seg,
                    "flux_mode": "atomic" if args.flux_mode == 0 else "deterministic",
                    "parallelism": f"iteration-sharded x{world}"},
-        "roofline": {"bound": "mfma", "achieved": tflops, "peak": PEAK_F64_MFMA_TFLOPS, "unit": "TFLOP/s",
-                     "frac": tflops / PEAK_F64_MFMA_TFLOPS, "traffic": pmc_traffic(cfg, n_iters),
-                     "kernel": "k_assign_sorted (v_mfma_f64_16x16x4_f64)",
+        "roofline": {"bound": "mfma", "achieved": tflops, "peak": peak, "unit": "TFLOP/s",
+                     "frac": tflops / peak, "traffic": pmc_traffic(cfg, n_iters),
+                     "kernel": kernel, "arithmetic": arithmetic,
+                     "f64_mfma_peak": PEAK_F64_MFMA_TFLOPS, "frac_of_f64_peak": tflops / PEAK_F64_MFMA_TFLOPS,
                      "avg_launch_ms": assign_avg_ms, "last_launch_ms": assign_ms,
                      "algorithmic_GBps": bytes_alg / (assign_avg_ms * 1e-3) / 1e9,
                      "hbm_frac": bytes_alg / (assign_avg_ms * 1e-3) / 1e9 / PEAK_HBM_GBS},

@@ -413,6 +413,7 @@ struct FiltArgs {
   float c1, c2;             // 2.02 * 2^-22 * (2 D + 8), 2.02 * 2^-22 * (D + 5)
   int DS;                   // row stride of the staged frames in floats (>= D, == 2 mod 4: conflict-free operand reads)
   int G;                    // centroid tiles per LDS group
+  unsigned magic;           // 2^24 / d + 1, d = loads per staged row: division by multiplication
 };
 
 __global__ __launch_bounds__(64) void k_pack_f32(const StratumDev *__restrict__ table, const FiltDev *__restrict__ ft,
@@ -454,161 +455,214 @@ __global__ void k_sort_offsets2(SortArgs g, const unsigned long long *cnt2, long
 }
 
 #define FILT_NW(KS) ((KS) <= 8 ? 8 : ((KS) <= 16 ? 4 : 2))
+#define FILT_NB_MAX 16
+// A workgroup serves up to NB consecutive blocks of FB = 32 NW frames of its stratum: the frame indices of all of them
+// and the centroid fragments are fetched once, and while the matrix unit works on block b the rows of block b + 1 are
+// already on their way (parked in registers, written to LDS after the block) -- the per-block cost is the MFMA sweep,
+// not a chain of dependent memory round trips.
 template <typename XT, int KS, int AUGX>
-__global__ __launch_bounds__(FILT_NW(KS) * 64, 2) void k_assign_filter(SortArgs g, FiltArgs f) {
-  constexpr int NW = FILT_NW(KS), NT = NW * 64, KH = 2 * KS + AUGX, FRB = 32 * NW;
+__global__ __launch_bounds__(FILT_NW(KS) * 64) __attribute__((amdgpu_waves_per_eu(KS <= 8 ? 4 : 2))) void k_assign_filter(SortArgs g, FiltArgs f) {
+  constexpr int NW = FILT_NW(KS), NT = NW * 64, KH = 2 * KS + AUGX, FB = 32 * NW;
+  APROF_INIT
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  typedef float v4f32 __attribute__((ext_vector_type(4)));
+  typedef const v4f32 __attribute__((address_space(1))) *gv4p;
+  typedef XT xt2 __attribute__((ext_vector_type(2)));
   const int DS = f.DS, D = g.D, G = f.G;
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  // which stratum?  one vector load of the block offsets (a scalar walk is a chain of dependent global loads)
   int s = 0;
   {
     const long long blk = blockIdx.x;
-    if (blk >= g.blkbase[g.S]) return;
-    while (g.blkbase[s + 1] <= blk) s++;
+    for (int s0 = 0; s0 < g.S; s0 += 64) {  // (block-uniform trip count)
+      const int i = s0 + lane;
+      const long long bb = g.blkbase[(i < g.S ? i : g.S - 1) + 1];
+      s += __builtin_popcountll(__ballot(i < g.S && bb <= blk));
+    }
+    if (s >= g.S) return;
   }
-  const long long p0 = g.base[s] + (long long)(blockIdx.x - g.blkbase[s]) * FRB;
-  const long long pend = g.base[s + 1];
-  const int nf = (int)((pend - p0) < FRB ? (pend - p0) : FRB);
-  float *Xs = (float *)smem;                      // [FRB][DS]
-  int *fidx = (int *)(Xs + (size_t)FRB * DS);     // [FRB]
-  float *As = (float *)(fidx + FRB);              // [G][KH][64]
-  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-  const float ninf = -__builtin_huge_valf();
   const StratumDev sd = g.table[s];
   const gcfp Ag = (gcfp)f.ft[s].A;
   const int njt = (sd.K + 31) >> 5;
-
-  for (int i = tid; i < nf; i += NT) fidx[i] = g.perm[p0 + i];
+  const bool oneg = njt <= G;  // all fragments of the stratum fit: loaded once for every block
+  float *Xs = (float *)smem;                      // [FB][DS]
+  int *fidx = (int *)(Xs + (size_t)FB * DS);      // [g.FRB] = all blocks of this workgroup
+  float *As = (float *)(fidx + g.FRB);            // [G][KH][64]
+  // the first group's centroid fragments: issued now, parked in registers while the frame indices arrive
+  constexpr int AQ = 4;
+  v4f32 areg[AQ];
+  const int gc0 = njt < G ? njt : G, tot0 = gc0 * KH * 64;
+#pragma unroll
+  for (int q = 0; q < AQ; q++) {
+    const int e = (tid + q * NT) * 4;
+    areg[q] = *(gv4p)(Ag + (e < tot0 ? e : 0));
+  }
+  const long long p0 = g.base[s] + (long long)(blockIdx.x - g.blkbase[s]) * g.FRB;
+  const long long pend = g.base[s + 1];
+  const int nfw = (int)((pend - p0) < g.FRB ? (pend - p0) : g.FRB);
+  const int nblk = (nfw + FB - 1) / FB;
+  const float ninf = -__builtin_huge_valf(), pinf = __builtin_huge_valf();
+  for (int i = tid; i < nfw; i += NT) fidx[i] = g.perm[p0 + i];
+#pragma unroll
+  for (int q = 0; q < AQ; q++) {
+    const int e = (tid + q * NT) * 4;
+    if (e < tot0) *(v4f32 *)(As + e) = areg[q];
+  }
+  for (int e = (tid + AQ * NT) * 4; e < tot0; e += NT * 4) *(v4f32 *)(As + e) = *(gv4p)(Ag + e);  // (beyond AQ pieces per thread)
   __syncthreads();
-  {
-    const XT *src = (const XT *)g.X;
-    constexpr int U = 8;
-    typedef XT xt2 __attribute__((ext_vector_type(2)));
-    if ((D & 1) == 0 && (g.ldx & 1) == 0 && ((uintptr_t)src & (2 * sizeof(XT) - 1)) == 0) {
-      const int D2 = D >> 1, tot2 = nf * D2;
-      for (int e0 = tid; e0 < tot2; e0 += NT * U) {
-        xt2 v[U];
+  APROF(0)
+  // row staging, split into issue (global loads into registers) and commit (LDS writes) so that a block's rows travel
+  // while the previous block computes.  Units are pairs of features when the rows allow 2-element loads.
+  const XT *src = (const XT *)g.X;
+  const bool pairs = (D & 1) == 0 && (g.ldx & 1) == 0 && ((uintptr_t)src & (2 * sizeof(XT) - 1)) == 0;
+  const int UW = pairs ? D >> 1 : D;  // units per row
+  const unsigned magic = f.magic;     // e / UW == umulhi(e << 8, 2^24 / UW + 1) for e < 2^16, UW <= 256
+  constexpr int U = 8;
+  const bool pre = pairs && FB * UW <= NT * U;  // one round of U pair loads per thread covers a block: prefetch possible
+  xt2 vp[U];
+  auto issue = [&](int b) {  // (pairs only)
+    const int nfb = (nfw - b * FB) < FB ? (nfw - b * FB) : FB, tot = nfb * UW;
+    const int *fi = fidx + b * FB;
 #pragma unroll
-        for (int u = 0; u < U; u++) {
-          int e = e0 + u * NT;
-          int ec = e < tot2 ? e : 0;
-          int r = ec / D2, k = ec - r * D2;
-          v[u] = *(const xt2 *)(src + (int64_t)fidx[r] * g.ldx + 2 * k);
-        }
+    for (int u = 0; u < U; u++) {
+      const int e = tid + u * NT;
+      const int ec = e < tot ? e : 0;
+      const int r = (int)__umulhi((unsigned)ec << 8, magic), k = ec - r * UW;
+      vp[u] = *(const xt2 *)(src + (int64_t)fi[r] * g.ldx + 2 * k);
+    }
+  };
+  auto commit = [&](int b) {
+    const int nfb = (nfw - b * FB) < FB ? (nfw - b * FB) : FB, tot = nfb * UW;
 #pragma unroll
-        for (int u = 0; u < U; u++) {
-          int e = e0 + u * NT;
-          if (e < tot2) {
-            int r = e / D2, k = e - r * D2;
-            *(float2 *)(Xs + (size_t)r * DS + 2 * k) = make_float2((float)v[u][0], (float)v[u][1]);
-          }
+    for (int u = 0; u < U; u++) {
+      const int e = tid + u * NT;
+      const int r = (int)__umulhi((unsigned)e << 8, magic), k = e - r * UW;
+      if (e < tot) *(float2 *)(Xs + r * DS + 2 * k) = make_float2((float)vp[u][0], (float)vp[u][1]);
+    }
+  };
+  auto stage_sync = [&](int b) {  // any layout, U loads in flight per thread
+    const int nfb = (nfw - b * FB) < FB ? (nfw - b * FB) : FB, tot = nfb * UW;
+    const int *fi = fidx + b * FB;
+    for (int e0 = tid; e0 < tot; e0 += NT * U) {
+      xt2 wp[U];
+      XT ws[U];
+#pragma unroll
+      for (int u = 0; u < U; u++) {
+        const int e = e0 + u * NT;
+        const int ec = e < tot ? e : 0;
+        const int r = (int)__umulhi((unsigned)ec << 8, magic), k = ec - r * UW;
+        const XT *rp = src + (int64_t)fi[r] * g.ldx;
+        if (pairs) wp[u] = *(const xt2 *)(rp + 2 * k);
+        else ws[u] = rp[k];
+      }
+#pragma unroll
+      for (int u = 0; u < U; u++) {
+        const int e = e0 + u * NT;
+        const int r = (int)__umulhi((unsigned)(e < tot ? e : 0) << 8, magic), k = e - r * UW;
+        if (e < tot) {
+          if (pairs) *(float2 *)(Xs + r * DS + 2 * k) = make_float2((float)wp[u][0], (float)wp[u][1]);
+          else Xs[r * DS + k] = (float)ws[u];
         }
       }
-    } else {
-      const int tot = nf * D;
-      for (int e0 = tid; e0 < tot; e0 += NT * U) {
-        XT v[U];
-#pragma unroll
-        for (int u = 0; u < U; u++) {
-          int e = e0 + u * NT;
-          int ec = e < tot ? e : 0;
-          int r = ec / D, k = ec - r * D;
-          v[u] = src[(int64_t)fidx[r] * g.ldx + k];
-        }
-#pragma unroll
-        for (int u = 0; u < U; u++) {
-          int e = e0 + u * NT;
-          if (e < tot) {
-            int r = e / D, k = e - r * D;
-            Xs[(size_t)r * DS + k] = (float)v[u];
-          }
-        }
-      }
     }
-  }
-  __syncthreads();
-  // this wave's frame tile as the B operand: lane l carries frame l % 32, slots 2 ks + l / 32 (slot D = 1: the csq term)
-  const int lr = wv * 32 + (lane & 31);
-  const bool ok = lr < nf;
-  float bx[KH];
-  float xn2 = 0.f;
-  {
-    const float *xr = Xs + (size_t)(ok ? lr : 0) * DS;
-#pragma unroll
-    for (int ks = 0; ks < KH; ks++) {
-      const int k = 2 * ks + (lane >> 5);
-      float v = xr[k < D ? k : 0];
-      v = (ok && k < D) ? v : 0.f;
-      xn2 = __builtin_fmaf(v, v, xn2);
-      bx[ks] = k == D ? 1.f : v;
-    }
-    xn2 += __shfl_xor(xn2, 32, 64);
-  }
-  float M1 = ninf, M2 = ninf;
-  int J = 0;
-  for (int g0 = 0; g0 < njt; g0 += G) {
-    const int gc = (njt - g0) < G ? (njt - g0) : G;
-    if (g0) __syncthreads();  // the previous group's fragments are no longer read
-    {
-      const gcfp srcA = Ag + (size_t)g0 * KH * 64;
-      const int tot = gc * KH * 64;
-      typedef float v4f32 __attribute__((ext_vector_type(4)));
-      for (int e = tid * 4; e < tot; e += NT * 4) *(v4f32 *)(As + e) = *(const v4f32 __attribute__((address_space(1))) *)(srcA + e);
-    }
+  };
+  if (pre) issue(0);
+  for (int b = 0; b < nblk; b++) {
+    if (pre) commit(b);
+    else stage_sync(b);
     __syncthreads();
-    for (int jt = 0; jt < gc; jt += 2) {
-      const bool two = jt + 1 < gc;  // wave-uniform
-      const float *a0 = As + (size_t)jt * KH * 64 + lane, *a1 = As + (size_t)(two ? jt + 1 : jt) * KH * 64 + lane;
-      v16f32 acc0, acc1;
-#pragma unroll
-      for (int r = 0; r < 16; r++) {
-        acc0[r] = 0.f;
-        acc1[r] = 0.f;
-      }
+    APROF(1)
+    // this wave's frame tile as the B operand: lane l carries frame l % 32, slots 2 ks + l / 32 (slot D = 1: the csq term)
+    const int nf = (nfw - b * FB) < FB ? (nfw - b * FB) : FB;
+    const int lr = wv * 32 + (lane & 31);
+    const bool ok = lr < nf;
+    float bx[KH];
+    float xn2 = 0.f;
+    {
+      const float *xr = Xs + (size_t)(ok ? lr : 0) * DS;
 #pragma unroll
       for (int ks = 0; ks < KH; ks++) {
-        acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[ks * 64], bx[ks], acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[ks * 64], bx[ks], acc1, 0, 0, 0);
+        const int k = 2 * ks + (lane >> 5);
+        float v = xr[k < D ? k : 0];
+        asm volatile("" : "+v"(v));  // (keeps the load unconditional: a select of a load becomes a branch per load)
+        v = k < D ? v : 0.f;
+        xn2 = __builtin_fmaf(v, v, xn2);
+        bx[ks] = k == D ? 1.f : v;
       }
-      const int code0 = (g0 + jt) * 16;
+      xn2 += __shfl_xor(xn2, 32, 64);
+    }
+    __syncthreads();  // every wave holds its operand: the staging buffer may take the next block
+    if (pre && b + 1 < nblk) issue(b + 1);
+    APROF(2)
+    // ranking state: largest s, largest s among the other centroids, and where the largest was found: Jt = centroid
+    // tile, Jr = accumulator register (both only change when the maximum does)
+    float M1 = ninf, M2 = ninf;
+    int Jr = 0, Jt = 0;
+    auto chain = [&](const float *ap) {
+      v16f32 acc;
+#pragma unroll
+      for (int r = 0; r < 16; r++) acc[r] = 0.f;
+#pragma unroll
+      for (int ks = 0; ks < KH; ks++) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ap[ks * 64], bx[ks], acc, 0, 0, 0);
+      return acc;
+    };
+    auto rank = [&](const v16f32 &acc, int tile) {
+      const float before = M1;
 #pragma unroll
       for (int r = 0; r < 16; r++) {  // ascending centroid index: strict > keeps the lowest
-        const float v = acc0[r];
-        J = v > M1 ? code0 + r : J;
+        const float v = acc[r];
+        Jr = v > M1 ? r : Jr;
         M2 = __builtin_amdgcn_fmed3f(M1, M2, v);
-        M1 = __builtin_fmaxf(M1, v);
+        M1 = __builtin_amdgcn_fmed3f(M1, v, pinf);  // max(M1, v)
       }
-      if (two) {
-#pragma unroll
-        for (int r = 0; r < 16; r++) {
-          const float v = acc1[r];
-          J = v > M1 ? code0 + 16 + r : J;
-          M2 = __builtin_amdgcn_fmed3f(M1, M2, v);
-          M1 = __builtin_fmaxf(M1, v);
-        }
+      Jt = M1 > before ? tile : Jt;
+    };
+    for (int g0 = 0; g0 < njt; g0 += G) {
+      const int gc = (njt - g0) < G ? (njt - g0) : G;
+      if (!oneg && (g0 || b)) {
+        __syncthreads();  // the previous group's fragments are no longer read
+        const gcfp srcA = Ag + (size_t)g0 * KH * 64;
+        const int tot = gc * KH * 64;
+        for (int e = tid * 4; e < tot; e += NT * 4) *(v4f32 *)(As + e) = *(gv4p)(srcA + e);
+        __syncthreads();
+      }
+      APROF(3)
+      // two accumulators in rotation: the matrix unit works on tile t + 1 while the vector unit ranks tile t
+      const float *ap = As + lane;
+      v16f32 accA = chain(ap), accB;
+      for (int jt = 0; jt < gc; jt += 2) {
+        const bool b1 = jt + 1 < gc, b2 = jt + 2 < gc;  // wave-uniform
+        if (b1) accB = chain(ap + (size_t)(jt + 1) * KH * 64);
+        rank(accA, g0 + jt);
+        if (b2) accA = chain(ap + (size_t)(jt + 2) * KH * 64);
+        if (b1) rank(accB, g0 + jt + 1);
       }
     }
-  }
-  // code -> centroid index; then lanes l and l ^ 32 (same frame, the other half of each tile's centroids) are merged
-  int j = (J >> 4) * 32 + 8 * ((J & 15) >> 2) + 4 * (lane >> 5) + (J & 3);
-  {
-    const float M1o = __shfl_xor(M1, 32, 64), M2o = __shfl_xor(M2, 32, 64);
-    const int jo = __shfl_xor(j, 32, 64);
-    const bool take = (M1o > M1) || (M1o == M1 && jo < j);
-    M2 = take ? __builtin_fmaxf(M2o, M1) : __builtin_fmaxf(M2, M1o);
-    j = take ? jo : j;
-    M1 = take ? M1o : M1;
-  }
-  if (lane < 32 && ok) {
-    const float cmax = __builtin_sqrtf(__uint_as_float(f.bnd[2 * s])) * 1.000001f, csqmax = __uint_as_float(f.bnd[2 * s + 1]);
-    const float thr = f.c1 * __builtin_sqrtf(xn2) * 1.000001f * cmax + f.c2 * csqmax + 1e-30f;
-    const int fr = fidx[lr];
-    if (2.f * (M1 - M2) > thr) {  // d = -2 s
-      g.labels[fr] = sd.off + j;  // stratified_clustering.py:195
-    } else {  // (also every NaN: the comparison is false)
-      const unsigned long long pos = atomicAdd(&f.cnt2[s], 1ull);
-      f.perm2[g.base[s] + (long long)pos] = fr;
+    APROF(4)
+    // -> centroid index; then lanes l and l ^ 32 (same frame, the other half of each tile's centroids) are merged
+    int j = Jt * 32 + 8 * (Jr >> 2) + 4 * (lane >> 5) + (Jr & 3);
+    {
+      const float M1o = __shfl_xor(M1, 32, 64), M2o = __shfl_xor(M2, 32, 64);
+      const int jo = __shfl_xor(j, 32, 64);
+      const bool take = (M1o > M1) || (M1o == M1 && jo < j);
+      M2 = take ? __builtin_fmaxf(M2o, M1) : __builtin_fmaxf(M2, M1o);
+      j = take ? jo : j;
+      M1 = take ? M1o : M1;
     }
+    if (lane < 32 && ok) {
+      const float cmax = __builtin_sqrtf(__uint_as_float(f.bnd[2 * s])) * 1.000001f, csqmax = __uint_as_float(f.bnd[2 * s + 1]);
+      const float thr = f.c1 * __builtin_sqrtf(xn2) * 1.000001f * cmax + f.c2 * csqmax + 1e-30f;
+      const int fr = fidx[b * FB + lr];
+      if (2.f * (M1 - M2) > thr) {  // d = -2 s
+        g.labels[fr] = sd.off + j;  // stratified_clustering.py:195
+      } else {  // (also every NaN: the comparison is false)
+        const unsigned long long pos = atomicAdd(&f.cnt2[s], 1ull);
+        f.perm2[g.base[s] + (long long)pos] = fr;
+      }
+    }
+    APROF(5)
   }
+  APROF_END
 }
 
 int hamsm_ensure_scratch2(hamsm_ctx *c, size_t bytes);
@@ -646,8 +700,9 @@ static int launch_sorted_ks(hamsm_ctx *c, SortArgs g) {
 
 template <typename XT, int KS>
 static int launch_filter_ks(hamsm_ctx *c, SortArgs g, FiltArgs f, int KH) {
-  constexpr int NW = FILT_NW(KS), FRB = 32 * NW;
-  size_t lds = sizeof(float) * (size_t)FRB * f.DS + sizeof(int) * FRB + sizeof(float) * (size_t)f.G * KH * 64 + 16;
+  constexpr int NW = FILT_NW(KS), FB = 32 * NW;
+  const int FRB = g.FRB;  // FB * blocks per workgroup
+  size_t lds = sizeof(float) * (size_t)FB * f.DS + sizeof(int) * FRB + sizeof(float) * (size_t)f.G * KH * 64 + 16;
   if (lds > 160 * 1024) return hamsm_fail(c, HAMSM_ENOTSUP, "assign filter needs %zu B of LDS", lds);
   const void *kern = KH == 2 * KS ? (const void *)k_assign_filter<XT, KS, 0> : (const void *)k_assign_filter<XT, KS, 1>;
   HIPCHK(c, hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -701,10 +756,14 @@ static int launch_sorted(hamsm_ctx *c, const AssignArgs &a) {
   c->filter_cnt2 = nullptr;
   if (filt) {
     f.DS = a.D + ((6 - (a.D & 3)) & 3);
-    g.FRB = 32 * FILT_NW(KS);
-    // centroid tiles per LDS group: frames + fragments within ~72 KB (two workgroups per CU)
-    size_t room = 72 * 1024 - (sizeof(float) * (size_t)g.FRB * f.DS + sizeof(int) * g.FRB);
-    f.G = (int)(room / (sizeof(float) * KH * 64));
+    const int FB = 32 * FILT_NW(KS);
+    // blocks per workgroup: enough to amortise the prologue, few enough that the grid still fills the chip ~8 times
+    int NB = (int)(n / ((long long)FB * 256 * 2 * 8));
+    NB = NB < 1 ? 1 : (NB > c->filter_nb ? c->filter_nb : NB);
+    g.FRB = FB * NB;
+    // centroid tiles per LDS group: frames + fragments within filter_lds_kb
+    long long room = (long long)c->filter_lds_kb * 1024 - (long long)(sizeof(float) * (size_t)FB * f.DS + sizeof(int) * g.FRB);
+    f.G = room > 0 ? (int)(room / (long long)(sizeof(float) * KH * 64)) : 0;
     f.G = f.G < 2 ? 2 : (f.G > tmax ? (tmax > 0 ? tmax : 1) : f.G & ~1);
   }
   HIPCHK(c, hipMemsetAsync(b + o_cnt, 0, sizeof(long long) * S, c->stream));
@@ -727,6 +786,7 @@ static int launch_sorted(hamsm_ctx *c, const AssignArgs &a) {
     f.cnt2 = (unsigned long long *)(b + o_zero);
     f.bnd = (const unsigned *)(b + o_zero + sizeof(long long) * S);
     f.perm2 = (int32_t *)(b + o_perm2);
+    f.magic = (1u << 24) / (unsigned)(((a.D & 1) == 0 && (a.ldx & 1) == 0 && ((uintptr_t)a.X & (2 * sizeof(XT) - 1)) == 0) ? a.D / 2 : a.D) + 1;
     f.c1 = 2.02f * (float)(2 * a.D + 8) / 4194304.0f;
     f.c2 = 2.02f * (float)(a.D + 5) / 4194304.0f;
     c->filter_cnt2 = f.cnt2;

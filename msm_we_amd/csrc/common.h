@@ -93,6 +93,8 @@ struct hamsm_ctx {
   hipEvent_t ev_cur0 = nullptr;
   double timers[ST_N] = {0};
   double last_ms[ST_N] = {0};
+  int filter_nb = 8;       // most frame blocks per filter workgroup (HAMSM_FILTER_NB, <= 16)
+  int filter_lds_kb = 72;  // LDS budget of a filter workgroup (HAMSM_FILTER_LDS_KB)
   int assign_filter = 1;   // f32-MFMA filter in front of the exact f64 distance kernel (HAMSM_ASSIGN_FILTER=0: exact kernel only)
   unsigned long long *filter_cnt2 = nullptr;  // (debug) uncertain-row counters of the last filtered assign, [S] in scratch2
   int assign_waves = 4;    // waves per workgroup of the sorted assign kernel (HAMSM_ASSIGN_W=8: 8 waves x 2 centroid tiles)

@@ -97,6 +97,84 @@ def test_assign_edge_cases(hip_h, oracle_h):
         assert np.array_equal(h.predict_host(Cm, np.full((8, 1), 0.5)), [0, 0, 2, 2, 4, 4, 6, 6])
 
 
+def _undecided(h):
+    fn = h.lib.hamsm_debug_filter_undecided
+    fn.restype = ctypes.c_longlong
+    fn.argtypes = [ctypes.c_void_p]
+    return fn(h.ctx)
+
+
+@pytest.mark.parametrize("D,K_s,dtype", [(30, 250, np.float32), (32, 40, np.float32), (64, 70, np.float64), (7, 3, np.float32),
+                                        (128, 33, np.float32)])
+def test_assign_filter_certifies_or_defers(hip_h, oracle_h, D, K_s, dtype):
+    """The f32 ranking pass may only finalise a label when its error bound separates the two best centroids; everything
+    else -- engineered near ties, duplicates, huge magnitudes, NaN / inf frames -- must reach the exact f64 kernel.  Labels
+    equal the oracle's in every case; the hook counts the deferred frames."""
+    S, n = 3, 6000
+    outs = {}
+    for name, h in (("oracle", oracle_h), ("hip", hip_h)):
+        rng = np.random.default_rng(7)
+        cents = _setup(h, D, S, K_s, rng)
+        X, p = _frames(rng, n, D, S, dtype)
+        lab_plain = h.predict_host(X, p)
+        und_plain = _undecided(h) if name == "hip" else None
+        # frames on (and a few ulps off) the bisector of two centroids of their stratum, frames equal to centroids
+        Xa = X.copy()
+        for i in range(0, 3000):
+            c = cents[min(int(p[i, 0]), S - 1)]
+            a, b = rng.integers(0, len(c), 2)
+            mid = 0.5 * (c[a] + c[b])
+            Xa[i] = (mid + (rng.integers(-2, 3) * 1e-7) * (c[a] - c[b])).astype(dtype)
+        Xa[3000:3100] = cents[0][rng.integers(0, K_s, 100)].astype(dtype)
+        Xa[3100:3110] *= dtype(1e18)       # overflows the f32 range of the squared norms
+        Xa[3110, 0] = np.nan
+        Xa[3111, D - 1] = np.inf
+        Xa[3112] = 0
+        lab_adv = h.predict_host(Xa, p)
+        und_adv = _undecided(h) if name == "hip" else None
+        outs[name] = (lab_plain, lab_adv, und_plain, und_adv)
+    assert np.array_equal(outs["oracle"][0], outs["hip"][0])
+    assert np.array_equal(outs["oracle"][1], outs["hip"][1])
+    und_plain, und_adv = outs["hip"][2:]
+    assert 0 <= und_plain < n // 20, und_plain   # well-separated data: (almost) everything certified in f32
+    assert und_adv >= 10, und_adv                # NaN / inf / overflow rows at least
+    # duplicated centroids: every frame is an exact tie between two centroids -> nothing may be certified
+    for h in (oracle_h, hip_h):
+        rng = np.random.default_rng(8)
+        _setup(h, D, 1, K_s, rng)
+        Cm = np.repeat(rng.normal(size=(K_s, D)) * 3, 2, axis=0)
+        h.set_centroids(0, Cm, csq=np.einsum("ij,ij->i", Cm, Cm))
+        X, p = _frames(rng, 2000, D, 1, dtype)
+        lab = h.predict_host(X, p)
+        inside = (p[:, 0] > 0.05) & (p[:, 0] < 0.95)
+        assert (lab[inside] % 2 == 0).all()      # first index wins
+        if h is hip_h:
+            assert _undecided(h) == int(inside.sum())
+            dup = lab
+        else:
+            ref = lab
+    assert np.array_equal(ref, dup)
+
+
+def test_assign_filter_can_be_disabled(hip_lib, oracle_h, monkeypatch):
+    """HAMSM_ASSIGN_FILTER=0 runs the exact kernel alone; same labels."""
+    from msm_we_amd import _abi
+
+    monkeypatch.setenv("HAMSM_ASSIGN_FILTER", "0")
+    h = _abi.Hamsm(lib=hip_lib, device=0)
+    try:
+        labs = []
+        for hh in (oracle_h, h):
+            rng = np.random.default_rng(3)
+            _setup(hh, 30, 4, 100, rng)
+            X, p = _frames(rng, 4000, 30, 4, np.float32)
+            labs.append(hh.predict_host(X, p))
+        assert np.array_equal(labs[0], labs[1])
+        assert _undecided(h) == -1
+    finally:
+        h.close()
+
+
 def test_assign_unfitted_stratum_raises(hip_h, oracle_h):
     from msm_we_amd._abi import HamsmError
 
