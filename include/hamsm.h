@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define HAMSM_ABI_VERSION 2
+#define HAMSM_ABI_VERSION 3
 
 #define HAMSM_OK 0
 #define HAMSM_EINVAL (-1)   /* bad argument / call order                                         */
@@ -95,6 +95,20 @@ int hamsm_classify(hamsm_ctx *ctx, const double *d_pcoord, int64_t n, int apply_
  * d_X holds n rows of Draw raw features (x_dtype, row stride ldx); d_Y is [n][d] float64.  Needs no geometry.      */
 int hamsm_project(hamsm_ctx *ctx, const void *d_X, int x_dtype, int64_t ldx, int64_t n, int Draw,
                   const double *h_mean, const double *h_W, int d, const double *h_scale, double *d_Y);
+
+/* ---- a1: the distance-to-reference featurizer the reference ships with its tests (`processCoordinates`,
+ * tests/test_msm_we.py:19-36: MDAnalysis `distances.dist(frame_atoms, reference_atoms)[2]` per frame; contract
+ * docs/usage.rst:41-60).  For frame i and selected atom a
+ *   d_X[i][a] = sqrt(dx*dx + dy*dy + dz*dz),   d? = (double)((float)coord[i][h_idx[a]][?] - h_ref[a][?])
+ * i.e. positions are float32, their difference is taken in float32, squares / sum (x, y, z in this order) / root in
+ * float64, nothing fused -- what MDAnalysis' calc_bonds kernel computes without a box.  d_coords holds n frames of
+ * n_atoms x 3 coordinates (c_dtype; float64 input is rounded to float32 first, as loading it into a Universe does),
+ * frame stride ldc elements; h_idx [n_sel] atom indices; h_ref [n_sel][3] float32 reference positions of the SELECTED
+ * atoms; d_X [n][n_sel] float64, row stride ldx >= n_sel.  Needs no geometry.  (The flattening featurizer of
+ * examples/hamsm_construction.ipynb needs no entry point: pass the coordinates as features with D = 3 n_atoms.)
+ * MDAnalysis is not in the build image: this entry point is pinned to its published algorithm, not to its output. */
+int hamsm_featurize_dist(hamsm_ctx *ctx, const void *d_coords, int c_dtype, int64_t ldc, int64_t n, int n_atoms,
+                         const int32_t *h_idx, int n_sel, const float *h_ref, double *d_X, int64_t ldx);
 
 /* ---- a9: StratifiedClusters.predict (stratified_clustering.py:101-212) fused with a3/a4 -------
  * label = Kfit+1 if target(p) else Kfit if basis(p) else off(s) + argmin_j ||x - c_j||^2 over

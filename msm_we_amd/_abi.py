@@ -20,7 +20,7 @@ _vp, _i32, _i64, _f64, _sz = C.c_void_p, C.c_int32, C.c_int64, C.c_double, C.c_s
 _int = C.c_int
 
 # name -> (restype, argtypes); kept in the order of include/hamsm.h
-ABI_VERSION = 2  # HAMSM_ABI_VERSION of include/hamsm.h
+ABI_VERSION = 3  # HAMSM_ABI_VERSION of include/hamsm.h
 
 SYMBOLS = {
     "hamsm_abi_version": (_int, []),
@@ -43,6 +43,7 @@ SYMBOLS = {
     "hamsm_num_centroids": (_int, [_vp, _int]),
     "hamsm_classify": (_int, [_vp, _vp, _i64, _int, _vp, _vp]),
     "hamsm_project": (_int, [_vp, _vp, _int, _i64, _i64, _int, _vp, _vp, _int, _vp, _vp]),
+    "hamsm_featurize_dist": (_int, [_vp, _vp, _int, _i64, _i64, _int, _vp, _int, _vp, _vp, _i64]),
     "hamsm_assign": (_int, [_vp, _vp, _int, _i64, _vp, _i64, _vp, _vp]),
     "hamsm_predict_host": (_int, [_vp, _vp, _int, _vp, _i64, _vp, _vp]),
     "hamsm_flux_accumulate": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _int, _vp, _int, _vp, _i64]),
@@ -289,6 +290,16 @@ class Hamsm:
         self._ck(self.lib.hamsm_project(self.ctx, _dp(d_X), int(x_dtype), int(ldx), int(n), int(Draw), _hp(mean), _hp(W), int(d),
                                         _hp(scale), _dp(d_Y)))
         return d_Y
+
+    def featurize_dist(self, d_coords, c_dtype, ldc, n, n_atoms, idx, ref, d_X=None):
+        """per-atom distance to a reference structure (the reference's test featurizer): -> DevBuf [n][len(idx)] float64"""
+        idx = np.ascontiguousarray(idx, dtype=np.int32)
+        ref = np.ascontiguousarray(ref, dtype=np.float32).reshape(len(idx), 3)
+        if d_X is None:
+            d_X = self.alloc(max(int(n), 1) * len(idx), np.float64)
+        self._ck(self.lib.hamsm_featurize_dist(self.ctx, _dp(d_coords), int(c_dtype), int(ldc), int(n), int(n_atoms), _hp(idx),
+                                               len(idx), _hp(ref), _dp(d_X), len(idx)))
+        return d_X
 
     def assign(self, d_X, x_dtype, ldx, d_pcoord, n, d_labels, d_seen=None):
         self._ck(self.lib.hamsm_assign(self.ctx, _dp(d_X), int(x_dtype), int(ldx), _dp(d_pcoord), int(n),

@@ -176,3 +176,55 @@ extern "C" int hamsm_project(hamsm_ctx *c, const void *X, int dt, int64_t ldx, i
   HIPCHK(c, hipStreamSynchronize(c->stream));  // h_W / h_mean / h_scale are the caller's
   return HAMSM_OK;
 }
+
+// ---- a1: distance-to-reference featurizer (include/hamsm.h) -- HBM-bound: a frame's coordinates in, n_sel doubles out.
+// blockDim = (ax atoms, 256 / ax frames), ax = the power of two >= n_sel up to 64: a frame's selected atoms are read by
+// consecutive lanes (ascending indices: the touched lines of a frame are fetched once), the feature row is written coalesced.
+template <typename CT>
+__global__ __launch_bounds__(256) void k_featurize_dist(const CT *__restrict__ coords, int64_t ldc, int64_t n,
+                                                        const int32_t *__restrict__ idx, int n_sel,
+                                                        const float *__restrict__ ref, double *__restrict__ X, int64_t ldx) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.y + threadIdx.y;
+  if (i >= n) return;
+  const CT *fr = coords + i * ldc;
+  for (int a = threadIdx.x; a < n_sel; a += blockDim.x) {
+    const int at = idx[a];
+    const float dx = (float)fr[3 * (int64_t)at] - ref[3 * a], dy = (float)fr[3 * (int64_t)at + 1] - ref[3 * a + 1],
+                dz = (float)fr[3 * (int64_t)at + 2] - ref[3 * a + 2];
+    double rsq = (double)dx * (double)dx;
+    rsq = rsq + (double)dy * (double)dy;
+    rsq = rsq + (double)dz * (double)dz;
+    X[i * ldx + a] = __builtin_sqrt(rsq);  // (IEEE: correctly rounded, like libm's)
+  }
+}
+
+extern "C" int hamsm_featurize_dist(hamsm_ctx *c, const void *coords, int dt, int64_t ldc, int64_t n, int n_atoms,
+                                    const int32_t *h_idx, int n_sel, const float *h_ref, double *X, int64_t ldx) {
+  if (dt != HAMSM_F32 && dt != HAMSM_F64) return hamsm_fail(c, HAMSM_EINVAL, "bad c_dtype");
+  if (n_atoms < 1 || n_sel < 1 || !h_idx || !h_ref || ldc < 3 * (int64_t)n_atoms || ldx < n_sel)
+    return hamsm_fail(c, HAMSM_EINVAL, "bad featurizer shape");
+  for (int a = 0; a < n_sel; a++)
+    if (h_idx[a] < 0 || h_idx[a] >= n_atoms) return hamsm_fail(c, HAMSM_EINVAL, "atom index %d out of range", (int)h_idx[a]);
+  if (n <= 0) return HAMSM_OK;
+  HIPCHK(c, hipSetDevice(c->device));
+  const size_t o_ref = (sizeof(int32_t) * (size_t)n_sel + 255) & ~(size_t)255;
+  int rc = hamsm_ensure_scratch2(c, o_ref + sizeof(float) * 3 * (size_t)n_sel);
+  if (rc) return rc;
+  char *b = (char *)c->scratch2;
+  HIPCHK(c, hipMemcpyAsync(b, h_idx, sizeof(int32_t) * (size_t)n_sel, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(b + o_ref, h_ref, sizeof(float) * 3 * (size_t)n_sel, hipMemcpyHostToDevice, c->stream));
+  hamsm_timer_begin(c);
+  int ax = 1;
+  while (ax < n_sel && ax < 64) ax <<= 1;
+  const dim3 block(ax, 256 / ax), grid((unsigned)((n + block.y - 1) / block.y));
+  if (dt == HAMSM_F32)
+    hipLaunchKernelGGL(k_featurize_dist<float>, grid, block, 0, c->stream, (const float *)coords, ldc, n, (const int32_t *)b, n_sel,
+                       (const float *)(b + o_ref), X, ldx);
+  else
+    hipLaunchKernelGGL(k_featurize_dist<double>, grid, block, 0, c->stream, (const double *)coords, ldc, n, (const int32_t *)b, n_sel,
+                       (const float *)(b + o_ref), X, ldx);
+  hamsm_timer_end(c, ST_OTHER);
+  HIPCHK(c, hipGetLastError());
+  HIPCHK(c, hipStreamSynchronize(c->stream));  // h_idx / h_ref are the caller's
+  return HAMSM_OK;
+}

@@ -135,6 +135,7 @@ class DeviceStore:
 
 class DataMixin:
     seg_weights = {}
+    device_featurizer = None  # set by `set_distance_featurizer`
 
     # -- source plumbing --------------------------------------------------------------------
     def set_iteration_source(self, source):
@@ -244,6 +245,8 @@ class DataMixin:
         if getattr(self, "_store", None) is not None:
             return self._store
         h = self.h
+        if getattr(self, "device_featurizer", None) is not None:
+            return self._stage_with_device_featurizer()
         lin = self._linear_map()
         parts = {k: [] for k in ("Xp", "Xc", "p0", "p1", "w")}
         sizes = []
@@ -289,6 +292,59 @@ class DataMixin:
             proj.append(h.project(d_raw, dt, Draw, n, W, mean, scale))
             d_raw.free()
         self._store = DeviceStore(h, W.shape[0], p0.shape[1], _abi.F64, offsets, proj[0], proj[1], h.to_device(p0), h.to_device(p1),
+                                  h.to_device(w))
+        return self._store
+
+    def set_distance_featurizer(self, atom_indices, reference_positions):
+        """Featurize on the device with the per-atom distance to a reference structure -- what the reference's test
+        `processCoordinates` computes with MDAnalysis (tests/test_msm_we.py:19-36).  `atom_indices`: the selection
+        (e.g. backbone) into the frame's atoms; `reference_positions`: [(len(atom_indices)), 3] positions of the same
+        atoms in the reference structure.  `processCoordinates` is then not called during staging."""
+        idx = np.ascontiguousarray(atom_indices, dtype=np.int32)
+        ref = np.ascontiguousarray(reference_positions, dtype=np.float32).reshape(len(idx), 3)
+        self.device_featurizer = ("dist", idx, ref)
+        self._store = None
+
+    def _stage_with_device_featurizer(self):
+        """raw coordinates up (float32 when exact), features computed in HBM (`hamsm_featurize_dist`), then the optional
+        linear map (`hamsm_project`); the raw copy is released at once"""
+        h = self.h
+        _, idx, ref = self.device_featurizer
+        lin = self._linear_map()
+        if lin is None and self.coordinates is not None and type(self.coordinates).__name__ != "Coordinates":
+            raise NotImplementedError("device featurizer + a non-linear coordinates.transform")
+        raw = {"parent": [], "child": []}
+        p0s, p1s, ws, sizes = [], [], [], []
+        for it in range(1, self.maxIter + 1):
+            d = self._load(it)
+            n = len(d["w"])
+            for which in raw:
+                raw[which].append(np.asarray(d[which]).reshape(n, -1))
+            p0s.append(np.asarray(d["p0"], dtype=np.float64).reshape(n, -1)[:, : self.pcoord_ndim])
+            p1s.append(np.asarray(d["p1"], dtype=np.float64).reshape(n, -1)[:, : self.pcoord_ndim])
+            ws.append(np.asarray(d["w"], dtype=np.float64))
+            sizes.append(n)
+        feats = []
+        for which in ("parent", "child"):
+            R = np.concatenate(raw[which])
+            if np.isnan(R).any():
+                raise NotImplementedError("NaN coordinates (_data.py:303-313,549-553) are not supported yet")
+            R32 = R.astype(np.float32)
+            dt, R = (_abi.F32, R32) if np.array_equal(R32.astype(np.float64), R) else (_abi.F64, R.astype(np.float64))
+            n, width = R.shape
+            d_raw = h.to_device(R)
+            d_X = h.featurize_dist(d_raw, dt, width, n, width // 3, idx, ref)
+            d_raw.free()
+            if lin is not None:
+                W, mean, scale = lin
+                d_Y = h.project(d_X, _abi.F64, len(idx), n, W, mean, scale)
+                d_X.free()
+                d_X = d_Y
+            feats.append(d_X)
+        D = len(idx) if lin is None else lin[0].shape[0]
+        offsets = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)
+        p0, p1, w = np.concatenate(p0s), np.concatenate(p1s), np.concatenate(ws)
+        self._store = DeviceStore(h, D, p0.shape[1], _abi.F64, offsets, feats[0], feats[1], h.to_device(p0), h.to_device(p1),
                                   h.to_device(w))
         return self._store
 

@@ -476,6 +476,32 @@ int hamsm_project(hamsm_ctx *c, const void *X, int dt, int64_t ldx, int64_t n, i
   return HAMSM_OK;
 }
 
+/* --- a1: tests/test_msm_we.py:19-36 -> MDAnalysis distances.dist(...)[2] = lib.distances.calc_bonds without a box
+ *     (float32 positions, float32 difference, float64 squares / sum / sqrt).  Restated from the published algorithm:
+ *     MDAnalysis is not available here, so this function is NOT pinned by reference output ("parity unpinned"). */
+int hamsm_featurize_dist(hamsm_ctx *c, const void *coords, int dt, int64_t ldc, int64_t n, int n_atoms, const int32_t *idx,
+                         int n_sel, const float *ref, double *X, int64_t ldx) {
+  if (dt != HAMSM_F32 && dt != HAMSM_F64) return fail(c, HAMSM_EINVAL, "bad c_dtype");
+  if (n_atoms < 1 || n_sel < 1 || !idx || !ref || ldc < 3 * (int64_t)n_atoms || ldx < n_sel)
+    return fail(c, HAMSM_EINVAL, "bad featurizer shape");
+  for (int a = 0; a < n_sel; a++)
+    if (idx[a] < 0 || idx[a] >= n_atoms) return fail(c, HAMSM_EINVAL, "atom index %d out of range", (int)idx[a]);
+  for (int64_t i = 0; i < n; i++)
+    for (int a = 0; a < n_sel; a++) {
+      double d[3];
+      for (int q = 0; q < 3; q++) {
+        float x = (float)xval(coords, dt, i * ldc + 3 * (int64_t)idx[a] + q);
+        float df = x - ref[3 * a + q];
+        d[q] = (double)df;
+      }
+      double rsq = d[0] * d[0];
+      rsq = rsq + d[1] * d[1];
+      rsq = rsq + d[2] * d[2];
+      X[i * ldx + a] = sqrt(rsq);
+    }
+  return HAMSM_OK;
+}
+
 /* --- a5 support: _clustering.py:872-886 */
 int hamsm_train_prepass(hamsm_ctx *c, const double *p, int64_t n, const int64_t *offs, int64_t n_iters, int32_t *bin,
                         int64_t *hist) {
