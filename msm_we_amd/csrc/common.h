@@ -82,6 +82,9 @@ struct hamsm_ctx {
   size_t scratch_bytes = 0;
   void *scratch2 = nullptr;  // second arena: internals of hamsm_assign (its caller may hold `scratch`)
   size_t scratch2_bytes = 0;
+  double *flux_part = nullptr;  // per-XCD partial flux matrices (flux.hip)
+  size_t flux_part_bytes = 0;
+  int flux_xcd = 1;             // HAMSM_FLUX_XCD=0: one matrix, device-scope atomics
   void *h_pinned = nullptr;  // small pinned staging buffer
   size_t h_pinned_bytes = 0;
   struct EvPair {

@@ -23,6 +23,7 @@ extern "C" int hamsm_create(int device, hamsm_ctx **out) {
   c->device = device;
   memset(&c->mapper, 0, sizeof c->mapper);
   if (const char *v = getenv("HAMSM_ASSIGN_W")) c->assign_waves = atoi(v) == 8 ? 8 : 4;
+  if (const char *v = getenv("HAMSM_FLUX_XCD")) c->flux_xcd = atoi(v) != 0;
   if (const char *v = getenv("HAMSM_ASSIGN_FILTER")) c->assign_filter = atoi(v) != 0;
   if (const char *v = getenv("HAMSM_FILTER_NB")) c->filter_nb = atoi(v) < 1 ? 1 : (atoi(v) > 16 ? 16 : atoi(v));
   if (const char *v = getenv("HAMSM_FILTER_LDS_KB")) c->filter_lds_kb = atoi(v) < 40 ? 40 : (atoi(v) > 150 ? 150 : atoi(v));
@@ -69,6 +70,7 @@ extern "C" void hamsm_destroy(hamsm_ctx *c) {
   hipHostFree(c->h_err);
   hipFree(c->scratch);
   hipFree(c->scratch2);
+  hipFree(c->flux_part);
   hipHostFree(c->h_pinned);
   for (auto &p : c->ev_pending) {
     hipEventDestroy(p.e0);

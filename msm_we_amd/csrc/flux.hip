@@ -36,6 +36,44 @@ __global__ void k_flux_atomic(MapperDev m, FluxArgs g) {
   unsafeAtomicAdd(&g.F[(size_t)a * (K + 2) + b], g.w[i]);
 }
 
+// Device-scope f64 atomics are executed beyond the XCDs' L2s (the 8 L2s are not coherent with each other inside a kernel):
+// 10^7 of them take 0.93 ms whatever the matrix size.  When 8 copies of the matrix are affordable, every XCD adds into
+// ITS OWN copy with workgroup-scope atomics -- performed in its L2, at L2 rate -- and a second kernel sums the copies in
+// XCD order into F.  (The XCD is read from the hardware register, not inferred from the workgroup id.)
+#define FLUX_NXCD 8
+#define FLUX_PART_MAX_BYTES ((size_t)512 << 20)
+__global__ void k_flux_xcd(MapperDev m, FluxArgs g, double *__restrict__ part, size_t cells) {
+  int64_t i = g.i0 + (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= g.i0 + g.n) return;
+  unsigned xcc;
+  asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+  xcc &= FLUX_NXCD - 1;
+  double q0[HAMSM_MAX_NDIM], q1[HAMSM_MAX_NDIM];
+  for (int d = 0; d < m.ndim; d++) {
+    q0[d] = g.p0[i * m.ndim + d];
+    q1[d] = g.p1[i * m.ndim + d];
+  }
+  int a = g.pa[i], b = g.ch[i];
+  const int K = g.K;
+  if (dev_in_box(m.target, m.ndim, q1)) b = K + 1;  // _fluxmatrix.py:135
+  if (dev_in_box(m.basis, m.ndim, q0)) a = K;       // :136
+  if (dev_in_box(m.basis, m.ndim, q1)) b = K;       // :137
+  if (a < 0 || b < 0 || a >= K + 2 || b >= K + 2) {
+    dev_set_error(g.err, HAMSM_ERANGE, (int)i, a < 0 || a >= K + 2 ? a : b);
+    return;
+  }
+  __hip_atomic_fetch_add(&part[xcc * cells + (size_t)a * (K + 2) + b], g.w[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+
+__global__ void k_flux_fold(double *__restrict__ F, const double *__restrict__ part, size_t cells) {
+  const size_t c = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= cells) return;
+  double s = part[c];
+#pragma unroll
+  for (int x = 1; x < FLUX_NXCD; x++) s = s + part[x * cells + c];
+  if (s != 0.0) F[c] = F[c] + s;
+}
+
 int hamsm_flux_sorted(hamsm_ctx *c, const MapperDev &m, const FluxArgs &g, const int64_t *d_offs, int64_t n_iters);
 
 extern "C" int hamsm_flux_accumulate(hamsm_ctx *c, const int32_t *pa, const int32_t *ch, const double *p0, const double *p1,
@@ -51,7 +89,23 @@ extern "C" int hamsm_flux_accumulate(hamsm_ctx *c, const int32_t *pa, const int3
   FluxArgs g{pa, ch, p0, p1, w, i0, n, K, F, c->d_err};
   hamsm_timer_begin(c);
   int rc = HAMSM_OK;
-  if (mode == 0) {
+  const size_t cells = (size_t)(K + 2) * (K + 2), part_bytes = sizeof(double) * cells * FLUX_NXCD;
+  if (mode == 0 && c->flux_xcd && part_bytes <= FLUX_PART_MAX_BYTES && n >= 100000) {
+    if (part_bytes > c->flux_part_bytes) {
+      HIPCHK(c, hipStreamSynchronize(c->stream));
+      hipFree(c->flux_part);
+      c->flux_part = nullptr;
+      c->flux_part_bytes = 0;
+      hipError_t e = hipMalloc((void **)&c->flux_part, part_bytes);
+      if (e != hipSuccess) return hamsm_fail(c, HAMSM_ENOMEM, "flux partials hipMalloc(%zu): %s", part_bytes, hipGetErrorString(e));
+      c->flux_part_bytes = part_bytes;
+    }
+    HIPCHK(c, hipMemsetAsync(c->flux_part, 0, part_bytes, c->stream));
+    hipLaunchKernelGGL(k_flux_xcd, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, c->mapper, g, c->flux_part, cells);
+    hipLaunchKernelGGL(k_flux_fold, dim3((unsigned)((cells + 255) / 256)), dim3(256), 0, c->stream, F, (const double *)c->flux_part, cells);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) rc = hamsm_fail(c, HAMSM_EDEVICE, "k_flux_xcd: %s", hipGetErrorString(e));
+  } else if (mode == 0) {
     hipLaunchKernelGGL(k_flux_atomic, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, c->mapper, g);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) rc = hamsm_fail(c, HAMSM_EDEVICE, "k_flux_atomic: %s", hipGetErrorString(e));

@@ -282,6 +282,32 @@ def test_flux_matches_oracle(hip_h, oracle_h, mode):
         np.testing.assert_allclose(Fs[1], Fs[0], rtol=1e-12)  # f64 atomics: order-free
 
 
+def test_flux_per_xcd_partials_match_oracle(hip_h, oracle_h):
+    """calls of >= 1e5 segments accumulate into one private matrix per XCD (L2-scope atomics) folded into F afterwards; a bad
+    label raises there too"""
+    from msm_we_amd._abi import HamsmError
+
+    K, n, n_iters = 301, 250000, 50
+    Fs = []
+    for h in (oracle_h, hip_h):
+        rng = np.random.default_rng(15)
+        _setup(h, 4, 4, 4, rng)
+        pa, ch, p0, p1, w, offs = _flux_inputs(rng, n, K, n_iters)
+        d = [h.to_device(a) for a in (pa, ch, p0, p1, w, offs)]
+        d_F = h.to_device(rng.uniform(size=(K + 2, K + 2)))
+        for _ in range(2):  # accumulates on top of existing values, twice
+            h.flux_accumulate(d[0], d[1], d[2], d[3], d[4], n, K, d_F, 0, d[5], n_iters)
+        Fs.append(d_F.to_host())
+    np.testing.assert_allclose(Fs[1], Fs[0], rtol=1e-12)
+    ch[123456] = K + 7
+    p0[:] = 1.0
+    p1[:] = 1.0
+    d = [hip_h.to_device(a) for a in (pa, ch, p0, p1, w)]
+    with pytest.raises(HamsmError) as e:
+        hip_h.flux_accumulate(d[0], d[1], d[2], d[3], d[4], n, K, hip_h.zeros((K + 2, K + 2), np.float64), 0)
+    assert e.value.code == -5
+
+
 def test_flux_bad_label_raises(hip_h):
     from msm_we_amd._abi import HamsmError
 
