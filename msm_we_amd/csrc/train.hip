@@ -467,7 +467,6 @@ __device__ __forceinline__ double readlane_f64(double v, int l) {
   return __longlong_as_double(((long long)hi << 32) | lo);
 }
 
-#define SEED_G_BUDGET ((size_t)4 << 30)      // bytes of Gram matrices resident at once (56 strata of 3072 rows)
 #define SEED_NCH (SEED_NLDS / SCAN_CHUNK)   // 48 chunks of the cumulative sum
 #define SEED_PST (SEED_NCH + 1)             // stride of the transposed product array: lanes = chunks, conflict-free
 #define SEED_PL (32 * 33)                   // one candidate's 1024 partial potentials, groups of 32 padded to 33
@@ -761,10 +760,10 @@ extern "C" int hamsm_kmeans_seed_multi(hamsm_ctx *c, int n_items, const int32_t 
   for (int i = 0; i < n_items; i++) fast = fast && lay[i].n <= SEED_NLDS && h_L[i] <= SEED_LFAST && h_L[i] == h_L[0];
   const size_t lds_fast = sizeof(double) * SEED_G_LDS(h_L[0]);
   const size_t g_bytes = (sizeof(double) * (size_t)nmax * nmax + 255) & ~(size_t)255;
-  int g_slots = 1;  // strata whose Gram matrices are resident at once (<= SEED_G_BUDGET bytes)
+  int g_slots = 1;  // strata whose Gram matrices are resident at once (<= ctx seed_g_budget bytes)
   size_t o_G = 0;
   if (fast) {
-    g_slots = (int)(SEED_G_BUDGET / g_bytes);
+    g_slots = (int)(c->seed_g_budget / g_bytes);
     g_slots = g_slots < 1 ? 1 : (g_slots > n_items ? n_items : g_slots);
     o_G = take(g_bytes * g_slots);
   }

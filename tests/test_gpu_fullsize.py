@@ -137,6 +137,43 @@ def test_c3_train_assign_full_size(c3_run, oracle_h):
     assert np.array_equal(np.concatenate(m2.dtrajs), child)
 
 
+def test_c3_filter_and_exact_kernel_agree_on_every_frame(c3_run, hip_lib, monkeypatch):
+    """all 2 x 10 M labels of the default path (f32 ranking + exact recheck of the undecided) equal those of the exact f64
+    kernel alone (HAMSM_ASSIGN_FILTER=0), and only a sliver of the frames needed the recheck"""
+    import ctypes
+
+    from msm_we_amd import _abi
+
+    cfg, d, h, m, store, bm = c3_run
+    n = store.N
+    monkeypatch.setenv("HAMSM_ASSIGN_FILTER", "0")
+    hx = _abi.Hamsm(lib=hip_lib)
+    try:
+        hx.set_geometry(cfg.D, 1, cfg.S)
+        hx.set_mapper_rectilinear([synthetic.strata_boundaries(cfg.S)])
+        basis, target = synthetic.basis_target_bounds(cfg.S)
+        hx.set_bounds(basis, target)
+        for s in range(cfg.S):
+            Cm, counts, csq = h.get_centroids(s)
+            hx.set_centroids(s, Cm, csq=csq)
+        fn = h.lib.hamsm_debug_filter_undecided
+        fn.restype = ctypes.c_longlong
+        fn.argtypes = [ctypes.c_void_p]
+        d_a, d_b = h.alloc(n, np.int32), hx.alloc(n, np.int32)
+        for X, p in ((d["Xc"], d["p1"]), (d["Xp"], d["p0"])):
+            d_X, d_p = h.to_device(X[:n]), h.to_device(p[:n])
+            h.assign(d_X, 0, cfg.D, d_p, n, d_a)
+            und = fn(h.ctx)
+            dx_X, dx_p = hx.to_device(X[:n]), hx.to_device(p[:n])
+            hx.assign(dx_X, 0, cfg.D, dx_p, n, d_b)
+            assert np.array_equal(d_a.to_host(), d_b.to_host())
+            assert 0 <= und < n // 1000, und
+            for b in (d_X, d_p, dx_X, dx_p):
+                b.free()
+    finally:
+        hx.close()
+
+
 def test_c3_flux_and_stats_full_size(c3_run):
     cfg, d, h, m, store, bm = c3_run
     K = m.n_clusters

@@ -105,7 +105,8 @@ def _undecided(h):
 
 
 @pytest.mark.parametrize("D,K_s,dtype", [(30, 250, np.float32), (32, 40, np.float32), (64, 70, np.float64), (7, 3, np.float32),
-                                        (128, 33, np.float32)])
+                                        (128, 33, np.float32), (47, 65, np.float32), (48, 31, np.float64), (90, 129, np.float32),
+                                        (96, 20, np.float32), (1, 9, np.float64)])
 def test_assign_filter_certifies_or_defers(hip_h, oracle_h, D, K_s, dtype):
     """The f32 ranking pass may only finalise a label when its error bound separates the two best centroids; everything
     else -- engineered near ties, duplicates, huge magnitudes, NaN / inf frames -- must reach the exact f64 kernel.  Labels
@@ -154,6 +155,32 @@ def test_assign_filter_certifies_or_defers(hip_h, oracle_h, D, K_s, dtype):
         else:
             ref = lab
     assert np.array_equal(ref, dup)
+
+
+def test_seeding_in_gram_groups(hip_lib, oracle_h, monkeypatch):
+    """k-means++ of several strata with room for only two Gram matrices at a time (HAMSM_SEED_G_MB): the strata are seeded in
+    groups that share the slots; centroids equal the oracle's"""
+    from msm_we_amd import _abi
+
+    monkeypatch.setenv("HAMSM_SEED_G_MB", "20")   # 1000-row batches: 8 MB per Gram matrix -> 2 slots
+    h = _abi.Hamsm(lib=hip_lib, device=0)
+    try:
+        D, S, K, nb = 12, 5, 40, 1000
+        out = []
+        for hh in (oracle_h, h):
+            rng = np.random.default_rng(21)
+            _setup(hh, D, S, 4, rng)
+            X = rng.normal(size=(S * nb, D)).astype(np.float32)
+            d_X = hh.to_device(X)
+            L = 2 + int(np.log(K))
+            hh.kmeans_seed_multi(list(range(S)), d_X, _abi.F32, D, [s * nb for s in range(S)], None, [0] * S, [nb] * S, None,
+                                 [None] * S, [K] * S, [int(rng.integers(nb)) for _ in range(S)],
+                                 [rng.uniform(size=(K - 1) * L) for _ in range(S)], [L] * S)
+            out.append([hh.get_centroids(s)[0] for s in range(S)])
+        for a, b in zip(*out):
+            assert np.array_equal(a, b)
+    finally:
+        h.close()
 
 
 def test_assign_filter_can_be_disabled(hip_lib, oracle_h, monkeypatch):
