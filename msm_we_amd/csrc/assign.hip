@@ -456,13 +456,16 @@ __global__ void k_sort_offsets2(SortArgs g, const unsigned long long *cnt2, long
 
 #define FILT_NW(KS) ((KS) <= 8 ? 8 : ((KS) <= 16 ? 4 : 2))
 #define FILT_NB_MAX 16
-// A workgroup serves up to NB consecutive blocks of FB = 32 NW frames of its stratum: the frame indices of all of them
-// and the centroid fragments are fetched once, and while the matrix unit works on block b the rows of block b + 1 are
-// already on their way (parked in registers, written to LDS after the block) -- the per-block cost is the MFMA sweep,
-// not a chain of dependent memory round trips.
+// A workgroup serves 32 NW NB consecutive frames of its stratum; wave w owns the frame tiles w, w + NW, ... and is
+// AUTONOMOUS: it gathers its tile's rows into a private LDS slab, reads them back as the B operand, sweeps all centroid
+// tiles and stores its labels without ever meeting the other waves at a barrier (the stratum's fragments are shared and
+// loaded once).  The rows of a wave's next tile are requested before the sweep of the current one and parked in
+// registers.  Why it matters: a wave that streams MFMAs monopolises its SIMD's issue port (tools/mfma_corun.hip), so
+// every instruction between two sweeps is dead time for the matrix unit unless it is short -- barriers made it long.
+// (More centroid tiles than fit in LDS: the fragment groups are exchanged between barriers; the waves then walk in step.)
 template <typename XT, int KS, int AUGX>
-__global__ __launch_bounds__(FILT_NW(KS) * 64) __attribute__((amdgpu_waves_per_eu(KS <= 8 ? 4 : 2))) void k_assign_filter(SortArgs g, FiltArgs f) {
-  constexpr int NW = FILT_NW(KS), NT = NW * 64, KH = 2 * KS + AUGX, FB = 32 * NW;
+__global__ __launch_bounds__(FILT_NW(KS) * 64) __attribute__((amdgpu_waves_per_eu(KS <= 8 ? 3 : 2))) void k_assign_filter(SortArgs g, FiltArgs f) {
+  constexpr int NW = FILT_NW(KS), NT = NW * 64, KH = 2 * KS + AUGX;
   APROF_INIT
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   typedef float v4f32 __attribute__((ext_vector_type(4)));
@@ -484,102 +487,107 @@ __global__ __launch_bounds__(FILT_NW(KS) * 64) __attribute__((amdgpu_waves_per_e
   const StratumDev sd = g.table[s];
   const gcfp Ag = (gcfp)f.ft[s].A;
   const int njt = (sd.K + 31) >> 5;
-  const bool oneg = njt <= G;  // all fragments of the stratum fit: loaded once for every block
-  float *Xs = (float *)smem;                      // [FB][DS]
-  int *fidx = (int *)(Xs + (size_t)FB * DS);      // [g.FRB] = all blocks of this workgroup
-  float *As = (float *)(fidx + g.FRB);            // [G][KH][64]
-  // the first group's centroid fragments: issued now, parked in registers while the frame indices arrive
-  constexpr int AQ = 4;
-  v4f32 areg[AQ];
-  const int gc0 = njt < G ? njt : G, tot0 = gc0 * KH * 64;
-#pragma unroll
-  for (int q = 0; q < AQ; q++) {
-    const int e = (tid + q * NT) * 4;
-    areg[q] = *(gv4p)(Ag + (e < tot0 ? e : 0));
-  }
-  const long long p0 = g.base[s] + (long long)(blockIdx.x - g.blkbase[s]) * g.FRB;
+  const bool oneg = njt <= G;  // all fragments of the stratum fit: loaded once
+  float *Xw = (float *)smem + (size_t)wv * 32 * DS;   // [NW][32][DS]: this wave's slab
+  float *As = (float *)smem + (size_t)NW * 32 * DS;   // [G][KH][64]
+  const long long base_s = g.base[s];
+  const long long p0 = base_s + (long long)(blockIdx.x - g.blkbase[s]) * g.FRB;
   const long long pend = g.base[s + 1];
-  const int nfw = (int)((pend - p0) < g.FRB ? (pend - p0) : g.FRB);
-  const int nblk = (nfw + FB - 1) / FB;
+  // the certainty threshold 2 E x 1.01 = thr_x ||x|| + thr_0 (per stratum: fetched once, not per tile)
+  const float thr_x = f.c1 * 1.000001f * __builtin_sqrtf(__uint_as_float(f.bnd[2 * s])) * 1.000001f;
+  const float thr_0 = f.c2 * __uint_as_float(f.bnd[2 * s + 1]) + 1e-30f;
+  const int nfw = (int)((pend - p0) < g.FRB ? (pend - p0) : g.FRB);  // frames of this workgroup
+  const int NB = g.FRB / (32 * NW);                                   // tiles per wave
   const float ninf = -__builtin_huge_valf(), pinf = __builtin_huge_valf();
-  for (int i = tid; i < nfw; i += NT) fidx[i] = g.perm[p0 + i];
-#pragma unroll
-  for (int q = 0; q < AQ; q++) {
-    const int e = (tid + q * NT) * 4;
-    if (e < tot0) *(v4f32 *)(As + e) = areg[q];
+  // frame indices of a tile: lane l < 32 holds row l (clamped inside the workgroup's range: such rows are never stored)
+  auto load_fidx = [&](int ti) {
+    const int i = ti * 32 + (lane & 31);
+    return g.perm[p0 + (i < nfw ? i : nfw - 1)];
+  };
+  if (oneg) {
+    const int tot0 = njt * KH * 64;
+    for (int e = tid * 4; e < tot0; e += NT * 4) *(v4f32 *)(As + e) = *(gv4p)(Ag + e);
   }
-  for (int e = (tid + AQ * NT) * 4; e < tot0; e += NT * 4) *(v4f32 *)(As + e) = *(gv4p)(Ag + e);  // (beyond AQ pieces per thread)
-  __syncthreads();
+  int fcur = load_fidx(wv), fnext = load_fidx(wv + NW);
+  if (oneg) __syncthreads();
   APROF(0)
-  // row staging, split into issue (global loads into registers) and commit (LDS writes) so that a block's rows travel
-  // while the previous block computes.  Units are pairs of features when the rows allow 2-element loads.
+  // row staging of ONE tile by ONE wave, split into issue (global loads into registers) and commit (writes to the wave's
+  // slab).  Units are pairs of features when the rows allow 2-element loads.
   const XT *src = (const XT *)g.X;
   const bool pairs = (D & 1) == 0 && (g.ldx & 1) == 0 && ((uintptr_t)src & (2 * sizeof(XT) - 1)) == 0;
   const int UW = pairs ? D >> 1 : D;  // units per row
   const unsigned magic = f.magic;     // e / UW == umulhi(e << 8, 2^24 / UW + 1) for e < 2^16, UW <= 256
   constexpr int U = 8;
-  const bool pre = pairs && FB * UW <= NT * U;  // one round of U pair loads per thread covers a block: prefetch possible
+  const bool pre = pairs && 32 * UW <= 64 * U;  // one round of U pair loads per lane covers a tile: prefetch possible
   xt2 vp[U];
-  auto issue = [&](int b) {  // (pairs only)
-    const int nfb = (nfw - b * FB) < FB ? (nfw - b * FB) : FB, tot = nfb * UW;
-    const int *fi = fidx + b * FB;
+  // which (row, pair) of a tile lane l moves in its u-th load never changes: decomposed once
+  int ru[U], ko[U], ro[U];
 #pragma unroll
-    for (int u = 0; u < U; u++) {
-      const int e = tid + u * NT;
-      const int ec = e < tot ? e : 0;
-      const int r = (int)__umulhi((unsigned)ec << 8, magic), k = ec - r * UW;
-      vp[u] = *(const xt2 *)(src + (int64_t)fi[r] * g.ldx + 2 * k);
-    }
-  };
-  auto commit = [&](int b) {
-    const int nfb = (nfw - b * FB) < FB ? (nfw - b * FB) : FB, tot = nfb * UW;
+  for (int u = 0; u < U; u++) {
+    const int e = lane + u * 64;
+    const int ec = e < 32 * UW ? e : 0;
+    const int r = (int)__umulhi((unsigned)ec << 8, magic), k = ec - r * UW;
+    ru[u] = r;
+    ko[u] = 2 * k;
+    ro[u] = e < 32 * UW ? r * DS + 2 * k : -1;
+  }
+  auto issue = [&](int fi) {  // (pairs only) fi: the tile's frame indices, one per lane < 32
 #pragma unroll
-    for (int u = 0; u < U; u++) {
-      const int e = tid + u * NT;
-      const int r = (int)__umulhi((unsigned)e << 8, magic), k = e - r * UW;
-      if (e < tot) *(float2 *)(Xs + r * DS + 2 * k) = make_float2((float)vp[u][0], (float)vp[u][1]);
-    }
+    for (int u = 0; u < U; u++) vp[u] = *(const xt2 *)(src + (int64_t)__shfl(fi, ru[u], 64) * g.ldx + ko[u]);
   };
-  auto stage_sync = [&](int b) {  // any layout, U loads in flight per thread
-    const int nfb = (nfw - b * FB) < FB ? (nfw - b * FB) : FB, tot = nfb * UW;
-    const int *fi = fidx + b * FB;
-    for (int e0 = tid; e0 < tot; e0 += NT * U) {
+  auto commit = [&]() {
+#pragma unroll
+    for (int u = 0; u < U; u++)
+      if (ro[u] >= 0) *(float2 *)(Xw + ro[u]) = make_float2((float)vp[u][0], (float)vp[u][1]);
+  };
+  auto stage_sync = [&](int fi) {  // any layout, U loads in flight per lane
+    const int tot = 32 * UW;
+    for (int e0 = lane; e0 < tot; e0 += 64 * U) {
       xt2 wp[U];
       XT ws[U];
 #pragma unroll
       for (int u = 0; u < U; u++) {
-        const int e = e0 + u * NT;
+        const int e = e0 + u * 64;
         const int ec = e < tot ? e : 0;
         const int r = (int)__umulhi((unsigned)ec << 8, magic), k = ec - r * UW;
-        const XT *rp = src + (int64_t)fi[r] * g.ldx;
+        const XT *rp = src + (int64_t)__shfl(fi, r, 64) * g.ldx;
         if (pairs) wp[u] = *(const xt2 *)(rp + 2 * k);
         else ws[u] = rp[k];
       }
 #pragma unroll
       for (int u = 0; u < U; u++) {
-        const int e = e0 + u * NT;
+        const int e = e0 + u * 64;
         const int r = (int)__umulhi((unsigned)(e < tot ? e : 0) << 8, magic), k = e - r * UW;
         if (e < tot) {
-          if (pairs) *(float2 *)(Xs + r * DS + 2 * k) = make_float2((float)wp[u][0], (float)wp[u][1]);
-          else Xs[r * DS + k] = (float)ws[u];
+          if (pairs) *(float2 *)(Xw + r * DS + 2 * k) = make_float2((float)wp[u][0], (float)wp[u][1]);
+          else Xw[r * DS + k] = (float)ws[u];
         }
       }
     }
   };
-  if (pre) issue(0);
-  for (int b = 0; b < nblk; b++) {
-    if (pre) commit(b);
-    else stage_sync(b);
-    __syncthreads();
-    APROF(1)
-    // this wave's frame tile as the B operand: lane l carries frame l % 32, slots 2 ks + l / 32 (slot D = 1: the csq term)
-    const int nf = (nfw - b * FB) < FB ? (nfw - b * FB) : FB;
-    const int lr = wv * 32 + (lane & 31);
-    const bool ok = lr < nf;
+  if (pre) issue(fcur);
+  // a tile's label store is held back until the NEXT tile's loads have been issued: stores count in vmcnt, and every wait
+  // for a load (the prefetched rows, the frame indices) otherwise also waits for the acknowledgement of a store issued a
+  // moment ago (~6 k cycles per tile)
+  int pend_fr = -1, pend_lab = 0;
+  auto flush = [&]() {
+    if (pend_fr >= 0) g.labels[pend_fr] = pend_lab;
+    pend_fr = -1;
+  };
+  for (int b = 0; b < NB; b++) {
+    const int ti = wv + NW * b;
+    const int nft = nfw - ti * 32;   // frames of this tile (<= 0: the wave only keeps the barriers of a grouped sweep)
+    const bool live = nft > 0;       // wave-uniform
     float bx[KH];
     float xn2 = 0.f;
-    {
-      const float *xr = Xs + (size_t)(ok ? lr : 0) * DS;
+    const int lr = lane & 31;
+    const bool ok = lr < nft;
+    if (live) {
+      if (pre) commit();
+      else stage_sync(fcur);
+      APROF(4)
+      // this wave's frame tile as the B operand: lane l carries frame l % 32, slots 2 ks + l / 32 (slot D = 1: the csq term)
+      const float *xr = Xw + (size_t)lr * DS;
 #pragma unroll
       for (int ks = 0; ks < KH; ks++) {
         const int k = 2 * ks + (lane >> 5);
@@ -591,9 +599,13 @@ __global__ __launch_bounds__(FILT_NW(KS) * 64) __attribute__((amdgpu_waves_per_e
       }
       xn2 += __shfl_xor(xn2, 32, 64);
     }
-    __syncthreads();  // every wave holds its operand: the staging buffer may take the next block
-    if (pre && b + 1 < nblk) issue(b + 1);
-    APROF(2)
+    APROF(5)
+    const int fthis = fcur;
+    fcur = fnext;
+    if (b + 2 < NB) fnext = load_fidx(ti + 2 * NW);
+    if (pre && b + 1 < NB && nfw - (ti + NW) * 32 > 0) issue(fcur);  // the next tile's rows travel during this sweep
+    flush();  // (the youngest memory operation before the sweep: acknowledged long before the next wait)
+    APROF(1)
     // ranking state: largest s, largest s among the other centroids, and where the largest was found: Jt = centroid
     // tile, Jr = accumulator register (both only change when the maximum does)
     float M1 = ninf, M2 = ninf;
@@ -619,14 +631,14 @@ __global__ __launch_bounds__(FILT_NW(KS) * 64) __attribute__((amdgpu_waves_per_e
     };
     for (int g0 = 0; g0 < njt; g0 += G) {
       const int gc = (njt - g0) < G ? (njt - g0) : G;
-      if (!oneg && (g0 || b)) {
+      if (!oneg) {
         __syncthreads();  // the previous group's fragments are no longer read
         const gcfp srcA = Ag + (size_t)g0 * KH * 64;
         const int tot = gc * KH * 64;
         for (int e = tid * 4; e < tot; e += NT * 4) *(v4f32 *)(As + e) = *(gv4p)(srcA + e);
         __syncthreads();
       }
-      APROF(3)
+      if (!live) continue;
       // two accumulators in rotation: the matrix unit works on tile t + 1 while the vector unit ranks tile t
       const float *ap = As + lane;
       v16f32 accA = chain(ap), accB;
@@ -638,7 +650,8 @@ __global__ __launch_bounds__(FILT_NW(KS) * 64) __attribute__((amdgpu_waves_per_e
         if (b1) rank(accB, g0 + jt + 1);
       }
     }
-    APROF(4)
+    APROF(2)
+    if (!live) continue;
     // -> centroid index; then lanes l and l ^ 32 (same frame, the other half of each tile's centroids) are merged
     int j = Jt * 32 + 8 * (Jr >> 2) + 4 * (lane >> 5) + (Jr & 3);
     {
@@ -650,18 +663,18 @@ __global__ __launch_bounds__(FILT_NW(KS) * 64) __attribute__((amdgpu_waves_per_e
       M1 = take ? M1o : M1;
     }
     if (lane < 32 && ok) {
-      const float cmax = __builtin_sqrtf(__uint_as_float(f.bnd[2 * s])) * 1.000001f, csqmax = __uint_as_float(f.bnd[2 * s + 1]);
-      const float thr = f.c1 * __builtin_sqrtf(xn2) * 1.000001f * cmax + f.c2 * csqmax + 1e-30f;
-      const int fr = fidx[b * FB + lr];
+      const float thr = thr_x * __builtin_sqrtf(xn2) + thr_0;
       if (2.f * (M1 - M2) > thr) {  // d = -2 s
-        g.labels[fr] = sd.off + j;  // stratified_clustering.py:195
+        pend_fr = fthis;
+        pend_lab = sd.off + j;  // stratified_clustering.py:195
       } else {  // (also every NaN: the comparison is false)
         const unsigned long long pos = atomicAdd(&f.cnt2[s], 1ull);
-        f.perm2[g.base[s] + (long long)pos] = fr;
+        f.perm2[base_s + (long long)pos] = fthis;
       }
     }
-    APROF(5)
+    APROF(3)
   }
+  flush();
   APROF_END
 }
 
@@ -702,7 +715,8 @@ template <typename XT, int KS>
 static int launch_filter_ks(hamsm_ctx *c, SortArgs g, FiltArgs f, int KH) {
   constexpr int NW = FILT_NW(KS), FB = 32 * NW;
   const int FRB = g.FRB;  // FB * blocks per workgroup
-  size_t lds = sizeof(float) * (size_t)FB * f.DS + sizeof(int) * FRB + sizeof(float) * (size_t)f.G * KH * 64 + 16;
+  size_t lds = sizeof(float) * (size_t)FB * f.DS + sizeof(float) * (size_t)f.G * KH * 64 + 16;
+  (void)FRB;
   if (lds > 160 * 1024) return hamsm_fail(c, HAMSM_ENOTSUP, "assign filter needs %zu B of LDS", lds);
   const void *kern = KH == 2 * KS ? (const void *)k_assign_filter<XT, KS, 0> : (const void *)k_assign_filter<XT, KS, 1>;
   HIPCHK(c, hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -762,7 +776,7 @@ static int launch_sorted(hamsm_ctx *c, const AssignArgs &a) {
     NB = NB < 1 ? 1 : (NB > c->filter_nb ? c->filter_nb : NB);
     g.FRB = FB * NB;
     // centroid tiles per LDS group: frames + fragments within filter_lds_kb
-    long long room = (long long)c->filter_lds_kb * 1024 - (long long)(sizeof(float) * (size_t)FB * f.DS + sizeof(int) * g.FRB);
+    long long room = (long long)c->filter_lds_kb * 1024 - (long long)(sizeof(float) * (size_t)FB * f.DS);
     f.G = room > 0 ? (int)(room / (long long)(sizeof(float) * KH * 64)) : 0;
     f.G = f.G < 2 ? 2 : (f.G > tmax ? (tmax > 0 ? tmax : 1) : f.G & ~1);
   }

@@ -5,7 +5,7 @@ lib = ctypes.CDLL('msm_we_amd/csrc/_var/lib_assignprof' + os.environ.get('PROF_V
 for waves in sys.argv[1:] or ['72']:
     os.environ['HAMSM_FILTER_LDS_KB'] = waves
     h = _abi.Hamsm(lib=lib)
-    D, S, K, n = 30, int(os.environ.get('PROF_S', '4')), 250, 2_000_000
+    D, S, K, n = 30, int(os.environ.get('PROF_S', '4')), 250, int(os.environ.get("PROF_N", "2000000"))
     h.set_geometry(D, 1, S)
     b = np.arange(S + 1, dtype=np.float32); b[-1] = np.inf
     h.set_mapper_rectilinear([b]); h.set_bounds([[-np.inf, 0.05]], [[S - 0.05, np.inf]])
@@ -20,7 +20,7 @@ for waves in sys.argv[1:] or ['72']:
     h.assign(dX, 0, D, dp, n, dl); h.sync()
     out = np.zeros(8, dtype=np.uint64); lib.hamsm_debug_assign_profile(out.ctypes.data_as(ctypes.c_void_p))
     d = (out - out0).astype(float); nb = d[7]
-    names = ['perm + barrier', 'gather rows + barrier', 'B operand', 'A group copy + barriers', 'MFMA + ranking', 'merge + store']
+    names = ['prologue', 'perm load + next issue', 'MFMA sweep + ranking', 'merge + store', 'commit (wait rows, LDS writes)', 'B operand']
     tot = d[:6].sum()
     print(f'filter LDS budget {waves} KB: {nb:.0f} workgroups, {tot/nb:.0f} cycles per workgroup (thread 0 view)')
     for nm, v in zip(names, d[:6]):

@@ -16,6 +16,7 @@ __global__ __launch_bounds__(512) void k(float *out, unsigned long long *cyc, in
   __syncthreads();
   if (wv < 4) {
     if (MODE == 0) return;
+    unsigned long long tm0 = __builtin_amdgcn_s_memtime();
     v16f32 a0, a1;
     for (int r = 0; r < 16; r++) a0[r] = a1[r] = 0.f;
     float x = tid * 1e-3f, y = 1.0f - tid * 1e-4f;
@@ -23,13 +24,39 @@ __global__ __launch_bounds__(512) void k(float *out, unsigned long long *cyc, in
       if (MODE == 1) {
         a0 = __builtin_amdgcn_mfma_f32_32x32x2f32(x, y, a0, 0, 0, 0);
         a0 = __builtin_amdgcn_mfma_f32_32x32x2f32(y, x, a0, 0, 0, 0);
-      } else {
+      } else if (MODE == 2) {
         a0 = __builtin_amdgcn_mfma_f32_32x32x2f32(x, y, a0, 0, 0, 0);
         a1 = __builtin_amdgcn_mfma_f32_32x32x2f32(y, x, a1, 0, 0, 0);
+      } else if (MODE == 3) {  // yield the issue port while the MFMA runs
+        a0 = __builtin_amdgcn_mfma_f32_32x32x2f32(x, y, a0, 0, 0, 0);
+        __builtin_amdgcn_s_sleep(1);
+        a1 = __builtin_amdgcn_mfma_f32_32x32x2f32(y, x, a1, 0, 0, 0);
+        __builtin_amdgcn_s_sleep(1);
+      } else if (MODE == 4) {  // s_nop padding instead (s_nop n = n + 1 quad-cycles)
+        a0 = __builtin_amdgcn_mfma_f32_32x32x2f32(x, y, a0, 0, 0, 0);
+        asm volatile("s_nop 15");
+        a1 = __builtin_amdgcn_mfma_f32_32x32x2f32(y, x, a1, 0, 0, 0);
+        asm volatile("s_nop 15");
+      } else if (MODE == 5) {
+        a0 = __builtin_amdgcn_mfma_f32_32x32x2f32(x, y, a0, 0, 0, 0);
+        asm volatile("s_nop 13");
+        a1 = __builtin_amdgcn_mfma_f32_32x32x2f32(y, x, a1, 0, 0, 0);
+        asm volatile("s_nop 13");
+      } else if (MODE == 6) {
+        a0 = __builtin_amdgcn_mfma_f32_32x32x2f32(x, y, a0, 0, 0, 0);
+        asm volatile("s_nop 11");
+        a1 = __builtin_amdgcn_mfma_f32_32x32x2f32(y, x, a1, 0, 0, 0);
+        asm volatile("s_nop 11");
+      } else {  // 7
+        a0 = __builtin_amdgcn_mfma_f32_32x32x2f32(x, y, a0, 0, 0, 0);
+        asm volatile("s_nop 7");
+        a1 = __builtin_amdgcn_mfma_f32_32x32x2f32(y, x, a1, 0, 0, 0);
+        asm volatile("s_nop 7");
       }
     }
     float s = 0;
     for (int r = 0; r < 16; r++) s += a0[r] + a1[r];
+    if ((tid & 63) == 0 && blockIdx.x == 0) cyc[4 + wv] = __builtin_amdgcn_s_memtime() - tm0;
     out[blockIdx.x * 512 + tid] = s;
   } else {
     if (PRIO) __builtin_amdgcn_s_setprio(3);
@@ -51,14 +78,15 @@ __global__ __launch_bounds__(512) void k(float *out, unsigned long long *cyc, in
 template <int MODE, int PRIO>
 void run(const char *tag) {
   float *out;
-  unsigned long long *cyc, h[4];
+  unsigned long long *cyc, h[8];
   hipMalloc(&out, 256 * 512 * 4);
-  hipMalloc(&cyc, 32);
+  hipMalloc(&cyc, 64);
   const int iters = 2000;
   hipLaunchKernelGGL((k<MODE, PRIO>), dim3(256), dim3(512), 0, 0, out, cyc, iters);
   hipDeviceSynchronize();
-  hipMemcpy(h, cyc, 32, hipMemcpyDeviceToHost);
-  printf("%-44s latency-loop waves: %.0f cycles per iteration\n", tag, (double)h[0] / iters);
+  hipMemcpy(h, cyc, 64, hipMemcpyDeviceToHost);
+  printf("%-44s latency-loop waves: %.0f cycles per iteration; MFMA waves: %.1f cycles per MFMA\n", tag, (double)h[0] / iters,
+         MODE ? (double)h[4] / (iters * 16.0) : 0.0);
   hipFree(out);
   hipFree(cyc);
 }
@@ -69,5 +97,10 @@ int main() {
   run<2, 0>("beside TWO alternating MFMA chains per wave");
   run<1, 1>("same, latency waves at s_setprio 3");
   run<2, 1>("two chains, latency waves at s_setprio 3");
+  run<3, 0>("two chains, s_sleep 1 after every MFMA");
+  run<4, 0>("two chains, s_nop 15 after every MFMA");
+  run<5, 0>("two chains, s_nop 13 after every MFMA");
+  run<6, 0>("two chains, s_nop 11 after every MFMA");
+  run<7, 0>("two chains, s_nop 7 after every MFMA");
   return 0;
 }
