@@ -114,7 +114,11 @@ int hamsm_featurize_dist(hamsm_ctx *ctx, const void *d_coords, int c_dtype, int6
  * label = Kfit+1 if target(p) else Kfit if basis(p) else off(s) + argmin_j ||x - c_j||^2 over
  * the centroids of s = remap[bin(p)].  d_seen (nullable): int32[2][n_strata], [0][s]=1 when a
  * target frame was seen in stratum s, [1][s]=1 for basis (target_bins / basis_bins sets, :159-169).
- * ldx = row stride of d_X in elements (>= D).                                                    */
+ * ldx = row stride of d_X in elements (>= D).
+ * The argmin is the one of the arithmetic contract above (f64 fma chains, first index on ties).  The HIP library reaches
+ * it in two passes: the centroids are ranked in f32 on the matrix unit and a label is final only when a proven bound on
+ * the f32-vs-f64 difference separates the two best candidates; every other frame (near ties, NaN / inf, f32 overflow) is
+ * decided by the exact f64 kernel.  HAMSM_ASSIGN_FILTER=0 in the environment runs the exact kernel alone.        */
 int hamsm_assign(hamsm_ctx *ctx, const void *d_X, int x_dtype, int64_t ldx, const double *d_pcoord,
                  int64_t n, int32_t *d_labels, int32_t *d_seen);
 /* Same, host buffers in and out (the drop-in `predict(coords)` call of B3).                      */
