@@ -17,11 +17,12 @@ for waves in sys.argv[1:] or ['72']:
     z = np.zeros(8, dtype=np.uint64)
     h.assign(dX, 0, D, dp, n, dl); h.sync()
     out0 = np.zeros(8, dtype=np.uint64); lib.hamsm_debug_assign_profile(out0.ctypes.data_as(ctypes.c_void_p))
-    h.assign(dX, 0, D, dp, n, dl); h.sync()
+    import time; h.sync(); tw = time.perf_counter(); h.assign(dX, 0, D, dp, n, dl); h.sync(); tw = time.perf_counter() - tw
     out = np.zeros(8, dtype=np.uint64); lib.hamsm_debug_assign_profile(out.ctypes.data_as(ctypes.c_void_p))
     d = (out - out0).astype(float); nb = d[7]
     names = ['prologue', 'perm load + next issue', 'MFMA sweep + ranking', 'merge + store', 'commit (wait rows, LDS writes)', 'B operand']
     tot = d[:6].sum()
+    print(f'wall {tw*1e3:.3f} ms for the call; if one workgroup per CU at a time: {tot/256/tw/1e9:.2f} G stamps/s per CU')
     print(f'filter LDS budget {waves} KB: {nb:.0f} workgroups, {tot/nb:.0f} cycles per workgroup (thread 0 view)')
     for nm, v in zip(names, d[:6]):
         print(f'  {nm:24s} {v/nb:9.0f}  {100*v/tot:5.1f}%')
