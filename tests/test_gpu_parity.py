@@ -157,6 +157,38 @@ def test_assign_filter_certifies_or_defers(hip_h, oracle_h, D, K_s, dtype):
     assert np.array_equal(ref, dup)
 
 
+@pytest.mark.parametrize("seed", range(int(__import__("os").environ.get("HAMSM_FUZZ_SEEDS", "16"))))
+def test_assign_random_shapes_hip_equals_oracle(hip_h, oracle_h, seed):
+    """seeded fuzz of hamsm_assign over feature width, cluster counts, strata, dtype, data scale, clustered vs diffuse frames:
+    the labels of the two-pass path equal the oracle's"""
+    rng = np.random.default_rng(7000 + seed)
+    D = int(rng.integers(1, 129))
+    S = int(rng.integers(1, 6))
+    K_s = [int(rng.integers(1, 300)) for _ in range(S)]
+    dtype = np.float32 if rng.integers(2) else np.float64
+    scale = float(10.0 ** rng.integers(-6, 7))
+    n = int(rng.integers(1, 3000))
+    outs = []
+    for h in (oracle_h, hip_h):
+        r = np.random.default_rng(seed)
+        cents = _setup(h, D, S, K_s, r)
+        for s_, Cm in enumerate(cents):   # rescale the model (and make a few centroids near-duplicates)
+            Cm = Cm * scale
+            if len(Cm) > 3:
+                Cm[1] = Cm[0] * (1 + 1e-7)
+                Cm[3] = Cm[2]
+            h.set_centroids(s_, Cm, csq=np.einsum("ij,ij->i", Cm, Cm))
+            cents[s_] = Cm
+        X, p = _frames(r, n, D, S, dtype)
+        X = (X * scale).astype(dtype)
+        near = r.integers(0, n, n // 3)   # a third of the frames sit on top of centroids of their stratum (+ noise)
+        for i in near:
+            Cm = cents[min(int(p[i, 0]), S - 1)]
+            X[i] = (Cm[r.integers(len(Cm))] * (1 + 1e-4 * r.normal())).astype(dtype)
+        outs.append(h.predict_host(X, p))
+    assert np.array_equal(outs[0], outs[1]), (D, S, K_s, dtype, scale, n)
+
+
 def test_seeding_in_gram_groups(hip_lib, oracle_h, monkeypatch):
     """k-means++ of several strata with room for only two Gram matrices at a time (HAMSM_SEED_G_MB): the strata are seeded in
     groups that share the slots; centroids equal the oracle's"""

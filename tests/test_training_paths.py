@@ -1,5 +1,7 @@
 """The planned (no host round trips) and stepwise training paths must agree, including when the plan's
 prediction "no random reassignment" is wrong and the run falls back (few modes, many centroids)."""
+import os
+
 import numpy as np
 import pytest
 
@@ -141,7 +143,7 @@ def test_many_strata_take_the_descriptor_table_path(hip_h, oracle_h):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("seed", range(24))
+@pytest.mark.parametrize("seed", range(int(os.environ.get("HAMSM_FUZZ_SEEDS", "24"))))  # (a longer soak: HAMSM_FUZZ_SEEDS=300)
 def test_random_configurations_hip_equals_oracle(hip_h, oracle_h, seed):
     """seeded fuzz over the shape space (strata, clusters, features, batch sizes, weights, skewed data): the whole
     training pass and the discretization on the HIP library equal the oracle's bit for bit"""
