@@ -67,7 +67,7 @@ extern "C" int hamsm_classify(hamsm_ctx *c, const double *p, int64_t n, int appl
 
 #ifdef ASSIGN_PROFILE
 __device__ unsigned long long g_assign_prof[8];
-#define APROF_INIT unsigned long long t_last_ = __builtin_amdgcn_s_memtime(), t_acc_[6] = {0, 0, 0, 0, 0, 0};
+#define APROF_INIT unsigned long long t_last_ = __builtin_amdgcn_s_memtime(), t_acc_[6] = {0, 0, 0, 0, 0, 0}, w0_ = wall_clock64();
 #define APROF(i)                                             \
   {                                                          \
     unsigned long long t_ = __builtin_amdgcn_s_memtime();    \
@@ -77,6 +77,7 @@ __device__ unsigned long long g_assign_prof[8];
 #define APROF_END                                                                        \
   if (threadIdx.x == 0) {                                                                \
     for (int i_ = 0; i_ < 6; i_++) atomicAdd(&g_assign_prof[i_], t_acc_[i_]);            \
+    atomicAdd(&g_assign_prof[6], (unsigned long long)(wall_clock64() - w0_)); /* 100 MHz ticks: the core clock */ \
     atomicAdd(&g_assign_prof[7], 1ull);                                                  \
   }
 extern "C" int hamsm_debug_assign_profile(unsigned long long *h_out) {

@@ -22,6 +22,7 @@ for waves in sys.argv[1:] or ['72']:
     d = (out - out0).astype(float); nb = d[7]
     names = ['prologue', 'perm load + next issue', 'MFMA sweep + ranking', 'merge + store', 'commit (wait rows, LDS writes)', 'B operand']
     tot = d[:6].sum()
+    if d[6] > 0: print(f'core clock while the workgroups ran: {tot / (d[6] * 10e-9) / 1e9:.2f} GHz (s_memtime cycles per 100 MHz wall tick)')
     print(f'wall {tw*1e3:.3f} ms for the call; if one workgroup per CU at a time: {tot/256/tw/1e9:.2f} G stamps/s per CU')
     print(f'filter LDS budget {waves} KB: {nb:.0f} workgroups, {tot/nb:.0f} cycles per workgroup (thread 0 view)')
     for nm, v in zip(names, d[:6]):
