@@ -125,13 +125,80 @@ __global__ __launch_bounds__(BR_T) void k_build_rows(const int32_t *__restrict__
   }
 }
 
+// The same lists by ONE WAVE per call, for calls of up to BR_WAVE_MAX rows (a training call is one WE iteration: ~10^4):
+// 64 rows at a time, positions from ballots (mbcnt = set bits below this lane), no LDS, no barrier; S + 1 coalesced sweeps.
+#define BR_WAVE_MAX 65536
+__global__ __launch_bounds__(256) void k_build_rows_wave(const int32_t *__restrict__ bin_all, const long long *__restrict__ range,
+                                                         const int32_t *__restrict__ cr_all, int S, long long G,
+                                                         int32_t *__restrict__ rank_all, int32_t *__restrict__ rows_all,
+                                                         long long *__restrict__ counts, long long *__restrict__ starts) {
+  const long long g = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (g >= G) return;
+  const int lane = threadIdx.x & 63;
+  const long long g0 = range[2 * g];
+  const int n = (int)(range[2 * g + 1] - g0);
+  const int32_t *bin = bin_all + g0, *cr = cr_all + (size_t)g * S;
+  int32_t *rank = rank_all + g0, *rows = rows_all + g0;
+  auto below = [&](unsigned long long m) {  // set bits of m below this lane
+    return (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+  };
+  constexpr int U = 8;  // chunks whose loads are in flight together (one chunk at a time exposes a memory round trip each)
+  int base = 0;
+  for (int c0 = 0; c0 < n; c0 += 64 * U) {
+    int bb[U];
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+      const int i = c0 + u * 64 + lane;
+      bb[u] = bin[i < n ? i : n - 1];
+    }
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+      const int i = c0 + u * 64 + lane;
+      const bool v = i < n && bb[u] >= 0;
+      const unsigned long long m = __ballot(v);
+      if (v) rank[i] = base + below(m);
+      base += __builtin_popcountll(m);
+    }
+  }
+  int start = 0;
+  for (int s = 0; s < S; s++) {
+    int cnt = 0;
+    for (int c0 = 0; c0 < n; c0 += 64 * U) {
+      int bb[U], rk[U];
+#pragma unroll
+      for (int u = 0; u < U; u++) {
+        const int i = c0 + u * 64 + lane;
+        bb[u] = bin[i < n ? i : n - 1];
+        rk[u] = rank[i < n ? i : n - 1];  // (written by this same lane in the first sweep; unused for filtered rows)
+      }
+      int sl[U];
+#pragma unroll
+      for (int u = 0; u < U; u++) sl[u] = cr[bb[u] >= 0 ? bb[u] : 0];
+#pragma unroll
+      for (int u = 0; u < U; u++) {
+        const int i = c0 + u * 64 + lane;
+        const bool v = i < n && bb[u] >= 0 && sl[u] == s;
+        const unsigned long long m = __ballot(v);
+        if (v) rows[start + cnt + below(m)] = rk[u];
+        cnt += __builtin_popcountll(m);
+      }
+    }
+    if (lane == 0) {
+      counts[(size_t)g * S + s] = cnt;
+      starts[(size_t)g * S + s] = g0 + start;
+    }
+    start += cnt;
+  }
+}
+
 extern "C" int hamsm_train_build_rows_batched(hamsm_ctx *c, const int32_t *bin, int64_t G, const int64_t *h_range,
                                               const int32_t *h_cr, int32_t *rows, int64_t *h_counts, int64_t *h_starts) {
   if (G <= 0) return HAMSM_OK;
-  int64_t hi = 0;
+  int64_t hi = 0, nmax = 0;
   for (int64_t g = 0; g < G; g++) {
     if (h_range[2 * g + 1] < h_range[2 * g]) return hamsm_fail(c, HAMSM_EINVAL, "bad group range");
     if (h_range[2 * g + 1] > hi) hi = h_range[2 * g + 1];
+    if (h_range[2 * g + 1] - h_range[2 * g] > nmax) nmax = h_range[2 * g + 1] - h_range[2 * g];
   }
   size_t off = 0;
   auto take = [&](size_t bytes) {
@@ -148,9 +215,14 @@ extern "C" int hamsm_train_build_rows_batched(hamsm_ctx *c, const int32_t *bin, 
   HIPCHK(c, hipMemcpyAsync(b + o_rg, h_range, sizeof(long long) * 2 * G, hipMemcpyHostToDevice, c->stream));
   HIPCHK(c, hipMemcpyAsync(b + o_cr, h_cr, sizeof(int32_t) * G * c->S, hipMemcpyHostToDevice, c->stream));
   hamsm_timer_begin(c);
-  hipLaunchKernelGGL(k_build_rows, dim3((unsigned)G), dim3(BR_T), 0, c->stream, bin, (const long long *)(b + o_rg),
-                     (const int32_t *)(b + o_cr), c->S, (int32_t *)(b + o_rank), rows, (long long *)(b + o_cnt),
-                     (long long *)(b + o_st));
+  if (nmax <= BR_WAVE_MAX)
+    hipLaunchKernelGGL(k_build_rows_wave, dim3((unsigned)((G + 3) / 4)), dim3(256), 0, c->stream, bin, (const long long *)(b + o_rg),
+                       (const int32_t *)(b + o_cr), c->S, (long long)G, (int32_t *)(b + o_rank), rows, (long long *)(b + o_cnt),
+                       (long long *)(b + o_st));
+  else
+    hipLaunchKernelGGL(k_build_rows, dim3((unsigned)G), dim3(BR_T), 0, c->stream, bin, (const long long *)(b + o_rg),
+                       (const int32_t *)(b + o_cr), c->S, (int32_t *)(b + o_rank), rows, (long long *)(b + o_cnt),
+                       (long long *)(b + o_st));
   hamsm_timer_end(c, ST_PREPASS);
   HIPCHK(c, hipGetLastError());
   HIPCHK(c, hipMemcpyAsync(h_counts, b + o_cnt, sizeof(int64_t) * G * c->S, hipMemcpyDeviceToHost, c->stream));
