@@ -447,6 +447,63 @@ __global__ __launch_bounds__(64) void k_pack_f32(const StratumDev *__restrict__ 
   }
 }
 
+// ---- bf16 x 3: the same ranking on the bf16 matrix unit (16x the f32 MFMA rate) ----------------------------------------
+// An f32 value is the EXACT sum of three bf16 pieces (8 + 8 + 8 significant bits, truncation splits), so
+//   x . c = sum_k (x1 + x2 + x3)(c1 + c2 + c3)  ~  x1 c1 + x1 c2 + x2 c1 + x1 c3 + x2 c2 + x3 c1   (products exact in f32)
+// with the dropped terms x2 c3 + x3 c2 + x3 c3 below 2^-20 |x_k| |c_k|.  One v_mfma_f32_32x32x16_bf16 handles 16 feature
+// slots of a 32 x 32 tile; six of them per 16 slots replace eight v_mfma_f32_32x32x2_f32 at a quarter of the pipe time.
+// The certainty bound grows accordingly (FiltArgs c1 / c2): dropped terms, 102 accumulations per 16 slots.
+typedef __bf16 v8bf16 __attribute__((ext_vector_type(8)));
+typedef unsigned v4u32 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void bf16_split3(float v, unsigned &p1, unsigned &p2, unsigned &p3) {
+  // pieces as the upper halves of f32 patterns (returned in the UPPER 16 bits).  Non-finite values stay in piece 1.
+  const bool fin = __builtin_fabsf(v) <= 3.4028234664e38f;
+  const unsigned b0 = __float_as_uint(v);
+  p1 = fin ? (b0 & 0xffff0000u) : (b0 | ((b0 & 0x007fffffu) ? 0x00400000u : 0u)) & 0xffff0000u;
+  const float r1 = fin ? v - __uint_as_float(p1) : 0.f;
+  p2 = __float_as_uint(r1) & 0xffff0000u;
+  const float r2 = r1 - __uint_as_float(p2);
+  p3 = __float_as_uint(r2) & 0xffff0000u;
+}
+
+// A fragments for the bf16 form: [tile][KB][3 pieces][64 lanes][8 bf16]; lane l = centroid l % 32, slots 16 m + 8 (l / 32) + i
+__global__ __launch_bounds__(64) void k_pack_bf16(const StratumDev *__restrict__ table, const FiltDev *__restrict__ ft,
+                                                  unsigned *__restrict__ bnd, int KS, int KB, int D) {
+  const int s = blockIdx.y, jt = blockIdx.x;
+  const StratumDev sd = table[s];
+  if (jt * 32 >= sd.K) return;
+  const int lane = threadIdx.x, row = lane & 31, h = lane >> 5;
+  const int j = jt * 32 + row;
+  const bool live = j < sd.K;
+  unsigned *A = (unsigned *)ft[s].A;
+  const double cs = live ? sd.csq[j] : 0.0;
+  double n2 = 0.0;
+  for (int m = 0; m < KB; m++) {
+    unsigned w[3][4];
+    for (int i = 0; i < 8; i++) {
+      const int k = 16 * m + 8 * h + i;
+      double v = 0.0;
+      if (live && k < D) v = sd.Bpack[((size_t)(j >> 4) * KS + (k >> 2)) * 64 + (k & 3) * 16 + (j & 15)];
+      n2 += v * v;
+      float vf = (float)v;
+      if (k == D) vf = live ? (float)(-0.5 * cs) : -3.0e38f;  // (a row past K never ranks first; finite: 0 x it stays 0)
+      unsigned p[3];
+      bf16_split3(vf, p[0], p[1], p[2]);
+      for (int q = 0; q < 3; q++) {
+        if (i & 1) w[q][i >> 1] |= p[q];
+        else w[q][i >> 1] = p[q] >> 16;
+      }
+    }
+    for (int q = 0; q < 3; q++)
+      for (int z = 0; z < 4; z++) A[((((size_t)jt * KB + m) * 3 + q) * 64 + lane) * 4 + z] = w[q][z];
+  }
+  n2 += __shfl_xor(n2, 32, 64);
+  if (h == 0 && live) {
+    atomicMax(&bnd[2 * s], __float_as_uint((float)n2 * 1.000001f));
+    atomicMax(&bnd[2 * s + 1], __float_as_uint(__builtin_fabsf((float)cs) * 1.000001f));
+  }
+}
+
 __global__ void k_sort_offsets2(SortArgs g, const unsigned long long *cnt2, long long *end2, long long *blkbase2) {
   if (threadIdx.x == 0 && blockIdx.x == 0) {
     long long k = 0;
@@ -468,9 +525,11 @@ __global__ void k_sort_offsets2(SortArgs g, const unsigned long long *cnt2, long
 // registers.  Why it matters: a wave that streams MFMAs monopolises its SIMD's issue port (tools/mfma_corun.hip), so
 // every instruction between two sweeps is dead time for the matrix unit unless it is short -- barriers made it long.
 // (More centroid tiles than fit in LDS: the fragment groups are exchanged between barriers; the waves then walk in step.)
-template <typename XT, int KS, int AUGX>
-__global__ __launch_bounds__(FILT_NW(KS) * 64) __attribute__((amdgpu_waves_per_eu(KS <= 8 ? 3 : 2))) void k_assign_filter(SortArgs g, FiltArgs f) {
+template <typename XT, int KS, int AUGX, bool BF>
+__global__ __launch_bounds__(FILT_NW(KS) * 64) __attribute__((amdgpu_waves_per_eu(BF ? 2 : (KS <= 8 ? 3 : 2)))) void k_assign_filter(SortArgs g, FiltArgs f) {
   constexpr int NW = FILT_NW(KS), NT = NW * 64, KH = 2 * KS + AUGX;
+  constexpr int KB = (4 * KS + 13) / 16 + AUGX;            // bf16 form: blocks of 16 feature slots (features, csq slot, padding)
+  constexpr int TW = BF ? KB * 3 * 256 : KH * 64;         // 32-bit words of fragments per centroid tile
   APROF_INIT
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   typedef float v4f32 __attribute__((ext_vector_type(4)));
@@ -510,7 +569,7 @@ __global__ __launch_bounds__(FILT_NW(KS) * 64) __attribute__((amdgpu_waves_per_e
     return g.perm[p0 + (i < nfw ? i : nfw - 1)];
   };
   if (oneg) {
-    const int tot0 = njt * KH * 64;
+    const int tot0 = njt * TW;
     for (int e = tid * 4; e < tot0; e += NT * 4) *(v4f32 *)(As + e) = *(gv4p)(Ag + e);
   }
   int fcur = load_fidx(wv), fnext = load_fidx(wv + NW);
@@ -583,7 +642,8 @@ __global__ __launch_bounds__(FILT_NW(KS) * 64) __attribute__((amdgpu_waves_per_e
     const int ti = wv + NW * b;
     const int nft = nfw - ti * 32;   // frames of this tile (<= 0: the wave only keeps the barriers of a grouped sweep)
     const bool live = nft > 0;       // wave-uniform
-    float bx[KH];
+    float bx[BF ? 1 : KH];
+    v4u32 bp[BF ? KB : 1][3];  // bf16 form: the row's three pieces, 8 slots per block and lane
     float xn2 = 0.f;
     const int lr = lane & 31;
     const bool ok = lr < nft;
@@ -593,14 +653,39 @@ __global__ __launch_bounds__(FILT_NW(KS) * 64) __attribute__((amdgpu_waves_per_e
       APROF(4)
       // this wave's frame tile as the B operand: lane l carries frame l % 32, slots 2 ks + l / 32 (slot D = 1: the csq term)
       const float *xr = Xw + (size_t)lr * DS;
+      if constexpr (BF) {
 #pragma unroll
-      for (int ks = 0; ks < KH; ks++) {
-        const int k = 2 * ks + (lane >> 5);
-        float v = xr[k < D ? k : 0];
-        asm volatile("" : "+v"(v));  // (keeps the load unconditional: a select of a load becomes a branch per load)
-        v = k < D ? v : 0.f;
-        xn2 = __builtin_fmaf(v, v, xn2);
-        bx[ks] = k == D ? 1.f : v;
+        for (int m = 0; m < KB; m++)
+#pragma unroll
+          for (int i2 = 0; i2 < 8; i2++) {
+            const int k = 16 * m + 8 * (lane >> 5) + i2;
+            float v = xr[k < D ? k : 0];
+            asm volatile("" : "+v"(v));
+            v = k < D ? v : 0.f;
+            xn2 = __builtin_fmaf(v, v, xn2);
+            v = k == D ? 1.f : v;
+            unsigned p1, p2, p3;
+            bf16_split3(v, p1, p2, p3);
+            if (i2 & 1) {
+              bp[m][0][i2 >> 1] |= p1;
+              bp[m][1][i2 >> 1] |= p2;
+              bp[m][2][i2 >> 1] |= p3;
+            } else {
+              bp[m][0][i2 >> 1] = p1 >> 16;
+              bp[m][1][i2 >> 1] = p2 >> 16;
+              bp[m][2][i2 >> 1] = p3 >> 16;
+            }
+          }
+      } else {
+#pragma unroll
+        for (int ks = 0; ks < KH; ks++) {
+          const int k = 2 * ks + (lane >> 5);
+          float v = xr[k < D ? k : 0];
+          asm volatile("" : "+v"(v));  // (keeps the load unconditional: a select of a load becomes a branch per load)
+          v = k < D ? v : 0.f;
+          xn2 = __builtin_fmaf(v, v, xn2);
+          bx[ks] = k == D ? 1.f : v;
+        }
       }
       xn2 += __shfl_xor(xn2, 32, 64);
     }
@@ -619,8 +704,25 @@ __global__ __launch_bounds__(FILT_NW(KS) * 64) __attribute__((amdgpu_waves_per_e
       v16f32 acc;
 #pragma unroll
       for (int r = 0; r < 16; r++) acc[r] = 0.f;
+      if constexpr (BF) {
+        const v4u32 *aq = (const v4u32 *)ap;  // (ap = tile base + lane * 4 words in this form)
 #pragma unroll
-      for (int ks = 0; ks < KH; ks++) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ap[ks * 64], bx[ks], acc, 0, 0, 0);
+        for (int m = 0; m < KB; m++) {
+          const v8bf16 c1 = __builtin_bit_cast(v8bf16, aq[(m * 3 + 0) * 64]), c2 = __builtin_bit_cast(v8bf16, aq[(m * 3 + 1) * 64]),
+                       c3 = __builtin_bit_cast(v8bf16, aq[(m * 3 + 2) * 64]);
+          const v8bf16 x1 = __builtin_bit_cast(v8bf16, bp[m][0]), x2 = __builtin_bit_cast(v8bf16, bp[m][1]),
+                       x3 = __builtin_bit_cast(v8bf16, bp[m][2]);
+          acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(c1, x3, acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(c2, x2, acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(c3, x1, acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(c1, x2, acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(c2, x1, acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(c1, x1, acc, 0, 0, 0);
+        }
+      } else {
+#pragma unroll
+        for (int ks = 0; ks < KH; ks++) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ap[ks * 64], bx[ks], acc, 0, 0, 0);
+      }
       return acc;
     };
     auto rank = [&](const v16f32 &acc, int tile) {
@@ -638,20 +740,20 @@ __global__ __launch_bounds__(FILT_NW(KS) * 64) __attribute__((amdgpu_waves_per_e
       const int gc = (njt - g0) < G ? (njt - g0) : G;
       if (!oneg) {
         __syncthreads();  // the previous group's fragments are no longer read
-        const gcfp srcA = Ag + (size_t)g0 * KH * 64;
-        const int tot = gc * KH * 64;
+        const gcfp srcA = Ag + (size_t)g0 * TW;
+        const int tot = gc * TW;
         for (int e = tid * 4; e < tot; e += NT * 4) *(v4f32 *)(As + e) = *(gv4p)(srcA + e);
         __syncthreads();
       }
       if (!live) continue;
       // two accumulators in rotation: the matrix unit works on tile t + 1 while the vector unit ranks tile t
-      const float *ap = As + lane;
+      const float *ap = As + (BF ? lane * 4 : lane);
       v16f32 accA = chain(ap), accB;
       for (int jt = 0; jt < gc; jt += 2) {
         const bool b1 = jt + 1 < gc, b2 = jt + 2 < gc;  // wave-uniform
-        if (b1) accB = chain(ap + (size_t)(jt + 1) * KH * 64);
+        if (b1) accB = chain(ap + (size_t)(jt + 1) * TW);
         rank(accA, g0 + jt);
-        if (b2) accA = chain(ap + (size_t)(jt + 2) * KH * 64);
+        if (b2) accA = chain(ap + (size_t)(jt + 2) * TW);
         if (b1) rank(accB, g0 + jt + 1);
       }
     }
@@ -717,13 +819,13 @@ static int launch_sorted_ks(hamsm_ctx *c, SortArgs g) {
 }
 
 template <typename XT, int KS>
-static int launch_filter_ks(hamsm_ctx *c, SortArgs g, FiltArgs f, int KH) {
+static int launch_filter_ks(hamsm_ctx *c, SortArgs g, FiltArgs f, int TW, int aug, bool bf) {
   constexpr int NW = FILT_NW(KS), FB = 32 * NW;
   const int FRB = g.FRB;  // FB * blocks per workgroup
-  size_t lds = sizeof(float) * (size_t)FB * f.DS + sizeof(float) * (size_t)f.G * KH * 64 + 16;
-  (void)FRB;
+  size_t lds = sizeof(float) * (size_t)FB * f.DS + sizeof(float) * (size_t)f.G * TW + 16;
   if (lds > 160 * 1024) return hamsm_fail(c, HAMSM_ENOTSUP, "assign filter needs %zu B of LDS", lds);
-  const void *kern = KH == 2 * KS ? (const void *)k_assign_filter<XT, KS, 0> : (const void *)k_assign_filter<XT, KS, 1>;
+  const void *kern = bf ? (aug ? (const void *)k_assign_filter<XT, KS, 1, true> : (const void *)k_assign_filter<XT, KS, 0, true>)
+                        : (aug ? (const void *)k_assign_filter<XT, KS, 1, false> : (const void *)k_assign_filter<XT, KS, 0, false>);
   HIPCHK(c, hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   unsigned grid = (unsigned)((g.n + FRB - 1) / FRB + c->S);  // upper bound; surplus workgroups exit at once
   void *args[] = {(void *)&g, (void *)&f};
@@ -747,6 +849,10 @@ static int launch_sorted(hamsm_ctx *c, const AssignArgs &a) {
   // filter: f32 fragments of the centroids, undecided-frame lists and the second set of block offsets
   size_t o_perm2 = 0, o_zero = 0, o_end2 = 0, o_blk2 = 0, o_ft = 0, o_A = 0;
   const int KH = a.D == 4 * KS ? 2 * KS + 1 : 2 * KS;  // feature slots of the f32 fragments, in pairs: the features, the csq slot, padding
+  const bool bf = c->filter_bf16 != 0 && KS <= 8;        // bf16 x 3 form of the ranking pass (D <= 32)
+  const int KBmin = (4 * KS + 13) / 16, KB = (a.D + 16) / 16;  // bf16 form: blocks of 16 slots
+  const int aug = bf ? KB - KBmin : KH - 2 * KS;
+  const int TW = bf ? KB * 3 * 256 : KH * 64;            // 32-bit words of fragments per centroid tile
   std::vector<size_t> tile0(S + 1, 0);
   int tmax = 0;
   if (filt) {
@@ -760,7 +866,7 @@ static int launch_sorted(hamsm_ctx *c, const AssignArgs &a) {
     o_end2 = take(sizeof(long long) * S);
     o_blk2 = take(sizeof(long long) * (S + 1));
     o_ft = take(sizeof(FiltDev) * S);
-    o_A = take(sizeof(float) * tile0[S] * KH * 64);
+    o_A = take(sizeof(float) * tile0[S] * TW);
   }
   int rc = hamsm_ensure_scratch2(c, off);
   if (rc) return rc;
@@ -781,8 +887,9 @@ static int launch_sorted(hamsm_ctx *c, const AssignArgs &a) {
     NB = NB < 1 ? 1 : (NB > c->filter_nb ? c->filter_nb : NB);
     g.FRB = FB * NB;
     // centroid tiles per LDS group: frames + fragments within filter_lds_kb
-    long long room = (long long)c->filter_lds_kb * 1024 - (long long)(sizeof(float) * (size_t)FB * f.DS);
-    f.G = room > 0 ? (int)(room / (long long)(sizeof(float) * KH * 64)) : 0;
+    // (the bf16 form's fragments are 1.5x larger: one workgroup per CU, up to 112 KB)
+    long long room = (long long)(bf && c->filter_lds_kb < 112 ? 112 : c->filter_lds_kb) * 1024 - (long long)(sizeof(float) * (size_t)FB * f.DS);
+    f.G = room > 0 ? (int)(room / (long long)(sizeof(float) * TW)) : 0;
     f.G = f.G < 2 ? 2 : (f.G > tmax ? (tmax > 0 ? tmax : 1) : f.G & ~1);
   }
   HIPCHK(c, hipMemsetAsync(b + o_cnt, 0, sizeof(long long) * S, c->stream));
@@ -797,7 +904,7 @@ static int launch_sorted(hamsm_ctx *c, const AssignArgs &a) {
   if (filt) {
     std::vector<FiltDev> ft(S);
     for (int s = 0; s < S; s++) {
-      ft[s].A = (const float *)(b + o_A) + tile0[s] * KH * 64;
+      ft[s].A = (const float *)(b + o_A) + tile0[s] * TW;
     }
     HIPCHK(c, hipMemcpyAsync(b + o_ft, ft.data(), sizeof(FiltDev) * S, hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipMemsetAsync(b + o_zero, 0, sizeof(long long) * S + sizeof(unsigned) * 2 * S, c->stream));
@@ -806,15 +913,23 @@ static int launch_sorted(hamsm_ctx *c, const AssignArgs &a) {
     f.bnd = (const unsigned *)(b + o_zero + sizeof(long long) * S);
     f.perm2 = (int32_t *)(b + o_perm2);
     f.magic = (1u << 24) / (unsigned)(((a.D & 1) == 0 && (a.ldx & 1) == 0 && ((uintptr_t)a.X & (2 * sizeof(XT) - 1)) == 0) ? a.D / 2 : a.D) + 1;
-    f.c1 = 2.02f * (float)(2 * a.D + 8) / 4194304.0f;
-    f.c2 = 2.02f * (float)(a.D + 5) / 4194304.0f;
+    if (bf) {  // per 16 slots: 6 MFMAs x (16 products + 1 accumulate) roundings, taken twice; + the dropped terms (16 u) + rounding of c (1 u)
+      f.c1 = 4.04f * (float)(17 + 204 * KB) / 16777216.0f;
+      f.c2 = 2.02f * (float)(204 * KB + 1) / 16777216.0f;
+    } else {
+      f.c1 = 2.02f * (float)(2 * a.D + 8) / 4194304.0f;
+      f.c2 = 2.02f * (float)(a.D + 5) / 4194304.0f;
+    }
     c->filter_cnt2 = f.cnt2;
-    if (tmax > 0)
+    if (tmax > 0 && bf)
+      hipLaunchKernelGGL(k_pack_bf16, dim3((unsigned)tmax, (unsigned)S), dim3(64), 0, c->stream, a.table, f.ft, (unsigned *)f.bnd, KS, KB,
+                         a.D);
+    else if (tmax > 0)
       hipLaunchKernelGGL(k_pack_f32, dim3((unsigned)tmax, (unsigned)S), dim3(64), 0, c->stream, a.table, f.ft, (unsigned *)f.bnd, KS, KH,
                          a.D);
     switch (KS) {
 #define CASE(KSV) \
-  case KSV: rc = launch_filter_ks<XT, KSV>(c, g, f, KH); break;
+  case KSV: rc = launch_filter_ks<XT, KSV>(c, g, f, TW, aug, bf); break;
       CASE(1) CASE(2) CASE(3) CASE(4) CASE(6) CASE(8) CASE(12) CASE(16) CASE(24) CASE(32)
 #undef CASE
       default: return hamsm_fail(c, HAMSM_ENOTSUP, "KS=%d", KS);
