@@ -39,6 +39,7 @@ from msm_we_amd.model import modelWE  # noqa: E402
 
 PEAK_F64_MFMA_TFLOPS = 78.6   # MI355X FP64 matrix (= vector) peak, dense (vendor figure)
 PEAK_F32_MFMA_TFLOPS = 157.3  # MI355X FP32 matrix peak, dense (MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 155 TF measured)
+PEAK_BF16_MFMA_TFLOPS = 2500.0  # MI355X BF16 matrix peak, dense (2.2 PFLOP/s measured here: csrc/tools/mfma_f32_rate.hip)
 PEAK_HBM_GBS = 8000.0         # MI355X_MICROARCH.md: 8.0 TB/s spec
 
 
@@ -456,7 +457,21 @@ def main():
     assign_avg_ms = assign_avg_ms or float("nan")  # (the CPU rehearsal has no kernel timers)
     tflops = flops / (assign_avg_ms * 1e-3) / 1e12
     K = cfg.K_s * cfg.S
-    if os.environ.get("HAMSM_ASSIGN_FILTER", "1") != "0":
+    extra = {}
+    if os.environ.get("HAMSM_ASSIGN_FILTER", "1") != "0" and os.environ.get("HAMSM_FILTER_BF16", "1") != "0" and cfg.D <= 32:
+        # every f32 product is formed as 6 bf16 products (3 x 3 pieces, the 3 smallest dropped): the roof of an algorithmic
+        # flop on this path is the bf16 MFMA peak / 6
+        peak = PEAK_BF16_MFMA_TFLOPS / 6.0
+        blocks = (cfg.D + 16) // 16
+        executed = flops * (6.0 * 16 * blocks / cfg.D) * (((cfg.K_s + 31) // 32) * 32 / cfg.K_s)
+        extra = {"bf16_mfma_peak": PEAK_BF16_MFMA_TFLOPS, "executed_bf16_TFLOPs": executed / (assign_avg_ms * 1e-3) / 1e12,
+                 "frac_of_f32_mfma_peak": tflops / PEAK_F32_MFMA_TFLOPS}
+        kernel = ("k_assign_filter (v_mfma_f32_32x32x16_bf16, f32 operands as three exact bf16 pieces) + k_assign_sorted "
+                  "(v_mfma_f64_16x16x4_f64) on the undecided frames")
+        arithmetic = ("centroids ranked on the bf16 matrix unit with f32-equivalent accuracy; a label is final only if the gap "
+                      "exceeds a proven bound on the difference to the f64 contract, otherwise the exact f64 kernel decides: "
+                      "labels identical to the f64 contract")
+    elif os.environ.get("HAMSM_ASSIGN_FILTER", "1") != "0":
         peak = PEAK_F32_MFMA_TFLOPS
         kernel = "k_assign_filter (v_mfma_f32_32x32x2_f32) + k_assign_sorted (v_mfma_f64_16x16x4_f64) on the undecided frames"
         arithmetic = ("centroids ranked in f32 on the matrix unit; a label is final only if the f32 gap exceeds a proven bound "
@@ -486,7 +501,7 @@ def main():
         "roofline": {"bound": "mfma", "achieved": tflops, "peak": peak, "unit": "TFLOP/s",
                      "frac": tflops / peak, "traffic": pmc_traffic(cfg, n_iters),
                      "kernel": kernel, "arithmetic": arithmetic,
-                     "f64_mfma_peak": PEAK_F64_MFMA_TFLOPS, "frac_of_f64_peak": tflops / PEAK_F64_MFMA_TFLOPS,
+                     "f64_mfma_peak": PEAK_F64_MFMA_TFLOPS, "frac_of_f64_peak": tflops / PEAK_F64_MFMA_TFLOPS, **extra,
                      "avg_launch_ms": assign_avg_ms, "last_launch_ms": assign_ms,
                      "algorithmic_GBps": bytes_alg / (assign_avg_ms * 1e-3) / 1e9,
                      "hbm_frac": bytes_alg / (assign_avg_ms * 1e-3) / 1e9 / PEAK_HBM_GBS},

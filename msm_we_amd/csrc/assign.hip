@@ -849,7 +849,7 @@ static int launch_sorted(hamsm_ctx *c, const AssignArgs &a) {
   // filter: f32 fragments of the centroids, undecided-frame lists and the second set of block offsets
   size_t o_perm2 = 0, o_zero = 0, o_end2 = 0, o_blk2 = 0, o_ft = 0, o_A = 0;
   const int KH = a.D == 4 * KS ? 2 * KS + 1 : 2 * KS;  // feature slots of the f32 fragments, in pairs: the features, the csq slot, padding
-  const bool bf = c->filter_bf16 != 0 && KS <= 8;        // bf16 x 3 form of the ranking pass (D <= 32)
+  const bool bf = c->filter_bf16 != 0 && KS <= 8;        // bf16 x 3 form of the ranking pass (D <= 32; measured slower at D = 64, K_s = 1250)
   const int KBmin = (4 * KS + 13) / 16, KB = (a.D + 16) / 16;  // bf16 form: blocks of 16 slots
   const int aug = bf ? KB - KBmin : KH - 2 * KS;
   const int TW = bf ? KB * 3 * 256 : KH * 64;            // 32-bit words of fragments per centroid tile
