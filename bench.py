@@ -333,9 +333,9 @@ def full_pipeline(m, cfg, seed, flux_mode):
 
 def pmc_traffic(cfg, n_iters):
     """HBM bytes per assign launch (ranking pass + exact pass) from the committed rocprofv3 PMC passes of this same workload
-    (profiles/r01_l_pmc_summary.csv: separate --pmc FETCH_SIZE / WRITE_SIZE runs; FETCH_SIZE doubled as
+    (profiles/r01_m_pmc_summary.csv: separate --pmc FETCH_SIZE / WRITE_SIZE runs; FETCH_SIZE doubled as
     MI355X_MICROARCH.md prescribes for gfx950, calibrated here on k_sort_count's 80 MB pcoord read)."""
-    path = os.path.join(ROOT, "profiles", "r01_l_pmc_summary.csv")
+    path = os.path.join(ROOT, "profiles", "r01_m_pmc_summary.csv")
     if cfg.name != "c3" or n_iters != cfg.n_iters or not os.path.exists(path):
         return None
     filt = os.environ.get("HAMSM_ASSIGN_FILTER", "1") != "0"
