@@ -116,8 +116,9 @@ int hamsm_featurize_dist(hamsm_ctx *ctx, const void *d_coords, int c_dtype, int6
  * target frame was seen in stratum s, [1][s]=1 for basis (target_bins / basis_bins sets, :159-169).
  * ldx = row stride of d_X in elements (>= D).
  * The argmin is the one of the arithmetic contract above (f64 fma chains, first index on ties).  The HIP library reaches
- * it in two passes: the centroids are ranked in f32 on the matrix unit and a label is final only when a proven bound on
- * the f32-vs-f64 difference separates the two best candidates; every other frame (near ties, NaN / inf, f32 overflow) is
+ * it in two passes: the centroids are ranked on the matrix unit in reduced precision (f32 operands as three exact bf16
+ * pieces, or plain f32) and a label is final only when a proven bound on the difference to the f64 values separates the
+ * two best candidates; every other frame (near ties, NaN / inf, f32 overflow) is
  * decided by the exact f64 kernel.  HAMSM_ASSIGN_FILTER=0 in the environment runs the exact kernel alone.        */
 int hamsm_assign(hamsm_ctx *ctx, const void *d_X, int x_dtype, int64_t ldx, const double *d_pcoord,
                  int64_t n, int32_t *d_labels, int32_t *d_seen);

@@ -13,14 +13,15 @@
 //       centroids (l>>4)+4r of each tile: csq - 2*dot and the running first-minimum are register-local, only the
 //       four lane groups and then the waves are merged (2 shuffles + one LDS round per batch of tiles).
 //   k_assign_filter (further down) : since state k the first pass over the sorted frames -- the centroids are RANKED in
-//       f32 on v_mfma_f32_32x32x2_f32 and a label is final only if a proven bound on the f32-vs-f64 difference separates
+//       reduced precision (v_mfma_f32_32x32x16_bf16 on three exact bf16 pieces per operand, or v_mfma_f32_32x32x2_f32)
+//       and a label is final only if a proven bound on the difference to the f64 values separates
 //       the two best centroids; the undecided frames are listed and k_assign_sorted (exact) decides them.
 // The dot product of a frame and a centroid is an f64 FMA chain over ascending k (the MFMA applies its four
 // k-products in order; zero padding adds exact zeros), i.e. the arithmetic contract of include/hamsm.h;
 // hamsm_selftest_mfma() checks that property of the hardware bit for bit.
 //
 // Measured on MI355X (C3: 10 M rows x 30 features, 4 strata x 250 centroids): exact kernel alone 3.5 ms = 42 TFLOP/s f64;
-// ranking pass + exact pass over the undecided 0.001 % 1.85 ms.  Earlier
+// ranking pass + exact pass over the undecided 0.002 % 1.39 ms.  Earlier
 // forms of this kernel are in the history (chunk-local buckets with L2-streamed fragments: 7.1 ms; 16-lane DPP
 // argmin: 4.8 ms) -- see DESIGN.md §5.1 for what each step bought.
 #include "common.h"
