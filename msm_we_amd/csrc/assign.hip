@@ -838,7 +838,10 @@ template <typename XT>
 static int launch_sorted(hamsm_ctx *c, const AssignArgs &a) {
   const int64_t n = a.n;
   const int S = c->S, KS = c->KS;
-  const bool filt = c->assign_filter != 0;
+  // the ranking pass is bypassed for a few calls after one in which it settled less than 3/4 of the frames (data full of
+  // near ties: both passes would then cost more than the exact one alone); the labels are the same either way
+  const bool filt = c->assign_filter != 0 && !(c->filter_skip > 0 && c->filter_skip--);
+  c->filter_ran = 0;
   size_t off = 0;
   auto take = [&](size_t bytes) {
     size_t o = off;
@@ -944,6 +947,9 @@ static int launch_sorted(hamsm_ctx *c, const AssignArgs &a) {
     g.blkbase = (long long *)(b + o_blk2);
     hipLaunchKernelGGL(k_sort_offsets2, dim3(1), dim3(64), 0, c->stream, g, f.cnt2, (long long *)(b + o_end2), (long long *)(b + o_blk2));
     HIPCHK(c, hipGetLastError());
+    if (!c->h_und) HIPCHK(c, hipHostMalloc((void **)&c->h_und, sizeof(unsigned long long) * S));
+    HIPCHK(c, hipMemcpyAsync(c->h_und, f.cnt2, sizeof(unsigned long long) * S, hipMemcpyDeviceToHost, c->stream));
+    c->filter_ran = 1;
   }
   switch (KS) {
 #define CASE(KSV) \
@@ -978,7 +984,13 @@ extern "C" int hamsm_assign(hamsm_ctx *c, const void *X, int dt, int64_t ldx, co
   rc = (dt == HAMSM_F32) ? launch_sorted<float>(c, g) : launch_sorted<double>(c, g);
   hamsm_timer_end(c, ST_ASSIGN);
   if (rc) return rc;
-  return hamsm_check_device_error(c, "assign");
+  rc = hamsm_check_device_error(c, "assign");  // (synchronises: the undecided counts have arrived too)
+  if (c->filter_ran) {
+    unsigned long long und = 0;
+    for (int s = 0; s < c->S; s++) und += c->h_und[s];
+    if (n >= 4096 && und * 4 > (unsigned long long)n) c->filter_skip = 7;
+  }
+  return rc;
 }
 
 extern "C" int hamsm_predict_host(hamsm_ctx *c, const void *X, int dt, const double *p, int64_t n, int32_t *labels,

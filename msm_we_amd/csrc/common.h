@@ -97,6 +97,9 @@ struct hamsm_ctx {
   double timers[ST_N] = {0};
   double last_ms[ST_N] = {0};
   size_t seed_g_budget = (size_t)4 << 30;  // bytes of Gram matrices resident at once (HAMSM_SEED_G_MB): 56 strata of 3072 rows
+  unsigned long long *h_und = nullptr;  // pinned [S]: undecided counts of the last filtered assign
+  int filter_skip = 0;     // calls left that bypass the ranking pass (it settled < 3/4 of the frames last time)
+  int filter_ran = 0;      // the last assign ran the ranking pass
   int filter_bf16 = 1;     // bf16 x 3 form of the ranking pass where it applies (D <= 32); HAMSM_FILTER_BF16=0: f32 form
   int filter_nb = 8;       // most frame blocks per filter workgroup (HAMSM_FILTER_NB, <= 16)
   int filter_lds_kb = 72;  // LDS budget of a filter workgroup (HAMSM_FILTER_LDS_KB)

@@ -70,6 +70,7 @@ extern "C" void hamsm_destroy(hamsm_ctx *c) {
   hipFree(c->d_bounds);
   hipFree(c->d_err);
   hipHostFree(c->h_err);
+  hipHostFree(c->h_und);
   hipFree(c->scratch);
   hipFree(c->scratch2);
   hipFree(c->flux_part);
@@ -270,6 +271,12 @@ extern "C" int hamsm_set_geometry(hamsm_ctx *c, int D, int ndim, int S) {
   if (D > 128) return hamsm_fail(c, HAMSM_ENOTSUP, "D=%d > 128 features is not supported yet", D);
   HIPCHK(c, hipSetDevice(c->device));
   HIPCHK(c, hipStreamSynchronize(c->stream));
+  c->filter_skip = 0;  // a new model: the ranking pass gets its chance again
+  c->filter_cnt2 = nullptr;
+  if (S != c->S) {
+    hipHostFree(c->h_und);
+    c->h_und = nullptr;
+  }
   if (D == c->D && ndim == c->ndim && S == c->S && (int)c->st.size() == S && c->d_remap && c->d_table) {
     // same geometry again (every cluster_coordinates call configures the context): keep the allocations, forget the
     // model -- unfitted strata, identity remap, mapper to be set anew

@@ -215,6 +215,28 @@ def test_seeding_in_gram_groups(hip_lib, oracle_h, monkeypatch):
         h.close()
 
 
+def test_assign_filter_steps_aside_on_data_full_of_ties(hip_h, oracle_h):
+    """when the ranking pass settles less than 3/4 of a (>= 4096-frame) call, the next 7 calls go straight to the exact kernel
+    (hook: -1), then it is tried again; labels equal the oracle's throughout"""
+    D, K_s, n = 12, 30, 5000
+    outs = []
+    for h in (oracle_h, hip_h):
+        rng = np.random.default_rng(33)
+        _setup(h, D, 1, K_s, rng)
+        Cm = np.repeat(rng.normal(size=(K_s, D)) * 3, 2, axis=0)      # every centroid twice: every frame an exact tie
+        h.set_centroids(0, Cm, csq=np.einsum("ij,ij->i", Cm, Cm))
+        X, p = _frames(rng, n, D, 1, np.float32)
+        labs, und = [], []
+        for _ in range(10):
+            labs.append(h.predict_host(X, p))
+            und.append(_undecided(h) if h is hip_h else None)
+        outs.append((labs, und))
+    for a, b in zip(outs[0][0], outs[1][0]):
+        assert np.array_equal(a, b)
+    und = outs[1][1]
+    assert und[0] > n // 2 and und[1:8] == [-1] * 7 and und[8] == und[0] and und[9] == -1, und
+
+
 def test_assign_filter_can_be_disabled(hip_lib, oracle_h, monkeypatch):
     """HAMSM_ASSIGN_FILTER=0 runs the exact kernel alone; same labels."""
     from msm_we_amd import _abi
