@@ -27,6 +27,21 @@ log = logging.getLogger("msm_we_amd")
 __all__ = ["AnalysisMixin", "inverse_iteration", "is_connected"]
 
 DENSE_LU_DENSITY = 0.10
+DENSE_LU_MAX_N = 6144      # states up to which a dense LAPACK factorisation (<= 300 MB, < 1 s) is preferred over a risky sparse one
+
+
+def _prefer_dense_lu(matrix, n):
+    """LAPACK getrf or SuperLU for (T^T - mu I)?  Dense when the matrix is dense anyway; for the sizes this package meets
+    (K + 2 <= ~5000) also whenever the pattern is not essentially banded: sparse LU of a cleaned haMSM with a percent of
+    long-range entries fills in catastrophically (5002 states, 1.5 % dense: SuperLU 11.7 s, getrf 0.5 s; tools/solvebench.py),
+    while a banded pattern factorises in milliseconds."""
+    if matrix.nnz > DENSE_LU_DENSITY * n * n:
+        return True
+    if n > DENSE_LU_MAX_N:
+        return False
+    coo = matrix.tocoo()
+    far = np.count_nonzero(np.abs(coo.row.astype(np.int64) - coo.col) > max(8, n // 16))
+    return far > 0.005 * max(1, matrix.nnz)
 BLAS_THREADS_MAX = 16
 
 
@@ -51,13 +66,15 @@ def _cpu_share():
     return n
 
 
-def _bounded_blas():
+def _bounded_blas(n=None):
     """OpenBLAS sizes its pool by the machine's core count (64 threads on a 256-core host): on a 16-CPU share that
     makes a 2600-state getrf 10x slower (0.49 s vs 0.045 s measured on the MI355X box; tools/lu_threads.py)."""
     try:
         from threadpoolctl import threadpool_limits
     except ImportError:
         return contextlib.nullcontext()
+    if n is not None and n <= 512:
+        return threadpool_limits(limits=1, user_api="blas")  # small matrices: waking a thread pool costs more than it saves
     return threadpool_limits(limits=max(1, min(BLAS_THREADS_MAX, _cpu_share())), user_api="blas")
 
 
@@ -83,9 +100,9 @@ def inverse_iteration(guess, matrix, mu=1):
     guess = np.asarray(guess, dtype=np.float64)
     matrix = sp.csr_matrix(matrix)
     x = None
-    if matrix.nnz > DENSE_LU_DENSITY * n * n:
+    if _prefer_dense_lu(matrix, n):
         # cleaned haMSM matrices are often 30-50 % dense: LAPACK getrf beats SuperLU there by 2-4x
-        with warnings.catch_warnings(), _bounded_blas():
+        with warnings.catch_warnings(), _bounded_blas(n):
             warnings.simplefilter("ignore", sla.LinAlgWarning)
             A = matrix.toarray().T
             A[np.diag_indices(n)] -= mu
@@ -111,7 +128,7 @@ class AnalysisMixin:
     pSS = None
     lagtime = None
     JtargetSS = None
-    dense_eig_max = 256  # states; above this the eigenvector seed comes from ARPACK on the CSR matrix
+    dense_eig_max = 128  # states; above this the eigenvector seed comes from ARPACK on the CSR matrix (300 states: 4 ms vs 190 ms)
 
     def get_Tmatrix(self):
         """`_analysis.py:23-79` on the device: row-normalise, zero rows -> self loop, target rows ->
@@ -147,7 +164,7 @@ class AnalysisMixin:
             except (spla.ArpackNoConvergence, spla.ArpackError) as e:
                 log.warning(f"ARPACK did not converge ({e}); falling back to dense eig")
         if pSS is None:
-            with _bounded_blas():
+            with _bounded_blas(n):
                 vals, vecs = np.linalg.eig(np.transpose(self.Tmatrix))
             pSS = np.real(vecs[:, np.argmax(np.real(vals))]).squeeze()
         assert not np.isclose(np.sum(pSS), 0), "Steady-state distribution sums to 0!"

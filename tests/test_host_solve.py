@@ -40,6 +40,25 @@ def test_inverse_iteration_dense_and_sparse_agree():
         np.testing.assert_allclose(x, pi, rtol=1e-8, atol=1e-14)
 
 
+def test_dense_lu_is_chosen_for_patterns_that_fill_in():
+    """banded pattern -> sparse LU; a percent of long-range entries (what cleaned haMSMs have) -> dense LU; both give the
+    stationary vector"""
+    from msm_we_amd.analysis import _prefer_dense_lu
+
+    rng = np.random.default_rng(2)
+    n = 400
+    band = sp.diags([rng.random(n - abs(k)) for k in range(-5, 6)], list(range(-5, 6))).tocsr()
+    assert not _prefer_dense_lu(band, n)
+    T = band.toarray() + (rng.random((n, n)) < 0.01) * rng.random((n, n))
+    T /= T.sum(1, keepdims=True)
+    Ts = sp.csr_matrix(T)
+    assert _prefer_dense_lu(Ts, n)
+    vals, vecs = np.linalg.eig(T.T)
+    pi = np.real(vecs[:, np.argmax(np.real(vals))])
+    pi /= pi.sum()
+    np.testing.assert_allclose(inverse_iteration(np.full(n, 1.0 / n), Ts), pi, rtol=1e-8, atol=1e-14)
+
+
 def test_cpu_share_is_sane():
     import os
     assert 1 <= _cpu_share() <= (os.cpu_count() or 1)
