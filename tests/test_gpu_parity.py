@@ -237,6 +237,26 @@ def test_assign_filter_steps_aside_on_data_full_of_ties(hip_h, oracle_h):
     assert und[0] > n // 2 and und[1:8] == [-1] * 7 and und[8] == und[0] and und[9] == -1, und
 
 
+def test_assign_f32_form_of_the_ranking_pass(hip_lib, oracle_h, monkeypatch):
+    """HAMSM_FILTER_BF16=0: the ranking pass on the f32 matrix unit also for D <= 32 (default there: bf16 x 3); same labels"""
+    from msm_we_amd import _abi
+
+    monkeypatch.setenv("HAMSM_FILTER_BF16", "0")
+    h = _abi.Hamsm(lib=hip_lib, device=0)
+    try:
+        for D, K_s in ((30, 250), (32, 33), (5, 7)):
+            labs = []
+            for hh in (oracle_h, h):
+                rng = np.random.default_rng(4)
+                _setup(hh, D, 3, K_s, rng)
+                X, p = _frames(rng, 5000, D, 3, np.float32)
+                labs.append(hh.predict_host(X, p))
+            assert np.array_equal(labs[0], labs[1])
+            assert 0 <= _undecided(h) < 250
+    finally:
+        h.close()
+
+
 def test_assign_filter_can_be_disabled(hip_lib, oracle_h, monkeypatch):
     """HAMSM_ASSIGN_FILTER=0 runs the exact kernel alone; same labels."""
     from msm_we_amd import _abi
