@@ -917,10 +917,11 @@ static int launch_sorted(hamsm_ctx *c, const AssignArgs &a) {
     f.bnd = (const unsigned *)(b + o_zero + sizeof(long long) * S);
     f.perm2 = (int32_t *)(b + o_perm2);
     f.magic = (1u << 24) / (unsigned)(((a.D & 1) == 0 && (a.ldx & 1) == 0 && ((uintptr_t)a.X & (2 * sizeof(XT) - 1)) == 0) ? a.D / 2 : a.D) + 1;
-    if (bf) {  // per 16 slots: 6 MFMAs x (16 products + 1 accumulate) roundings, taken twice; + the dropped terms (16 u) + rounding of
-               // c and of f64 frames to f32 (1 u each)
-      f.c1 = 4.04f * (float)(18 + 204 * KB) / 16777216.0f;
-      f.c2 = 2.02f * (float)(204 * KB + 1) / 16777216.0f;
+    if (bf) {  // per 16 slots: 6 MFMAs x (16 products + 1 accumulate) roundings, taken FOUR times (unit roundoff 2^-22 as in the
+               // f32 form: truncating or reordered accumulation inside the matrix unit is covered); + the dropped terms (16 u)
+               // + rounding of c and of f64 frames to f32 (1 u each)
+      f.c1 = 4.04f * (float)(18 + 408 * KB) / 16777216.0f;
+      f.c2 = 2.02f * (float)(408 * KB + 1) / 16777216.0f;
     } else {
       f.c1 = 2.02f * (float)(2 * a.D + 8) / 4194304.0f;
       f.c2 = 2.02f * (float)(a.D + 5) / 4194304.0f;
