@@ -492,6 +492,8 @@ def main():
         "scaling": "weak",
         "vs_baseline": None,
         "dtype": "f64",
+        "dtype_detail": "training, flux, statistics and the exact assignment kernel compute in f64; the assignment's ranking pass "
+                        "computes in bf16 x 3 (f32-equivalent) or f32 and only finalises labels its error bound certifies against f64",
         "data": "synthetic",
         "config": {"workload": f"{cfg.name}: {n_iters} WE iterations x {cfg.segs_per_iter} segments per GPU, "
                                f"{cfg.D} f32 features, {cfg.S} strata x {cfg.K_s} clusters (K={K}); "
