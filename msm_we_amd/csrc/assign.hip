@@ -58,6 +58,7 @@ __global__ void k_classify(MapperDev m, const double *__restrict__ p, int64_t n,
 }
 
 extern "C" int hamsm_classify(hamsm_ctx *c, const double *p, int64_t n, int apply_remap, int32_t *bin, uint8_t *flags) {
+  CTX(c);
   if (!c->have_mapper || !c->have_bounds) return hamsm_fail(c, HAMSM_EINVAL, "mapper/bounds not set");
   if (n <= 0) return HAMSM_OK;
   hipLaunchKernelGGL(k_classify, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, c->mapper, p, n, apply_remap,
@@ -906,11 +907,13 @@ static int launch_sorted(hamsm_ctx *c, const AssignArgs &a) {
   hamsm_timer_end(c, ST_OTHER);   // the three bucket passes
   hamsm_timer_begin(c);           // ... and the distance kernels proper (ST_ASSIGN, ended by the caller)
   if (filt) {
-    std::vector<FiltDev> ft(S);
+    // (staged in a buffer the ctx owns: an asynchronous copy must never read from a local that dies with this scope)
+    c->h_stage.resize(sizeof(FiltDev) * S);
+    FiltDev *ft = (FiltDev *)c->h_stage.data();
     for (int s = 0; s < S; s++) {
       ft[s].A = (const float *)(b + o_A) + tile0[s] * TW;
     }
-    HIPCHK(c, hipMemcpyAsync(b + o_ft, ft.data(), sizeof(FiltDev) * S, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(b + o_ft, ft, sizeof(FiltDev) * S, hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipMemsetAsync(b + o_zero, 0, sizeof(long long) * S + sizeof(unsigned) * 2 * S, c->stream));
     f.ft = (const FiltDev *)(b + o_ft);
     f.cnt2 = (unsigned long long *)(b + o_zero);
@@ -963,6 +966,7 @@ static int launch_sorted(hamsm_ctx *c, const AssignArgs &a) {
 
 // Not part of the product ABI (test hook): frames the last filtered hamsm_assign handed to the exact kernel.
 extern "C" long long hamsm_debug_filter_undecided(hamsm_ctx *c) {
+  CTX(c);
   if (!c->filter_cnt2) return -1;
   std::vector<unsigned long long> h(c->S);
   if (hipStreamSynchronize(c->stream) != hipSuccess) return -1;
@@ -974,6 +978,7 @@ extern "C" long long hamsm_debug_filter_undecided(hamsm_ctx *c) {
 
 extern "C" int hamsm_assign(hamsm_ctx *c, const void *X, int dt, int64_t ldx, const double *p, int64_t n, int32_t *labels,
                             int32_t *seen) {
+  CTX(c);
   if (!c->have_mapper || !c->have_bounds) return hamsm_fail(c, HAMSM_EINVAL, "mapper/bounds not set");
   if (dt != HAMSM_F32 && dt != HAMSM_F64) return hamsm_fail(c, HAMSM_EINVAL, "x_dtype");
   if (ldx < c->D) return hamsm_fail(c, HAMSM_EINVAL, "ldx < D");
@@ -996,6 +1001,7 @@ extern "C" int hamsm_assign(hamsm_ctx *c, const void *X, int dt, int64_t ldx, co
 
 extern "C" int hamsm_predict_host(hamsm_ctx *c, const void *X, int dt, const double *p, int64_t n, int32_t *labels,
                                   int32_t *seen) {
+  CTX(c);
   if (n <= 0) return HAMSM_OK;
   size_t xs = (dt == HAMSM_F32 ? 4 : 8) * (size_t)n * c->D;
   size_t ps = sizeof(double) * (size_t)n * c->ndim, ls = sizeof(int32_t) * (size_t)n, ss = sizeof(int32_t) * 2 * c->S;
@@ -1038,6 +1044,7 @@ __global__ void k_selftest(const double *A, const double *B, int KS, double *out
 // differ between the MFMA and the FMA chain, for A (16 x 4*KS) and B (4*KS x 16) given on the host.
 extern "C" int hamsm_selftest_mfma(hamsm_ctx *c, const double *hA, const double *hB, int KS, double *h_mfma,
                                    double *h_chain) {
+  CTX(c);
   size_t na = sizeof(double) * 16 * KS * 4;
   int rc = hamsm_ensure_scratch(c, 2 * na + 2 * 256 * sizeof(double));
   if (rc) return rc;

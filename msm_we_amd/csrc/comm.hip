@@ -24,26 +24,37 @@ extern "C" int hamsm_comm_unique_id(char *id128) {
 }
 
 extern "C" int hamsm_comm_init(hamsm_ctx *c, int nranks, int rank, const char *id128) {
+  CTX(c);
   if (nranks < 1 || rank < 0 || rank >= nranks) return hamsm_fail(c, HAMSM_EINVAL, "bad rank %d/%d", rank, nranks);
   HIPCHK(c, hipSetDevice(c->device));
-  c->nranks = nranks;
-  c->rank = rank;
-  if (nranks == 1 && !id128) return HAMSM_OK;
+  if (c->comm) return hamsm_fail(c, HAMSM_EINVAL, "comm_init: a communicator exists (hamsm_comm_destroy first)");
+  if (nranks == 1 && !id128) {
+    c->nranks = 1;
+    c->rank = 0;
+    return HAMSM_OK;
+  }
   if (!id128) return hamsm_fail(c, HAMSM_EINVAL, "comm_init: unique id missing");
   // a 1-rank communicator is legal and keeps every collective below on the RCCL path (used by the GPU tests)
   ncclUniqueId id;
   memcpy(&id, id128, 128);
   ncclComm_t comm;
+  // nranks / rank are published only with a live communicator: a failed init leaves the ctx a 1-rank context
+  // whose collectives are no-ops, never "nranks > 1 with a null comm"
   NCCLCHK(c, ncclCommInitRank(&comm, nranks, id, rank));
   c->comm = (void *)comm;
+  c->nranks = nranks;
+  c->rank = rank;
   return HAMSM_OK;
 }
 
 extern "C" int hamsm_comm_destroy(hamsm_ctx *c) {
-  if (c && c->comm) {
+  CTX(c);
+  if (c->comm) {
     ncclCommDestroy((ncclComm_t)c->comm);
     c->comm = nullptr;
   }
+  c->nranks = 1;
+  c->rank = 0;
   return HAMSM_OK;
 }
 
@@ -54,12 +65,25 @@ static int allreduce(hamsm_ctx *c, void *buf, int64_t count, ncclDataType_t dt, 
   return HAMSM_OK;
 }
 
-extern "C" int hamsm_allreduce_sum_f64(hamsm_ctx *c, double *b, int64_t n) { return allreduce(c, b, n, ncclDouble, ncclSum); }
-extern "C" int hamsm_allreduce_min_f64(hamsm_ctx *c, double *b, int64_t n) { return allreduce(c, b, n, ncclDouble, ncclMin); }
-extern "C" int hamsm_allreduce_max_f64(hamsm_ctx *c, double *b, int64_t n) { return allreduce(c, b, n, ncclDouble, ncclMax); }
-extern "C" int hamsm_allreduce_sum_i64(hamsm_ctx *c, int64_t *b, int64_t n) { return allreduce(c, b, n, ncclInt64, ncclSum); }
+extern "C" int hamsm_allreduce_sum_f64(hamsm_ctx *c, double *b, int64_t n) {
+  CTX(c);
+  return allreduce(c, b, n, ncclDouble, ncclSum);
+}
+extern "C" int hamsm_allreduce_min_f64(hamsm_ctx *c, double *b, int64_t n) {
+  CTX(c);
+  return allreduce(c, b, n, ncclDouble, ncclMin);
+}
+extern "C" int hamsm_allreduce_max_f64(hamsm_ctx *c, double *b, int64_t n) {
+  CTX(c);
+  return allreduce(c, b, n, ncclDouble, ncclMax);
+}
+extern "C" int hamsm_allreduce_sum_i64(hamsm_ctx *c, int64_t *b, int64_t n) {
+  CTX(c);
+  return allreduce(c, b, n, ncclInt64, ncclSum);
+}
 
 extern "C" int hamsm_bcast(hamsm_ctx *c, void *b, size_t bytes, int root) {
+  CTX(c);
   if (bytes == 0 || (c->nranks == 1 && !c->comm)) return HAMSM_OK;
   if (!c->comm) return hamsm_fail(c, HAMSM_EINVAL, "comm not initialised");
   NCCLCHK(c, ncclBroadcast(b, b, bytes, ncclChar, root, (ncclComm_t)c->comm, c->stream));
@@ -68,6 +92,7 @@ extern "C" int hamsm_bcast(hamsm_ctx *c, void *b, size_t bytes, int root) {
 
 // centroids, counts, ||c||^2 and remap of every stratum, root -> all (exact-mode training: SURVEY §7 hard part 3)
 extern "C" int hamsm_bcast_model(hamsm_ctx *c, int root) {
+  CTX(c);
   if (c->nranks == 1 && !c->comm) return HAMSM_OK;
   if (!c->comm) return hamsm_fail(c, HAMSM_EINVAL, "comm not initialised");
   const int S = c->S;

@@ -52,7 +52,11 @@ struct Stratum {
 
 enum { ST_ASSIGN = 0, ST_FLUX, ST_STATS, ST_SEED, ST_STEP, ST_REASSIGN, ST_PREPASS, ST_OTHER, ST_N };
 
+#define HAMSM_CTX_LIVE 0x68614d534d686970ull  // "haMSMhip"
+#define HAMSM_CTX_DEAD 0xdeadc0de0badc7c7ull
+
 struct hamsm_ctx {
+  uint64_t magic = 0;  // HAMSM_CTX_LIVE between hamsm_create and hamsm_destroy (the struct is never returned to the heap)
   char err[512];
   int device = 0;
   hipStream_t stream = nullptr;
@@ -85,6 +89,7 @@ struct hamsm_ctx {
   double *flux_part = nullptr;  // per-XCD partial flux matrices (flux.hip)
   size_t flux_part_bytes = 0;
   int flux_xcd = 1;             // HAMSM_FLUX_XCD=0: one matrix, device-scope atomics
+  std::vector<char> h_stage;  // host staging for small asynchronous H2D copies (lives as long as the ctx)
   void *h_pinned = nullptr;  // small pinned staging buffer
   size_t h_pinned_bytes = 0;
   struct EvPair {
@@ -112,6 +117,14 @@ struct hamsm_ctx {
 };
 
 int hamsm_fail(hamsm_ctx *c, int code, const char *fmt, ...);
+// every entry point starts with CTX(c): the handle must be one hamsm_create returned and hamsm_destroy has not seen
+// (looked up in a registry before it is dereferenced: a stale or foreign handle is an error, never a wild access)
+int hamsm_ctx_check(hamsm_ctx *c, const char *fn);
+#define CTX(c)                                   \
+  do {                                           \
+    int rc_ = hamsm_ctx_check((c), __func__);    \
+    if (rc_) return rc_;                         \
+  } while (0)
 
 #define HIPCHK(c, call)                                                                              \
   do {                                                                                               \

@@ -1,7 +1,43 @@
 // ctx.hip -- lifecycle, device memory, model state (mapper, bounds, remap, centroids).
 #include <stdlib.h>
 
+#include <mutex>
+#include <unordered_set>
+
 #include "common.h"
+
+// ---- handle registry ------------------------------------------------------------------------------
+// hamsm_destroy releases everything a context owns but never returns the struct itself to the heap: a handle stays
+// recognisable (HAMSM_CTX_DEAD) for the life of the process, so a stale wrapper -- a second destroy, a buffer freed
+// after its context -- gets HAMSM_EINVAL instead of acting on whatever the allocator placed at that address next.
+static std::mutex g_reg_mu;
+static std::unordered_set<const hamsm_ctx *> &registry() {
+  static std::unordered_set<const hamsm_ctx *> *r = new std::unordered_set<const hamsm_ctx *>();  // never destructed
+  return *r;
+}
+static thread_local char g_stale_msg[160];
+
+static bool ctx_known(const hamsm_ctx *c) {
+  std::lock_guard<std::mutex> lk(g_reg_mu);
+  return registry().count(c) != 0;
+}
+
+int hamsm_ctx_check(hamsm_ctx *c, const char *fn) {
+  if (!c) return HAMSM_EINVAL;
+  if (!ctx_known(c)) {
+    snprintf(g_stale_msg, sizeof g_stale_msg, "%s: %p is not a hamsm context of this library", fn, (void *)c);
+    return HAMSM_EINVAL;
+  }
+  if (c->magic == HAMSM_CTX_DEAD) {
+    snprintf(g_stale_msg, sizeof g_stale_msg, "%s: stale handle %p (context was destroyed)", fn, (void *)c);
+    return HAMSM_EINVAL;
+  }
+  if (c->magic != HAMSM_CTX_LIVE) {
+    snprintf(g_stale_msg, sizeof g_stale_msg, "%s: context %p OVERWRITTEN (magic %llx)", fn, (void *)c, (unsigned long long)c->magic);
+    return HAMSM_EINVAL;
+  }
+  return HAMSM_OK;
+}
 
 int hamsm_fail(hamsm_ctx *c, int code, const char *fmt, ...) {
   if (c) {
@@ -34,11 +70,18 @@ extern "C" int hamsm_create(int device, hamsm_ctx **out) {
       hipMalloc((void **)&c->d_err, 4 * sizeof(int)) != hipSuccess ||
       hipHostMalloc((void **)&c->h_err, 4 * sizeof(int)) != hipSuccess) {
     // no GPU, no product: the caller gets an error, never a CPU path
-    delete c;
+    if (c->stream) hipStreamDestroy(c->stream);
+    if (c->d_err) hipFree(c->d_err);
+    delete c;  // (never registered: no handle was handed out)
     return HAMSM_EDEVICE;
   }
   hipMemsetAsync(c->d_err, 0, 4 * sizeof(int), c->stream);
   hipStreamSynchronize(c->stream);
+  c->magic = HAMSM_CTX_LIVE;
+  {
+    std::lock_guard<std::mutex> lk(g_reg_mu);
+    registry().insert(c);
+  }
   *out = c;
   return HAMSM_OK;
 }
@@ -49,6 +92,7 @@ static void free_strata(hamsm_ctx *c) {
     hipFree(t.csq);
     hipFree(t.counts);
     hipFree(t.Bpack);
+    t.C = t.csq = t.counts = t.Bpack = nullptr;
   }
   c->st.clear();
   hipFree(c->d_table);
@@ -60,12 +104,20 @@ static void free_strata(hamsm_ctx *c) {
 extern "C" int hamsm_comm_destroy(hamsm_ctx *c);
 static void blk_cache_flush(hamsm_ctx *c);
 
+template <typename T>
+static void release(T &container) {
+  T().swap(container);
+}
+
 extern "C" void hamsm_destroy(hamsm_ctx *c) {
-  if (!c) return;
+  if (!c || !ctx_known(c) || c->magic != HAMSM_CTX_LIVE) return;  // foreign or already destroyed: nothing is freed twice
   hipSetDevice(c->device);
   hipStreamSynchronize(c->stream);
+  for (int i = 0; i < 3; i++)
+    if (c->side_stream[i]) hipStreamSynchronize(c->side_stream[i]);
   hamsm_comm_destroy(c);
   blk_cache_flush(c);
+  for (auto &kv : c->blk_live) hipFree(kv.first);  // device memory dies with its context
   free_strata(c);
   hipFree(c->d_bounds);
   hipFree(c->d_err);
@@ -86,10 +138,35 @@ extern "C" void hamsm_destroy(hamsm_ctx *c) {
   }
   if (c->ev_fork) hipEventDestroy(c->ev_fork);
   hipStreamDestroy(c->stream);
-  delete c;
+  // the struct stays (see the registry note): drop what it owns on the heap, null every pointer, mark it dead
+  release(c->blk_live);
+  release(c->blk_cache);
+  release(c->h_bounds);
+  release(c->st);
+  release(c->ev_pending);
+  release(c->ev_free);
+  c->d_bounds = nullptr;
+  c->d_err = c->h_err = nullptr;
+  c->h_und = nullptr;
+  c->scratch = c->scratch2 = nullptr;
+  c->scratch_bytes = c->scratch2_bytes = 0;
+  c->flux_part = nullptr;
+  c->h_pinned = nullptr;
+  c->stream = nullptr;
+  for (int i = 0; i < 3; i++) {
+    c->side_stream[i] = nullptr;
+    c->ev_join[i] = nullptr;
+  }
+  c->ev_fork = nullptr;
+  c->have_mapper = c->have_bounds = false;
+  c->magic = HAMSM_CTX_DEAD;
 }
 
-extern "C" const char *hamsm_last_error(hamsm_ctx *c) { return c ? c->err : "null ctx"; }
+extern "C" const char *hamsm_last_error(hamsm_ctx *c) {
+  if (!c) return "null ctx";
+  if (!ctx_known(c) || c->magic != HAMSM_CTX_LIVE) return g_stale_msg[0] ? g_stale_msg : "stale or foreign ctx handle";
+  return c->err;
+}
 
 // ---- memory -------------------------------------------------------------------------------------
 static const size_t BLK_CACHE_MAX = (size_t)8 << 30;  // bytes kept for reuse (of 288 GB)
@@ -103,6 +180,7 @@ static void blk_cache_flush(hamsm_ctx *c) {
 }
 
 extern "C" int hamsm_malloc(hamsm_ctx *c, size_t bytes, void **out) {
+  CTX(c);
   HIPCHK(c, hipSetDevice(c->device));
   const size_t want = ((bytes ? bytes : 1) + 255) & ~(size_t)255;
   auto it = c->blk_cache.lower_bound(want);
@@ -123,6 +201,7 @@ extern "C" int hamsm_malloc(hamsm_ctx *c, size_t bytes, void **out) {
   return HAMSM_OK;
 }
 extern "C" int hamsm_free(hamsm_ctx *c, void *p) {
+  CTX(c);
   if (!p) return HAMSM_OK;
   auto it = c->blk_live.find(p);
   if (it == c->blk_live.end()) return hamsm_fail(c, HAMSM_EINVAL, "hamsm_free: %p was not returned by hamsm_malloc", p);
@@ -138,20 +217,24 @@ extern "C" int hamsm_free(hamsm_ctx *c, void *p) {
   return HAMSM_OK;
 }
 extern "C" int hamsm_memcpy_h2d(hamsm_ctx *c, void *d, const void *h, size_t n) {
+  CTX(c);
   HIPCHK(c, hipMemcpyAsync(d, h, n, hipMemcpyHostToDevice, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));  // the host buffer is the caller's: it may be reused on return
   return HAMSM_OK;
 }
 extern "C" int hamsm_memcpy_d2h(hamsm_ctx *c, void *h, const void *d, size_t n) {
+  CTX(c);
   HIPCHK(c, hipMemcpyAsync(h, d, n, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
   return HAMSM_OK;
 }
 extern "C" int hamsm_memset(hamsm_ctx *c, void *d, int b, size_t n) {
+  CTX(c);
   HIPCHK(c, hipMemsetAsync(d, b, n, c->stream));
   return HAMSM_OK;
 }
 extern "C" int hamsm_sync(hamsm_ctx *c) {
+  CTX(c);
   HIPCHK(c, hipStreamSynchronize(c->stream));
   return hamsm_check_device_error(c, "sync");
 }
@@ -251,6 +334,7 @@ void hamsm_timer_end(hamsm_ctx *c, int stage) {
 }
 
 extern "C" int hamsm_timers(hamsm_ctx *c, double *out, int reset) {
+  CTX(c);
   timers_resolve(c, true);
   for (int i = 0; i < ST_N; i++) out[i] = c->timers[i];
   if (reset)
@@ -258,6 +342,7 @@ extern "C" int hamsm_timers(hamsm_ctx *c, double *out, int reset) {
   return HAMSM_OK;
 }
 extern "C" int hamsm_last_kernel_ms(hamsm_ctx *c, int stage, double *ms) {
+  CTX(c);
   if (stage < 0 || stage >= ST_N) return hamsm_fail(c, HAMSM_EINVAL, "bad stage");
   timers_resolve(c, true);
   *ms = c->last_ms[stage];
@@ -266,6 +351,7 @@ extern "C" int hamsm_last_kernel_ms(hamsm_ctx *c, int stage, double *ms) {
 
 // ---- model state --------------------------------------------------------------------------------
 extern "C" int hamsm_set_geometry(hamsm_ctx *c, int D, int ndim, int S) {
+  CTX(c);
   if (D < 1 || ndim < 1 || ndim > HAMSM_MAX_NDIM || S < 1 || S > HAMSM_MAX_STRATA)
     return hamsm_fail(c, HAMSM_EINVAL, "bad geometry D=%d ndim=%d S=%d", D, ndim, S);
   if (D > 128) return hamsm_fail(c, HAMSM_ENOTSUP, "D=%d > 128 features is not supported yet", D);
@@ -318,6 +404,7 @@ extern "C" int hamsm_set_geometry(hamsm_ctx *c, int D, int ndim, int S) {
 }
 
 extern "C" int hamsm_set_mapper_rectilinear(hamsm_ctx *c, const int32_t *nb, const float *b) {
+  CTX(c);
   if (c->st.empty()) return hamsm_fail(c, HAMSM_EINVAL, "set_geometry first");
   long nbins = 1;
   int tot = 0;
@@ -337,6 +424,10 @@ extern "C" int hamsm_set_mapper_rectilinear(hamsm_ctx *c, const int32_t *nb, con
   }
   HIPCHK(c, hipStreamSynchronize(c->stream));
   hipFree(c->d_bounds);
+  c->d_bounds = nullptr;
+  c->mapper.bounds = nullptr;
+  c->have_mapper = false;
+  c->h_bounds.clear();
   HIPCHK(c, hipMalloc((void **)&c->d_bounds, sizeof(float) * tot));
   HIPCHK(c, hipMemcpy(c->d_bounds, b, sizeof(float) * tot, hipMemcpyHostToDevice));
   c->h_bounds.assign(b, b + tot);
@@ -346,6 +437,7 @@ extern "C" int hamsm_set_mapper_rectilinear(hamsm_ctx *c, const int32_t *nb, con
 }
 
 extern "C" int hamsm_set_remap(hamsm_ctx *c, const int32_t *r) {
+  CTX(c);
   if (c->st.empty()) return hamsm_fail(c, HAMSM_EINVAL, "set_geometry first");
   for (int s = 0; s < c->S; s++)
     if (r[s] < 0 || r[s] >= c->S) return hamsm_fail(c, HAMSM_EINVAL, "remap[%d]=%d out of range", s, r[s]);
@@ -355,6 +447,7 @@ extern "C" int hamsm_set_remap(hamsm_ctx *c, const int32_t *r) {
 }
 
 extern "C" int hamsm_set_bounds(hamsm_ctx *c, const double *basis, const double *target) {
+  CTX(c);
   if (c->st.empty()) return hamsm_fail(c, HAMSM_EINVAL, "set_geometry first");
   for (int d = 0; d < c->ndim; d++) {
     c->mapper.basis[d][0] = basis[2 * d];
@@ -376,6 +469,10 @@ int hamsm_stratum_reserve(hamsm_ctx *c, int s, int K) {
   hipFree(t.csq);
   hipFree(t.counts);
   hipFree(t.Bpack);
+  t.C = t.csq = t.counts = t.Bpack = nullptr;  // a failed hipMalloc below must not leave dangling pointers behind
+  t.Kcap = 0;
+  t.K = 0;
+  c->table_dirty = true;
   int cap = kpad(K);
   HIPCHK(c, hipMalloc((void **)&t.C, sizeof(double) * (size_t)cap * c->D));
   HIPCHK(c, hipMalloc((void **)&t.csq, sizeof(double) * cap));
@@ -417,6 +514,7 @@ int hamsm_pack_stratum(hamsm_ctx *c, int s, const double *d_csq_in) {
 }
 
 extern "C" int hamsm_set_centroids(hamsm_ctx *c, int s, int K, const double *C, const double *csq, const double *counts) {
+  CTX(c);
   if (c->st.empty() || s < 0 || s >= c->S || K < 0) return hamsm_fail(c, HAMSM_EINVAL, "bad stratum/K");
   HIPCHK(c, hipSetDevice(c->device));
   Stratum &t = c->st[s];
@@ -445,6 +543,7 @@ extern "C" int hamsm_set_centroids(hamsm_ctx *c, int s, int K, const double *C, 
 }
 
 extern "C" int hamsm_get_centroids(hamsm_ctx *c, int s, double *C, double *counts, double *csq) {
+  CTX(c);
   if (c->st.empty() || s < 0 || s >= c->S) return hamsm_fail(c, HAMSM_EINVAL, "bad stratum");
   Stratum &t = c->st[s];
   if (t.K == 0) return HAMSM_OK;
@@ -456,11 +555,13 @@ extern "C" int hamsm_get_centroids(hamsm_ctx *c, int s, double *C, double *count
 }
 
 extern "C" int hamsm_num_centroids(hamsm_ctx *c, int s) {
+  CTX(c);
   if (c->st.empty() || s < 0 || s >= c->S) return hamsm_fail(c, HAMSM_EINVAL, "bad stratum");
   return c->st[s].K;
 }
 
 extern "C" int hamsm_get_counts(hamsm_ctx *c, int s, double *counts) {
+  CTX(c);
   if (c->st.empty() || s < 0 || s >= c->S) return hamsm_fail(c, HAMSM_EINVAL, "bad stratum");
   Stratum &t = c->st[s];
   if (t.K == 0) return HAMSM_OK;

@@ -79,6 +79,7 @@ int hamsm_flux_sorted(hamsm_ctx *c, const MapperDev &m, const FluxArgs &g, const
 extern "C" int hamsm_flux_accumulate(hamsm_ctx *c, const int32_t *pa, const int32_t *ch, const double *p0, const double *p1,
                                      const double *w, int64_t n, int K, double *F, int mode, const int64_t *d_offs,
                                      int64_t n_iters) {
+  CTX(c);
   if (!c->have_bounds) return hamsm_fail(c, HAMSM_EINVAL, "bounds not set");
   if (n <= 0) return HAMSM_OK;
   int64_t i0 = 0;
@@ -123,6 +124,7 @@ __global__ void k_scale(double *F, int64_t n, double div) {
 }
 
 extern "C" int hamsm_scale(hamsm_ctx *c, double *F, int64_t count, double div) {
+  CTX(c);
   if (count <= 0) return HAMSM_OK;
   hipLaunchKernelGGL(k_scale, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, c->stream, F, count, div);
   HIPCHK(c, hipGetLastError());
@@ -220,6 +222,7 @@ __global__ void k_stats_fin(const unsigned long long *kmin, const unsigned long 
 
 extern "C" int hamsm_cluster_stats(hamsm_ctx *c, const int32_t *lab, const double *p, int64_t n, int ns, double *sum,
                                    double *mn, double *mx, int64_t *cnt) {
+  CTX(c);
   if (n <= 0) return HAMSM_OK;
   int rc = hamsm_ensure_scratch(c, sizeof(unsigned long long) * 2 * (size_t)ns);
   if (rc) return rc;
@@ -309,6 +312,7 @@ __global__ void k_tfill(const double *F, int ns, const int32_t *basis, int nb, c
 
 extern "C" int hamsm_tmatrix_csr(hamsm_ctx *c, const double *F, int ns, const int32_t *basis, int nb, const int32_t *target,
                                  int nt, int64_t *indptr, int32_t *indices, double *data, int64_t cap, int64_t *nnz_out) {
+  CTX(c);
   if (ns <= 0) return hamsm_fail(c, HAMSM_EINVAL, "nstates");
   size_t o_rs = 0, o_nz = o_rs + sizeof(double) * ns, o_ip = o_nz + sizeof(int64_t) * ns,
          o_bt = o_ip + sizeof(int64_t) * (ns + 1), o_end = o_bt + sizeof(int32_t) * (nb + nt + 2);

@@ -136,6 +136,7 @@ static int launch_project(hamsm_ctx *c, const XT *X, int64_t ldx, int64_t n, int
 
 extern "C" int hamsm_project(hamsm_ctx *c, const void *X, int dt, int64_t ldx, int64_t n, int Draw, const double *h_mean,
                              const double *h_W, int d, const double *h_scale, double *Y) {
+  CTX(c);
   if (Draw < 1 || d < 1 || !h_W || ldx < Draw) return hamsm_fail(c, HAMSM_EINVAL, "bad projection shape (%d x %d, ldx %lld)", d, Draw, (long long)ldx);
   if (dt != HAMSM_F32 && dt != HAMSM_F64) return hamsm_fail(c, HAMSM_EINVAL, "bad x_dtype");
   if (n <= 0) return HAMSM_OK;
@@ -200,6 +201,7 @@ __global__ __launch_bounds__(256) void k_featurize_dist(const CT *__restrict__ c
 
 extern "C" int hamsm_featurize_dist(hamsm_ctx *c, const void *coords, int dt, int64_t ldc, int64_t n, int n_atoms,
                                     const int32_t *h_idx, int n_sel, const float *h_ref, double *X, int64_t ldx) {
+  CTX(c);
   if (dt != HAMSM_F32 && dt != HAMSM_F64) return hamsm_fail(c, HAMSM_EINVAL, "bad c_dtype");
   if (n_atoms < 1 || n_sel < 1 || !h_idx || !h_ref || ldc < 3 * (int64_t)n_atoms || ldx < n_sel)
     return hamsm_fail(c, HAMSM_EINVAL, "bad featurizer shape");

@@ -50,6 +50,7 @@ __global__ void k_prepass(MapperDev m, const double *__restrict__ p, const int64
 
 extern "C" int hamsm_train_prepass(hamsm_ctx *c, const double *p, int64_t n, const int64_t *h_offs, int64_t n_iters,
                                    int32_t *bin, int64_t *h_hist) {
+  CTX(c);
   (void)n;
   if (!c->have_mapper || !c->have_bounds) return hamsm_fail(c, HAMSM_EINVAL, "mapper/bounds not set");
   if (n_iters <= 0) return HAMSM_OK;
@@ -193,6 +194,7 @@ __global__ __launch_bounds__(256) void k_build_rows_wave(const int32_t *__restri
 
 extern "C" int hamsm_train_build_rows_batched(hamsm_ctx *c, const int32_t *bin, int64_t G, const int64_t *h_range,
                                               const int32_t *h_cr, int32_t *rows, int64_t *h_counts, int64_t *h_starts) {
+  CTX(c);
   if (G <= 0) return HAMSM_OK;
   int64_t hi = 0, nmax = 0;
   for (int64_t g = 0; g < G; g++) {
@@ -233,6 +235,7 @@ extern "C" int hamsm_train_build_rows_batched(hamsm_ctx *c, const int32_t *bin, 
 
 extern "C" int hamsm_train_build_rows(hamsm_ctx *c, const int32_t *bin, int64_t n, const int32_t *h_cr, int32_t *rows,
                                       int64_t *h_counts, int64_t *h_starts) {
+  CTX(c);
   if (n <= 0) {
     for (int s = 0; s < c->S; s++) h_counts[s] = h_starts[s] = 0;
     return HAMSM_OK;
@@ -784,6 +787,7 @@ extern "C" int hamsm_kmeans_seed_multi(hamsm_ctx *c, int n_items, const int32_t 
                                        const int64_t *h_x_off, const int32_t *d_rows, const int64_t *h_rows_off,
                                        const int64_t *h_n_b, const double *d_w, const int64_t *h_sub, const int64_t *h_n_sub,
                                        const int32_t *h_K, const int64_t *h_first, const double *h_u, const int32_t *h_L) {
+  CTX(c);
   if (n_items <= 0) return HAMSM_OK;
   if (c->st.empty()) return hamsm_fail(c, HAMSM_EINVAL, "set_geometry first");
   const int D = c->D;
@@ -925,6 +929,7 @@ extern "C" int hamsm_kmeans_seed_multi(hamsm_ctx *c, int n_items, const int32_t 
 extern "C" int hamsm_kmeans_seed(hamsm_ctx *c, int s, const void *X, int dt, int64_t ldx, const int32_t *rows, int64_t n_b,
                                  const double *wf, const int64_t *h_sub, int64_t n_sub, int K, int64_t first,
                                  const double *h_u, int L, int64_t *h_chosen) {
+  CTX(c);
   int32_t st = s, k = K, l = L;
   int64_t zero = 0, nb = n_b, ns = h_sub ? n_sub : 0, f = first;
   int rc = hamsm_kmeans_seed_multi(c, 1, &st, X, dt, ldx, &zero, rows, &zero, &nb, wf, h_sub, &ns, &k, &f, h_u, &l);
@@ -1791,7 +1796,10 @@ static int run_steps(hamsm_ctx *c, const void *X, int dt, int64_t ldx, const int
       }
       rc = (dt == HAMSM_F32) ? launch_steps<float>(c, lanes[l], dptr, pk, ny, max_nb, maxK, ldx, ratio, any_perm)
                              : launch_steps<double>(c, lanes[l], dptr, pk, ny, max_nb, maxK, ldx, ratio, any_perm);
-      if (rc) return rc;
+      if (rc) {
+        hipDeviceSynchronize();  // (all lanes: nothing may still read `sd` once it is gone)
+        return rc;
+      }
     }
   }
   if (dbg_enq) {
@@ -1806,12 +1814,17 @@ static int run_steps(hamsm_ctx *c, const void *X, int dt, int64_t ldx, const int
   for (int64_t i : tail_checks)
     hipLaunchKernelGGL(k_step_check, dim3(1), dim3(256), 0, c->stream, d_steps + i, ratio, (int)n_steps);
   hamsm_timer_end(c, ST_STEP);
-  HIPCHK(c, hipGetLastError());
+  if (hipError_t le = hipGetLastError(); le != hipSuccess) {
+    hipDeviceSynchronize();
+    return hamsm_fail(c, HAMSM_EDEVICE, "step launches: %s", hipGetErrorString(le));
+  }
   if (h_report) {
     std::vector<int32_t> hw(2 * (size_t)c->S);
-    HIPCHK(c, hipMemcpyAsync(h_report, b + o_rep, sizeof(int32_t) * 2 * n_steps, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipMemcpyAsync(hw.data(), b + o_halt, sizeof(int32_t) * 2 * c->S, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    hipError_t e = hipMemcpyAsync(h_report, b + o_rep, sizeof(int32_t) * 2 * n_steps, hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(hw.data(), b + o_halt, sizeof(int32_t) * 2 * c->S, hipMemcpyDeviceToHost, c->stream);
+    hipError_t es = hipStreamSynchronize(c->stream);  // always: `sd` and `hw` are locals the copies above read / write
+    if (e == hipSuccess) e = es;
+    if (e != hipSuccess) return hamsm_fail(c, HAMSM_EDEVICE, "minibatch_run read-back: %s", hipGetErrorString(e));
     if (h_resume && h_reason) {
       // stop word -> first step of the stratum that was not applied
       for (int s = 0; s < c->S; s++) {
@@ -1823,6 +1836,8 @@ static int run_steps(hamsm_ctx *c, const void *X, int dt, int64_t ldx, const int
         if (i >= hw[s]) h_resume[s] = i;
       }
     }
+  } else {
+    HIPCHK(c, hipStreamSynchronize(c->stream));  // the descriptor upload reads from the local `sd`
   }
   return HAMSM_OK;
 }
@@ -1830,6 +1845,7 @@ static int run_steps(hamsm_ctx *c, const void *X, int dt, int64_t ldx, const int
 extern "C" int hamsm_minibatch_run(hamsm_ctx *c, const void *X, int dt, int64_t ldx, const int32_t *d_rows, const double *d_w,
                                    const hamsm_step *h_steps, int64_t n_steps, double ratio, const int32_t *h_perm,
                                    int64_t n_perm_total, int32_t *h_report, int64_t *h_resume, int32_t *h_reason) {
+  CTX(c);
   if (c->st.empty()) return hamsm_fail(c, HAMSM_EINVAL, "set_geometry first");
   if (!h_report || !h_resume || !h_reason) return hamsm_fail(c, HAMSM_EINVAL, "h_report / h_resume / h_reason missing");
   for (int s = 0; s < c->S; s++) {
@@ -1843,6 +1859,7 @@ extern "C" int hamsm_minibatch_run(hamsm_ctx *c, const void *X, int dt, int64_t 
 
 extern "C" int hamsm_minibatch_step(hamsm_ctx *c, int s, const void *X, int dt, int64_t ldx, const int32_t *rows, int64_t n_b,
                                     const double *wf, int32_t *labels_out) {
+  CTX(c);
   if (c->st.empty() || s < 0 || s >= c->S) return hamsm_fail(c, HAMSM_EINVAL, "bad stratum");
   if (c->st[s].K == 0) return hamsm_fail(c, HAMSM_EUNFIT, "stratum %d has no centroids", s);
   if (n_b <= 0) return HAMSM_OK;
@@ -1885,6 +1902,7 @@ __global__ void k_reassign(const XT *__restrict__ X, int64_t ldx, int D, int KS,
 
 extern "C" int hamsm_reassign(hamsm_ctx *c, int s, const void *X, int dt, int64_t ldx, const int32_t *rows,
                               const int32_t *h_cl, const int64_t *h_brow, int n_re, double new_count) {
+  CTX(c);
   if (c->st.empty() || s < 0 || s >= c->S) return hamsm_fail(c, HAMSM_EINVAL, "bad stratum");
   if (n_re <= 0) return HAMSM_OK;
   Stratum &t = c->st[s];

@@ -24,6 +24,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <sys/mman.h>
 
 #define MAX_NDIM 8
 #define POT_LANES 1024 /* strided partial sums for potentials */
@@ -37,7 +38,14 @@ typedef struct {
   double *counts; /* [K]    */
 } stratum_t;
 
+#define CTX_MAGIC_LIVE 0x68614d534d6f7263ull /* "haMSMorc" */
+#define CTX_MAGIC_DEAD 0xdeadc0de0badc7c7ull
+
 struct hamsm_ctx {
+  uint64_t magic;   /* CTX_MAGIC_LIVE between hamsm_create and hamsm_destroy */
+  struct hamsm_ctx *next; /* registry of every ctx ever created (see ctx_check) */
+  void **blocks;    /* live hamsm_malloc blocks of this ctx */
+  size_t n_blocks, cap_blocks;
   char err[512];
   int D, ndim, S;
   int nb[MAX_NDIM];
@@ -61,10 +69,62 @@ static int fail(hamsm_ctx *c, int code, const char *fmt, ...) {
 int hamsm_abi_version(void) { return HAMSM_ABI_VERSION; }
 const char *hamsm_backend_name(void) { return "cpu-oracle"; }
 
+/* Handle hygiene (round-2 fix).  A ctx struct is NEVER returned to the heap: hamsm_destroy releases what
+ * the ctx owns, stamps it CTX_MAGIC_DEAD and leaves the struct (one private page) on a registry list, so that a stale handle (a wrapper
+ * that outlived its context, a second destroy) is recognised for ever instead of aliasing whatever malloc placed there
+ * next -- which is how a live context once came to read as zero-filled.  Every entry point starts with CTX(c): the
+ * handle must be on the registry (checked WITHOUT dereferencing it first) and live. */
+static hamsm_ctx *g_registry = NULL;
+static char g_stale_msg[128];
+
+static int ctx_known(const hamsm_ctx *c) {
+  for (const hamsm_ctx *q = g_registry; q; q = q->next)
+    if (q == c) return 1;
+  return 0;
+}
+static int ctx_check(hamsm_ctx *c, const char *fn) {
+  if (!c) return HAMSM_EINVAL;
+  if (!ctx_known(c)) {
+    snprintf(g_stale_msg, sizeof g_stale_msg, "%s: %p is not a hamsm context of this library", fn, (void *)c);
+    return HAMSM_EINVAL;
+  }
+  if (c->magic == CTX_MAGIC_DEAD) {
+    snprintf(g_stale_msg, sizeof g_stale_msg, "%s: stale handle %p (context was destroyed)", fn, (void *)c);
+    return HAMSM_EINVAL;
+  }
+  if (c->magic != CTX_MAGIC_LIVE) { /* neither live nor destroyed: somebody else wrote here -- say so, with evidence */
+    const unsigned char *b = (const unsigned char *)c;
+    size_t nz = 0, first = sizeof *c;
+    for (size_t i = 0; i < sizeof *c; i++)
+      if (b[i]) {
+        nz++;
+        if (first == sizeof *c) first = i;
+      }
+    snprintf(g_stale_msg, sizeof g_stale_msg, "%s: context %p OVERWRITTEN (magic %llx, %zu of %zu bytes non-zero, first at %zu)",
+             fn, (void *)c, (unsigned long long)c->magic, nz, sizeof *c, first);
+    return HAMSM_EINVAL;
+  }
+  return HAMSM_OK;
+}
+#define CTX(c)                                  \
+  do {                                          \
+    int rc_ = ctx_check((c), __func__);         \
+    if (rc_) return rc_;                        \
+  } while (0)
+
 int hamsm_create(int device, hamsm_ctx **out) {
   (void)device;
-  hamsm_ctx *c = (hamsm_ctx *)calloc(1, sizeof *c);
-  if (!c) return HAMSM_ENOMEM;
+  if (!out) return HAMSM_EINVAL;
+  /* the struct lives on pages of its own, between two inaccessible guard pages: it shares no page and no allocator bin
+   * with NumPy buffers, the HIP runtime's host objects or anything that library pins for DMA */
+  const size_t pg = 4096, body = (sizeof(hamsm_ctx) + pg - 1) / pg * pg;
+  char *m = (char *)mmap(NULL, body + 2 * pg, PROT_NONE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0);
+  if (m == MAP_FAILED) return HAMSM_ENOMEM;
+  if (mprotect(m + pg, body, PROT_READ | PROT_WRITE) != 0) return HAMSM_ENOMEM;
+  hamsm_ctx *c = (hamsm_ctx *)(m + pg);
+  c->magic = CTX_MAGIC_LIVE;
+  c->next = g_registry;
+  g_registry = c;
   *out = c;
   return HAMSM_OK;
 }
@@ -84,46 +144,80 @@ static void free_strata(hamsm_ctx *c) {
 }
 
 void hamsm_destroy(hamsm_ctx *c) {
-  if (!c) return;
+  if (!c || !ctx_known(c) || c->magic != CTX_MAGIC_LIVE) return; /* unknown or already destroyed: nothing to free twice */
   free_strata(c);
-  for (int d = 0; d < MAX_NDIM; d++) free(c->bounds[d]);
-  free(c);
+  for (int d = 0; d < MAX_NDIM; d++) {
+    free(c->bounds[d]);
+    c->bounds[d] = NULL;
+  }
+  for (size_t i = 0; i < c->n_blocks; i++) free(c->blocks[i]); /* "device" memory dies with its context, as hipFree'd */
+  free(c->blocks);
+  c->blocks = NULL;
+  c->n_blocks = c->cap_blocks = 0;
+  c->have_bounds = c->have_mapper = 0;
+  c->magic = CTX_MAGIC_DEAD; /* the struct itself stays on the registry (see above) */
 }
 
-const char *hamsm_last_error(hamsm_ctx *c) { return c ? c->err : "null ctx"; }
+const char *hamsm_last_error(hamsm_ctx *c) {
+  if (!c) return "null ctx";
+  if (!ctx_known(c) || c->magic != CTX_MAGIC_LIVE) return g_stale_msg[0] ? g_stale_msg : "stale or foreign ctx handle";
+  return c->err;
+}
 
+/* "device" memory = host heap, owned by the ctx that allocated it: hamsm_free of a pointer this ctx does not hold
+ * (double free, a block of another context) is an error, never a free() of somebody else's memory */
 int hamsm_malloc(hamsm_ctx *c, size_t bytes, void **out) {
+  CTX(c);
+  if (c->n_blocks == c->cap_blocks) {
+    size_t cap = c->cap_blocks ? 2 * c->cap_blocks : 64;
+    void **nb = (void **)realloc(c->blocks, cap * sizeof(void *));
+    if (!nb) return fail(c, HAMSM_ENOMEM, "block table");
+    c->blocks = nb;
+    c->cap_blocks = cap;
+  }
   void *p = malloc(bytes ? bytes : 1);
   if (!p) return fail(c, HAMSM_ENOMEM, "malloc(%zu)", bytes);
+  c->blocks[c->n_blocks++] = p;
   *out = p;
   return HAMSM_OK;
 }
 int hamsm_free(hamsm_ctx *c, void *p) {
-  (void)c;
-  free(p);
-  return HAMSM_OK;
+  CTX(c);
+  if (!p) return HAMSM_OK;
+  for (size_t i = c->n_blocks; i-- > 0;)
+    if (c->blocks[i] == p) {
+      c->blocks[i] = c->blocks[--c->n_blocks];
+      free(p);
+      return HAMSM_OK;
+    }
+  return fail(c, HAMSM_EINVAL, "hamsm_free: %p was not returned by hamsm_malloc of this context (double free?)", p);
 }
 int hamsm_memcpy_h2d(hamsm_ctx *c, void *d, const void *h, size_t n) {
+  CTX(c);
   (void)c;
   memcpy(d, h, n);
   return HAMSM_OK;
 }
 int hamsm_memcpy_d2h(hamsm_ctx *c, void *h, const void *d, size_t n) {
+  CTX(c);
   (void)c;
   memcpy(h, d, n);
   return HAMSM_OK;
 }
 int hamsm_memset(hamsm_ctx *c, void *d, int b, size_t n) {
+  CTX(c);
   (void)c;
   memset(d, b, n);
   return HAMSM_OK;
 }
 int hamsm_sync(hamsm_ctx *c) {
+  CTX(c);
   (void)c;
   return HAMSM_OK;
 }
 
 int hamsm_set_geometry(hamsm_ctx *c, int D, int ndim, int S) {
+  CTX(c);
   if (D < 1 || ndim < 1 || ndim > MAX_NDIM || S < 1) return fail(c, HAMSM_EINVAL, "bad geometry");
   free_strata(c);
   c->D = D;
@@ -136,6 +230,7 @@ int hamsm_set_geometry(hamsm_ctx *c, int D, int ndim, int S) {
 }
 
 int hamsm_set_mapper_rectilinear(hamsm_ctx *c, const int32_t *nb, const float *b) {
+  CTX(c);
   if (!c->st) return fail(c, HAMSM_EINVAL, "set_geometry first");
   long nbins = 1;
   for (int d = 0; d < c->ndim; d++) {
@@ -153,6 +248,7 @@ int hamsm_set_mapper_rectilinear(hamsm_ctx *c, const int32_t *nb, const float *b
 }
 
 int hamsm_set_remap(hamsm_ctx *c, const int32_t *r) {
+  CTX(c);
   if (!c->st) return fail(c, HAMSM_EINVAL, "set_geometry first");
   for (int s = 0; s < c->S; s++)
     if (r[s] < 0 || r[s] >= c->S) return fail(c, HAMSM_EINVAL, "remap[%d]=%d out of range", s, r[s]);
@@ -161,6 +257,7 @@ int hamsm_set_remap(hamsm_ctx *c, const int32_t *r) {
 }
 
 int hamsm_set_bounds(hamsm_ctx *c, const double *basis, const double *target) {
+  CTX(c);
   if (!c->st) return fail(c, HAMSM_EINVAL, "set_geometry first");
   for (int d = 0; d < c->ndim; d++) {
     c->basis[d][0] = basis[2 * d];
@@ -181,6 +278,7 @@ static double sqnorm_chain(const double *v, int D) {
 }
 
 int hamsm_set_centroids(hamsm_ctx *c, int s, int K, const double *C, const double *csq, const double *counts) {
+  CTX(c);
   if (!c->st || s < 0 || s >= c->S || K < 0) return fail(c, HAMSM_EINVAL, "bad stratum/K");
   stratum_t *t = &c->st[s];
   free(t->C);
@@ -199,6 +297,7 @@ int hamsm_set_centroids(hamsm_ctx *c, int s, int K, const double *C, const doubl
 }
 
 int hamsm_get_centroids(hamsm_ctx *c, int s, double *C, double *counts, double *csq) {
+  CTX(c);
   if (!c->st || s < 0 || s >= c->S) return fail(c, HAMSM_EINVAL, "bad stratum");
   stratum_t *t = &c->st[s];
   if (C) memcpy(C, t->C, sizeof(double) * (size_t)t->K * c->D);
@@ -208,6 +307,7 @@ int hamsm_get_centroids(hamsm_ctx *c, int s, double *C, double *counts, double *
 }
 
 int hamsm_num_centroids(hamsm_ctx *c, int s) {
+  CTX(c);
   if (!c->st || s < 0 || s >= c->S) return fail(c, HAMSM_EINVAL, "bad stratum");
   return c->st[s].K;
 }
@@ -240,6 +340,7 @@ static int in_box(const double (*box)[2], int ndim, const double *p) {
 }
 
 int hamsm_classify(hamsm_ctx *c, const double *p, int64_t n, int apply_remap, int32_t *bin, uint8_t *flags) {
+  CTX(c);
   if (!c->have_mapper || !c->have_bounds) return fail(c, HAMSM_EINVAL, "mapper/bounds not set");
   for (int64_t i = 0; i < n; i++) {
     const double *pi = p + i * c->ndim;
@@ -276,6 +377,7 @@ static int argmin_row(const double *x, const stratum_t *t, int D) {
 /* --- a9: StratifiedClusters.predict, stratified_clustering.py:129-212 */
 int hamsm_assign(hamsm_ctx *c, const void *X, int dt, int64_t ldx, const double *p, int64_t n, int32_t *labels,
                  int32_t *seen) {
+  CTX(c);
   if (!c->have_mapper || !c->have_bounds) return fail(c, HAMSM_EINVAL, "mapper/bounds not set");
   if (dt != HAMSM_F32 && dt != HAMSM_F64) return fail(c, HAMSM_EINVAL, "x_dtype");
   if (ldx < c->D) return fail(c, HAMSM_EINVAL, "ldx < D");
@@ -320,6 +422,7 @@ int hamsm_assign(hamsm_ctx *c, const void *X, int dt, int64_t ldx, const double 
 
 int hamsm_predict_host(hamsm_ctx *c, const void *X, int dt, const double *p, int64_t n, int32_t *labels,
                        int32_t *seen) {
+  CTX(c);
   return hamsm_assign(c, X, dt, c->D, p, n, labels, seen);
 }
 
@@ -330,6 +433,7 @@ int hamsm_predict_host(hamsm_ctx *c, const void *X, int dt, const double *p, int
 int hamsm_flux_accumulate(hamsm_ctx *c, const int32_t *pa, const int32_t *ch, const double *p0, const double *p1,
                           const double *w, int64_t n, int K, double *F, int mode, const int64_t *offs,
                           int64_t n_iters) {
+  CTX(c);
   (void)mode;
   if (!c->have_bounds) return fail(c, HAMSM_EINVAL, "bounds not set");
   int64_t N2 = (int64_t)(K + 2) * (K + 2);
@@ -372,6 +476,7 @@ int hamsm_flux_accumulate(hamsm_ctx *c, const int32_t *pa, const int32_t *ch, co
 }
 
 int hamsm_scale(hamsm_ctx *c, double *F, int64_t count, double div) {
+  CTX(c);
   (void)c;
   for (int64_t i = 0; i < count; i++) F[i] = F[i] / div; /* _fluxmatrix.py:342 */
   return HAMSM_OK;
@@ -381,6 +486,7 @@ int hamsm_scale(hamsm_ctx *c, double *F, int64_t count, double div) {
  * the mean only feeds an argsort, so the contract is sum in ascending frame order, |rel| 1e-12.) */
 int hamsm_cluster_stats(hamsm_ctx *c, const int32_t *lab, const double *p, int64_t n, int nstates, double *sum,
                         double *mn, double *mx, int64_t *cnt) {
+  CTX(c);
   for (int64_t i = 0; i < n; i++) {
     int l = lab[i];
     if (l < 0 || l >= nstates) return fail(c, HAMSM_ERANGE, "label %d outside %d states", l, nstates);
@@ -420,6 +526,7 @@ static double np_pairwise(const double *a, int64_t n) {
 /* --- a13 feed: _analysis.py:44-79 */
 int hamsm_tmatrix_csr(hamsm_ctx *c, const double *F, int ns, const int32_t *basis, int nb, const int32_t *target,
                       int nt, int64_t *indptr, int32_t *indices, double *data, int64_t cap, int64_t *nnz_out) {
+  CTX(c);
   int64_t nnz = 0;
   indptr[0] = 0;
   for (int i = 0; i < ns; i++) {
@@ -455,6 +562,7 @@ int hamsm_tmatrix_csr(hamsm_ctx *c, const double *F, int ns, const int32_t *basi
  *     dot product an fma chain over ascending k */
 int hamsm_project(hamsm_ctx *c, const void *X, int dt, int64_t ldx, int64_t n, int Draw, const double *mean, const double *W,
                   int d, const double *scale, double *Y) {
+  CTX(c);
   if (Draw < 1 || d < 1 || !W || ldx < Draw) return fail(c, HAMSM_EINVAL, "bad projection shape");
   if (dt != HAMSM_F32 && dt != HAMSM_F64) return fail(c, HAMSM_EINVAL, "bad x_dtype");
   double *m = (double *)calloc((size_t)d, sizeof(double));
@@ -481,6 +589,7 @@ int hamsm_project(hamsm_ctx *c, const void *X, int dt, int64_t ldx, int64_t n, i
  *     MDAnalysis is not available here, so this function is NOT pinned by reference output ("parity unpinned"). */
 int hamsm_featurize_dist(hamsm_ctx *c, const void *coords, int dt, int64_t ldc, int64_t n, int n_atoms, const int32_t *idx,
                          int n_sel, const float *ref, double *X, int64_t ldx) {
+  CTX(c);
   if (dt != HAMSM_F32 && dt != HAMSM_F64) return fail(c, HAMSM_EINVAL, "bad c_dtype");
   if (n_atoms < 1 || n_sel < 1 || !idx || !ref || ldc < 3 * (int64_t)n_atoms || ldx < n_sel)
     return fail(c, HAMSM_EINVAL, "bad featurizer shape");
@@ -505,6 +614,7 @@ int hamsm_featurize_dist(hamsm_ctx *c, const void *coords, int dt, int64_t ldc, 
 /* --- a5 support: _clustering.py:872-886 */
 int hamsm_train_prepass(hamsm_ctx *c, const double *p, int64_t n, const int64_t *offs, int64_t n_iters, int32_t *bin,
                         int64_t *hist) {
+  CTX(c);
   if (!c->have_mapper || !c->have_bounds) return fail(c, HAMSM_EINVAL, "mapper/bounds not set");
   memset(hist, 0, sizeof(int64_t) * (size_t)n_iters * c->S);
   for (int64_t t = 0; t < n_iters; t++)
@@ -525,6 +635,7 @@ int hamsm_train_prepass(hamsm_ctx *c, const double *p, int64_t n, const int64_t 
 
 int hamsm_train_build_rows(hamsm_ctx *c, const int32_t *bin, int64_t n, const int32_t *call_remap, int32_t *rows,
                            int64_t *counts, int64_t *starts) {
+  CTX(c);
   memset(counts, 0, sizeof(int64_t) * (size_t)c->S);
   for (int64_t i = 0; i < n; i++)
     if (bin[i] >= 0) counts[call_remap[bin[i]]]++;
@@ -579,6 +690,7 @@ static double pot_sum(const double *d, const double *w, int64_t n) {
 int hamsm_kmeans_seed(hamsm_ctx *c, int s, const void *X, int dt, int64_t ldx, const int32_t *rows, int64_t n_b,
                       const double *wf, const int64_t *sub, int64_t n_sub, int K, int64_t first, const double *u,
                       int L, int64_t *chosen) {
+  CTX(c);
   if (!c->st || s < 0 || s >= c->S) return fail(c, HAMSM_EINVAL, "bad stratum");
   int D = c->D;
   int64_t n = sub ? n_sub : n_b;
@@ -669,6 +781,7 @@ int hamsm_kmeans_seed(hamsm_ctx *c, int s, const void *X, int dt, int64_t ldx, c
 /* --- a7: _kmeans.py:1620-1642 + _k_means_minibatch.pyx:59-108 */
 int hamsm_minibatch_step(hamsm_ctx *c, int s, const void *X, int dt, int64_t ldx, const int32_t *rows, int64_t n_b,
                          const double *wf, int32_t *labels_out) {
+  CTX(c);
   if (!c->st || s < 0 || s >= c->S) return fail(c, HAMSM_EINVAL, "bad stratum");
   stratum_t *t = &c->st[s];
   if (t->K == 0) return fail(c, HAMSM_EUNFIT, "stratum %d has no centroids", s);
@@ -705,6 +818,7 @@ int hamsm_minibatch_step(hamsm_ctx *c, int s, const void *X, int dt, int64_t ldx
 }
 
 int hamsm_get_counts(hamsm_ctx *c, int s, double *counts) {
+  CTX(c);
   if (!c->st || s < 0 || s >= c->S) return fail(c, HAMSM_EINVAL, "bad stratum");
   memcpy(counts, c->st[s].counts, sizeof(double) * (size_t)c->st[s].K);
   return HAMSM_OK;
@@ -713,6 +827,7 @@ int hamsm_get_counts(hamsm_ctx *c, int s, double *counts) {
 /* --- _kmeans.py:1652-1673 */
 int hamsm_reassign(hamsm_ctx *c, int s, const void *X, int dt, int64_t ldx, const int32_t *rows, const int32_t *cl,
                    const int64_t *brow, int n_re, double new_count) {
+  CTX(c);
   if (!c->st || s < 0 || s >= c->S) return fail(c, HAMSM_EINVAL, "bad stratum");
   stratum_t *t = &c->st[s];
   for (int i = 0; i < n_re; i++) {
@@ -730,6 +845,7 @@ int hamsm_reassign(hamsm_ctx *c, int s, const void *X, int dt, int64_t ldx, cons
 /* --- batched forms: loops over the single-call restatements above ------------------------------- */
 int hamsm_train_build_rows_batched(hamsm_ctx *c, const int32_t *bin, int64_t n_groups, const int64_t *goff,
                                    const int32_t *call_remap, int32_t *rows, int64_t *counts, int64_t *starts) {
+  CTX(c);
   for (int64_t g = 0; g < n_groups; g++) {
     int64_t b = goff[2 * g], e = goff[2 * g + 1];
     int rc = hamsm_train_build_rows(c, bin + b, e - b, call_remap + g * c->S, rows + b, counts + g * c->S, starts + g * c->S);
@@ -743,6 +859,7 @@ int hamsm_kmeans_seed_multi(hamsm_ctx *c, int n_items, const int32_t *stratum, c
                             const int64_t *x_off, const int32_t *rows, const int64_t *rows_off, const int64_t *n_b,
                             const double *wf, const int64_t *sub, const int64_t *n_sub, const int32_t *K,
                             const int64_t *first, const double *u, const int32_t *L) {
+  CTX(c);
   size_t esz = dt == HAMSM_F32 ? 4 : 8;
   for (int i = 0; i < n_items; i++) {
     const char *Xi = (const char *)X + (size_t)x_off[i] * ldx * esz;
@@ -759,6 +876,7 @@ int hamsm_kmeans_seed_multi(hamsm_ctx *c, int n_items, const int32_t *stratum, c
 int hamsm_minibatch_run(hamsm_ctx *c, const void *X, int dt, int64_t ldx, const int32_t *rows, const double *wf,
                         const hamsm_step *steps, int64_t n_steps, double ratio, const int32_t *perm, int64_t n_perm_total,
                         int32_t *report, int64_t *resume, int32_t *reason) {
+  CTX(c);
   size_t esz = dt == HAMSM_F32 ? 4 : 8;
   char *stopped = (char *)calloc((size_t)c->S, 1);
   for (int s = 0; s < c->S; s++) {
@@ -850,44 +968,54 @@ int hamsm_comm_unique_id(char *id) {
   return HAMSM_OK;
 }
 int hamsm_comm_init(hamsm_ctx *c, int nranks, int rank, const char *id) {
+  CTX(c);
   (void)id;
   (void)rank;
   return nranks == 1 ? HAMSM_OK : fail(c, HAMSM_ENOTSUP, "cpu-oracle has no collective backend");
 }
 int hamsm_comm_destroy(hamsm_ctx *c) {
+  CTX(c);
   (void)c;
   return HAMSM_OK;
 }
 int hamsm_allreduce_sum_f64(hamsm_ctx *c, double *b, int64_t n) {
+  CTX(c);
   (void)c, (void)b, (void)n;
   return HAMSM_OK;
 }
 int hamsm_allreduce_min_f64(hamsm_ctx *c, double *b, int64_t n) {
+  CTX(c);
   (void)c, (void)b, (void)n;
   return HAMSM_OK;
 }
 int hamsm_allreduce_max_f64(hamsm_ctx *c, double *b, int64_t n) {
+  CTX(c);
   (void)c, (void)b, (void)n;
   return HAMSM_OK;
 }
 int hamsm_allreduce_sum_i64(hamsm_ctx *c, int64_t *b, int64_t n) {
+  CTX(c);
   (void)c, (void)b, (void)n;
   return HAMSM_OK;
 }
 int hamsm_bcast(hamsm_ctx *c, void *b, size_t n, int root) {
+  CTX(c);
   (void)c, (void)b, (void)n, (void)root;
   return HAMSM_OK;
 }
 int hamsm_bcast_model(hamsm_ctx *c, int root) {
+  CTX(c);
   (void)c, (void)root;
   return HAMSM_OK;
 }
 int hamsm_timers(hamsm_ctx *c, double *out, int reset) {
+  CTX(c);
   (void)c, (void)reset;
   memset(out, 0, sizeof(double) * 8);
   return HAMSM_OK;
 }
 int hamsm_last_kernel_ms(hamsm_ctx *c, int stage, double *ms) {
+  CTX(c);
   (void)c, (void)stage;
   *ms = 0.0;
   return HAMSM_OK;

@@ -19,6 +19,8 @@ def pytest_configure(config):
 
 
 def _build_oracle():
+    if os.environ.get("HAMSM_ORACLE_SO"):   # oracle/run_asan.sh: the sanitizer build of the same source
+        return os.environ["HAMSM_ORACLE_SO"]
     so = os.path.join(ROOT, "oracle", "_build", "libhamsm_oracle.so")
     src = os.path.join(ROOT, "oracle", "hamsm_oracle.c")
     if not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
@@ -45,6 +47,13 @@ def oracle_h(oracle_lib):
 def hip_lib():
     from msm_we_amd import _abi
 
+    if os.environ.get("HAMSM_HIP_STANDIN"):
+        # sanitizer runs only (oracle/run_asan.sh --gpu-logic): the GPU suite's host logic with a second copy of the oracle in
+        # the product's seat, so that AddressSanitizer sees every buffer the tests hand across the ABI.  Never set by the driver.
+        import shutil, tempfile
+        twin = os.path.join(tempfile.mkdtemp(), "libhamsm_standin.so")
+        shutil.copy(os.environ["HAMSM_HIP_STANDIN"], twin)
+        return ctypes.CDLL(twin)
     return _abi.load()  # raises if the HIP library is missing: no fallback
 
 
@@ -53,7 +62,7 @@ def hip_h(hip_lib):
     from msm_we_amd import _abi
 
     h = _abi.Hamsm(lib=hip_lib, device=0)
-    assert h.backend == "hip-gfx950"
+    assert h.backend == "hip-gfx950" or os.environ.get("HAMSM_HIP_STANDIN")
     yield h
     h.close()
 
