@@ -132,6 +132,13 @@ class DevBuf:
     def __deepcopy__(self, memo):
         return self  # device buffers are shared by reference (never written after creation by the mixins)
 
+    def __copy__(self):
+        return self  # one owner per block: a shallow copy must not become a second one
+
+    def __reduce__(self):
+        raise TypeError("a DevBuf is a live device allocation and cannot be pickled (modelWE / StratifiedClusters pickle "
+                        "their state as NumPy arrays and drop device buffers)")
+
     def to_host(self):
         out = np.empty(self.shape, dtype=self.dtype)
         self.h.d2h(out, self)
@@ -185,6 +192,14 @@ class Hamsm:
             self.close()
         except Exception:
             pass
+
+    def __deepcopy__(self, memo):
+        return self  # a context is shared, never duplicated: two owners of one handle would destroy it twice
+
+    __copy__ = lambda self: self  # noqa: E731
+
+    def __reduce__(self):
+        raise TypeError("a Hamsm context is a live GPU handle and cannot be pickled; pickle the model and `attach(h)` after loading")
 
     def alloc(self, shape, dtype) -> DevBuf:
         shape = (shape,) if np.isscalar(shape) else tuple(shape)

@@ -488,6 +488,8 @@ class ClusteringMixin:
 
     # dtrajs / pair_dtrajs are host views of the device labels, materialised on first access
     def _labels_host(self):
+        if getattr(self, "_d_child", None) is None:  # unpickled / never discretized: the plain host lists
+            return self.__dict__.get("_dtrajs_plain", []), self.__dict__.get("_pairs_plain", [])
         if getattr(self, "_dtrajs_cache", None) is None:
             n = self._n_labelled
             pa = np.empty(n, dtype=np.int32)
@@ -501,11 +503,22 @@ class ClusteringMixin:
                                  for i in range(n_it)]
         return self._dtrajs_cache, self._pairs_cache
 
+    def _labels_device(self):
+        """(d_parent, d_child) -- uploaded again from the host lists when the model came out of a pickle"""
+        if getattr(self, "_d_child", None) is None:
+            pairs = self.__dict__.get("_pairs_plain") or []
+            if not len(pairs):
+                raise RuntimeError("no discretization: call cluster_coordinates / launch_ray_discretization first")
+            flat = np.concatenate([np.asarray(p, dtype=np.int64).reshape(-1, 2) for p in pairs])
+            self._d_parent = self.h.to_device(np.ascontiguousarray(flat[:, 0], dtype=np.int32))
+            self._d_child = self.h.to_device(np.ascontiguousarray(flat[:, 1], dtype=np.int32))
+            self._n_labelled = len(flat)
+            self._dtrajs_cache = self._pairs_cache = None
+        return self._d_parent, self._d_child
+
     @property
     def dtrajs(self):
         """list over iterations 1..maxIter-1 of child-frame labels (`_clustering.py:1226,1238`)."""
-        if getattr(self, "_d_child", None) is None:
-            return self.__dict__.get("_dtrajs_plain", [])
         return self._labels_host()[0]
 
     @dtrajs.setter
@@ -517,6 +530,10 @@ class ClusteringMixin:
         """per iteration an (nSeg, 2) array of (parent, child) labels -- `np.array(pair_dtrajs[i])` of the
         reference's list of tuples (`_clustering.py:1228,1240`; `_fluxmatrix.py:288`)."""
         return self._labels_host()[1]
+
+    @pair_dtrajs.setter
+    def pair_dtrajs(self, v):
+        self.__dict__["_pairs_plain"] = v
 
     # ------------------------------------------------------------------------------------------
     @staticmethod
@@ -551,15 +568,16 @@ class ClusteringMixin:
         """`_clustering.py:1528-1599`: per-cluster mean / min / max of the child pcoord (dim 0) over
         the discretized frames, then the pcoord sort order.  Segmented reduction on the device."""
         h = self.h
-        store = self._store
+        store = self.stage_iterations()
         K = self.n_clusters
         ns = K + 2
+        _, d_child = self._labels_device()
         n = self._n_labelled
         d_sum = h.zeros(ns, np.float64)
         d_min = h.to_device(np.full(ns, np.inf))
         d_max = h.to_device(np.full(ns, -np.inf))
         d_cnt = h.zeros(ns, np.int64)
-        h.cluster_stats(self._d_child, store.p1, n, ns, d_sum, d_min, d_max, d_cnt)
+        h.cluster_stats(d_child, store.p1, n, ns, d_sum, d_min, d_max, d_cnt)
         if getattr(h, "nranks", 1) > 1:
             # exchange step (SURVEY §8e): per-cluster pcoord sums, extrema and counts of the iteration shards
             h.allreduce_sum_f64(d_sum, ns)

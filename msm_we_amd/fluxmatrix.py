@@ -55,7 +55,8 @@ class FluxMatrixMixin:
     def _flux_device(self, iters):
         """Sum of the per-iteration flux matrices of `iters` as a device (K+2)^2 buffer (caller frees)."""
         h = self.h
-        store = self._store
+        store = self.stage_iterations()
+        d_parent, d_child = self._labels_device()
         K = self.n_clusters
         ns = K + 2
         d_F = h.zeros((ns, ns), np.float64)
@@ -71,7 +72,7 @@ class FluxMatrixMixin:
         for a, b in runs:
             f0, f1 = store.span(a, b)
             # array bases are unshifted: d_iter_offsets holds absolute segment positions (hamsm.h)
-            h.flux_accumulate(self._d_parent, self._d_child, store.p0, store.p1, store.w, f1 - f0, K, d_F,
+            h.flux_accumulate(d_parent, d_child, store.p0, store.p1, store.w, f1 - f0, K, d_F,
                               self.flux_mode, store.d_offsets.offset(a - 1), b - a + 1)
         return d_F
 

@@ -84,6 +84,48 @@ class modelWE(DataMixin, ClusteringMixin, FluxMatrixMixin, AnalysisMixin):
                 new.__dict__[k] = deepcopy(v, memo)
         return new
 
+    # -- pickling (the reference pickles the model after every stage: tests/fixtures/hamsms.py:13-56, the restart
+    #    plugin, ray.put at _clustering.py:1165-1176).  The pickle holds plain NumPy / Python state: no context, no
+    #    device buffers; the discretization is materialised (`dtrajs`, `pair_dtrajs` as host arrays).  After loading,
+    #    `attach(h)` binds a context; frames are re-staged from the iteration source on first use. -----------------------
+    _DEVICE_STATE = ("_h", "_store", "_d_parent", "_d_child", "_dtrajs_cache", "_pairs_cache")
+
+    def __getstate__(self):
+        d = dict(self.__dict__)
+        if d.get("_d_child") is not None:
+            dtr, pairs = self._labels_host()
+            d["_dtrajs_plain"], d["_pairs_plain"] = dtr, pairs
+        for k in self._DEVICE_STATE:
+            if k in d:
+                d[k] = None
+        return d
+
+    def __setstate__(self, d):
+        self.__dict__.update(d)
+        cl = self.__dict__.get("clusters")
+        if cl is not None and getattr(cl, "model", None) is None:
+            cl.model = self
+
+    def attach(self, h: "_abi.Hamsm" = None):
+        """Bind an unpickled model (and its cluster object, validation copies) to a device context; the default creates
+        one on `self._device`.  Geometry, mapper and bounds are pushed again, centroids follow on the first device op."""
+        if h is None:
+            h = _abi.Hamsm(device=self._device)
+        self._h = h
+        seen = {id(self)}
+        for m in [getattr(self, "post_cluster_model", None), getattr(self, "pre_discretization_model", None),
+                  *(getattr(self, "validation_models", None) or [])]:
+            if m is not None and id(m) not in seen and hasattr(m, "attach"):
+                seen.add(id(m))
+                m.attach(h)
+        cl = getattr(self, "clusters", None)
+        if cl is not None:
+            cl.attach(h)
+            if getattr(self, "_source", None) is not None and getattr(self, "maxIter", None):
+                store = self.stage_iterations()
+                self._configure_device(cl.bin_mapper, store.D)
+        return self
+
     # -- msm_we.py:143-277 ------------------------------------------------------------------
     def initialize(self, fileSpecifier, refPDBfile, modelName, basis_pcoord_bounds=None, target_pcoord_bounds=None,
                    dim_reduce_method="none", tau=None, pcoord_ndim=1, auxpath="coord",
@@ -113,13 +155,23 @@ class modelWE(DataMixin, ClusteringMixin, FluxMatrixMixin, AnalysisMixin):
         self.use_weights_in_clustering = use_weights_in_clustering
 
     def set_topology(self, topology):
-        # msm_we.py:1071-1075: only the dict form is on the path; PDB parsing is out of scope
+        """msm_we.py:1011-1075.  The dict form carries what the hot path needs (`nAtoms`, `coord_ndim`, `coords`); a file
+        path (PDB / .dat, parsed with mdtraj in the reference -- "should no longer be necessary", hamsm_driver.py:90) or
+        None leaves the atom count to be read off the first iteration's coordinates."""
         if isinstance(topology, dict):
             self.reference_coord = topology["coords"]
             self.nAtoms = topology["nAtoms"]
             self.coord_ndim = topology["coord_ndim"]
-        else:
-            raise NotImplementedError("pass the topology as dict(coords=, nAtoms=, coord_ndim=)")
+            return
+        src = getattr(self, "_source", None)
+        if src is None:
+            raise NotImplementedError("pass the topology as dict(coords=, nAtoms=, coord_ndim=), or set an iteration source first")
+        d = src.load(src.iterations()[0])
+        c = np.asarray(d["child"] if "child" in d else np.asarray(d["Xc"])[:, :, None])
+        self.reference_structure_file = topology
+        self.reference_coord = None
+        self.nAtoms = int(c.shape[1])
+        self.coord_ndim = int(c.shape[2]) if c.ndim > 2 else 1
 
     # msm_we.py:300-347 / 397-444
     @staticmethod

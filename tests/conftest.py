@@ -76,10 +76,67 @@ class RectilinearBinMapper:
         self.nbins = int(np.prod([len(b) - 1 for b in self.boundaries]))
 
 
+class _Golden(dict):
+    """a golden case as a dict of arrays with np.load's `.files` (compact cases are expanded on load)"""
+
+    @property
+    def files(self):
+        return list(self.keys())
+
+
 def load_golden(case):
-    g = np.load(os.path.join(GOLDEN, f"{case}.npz"))
-    meta = json.loads(str(g["meta"]))
+    z = np.load(os.path.join(GOLDEN, f"{case}.npz"))
+    meta = json.loads(str(z["meta"]))
+    if "parents_clean" not in z.files:
+        return z, meta
+    # compact case (make_golden.compact): inputs are regenerated from the seed with the generator that produced them,
+    # COO triplets become dense matrices again, (parent, child) pairs are re-joined, T is left to the caller
+    from msm_we_amd import synthetic
+
+    g = _Golden()
+    for k in z.files:
+        if k.endswith("__coo_rc"):
+            base = k[: -len("__coo_rc")]
+            n = int(z[base + "__coo_n"])
+            M = np.zeros((n, n))
+            rc = z[k]
+            M[rc[0], rc[1]] = z[base + "__coo_v"]
+            g[base] = M
+        elif k.endswith("__coo_v") or k.endswith("__coo_n"):
+            continue
+        else:
+            v = z[k]
+            g[k] = v.astype(np.int64) if v.dtype == np.int16 else v
+    cfg = synthetic.WEConfig(meta["case"], meta["gen_seed"], meta["n_iters"], meta["segs_per_iter"], meta["D"], meta["S"], meta["K_s"])
+    blk = synthetic.make_block(cfg, 1, cfg.n_iters)
+    for k in ("Xp", "Xc", "p0", "p1", "w"):
+        g["in_" + k] = blk[k]
+    assert np.array_equal(blk["offsets"], g["in_offsets"])
+    for tag in ("post_cluster", "clean"):
+        g[f"pairs_{tag}"] = np.stack([g[f"parents_{tag}"], g[f"dtrajs_{tag}"]], axis=1)
     return g, meta
+
+
+def check_block_validation(m, g):
+    """a14: `do_block_validation` (msm_we.py:884-1009) against what the REAL reference produced for the same split:
+    iteration lists, per-group raw and organised flux matrices, cleaned state counts, discretization and remap identical;
+    steady state and target flux within 1e-6 rel."""
+    if not bool(g["bv_ok"]):
+        with pytest.raises(Exception):
+            m.do_block_validation(2, 4)
+        return
+    groups, blocks = (int(x) for x in g["bv_groups_blocks"])
+    m.do_block_validation(cross_validation_groups=groups, cross_validation_blocks=blocks)
+    assert len(m.validation_models) == groups
+    for gi, (its, vm) in enumerate(zip(m.validation_iterations, m.validation_models)):
+        assert list(its) == list(g[f"bv_iters_{gi}"])
+        assert vm.n_clusters == int(g[f"bv_n_clusters_{gi}"])
+        assert [vm.clusters.we_remap[b] for b in range(len(g[f"bv_remap_{gi}"]))] == list(g[f"bv_remap_{gi}"])
+        assert np.array_equal(np.concatenate(vm.dtrajs), g[f"bv_dtrajs_{gi}"])
+        assert np.array_equal(vm.fluxMatrixRaw, g[f"bv_fluxMatrixRaw_{gi}"])
+        assert np.array_equal(vm.fluxMatrix, g[f"bv_fluxMatrix_{gi}"])
+        np.testing.assert_allclose(vm.pSS, g[f"bv_pSS_{gi}"], rtol=1e-6, atol=1e-300)
+        assert abs(vm.JtargetSS - float(g[f"bv_JtargetSS_{gi}"])) <= 1e-6 * float(g[f"bv_JtargetSS_{gi}"])
 
 
 def golden_iterations(g):
@@ -138,7 +195,7 @@ def build_model(h, g, meta, seed_forcing=True, planned=True, source=None):
     bm = RectilinearBinMapper([np.array(meta["boundaries"], dtype=np.float32)])
     try:
         m.cluster_coordinates(meta["K_s"], streaming=True, use_ray=True, stratified=True, user_bin_mapper=bm,
-                              random_state=meta["seed"])
+                              random_state=meta["seed"], store_validation_model=True)
     finally:
         h.kmeans_seed = orig
         h.kmeans_seed_multi = orig_multi

@@ -6,7 +6,7 @@ import ctypes
 import numpy as np
 import pytest
 
-from conftest import GOLDEN_CASES, build_model, load_golden
+from conftest import GOLDEN_CASES, build_model, check_block_validation, load_golden
 
 pytestmark = pytest.mark.gpu
 
@@ -631,11 +631,20 @@ def test_pipeline_on_reference_goldens(hip_h, case):
     np.testing.assert_allclose(m.pSS, g["pSS"], rtol=1e-6, atol=1e-300)
     m.get_steady_state_target_flux()
     assert abs(m.JtargetSS - float(g["JtargetSS"])) <= 1e-6 * float(g["JtargetSS"])
+    check_block_validation(m, g)  # a14: the reference's own validation groups
     # atomic-mode flux agrees with the deterministic one to 1e-12
     m2, _ = build_model(hip_h, g, meta)
     m2.flux_mode = 0
     m2.get_fluxMatrix(0, first_iter=1, last_iter=m2.maxIter)
     np.testing.assert_allclose(m2.fluxMatrixRaw, g["fluxMatrixRaw"], rtol=1e-12, atol=1e-300)
+
+
+def test_c3_shaped_slice_on_reference_golden(hip_h):
+    """golden c3s: the real reference's outputs at BASELINE config 3's geometry (12 iterations), HIP library"""
+    from test_oracle_golden import check_c3_shaped
+
+    g, meta = load_golden("c3s")
+    check_c3_shaped(hip_h, g, meta)
 
 
 def test_pca_pipeline_on_reference_golden(hip_h, oracle_h):

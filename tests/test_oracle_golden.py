@@ -7,7 +7,7 @@ Bars: labels / indices identical; centroids and counts bit-identical; flux, T bi
 import numpy as np
 import pytest
 
-from conftest import GOLDEN_CASES, build_model, load_golden
+from conftest import GOLDEN_CASES, build_model, check_block_validation, load_golden
 
 
 @pytest.mark.parametrize("planned", [True, False], ids=["planned", "stepwise"])
@@ -63,6 +63,7 @@ def test_pipeline_matches_reference(oracle_h, case, planned):
     np.testing.assert_allclose(m.pSS, g["pSS"], rtol=1e-6, atol=1e-300)
     m.get_steady_state_target_flux()
     assert abs(m.JtargetSS - float(g["JtargetSS"])) <= 1e-6 * float(g["JtargetSS"])
+    check_block_validation(m, g)  # a14, against the reference's own groups
 
 
 def test_every_partial_fit_matches_reference(oracle_h):
@@ -146,3 +147,35 @@ def test_pca_pipeline_matches_reference(oracle_h):
     np.testing.assert_allclose(m.pSS, g["pSS"], rtol=1e-6, atol=1e-300)
     m.get_steady_state_target_flux()
     assert abs(m.JtargetSS - float(g["JtargetSS"])) <= 1e-6 * float(g["JtargetSS"])
+
+
+def check_c3_shaped(h, g, meta):
+    """BASELINE config 3's geometry (D = 30, 4 strata x 250 clusters, 10 000 segments per iteration, the bench generator's
+    seed) over 12 iterations against the REAL reference's outputs for exactly these inputs (golden c3s; inputs regenerated
+    from the seed): every label of both passes, every centroid table, both flux matrices, T's input and the block-validation
+    groups identical; steady state / target flux within 1e-6 rel.  No k-means++ seeding is teacher-forced here."""
+    m, st = build_model(h, g, meta, seed_forcing=False)
+    assert m.n_clusters == int(g["n_clusters_post_cluster"]) == 1000
+    for b, cm in enumerate(m.clusters.cluster_models):
+        assert np.array_equal(cm.cluster_centers_, g[f"centers_post_cluster_{b}"])
+        assert np.array_equal(cm._counts, g[f"counts_post_cluster_{b}"])
+    assert np.array_equal(np.concatenate(m.dtrajs), g["dtrajs_post_cluster"])
+    assert np.array_equal(np.concatenate(m.pair_dtrajs), g["pairs_post_cluster"])
+    m.get_fluxMatrix(0, first_iter=1, last_iter=m.maxIter, use_ray=True)
+    assert np.array_equal(m.fluxMatrixRaw, g["fluxMatrixRaw"])
+    m.organize_fluxMatrix(use_ray=True)
+    assert m.n_clusters == int(g["n_clusters_clean"])
+    assert np.array_equal(np.concatenate(m.dtrajs), g["dtrajs_clean"])
+    assert np.array_equal(np.concatenate(m.pair_dtrajs), g["pairs_clean"])
+    assert np.array_equal(m.fluxMatrix, g["fluxMatrix"])
+    m.get_Tmatrix()
+    m.get_steady_state()
+    np.testing.assert_allclose(m.pSS, g["pSS"], rtol=1e-6, atol=1e-300)
+    m.get_steady_state_target_flux()
+    assert abs(m.JtargetSS - float(g["JtargetSS"])) <= 1e-6 * float(g["JtargetSS"])
+    check_block_validation(m, g)
+
+
+def test_c3_shaped_slice_matches_reference(oracle_h):
+    g, meta = load_golden("c3s")
+    check_c3_shaped(oracle_h, g, meta)
