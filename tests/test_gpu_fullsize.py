@@ -247,3 +247,92 @@ def test_c5_shaped_plan_with_reseeding_equals_stepwise(hip_lib):
         assert out[0][2][0].sum() != seen0
     finally:
         h.close()
+
+
+# ---- BASELINE config 5's exact shape: D = 64, 4 strata x 1250 clusters, float32 frames, 50 000 segments per iteration ---------
+# (VERDICT r1 "parity gap 1": this regime -- f32 ranking pass with grouped LDS sweeps, the 2-row-tile E-step, k-means++ with
+# L = 9 candidates on a 3072-row subsample -- had only been compared with itself.)
+C5_TRAIN = synthetic.WEConfig("c5t", 5, 4, 50000, 64, 4, 1250)      # training: 4 iterations = 12 500 rows per stratum and call
+C5_ASSIGN = synthetic.WEConfig("c5t", 5, 24, 50000, 64, 4, 1250)    # assignment: 1.2 M segments (same generator stream)
+
+
+@pytest.fixture(scope="module")
+def c5_trained(hip_lib):
+    """the fused (planned) training pass at C5's shape on the HIP library + the same pass on the oracle"""
+    import ctypes
+
+    from conftest import _build_oracle
+    from msm_we_amd import _abi
+
+    cfg = C5_TRAIN
+    d = _shard(cfg, cfg.n_iters)
+    bm = RectilinearBinMapper([synthetic.strata_boundaries(cfg.S)])
+    res = {}
+    hs = {"hip": _abi.Hamsm(lib=hip_lib), "oracle": _abi.Hamsm(lib=ctypes.CDLL(_build_oracle()))}
+    for name, h in hs.items():
+        m, store = _model(h, cfg, d)
+        if name == "oracle":
+            m.launch_ray_discretization = lambda progress_bar=None: None   # 2 x 200 k rows x 1250 x 64 on a scalar core: skipped
+        m.cluster_coordinates(cfg.K_s, streaming=True, use_ray=True, stratified=True, user_bin_mapper=bm, random_state=5)
+        res[name] = m
+    yield cfg, d, hs, res, bm
+    for h in hs.values():
+        h.close()
+
+
+def test_c5_shape_training_equals_oracle(c5_trained):
+    """k-means++ (K = 1250, L = 9, 3072-row subsample) + 4 fused minibatch steps per stratum on 12 500-row batches:
+    centroids, counts and bookkeeping bit-identical to the oracle's"""
+    cfg, d, hs, res, bm = c5_trained
+    a, b = res["hip"], res["oracle"]
+    assert a.training_path == b.training_path == "planned"
+    for s, (ca, cb) in enumerate(zip(a.clusters.cluster_models, b.clusters.cluster_models)):
+        assert ca.cluster_centers_.shape == (cfg.K_s, cfg.D)
+        assert np.array_equal(ca.cluster_centers_, cb.cluster_centers_), s
+        assert np.array_equal(ca._counts, cb._counts), s
+        assert ca._n_since_last_reassign == cb._n_since_last_reassign and ca.n_steps_ == cb.n_steps_ == cfg.n_iters
+    # the discretization of the HIP run (2 x 200 k rows), oracle-checked on samples
+    n = a._store.N
+    rng = np.random.default_rng(15)
+    orc = hs["oracle"]
+    _check_assign_sample(orc, hs["hip"], cfg, d["Xc"][:n], d["p1"][:n], np.concatenate(a.dtrajs).astype(np.int32), rng, 3000)
+    _check_assign_sample(orc, hs["hip"], cfg, d["Xp"][:n], d["p0"][:n],
+                         np.concatenate([p[:, 0] for p in a.pair_dtrajs]).astype(np.int32), rng, 3000)
+
+
+@pytest.mark.parametrize("variant", ["default", "small_lds_groups", "large_lds_groups", "exact_only"])
+def test_c5_shape_assign_million_rows_equals_oracle(c5_trained, hip_lib, monkeypatch, variant):
+    """hamsm_assign over 1.2 M rows at D = 64, 4 x 1250: the f32 form of the ranking pass (the bf16 x 3 form exists for D <= 32
+    only) with the centroid fragments swept through the LDS in groups -- default budget, 40 KB groups, 150 KB groups -- and the
+    exact f64 kernel alone: all labels equal each other's, and the oracle's on 4000 random rows"""
+    from msm_we_amd import _abi
+
+    cfg, d_small, hs, res, bm = c5_trained
+    env = {"default": {}, "small_lds_groups": {"HAMSM_FILTER_LDS_KB": "40"}, "large_lds_groups": {"HAMSM_FILTER_LDS_KB": "150"},
+           "exact_only": {"HAMSM_ASSIGN_FILTER": "0"}}[variant]
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    big = _shard(C5_ASSIGN, C5_ASSIGN.n_iters)
+    n = len(big["w"])
+    assert n >= 1_000_000
+    h = _abi.Hamsm(lib=hip_lib)
+    try:
+        h.set_geometry(cfg.D, 1, cfg.S)
+        h.set_mapper_rectilinear([synthetic.strata_boundaries(cfg.S)])
+        basis, target = synthetic.basis_target_bounds(cfg.S)
+        h.set_bounds(basis, target)
+        for s in range(cfg.S):
+            Cm, counts, csq = hs["hip"].get_centroids(s)
+            h.set_centroids(s, Cm, csq=csq)
+        d_X, d_p, d_l = h.to_device(big["Xc"]), h.to_device(big["p1"]), h.alloc(n, np.int32)
+        h.assign(d_X, 0, cfg.D, d_p, n, d_l)
+        lab = d_l.to_host()
+        _check_assign_sample(hs["oracle"], h, cfg, big["Xc"], big["p1"], lab, np.random.default_rng(25), 4000)
+        K = cfg.S * cfg.K_s
+        tgt = big["p1"][:, 0] > cfg.S - 0.05
+        bas = big["p1"][:, 0] < 0.05
+        assert np.all(lab[tgt] == K + 1) and np.all(lab[bas & ~tgt] == K) and lab[~(tgt | bas)].max() < K
+        ref = c5_trained[3].setdefault("_assign_ref", lab)     # the first variant's labels: every later variant must equal them
+        assert np.array_equal(lab, ref)
+    finally:
+        h.close()
