@@ -65,6 +65,9 @@ struct hamsm_ctx {
   hipStream_t side_stream[3] = {nullptr, nullptr, nullptr};
   hipEvent_t ev_fork = nullptr, ev_join[3] = {nullptr, nullptr, nullptr};
   int step_lanes = 2;  // queues used by the training steps (HAMSM_STEP_LANES = 1..4)
+  int train_persist = 0;  // HAMSM_TRAIN_PERSIST=1: planned training passes run as ONE persistent launch (measured slower than the
+                          // multi-kernel path on every shape tried -- DESIGN.md §5.3a -- and therefore off; kept as a tested alternative)
+  int persist_wpx = 64;   // workgroups per XCD of that launch (HAMSM_PERSIST_WPX, 8 XCDs: grid = 8 x this)
   // hamsm_malloc / hamsm_free keep released blocks for reuse (hipMalloc costs ~1 ms per 40 MB block and hipFree
   // synchronises the device; every use of a block is ordered on `stream`, so reuse needs no synchronisation)
   std::unordered_map<void *, size_t> blk_live;

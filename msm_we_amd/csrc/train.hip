@@ -1569,6 +1569,660 @@ __global__ __launch_bounds__(256) void k_step_reassign(const StepDev *__restrict
   }
 }
 
+// ===================================================================================================
+// Persistent training pass: every step of every stratum in ONE launch.
+//
+// A stratum's chain of partial_fits is a strict sequence E-step -> M-step -> E-step ...: all rows need all centroids, every
+// centroid needs all its member rows.  As separate kernels each hand-off costs a kernel boundary plus the start and the
+// drain of a grid (~4 us of each ~8 us kernel).  Here the workgroups that landed on one XCD serve one stratum for its
+// whole chain: they share that XCD's L2, so the two hand-offs per step are an XCD-LOCAL barrier -- stores drained to L2
+// (the vector L1 is write-through), one atomic on a counter, one polling lane, and every load of handed-off bytes a
+// `global_load ... sc1` (bypasses the reader's L1, served by the shared L2).  No L2 write-back / invalidate (the
+// agent-scope fences cost 1.7 us each) is needed, because no other XCD ever reads these bytes inside the launch.
+//
+// Placement is not assumed: a workgroup reads its XCD from the hardware register, registers there (rank within the XCD),
+// one chip-wide arrival count closes the registration, and strata are dealt over the XCDs that actually received
+// workgroups (an XCD serves several strata one chain after the other when there are more strata than populated XCDs).
+// Every spin is bounded by the 100 MHz wall clock; a timeout sets `ctl->err` and the workgroup leaves (1 = during
+// registration, nothing has been modified and the host takes the multi-kernel path; 2 = inside a chain: an error).
+//
+// Arithmetic, orders and the stop protocol are those of k_step_assign / k_step_update / k_step_reassign / k_step_check
+// above (same descriptors, same report / halt / reason words): results are bit-identical to that path and to the oracle.
+#ifndef PERSIST_ATOMIC_SCOPE
+// Atomics on words shared by the workgroups of ONE XCD are performed in that XCD's L2 at workgroup scope (at agent scope
+// they travel beyond the L2s: ~2x the latency).  -DPERSIST_ATOMIC_SCOPE=__HIP_MEMORY_SCOPE_AGENT builds the conservative form.
+#define PERSIST_ATOMIC_SCOPE __HIP_MEMORY_SCOPE_WORKGROUP
+#endif
+struct PersistCtl {     // zeroed by one hipMemsetAsync before every launch
+  unsigned arrive_all;  // registration: workgroups that have registered
+  unsigned err;         // 0, 1 = registration timed out, 2 = a barrier timed out
+  unsigned nwg_xcd[8];  // workgroups per XCD
+  unsigned pad[6];
+  unsigned bar[];       // [S] one monotonic arrival counter per stratum
+};
+
+template <typename T>
+__device__ __forceinline__ T ld_l2(const GAS T *p) {  // global_load ... sc1: never served by this CU's L1
+  if constexpr (sizeof(T) == 8) {
+    unsigned long long v = __hip_atomic_load((const GAS unsigned long long *)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return __builtin_bit_cast(T, v);
+  } else {
+    static_assert(sizeof(T) == 4, "ld_l2: 4 or 8 bytes");
+    unsigned v = __hip_atomic_load((const GAS unsigned *)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return __builtin_bit_cast(T, v);
+  }
+}
+
+#define PERSIST_TMO_REG 2000000ull    // 20 ms of 100 MHz ticks: every workgroup of the grid resident and registered
+#define PERSIST_TMO_BAR 30000000ull   // 300 ms per barrier (a phase takes microseconds)
+
+// XCD-local barrier among the W workgroups that serve one stratum.  `sh_ok` is an LDS word of the caller.
+__device__ __forceinline__ bool xcd_barrier(GAS unsigned *bar, unsigned target, GAS unsigned *err, int *sh_ok) {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every wave: its stores and atomics have reached the L2
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    __hip_atomic_fetch_add(bar, 1u, __ATOMIC_RELAXED, PERSIST_ATOMIC_SCOPE);
+    int ok = 1;
+    const unsigned long long t0 = wall_clock64();
+    while ((int)(ld_l2(bar) - target) < 0) {
+      __builtin_amdgcn_s_sleep(1);
+      if (wall_clock64() - t0 > PERSIST_TMO_BAR || ld_l2(err) != 0u) {
+        __hip_atomic_store(err, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        ok = 0;
+        break;
+      }
+    }
+    *sh_ok = ok;
+  }
+  __syncthreads();
+  asm volatile("" ::: "memory");
+  return *sh_ok != 0;
+}
+
+// The phases are separate (non-inlined) functions: each keeps only its own operands live (as one body the kernel needed more
+// than 256 VGPRs).  LDS scratch is handed in by the kernel.
+struct PersistLds {
+  double sd[4][32];
+  int sj[4][32];
+  double shd[4];
+  int shi[4];
+  int lj[256], lr[256];
+  int sh_i[16];
+};
+
+// low-count test of the stratum's previous step / zero-count test before this one -- workgroup 0 of k_step_assign
+__device__ __attribute__((noinline)) void persist_precheck(const StepDev *sp, double ratio, PersistLds *L) {
+  const StepDev &sdesc = *sp;
+  const StepG st(sdesc);
+  const int tid = threadIdx.x;
+  const double inf = __builtin_huge_val();
+  GAS int32_t *halt = gp(sdesc.halt);
+  const GAS int32_t *prev = gp(sdesc.prev_report);
+  int z = 0;
+  double mx = -inf;
+  for (int j = tid; j < st.K; j += 256) {
+    double cj = ld_l2(st.counts + j);
+    z |= (cj == 0.0);
+    mx = cj > mx ? cj : mx;
+  }
+  int any_low = 0;
+  if (st.flags & 4) {
+    mx = block_max_f64(mx, L->shd);
+    const double thr = ratio * mx;
+    int low = 0;
+    for (int j = tid; j < st.K; j += 256) low += ld_l2(st.counts + j) < thr;
+    if (low) __hip_atomic_fetch_add((GAS int32_t *)prev + 1, low, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    any_low = __syncthreads_or(low);
+  }
+  const int any_z = __syncthreads_or((st.flags & 2) ? z : 0);
+  if (tid == 0) {
+    if (any_low) {
+      *halt = st.idx;
+      *gp(sdesc.reason) = HAMSM_STOP_LOW;
+    } else if (any_z) {
+      st.report[0] = 1;
+      *halt = st.idx;
+      *gp(sdesc.reason) = HAMSM_STOP_ZERO;
+    }
+  }
+}
+
+// The batch rows are static data: the rows a workgroup will need for the stratum's NEXT step are requested while the
+// current step's M-step runs and parked in an LDS slab (PF_TILES tiles of 16 rows, row stride 4 KS + 1 elements), so that
+// the E-step starts from LDS instead of two dependent global round trips (row index -> row).  Workgroup `erank` of `We`
+// owns the tiles erank, erank + We, ...; tiles beyond the slab (fewer workgroups on this XCD than expected) are loaded
+// directly.  Slots past D hold the row's last feature and rows past the batch its last row, as k_step_assign reads them.
+#define PF_TILES 4
+#ifdef PERSIST_FINE
+__device__ unsigned long long g_persist_fine[16];
+extern "C" int hamsm_debug_persist_fine(unsigned long long *h_out) {
+  if (hipMemcpyFromSymbol(h_out, HIP_SYMBOL(g_persist_fine), sizeof(unsigned long long) * 16) != hipSuccess) return -1;
+  unsigned long long z[16] = {0};
+  hipMemcpyToSymbol(HIP_SYMBOL(g_persist_fine), z, sizeof z);
+  return 0;
+}
+#define FSTAMP_INIT unsigned long long f_last = wall_clock64();
+#define FSTAMP(slot, cond)                                                \
+  {                                                                       \
+    __builtin_amdgcn_s_waitcnt(0);                                        \
+    if ((cond) && threadIdx.x == 0) {                                     \
+      const unsigned long long n_ = wall_clock64();                       \
+      atomicAdd(&g_persist_fine[slot], n_ - f_last);                      \
+      f_last = n_;                                                        \
+    }                                                                     \
+  }
+#else
+#define FSTAMP_INIT
+#define FSTAMP(slot, cond)
+#endif
+template <typename XT, int KS>
+__device__ __forceinline__ void persist_pf_issue(const StepDev *sp, int erank, int We, int64_t ldx, int D, XT (&pf)[KS]) {
+  // thread t: slab row t / 4 (tile t / 64, row (t / 4) % 16), elements (t % 4) + 4 m
+  const int tid = threadIdx.x, srow = tid >> 2;
+  const long long n_b = sp->n_b;
+  const long long tile = (long long)erank + (long long)We * (srow >> 4);
+  long long r = tile * 16 + (srow & 15);
+  r = r < n_b ? r : n_b - 1;
+  r = r < 0 ? 0 : r;
+  const GAS int32_t *rows = gp(sp->rows);
+  const long long f = rows ? (long long)rows[r] : r;
+  const GAS XT *X = (const GAS XT *)gp((const XT *)sp->X);
+#pragma unroll
+  for (int m = 0; m < KS; m++) {
+    const int k = (tid & 3) + 4 * m;
+    pf[m] = X[f * ldx + (k < D ? k : D - 1)];
+  }
+}
+template <typename XT, int KS>
+__device__ __forceinline__ void persist_pf_store(XT *xa, const XT (&pf)[KS]) {
+  const int tid = threadIdx.x, srow = tid >> 2;
+#pragma unroll
+  for (int m = 0; m < KS; m++) xa[srow * (4 * KS + 1) + (tid & 3) + 4 * m] = pf[m];
+}
+
+// E-step: the row tiles erank, erank + We, ... of the step (16 rows each), RT at a time -- the arithmetic of k_step_assign
+template <typename XT, int KS, int JB, int RT>
+__device__ __attribute__((noinline)) void persist_estep(const StepDev *sp, int erank, int We, int64_t ldx, int D, PersistLds *L,
+                                                        const XT *xa) {
+  constexpr int RW = 16 * RT;
+  static_assert(RW <= 32, "PersistLds::sd holds 32 rows");
+  static_assert(PF_TILES % RT == 0, "a pass never straddles the slab's end");
+  const StepDev &sdesc = *sp;
+  const StepG st(sdesc);
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const double inf = __builtin_huge_val();
+  const GAS XT *X = (const GAS XT *)st.X;
+  const int njt = (st.K + 15) >> 4;
+  const long long ntile = (st.n_b + 15) >> 4;
+  double b[JB][KS], cs[JB][4];
+  auto load_group = [&](int t0) {
+#pragma unroll
+    for (int u = 0; u < JB; u++) {
+      const int jt = t0 + 4 * u < njt ? t0 + 4 * u : njt - 1;
+#pragma unroll
+      for (int q = 0; q < 4; q++) cs[u][q] = ld_l2(st.csq + jt * 16 + (lane >> 4) + 4 * q);
+#pragma unroll
+      for (int ks = 0; ks < KS; ks++) b[u][ks] = ld_l2(st.Bpack + ((size_t)jt * KS + ks) * 64 + lane);
+    }
+  };
+  const bool one_group = njt <= 4 * JB;  // the stratum's operands stay in registers for all of the workgroup's tiles
+  FSTAMP_INIT
+  if (one_group) load_group(wv);
+  FSTAMP(0, erank == 0)
+  // pass p covers this workgroup's tiles number p RT .. p RT + RT - 1 (tile number q = tile erank + q We)
+  for (int q0 = 0; (long long)erank + (long long)We * q0 < ntile; q0 += RT) {
+    long long tile[RT];
+#pragma unroll
+    for (int rt = 0; rt < RT; rt++) tile[rt] = (long long)erank + (long long)We * (q0 + rt);
+    double a[RT][KS];
+    if (q0 < PF_TILES) {
+#pragma unroll
+      for (int rt = 0; rt < RT; rt++)
+#pragma unroll
+        for (int ks = 0; ks < KS; ks++) a[rt][ks] = (double)xa[((q0 + rt) * 16 + (lane & 15)) * (4 * KS + 1) + ks * 4 + (lane >> 4)];
+    } else {
+      long long f[RT];
+#pragma unroll
+      for (int rt = 0; rt < RT; rt++) {
+        const long long r = tile[rt] * 16 + (lane & 15);
+        const long long rc = r < st.n_b ? r : st.n_b - 1;
+        f[rt] = st.rows ? (long long)st.rows[rc] : rc;
+      }
+#pragma unroll
+      for (int rt = 0; rt < RT; rt++)
+#pragma unroll
+        for (int ks = 0; ks < KS; ks++) {
+          const int k = ks * 4 + (lane >> 4);
+          a[rt][ks] = (double)X[f[rt] * ldx + (k < D ? k : D - 1)];
+        }
+    }
+    double bd[RT];
+    int bi[RT];
+#pragma unroll
+    for (int rt = 0; rt < RT; rt++) {
+      bd[rt] = inf;
+      bi[rt] = 0x7fffffff;
+    }
+    FSTAMP(1, erank == 0)
+    for (int t0 = wv; t0 < njt; t0 += 4 * JB) {
+      if (!one_group) load_group(t0);
+#pragma unroll
+      for (int u = 0; u < JB; u++) {
+        const int jt = t0 + 4 * u;
+        if (jt < njt) {
+          v4f64 acc[RT];
+#pragma unroll
+          for (int rt = 0; rt < RT; rt++) acc[rt] = (v4f64){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+          for (int ks = 0; ks < KS; ks++)
+#pragma unroll
+            for (int rt = 0; rt < RT; rt++) acc[rt] = __builtin_amdgcn_mfma_f64_16x16x4f64(b[u][ks], a[rt][ks], acc[rt], 0, 0, 0);
+          const int j0 = jt * 16 + (lane >> 4);
+#pragma unroll
+          for (int rt = 0; rt < RT; rt++)
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+              double d = __builtin_fma(-2.0, acc[rt][q], cs[u][q]);
+              bool lt = d < bd[rt];
+              bd[rt] = lt ? d : bd[rt];
+              bi[rt] = lt ? j0 + 4 * q : bi[rt];
+            }
+        }
+      }
+    }
+    FSTAMP(2, erank == 0)
+    // the batch rows as f64 for the M-step (rows of 4 KS doubles; the buffer is padded to 64-row multiples)
+#pragma unroll
+    for (int rt = 0; rt < RT; rt++)
+      if (((rt + 1) & 3) == wv && tile[rt] < ((st.n_b + 63) >> 6) * 4) {
+        const long long r = tile[rt] * 16 + (lane & 15);
+#pragma unroll
+        for (int ks = 0; ks < KS; ks++) st.Xg[(size_t)r * (4 * KS) + ks * 4 + (lane >> 4)] = a[rt][ks];
+      }
+#pragma unroll
+    for (int rt = 0; rt < RT; rt++) {
+      double d = bd[rt];
+      int j = bi[rt];
+#pragma unroll
+      for (int off = 16; off <= 32; off <<= 1) {
+        double d2 = __shfl_xor(d, off, 64);
+        int j2 = __shfl_xor(j, off, 64);
+        bool take = (d2 < d) || (d2 == d && j2 < j);
+        d = take ? d2 : d;
+        j = take ? j2 : j;
+      }
+      if (lane < 16) {
+        L->sd[wv][rt * 16 + lane] = d;
+        L->sj[wv][rt * 16 + lane] = j;
+      }
+    }
+    __syncthreads();
+    if (tid < RW) {
+      const long long r = ((long long)erank + (long long)We * (q0 + (tid >> 4))) * 16 + (tid & 15);
+      if (r < st.n_b) {
+        double d = L->sd[0][tid];
+        int j = L->sj[0][tid];
+#pragma unroll
+        for (int w = 1; w < 4; w++) {
+          double d2 = L->sd[w][tid];
+          int j2 = L->sj[w][tid];
+          bool take = (d2 < d) || (d2 == d && j2 < j);
+          d = take ? d2 : d;
+          j = take ? j2 : j;
+        }
+        if (j == 0x7fffffff) j = 0;
+        st.labels[r] = j;
+        __hip_atomic_fetch_or(&st.mbits[(size_t)j * sdesc.wstride + (r >> 6)], 1ull << (r & 63), __ATOMIC_RELAXED,
+                              PERSIST_ATOMIC_SCOPE);
+      }
+    }
+    __syncthreads();  // sd / sj are reused by the next pass
+    FSTAMP(3, erank == 0)
+  }
+}
+
+// M-step: one wave per centroid (rank * 4 + wave, + 4 W, ...) -- the arithmetic of k_step_update<H = 1>
+template <typename XT, int KS>
+__device__ __attribute__((noinline)) void persist_mstep(const StepDev *sp, int rank, int W, int D, int *lds_i, const StepDev *sp_next,
+                                                        int erank, int We, int64_t ldx, XT *xa) {
+  const StepDev &sdesc = *sp;
+  const StepG st(sdesc);
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  // the next step's rows of this workgroup: requested now, parked in the slab when this M-step is done (the E-step that
+  // read the slab finished before the barrier in front of this call)
+  XT pf[KS];
+  FSTAMP_INIT
+  if (sp_next) persist_pf_issue<XT, KS>(sp_next, erank, We, ldx, D, pf);
+  FSTAMP(4, rank == 0)
+  int *list = lds_i + wv * UPD_LIST;
+  unsigned *srow = (unsigned *)list;
+  double *swl = (double *)(list + UPD_SC);
+  const GAS double *Xg = st.Xg;
+  const int ldg = 4 * KS;
+  const int nw = (int)((st.n_b + 63) >> 6);
+  const bool weighted = st.wf != nullptr;
+  const int kq = lane < D ? lane : D - 1;
+  for (int j = rank * 4 + wv; j < st.K; j += 4 * W) {
+    GAS unsigned long long *mb = st.mbits + (size_t)j * sdesc.wstride;
+    const double cnt0 = ld_l2(st.counts + j);
+    double acc = ld_l2(st.C + (size_t)j * D + kq) * cnt0;  // (KS <= 16: D <= 64, one feature per lane)
+    double wsum = 0.0;
+    long long total = 0;
+    for (int wb = 0; wb < nw; wb += 64) {
+      // read and clear in one: the word is ready for the stratum's next step (wstride is a multiple of 64)
+      const unsigned long long w = __hip_atomic_exchange(mb + wb + lane, 0ull, __ATOMIC_RELAXED, PERSIST_ATOMIC_SCOPE);
+      FSTAMP(5, rank == 0)
+      const int pc = __popcll(w);
+      int inc = pc;
+#pragma unroll
+      for (int off = 1; off < 64; off <<= 1) {
+        const int t = __shfl_up(inc, off, 64);
+        inc += lane >= off ? t : 0;
+      }
+      const int excl = inc - pc, blk = __shfl(inc, 63, 64);
+      for (int p0 = 0; p0 < blk; p0 += UPD_SC) {
+        {
+          unsigned long long t = w;
+          int idx = excl - p0;
+          while (t) {
+            const int bit = __builtin_ctzll(t);
+            t &= t - 1;
+            if (idx >= 0 && idx < UPD_SC) srow[idx] = (unsigned)((wb + lane) * 64 + bit);
+            idx++;
+          }
+        }
+        const int np = blk - p0 < UPD_SC ? blk - p0 : UPD_SC;
+        for (int m0 = 0; m0 < np; m0 += 64) {
+          const int cm = np - m0 < 64 ? np - m0 : 64;
+          if (weighted) {
+            if (lane < cm) {
+              const long long r = srow[m0 + lane];
+              swl[lane] = st.wf[st.rows ? (long long)st.rows[r] : r];
+            }
+            for (int q = 0; q < cm; q++) wsum = wsum + swl[q];
+          }
+          // member rows: up to 32 requested before the first add, added in sample order
+          for (int q0 = 0; q0 < cm; q0 += 32) {
+            double xv[32];
+#pragma unroll
+            for (int q = 0; q < 32; q++) {
+              const int mq = q0 + q < cm ? q0 + q : cm - 1;
+              xv[q] = ld_l2(Xg + (size_t)srow[m0 + mq] * ldg + kq);
+            }
+#pragma unroll
+            for (int q = 0; q < 32; q++) {
+              const int mq = q0 + q < cm ? q0 + q : cm - 1;
+              const double wq = weighted ? swl[mq] : 1.0;
+              const double nv = acc + xv[q] * wq;
+              acc = (q0 + q < cm) ? nv : acc;
+            }
+          }
+        }
+      }
+      total += blk;
+    }
+    FSTAMP(6, rank == 0)
+    if (total == 0) continue;
+    if (!weighted) wsum = (double)total;
+    if (!(wsum > 0)) continue;
+    const double cnt1 = cnt0 + wsum;
+    const double alpha = 1.0 / cnt1;
+    const double v = acc * alpha;
+    if (lane < D) {
+      st.C[(size_t)j * D + lane] = v;
+      st.Bpack[((size_t)(j >> 4) * KS + (lane >> 2)) * 64 + (lane & 3) * 16 + (j & 15)] = v;
+    }
+    if (lane == 0) st.counts[j] = cnt1;
+    double *vb = (double *)list;
+    vb[lane] = lane < D ? v : 0.0;
+    double a2 = 0.0;
+    for (int k = 0; k + 1 < D; k += 2) {
+      const double2 t = *(const double2 *)&vb[k];
+      a2 = __builtin_fma(t.x, t.x, a2);
+      a2 = __builtin_fma(t.y, t.y, a2);
+    }
+    if (D & 1) a2 = __builtin_fma(vb[D - 1], vb[D - 1], a2);
+    if (lane == 0) st.csq[j] = a2;
+    FSTAMP(7, rank == 0)
+  }
+  if (sp_next) persist_pf_store<XT, KS>(xa, pf);
+  FSTAMP(8, rank == 0)
+}
+
+// re-seeding of low-count centroids from the permutation head the step carries -- k_step_reassign (one workgroup)
+template <typename XT, int KS>
+__device__ __attribute__((noinline)) void persist_reassign(const StepDev *sp, int64_t ldx, int D, double ratio, PersistLds *L) {
+  const StepDev &sdesc = *sp;
+  const StepG st(sdesc);
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const double inf = __builtin_huge_val();
+  const GAS XT *X = (const GAS XT *)st.X;
+  double mx = -inf;
+  for (int j = tid; j < st.K; j += 256) {
+    const double cj = ld_l2(st.counts + j);
+    mx = cj > mx ? cj : mx;
+  }
+  mx = block_max_f64(mx, L->shd);
+  const double thr = ratio * mx;
+  int low = 0;
+  double mn = -inf;
+  for (int j = tid; j < st.K; j += 256) {
+    const double cj = ld_l2(st.counts + j);
+    if (cj < thr) low++;
+    else mn = -cj > mn ? -cj : mn;
+  }
+  low = block_sum_i32(low, L->shi);
+  const double new_count = -block_max_f64(mn, L->shd);
+  if (tid == 0) st.report[1] = low;
+  int why = 0;
+  if (low == 0) why = HAMSM_STOP_UNUSED;
+  else if (low > sdesc.n_perm || (double)low > 0.5 * (double)st.n_b) why = HAMSM_STOP_CAP;
+  if (why) {
+    if (tid == 0) {
+      *gp(sdesc.halt) = st.idx + 1;
+      *gp(sdesc.reason) = why;
+    }
+    return;
+  }
+  const GAS int32_t *perm = gp(sdesc.perm);
+  int base = 0;
+  for (int j0 = 0; j0 < st.K; j0 += 256) {
+    const int j = j0 + tid;
+    const bool flag = j < st.K && ld_l2(st.counts + (j < st.K ? j : 0)) < thr;
+    const unsigned long long bal = __ballot(flag);
+    const int in_wave = __popcll(bal & ((1ull << lane) - 1));
+    __syncthreads();
+    if (lane == 0) L->shi[wv] = __popcll(bal);
+    __syncthreads();
+    int before = 0, total = 0;
+#pragma unroll
+    for (int w = 0; w < 4; w++) {
+      before += w < wv ? L->shi[w] : 0;
+      total += L->shi[w];
+    }
+    if (flag) {
+      const int e = before + in_wave;
+      L->lj[e] = j;
+      L->lr[e] = perm[base + e];
+    }
+    __syncthreads();
+    for (int e = wv; e < total; e += 4) {
+      const int jc = L->lj[e];
+      const long long r = L->lr[e];
+      const long long fr = st.rows ? (long long)st.rows[r] : r;
+      const double v = (lane < D) ? (double)X[fr * ldx + lane] : 0.0;
+      if (lane < D) {
+        st.C[(size_t)jc * D + lane] = v;
+        st.Bpack[((size_t)(jc >> 4) * KS + (lane >> 2)) * 64 + (lane & 3) * 16 + (jc & 15)] = v;
+      }
+      double a2 = 0.0;
+      for (int k = 0; k < D; k++) {
+        const double vk = readlane_f64(v, k);
+        a2 = __builtin_fma(vk, vk, a2);
+      }
+      if (lane == 0) {
+        st.csq[jc] = a2;
+        st.counts[jc] = new_count;
+      }
+    }
+    base += total;
+    __syncthreads();
+  }
+}
+
+// low-count test of a chain's LAST step when no permutation came with it -- k_step_check
+__device__ __attribute__((noinline)) void persist_tailcheck(const StepDev *sp, double ratio, int n_steps, PersistLds *L) {
+  const StepDev &sdesc = *sp;
+  const StepG st(sdesc);
+  const int tid = threadIdx.x;
+  double mx = -__builtin_huge_val();
+  for (int j = tid; j < st.K; j += 256) {
+    const double cj = ld_l2(st.counts + j);
+    mx = cj > mx ? cj : mx;
+  }
+  mx = block_max_f64(mx, L->shd);
+  const double thr = ratio * mx;
+  int low = 0;
+  for (int j = tid; j < st.K; j += 256) low += ld_l2(st.counts + j) < thr;
+  low = block_sum_i32(low, L->shi);
+  if (tid == 0 && low) {
+    st.report[1] = low;
+    *gp(sdesc.halt) = n_steps;
+    *gp(sdesc.reason) = HAMSM_STOP_LOW;
+  }
+}
+
+// phase timers of the persistent pass (HAMSM_PERSIST_PROF=1): 100 MHz ticks summed over the steps, as seen by thread 0 of
+// every workgroup with rank 0 (one per stratum): [0] tests, [1] E-step, [2] wait at barrier A, [3] M-step, [4] re-seeding,
+// [5] wait at barrier B, [6] steps, [7] whole chain
+__device__ unsigned long long g_persist_prof[8];
+extern "C" int hamsm_debug_persist_profile(unsigned long long *h_out, int reset) {
+  if (hipMemcpyFromSymbol(h_out, HIP_SYMBOL(g_persist_prof), sizeof(unsigned long long) * 8) != hipSuccess) return -1;
+  if (reset) {
+    unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (hipMemcpyToSymbol(HIP_SYMBOL(g_persist_prof), z, sizeof z) != hipSuccess) return -1;
+  }
+  return 0;
+}
+#define PPROF(slot)                                                              \
+  if (prof && rank == 0 && tid == 0) {                                           \
+    const unsigned long long now_ = wall_clock64();                              \
+    atomicAdd(&g_persist_prof[slot], now_ - t_last);                             \
+    t_last = now_;                                                               \
+  }
+
+template <typename XT, int KS, int JB>
+__global__ __launch_bounds__(256, 2) void k_train_persist(const StepDev *__restrict__ steps, const int *__restrict__ chain_off,
+                                                          const int *__restrict__ chain_idx, PersistCtl *ctl_, int S,
+                                                          int64_t ldx, int D, double ratio, int n_steps, int prof) {
+  constexpr int RT = 2;  // row tiles in flight per workgroup pass
+  const int tid = threadIdx.x;
+  GAS PersistCtl *ctl = (GAS PersistCtl *)ctl_;
+  GAS unsigned *err = &ctl->err;
+  __shared__ PersistLds L;
+  extern __shared__ int lds_i[];  // M-step strips: 4 x UPD_LIST ints
+
+  // ---- registration ---------------------------------------------------------------------------------
+  unsigned xcc;
+  asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+  xcc &= 7;
+  if (tid == 0) {
+    // (agent scope: every XCD must see these)
+    L.sh_i[0] = (int)__hip_atomic_fetch_add(&ctl->nwg_xcd[xcc], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __hip_atomic_fetch_add(&ctl->arrive_all, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    int ok = 1;
+    const unsigned long long t0 = wall_clock64();
+    while (ld_l2(&ctl->arrive_all) < gridDim.x) {
+      __builtin_amdgcn_s_sleep(2);
+      if (wall_clock64() - t0 > PERSIST_TMO_REG || ld_l2(err) != 0u) {
+        __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        ok = 0;
+        break;
+      }
+    }
+    L.sh_i[1] = ok;
+    int n_act = 0, mine = -1;
+    for (int x = 0; x < 8; x++) {
+      const unsigned nx = ld_l2(&ctl->nwg_xcd[x]);
+      if (x == (int)xcc) {
+        mine = n_act;
+        L.sh_i[2] = (int)nx;
+      }
+      n_act += nx > 0;
+    }
+    L.sh_i[3] = n_act;
+    L.sh_i[4] = mine;
+  }
+  __syncthreads();
+  if (!L.sh_i[1]) return;
+  const int rank = L.sh_i[0], W = L.sh_i[2], n_act = L.sh_i[3], a_idx = L.sh_i[4];
+  __syncthreads();
+
+  // workgroup W - 1 of an XCD runs the tests that ride on a step (they need the counts the previous M-step left: 2 us of
+  // dependent reductions) instead of row tiles; the tiles are dealt over the other W - 1
+  const int We = W > 1 ? W - 1 : 1, erank = rank < We ? rank : -1;
+  const bool tester = rank == W - 1;
+  XT *xa = (XT *)(lds_i + 4 * UPD_LIST);  // [PF_TILES * 16][4 KS + 1]
+  for (int s = a_idx; s < S; s += n_act) {
+    GAS unsigned *bar = &ctl->bar[s];
+    unsigned epoch = 0;
+    const int c0 = chain_off[s], c1 = chain_off[s + 1];
+    int last_ci = -1;
+    bool stopped = false;
+    unsigned long long t_last = wall_clock64();
+    const unsigned long long t_chain = t_last;
+    // first step of the chain with rows: its slab is filled here
+    int ci = c0;
+    while (ci < c1 && steps[__builtin_amdgcn_readfirstlane(chain_idx[ci])].n_b <= 0) ci++;
+    if (ci < c1 && erank >= 0) {
+      XT pf[KS];
+      persist_pf_issue<XT, KS>(steps + __builtin_amdgcn_readfirstlane(chain_idx[ci]), erank, We, ldx, D, pf);
+      persist_pf_store<XT, KS>(xa, pf);
+    }
+    __syncthreads();
+    for (; ci < c1;) {
+      const StepDev *sp = steps + __builtin_amdgcn_readfirstlane(chain_idx[ci]);  // static, uniform: scalar loads
+      int cn = ci + 1;  // the stratum's next step with rows (the multi-kernel path launches nothing for empty ones either)
+      while (cn < c1 && steps[__builtin_amdgcn_readfirstlane(chain_idx[cn])].n_b <= 0) cn++;
+      const StepDev *sp_next = cn < c1 ? steps + __builtin_amdgcn_readfirstlane(chain_idx[cn]) : nullptr;
+      last_ci = ci;
+      ci = cn;
+      GAS int32_t *halt = gp(sp->halt);
+      const int idx = sp->idx, flags = sp->flags;
+      // the tests that ride on the step (the counts are final since the previous step's barrier) beside the E-step
+      if (tester && (flags & 6) && idx < ld_l2(halt)) persist_precheck(sp, ratio, &L);
+      PPROF(0)
+      if (erank >= 0) persist_estep<XT, KS, JB, RT>(sp, erank, We, ldx, D, &L, xa);
+      PPROF(1)
+      if (!xcd_barrier(bar, (unsigned)W * ++epoch, err, &L.sh_i[8])) return;
+      PPROF(2)
+      // the stratum's chain stops here when a test said so: every workgroup reads the same word in the same window
+      // (nobody writes it between this barrier and the next)
+      if (idx >= ld_l2(halt)) {
+        stopped = true;
+        break;
+      }
+      persist_mstep<XT, KS>(sp, rank, W, D, lds_i, erank >= 0 ? sp_next : nullptr, erank, We, ldx, xa);
+      PPROF(3)
+      if ((flags & 1) && sp->perm) {
+        if (!xcd_barrier(bar, (unsigned)W * ++epoch, err, &L.sh_i[8])) return;
+        if (rank == 0 && idx < ld_l2(halt)) persist_reassign<XT, KS>(sp, ldx, D, ratio, &L);
+        PPROF(4)
+      }
+      if (!xcd_barrier(bar, (unsigned)W * ++epoch, err, &L.sh_i[8])) return;
+      PPROF(5)
+      if (prof && rank == 0 && tid == 0) atomicAdd(&g_persist_prof[6], 1ull);
+    }
+    if (prof && rank == 0 && tid == 0) atomicAdd(&g_persist_prof[7], wall_clock64() - t_chain);
+    if (!stopped && last_ci >= 0 && rank == 0) {
+      const StepDev *sp = steps + __builtin_amdgcn_readfirstlane(chain_idx[last_ci]);
+      if ((sp->flags & 1) && !sp->perm && sp->idx < ld_l2(gp(sp->halt))) persist_tailcheck(sp, ratio, n_steps, &L);
+    }
+    __syncthreads();
+  }
+}
+
 template <typename XT, int KS, int RT, bool BYVAL>
 static void launch_step_kernels(hamsm_ctx *c, hipStream_t q, const StepDev *d_steps, const StepPack &pk, int ny,
                                 long long max_nb, int maxK, int64_t ldx, double ratio, bool any_perm) {
@@ -1623,6 +2277,26 @@ static int launch_steps(hamsm_ctx *c, hipStream_t q, const StepDev *d_steps, con
   return HAMSM_OK;
 }
 
+template <typename XT>
+static int launch_persist(hamsm_ctx *c, const StepDev *d_steps, const int *d_coff, const int *d_cidx, PersistCtl *d_ctl,
+                          int64_t ldx, double ratio, int n_steps) {
+  const size_t lds = sizeof(int) * (4 * UPD_LIST) + sizeof(XT) * (PF_TILES * 16) * (4 * (size_t)c->KS + 1);
+  const dim3 grid((unsigned)(8 * c->persist_wpx)), block(256);
+  static const int prof = getenv("HAMSM_PERSIST_PROF") ? atoi(getenv("HAMSM_PERSIST_PROF")) : 0;
+  switch (c->KS) {
+#define CASE(KSV, JBV)                                                                                                   \
+  case KSV:                                                                                                              \
+    hipLaunchKernelGGL((k_train_persist<XT, KSV, JBV>), grid, block, lds, c->stream, d_steps, d_coff, d_cidx, d_ctl, c->S, ldx, \
+                       c->D, ratio, n_steps, prof);                                                                      \
+    break;
+    CASE(1, 8) CASE(2, 8) CASE(3, 8) CASE(4, 8) CASE(6, 4) CASE(8, 4) CASE(12, 2) CASE(16, 2)
+#undef CASE
+    default: return hamsm_fail(c, HAMSM_ENOTSUP, "persistent training: KS=%d", c->KS);
+  }
+  HIPCHK(c, hipGetLastError());
+  return HAMSM_OK;
+}
+
 // steps [0,n): consecutive steps of distinct strata share launches (grid.y)
 static int run_steps(hamsm_ctx *c, const void *X, int dt, int64_t ldx, const int32_t *d_rows, const double *d_w,
                      const hamsm_step *h_steps, int64_t n_steps, double ratio, const int32_t *h_perm, int64_t n_perm_total,
@@ -1661,6 +2335,9 @@ static int run_steps(hamsm_ctx *c, const void *X, int dt, int64_t ldx, const int
   for (int s = 0; s < c->S; s++) Kmax = c->st[s].K > Kmax ? c->st[s].K : Kmax;
   const int wstride = (int)((((nb_max + 63) >> 6) + 63) & ~(int64_t)63);  // bitmap words per centroid
   size_t o_mb = take(sizeof(unsigned long long) * (size_t)nslot * Kmax * wstride);
+  // persistent pass: control block (registration, error word, one barrier counter per stratum) and the strata's chains
+  const size_t ctl_bytes = (sizeof(PersistCtl) + sizeof(unsigned) * (size_t)c->S + 15) & ~(size_t)15;
+  size_t o_ctl = take(ctl_bytes), o_coff = take(sizeof(int) * ((size_t)c->S + 1)), o_cidx = take(sizeof(int) * (size_t)n_steps);
   int rc = hamsm_ensure_scratch(c, off);
   if (rc) return rc;
   char *b = (char *)c->scratch;
@@ -1735,6 +2412,42 @@ static int run_steps(hamsm_ctx *c, const void *X, int dt, int64_t ldx, const int
     HIPCHK(c, hipMemcpyAsync(b + o_perm, h_perm, sizeof(int32_t) * (size_t)n_perm_total, hipMemcpyHostToDevice, c->stream));
   HIPCHK(c, hipMemsetAsync(b + o_mb, 0, sizeof(unsigned long long) * (size_t)nslot * Kmax * wstride, c->stream));
   const StepDev *d_steps = (const StepDev *)(b + o_steps);
+  // One persistent launch for the whole run (§5.3a) when the run is a planned pass (row lists, a scratch slot per stratum,
+  // more than one launch group) of at most 64 features, when HAMSM_TRAIN_PERSIST=1 asks for it (off by default: §5.3a).
+  bool persist_done = false;
+  if (c->train_persist && h_report && d_rows && nslot == c->S && c->KS <= 16 && gstart.size() > 2 && n_steps < 0x7fffffff) {
+    std::vector<int> coff(c->S + 1, 0), cidx((size_t)n_steps);
+    for (int64_t i = 0; i < n_steps; i++) coff[h_steps[i].stratum + 1]++;
+    for (int s = 0; s < c->S; s++) coff[s + 1] += coff[s];
+    {
+      std::vector<int> fill(coff.begin(), coff.end() - 1);
+      for (int64_t i = 0; i < n_steps; i++) cidx[fill[h_steps[i].stratum]++] = (int)i;
+    }
+    HIPCHK(c, hipMemcpyAsync(b + o_coff, coff.data(), sizeof(int) * coff.size(), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(b + o_cidx, cidx.data(), sizeof(int) * cidx.size(), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemsetAsync(b + o_ctl, 0, ctl_bytes, c->stream));
+    hamsm_timer_begin(c);
+    rc = (dt == HAMSM_F32) ? launch_persist<float>(c, d_steps, (const int *)(b + o_coff), (const int *)(b + o_cidx),
+                                                   (PersistCtl *)(b + o_ctl), ldx, ratio, (int)n_steps)
+                           : launch_persist<double>(c, d_steps, (const int *)(b + o_coff), (const int *)(b + o_cidx),
+                                                    (PersistCtl *)(b + o_ctl), ldx, ratio, (int)n_steps);
+    hamsm_timer_end(c, ST_STEP);
+    if (rc) {
+      hipDeviceSynchronize();
+      return rc;
+    }
+    unsigned perr = 0;
+    HIPCHK(c, hipMemcpyAsync(&perr, b + o_ctl + offsetof(PersistCtl, err), sizeof(unsigned), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));  // (also: coff / cidx / sd are locals the uploads read)
+    if (perr == 0) persist_done = true;
+    else if (perr == 1) {
+      // not every workgroup of the grid became resident: nothing was modified; this context keeps to the multi-kernel path
+      c->train_persist = 0;
+      fprintf(stderr, "[hamsm] persistent training launch could not register all workgroups: using the multi-kernel path\n");
+    } else
+      return hamsm_fail(c, HAMSM_EDEVICE, "persistent training kernel: a barrier timed out (ctl.err=%u)", perr);
+  }
+  if (!persist_done) {
   hamsm_timer_begin(c);
   // lanes: stratum s always runs on queue s % n_lanes, so every stratum's chain stays ordered; a lane's part of a
   // launch group travels by value (<= PACK_NY strata) -- otherwise one queue and descriptors in memory
@@ -1814,6 +2527,7 @@ static int run_steps(hamsm_ctx *c, const void *X, int dt, int64_t ldx, const int
   for (int64_t i : tail_checks)
     hipLaunchKernelGGL(k_step_check, dim3(1), dim3(256), 0, c->stream, d_steps + i, ratio, (int)n_steps);
   hamsm_timer_end(c, ST_STEP);
+  }  // !persist_done
   if (hipError_t le = hipGetLastError(); le != hipSuccess) {
     hipDeviceSynchronize();
     return hamsm_fail(c, HAMSM_EDEVICE, "step launches: %s", hipGetErrorString(le));
