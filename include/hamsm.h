@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define HAMSM_ABI_VERSION 3
+#define HAMSM_ABI_VERSION 4
 
 #define HAMSM_OK 0
 #define HAMSM_EINVAL (-1)   /* bad argument / call order                                         */
@@ -69,6 +69,19 @@ int hamsm_set_geometry(hamsm_ctx *ctx, int D, int pcoord_ndim, int n_strata);
 /* RectilinearBinMapper: per dimension n_bounds[d] float32 boundaries, concatenated in h_bounds.
  * bin_mapper.assign call sites: stratified_clustering.py:134, _clustering.py:877.                */
 int hamsm_set_mapper_rectilinear(hamsm_ctx *ctx, const int32_t *h_n_bounds, const float *h_bounds);
+/* VoronoiBinMapper with the Euclidean distance function (westpa: bin = argmin_c dfunc(p, centers); reference call sites
+ * as above, `find_nearest_bin` _clustering.py:1357-1396): n_centers == n_strata float32 centres [n][ndim]; the pcoord is cast
+ * to float32 like westpa's coord_dtype, squared distances are accumulated in float64 over ascending dimension, the first
+ * minimum wins.  westpa's source is not in the build image: restated from its documented behaviour, parity unpinned.       */
+int hamsm_set_mapper_voronoi(hamsm_ctx *ctx, int n_centers, const float *h_centers);
+/* Any other mapper (a Voronoi mapper with a user distance function, FuncBinMapper, recursive mappers ...): its `assign`
+ * is Python and runs on the host; the library then takes the bin of every frame from an array instead of computing it.
+ * After hamsm_set_mapper_external, hamsm_set_frame_bins names that array (int32, device, -1 = outside the bin space) for the
+ * NEXT call of hamsm_classify / hamsm_assign / hamsm_predict_host / hamsm_train_prepass: element i is the bin of the frame
+ * whose pcoord is d_pcoord[i] of that call (hamsm_predict_host: h_bins is a HOST array).                                   */
+int hamsm_set_mapper_external(hamsm_ctx *ctx);
+int hamsm_set_frame_bins(hamsm_ctx *ctx, const int32_t *d_bins);
+int hamsm_set_frame_bins_host(hamsm_ctx *ctx, const int32_t *h_bins, int64_t n);
 /* we_remap table (stratified_clustering.py:85,135; written at _clustering.py:730,1078).          */
 int hamsm_set_remap(hamsm_ctx *ctx, const int32_t *h_remap);
 /* basis / target pcoord boxes [ndim][2], strict inequalities (msm_we.py:462-527).                */

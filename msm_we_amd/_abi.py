@@ -20,7 +20,7 @@ _vp, _i32, _i64, _f64, _sz = C.c_void_p, C.c_int32, C.c_int64, C.c_double, C.c_s
 _int = C.c_int
 
 # name -> (restype, argtypes); kept in the order of include/hamsm.h
-ABI_VERSION = 3  # HAMSM_ABI_VERSION of include/hamsm.h
+ABI_VERSION = 4  # HAMSM_ABI_VERSION of include/hamsm.h
 
 SYMBOLS = {
     "hamsm_abi_version": (_int, []),
@@ -36,6 +36,10 @@ SYMBOLS = {
     "hamsm_sync": (_int, [_vp]),
     "hamsm_set_geometry": (_int, [_vp, _int, _int, _int]),
     "hamsm_set_mapper_rectilinear": (_int, [_vp, _vp, _vp]),
+    "hamsm_set_mapper_voronoi": (_int, [_vp, _int, _vp]),
+    "hamsm_set_mapper_external": (_int, [_vp]),
+    "hamsm_set_frame_bins": (_int, [_vp, _vp]),
+    "hamsm_set_frame_bins_host": (_int, [_vp, _vp, _i64]),
     "hamsm_set_remap": (_int, [_vp, _vp]),
     "hamsm_set_bounds": (_int, [_vp, _vp, _vp]),
     "hamsm_set_centroids": (_int, [_vp, _int, _int, _vp, _vp, _vp]),
@@ -252,6 +256,21 @@ class Hamsm:
         nb = np.array([len(b) for b in bs], dtype=np.int32)
         flat = np.concatenate(bs).astype(np.float32)
         self._ck(self.lib.hamsm_set_mapper_rectilinear(self.ctx, _hp(nb), _hp(flat)))
+
+    def set_mapper_voronoi(self, centers):
+        cs = np.ascontiguousarray(centers, dtype=np.float32).reshape(-1, self.ndim)
+        self._ck(self.lib.hamsm_set_mapper_voronoi(self.ctx, cs.shape[0], _hp(cs)))
+
+    def set_mapper_external(self):
+        self._ck(self.lib.hamsm_set_mapper_external(self.ctx))
+
+    def set_frame_bins(self, d_bins):
+        """external mapper: the bins of the frames of the NEXT classify / assign / train_prepass call (device int32)"""
+        self._ck(self.lib.hamsm_set_frame_bins(self.ctx, _dp(d_bins)))
+
+    def set_frame_bins_host(self, bins):
+        b = np.ascontiguousarray(bins, dtype=np.int32)
+        self._ck(self.lib.hamsm_set_frame_bins_host(self.ctx, _hp(b), b.size))
 
     def set_remap(self, remap):
         r = np.ascontiguousarray(remap, dtype=np.int32)

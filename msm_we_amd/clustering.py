@@ -63,16 +63,40 @@ class ClusteringMixin:
 
     # ------------------------------------------------------------------------------------------
     def _configure_device(self, bin_mapper, D):
-        """Push geometry / mapper / bounds (the state `predict` reads, hamsm.h 'model state')."""
+        """Push geometry / mapper / bounds (the state `predict` reads, hamsm.h 'model state').  Dispatch is by class name, as
+        in the reference (`SUPPORTED_MAPPERS`, `_clustering.py:598-609`): rectilinear and Euclidean Voronoi mappers are
+        evaluated on the device; a Voronoi mapper with a user distance function keeps its own `assign` (host) and the
+        library reads the bins from arrays (`_frame_bins`)."""
         h = self.h
-        if type(bin_mapper).__name__ != "RectilinearBinMapper":
-            # `_clustering.py:604-609`: only static mappers are supported; Voronoi is not built yet
-            raise Exception(f"{type(bin_mapper)} mapper is not supported (RectilinearBinMapper only)")
-        bounds = [np.asarray(b, dtype=np.float32) for b in bin_mapper.boundaries]
+        name = type(bin_mapper).__name__
         h.set_geometry(D, self.pcoord_ndim, bin_mapper.nbins)
-        h.set_mapper_rectilinear(bounds)
+        self._mapper_external = False
+        if name == "RectilinearBinMapper":
+            h.set_mapper_rectilinear([np.asarray(b, dtype=np.float32) for b in bin_mapper.boundaries])
+        elif name == "VoronoiBinMapper":
+            if getattr(bin_mapper.dfunc, "hamsm_kind", None) == "euclidean" and not getattr(bin_mapper, "dfargs", None) \
+                    and not getattr(bin_mapper, "dfkwargs", None):
+                h.set_mapper_voronoi(np.asarray(bin_mapper.centers, dtype=np.float32).reshape(bin_mapper.nbins, -1))
+            else:
+                h.set_mapper_external()
+                self._mapper_external = True
+        else:
+            # `_clustering.py:598-609`: functional mappers may re-bin on the fly -- unsupported there too
+            raise Exception(f"{type(bin_mapper)} mapper loaded, but supported mappers are RectilinearBinMapper and "
+                            f"VoronoiBinMapper. Please provide a supported user_bin_mapper.")
         h.set_bounds(self.basis_pcoord_bounds, self.target_pcoord_bounds)
         h._active_clusters = None
+
+    def _frame_bins(self, which, bin_mapper):
+        """external mapper: device int32 bins of every staged frame's parent (`p0`) / child (`p1`) pcoord, computed ONCE by
+        the mapper's own `assign` on the host and cached on the store"""
+        store = self._store
+        cache = store.__dict__.setdefault("_ext_bins", {})
+        key = (which, id(bin_mapper))
+        if key not in cache:
+            p = getattr(store, which).to_host().reshape(store.N, -1)
+            cache[key] = (self.h.to_device(np.asarray(bin_mapper.assign(p), dtype=np.int64).astype(np.int32)), bin_mapper)
+        return cache[key][0]
 
     def cluster_stratified(self, n_clusters, streaming=True, first_cluster_iter=None, use_ray=True, bin_iteration=2,
                            iters_to_use=None, user_bin_mapper=None, progress_bar=None, **_cluster_args):
@@ -93,6 +117,8 @@ class ClusteringMixin:
         # a5 planning support: raw bin (or -1 in basis/target) of every frame's PARENT pcoord
         # (:849-852 pcoord0List, quirk Q2) + per-iteration histograms, one pass over p0
         d_bin = h.alloc(store.N, np.int32)
+        if self._mapper_external:
+            h.set_frame_bins(self._frame_bins("p0", bin_mapper))
         hist = h.train_prepass(store.p0, store.N, store.offsets, d_bin)
         d_rows = h.alloc(max(store.N, 1), np.int32)
 
@@ -102,7 +128,7 @@ class ClusteringMixin:
         trains_here = getattr(h, "rank", 0) == 0
         all_filled = set()
         if trains_here:
-            plan, all_filled = self._plan_training_calls(hist, iters_to_use, n_clusters, bin_mapper)
+            plan, all_filled = self._plan_training_calls(hist, iters_to_use, n_clusters, bin_mapper, store=store)
             done = False
             if getattr(self, "speculative_training", True):
                 done = self._train_planned(plan, clusters, store, d_bin, d_rows)
@@ -140,7 +166,7 @@ class ClusteringMixin:
         self.launch_ray_discretization(progress_bar)
 
     # ------------------------------------------------------------------------------------------
-    def _plan_training_calls(self, hist, iters_to_use, n_clusters, bin_mapper):
+    def _plan_training_calls(self, hist, iters_to_use, n_clusters, bin_mapper, store=None):
         """The control flow of `cluster_stratified` / `do_stratified_clustering` (`_clustering.py:664-716,
         794-886`): which iterations each training call consumes and which bins it fits.  It depends only
         on the per-iteration bin histogram, so every call is known before any arithmetic runs.
@@ -154,8 +180,15 @@ class ClusteringMixin:
         valid = its <= self.maxIter
         H = np.zeros((n, S), dtype=np.int64)
         H[valid] = hist[its[valid] - 1]
+        # iterations with NaN child coordinates: `get_iter_coordinates` drops those rows (_data.py:549-553), the call's
+        # `assert pcoord_array.shape[0] == iter_coords.shape[0]` (_clustering.py:860-862) then fails -- fatal on the first
+        # call, swallowed afterwards (:693-705), i.e. the call is lost and the loop advances by one iteration
+        nan_it = np.zeros(self.maxIter + 2, dtype=bool)
+        if store is not None and getattr(store, "nan_child", None) is not None:
+            per_it = np.add.reduceat(store.nan_child.astype(np.int64), store.offsets[:-1][np.diff(store.offsets) > 0])
+            nan_it[np.nonzero(np.diff(store.offsets) > 0)[0] + 1] = per_it > 0
         # an iteration that fills every bin it touches is a training call by itself (:885-886)
-        alone = valid & np.all((H >= n_clusters) | (H == 0), axis=1)
+        alone = valid & np.all((H >= n_clusters) | (H == 0), axis=1) & ~nan_it[np.minimum(its, self.maxIter + 1)]
         stops = np.nonzero(~alone)[0]
         firsts, lasts, remaps, nrows, fits = [], [], [], [], []
         pos, first_call = 0, True
@@ -177,6 +210,7 @@ class ClusteringMixin:
             group, counts = [], np.zeros(S, dtype=np.int64)
             call_remap = ident.copy()
             ran_out = False
+            nan_failed = False
             while True:
                 if pos + len(group) >= n:  # :798-826 IndexError branch
                     ran_out = True
@@ -185,6 +219,13 @@ class ClusteringMixin:
                 if it > self.maxIter:  # :834-840
                     break
                 group.append(it)
+                if nan_it[it]:
+                    if first_call:
+                        raise AssertionError(f"iteration {it}: coordinates of {int(hist[it - 1].sum())}+ segments vs NaN-free "
+                                             "coordinates differ in length (NaN coordinates in the first clustering call)")
+                    log.info("Clustering couldn't use last iteration, not all bins filled.")
+                    nan_failed = True
+                    break
                 counts += hist[it - 1]
                 seen = counts > 0
                 if np.all(counts[seen] >= n_clusters):  # :885-886
@@ -192,8 +233,8 @@ class ClusteringMixin:
             if not all(b == a + 1 for a, b in zip(group, group[1:])):
                 raise NotImplementedError("non-contiguous iters_to_use within one training call")
             unique_bins = np.nonzero(counts > 0)[0]
-            failed = False
-            if ran_out:
+            failed = nan_failed
+            if ran_out and not failed:
                 unfilled = unique_bins[counts[unique_bins] < n_clusters]
                 filled = np.setdiff1d(unique_bins, unfilled)
                 try:
@@ -470,8 +511,13 @@ class ClusteringMixin:
         d_parent = h.alloc(max(nseg, 1), np.int32)
         d_child = h.alloc(max(nseg, 1), np.int32)
         d_seen = h.zeros((2, self.clusters.bin_mapper.nbins), np.int32)
+        ext = getattr(self, "_mapper_external", False)
         if nseg:
+            if ext:
+                h.set_frame_bins(self._frame_bins("p0", self.clusters.bin_mapper))
             h.assign(store.Xp, store.x_dtype, store.D, store.p0, nseg, d_parent, d_seen)  # :1299-1301
+            if ext:
+                h.set_frame_bins(self._frame_bins("p1", self.clusters.bin_mapper))
             h.assign(store.Xc, store.x_dtype, store.D, store.p1, nseg, d_child, d_seen)   # :1315-1316
         seen = d_seen.to_host()
         d_seen.free()
@@ -485,6 +531,16 @@ class ClusteringMixin:
         self._d_parent, self._d_child, self._n_labelled = d_parent, d_child, nseg
         self._dtrajs_cache = None
         self._pairs_cache = None
+        if getattr(store, "nan_child", None) is not None and nseg:
+            # the reference discretizes every segment; a NaN frame survives only where the label needs no coordinates
+            # (basis / target, stratified_clustering.py:159-169) -- anywhere else sklearn's input validation raises
+            Kfit = sum(self.clusters.n_fitted())
+            for d_lab, mask in ((d_parent, store.nan_parent[:nseg]), (d_child, store.nan_child[:nseg])):
+                if mask.any():
+                    lab = np.empty(nseg, dtype=np.int32)
+                    h.d2h(lab, d_lab, lab.nbytes)
+                    if np.any(lab[mask] < Kfit):
+                        raise ValueError("Input contains NaN.")
 
     # dtrajs / pair_dtrajs are host views of the device labels, materialised on first access
     def _labels_host(self):

@@ -51,7 +51,7 @@ __global__ void k_classify(MapperDev m, const double *__restrict__ p, int64_t n,
   if (i >= n) return;
   double pi[HAMSM_MAX_NDIM];
   for (int d = 0; d < m.ndim; d++) pi[d] = p[i * m.ndim + d];
-  int b = dev_bin_of(m, pi);
+  int b = dev_bin_of(m, pi, i);
   if (b >= 0 && apply_remap) b = m.remap[b];
   if (bin) bin[i] = b;
   if (flags) flags[i] = (uint8_t)((dev_in_box(m.basis, m.ndim, pi) ? 1 : 0) | (dev_in_box(m.target, m.ndim, pi) ? 2 : 0));
@@ -61,6 +61,7 @@ extern "C" int hamsm_classify(hamsm_ctx *c, const double *p, int64_t n, int appl
   CTX(c);
   if (!c->have_mapper || !c->have_bounds) return hamsm_fail(c, HAMSM_EINVAL, "mapper/bounds not set");
   if (n <= 0) return HAMSM_OK;
+  if (int rcb = hamsm_take_frame_bins(c, "classify")) return rcb;
   hipLaunchKernelGGL(k_classify, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, c->mapper, p, n, apply_remap,
                      bin, flags);
   HIPCHK(c, hipGetLastError());
@@ -121,8 +122,9 @@ __global__ __launch_bounds__(256) void k_sort_count(MapperDev mp, SortArgs g) {
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < g.n; i += (int64_t)gridDim.x * 256) {
     double pi[HAMSM_MAX_NDIM];
     for (int d = 0; d < mp.ndim; d++) pi[d] = g.pcoord[i * mp.ndim + d];
-    int b = dev_bin_of(mp, pi);
+    int b = dev_bin_of(mp, pi, i);
     int code = -1;
+    if (b >= g.S) b = -1;  // (an external mapper's bins are the caller's data)
     if (b < 0) {
       dev_set_error(g.err, HAMSM_ERANGE, (int)i, b);
     } else {
@@ -983,7 +985,9 @@ extern "C" int hamsm_assign(hamsm_ctx *c, const void *X, int dt, int64_t ldx, co
   if (dt != HAMSM_F32 && dt != HAMSM_F64) return hamsm_fail(c, HAMSM_EINVAL, "x_dtype");
   if (ldx < c->D) return hamsm_fail(c, HAMSM_EINVAL, "ldx < D");
   if (n <= 0) return HAMSM_OK;
-  int rc = hamsm_refresh_table(c);
+  int rc = hamsm_take_frame_bins(c, "assign");
+  if (rc) return rc;
+  rc = hamsm_refresh_table(c);
   if (rc) return rc;
   AssignArgs g{X, ldx, p, n, labels, seen, c->d_table, c->S, c->D, c->Kfit, c->d_err};
   hamsm_timer_begin(c);  // bucket passes -> ST_OTHER (ended inside launch_sorted), distance kernel -> ST_ASSIGN

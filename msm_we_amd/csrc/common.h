@@ -22,7 +22,14 @@
 #define SCAN_CHUNK 64   // chunked cumulative sum (oracle: SCAN_CHUNK)
 
 // ---- device view of the mapper / bounds (passed by value to kernels) ---------------------------
+#define MAPPER_RECT 0
+#define MAPPER_VORONOI 1
+#define MAPPER_EXTERNAL 2
 struct MapperDev {
+  int kind;                  // MAPPER_*
+  int ncent;                 // Voronoi: centres (= strata)
+  const float *centers;      // Voronoi: device [ncent][ndim]
+  const int32_t *ext_bins;   // external: bin of frame i of the current call (device)
   int ndim;
   int nb[HAMSM_MAX_NDIM];    // boundaries per dim
   int boff[HAMSM_MAX_NDIM];  // offset of each dim's boundaries in `bounds`
@@ -77,6 +84,10 @@ struct hamsm_ctx {
   bool have_mapper = false, have_bounds = false;
   MapperDev mapper;  // host copy with device pointers inside
   float *d_bounds = nullptr;
+  float *d_centers = nullptr;    // Voronoi centres
+  int32_t *d_ext_bins_own = nullptr;  // device copy of host-supplied frame bins (hamsm_set_frame_bins_host)
+  size_t ext_bins_own_cap = 0;
+  bool ext_bins_set = false;     // external mapper: bins named for the next call
   std::vector<float> h_bounds;  // host copy of what d_bounds holds
   int32_t *d_remap = nullptr;
   std::vector<Stratum> st;
@@ -136,6 +147,7 @@ int hamsm_ctx_check(hamsm_ctx *c, const char *fn);
       return hamsm_fail((c), HAMSM_EDEVICE, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); \
   } while (0)
 
+int hamsm_take_frame_bins(hamsm_ctx *c, const char *what);  // external mapper: consume the bins named for this call
 int hamsm_ensure_scratch(hamsm_ctx *c, size_t bytes);
 int hamsm_ensure_scratch2(hamsm_ctx *c, size_t bytes);
 int hamsm_ensure_pinned(hamsm_ctx *c, size_t bytes);
@@ -150,7 +162,24 @@ void hamsm_timer_end(hamsm_ctx *c, int stage);
 #ifdef __HIPCC__
 // westpa RectilinearBinMapper.assign restated (oracle bin_of): float32 compare, half-open bins,
 // row-major over dims; -1 outside the bin space (also NaN).
-__device__ __forceinline__ int dev_bin_of(const MapperDev &m, const double *p) {
+__device__ __forceinline__ int dev_bin_of(const MapperDev &m, const double *p, int64_t i) {
+  if (m.kind == MAPPER_EXTERNAL) return m.ext_bins[i];  // the mapper's own `assign` ran on the host
+  if (m.kind == MAPPER_VORONOI) {  // nearest centre, float32 coordinates, float64 squared distance, first minimum
+    int best = -1;
+    double bd = 0.0;
+    for (int c = 0; c < m.ncent; c++) {
+      double d2 = 0.0;
+      for (int d = 0; d < m.ndim; d++) {
+        const double t = (double)(float)p[d] - (double)m.centers[c * m.ndim + d];
+        d2 = d2 + t * t;
+      }
+      if (best < 0 || d2 < bd) {
+        bd = d2;
+        best = c;
+      }
+    }
+    return bd == bd ? best : -1;  // NaN coordinates are outside the bin space
+  }
   int idx = 0;
   for (int d = 0; d < m.ndim; d++) {
     float pf = (float)p[d];

@@ -122,6 +122,8 @@ extern "C" void hamsm_destroy(hamsm_ctx *c) {
   for (auto &kv : c->blk_live) hipFree(kv.first);  // device memory dies with its context
   free_strata(c);
   hipFree(c->d_bounds);
+  hipFree(c->d_centers);
+  hipFree(c->d_ext_bins_own);
   hipFree(c->d_err);
   hipHostFree(c->h_err);
   hipHostFree(c->h_und);
@@ -148,6 +150,8 @@ extern "C" void hamsm_destroy(hamsm_ctx *c) {
   release(c->ev_pending);
   release(c->ev_free);
   c->d_bounds = nullptr;
+  c->d_centers = nullptr;
+  c->d_ext_bins_own = nullptr;
   c->d_err = c->h_err = nullptr;
   c->h_und = nullptr;
   c->scratch = c->scratch2 = nullptr;
@@ -418,6 +422,8 @@ extern "C" int hamsm_set_mapper_rectilinear(hamsm_ctx *c, const int32_t *nb, con
     nbins *= nb[d] - 1;
   }
   if (nbins != c->S) return hamsm_fail(c, HAMSM_EINVAL, "mapper has %ld bins, geometry says %d", nbins, c->S);
+  c->mapper.kind = MAPPER_RECT;
+  c->ext_bins_set = false;
   // the same boundaries again (every cluster_coordinates call sets the mapper): nothing to upload
   if (c->d_bounds && (int)c->h_bounds.size() == tot && memcmp(c->h_bounds.data(), b, sizeof(float) * tot) == 0) {
     c->mapper.bounds = c->d_bounds;
@@ -435,6 +441,71 @@ extern "C" int hamsm_set_mapper_rectilinear(hamsm_ctx *c, const int32_t *nb, con
   c->h_bounds.assign(b, b + tot);
   c->mapper.bounds = c->d_bounds;
   c->have_mapper = true;
+  return HAMSM_OK;
+}
+
+extern "C" int hamsm_set_mapper_voronoi(hamsm_ctx *c, int n_centers, const float *h_centers) {
+  CTX(c);
+  if (c->st.empty()) return hamsm_fail(c, HAMSM_EINVAL, "set_geometry first");
+  if (n_centers != c->S) return hamsm_fail(c, HAMSM_EINVAL, "mapper has %d centres, geometry says %d bins", n_centers, c->S);
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  hipFree(c->d_centers);
+  c->d_centers = nullptr;
+  c->have_mapper = false;
+  const size_t bytes = sizeof(float) * (size_t)n_centers * c->ndim;
+  HIPCHK(c, hipMalloc((void **)&c->d_centers, bytes));
+  HIPCHK(c, hipMemcpy(c->d_centers, h_centers, bytes, hipMemcpyHostToDevice));
+  c->mapper.kind = MAPPER_VORONOI;
+  c->mapper.ncent = n_centers;
+  c->mapper.centers = c->d_centers;
+  c->ext_bins_set = false;
+  c->have_mapper = true;
+  return HAMSM_OK;
+}
+
+extern "C" int hamsm_set_mapper_external(hamsm_ctx *c) {
+  CTX(c);
+  if (c->st.empty()) return hamsm_fail(c, HAMSM_EINVAL, "set_geometry first");
+  c->mapper.kind = MAPPER_EXTERNAL;
+  c->mapper.ext_bins = nullptr;
+  c->ext_bins_set = false;
+  c->have_mapper = true;
+  return HAMSM_OK;
+}
+
+extern "C" int hamsm_set_frame_bins(hamsm_ctx *c, const int32_t *d_bins) {
+  CTX(c);
+  if (c->mapper.kind != MAPPER_EXTERNAL) return hamsm_fail(c, HAMSM_EINVAL, "frame bins are for the external mapper only");
+  c->mapper.ext_bins = d_bins;
+  c->ext_bins_set = d_bins != nullptr;
+  return HAMSM_OK;
+}
+
+extern "C" int hamsm_set_frame_bins_host(hamsm_ctx *c, const int32_t *h_bins, int64_t n) {
+  CTX(c);
+  if (c->mapper.kind != MAPPER_EXTERNAL) return hamsm_fail(c, HAMSM_EINVAL, "frame bins are for the external mapper only");
+  if (n <= 0 || !h_bins) return hamsm_fail(c, HAMSM_EINVAL, "frame bins missing");
+  const size_t bytes = sizeof(int32_t) * (size_t)n;
+  if (bytes > c->ext_bins_own_cap) {
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    hipFree(c->d_ext_bins_own);
+    c->d_ext_bins_own = nullptr;
+    c->ext_bins_own_cap = 0;
+    HIPCHK(c, hipMalloc((void **)&c->d_ext_bins_own, bytes + bytes / 4 + 256));
+    c->ext_bins_own_cap = bytes + bytes / 4 + 256;
+  }
+  HIPCHK(c, hipMemcpyAsync(c->d_ext_bins_own, h_bins, bytes, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  c->mapper.ext_bins = c->d_ext_bins_own;
+  c->ext_bins_set = true;
+  return HAMSM_OK;
+}
+
+// external mapper: a call that maps frames to bins needs the bins named for it, and uses them up
+int hamsm_take_frame_bins(hamsm_ctx *c, const char *what) {
+  if (c->mapper.kind != MAPPER_EXTERNAL) return HAMSM_OK;
+  if (!c->ext_bins_set) return hamsm_fail(c, HAMSM_EINVAL, "%s: external mapper -- call hamsm_set_frame_bins first", what);
+  c->ext_bins_set = false;
   return HAMSM_OK;
 }
 

@@ -36,7 +36,8 @@ __global__ void k_prepass(MapperDev m, const double *__restrict__ p, const int64
       int b;
       if (dev_in_box(m.target, m.ndim, pi) || dev_in_box(m.basis, m.ndim, pi)) b = -1;  // _clustering.py:872-874
       else {
-        b = dev_bin_of(m, pi);  // :877 (no we_remap)
+        b = dev_bin_of(m, pi, i);  // :877 (no we_remap)
+        if (b >= S) b = -1;
         if (b < 0) dev_set_error(err, HAMSM_ERANGE, (int)i, b);
         else atomicAdd(&lh[b], 1u);
       }
@@ -54,6 +55,7 @@ extern "C" int hamsm_train_prepass(hamsm_ctx *c, const double *p, int64_t n, con
   (void)n;
   if (!c->have_mapper || !c->have_bounds) return hamsm_fail(c, HAMSM_EINVAL, "mapper/bounds not set");
   if (n_iters <= 0) return HAMSM_OK;
+  if (int rcb = hamsm_take_frame_bins(c, "train_prepass")) return rcb;
   size_t ob = sizeof(int64_t) * (n_iters + 1), hb = sizeof(unsigned long long) * (size_t)n_iters * c->S;
   size_t o_h = (ob + 255) & ~(size_t)255;
   int rc = hamsm_ensure_scratch(c, o_h + hb);

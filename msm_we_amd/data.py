@@ -111,6 +111,18 @@ class DeviceStore:
         self.Xp, self.Xc, self.p0, self.p1, self.w = Xp, Xc, p0, p1, w
         self.N = int(self.offsets[-1])
         self.d_offsets = h.to_device(self.offsets)
+        # segments with NaN coordinates (`_data.py:303-313, 549-553`): their weight is 0 in the flux matrix (`w_flux`), their
+        # iteration is unusable for training, and they may only be discretized inside the basis / target
+        self.w_flux = w
+        self.nan_parent = self.nan_child = None
+
+    def mark_nan_segments(self, nan_parent, nan_child, w_host):
+        if not (nan_parent.any() or nan_child.any()):
+            return
+        self.nan_parent, self.nan_child = nan_parent, nan_child
+        wz = np.array(w_host, dtype=np.float64, copy=True)
+        wz[nan_parent | nan_child] = 0.0
+        self.w_flux = self.h.to_device(wz)
 
     @property
     def n_iters(self):
@@ -262,8 +274,6 @@ class DataMixin:
                     X = self.processCoordinates(np.asarray(d[which], dtype=np.float64))
                 else:
                     X = self._featurize(d[which])
-                if np.isnan(X).any():
-                    raise NotImplementedError("NaN coordinates (_data.py:303-313,549-553) are not supported yet")
                 parts[key].append(X)
             parts["p0"].append(np.asarray(d["p0"], dtype=np.float64).reshape(n, -1)[:, : self.pcoord_ndim])
             parts["p1"].append(np.asarray(d["p1"], dtype=np.float64).reshape(n, -1)[:, : self.pcoord_ndim])
@@ -272,9 +282,10 @@ class DataMixin:
         Xp = np.concatenate(parts["Xp"])
         Xc = np.concatenate(parts["Xc"])
         # store float32 when that loses nothing (on-disk WESTPA coordinates are float32)
+        nan_p, nan_c = np.isnan(Xp).any(axis=1), np.isnan(Xc).any(axis=1)
         if Xp.dtype != np.float32 or Xc.dtype != np.float32:
             Xp32, Xc32 = Xp.astype(np.float32), Xc.astype(np.float32)
-            if np.array_equal(Xp32.astype(np.float64), Xp) and np.array_equal(Xc32.astype(np.float64), Xc):
+            if np.array_equal(Xp32.astype(np.float64), Xp, equal_nan=True) and np.array_equal(Xc32.astype(np.float64), Xc, equal_nan=True):
                 Xp, Xc = Xp32, Xc32
             else:
                 Xp, Xc = Xp.astype(np.float64), Xc.astype(np.float64)
@@ -282,6 +293,7 @@ class DataMixin:
         p0, p1, w = np.concatenate(parts["p0"]), np.concatenate(parts["p1"]), np.concatenate(parts["w"])
         if lin is None:
             self._store = DeviceStore.from_host(h, Xp, Xc, p0, p1, w, offsets)
+            self._store.mark_nan_segments(nan_p, nan_c, w)
             return self._store
         W, mean, scale = lin
         dt = _abi.F32 if Xp.dtype == np.float32 else _abi.F64
@@ -293,6 +305,7 @@ class DataMixin:
             d_raw.free()
         self._store = DeviceStore(h, W.shape[0], p0.shape[1], _abi.F64, offsets, proj[0], proj[1], h.to_device(p0), h.to_device(p1),
                                   h.to_device(w))
+        self._store.mark_nan_segments(nan_p, nan_c, w)
         return self._store
 
     def set_distance_featurizer(self, atom_indices, reference_positions):
@@ -324,13 +337,12 @@ class DataMixin:
             p1s.append(np.asarray(d["p1"], dtype=np.float64).reshape(n, -1)[:, : self.pcoord_ndim])
             ws.append(np.asarray(d["w"], dtype=np.float64))
             sizes.append(n)
-        feats = []
+        feats, nans = [], []
         for which in ("parent", "child"):
             R = np.concatenate(raw[which])
-            if np.isnan(R).any():
-                raise NotImplementedError("NaN coordinates (_data.py:303-313,549-553) are not supported yet")
+            nans.append(np.isnan(R).any(axis=1))
             R32 = R.astype(np.float32)
-            dt, R = (_abi.F32, R32) if np.array_equal(R32.astype(np.float64), R) else (_abi.F64, R.astype(np.float64))
+            dt, R = (_abi.F32, R32) if np.array_equal(R32.astype(np.float64), R, equal_nan=True) else (_abi.F64, R.astype(np.float64))
             n, width = R.shape
             d_raw = h.to_device(R)
             d_X = h.featurize_dist(d_raw, dt, width, n, width // 3, idx, ref)
@@ -346,6 +358,7 @@ class DataMixin:
         p0, p1, w = np.concatenate(p0s), np.concatenate(p1s), np.concatenate(ws)
         self._store = DeviceStore(h, D, p0.shape[1], _abi.F64, offsets, feats[0], feats[1], h.to_device(p0), h.to_device(p1),
                                   h.to_device(w))
+        self._store.mark_nan_segments(nans[0], nans[1], w)
         return self._store
 
     def attach_store(self, store: DeviceStore, maxIter=None):

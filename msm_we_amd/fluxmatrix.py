@@ -72,7 +72,7 @@ class FluxMatrixMixin:
         for a, b in runs:
             f0, f1 = store.span(a, b)
             # array bases are unshifted: d_iter_offsets holds absolute segment positions (hamsm.h)
-            h.flux_accumulate(d_parent, d_child, store.p0, store.p1, store.w, f1 - f0, K, d_F,
+            h.flux_accumulate(d_parent, d_child, store.p0, store.p1, store.w_flux, f1 - f0, K, d_F,
                               self.flux_mode, store.d_offsets.offset(a - 1), b - a + 1)
         return d_F
 

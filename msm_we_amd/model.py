@@ -60,6 +60,7 @@ class modelWE(DataMixin, ClusteringMixin, FluxMatrixMixin, AnalysisMixin):
         self._h = h
         self._device = device
         self._store = None
+        self._mapper_external = False
         self.seg_weights = {}
 
     # -- device context ---------------------------------------------------------------------

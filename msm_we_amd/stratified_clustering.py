@@ -330,6 +330,8 @@ class StratifiedClusters:
     def predict(self, coords):
         iter_pcoords = self.model.pcoord0List if self.processing_from else self.model.pcoord1List
         self._activate()
+        if getattr(self.model, "_mapper_external", False):  # the mapper's own assign (stratified_clustering.py:134)
+            self._h.set_frame_bins_host(np.asarray(self.bin_mapper.assign(np.asarray(iter_pcoords)), dtype=np.int64))
         labels, seen = self._h.predict_host(np.asarray(coords), np.asarray(iter_pcoords), want_seen=True)
         self.target_bins.update(np.nonzero(seen[0])[0].tolist())
         self.basis_bins.update(np.nonzero(seen[1])[0].tolist())

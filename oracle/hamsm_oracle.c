@@ -53,6 +53,11 @@ struct hamsm_ctx {
   int32_t *remap;
   double basis[MAX_NDIM][2], target[MAX_NDIM][2];
   int have_bounds, have_mapper;
+  int mapper_kind;          /* 0 rectilinear, 1 Voronoi (Euclidean), 2 external (bins supplied per call) */
+  float *centers;           /* Voronoi [S][ndim] */
+  const int32_t *ext_bins;  /* external: bins of the next call's frames */
+  int32_t *ext_own;         /* copy of host-supplied bins */
+  int ext_set;
   stratum_t *st;
 };
 
@@ -150,6 +155,10 @@ void hamsm_destroy(hamsm_ctx *c) {
     free(c->bounds[d]);
     c->bounds[d] = NULL;
   }
+  free(c->centers);
+  free(c->ext_own);
+  c->centers = NULL;
+  c->ext_own = NULL;
   for (size_t i = 0; i < c->n_blocks; i++) free(c->blocks[i]); /* "device" memory dies with its context, as hipFree'd */
   free(c->blocks);
   c->blocks = NULL;
@@ -243,7 +252,52 @@ int hamsm_set_mapper_rectilinear(hamsm_ctx *c, const int32_t *nb, const float *b
     nbins *= nb[d] - 1;
   }
   if (nbins != c->S) return fail(c, HAMSM_EINVAL, "mapper has %ld bins, geometry says %d", nbins, c->S);
+  c->mapper_kind = 0;
+  c->ext_set = 0;
   c->have_mapper = 1;
+  return HAMSM_OK;
+}
+
+int hamsm_set_mapper_voronoi(hamsm_ctx *c, int n_centers, const float *centers) {
+  CTX(c);
+  if (!c->st) return fail(c, HAMSM_EINVAL, "set_geometry first");
+  if (n_centers != c->S) return fail(c, HAMSM_EINVAL, "mapper has %d centres, geometry says %d bins", n_centers, c->S);
+  free(c->centers);
+  c->centers = (float *)malloc(sizeof(float) * (size_t)n_centers * c->ndim);
+  memcpy(c->centers, centers, sizeof(float) * (size_t)n_centers * c->ndim);
+  c->mapper_kind = 1;
+  c->ext_set = 0;
+  c->have_mapper = 1;
+  return HAMSM_OK;
+}
+
+int hamsm_set_mapper_external(hamsm_ctx *c) {
+  CTX(c);
+  if (!c->st) return fail(c, HAMSM_EINVAL, "set_geometry first");
+  c->mapper_kind = 2;
+  c->ext_bins = NULL;
+  c->ext_set = 0;
+  c->have_mapper = 1;
+  return HAMSM_OK;
+}
+
+int hamsm_set_frame_bins(hamsm_ctx *c, const int32_t *bins) {
+  CTX(c);
+  if (c->mapper_kind != 2) return fail(c, HAMSM_EINVAL, "frame bins are for the external mapper only");
+  c->ext_bins = bins;
+  c->ext_set = bins != NULL;
+  return HAMSM_OK;
+}
+
+int hamsm_set_frame_bins_host(hamsm_ctx *c, const int32_t *bins, int64_t n) {
+  CTX(c);
+  if (c->mapper_kind != 2) return fail(c, HAMSM_EINVAL, "frame bins are for the external mapper only");
+  if (n <= 0 || !bins) return fail(c, HAMSM_EINVAL, "frame bins missing");
+  free(c->ext_own);
+  c->ext_own = (int32_t *)malloc(sizeof(int32_t) * (size_t)n);
+  memcpy(c->ext_own, bins, sizeof(int32_t) * (size_t)n);
+  c->ext_bins = c->ext_own;
+  c->ext_set = 1;
   return HAMSM_OK;
 }
 
@@ -314,7 +368,24 @@ int hamsm_num_centroids(hamsm_ctx *c, int s) {
 
 /* --- a3: westpa RectilinearBinMapper.assign restated (third-party, source absent):
  * float32 compare, half-open bins, row-major over dims.  -1 = outside the bin space. */
-static int bin_of(const hamsm_ctx *c, const double *p) {
+static int bin_of(const hamsm_ctx *c, const double *p, int64_t i) {
+  if (c->mapper_kind == 2) return c->ext_bins[i]; /* the mapper's own assign ran on the host */
+  if (c->mapper_kind == 1) { /* VoronoiBinMapper, Euclidean dfunc: float32 coordinates, float64 squared distance, first minimum */
+    int best = -1;
+    double bd = 0.0;
+    for (int k = 0; k < c->S; k++) {
+      double d2 = 0.0;
+      for (int d = 0; d < c->ndim; d++) {
+        const double t = (double)(float)p[d] - (double)c->centers[k * c->ndim + d];
+        d2 = d2 + t * t;
+      }
+      if (best < 0 || d2 < bd) {
+        bd = d2;
+        best = k;
+      }
+    }
+    return bd == bd ? best : -1;
+  }
   int idx = 0;
   for (int d = 0; d < c->ndim; d++) {
     float pf = (float)p[d];
@@ -332,6 +403,13 @@ static int bin_of(const hamsm_ctx *c, const double *p) {
   return idx;
 }
 
+static int take_frame_bins(hamsm_ctx *c, const char *what) {
+  if (c->mapper_kind != 2) return HAMSM_OK;
+  if (!c->ext_set) return fail(c, HAMSM_EINVAL, "%s: external mapper -- call hamsm_set_frame_bins first", what);
+  c->ext_set = 0;
+  return HAMSM_OK;
+}
+
 /* --- a4: msm_we.py:480-492, 515-527: all dims strictly inside (lo, hi), float64 */
 static int in_box(const double (*box)[2], int ndim, const double *p) {
   for (int d = 0; d < ndim; d++)
@@ -342,9 +420,11 @@ static int in_box(const double (*box)[2], int ndim, const double *p) {
 int hamsm_classify(hamsm_ctx *c, const double *p, int64_t n, int apply_remap, int32_t *bin, uint8_t *flags) {
   CTX(c);
   if (!c->have_mapper || !c->have_bounds) return fail(c, HAMSM_EINVAL, "mapper/bounds not set");
+  if (n <= 0) return HAMSM_OK;
+  if (take_frame_bins(c, "classify")) return HAMSM_EINVAL;
   for (int64_t i = 0; i < n; i++) {
     const double *pi = p + i * c->ndim;
-    int b = bin_of(c, pi);
+    int b = bin_of(c, pi, i);
     if (b >= 0 && apply_remap) b = c->remap[b];
     if (bin) bin[i] = b;
     if (flags) flags[i] = (uint8_t)((in_box(c->basis, c->ndim, pi) ? 1 : 0) | (in_box(c->target, c->ndim, pi) ? 2 : 0));
@@ -381,6 +461,8 @@ int hamsm_assign(hamsm_ctx *c, const void *X, int dt, int64_t ldx, const double 
   if (!c->have_mapper || !c->have_bounds) return fail(c, HAMSM_EINVAL, "mapper/bounds not set");
   if (dt != HAMSM_F32 && dt != HAMSM_F64) return fail(c, HAMSM_EINVAL, "x_dtype");
   if (ldx < c->D) return fail(c, HAMSM_EINVAL, "ldx < D");
+  if (n <= 0) return HAMSM_OK;
+  if (take_frame_bins(c, "assign")) return HAMSM_EINVAL;
   int D = c->D;
   /* :143-150 total_clusters over all strata; :178-185 offset of earlier strata */
   int Kfit = 0;
@@ -393,8 +475,8 @@ int hamsm_assign(hamsm_ctx *c, const void *X, int dt, int64_t ldx, const double 
   int rc = HAMSM_OK;
   for (int64_t i = 0; i < n && rc == HAMSM_OK; i++) {
     const double *pi = p + i * c->ndim;
-    int b = bin_of(c, pi); /* :134 assign is evaluated for every frame, basis/target included */
-    if (b < 0) {
+    int b = bin_of(c, pi, i); /* :134 assign is evaluated for every frame, basis/target included */
+    if (b < 0 || b >= c->S) {
       rc = fail(c, HAMSM_ERANGE, "frame %lld: pcoord outside the bin space", (long long)i);
       break;
     }
@@ -616,6 +698,8 @@ int hamsm_train_prepass(hamsm_ctx *c, const double *p, int64_t n, const int64_t 
                         int64_t *hist) {
   CTX(c);
   if (!c->have_mapper || !c->have_bounds) return fail(c, HAMSM_EINVAL, "mapper/bounds not set");
+  if (n_iters <= 0) return HAMSM_OK;
+  if (take_frame_bins(c, "train_prepass")) return HAMSM_EINVAL;
   memset(hist, 0, sizeof(int64_t) * (size_t)n_iters * c->S);
   for (int64_t t = 0; t < n_iters; t++)
     for (int64_t i = offs[t]; i < offs[t + 1]; i++) {
@@ -623,8 +707,8 @@ int hamsm_train_prepass(hamsm_ctx *c, const double *p, int64_t n, const int64_t 
       int b;
       if (in_box(c->target, c->ndim, pi) || in_box(c->basis, c->ndim, pi)) b = -1; /* :872-874 */
       else {
-        b = bin_of(c, pi); /* :877, no we_remap here */
-        if (b < 0) return fail(c, HAMSM_ERANGE, "frame %lld: pcoord outside the bin space", (long long)i);
+        b = bin_of(c, pi, i); /* :877, no we_remap here */
+        if (b < 0 || b >= c->S) return fail(c, HAMSM_ERANGE, "frame %lld: pcoord outside the bin space", (long long)i);
         hist[t * c->S + b]++;
       }
       bin[i] = b;

@@ -145,7 +145,7 @@ def golden_iterations(g):
             for i in range(len(offs) - 1)}
 
 
-def build_model(h, g, meta, seed_forcing=True, planned=True, source=None):
+def build_model(h, g, meta, seed_forcing=True, planned=True, source=None, mapper_dfunc=None):
     """modelWE on golden inputs, up to (and including) cluster_coordinates.  Returns (model, forced)
     where forced counts k-means++ seedings replaced by the reference's (exact-tie flips)."""
     from msm_we_amd.data import InMemorySource
@@ -193,6 +193,12 @@ def build_model(h, g, meta, seed_forcing=True, planned=True, source=None):
     h.kmeans_seed_multi = seed_multi
     m.speculative_training = planned
     bm = RectilinearBinMapper([np.array(meta["boundaries"], dtype=np.float32)])
+    if meta.get("voronoi"):
+        from msm_we_amd.binning import VoronoiBinMapper, euclidean_dfunc
+
+        # mapper_dfunc = None: the tagged Euclidean function (bins computed on the device); anything else: the mapper's own
+        # `assign` on the host (external path)
+        bm = VoronoiBinMapper(mapper_dfunc or euclidean_dfunc, np.array(meta["voronoi"], dtype=np.float32))
     try:
         m.cluster_coordinates(meta["K_s"], streaming=True, use_ray=True, stratified=True, user_bin_mapper=bm,
                               random_state=meta["seed"], store_validation_model=True)
@@ -202,4 +208,4 @@ def build_model(h, g, meta, seed_forcing=True, planned=True, source=None):
     return m, state
 
 
-GOLDEN_CASES = ["c1p_d10", "c1p_d30", "c1p_d10_weighted", "gap_d10", "sparse_d10"]
+GOLDEN_CASES = ["c1p_d10", "c1p_d30", "c1p_d10_weighted", "gap_d10", "sparse_d10", "voronoi_d10", "nan_d10"]

@@ -39,6 +39,13 @@ CASES = {
     # dimensionality reduction: IncrementalPCA fitted by the reference's two-pass scheme (`_dimensionality.py:139-241`),
     # every frame transformed before clustering (`reduceCoordinates`)
     "c1p_d30_pca": dict(cfg="c1p_d30", dim_reduce="pca"),
+    # VoronoiBinMapper (SUPPORTED_MAPPERS, _clustering.py:598-609): Euclidean distance function, four centres of which the
+    # last is never visited -> `find_nearest_bin`'s Voronoi branch (:1362-1365)
+    "voronoi_d10": dict(cfg="c1p_d10", voronoi=[[0.3], [0.9], [1.6], [5.0]]),
+    # NaN-coordinate segments (`_data.py:303-313, 549-553`): the child frames of the target-bound segments of iterations 12 and
+    # 30 and the parent frames of the basis-bound segments of iteration 20 are NaN -- weight 0 in the flux matrix, their
+    # iterations lost for training (AssertionError swallowed, `_clustering.py:693-705`), discretized by pcoord alone
+    "nan_d10": dict(cfg="c1p_d10", nan_child_in_target=[12, 30], nan_parent_in_basis=[20]),
     # C3-SHAPED slice: BASELINE config 3's geometry -- D = 30, 4 strata x 250 clusters, 10 000 segments
     # per iteration, the bench generator's own seed -- over 12 iterations.  Inputs are NOT stored (the tests regenerate
     # them from the seed with msm_we_amd.synthetic, 29 MB); outputs are stored compactly (labels int16, flux as COO).
@@ -58,6 +65,10 @@ def build_inputs(case):
             for key, xkey in (("p0", "Xp"), ("p1", "Xc")):
                 m = np.floor(d[key][:, 0]) == s
                 d[key][m, 0] += 1.0
+        if it in spec.get("nan_child_in_target", ()):
+            d["Xc"][d["p1"][:, 0] > cfg.S - 0.05] = np.nan
+        if it in spec.get("nan_parent_in_basis", ()):
+            d["Xp"][d["p0"][:, 0] < 0.05] = np.nan
         iters[it] = d
     return cfg, iters
 
@@ -170,6 +181,10 @@ def run_case(case):
         out["pca_ndim"] = np.int64(model.ndim)
         out["pca_n_samples_seen"] = np.int64(model.coordinates.n_samples_seen_)
     bm = ref_harness.RectilinearBinMapper([synthetic.strata_boundaries(cfg.S)])
+    if "voronoi" in spec:
+        from msm_we_amd.binning import euclidean_dfunc
+
+        bm = ref_harness.VoronoiBinMapper(euclidean_dfunc, np.array(spec["voronoi"], dtype=np.float32))
     model.cluster_coordinates(
         n_clusters=cfg.K_s, streaming=True, use_ray=True, stratified=True,
         user_bin_mapper=bm, random_state=seed, store_validation_model=True,
@@ -252,7 +267,8 @@ def run_case(case):
     sizes = np.array([iters[i]["w"].shape[0] for i in its], dtype=np.int64)
     out["in_offsets"] = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)
     meta = dict(
-        case=case, seed=seed, gen_seed=cfg.seed, segs_per_iter=cfg.segs_per_iter, D=cfg.D, S=cfg.S, K_s=cfg.K_s,
+        case=case, seed=seed, voronoi=spec.get("voronoi"), gen_seed=cfg.seed, segs_per_iter=cfg.segs_per_iter, D=cfg.D,
+        S=int(bm.nbins), K_s=cfg.K_s,
         n_iters=cfg.n_iters, maxIter=int(model.maxIter),
         tau=1e-9, use_weights=bool(spec.get("use_weights", False)), dim_reduce=spec.get("dim_reduce", "none"),
         boundaries=[float(x) for x in synthetic.strata_boundaries(cfg.S)],

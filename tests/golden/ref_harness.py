@@ -64,9 +64,25 @@ class RectilinearBinMapper:
 
 
 class VoronoiBinMapper:
+    """Stub of westpa.core.binning.VoronoiBinMapper (third-party, absent here), restated from its documented behaviour:
+    float32 coordinates and centres, bin = first argmin of ``dfunc(coordvec, centers, *dfargs, **dfkwargs)``, uint16 output.
+    "Parity unpinned" for westpa itself."""
+
     def __init__(self, dfunc, centers, dfargs=None, dfkwargs=None):
-        self.dfunc, self.centers = dfunc, np.asarray(centers)
+        self.dfunc = dfunc
+        self.centers = np.require(centers, dtype=np.float32)
+        if self.centers.ndim == 1:
+            self.centers = self.centers[:, None]
+        self.dfargs, self.dfkwargs = dfargs or (), dfkwargs or {}
+        self.ndim = self.centers.shape[1]
         self.nbins = len(self.centers)
+
+    def assign(self, coords, mask=None, output=None):
+        coords = np.require(coords, dtype=np.float32).reshape(-1, self.ndim)
+        out = np.empty(len(coords), dtype=np.uint16)
+        for i, c in enumerate(coords):
+            out[i] = np.argmin(self.dfunc(c, self.centers, *self.dfargs, **self.dfkwargs))
+        return out
 
 
 class FuncBinMapper:
@@ -227,6 +243,11 @@ def make_model_class(msm_we):
             cp[..., 0] = self._coords(d["Xp"])
             cp[..., 1] = self._coords(d["Xc"])
             self.coordPairList = cp
+            # the reference's own method does this after reading HDF5 (`_data.py:303-313`); this override replaces that
+            # method, so its NaN rule is restated here: segments with NaN coordinates get weight 0
+            nan_segments = np.isnan(cp).any(axis=(1, 2, 3))
+            if nan_segments.any():
+                self.weightList[nan_segments] = 0.0
             self.transitionWeights = self.weightList.copy()
             self.departureWeights = self.weightList.copy()
 

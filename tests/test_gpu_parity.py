@@ -639,6 +639,40 @@ def test_pipeline_on_reference_goldens(hip_h, case):
     np.testing.assert_allclose(m2.fluxMatrixRaw, g["fluxMatrixRaw"], rtol=1e-12, atol=1e-300)
 
 
+def test_voronoi_mapper_with_user_dfunc_hip(hip_h):
+    """external-mapper path (bins from the mapper's own assign, read from arrays by the kernels) on the HIP library"""
+    from test_oracle_golden import check_voronoi_external
+
+    check_voronoi_external(hip_h)
+
+
+@pytest.mark.parametrize("ndim", [1, 2, 3])
+def test_voronoi_classify_matches_oracle(hip_h, oracle_h, ndim):
+    """device Voronoi mapper: bins of random pcoords (and of points on / near the bisectors) equal the oracle's and a NumPy
+    nearest-centre restatement"""
+    rng = np.random.default_rng(ndim)
+    S, n = 37, 20000
+    centers = rng.normal(size=(S, ndim)).astype(np.float32)
+    p = rng.normal(size=(n, ndim)) * 1.5
+    mid = (centers[rng.integers(0, S, 500)] + centers[rng.integers(0, S, 500)]) / 2
+    p[:500] = mid.astype(np.float64) * (1 + 1e-9 * rng.normal(size=(500, 1)))
+    outs = []
+    for h in (oracle_h, hip_h):
+        h.set_geometry(5, ndim, S)
+        h.set_mapper_voronoi(centers)
+        h.set_bounds([[-np.inf, -50.0]] + [[-np.inf, np.inf]] * (ndim - 1), [[50.0, np.inf]] + [[-np.inf, np.inf]] * (ndim - 1))
+        d_p, d_b = h.to_device(p), h.alloc(n, np.int32)
+        h.classify(d_p, n, 0, d_b, None)
+        outs.append(d_b.to_host())
+    assert np.array_equal(outs[0], outs[1])
+    pf = p.astype(np.float32).astype(np.float64)
+    d2 = ((pf[:, None, :] - centers[None].astype(np.float64)) ** 2).sum(-1)
+    ref = d2.argmin(1)
+    clear = np.sort(d2, axis=1)
+    clear = clear[:, 1] - clear[:, 0] > 1e-9
+    assert np.array_equal(outs[1][clear], ref[clear])
+
+
 def test_c3_shaped_slice_on_reference_golden(hip_h):
     """golden c3s: the real reference's outputs at BASELINE config 3's geometry (12 iterations), HIP library"""
     from test_oracle_golden import check_c3_shaped

@@ -179,3 +179,74 @@ def check_c3_shaped(h, g, meta):
 def test_c3_shaped_slice_matches_reference(oracle_h):
     g, meta = load_golden("c3s")
     check_c3_shaped(oracle_h, g, meta)
+
+
+def plain_euclid(coordvec, centers):
+    """the same distance function WITHOUT the device marker: the mapper's own assign runs on the host"""
+    d = np.asarray(centers, dtype=np.float64) - np.asarray(coordvec, dtype=np.float64)
+    return np.sqrt(np.sum(d * d, axis=1))
+
+
+def check_voronoi_external(h):
+    """VoronoiBinMapper whose dfunc the library does not know: bins from the mapper's own `assign` on the host
+    (hamsm_set_mapper_external / hamsm_set_frame_bins) -- same outputs as the reference run of golden voronoi_d10, and
+    `clusters.predict` (B3) goes through the same path"""
+    from conftest import golden_iterations
+
+    g, meta = load_golden("voronoi_d10")
+    m, st = build_model(h, g, meta, mapper_dfunc=plain_euclid)
+    assert m._mapper_external and st["forced"] <= 1
+    assert [m.clusters.we_remap[b] for b in range(meta["S"])] == list(g["remap_post_cluster"])
+    assert np.array_equal(np.concatenate(m.dtrajs), g["dtrajs_post_cluster"])
+    assert np.array_equal(np.concatenate(m.pair_dtrajs), g["pairs_post_cluster"])
+    m.get_fluxMatrix(0, first_iter=1, last_iter=m.maxIter, use_ray=True)
+    assert np.array_equal(m.fluxMatrixRaw, g["fluxMatrixRaw"])
+    it = 9
+    m.load_iter_data(it)
+    assert np.array_equal(m.clusters.predict(golden_iterations(g)[it]["Xc"]), m.dtrajs[it - 1])
+    m.organize_fluxMatrix(use_ray=True)
+    assert np.array_equal(np.concatenate(m.dtrajs), g["dtrajs_clean"]) and np.array_equal(m.fluxMatrix, g["fluxMatrix"])
+
+
+def test_voronoi_mapper_with_user_dfunc_runs_on_the_host(oracle_h):
+    check_voronoi_external(oracle_h)
+
+
+def test_unsupported_mapper_is_refused_like_the_reference(oracle_h):
+    """`_clustering.py:598-609`: functional mappers may re-bin on the fly; only the two static ones are accepted"""
+    g, meta = load_golden("c1p_d10")
+
+    class FuncBinMapper:
+        nbins = 2
+
+    from msm_we_amd.data import InMemorySource
+    from msm_we_amd.model import modelWE
+    from conftest import golden_iterations
+
+    m = modelWE(h=oracle_h)
+    m.set_iteration_source(InMemorySource(golden_iterations(g)))
+    m.initialize(["g.h5"], {"coords": None, "nAtoms": meta["D"], "coord_ndim": 1}, "g", basis_pcoord_bounds=meta["basis"],
+                 target_pcoord_bounds=meta["target"], tau=1.0, pcoord_ndim=1)
+    m.get_iterations()
+    m.get_coordSet(m.maxIter)
+    m.dimReduce()
+    with pytest.raises(Exception, match="supported mappers"):
+        m.cluster_coordinates(25, streaming=True, use_ray=True, stratified=True, user_bin_mapper=FuncBinMapper())
+
+
+def test_nan_coordinates_fail_where_the_reference_fails(oracle_h):
+    """a NaN frame outside basis / target reaches sklearn's input validation in the reference (ValueError at discretization);
+    NaN coordinates in the FIRST clustering call are fatal there (AssertionError, `_clustering.py:693-701`)"""
+    from conftest import golden_iterations
+    from msm_we_amd.data import InMemorySource
+
+    g, meta = load_golden("c1p_d10")
+    its = {k: {a: np.array(b, copy=True) for a, b in v.items()} for k, v in golden_iterations(g).items()}
+    mid = np.nonzero((its[9]["p1"][:, 0] > 0.5) & (its[9]["p1"][:, 0] < 1.5))[0][0]
+    its[9]["Xc"][mid, 3] = np.nan
+    with pytest.raises(ValueError, match="NaN"):
+        build_model(oracle_h, g, meta, source=InMemorySource(its))
+    its = {k: {a: np.array(b, copy=True) for a, b in v.items()} for k, v in golden_iterations(g).items()}
+    its[1]["Xc"][0, 0] = np.nan
+    with pytest.raises(AssertionError):
+        build_model(oracle_h, g, meta, source=InMemorySource(its))
