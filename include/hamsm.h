@@ -60,6 +60,15 @@ int hamsm_free(hamsm_ctx *ctx, void *d_ptr);
 int hamsm_memcpy_h2d(hamsm_ctx *ctx, void *d_dst, const void *h_src, size_t bytes);
 int hamsm_memcpy_d2h(hamsm_ctx *ctx, void *h_dst, const void *d_src, size_t bytes);
 int hamsm_memset(hamsm_ctx *ctx, void *d_dst, int byte, size_t bytes);
+/* Ingest (the reference re-opens west.h5 and appends per segment, _data.py:807-932): page-locked host
+ * staging buffers and uploads that overlap the host's reading / featurizing of the next block.  hamsm_memcpy_h2d_async
+ * enqueues on the context's COPY stream and returns at once: the host buffer must be page-locked (hamsm_malloc_host) and
+ * must not be rewritten before hamsm_copy_sync; the copied bytes are visible to later calls on the context after
+ * hamsm_copy_sync (which also orders the compute stream behind the copies).                                              */
+int hamsm_malloc_host(hamsm_ctx *ctx, size_t bytes, void **h_out);
+int hamsm_free_host(hamsm_ctx *ctx, void *h_ptr);
+int hamsm_memcpy_h2d_async(hamsm_ctx *ctx, void *d_dst, const void *h_src, size_t bytes);
+int hamsm_copy_sync(hamsm_ctx *ctx);
 int hamsm_sync(hamsm_ctx *ctx);
 
 /* ---- model state (replaces the attributes of StratifiedClusters / modelWE that predict() reads:

@@ -33,6 +33,10 @@ SYMBOLS = {
     "hamsm_memcpy_h2d": (_int, [_vp, _vp, _vp, _sz]),
     "hamsm_memcpy_d2h": (_int, [_vp, _vp, _vp, _sz]),
     "hamsm_memset": (_int, [_vp, _vp, _int, _sz]),
+    "hamsm_malloc_host": (_int, [_vp, _sz, C.POINTER(_vp)]),
+    "hamsm_free_host": (_int, [_vp, _vp]),
+    "hamsm_memcpy_h2d_async": (_int, [_vp, _vp, _vp, _sz]),
+    "hamsm_copy_sync": (_int, [_vp]),
     "hamsm_sync": (_int, [_vp]),
     "hamsm_set_geometry": (_int, [_vp, _int, _int, _int]),
     "hamsm_set_mapper_rectilinear": (_int, [_vp, _vp, _vp]),
@@ -233,6 +237,31 @@ class Hamsm:
         if n:
             self._ck(self.lib.hamsm_memcpy_d2h(self.ctx, _hp(out), _dp(src), n))
         return out
+
+    def pinned(self, shape, dtype) -> np.ndarray:
+        """a page-locked host array (freed by `free_pinned`, or with the context)"""
+        shape = (shape,) if np.isscalar(shape) else tuple(shape)
+        nbytes = int(np.prod(shape, dtype=np.int64)) * np.dtype(dtype).itemsize
+        p = _vp()
+        self._ck(self.lib.hamsm_malloc_host(self.ctx, max(nbytes, 1), C.byref(p)))
+        buf = (C.c_char * max(nbytes, 1)).from_address(p.value)
+        a = np.frombuffer(buf, dtype=dtype, count=int(np.prod(shape, dtype=np.int64))).reshape(shape)
+        self.__dict__.setdefault("_pinned", {})[a.ctypes.data] = p.value
+        return a
+
+    def free_pinned(self, a: np.ndarray):
+        ptr = self.__dict__.get("_pinned", {}).pop(a.ctypes.data, None)
+        if ptr is not None and getattr(self, "ctx", None):
+            self._ck(self.lib.hamsm_free_host(self.ctx, ptr))
+
+    def h2d_async(self, dst, a: np.ndarray, nbytes=None):
+        """upload from a PINNED array on the copy stream; `a` must stay untouched until `copy_sync`"""
+        n = a.nbytes if nbytes is None else int(nbytes)
+        if n:
+            self._ck(self.lib.hamsm_memcpy_h2d_async(self.ctx, _dp(dst), _hp(a), n))
+
+    def copy_sync(self):
+        self._ck(self.lib.hamsm_copy_sync(self.ctx))
 
     def zeros(self, shape, dtype) -> DevBuf:
         b = self.alloc(shape, dtype)

@@ -67,6 +67,8 @@ struct hamsm_ctx {
   char err[512];
   int device = 0;
   hipStream_t stream = nullptr;
+  hipStream_t copy_stream = nullptr;  // uploads that overlap host work (hamsm_memcpy_h2d_async)
+  std::unordered_map<void *, size_t> host_live;  // page-locked blocks handed out by hamsm_malloc_host
   // training steps of different strata are independent chains of small latency-bound kernels: strata alternate
   // between `stream` and these side queues so that the chains overlap (fork/join with events inside run_steps)
   hipStream_t side_stream[3] = {nullptr, nullptr, nullptr};

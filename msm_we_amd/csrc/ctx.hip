@@ -119,6 +119,13 @@ extern "C" void hamsm_destroy(hamsm_ctx *c) {
     if (c->side_stream[i]) hipStreamSynchronize(c->side_stream[i]);
   hamsm_comm_destroy(c);
   blk_cache_flush(c);
+  if (c->copy_stream) {
+    hipStreamSynchronize(c->copy_stream);
+    hipStreamDestroy(c->copy_stream);
+    c->copy_stream = nullptr;
+  }
+  for (auto &kv : c->host_live) hipHostFree(kv.first);
+  release(c->host_live);
   for (auto &kv : c->blk_live) hipFree(kv.first);  // device memory dies with its context
   free_strata(c);
   hipFree(c->d_bounds);
@@ -232,6 +239,43 @@ extern "C" int hamsm_memcpy_d2h(hamsm_ctx *c, void *h, const void *d, size_t n) 
   CTX(c);
   HIPCHK(c, hipMemcpyAsync(h, d, n, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
+  return HAMSM_OK;
+}
+extern "C" int hamsm_malloc_host(hamsm_ctx *c, size_t bytes, void **out) {
+  CTX(c);
+  if (!out) return hamsm_fail(c, HAMSM_EINVAL, "malloc_host: out");
+  HIPCHK(c, hipSetDevice(c->device));
+  void *p = nullptr;
+  hipError_t e = hipHostMalloc(&p, bytes ? bytes : 1);
+  if (e != hipSuccess) return hamsm_fail(c, HAMSM_ENOMEM, "hipHostMalloc(%zu): %s", bytes, hipGetErrorString(e));
+  c->host_live[p] = bytes;
+  *out = p;
+  return HAMSM_OK;
+}
+extern "C" int hamsm_free_host(hamsm_ctx *c, void *p) {
+  CTX(c);
+  if (!p) return HAMSM_OK;
+  auto it = c->host_live.find(p);
+  if (it == c->host_live.end()) return hamsm_fail(c, HAMSM_EINVAL, "hamsm_free_host: %p was not returned by hamsm_malloc_host", p);
+  if (c->copy_stream) HIPCHK(c, hipStreamSynchronize(c->copy_stream));  // no upload may still read from it
+  c->host_live.erase(it);
+  HIPCHK(c, hipHostFree(p));
+  return HAMSM_OK;
+}
+extern "C" int hamsm_memcpy_h2d_async(hamsm_ctx *c, void *d, const void *h, size_t n) {
+  CTX(c);
+  if (n == 0) return HAMSM_OK;
+  bool pinned = false;  // a pageable source would make the call synchronous and its lifetime the caller's problem: refuse
+  for (auto &kv : c->host_live)
+    if ((const char *)h >= (const char *)kv.first && (const char *)h + n <= (const char *)kv.first + kv.second) pinned = true;
+  if (!pinned) return hamsm_fail(c, HAMSM_EINVAL, "memcpy_h2d_async: the source is not inside a hamsm_malloc_host block");
+  if (!c->copy_stream) HIPCHK(c, hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
+  HIPCHK(c, hipMemcpyAsync(d, h, n, hipMemcpyHostToDevice, c->copy_stream));
+  return HAMSM_OK;
+}
+extern "C" int hamsm_copy_sync(hamsm_ctx *c) {
+  CTX(c);
+  if (c->copy_stream) HIPCHK(c, hipStreamSynchronize(c->copy_stream));
   return HAMSM_OK;
 }
 extern "C" int hamsm_memset(hamsm_ctx *c, void *d, int b, size_t n) {

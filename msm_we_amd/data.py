@@ -74,32 +74,49 @@ class NpzDirectorySource:
 
 
 class WestpaH5Source:
-    """WESTPA ``west.h5`` reader for the layout the reference consumes (``_data.py:853-916, 283-300``):
-    ``iterations/iter_%08d/{seg_index['weight'], pcoord, auxdata/<auxpath>}``.  Needs h5py, which is
-    an optional dependency (absent in the build image): constructing this class without it raises."""
+    """WESTPA ``west.h5`` reader for the layout the reference consumes (``_data.py:853-916, 283-300``; written by
+    ``augmentation_driver.py:173-180``): ``iterations/iter_%08d/{seg_index['weight'], pcoord (nSeg, pcoord_len, ndim),
+    auxdata/<auxpath> (nSeg, 2, nAtoms, 3) float32}``.  The file is opened once and every iteration is read exactly once per
+    pass (the reference re-opens it per iteration and appends segment by segment).  Several files (the reference's
+    ``fileList``) are read one after the other, iterations concatenated segment-wise like ``load_iter_data`` does.
+    Needs h5py, an optional dependency (absent in the build image: the tests run this class against a stand-in module)."""
 
     def __init__(self, path, auxpath="coord", pcoord_ndim=1):
         try:
-            import h5py  # noqa: F401
-        except ImportError as e:  # pragma: no cover - h5py is not in the image
+            import h5py
+        except ImportError as e:
             raise ImportError("WestpaH5Source needs h5py") from e
-        self.path, self.auxpath, self.ndim = path, auxpath, pcoord_ndim
+        self.paths = [path] if isinstance(path, (str, bytes)) or hasattr(path, "__fspath__") else list(path)
+        self.auxpath, self.ndim = auxpath, pcoord_ndim
+        self._files = [h5py.File(p, "r") for p in self.paths]
 
-    def iterations(self):  # pragma: no cover
-        import h5py
+    def close(self):
+        for f in self._files:
+            f.close()
+        self._files = []
 
-        with h5py.File(self.path, "r") as f:
-            return sorted(int(k.split("_")[1]) for k in f["iterations"].keys())
+    def iterations(self):
+        its = None
+        for f in self._files:
+            here = {int(k.split("_")[1]) for k in f["iterations"].keys()}
+            its = here if its is None else its | here
+        return sorted(its or ())
 
-    def load(self, n):  # pragma: no cover
-        import h5py
-
-        with h5py.File(self.path, "r") as f:
-            g = f["iterations/iter_%08d" % int(n)]
-            pc = g["pcoord"][:]
-            co = g["auxdata/" + self.auxpath][:]
-            return dict(parent=co[:, 0], child=co[:, -1], p0=pc[:, 0, : self.ndim].astype(np.float64),
-                        p1=pc[:, -1, : self.ndim].astype(np.float64), w=g["seg_index"]["weight"].astype(np.float64))
+    def load(self, n):
+        key = "iterations/iter_%08d" % int(n)
+        parts = []
+        for f in self._files:
+            if key not in f:
+                continue
+            g = f[key]
+            pc = np.asarray(g["pcoord"][:])
+            co = np.asarray(g["auxdata/" + self.auxpath][:])
+            parts.append(dict(parent=co[:, 0], child=co[:, -1], p0=pc[:, 0, : self.ndim].astype(np.float64),
+                              p1=pc[:, -1, : self.ndim].astype(np.float64),
+                              w=np.asarray(g["seg_index"]["weight"], dtype=np.float64)))
+        if not parts:
+            raise KeyError(key)
+        return parts[0] if len(parts) == 1 else {k: np.concatenate([p[k] for p in parts]) for k in parts[0]}
 
 
 class DeviceStore:
@@ -250,62 +267,152 @@ class DataMixin:
             scale[scale < np.finfo(scale.dtype).eps] = np.finfo(scale.dtype).eps
         return np.asarray(W, dtype=np.float64), (None if c.mean_ is None else np.asarray(c.mean_, dtype=np.float64)), scale
 
-    def stage_iterations(self):
-        """Featurize and upload iterations 1..maxIter once.  Idempotent.  `processCoordinates` (user code) runs on the
-        host; a PCA transform (`reduceCoordinates`, _dimensionality.py:37-66) runs on the device over the uploaded raw
-        features; any other `coordinates.transform` runs on the host."""
-        if getattr(self, "_store", None) is not None:
-            return self._store
-        h = self.h
-        if getattr(self, "device_featurizer", None) is not None:
-            return self._stage_with_device_featurizer()
-        lin = self._linear_map()
-        parts = {k: [] for k in ("Xp", "Xc", "p0", "p1", "w")}
-        sizes = []
-        for it in range(1, self.maxIter + 1):
+    # -- staging: one pass over the iterations, host work overlapped with the uploads --------------
+    STAGE_CHUNK_BYTES = 64 << 20  # host bytes per upload block
+
+    def _chunk_host(self, its, mode):
+        """host side of one block of iterations (runs on the reader thread): arrays ready to upload"""
+        Xp, Xc, p0, p1, w = [], [], [], [], []
+        for it in its:
             d = self._load(it)
             n = len(d["w"])
-            for which, key in (("parent", "Xp"), ("child", "Xc")):
-                if key in d and which not in d:
-                    X = np.asarray(d[key])
-                    if lin is None and self.coordinates is not None and type(self.coordinates).__name__ != "Coordinates":
+            for which, key, out in (("parent", "Xp", Xp), ("child", "Xc", Xc)):
+                if mode == "device_featurizer":
+                    X = np.asarray(d[which]).reshape(n, -1)           # raw coordinates, featurized in HBM
+                elif key in d and which not in d:
+                    X = np.asarray(d[key])                            # already featurized by the source
+                    if mode == "host" and self.coordinates is not None and type(self.coordinates).__name__ != "Coordinates":
                         X = self.coordinates.transform(np.asarray(X, dtype=np.float64))
-                elif lin is not None:
-                    X = self.processCoordinates(np.asarray(d[which], dtype=np.float64))
+                elif mode == "device_pca":
+                    X = self.processCoordinates(np.asarray(d[which], dtype=np.float64))   # raw features, projected in HBM
                 else:
                     X = self._featurize(d[which])
-                parts[key].append(X)
-            parts["p0"].append(np.asarray(d["p0"], dtype=np.float64).reshape(n, -1)[:, : self.pcoord_ndim])
-            parts["p1"].append(np.asarray(d["p1"], dtype=np.float64).reshape(n, -1)[:, : self.pcoord_ndim])
-            parts["w"].append(np.asarray(d["w"], dtype=np.float64))
-            sizes.append(n)
-        Xp = np.concatenate(parts["Xp"])
-        Xc = np.concatenate(parts["Xc"])
-        # store float32 when that loses nothing (on-disk WESTPA coordinates are float32)
-        nan_p, nan_c = np.isnan(Xp).any(axis=1), np.isnan(Xc).any(axis=1)
-        if Xp.dtype != np.float32 or Xc.dtype != np.float32:
-            Xp32, Xc32 = Xp.astype(np.float32), Xc.astype(np.float32)
-            if np.array_equal(Xp32.astype(np.float64), Xp, equal_nan=True) and np.array_equal(Xc32.astype(np.float64), Xc, equal_nan=True):
-                Xp, Xc = Xp32, Xc32
-            else:
-                Xp, Xc = Xp.astype(np.float64), Xc.astype(np.float64)
-        offsets = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)
-        p0, p1, w = np.concatenate(parts["p0"]), np.concatenate(parts["p1"]), np.concatenate(parts["w"])
-        if lin is None:
-            self._store = DeviceStore.from_host(h, Xp, Xc, p0, p1, w, offsets)
-            self._store.mark_nan_segments(nan_p, nan_c, w)
+                out.append(X)
+            p0.append(np.asarray(d["p0"], dtype=np.float64).reshape(n, -1)[:, : self.pcoord_ndim])
+            p1.append(np.asarray(d["p1"], dtype=np.float64).reshape(n, -1)[:, : self.pcoord_ndim])
+            w.append(np.asarray(d["w"], dtype=np.float64))
+        cat = lambda v: np.concatenate(v) if len(v) > 1 else np.asarray(v[0])  # noqa: E731
+        return cat(Xp), cat(Xc), cat(p0), cat(p1), cat(w)
+
+    def stage_iterations(self):
+        """Featurize and upload iterations 1..maxIter once.  Idempotent.  One pass: a reader thread loads and featurizes
+        block k+1 (`processCoordinates` is user code and stays on the host) while block k travels -- copied into one of two
+        page-locked slabs and uploaded on the context's copy stream -- and while the device turns the uploaded block into
+        features where that is its job: the shipped distance featurizer (`hamsm_featurize_dist`) and / or a fitted PCA's
+        transform (`hamsm_project`; `reduceCoordinates`, _dimensionality.py:37-66).  Any other `coordinates.transform` runs on
+        the host.  Frames are stored float32 when that loses nothing (WESTPA's auxdata/coord is float32), else float64."""
+        if getattr(self, "_store", None) is not None:
             return self._store
-        W, mean, scale = lin
-        dt = _abi.F32 if Xp.dtype == np.float32 else _abi.F64
-        n, Draw = Xp.shape
-        proj = []
-        for X in (Xp, Xc):  # raw features up, reduced features stay: the raw copy is released at once
-            d_raw = h.to_device(X)
-            proj.append(h.project(d_raw, dt, Draw, n, W, mean, scale))
-            d_raw.free()
-        self._store = DeviceStore(h, W.shape[0], p0.shape[1], _abi.F64, offsets, proj[0], proj[1], h.to_device(p0), h.to_device(p1),
-                                  h.to_device(w))
-        self._store.mark_nan_segments(nan_p, nan_c, w)
+        import time
+        from concurrent.futures import ThreadPoolExecutor
+
+        h = self.h
+        t_start = time.perf_counter()
+        lin = self._linear_map()
+        feat = getattr(self, "device_featurizer", None)
+        if feat is not None and lin is None and self.coordinates is not None and type(self.coordinates).__name__ != "Coordinates":
+            raise NotImplementedError("device featurizer + a non-linear coordinates.transform")
+        mode = "device_featurizer" if feat is not None else ("device_pca" if lin is not None else "host")
+        its = list(range(1, self.maxIter + 1))
+        sizes = np.array([len(self._load(i)["w"]) for i in its], dtype=np.int64) if len(getattr(self, "numSegments", ())) != len(its) \
+            else np.asarray(self.numSegments, dtype=np.int64)
+        offsets = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)
+        N = int(offsets[-1])
+        # first block: fixes the widths and the storage type
+        first = self._chunk_host(its[:1], mode)
+        raw_w = first[0].shape[1]
+        ndim = first[2].shape[1]
+        row_bytes = 2 * raw_w * first[0].dtype.itemsize + 16 * ndim + 8
+        per_chunk = max(1, int(self.STAGE_CHUNK_BYTES // max(1, row_bytes * max(1, int(sizes.mean())))))
+        chunks = [its[i: i + per_chunk] for i in range(0, len(its), per_chunk)]
+        rows_max = int(max(offsets[c[-1]] - offsets[c[0] - 1] for c in chunks))
+
+        def run(up_dtype):
+            """one streaming pass with the uploaded blocks stored as `up_dtype`; returns None when a block does not fit it"""
+            up_dt = _abi.F32 if up_dtype == np.float32 else _abi.F64
+            if mode == "host":
+                D, x_dt = raw_w, up_dt
+                Xd = [h.alloc(max(N, 1) * D, up_dtype) for _ in range(2)]
+                raw = None
+            else:
+                D = (len(feat[1]) if feat is not None else raw_w) if lin is None else lin[0].shape[0]
+                x_dt = _abi.F64
+                Xd = [h.alloc(max(N, 1) * D, np.float64) for _ in range(2)]
+                raw = [h.alloc(max(rows_max, 1) * raw_w, up_dtype) for _ in range(2)]       # uploaded block, parent / child
+                mid = [h.alloc(max(rows_max, 1) * len(feat[1]), np.float64) for _ in range(2)] if feat is not None and lin is not None else None
+            d_p0, d_p1, d_w = h.alloc(max(N, 1) * ndim, np.float64), h.alloc(max(N, 1) * ndim, np.float64), h.alloc(max(N, 1), np.float64)
+            slabs = [dict(X=[h.pinned((rows_max, raw_w), up_dtype) for _ in range(2)], p0=h.pinned((rows_max, ndim), np.float64),
+                          p1=h.pinned((rows_max, ndim), np.float64), w=h.pinned(rows_max, np.float64)) for _ in range(2)]
+            nan = [np.zeros(N, dtype=bool), np.zeros(N, dtype=bool)]
+            w_all = np.empty(N)
+            ok = True
+            try:
+                with ThreadPoolExecutor(1) as pool:
+                    fut = pool.submit(lambda: first if chunks[0] == its[:1] else self._chunk_host(chunks[0], mode))
+                    for k, ch in enumerate(chunks):
+                        blk = fut.result()
+                        if k + 1 < len(chunks):
+                            fut = pool.submit(self._chunk_host, chunks[k + 1], mode)
+                        f0, f1 = int(offsets[ch[0] - 1]), int(offsets[ch[-1]])
+                        n = f1 - f0
+                        if n == 0:
+                            continue
+                        sl = slabs[k & 1]
+                        h.copy_sync()   # the slab's previous upload (block k-2) is done -- and so is block k-1's
+                        if mode != "host":
+                            h.sync()    # ... and the kernels that read the raw blocks
+                        for side in range(2):
+                            X = blk[side]
+                            nan[side][f0:f1] = np.isnan(X).any(axis=1)
+                            if X.dtype != up_dtype:
+                                Xc_ = X.astype(up_dtype)
+                                if up_dtype == np.float32 and not np.array_equal(Xc_.astype(X.dtype), X, equal_nan=True):
+                                    ok = False
+                                    break
+                                X = Xc_
+                            sl["X"][side][:n] = X
+                            dst = Xd[side].offset(f0 * D) if mode == "host" else raw[side]
+                            h.h2d_async(dst, sl["X"][side], n * raw_w * np.dtype(up_dtype).itemsize)
+                        if not ok:
+                            break
+                        sl["p0"][:n], sl["p1"][:n], sl["w"][:n] = blk[2], blk[3], blk[4]
+                        w_all[f0:f1] = blk[4]
+                        h.h2d_async(d_p0.offset(f0 * ndim), sl["p0"], n * ndim * 8)
+                        h.h2d_async(d_p1.offset(f0 * ndim), sl["p1"], n * ndim * 8)
+                        h.h2d_async(d_w.offset(f0), sl["w"], n * 8)
+                        if mode != "host":
+                            h.copy_sync()   # the device stage reads the uploaded block
+                            for side in range(2):
+                                src, src_dt, src_w = raw[side], up_dt, raw_w
+                                if feat is not None:
+                                    out = mid[side] if lin is not None else Xd[side].offset(f0 * D)
+                                    h.featurize_dist(src, src_dt, src_w, n, src_w // 3, feat[1], feat[2], d_X=out)
+                                    src, src_dt, src_w = out, _abi.F64, len(feat[1])
+                                if lin is not None:
+                                    h.project(src, src_dt, src_w, n, lin[0], lin[1], lin[2], d_Y=Xd[side].offset(f0 * D))
+                    h.copy_sync()
+                    h.sync()
+            finally:
+                for sl in slabs:
+                    for a in (*sl["X"], sl["p0"], sl["p1"], sl["w"]):
+                        h.free_pinned(a)
+                for bufs in (raw, mid if mode != "host" else None):
+                    for b_ in bufs or ():
+                        b_.free()
+            if not ok:
+                for b_ in (*Xd, d_p0, d_p1, d_w):
+                    b_.free()
+                return None
+            store = DeviceStore(h, D, ndim, x_dt, offsets, Xd[0], Xd[1], d_p0, d_p1, d_w)
+            store.mark_nan_segments(nan[0], nan[1], w_all)
+            return store
+
+        store = run(np.float32)      # float32 storage / upload when it is exact (checked block by block) ...
+        if store is None:
+            store = run(np.float64)  # ... else once more in float64
+        self._store = store
+        nbytes = N * (2 * raw_w * (4 if store.x_dtype == _abi.F32 and mode == "host" else first[0].dtype.itemsize) + 16 * ndim + 8)
+        self.ingest_stats = {"seconds": time.perf_counter() - t_start, "bytes": int(nbytes), "blocks": len(chunks), "mode": mode}
         return self._store
 
     def set_distance_featurizer(self, atom_indices, reference_positions):
@@ -317,49 +424,6 @@ class DataMixin:
         ref = np.ascontiguousarray(reference_positions, dtype=np.float32).reshape(len(idx), 3)
         self.device_featurizer = ("dist", idx, ref)
         self._store = None
-
-    def _stage_with_device_featurizer(self):
-        """raw coordinates up (float32 when exact), features computed in HBM (`hamsm_featurize_dist`), then the optional
-        linear map (`hamsm_project`); the raw copy is released at once"""
-        h = self.h
-        _, idx, ref = self.device_featurizer
-        lin = self._linear_map()
-        if lin is None and self.coordinates is not None and type(self.coordinates).__name__ != "Coordinates":
-            raise NotImplementedError("device featurizer + a non-linear coordinates.transform")
-        raw = {"parent": [], "child": []}
-        p0s, p1s, ws, sizes = [], [], [], []
-        for it in range(1, self.maxIter + 1):
-            d = self._load(it)
-            n = len(d["w"])
-            for which in raw:
-                raw[which].append(np.asarray(d[which]).reshape(n, -1))
-            p0s.append(np.asarray(d["p0"], dtype=np.float64).reshape(n, -1)[:, : self.pcoord_ndim])
-            p1s.append(np.asarray(d["p1"], dtype=np.float64).reshape(n, -1)[:, : self.pcoord_ndim])
-            ws.append(np.asarray(d["w"], dtype=np.float64))
-            sizes.append(n)
-        feats, nans = [], []
-        for which in ("parent", "child"):
-            R = np.concatenate(raw[which])
-            nans.append(np.isnan(R).any(axis=1))
-            R32 = R.astype(np.float32)
-            dt, R = (_abi.F32, R32) if np.array_equal(R32.astype(np.float64), R, equal_nan=True) else (_abi.F64, R.astype(np.float64))
-            n, width = R.shape
-            d_raw = h.to_device(R)
-            d_X = h.featurize_dist(d_raw, dt, width, n, width // 3, idx, ref)
-            d_raw.free()
-            if lin is not None:
-                W, mean, scale = lin
-                d_Y = h.project(d_X, _abi.F64, len(idx), n, W, mean, scale)
-                d_X.free()
-                d_X = d_Y
-            feats.append(d_X)
-        D = len(idx) if lin is None else lin[0].shape[0]
-        offsets = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)
-        p0, p1, w = np.concatenate(p0s), np.concatenate(p1s), np.concatenate(ws)
-        self._store = DeviceStore(h, D, p0.shape[1], _abi.F64, offsets, feats[0], feats[1], h.to_device(p0), h.to_device(p1),
-                                  h.to_device(w))
-        self._store.mark_nan_segments(nans[0], nans[1], w)
-        return self._store
 
     def attach_store(self, store: DeviceStore, maxIter=None):
         """Use frames that are already resident (bench.py generates shards straight into HBM)."""

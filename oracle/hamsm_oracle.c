@@ -201,6 +201,17 @@ int hamsm_free(hamsm_ctx *c, void *p) {
     }
   return fail(c, HAMSM_EINVAL, "hamsm_free: %p was not returned by hamsm_malloc of this context (double free?)", p);
 }
+int hamsm_malloc_host(hamsm_ctx *c, size_t bytes, void **out) { return hamsm_malloc(c, bytes, out); }
+int hamsm_free_host(hamsm_ctx *c, void *p) { return hamsm_free(c, p); }
+int hamsm_memcpy_h2d_async(hamsm_ctx *c, void *d, const void *h, size_t n) {
+  CTX(c);
+  memcpy(d, h, n);
+  return HAMSM_OK;
+}
+int hamsm_copy_sync(hamsm_ctx *c) {
+  CTX(c);
+  return HAMSM_OK;
+}
 int hamsm_memcpy_h2d(hamsm_ctx *c, void *d, const void *h, size_t n) {
   CTX(c);
   (void)c;
