@@ -299,7 +299,15 @@ def torch_exchange(h, dist, torch, rank, world, dev="cuda"):
             for s, (Cm, counts, csq) in enumerate(state[0]):
                 h.set_centroids(s, Cm if len(Cm) else None, csq=csq if len(Cm) else None, counts=counts if len(Cm) else None)
 
-    h.bcast, h.bcast_model = bcast, bcast_model
+    def gather_to_root(d_send, send_bytes, d_recv, recv_bytes, root=0):
+        a = np.empty(int(send_bytes), dtype=np.uint8)
+        h.d2h(a, d_send)
+        parts = [None] * world if rank == root else None
+        dist.gather_object(a, parts, dst=root)
+        if rank == root:
+            h.h2d(d_recv, np.concatenate(parts))
+
+    h.bcast, h.bcast_model, h.gather_to_root = bcast, bcast_model, gather_to_root
     h.comm_destroy = lambda: None
 
 

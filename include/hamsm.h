@@ -171,6 +171,13 @@ int hamsm_scale(hamsm_ctx *ctx, double *d_F, int64_t count, double divisor);
 int hamsm_cluster_stats(hamsm_ctx *ctx, const int32_t *d_labels, const double *d_pcoord, int64_t n,
                         int nstates, double *d_sum, double *d_min, double *d_max, int64_t *d_count);
 
+/* ---- f4: segments grouped by cluster (the gather of ClusteringMixin.update_cluster_structures, _clustering.py:1398-1526:
+ *      "for every segment, append its structure to its cluster's list", i.e. a stable grouping by label).  d_order[k] (int32,
+ *      device, length n) receives the segment indices sorted by label, segments of one label in ascending order;
+ *      h_indptr[nstates + 1] (host) the offsets of each label's run in it.  Labels outside [0, nstates) -> HAMSM_ERANGE.   */
+int hamsm_group_by_label(hamsm_ctx *ctx, const int32_t *d_labels, int64_t n, int nstates, int32_t *d_order,
+                         int64_t *h_indptr);
+
 /* ---- a13 feed: row-normalised transition matrix as CSR (AnalysisMixin.get_Tmatrix,
  *      _analysis.py:23-79): zero rows -> self loop, target rows -> uniform over basis.
  *      d_F is nstates^2 (already organised).  Outputs are HOST arrays: h_indptr[nstates+1],
@@ -300,6 +307,12 @@ int hamsm_allreduce_min_f64(hamsm_ctx *ctx, double *d_buf, int64_t count);
 int hamsm_allreduce_max_f64(hamsm_ctx *ctx, double *d_buf, int64_t count);
 int hamsm_allreduce_sum_i64(hamsm_ctx *ctx, int64_t *d_buf, int64_t count);
 int hamsm_bcast(hamsm_ctx *ctx, void *d_buf, size_t bytes, int root);
+/* every rank's block to the root, rank by rank: rank r's send_bytes bytes land at d_recv + sum of h_recv_bytes[0..r) on the
+ * root (h_recv_bytes[nranks], the same on every rank; d_recv is only read on the root).  Used to bring the training frames
+ * of every iteration shard to the rank that trains ("exact" mode over ALL iterations): point-to-point
+ * sends over xGMI inside one RCCL group.  One rank: a device copy.                                                  */
+int hamsm_gather_to_root(hamsm_ctx *ctx, const void *d_send, size_t send_bytes, void *d_recv, const int64_t *h_recv_bytes,
+                         int root);
 /* broadcast the whole model state (centroids, counts, csq, remap) from root to every rank.       */
 int hamsm_bcast_model(hamsm_ctx *ctx, int root);
 

@@ -57,6 +57,7 @@ SYMBOLS = {
     "hamsm_flux_accumulate": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _int, _vp, _int, _vp, _i64]),
     "hamsm_scale": (_int, [_vp, _vp, _i64, _f64]),
     "hamsm_cluster_stats": (_int, [_vp, _vp, _vp, _i64, _int, _vp, _vp, _vp, _vp]),
+    "hamsm_group_by_label": (_int, [_vp, _vp, _i64, _int, _vp, _vp]),
     "hamsm_tmatrix_csr": (_int, [_vp, _vp, _int, _vp, _int, _vp, _int, _vp, _vp, _vp, _i64, _vp]),
     "hamsm_train_prepass": (_int, [_vp, _vp, _i64, _vp, _i64, _vp, _vp]),
     "hamsm_train_build_rows": (_int, [_vp, _vp, _i64, _vp, _vp, _vp, _vp]),
@@ -75,6 +76,7 @@ SYMBOLS = {
     "hamsm_allreduce_max_f64": (_int, [_vp, _vp, _i64]),
     "hamsm_allreduce_sum_i64": (_int, [_vp, _vp, _i64]),
     "hamsm_bcast": (_int, [_vp, _vp, _sz, _int]),
+    "hamsm_gather_to_root": (_int, [_vp, _vp, _sz, _vp, _vp, _int]),
     "hamsm_bcast_model": (_int, [_vp, _int]),
     "hamsm_timers": (_int, [_vp, _vp, _int]),
     "hamsm_last_kernel_ms": (_int, [_vp, _int, _vp]),
@@ -394,6 +396,18 @@ class Hamsm:
         self._ck(self.lib.hamsm_cluster_stats(self.ctx, _dp(d_labels), _dp(d_pcoord), int(n), int(nstates),
                                               _dp(d_sum), _dp(d_min), _dp(d_max), _dp(d_count)))
 
+    def group_by_label(self, d_labels, n, nstates):
+        """-> (order int32[n] host, indptr int64[nstates + 1]): segment indices grouped by label, stable"""
+        indptr = np.zeros(nstates + 1, dtype=np.int64)
+        d_order = self.alloc(max(int(n), 1), np.int32)
+        try:
+            self._ck(self.lib.hamsm_group_by_label(self.ctx, _dp(d_labels), int(n), int(nstates), _dp(d_order), _hp(indptr)))
+            order = np.empty(int(n), dtype=np.int32)
+            self.d2h(order, d_order, order.nbytes)
+        finally:
+            d_order.free()
+        return order, indptr
+
     def tmatrix_csr(self, d_F, nstates, basis_idx, target_idx):
         b = np.ascontiguousarray(basis_idx, dtype=np.int32)
         t = np.ascontiguousarray(target_idx, dtype=np.int32)
@@ -517,6 +531,10 @@ class Hamsm:
 
     def bcast(self, d_buf, nbytes, root=0):
         self._ck(self.lib.hamsm_bcast(self.ctx, _dp(d_buf), int(nbytes), int(root)))
+
+    def gather_to_root(self, d_send, send_bytes, d_recv, recv_bytes, root=0):
+        rb = np.ascontiguousarray(recv_bytes, dtype=np.int64)
+        self._ck(self.lib.hamsm_gather_to_root(self.ctx, _dp(d_send), int(send_bytes), _dp(d_recv), _hp(rb), int(root)))
 
     def bcast_model(self, root=0):
         self._ck(self.lib.hamsm_bcast_model(self.ctx, int(root)))

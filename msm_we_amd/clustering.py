@@ -87,10 +87,10 @@ class ClusteringMixin:
         h.set_bounds(self.basis_pcoord_bounds, self.target_pcoord_bounds)
         h._active_clusters = None
 
-    def _frame_bins(self, which, bin_mapper):
+    def _frame_bins(self, which, bin_mapper, store=None):
         """external mapper: device int32 bins of every staged frame's parent (`p0`) / child (`p1`) pcoord, computed ONCE by
         the mapper's own `assign` on the host and cached on the store"""
-        store = self._store
+        store = self._store if store is None else store
         cache = store.__dict__.setdefault("_ext_bins", {})
         key = (which, id(bin_mapper))
         if key not in cache:
@@ -110,33 +110,33 @@ class ClusteringMixin:
         h = self.h
         clusters = StratifiedClusters(bin_mapper, self, n_clusters, [], h=h, **_cluster_args)
 
-        if iters_to_use is None:  # :640-651
-            iters_to_use = range(first_cluster_iter if first_cluster_iter is not None else 1, self.maxIter)
-        iters_to_use = [int(i) for i in iters_to_use]
-
-        # a5 planning support: raw bin (or -1 in basis/target) of every frame's PARENT pcoord
-        # (:849-852 pcoord0List, quirk Q2) + per-iteration histograms, one pass over p0
-        d_bin = h.alloc(store.N, np.int32)
-        if self._mapper_external:
-            h.set_frame_bins(self._frame_bins("p0", bin_mapper))
-        hist = h.train_prepass(store.p0, store.N, store.offsets, d_bin)
-        d_rows = h.alloc(max(store.N, 1), np.int32)
-
-        self.dtrajs = []
         S = bin_mapper.nbins
-        # sharded runs (SURVEY §8e "exact" mode): rank 0 trains on its iterations, the model is broadcast
+        self.dtrajs = []
+        # sharded runs (SURVEY §8e "exact" mode): rank 0 trains -- on every rank's iterations (`train_shards == "all"`: the
+        # frames were gathered to it once, DataMixin.training_store) or on its own block -- and the model is broadcast
         trains_here = getattr(h, "rank", 0) == 0
+        tstore, t_maxIter = self.training_store()
         all_filled = set()
         if trains_here:
-            plan, all_filled = self._plan_training_calls(hist, iters_to_use, n_clusters, bin_mapper, store=store)
+            if iters_to_use is None:  # :640-651
+                iters_to_use = range(first_cluster_iter if first_cluster_iter is not None else 1, t_maxIter)
+            iters_to_use = [int(i) for i in iters_to_use]
+            # a5 planning support: raw bin (or -1 in basis/target) of every frame's PARENT pcoord
+            # (:849-852 pcoord0List, quirk Q2) + per-iteration histograms, one pass over p0
+            d_bin = h.alloc(tstore.N, np.int32)
+            if self._mapper_external:
+                h.set_frame_bins(self._frame_bins("p0", bin_mapper, tstore))
+            hist = h.train_prepass(tstore.p0, tstore.N, tstore.offsets, d_bin)
+            d_rows = h.alloc(max(tstore.N, 1), np.int32)
+            plan, all_filled = self._plan_training_calls(hist, iters_to_use, n_clusters, bin_mapper, store=tstore, maxIter=t_maxIter)
             done = False
             if getattr(self, "speculative_training", True):
-                done = self._train_planned(plan, clusters, store, d_bin, d_rows)
+                done = self._train_planned(plan, clusters, tstore, d_bin, d_rows)
             if not done:
-                self._train_stepwise(plan, clusters, store, d_bin, d_rows)
+                self._train_stepwise(plan, clusters, tstore, d_bin, d_rows)
             self.training_path = "planned" if done else "stepwise"
-        d_bin.free()
-        d_rows.free()
+            d_bin.free()
+            d_rows.free()
 
         # :718-731 never-trained bins are remapped to the nearest trained one
         true_unfilled = np.setdiff1d(range(S), list(all_filled))
@@ -166,7 +166,7 @@ class ClusteringMixin:
         self.launch_ray_discretization(progress_bar)
 
     # ------------------------------------------------------------------------------------------
-    def _plan_training_calls(self, hist, iters_to_use, n_clusters, bin_mapper, store=None):
+    def _plan_training_calls(self, hist, iters_to_use, n_clusters, bin_mapper, store=None, maxIter=None):
         """The control flow of `cluster_stratified` / `do_stratified_clustering` (`_clustering.py:664-716,
         794-886`): which iterations each training call consumes and which bins it fits.  It depends only
         on the per-iteration bin histogram, so every call is known before any arithmetic runs.
@@ -174,21 +174,22 @@ class ClusteringMixin:
         Returns (plan, all_filled); plan = arrays over calls: first / last iteration, call_remap [G,S],
         nrows [G,S] (rows per bin after the call's remap) and fit [G,S] (bins fitted by the call)."""
         S = bin_mapper.nbins
+        maxIter = self.maxIter if maxIter is None else maxIter
         its = np.asarray(iters_to_use, dtype=np.int64)
         n = len(its)
         ident = np.arange(S, dtype=np.int32)
-        valid = its <= self.maxIter
+        valid = its <= maxIter
         H = np.zeros((n, S), dtype=np.int64)
         H[valid] = hist[its[valid] - 1]
         # iterations with NaN child coordinates: `get_iter_coordinates` drops those rows (_data.py:549-553), the call's
         # `assert pcoord_array.shape[0] == iter_coords.shape[0]` (_clustering.py:860-862) then fails -- fatal on the first
         # call, swallowed afterwards (:693-705), i.e. the call is lost and the loop advances by one iteration
-        nan_it = np.zeros(self.maxIter + 2, dtype=bool)
+        nan_it = np.zeros(maxIter + 2, dtype=bool)
         if store is not None and getattr(store, "nan_child", None) is not None:
             per_it = np.add.reduceat(store.nan_child.astype(np.int64), store.offsets[:-1][np.diff(store.offsets) > 0])
             nan_it[np.nonzero(np.diff(store.offsets) > 0)[0] + 1] = per_it > 0
         # an iteration that fills every bin it touches is a training call by itself (:885-886)
-        alone = valid & np.all((H >= n_clusters) | (H == 0), axis=1) & ~nan_it[np.minimum(its, self.maxIter + 1)]
+        alone = valid & np.all((H >= n_clusters) | (H == 0), axis=1) & ~nan_it[np.minimum(its, maxIter + 1)]
         stops = np.nonzero(~alone)[0]
         firsts, lasts, remaps, nrows, fits = [], [], [], [], []
         pos, first_call = 0, True
@@ -216,7 +217,7 @@ class ClusteringMixin:
                     ran_out = True
                     break
                 it = int(its[pos + len(group)])
-                if it > self.maxIter:  # :834-840
+                if it > maxIter:  # :834-840
                     break
                 group.append(it)
                 if nan_it[it]:
@@ -671,6 +672,49 @@ class ClusteringMixin:
         bin_centers[self.indBasis] = self.basis_bin_centers
         self.all_centers = bin_centers
         self.sorted_centers = np.argsort(bin_centers)
+
+    # ------------------------------------------------------------------------------------------
+    removed_clusters = ()
+
+    def update_cluster_structures(self, build_pcoord_cache=False):
+        """`_clustering.py:1398-1526`: the structures (segment-end coordinates), weights and provenance of every cluster, for
+        iterations 1..maxIter-2.  The reference appends segment by segment; here the segments are grouped by cluster on the
+        device (`hamsm_group_by_label`, stable) and each iteration's coordinates are gathered once."""
+        assert self.clusters is not None, "Clusters have not been computed!"
+        h = self.h
+        _, d_child = self._labels_device()
+        last = self.maxIter - 2                                   # `range(1, total_num_iterations - 1)` (:1437, 1464)
+        offs = self.stage_iterations().offsets
+        n = int(offs[last]) if last >= 1 else 0
+        ns = int(self.n_clusters) + 2
+        order, indptr = h.group_by_label(d_child, n, ns)
+        it_of = np.searchsorted(offs, order, side="right")       # 1-based iteration of every grouped segment
+        seg_of = order - offs[it_of - 1]
+        coords, weights, pcs = {}, {}, {}
+        for it in range(1, last + 1):
+            # (`get_iter_coordinates` drops NaN rows, and the reference indexes what remains by segment number, :1466-1493:
+            # kept as it is -- an IndexError, or rows shifted by one, where an iteration has NaN coordinates)
+            coords[it] = self.get_iter_coordinates(it)
+            weights[it] = self.seg_weights[it]
+            pcs[it] = self.pcoord1List
+        cluster_structures, cluster_structure_weights, structure_iteration_segments = {}, {}, {}
+        pcoord_cache = {} if build_pcoord_cache else None
+        # keys appear in the order in which the reference first meets each cluster (dict insertion order)
+        first_seen = {c: int(order[indptr[c]]) for c in range(ns) if indptr[c + 1] > indptr[c]}
+        for c in sorted(first_seen, key=first_seen.get):
+            sl = slice(int(indptr[c]), int(indptr[c + 1]))
+            its, segs = it_of[sl], seg_of[sl]
+            if c in self.removed_clusters:
+                raise Exception("This dtraj point was in a removed cluster -- this should never happen!")
+            cluster_structures[c] = [coords[int(i)][int(s)] for i, s in zip(its, segs)]
+            cluster_structure_weights[c] = [weights[int(i)][int(s)] for i, s in zip(its, segs)]
+            structure_iteration_segments[c] = [[int(i), int(s), self.fileList[0]] for i, s in zip(its, segs)]
+            if build_pcoord_cache:
+                pcoord_cache[c] = [pcs[int(i)][int(s)] for i, s in zip(its, segs)]
+        self.cluster_structures = cluster_structures
+        self.cluster_structure_weights = cluster_structure_weights
+        self.pcoord_cache = pcoord_cache
+        self.structure_iteration_segments = structure_iteration_segments
 
     # ------------------------------------------------------------------------------------------
     def organize_stratified(self, use_ray=True, progress_bar=None):

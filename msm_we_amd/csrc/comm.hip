@@ -90,6 +90,30 @@ extern "C" int hamsm_bcast(hamsm_ctx *c, void *b, size_t bytes, int root) {
   return HAMSM_OK;
 }
 
+extern "C" int hamsm_gather_to_root(hamsm_ctx *c, const void *d_send, size_t send_bytes, void *d_recv, const int64_t *h_recv_bytes,
+                                    int root) {
+  CTX(c);
+  if (c->nranks == 1 && !c->comm) {
+    if (send_bytes) HIPCHK(c, hipMemcpyAsync(d_recv, d_send, send_bytes, hipMemcpyDeviceToDevice, c->stream));
+    return HAMSM_OK;
+  }
+  if (!c->comm) return hamsm_fail(c, HAMSM_EINVAL, "comm not initialised");
+  if (root < 0 || root >= c->nranks || !h_recv_bytes) return hamsm_fail(c, HAMSM_EINVAL, "gather_to_root: root / sizes");
+  if ((int64_t)send_bytes != h_recv_bytes[c->rank]) return hamsm_fail(c, HAMSM_EINVAL, "gather_to_root: send size disagrees with the size table");
+  ncclComm_t cm = (ncclComm_t)c->comm;
+  NCCLCHK(c, ncclGroupStart());
+  if (send_bytes) ncclSend(d_send, send_bytes, ncclChar, root, cm, c->stream);
+  if (c->rank == root) {
+    size_t off = 0;
+    for (int r = 0; r < c->nranks; r++) {
+      if (h_recv_bytes[r]) ncclRecv((char *)d_recv + off, (size_t)h_recv_bytes[r], ncclChar, r, cm, c->stream);
+      off += (size_t)h_recv_bytes[r];
+    }
+  }
+  NCCLCHK(c, ncclGroupEnd());
+  return HAMSM_OK;
+}
+
 // centroids, counts, ||c||^2 and remap of every stratum, root -> all (exact-mode training: SURVEY §7 hard part 3)
 extern "C" int hamsm_bcast_model(hamsm_ctx *c, int root) {
   CTX(c);

@@ -7,6 +7,7 @@
 // then two hand-written passes: per (cell, iteration) run an in-order partial sum, per cell an
 // in-order sum of those partials on top of the value already in F.
 #include <cstring>
+#include <vector>
 #include <hip/hip_runtime.h>
 #include <rocprim/rocprim.hpp>
 
@@ -119,4 +120,53 @@ int hamsm_flux_sorted(hamsm_ctx *c, const MapperDev &m, const FluxArgs &g, const
   e = hipGetLastError();
   if (e != hipSuccess) return hamsm_fail(c, HAMSM_EDEVICE, "flux_sorted: %s", hipGetErrorString(e));
   return HAMSM_OK;
+}
+
+// ---- f4: stable grouping of segment indices by label -----------------------------------------------------------------------
+__global__ void k_group_keys(const int32_t *__restrict__ lab, int64_t n, int ns, unsigned *keys, int32_t *vals,
+                             unsigned long long *cnt, int *err) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  int l = lab[i];
+  if (l < 0 || l >= ns) {
+    dev_set_error(err, HAMSM_ERANGE, (int)i, l);
+    l = 0;
+  } else {
+    atomicAdd(&cnt[l], 1ull);
+  }
+  keys[i] = (unsigned)l;
+  vals[i] = (int32_t)i;
+}
+
+extern "C" int hamsm_group_by_label(hamsm_ctx *c, const int32_t *lab, int64_t n, int ns, int32_t *order, int64_t *h_indptr) {
+  CTX(c);
+  if (ns <= 0 || !h_indptr) return hamsm_fail(c, HAMSM_EINVAL, "group_by_label: nstates / indptr");
+  for (int s = 0; s <= ns; s++) h_indptr[s] = 0;
+  if (n <= 0) return HAMSM_OK;
+  if (n > 0x7fffffffLL) return hamsm_fail(c, HAMSM_ENOTSUP, "group_by_label: more than 2^31 segments");
+  int bits = 1;
+  while (bits < 32 && ((unsigned)ns >> bits)) bits++;
+  size_t temp_bytes = 0;
+  unsigned *nk = nullptr;
+  int32_t *nv = nullptr;
+  hipError_t e = rocprim::radix_sort_pairs(nullptr, temp_bytes, nk, nk, nv, nv, (size_t)n, 0, bits, c->stream);
+  if (e != hipSuccess) return hamsm_fail(c, HAMSM_EDEVICE, "radix_sort_pairs(size): %s", hipGetErrorString(e));
+  const size_t a4 = ((size_t)n * 4 + 255) & ~(size_t)255, ac = ((size_t)ns * 8 + 255) & ~(size_t)255;
+  int rc = hamsm_ensure_scratch(c, 3 * a4 + ac + temp_bytes + 256);
+  if (rc) return rc;
+  char *base = (char *)c->scratch;
+  unsigned *k_in = (unsigned *)base, *k_out = (unsigned *)(base + a4);
+  int32_t *v_in = (int32_t *)(base + 2 * a4);
+  unsigned long long *cnt = (unsigned long long *)(base + 3 * a4);
+  void *temp = base + 3 * a4 + ac;
+  HIPCHK(c, hipMemsetAsync(cnt, 0, sizeof(unsigned long long) * ns, c->stream));
+  hipLaunchKernelGGL(k_group_keys, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, lab, n, ns, k_in, v_in, cnt, c->d_err);
+  e = rocprim::radix_sort_pairs(temp, temp_bytes, k_in, k_out, v_in, order, (size_t)n, 0, bits, c->stream);  // stable
+  if (e != hipSuccess) return hamsm_fail(c, HAMSM_EDEVICE, "radix_sort_pairs: %s", hipGetErrorString(e));
+  std::vector<unsigned long long> hc((size_t)ns);
+  e = hipMemcpyAsync(hc.data(), cnt, sizeof(unsigned long long) * ns, hipMemcpyDeviceToHost, c->stream);
+  hipError_t es = hipStreamSynchronize(c->stream);
+  if (e != hipSuccess || es != hipSuccess) return hamsm_fail(c, HAMSM_EDEVICE, "group_by_label read-back");
+  for (int s = 0; s < ns; s++) h_indptr[s + 1] = h_indptr[s] + (int64_t)hc[s];
+  return hamsm_check_device_error(c, "group_by_label");
 }

@@ -170,6 +170,7 @@ class DataMixin:
     def set_iteration_source(self, source):
         self._source = source
         self._store = None
+        self._train_store = None
 
     def _featurize(self, coords):
         """a1 + a2 on the host for now: user ``processCoordinates`` then ``coordinates.transform``
@@ -425,9 +426,69 @@ class DataMixin:
         self.device_featurizer = ("dist", idx, ref)
         self._store = None
 
+    # -- sharded runs: the frames training needs, on the rank that trains --------------------------------------------
+    train_shards = "all"   # "all": rank 0 trains on every rank's iterations (N ranks == one process on the same data);
+                           # "rank0": on its own shard only (the reference's `iters_to_use` restricted to that block)
+
+    def training_store(self):
+        """(store, maxIter) the training pass runs over.  One rank, or `train_shards == "rank0"`: the local store.  Otherwise
+        the child frames, parent pcoords and weights of iterations 1..maxIter-1 of EVERY rank are brought to rank 0 once
+        (`hamsm_gather_to_root`: point-to-point over xGMI; they stay resident next to rank 0's own shard) and chained in rank
+        order -- shards are consecutive blocks of WE iterations -- so that training sees exactly the frames, in exactly the
+        order, a single process holding all iterations would.  Other ranks get (None, 0): they do not train."""
+        h = self.h
+        R = getattr(h, "nranks", 1)
+        store = self.stage_iterations()
+        if R == 1 or self.train_shards != "all":
+            return store, self.maxIter
+        if getattr(self, "_train_store", None) is not None:
+            return self._train_store
+        if store.nan_child is not None:
+            raise NotImplementedError("NaN-coordinate segments in a sharded run with train_shards='all'")
+        n_it = self.maxIter - 1
+        sizes = np.diff(store.offsets[: n_it + 1]).astype(np.int64)
+        # per-rank iteration counts, then per-iteration segment counts of all ranks (two small exchanges)
+        cnt = np.zeros(R, dtype=np.int64)
+        cnt[h.rank] = n_it
+        d = h.to_device(cnt)
+        h.allreduce_sum_i64(d, R)
+        cnt = d.to_host()
+        d.free()
+        meta = np.zeros(int(cnt.sum()) + 2 * R, dtype=np.int64)
+        lo = int(cnt[: h.rank].sum())
+        meta[lo: lo + n_it] = sizes
+        meta[int(cnt.sum()) + 2 * h.rank] = store.x_dtype
+        meta[int(cnt.sum()) + 2 * h.rank + 1] = store.D
+        d = h.to_device(meta)
+        h.allreduce_sum_i64(d, meta.size)
+        meta = d.to_host()
+        d.free()
+        all_sizes, tail = meta[: int(cnt.sum())], meta[int(cnt.sum()):].reshape(R, 2)
+        assert (tail[:, 0] == store.x_dtype).all() and (tail[:, 1] == store.D).all(), "ranks staged different frame layouts"
+        rows = np.array([all_sizes[int(cnt[:r].sum()): int(cnt[: r + 1].sum())].sum() for r in range(R)], dtype=np.int64)
+        n_local = int(rows[h.rank])
+        esz = 4 if store.x_dtype == _abi.F32 else 8
+        root = h.rank == 0
+        N = int(rows.sum())
+        Xc = h.alloc(max(N, 1) * store.D, np.float32 if esz == 4 else np.float64) if root else None
+        p0 = h.alloc(max(N, 1) * store.ndim, np.float64) if root else None
+        w = h.alloc(max(N, 1), np.float64) if root else None
+        h.gather_to_root(store.Xc, n_local * store.D * esz, Xc, rows * store.D * esz, 0)
+        h.gather_to_root(store.p0, n_local * store.ndim * 8, p0, rows * store.ndim * 8, 0)
+        h.gather_to_root(store.w, n_local * 8, w, rows * 8, 0)
+        h.sync()
+        if root:
+            offsets = np.concatenate([[0], np.cumsum(all_sizes)]).astype(np.int64)
+            ts = DeviceStore(h, store.D, store.ndim, store.x_dtype, offsets, None, Xc, p0, None, w)
+            self._train_store = (ts, len(all_sizes) + 1)
+        else:
+            self._train_store = (None, 0)
+        return self._train_store
+
     def attach_store(self, store: DeviceStore, maxIter=None):
         """Use frames that are already resident (bench.py generates shards straight into HBM)."""
         self._store = store
+        self._train_store = None
         if maxIter is not None:
             self.maxIter = maxIter
             self.numSegments = np.diff(store.offsets).astype(float)[:maxIter]

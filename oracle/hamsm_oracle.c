@@ -704,6 +704,24 @@ int hamsm_featurize_dist(hamsm_ctx *c, const void *coords, int dt, int64_t ldc, 
   return HAMSM_OK;
 }
 
+/* --- f4: the grouping of update_cluster_structures (_clustering.py:1460-1500): segments appended to their cluster's list in
+ * segment order = a stable counting sort of the segment indices by label */
+int hamsm_group_by_label(hamsm_ctx *c, const int32_t *lab, int64_t n, int ns, int32_t *order, int64_t *indptr) {
+  CTX(c);
+  if (ns <= 0 || !indptr) return fail(c, HAMSM_EINVAL, "group_by_label: nstates / indptr");
+  for (int s = 0; s <= ns; s++) indptr[s] = 0;
+  for (int64_t i = 0; i < n; i++) {
+    if (lab[i] < 0 || lab[i] >= ns) return fail(c, HAMSM_ERANGE, "group_by_label: index out of range at element %lld (value %d)", (long long)i, lab[i]);
+    indptr[lab[i] + 1]++;
+  }
+  for (int s = 0; s < ns; s++) indptr[s + 1] += indptr[s];
+  int64_t *fill = (int64_t *)malloc(sizeof(int64_t) * (size_t)ns);
+  for (int s = 0; s < ns; s++) fill[s] = indptr[s];
+  for (int64_t i = 0; i < n; i++) order[fill[lab[i]]++] = (int32_t)i;
+  free(fill);
+  return HAMSM_OK;
+}
+
 /* --- a5 support: _clustering.py:872-886 */
 int hamsm_train_prepass(hamsm_ctx *c, const double *p, int64_t n, const int64_t *offs, int64_t n_iters, int32_t *bin,
                         int64_t *hist) {
@@ -1096,6 +1114,13 @@ int hamsm_allreduce_sum_i64(hamsm_ctx *c, int64_t *b, int64_t n) {
 int hamsm_bcast(hamsm_ctx *c, void *b, size_t n, int root) {
   CTX(c);
   (void)c, (void)b, (void)n, (void)root;
+  return HAMSM_OK;
+}
+int hamsm_gather_to_root(hamsm_ctx *c, const void *s, size_t n, void *r, const int64_t *sizes, int root) {
+  CTX(c);
+  (void)sizes;
+  (void)root;
+  if (n) memcpy(r, s, n); /* one rank */
   return HAMSM_OK;
 }
 int hamsm_bcast_model(hamsm_ctx *c, int root) {

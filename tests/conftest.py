@@ -117,6 +117,30 @@ def load_golden(case):
     return g, meta
 
 
+def check_cluster_structures(m, g):
+    """f4: `update_cluster_structures` on the organised model against the reference's: clusters in the order the reference
+    first meets them, per cluster the same segments (iteration, segment), weights, pcoords and coordinates -- or the same
+    failure where the reference fails (NaN coordinates)."""
+    if "ucs_error" in g.files:
+        with pytest.raises(Exception) as ei:
+            m.update_cluster_structures(build_pcoord_cache=True)
+        assert type(ei.value).__name__ == str(g["ucs_error"]).split(":")[0]
+        return
+    m.update_cluster_structures(build_pcoord_cache=True)
+    keys = list(m.cluster_structures.keys())
+    assert keys == list(g["ucs_keys"])
+    assert [len(m.cluster_structures[k]) for k in keys] == list(g["ucs_counts"])
+    if "ucs_weights" in g.files:   # (compact cases keep the per-cluster summaries only)
+        assert np.array_equal(np.concatenate([np.asarray(m.cluster_structure_weights[k]) for k in keys]), g["ucs_weights"])
+        its = np.concatenate([np.array([[a, b] for a, b, _ in m.structure_iteration_segments[k]]) for k in keys])
+        assert np.array_equal(its, g["ucs_iter_seg"])
+    assert np.array_equal(np.stack([np.asarray(m.cluster_structures[k][0], dtype=np.float64).ravel() for k in keys]), g["ucs_first_coord"])
+    np.testing.assert_allclose([np.sum(np.asarray(m.cluster_structures[k], dtype=np.float64)) for k in keys], g["ucs_coord_sums"], rtol=1e-13)
+    if "ucs_pcoords" in g.files:
+        pcs = np.concatenate([np.asarray(m.pcoord_cache[k], dtype=np.float64).reshape(len(m.pcoord_cache[k]), -1) for k in keys])
+        assert np.array_equal(pcs, g["ucs_pcoords"])
+
+
 def check_block_validation(m, g):
     """a14: `do_block_validation` (msm_we.py:884-1009) against what the REAL reference produced for the same split:
     iteration lists, per-group raw and organised flux matrices, cleaned state counts, discretization and remap identical;

@@ -81,7 +81,7 @@ def compact(out):
     for k, v in out.items():
         if k.startswith("in_") and k != "in_offsets":
             continue   # regenerated from the seed
-        if k in ("fit_centers", "pairs_post_cluster", "pairs_clean", "Tmatrix"):
+        if k in ("fit_centers", "pairs_post_cluster", "pairs_clean", "Tmatrix", "ucs_iter_seg", "ucs_pcoords", "ucs_weights"):
             continue   # (pairs = parent labels + dtrajs: parent labels kept below; T is a function of fluxMatrix)
         v = np.asarray(v)
         if v.ndim == 2 and v.shape[0] == v.shape[1] and v.shape[0] > 64 and v.dtype == np.float64:
@@ -227,6 +227,22 @@ def run_case(case):
     out["pSS"] = np.asarray(model.pSS).copy()
     model.get_steady_state_target_flux()
     out["JtargetSS"] = np.float64(model.JtargetSS)
+
+    # --- f4: update_cluster_structures (_clustering.py:1398-1526) on the organised model -----------------------------------
+    try:
+        model.update_cluster_structures(build_pcoord_cache=True)
+        keys = list(model.cluster_structures.keys())
+        out["ucs_keys"] = np.array(keys, dtype=np.int64)
+        out["ucs_counts"] = np.array([len(model.cluster_structures[k]) for k in keys], dtype=np.int64)
+        out["ucs_weights"] = np.concatenate([np.asarray(model.cluster_structure_weights[k], dtype=np.float64) for k in keys])
+        out["ucs_coord_sums"] = np.array([np.sum(np.asarray(model.cluster_structures[k], dtype=np.float64)) for k in keys])
+        out["ucs_first_coord"] = np.stack([np.asarray(model.cluster_structures[k][0], dtype=np.float64).ravel() for k in keys])
+        out["ucs_iter_seg"] = np.concatenate([np.array([[a, b] for a, b, _ in model.structure_iteration_segments[k]], dtype=np.int64)
+                                              for k in keys])
+        out["ucs_pcoords"] = np.concatenate([np.asarray(model.pcoord_cache[k], dtype=np.float64).reshape(len(model.pcoord_cache[k]), -1)
+                                             for k in keys])
+    except Exception as e:  # noqa: BLE001
+        out["ucs_error"] = np.array(f"{type(e).__name__}: {e}"[:300])
 
     # --- a14: do_block_validation (msm_we.py:884-1009): per group flux matrix -> clean -> T -> steady state -> J ----------
     groups, blocks = spec.get("block_validation", (2, 4))

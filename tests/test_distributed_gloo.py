@@ -59,6 +59,17 @@ def _gloo_comm(h, dist, rank, world):
 
     h.bcast_model = bcast_model
 
+    def gather_to_root(d_send, send_bytes, d_recv, recv_bytes, root=0):
+        a = np.empty(int(send_bytes), dtype=np.uint8)
+        h.d2h(a, d_send)
+        parts = [None] * world if rank == root else None
+        dist.gather_object(a, parts, dst=root)
+        if rank == root:
+            assert [len(p) for p in parts] == [int(b) for b in recv_bytes]
+            h.h2d(d_recv, np.concatenate(parts))
+
+    h.gather_to_root = gather_to_root
+
 
 def _shard_model(h, g, meta, first, last):
     from msm_we_amd.data import InMemorySource
@@ -75,7 +86,7 @@ def _shard_model(h, g, meta, first, last):
     return m
 
 
-def _worker(rank, world, port, out):
+def _worker(rank, world, port, out, train_shards="all"):
     sys.path.insert(0, ROOT)
     import torch.distributed as dist
 
@@ -90,6 +101,7 @@ def _worker(rank, world, port, out):
     # loaded iterations 1..21 and 20..39: the reference's maxIter bookkeeping discretizes all but the last two loaded
     # ones (_data.py:860-866), i.e. 1..19 and 20..37 -- disjoint, and together what one process makes of 1..39
     m = _shard_model(h, g, meta, (1, 20)[rank], (20, 38)[rank])
+    m.train_shards = train_shards
     bm = RectilinearBinMapper([np.array(meta["boundaries"], dtype=np.float32)])
     m.cluster_coordinates(meta["K_s"], streaming=True, use_ray=True, stratified=True, user_bin_mapper=bm,
                           random_state=meta["seed"])
@@ -108,13 +120,49 @@ def _worker(rank, world, port, out):
     dist.destroy_process_group()
 
 
-def test_two_ranks_match_single_process(tmp_path, oracle_lib):
+def test_two_ranks_equal_one_process_on_all_iterations(tmp_path, oracle_lib):
+    """`train_shards = "all"` (the default): the training frames of every shard are gathered to rank 0, which then trains
+    on all iterations in order -- the two-rank run IS the single-process run of the same data: every label, the raw flux
+    matrix, the cleaned model, T, the steady state."""
     import torch.multiprocessing as mp
 
     from msm_we_amd import _abi
 
     out = str(tmp_path / "rank{}.npz")
-    mp.spawn(_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    mp.spawn(_worker, args=(2, _free_port(), out, "all"), nprocs=2, join=True)
+    r0, r1 = np.load(out.format(0)), np.load(out.format(1))
+    g, meta = load_golden("c1p_d10")
+    bm = RectilinearBinMapper([np.array(meta["boundaries"], dtype=np.float32)])
+    h = _abi.Hamsm(lib=oracle_lib)
+    c = _shard_model(h, g, meta, 1, 38)
+    c.cluster_coordinates(meta["K_s"], streaming=True, use_ray=True, stratified=True, user_bin_mapper=bm, random_state=meta["seed"])
+    labels = np.concatenate(c.dtrajs)
+    assert np.array_equal(np.concatenate([r0["labels"], r1["labels"]]), labels)
+    assert np.array_equal(r0["centers0"], c.clusters.cluster_models[0].cluster_centers_) and np.array_equal(r0["centers0"], r1["centers0"])
+    c.get_fluxMatrix(0, first_iter=0, last_iter=c.maxIter)
+    assert np.array_equal(r0["flux"], r1["flux"])
+    np.testing.assert_allclose(r0["flux"], c.fluxMatrixRaw, rtol=1e-12, atol=1e-300)
+    c.organize_fluxMatrix(use_ray=True)
+    c.get_Tmatrix()
+    c.get_steady_state()
+    c.get_steady_state_target_flux()
+    assert np.array_equal(np.concatenate([r0["labels2"], r1["labels2"]]), np.concatenate(c.dtrajs))
+    for k in ("fluxMatrix", "T", "pSS", "J", "centers", "minmax", "counts"):
+        assert np.array_equal(r0[k], r1[k], equal_nan=True), k
+    np.testing.assert_allclose(r0["fluxMatrix"], c.fluxMatrix, rtol=1e-11, atol=1e-300)
+    np.testing.assert_allclose(r0["T"], c.Tmatrix, rtol=1e-11, atol=1e-300)
+    np.testing.assert_allclose(r0["pSS"], c.pSS, rtol=1e-8, atol=1e-300)
+    assert abs(float(r0["J"]) - c.JtargetSS) <= 1e-8 * c.JtargetSS
+
+
+def test_two_ranks_match_single_process(tmp_path, oracle_lib):
+    """`train_shards = "rank0"`: rank 0 trains on its own block of iterations only (the reference's `iters_to_use`)"""
+    import torch.multiprocessing as mp
+
+    from msm_we_amd import _abi
+
+    out = str(tmp_path / "rank{}.npz")
+    mp.spawn(_worker, args=(2, _free_port(), out, "rank0"), nprocs=2, join=True)
     r0, r1 = np.load(out.format(0)), np.load(out.format(1))
 
     # single process: train on shard 0, reuse its centroids for shard 1, combine the flux by hand
