@@ -339,11 +339,76 @@ def full_pipeline(m, cfg, seed, flux_mode):
             "validation_JtargetSS": [float(v.JtargetSS) for v in m.validation_models]}
 
 
+def roofline_by_kernel(cfg, n_iters, n_seg, timers, steps, assign_tflops, assign_peak, assign_avg_ms):
+    """One entry per stage of the timed step, from the HIP-event stage timers of THIS run (the library brackets every launch
+    group with events on its stream): device milliseconds per step, the algorithmic work of SURVEY.md §8d, and the fraction
+    of the roof that binds the stage.  The training steps dominate the step and are latency-bound."""
+    per = {k: v / steps * 1e3 for k, v in timers.items()}
+    S, K_s, D = cfg.S, cfg.K_s, cfg.D
+    rows_trained = n_seg * (1.0 - 0.1 / S)            # parent pcoord outside basis (< 0.05) and target (> S - 0.05)
+    train_flops = 2.0 * rows_trained * K_s * D        # E-step distances (the M-step adds 2 D per row)
+    train_bytes = rows_trained * (2 * (D * 4 + 8) + 8 * D)   # rows read by the E-step, f64 copy written and re-read by the M-step
+    out = [
+        {"stage": "training steps", "kernels": "k_step_assign (v_mfma_f64_16x16x4_f64) + k_step_update, one pair per WE iteration "
+                                               "and queue, two strata per launch", "launches_per_step": 4 * (n_iters - 0),
+         "device_ms_per_step": per["step"], "flop": train_flops, "achieved_TFLOPs": train_flops / (per["step"] * 1e-3) / 1e12,
+         "peak_TFLOPs": PEAK_F64_MFMA_TFLOPS, "frac": train_flops / (per["step"] * 1e-3) / 1e12 / PEAK_F64_MFMA_TFLOPS,
+         "algorithmic_GBps": train_bytes / (per["step"] * 1e-3) / 1e9, "bound": "latency: a chain of 2 x n_iterations dependent "
+                                                                                 "launches of ~8 us on ~2500-row batches"},
+        {"stage": "assign (2 launches)", "kernels": "k_assign_filter + k_assign_sorted", "device_ms_per_step": per["assign"],
+         "avg_launch_ms": assign_avg_ms, "achieved_TFLOPs": assign_tflops, "peak_TFLOPs": assign_peak, "frac": assign_tflops / assign_peak,
+         "bound": "mfma / vector issue"},
+        {"stage": "k-means++ seeding", "kernels": "k_seed_gather + k_seed_gram + k_seed_g", "device_ms_per_step": per["seed"],
+         "bound": "latency: K_s - 1 sequential greedy steps per stratum"},
+        {"stage": "flux matrix", "kernels": "k_flux_xcd + k_flux_fold (atomic mode) or rocPRIM sort + 2 ordered passes",
+         "device_ms_per_step": per["flux"], "bytes": 32.0 * n_seg, "achieved_GBps": 32.0 * n_seg / (per["flux"] * 1e-3) / 1e9
+         if per["flux"] > 0 else None, "peak_GBps": PEAK_HBM_GBS, "frac": 32.0 * n_seg / (per["flux"] * 1e-3) / 1e9 / PEAK_HBM_GBS
+         if per["flux"] > 0 else None, "bound": "L2 atomics"},
+        {"stage": "bucket passes + training prepass", "kernels": "k_sort_count / k_sort_offsets / k_sort_fill, k_prepass, k_build_rows_wave",
+         "device_ms_per_step": per["other"] + per["prepass"], "bytes": (3 * 12.0 * 2 + 12.0) * n_seg, "bound": "hbm"},
+    ]
+    return out
+
+
+def ingest_leg(h, cfg, n_it, log):
+    """f2: `stage_iterations` from per-iteration files (NpzDirectorySource, the h5py-free layout) -- reader thread, two pinned
+    slabs, uploads on the copy stream -- against the same frames uploaded from one host array in one piece."""
+    import shutil
+    import tempfile
+    from msm_we_amd.data import InMemorySource, NpzDirectorySource
+
+    lat = synthetic.latent_centres(cfg)
+    its = {it: synthetic.make_iteration(cfg, it, lat) for it in range(1, n_it + 2)}
+    tmp = tempfile.mkdtemp(prefix="hamsm_ingest_")
+    try:
+        src = NpzDirectorySource.export(InMemorySource(its), tmp)
+        res = {}
+        for name, source in (("npz_files", src), ("in_memory", InMemorySource(its))):
+            m = modelWE(h=h)
+            m.pcoord_ndim = 1
+            m.set_iteration_source(source)
+            m.get_iterations()
+            t0 = time.perf_counter()
+            st = m.stage_iterations()
+            h.sync()
+            dt = time.perf_counter() - t0
+            res[name] = {"seconds": dt, "GBps": m.ingest_stats["bytes"] / dt / 1e9, "bytes": m.ingest_stats["bytes"],
+                         "blocks": m.ingest_stats["blocks"], "frames": int(st.N)}
+            for b in (st.Xp, st.Xc, st.p0, st.p1, st.w):
+                b.free()
+        log(f"ingest: {res}")
+        return res
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
 def pmc_traffic(cfg, n_iters):
     """HBM bytes per assign launch (ranking pass + exact pass) from the committed rocprofv3 PMC passes of this same workload
     (profiles/r01_m_pmc_summary.csv: separate --pmc FETCH_SIZE / WRITE_SIZE runs; FETCH_SIZE doubled as
     MI355X_MICROARCH.md prescribes for gfx950, calibrated here on k_sort_count's 80 MB pcoord read)."""
-    path = os.path.join(ROOT, "profiles", "r01_m_pmc_summary.csv")
+    path = os.path.join(ROOT, "profiles", "r02_pmc_summary.csv")
+    if not os.path.exists(path):
+        path = os.path.join(ROOT, "profiles", "r01_m_pmc_summary.csv")
     if cfg.name != "c3" or n_iters != cfg.n_iters or not os.path.exists(path):
         return None
     filt = os.environ.get("HAMSM_ASSIGN_FILTER", "1") != "0"
@@ -371,6 +436,14 @@ def main():
     ap.add_argument("--cpu-iters", type=int, default=32)
     ap.add_argument("--cpu-cores", type=int, default=min(16, os.cpu_count() or 1), help="processes of the all-cores CPU leg")
     ap.add_argument("--no-full-pipeline", action="store_true")
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
+                    help="weak: every rank its own full shard (N x the frames); strong: the workload's frames split over the ranks "
+                         "(BASELINE config 4: 10 M frames in all)")
+    ap.add_argument("--train-on", default=None, choices=["rank0", "all"],
+                    help="sharded runs: rank 0 trains on its own block of iterations (default for weak scaling: training time does "
+                         "not grow with N) or on every rank's iterations, gathered to it once at staging (default for strong "
+                         "scaling: N ranks == one process on the same data)")
+    ap.add_argument("--no-ingest", action="store_true")
     ap.add_argument("--lib", default=None, help="(kernel A/B experiments) path of an alternative build of the HIP library")
     args = ap.parse_args()
 
@@ -397,8 +470,16 @@ def main():
         dist.init_process_group(backend, rank=rank, world_size=world)
 
     cfg = bench_configs()[args.workload]
-    n_iters = args.iters or cfg.n_iters
+    n_total = args.iters or cfg.n_iters
+    if args.scaling == "strong" and world > 1:
+        per = n_total // world
+        first_iter = 1 + rank * per
+        n_iters = per if rank < world - 1 else n_total - per * (world - 1)
+    else:
+        n_iters, first_iter = n_total, 1 + rank * n_total
+    train_on = args.train_on or ("all" if args.scaling == "strong" else "rank0")
     seed = 1337
+    exchange = "none (one rank)"
 
     # (HAMSM_BENCH_DEVICE: rehearsals of the N > 1 flow on a box with fewer GPUs than ranks)
     device = int(os.environ.get("HAMSM_BENCH_DEVICE", local_rank))
@@ -416,18 +497,33 @@ def main():
             ok = 0
         flag = torch.tensor([ok], device=dev)
         dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        exchange = "rccl-in-library"
         if int(flag.item()) == 0:
+            # the collectives of the product are the library's RCCL calls (csrc/comm.hip).  A run that cannot create that
+            # communicator is NOT a measurement of them: it stops, unless a rehearsal asks for the host-staged stand-in
+            if os.environ.get("HAMSM_BENCH_ALLOW_FALLBACK", "0") != "1":
+                raise SystemExit(f"[bench] rank {rank}: in-library RCCL communicator unavailable on some rank; refusing to fall back "
+                                 "to host-staged torch.distributed collectives (set HAMSM_BENCH_ALLOW_FALLBACK=1 to rehearse)")
             if ok:
                 h.comm_destroy()
             torch_exchange(h, dist, torch, rank, world, dev)
+            exchange = "torch-fallback (host-staged; not the product path)"
 
     log(f"workload {cfg.name}: {n_iters} iterations x {cfg.segs_per_iter} segments x {cfg.D} features, "
-        f"{cfg.S} strata x {cfg.K_s} clusters, rank shard starts at iteration {1 + rank * n_iters}")
-    Xp, Xc, p0, p1, w, offs = make_shard(cfg, 1 + rank * n_iters, n_iters, log)
+        f"{cfg.S} strata x {cfg.K_s} clusters, rank shard starts at iteration {first_iter}; scaling {args.scaling}, "
+        f"training on {train_on}, exchange {exchange}")
+    Xp, Xc, p0, p1, w, offs = make_shard(cfg, first_iter, n_iters, log)
     store = DeviceStore.from_host(h, Xp, Xc, p0, p1, w, offs)
     del Xp, Xc
     n_seg = int(offs[-1])
     m = new_model(h, cfg, store, n_iters)
+    m.train_shards = train_on
+    n_seg_all = n_seg
+    if world > 1:
+        t = torch.tensor([n_seg], device=dev, dtype=torch.int64)
+        dist.all_reduce(t)
+        n_seg_all = int(t.item())
+        m.training_store()   # (train-on all: the one-off gather of the training frames to rank 0 belongs to staging)
 
     def barrier():
         h.sync()
@@ -455,6 +551,23 @@ def main():
         elapsed = float(t.item())
 
     timers = h.timers()   # HIP events on the library's stream around every kernel (lazy: no sync on the launch path)
+    # what the reference's post-condition adds when the caller wants host arrays (not part of the timed step: `dtrajs` /
+    # `pair_dtrajs` are materialised on first access): 2 x N int32 labels D2H + the per-iteration views
+    t0 = time.perf_counter()
+    _ = m.dtrajs
+    labels_to_host_ms = (time.perf_counter() - t0) * 1e3
+    # the flux build in both modes (the timed step uses --flux-mode; the product default is the deterministic one)
+    flux_ms = {}
+    for mode, name in ((0, "atomic"), (1, "deterministic")):
+        m.flux_mode = mode
+        m.get_fluxMatrix(0, first_iter=1, last_iter=m.maxIter)
+        h.sync()
+        t0 = time.perf_counter()
+        for _ in range(3):
+            m.get_fluxMatrix(0, first_iter=1, last_iter=m.maxIter)
+        h.sync()
+        flux_ms[name] = (time.perf_counter() - t0) * 1e3 / 3
+    m.flux_mode = args.flux_mode
     assign_ms = h.last_kernel_ms(0)
     n_assign_launch = 2 * args.steps
     assign_avg_ms = timers["assign"] * 1e3 / n_assign_launch   # the distance kernels alone (f32 ranking pass + exact f64 pass over
@@ -490,14 +603,14 @@ def main():
         arithmetic = "f64 in-order fma chains on the matrix unit"
     out = {
         "metric": "frames/sec clustered + fluxmatrix-built",
-        "value": world * n_seg * args.steps / elapsed,
+        "value": n_seg_all * args.steps / elapsed,
         "unit": "frames/s",
         "n_gpus": world,
         "steps": args.steps,
         "warmup": args.warmup,
         "ms_per_step": elapsed * 1e3 / args.steps,
         "higher_is_better": True,
-        "scaling": "weak",
+        "scaling": args.scaling,
         "vs_baseline": None,
         "dtype": "f64",
         "dtype_detail": "training, flux, statistics and the exact assignment kernel compute in f64; the assignment's ranking pass "
@@ -507,16 +620,27 @@ def main():
                                f"{cfg.D} f32 features, {cfg.S} strata x {cfg.K_s} clusters (K={K}); "
                                f"train + assign(2N) + flux per step", "frames_per_gpu": n_seg,
                    "flux_mode": "atomic" if args.flux_mode == 0 else "deterministic",
-                   "parallelism": f"iteration-sharded x{world}"},
+                   "frames_total": n_seg_all, "parallelism": f"iteration-sharded x{world}",
+                   "training": ("rank 0 trains on every rank's iterations (gathered to it at staging): same model as one process on "
+                                "all the data" if train_on == "all" else
+                                "rank 0 trains on its own block of iterations only (iters_to_use); --train-on all gathers every shard")
+                   if world > 1 else "all resident iterations", "exchange": exchange},
         "roofline": {"bound": "mfma", "achieved": tflops, "peak": peak, "unit": "TFLOP/s",
                      "frac": tflops / peak, "traffic": pmc_traffic(cfg, n_iters),
+                     "traffic_source": "committed rocprofv3 --pmc passes of this workload under profiles/ (r02_pmc_summary.csv, else "
+                                       "r01_m_pmc_summary.csv); not measured in this run" if pmc_traffic(cfg, n_iters) is not None else None,
                      "kernel": kernel, "arithmetic": arithmetic,
                      "f64_mfma_peak": PEAK_F64_MFMA_TFLOPS, "frac_of_f64_peak": tflops / PEAK_F64_MFMA_TFLOPS, **extra,
                      "avg_launch_ms": assign_avg_ms, "last_launch_ms": assign_ms,
                      "algorithmic_GBps": bytes_alg / (assign_avg_ms * 1e-3) / 1e9,
                      "hbm_frac": bytes_alg / (assign_avg_ms * 1e-3) / 1e9 / PEAK_HBM_GBS},
         "stage_seconds_per_step": {k: v / args.steps for k, v in timers.items()},
+        "roofline_by_kernel": roofline_by_kernel(cfg, n_iters, n_seg, timers, args.steps, tflops, peak, assign_avg_ms),
+        "labels_to_host_ms": labels_to_host_ms,
+        "flux_ms": flux_ms,
     }
+    if world == 1 and not args.no_ingest:
+        out["ingest"] = ingest_leg(h, cfg, min(n_iters, 100), log)
     if world == 1 and not args.no_full_pipeline:
         # BASELINE.json's second figure (steady-state solve wall-time) and SURVEY §8d's build_analyze_model-equivalent
         log("timing the full build_analyze_model sequence (clean, T, solve, block validation) ...")

@@ -144,6 +144,11 @@ int hamsm_featurize_dist(hamsm_ctx *ctx, const void *d_coords, int c_dtype, int6
  * decided by the exact f64 kernel.  HAMSM_ASSIGN_FILTER=0 in the environment runs the exact kernel alone.        */
 int hamsm_assign(hamsm_ctx *ctx, const void *d_X, int x_dtype, int64_t ldx, const double *d_pcoord,
                  int64_t n, int32_t *d_labels, int32_t *d_seen);
+/* The discretization as the reference hands it out (`dtrajs`: child labels, `pair_dtrajs`: (parent, child) per segment, both
+ * int64 -- _clustering.py:1226-1240): widened on the device and copied to the caller's HOST arrays h_child[n] and
+ * h_pairs[n][2] (either may be NULL).                                                                                      */
+int hamsm_labels_to_host(hamsm_ctx *ctx, const int32_t *d_parent, const int32_t *d_child, int64_t n, int64_t *h_child,
+                         int64_t *h_pairs);
 /* Same, host buffers in and out (the drop-in `predict(coords)` call of B3).                      */
 int hamsm_predict_host(hamsm_ctx *ctx, const void *h_X, int x_dtype, const double *h_pcoord,
                        int64_t n, int32_t *h_labels, int32_t *h_seen);

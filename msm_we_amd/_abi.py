@@ -53,6 +53,7 @@ SYMBOLS = {
     "hamsm_project": (_int, [_vp, _vp, _int, _i64, _i64, _int, _vp, _vp, _int, _vp, _vp]),
     "hamsm_featurize_dist": (_int, [_vp, _vp, _int, _i64, _i64, _int, _vp, _int, _vp, _vp, _i64]),
     "hamsm_assign": (_int, [_vp, _vp, _int, _i64, _vp, _i64, _vp, _vp]),
+    "hamsm_labels_to_host": (_int, [_vp, _vp, _vp, _i64, _vp, _vp]),
     "hamsm_predict_host": (_int, [_vp, _vp, _int, _vp, _i64, _vp, _vp]),
     "hamsm_flux_accumulate": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _int, _vp, _int, _vp, _i64]),
     "hamsm_scale": (_int, [_vp, _vp, _i64, _f64]),
@@ -369,6 +370,13 @@ class Hamsm:
     def assign(self, d_X, x_dtype, ldx, d_pcoord, n, d_labels, d_seen=None):
         self._ck(self.lib.hamsm_assign(self.ctx, _dp(d_X), int(x_dtype), int(ldx), _dp(d_pcoord), int(n),
                                        _dp(d_labels), _dp(d_seen)))
+
+    def labels_to_host(self, d_parent, d_child, n):
+        """-> (child int64[n], pairs int64[n, 2]): the discretization in the reference's layout"""
+        child = np.empty(int(n), dtype=np.int64)
+        pairs = np.empty((int(n), 2), dtype=np.int64)
+        self._ck(self.lib.hamsm_labels_to_host(self.ctx, _dp(d_parent), _dp(d_child), int(n), _hp(child), _hp(pairs)))
+        return child, pairs
 
     def predict_host(self, X: np.ndarray, pcoord: np.ndarray, want_seen=False):
         X = np.ascontiguousarray(X)

@@ -548,16 +548,12 @@ class ClusteringMixin:
         if getattr(self, "_d_child", None) is None:  # unpickled / never discretized: the plain host lists
             return self.__dict__.get("_dtrajs_plain", []), self.__dict__.get("_pairs_plain", [])
         if getattr(self, "_dtrajs_cache", None) is None:
-            n = self._n_labelled
-            pa = np.empty(n, dtype=np.int32)
-            ch = np.empty(n, dtype=np.int32)
-            self.h.d2h(pa, self._d_parent, pa.nbytes)
-            self.h.d2h(ch, self._d_child, ch.nbytes)
+            # widened to int64 and interleaved on the device, two copies; the per-iteration arrays are views of them
+            child, pairs = self.h.labels_to_host(self._d_parent, self._d_child, self._n_labelled)
             offs = self._store.offsets
             n_it = self.maxIter - 1
-            self._dtrajs_cache = [ch[offs[i]: offs[i + 1]].astype(np.int64) for i in range(n_it)]
-            self._pairs_cache = [np.stack([pa[offs[i]: offs[i + 1]], ch[offs[i]: offs[i + 1]]], axis=1).astype(np.int64)
-                                 for i in range(n_it)]
+            self._dtrajs_cache = [child[offs[i]: offs[i + 1]] for i in range(n_it)]
+            self._pairs_cache = [pairs[offs[i]: offs[i + 1]] for i in range(n_it)]
         return self._dtrajs_cache, self._pairs_cache
 
     def _labels_device(self):

@@ -1003,6 +1003,35 @@ extern "C" int hamsm_assign(hamsm_ctx *c, const void *X, int dt, int64_t ldx, co
   return rc;
 }
 
+__global__ void k_widen_labels(const int32_t *__restrict__ pa, const int32_t *__restrict__ ch, int64_t n, long long *ch64,
+                               longlong2 *pairs) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const long long c = ch[i];
+  if (ch64) ch64[i] = c;
+  if (pairs) pairs[i] = make_longlong2((long long)pa[i], c);
+}
+
+extern "C" int hamsm_labels_to_host(hamsm_ctx *c, const int32_t *pa, const int32_t *ch, int64_t n, int64_t *h_child,
+                                    int64_t *h_pairs) {
+  CTX(c);
+  if (n <= 0 || (!h_child && !h_pairs)) return HAMSM_OK;
+  const size_t b1 = (sizeof(long long) * (size_t)n + 255) & ~(size_t)255;
+  int rc = hamsm_ensure_scratch(c, 3 * b1);
+  if (rc) return rc;
+  long long *d1 = (long long *)c->scratch;
+  longlong2 *d2 = (longlong2 *)((char *)c->scratch + b1);
+  hipLaunchKernelGGL(k_widen_labels, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, pa, ch, n, h_child ? d1 : nullptr,
+                     h_pairs ? d2 : nullptr);
+  HIPCHK(c, hipGetLastError());
+  hipError_t e = hipSuccess;
+  if (h_child) e = hipMemcpyAsync(h_child, d1, sizeof(long long) * (size_t)n, hipMemcpyDeviceToHost, c->stream);
+  if (e == hipSuccess && h_pairs) e = hipMemcpyAsync(h_pairs, d2, 2 * sizeof(long long) * (size_t)n, hipMemcpyDeviceToHost, c->stream);
+  hipError_t es = hipStreamSynchronize(c->stream);
+  if (e != hipSuccess || es != hipSuccess) return hamsm_fail(c, HAMSM_EDEVICE, "labels_to_host: %s", hipGetErrorString(e != hipSuccess ? e : es));
+  return HAMSM_OK;
+}
+
 extern "C" int hamsm_predict_host(hamsm_ctx *c, const void *X, int dt, const double *p, int64_t n, int32_t *labels,
                                   int32_t *seen) {
   CTX(c);
@@ -1021,6 +1050,44 @@ extern "C" int hamsm_predict_host(hamsm_ctx *c, const void *X, int dt, const dou
   if (rc) return rc;
   HIPCHK(c, hipMemcpyAsync(labels, base + o_l, ls, hipMemcpyDeviceToHost, c->stream));
   if (seen) HIPCHK(c, hipMemcpyAsync(seen, base + o_s, ss, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return HAMSM_OK;
+}
+
+// ---- hardware property check: how exactly does v_mfma_f32_32x32x16_bf16 accumulate? ---------------------------------------
+// The certificate of the bf16 x 3 ranking pass charges every MFMA 17 roundings (16 products + the accumulator) at unit
+// roundoff 2^-22 (four times the standard model's 2^-24: launch_sorted, "c1 / c2").  This hook runs ONE instruction on
+// caller-supplied operands so that a test can measure the instruction's real error against exact arithmetic on adversarial
+// inputs (massive cancellation, 2^60 dynamic range, an accumulator far above or below the products).
+// hA: bf16 bit patterns [64 lanes][8], hB likewise, hC: f32 [64 lanes][16]; out: f32 [64 lanes][16] (same lane layout).
+__global__ void k_selftest_bf16(const unsigned short *A, const unsigned short *B, const float *C, float *out) {
+  const int lane = threadIdx.x;
+  v8bf16 a, b;
+  v16f32 c;
+  for (int i = 0; i < 8; i++) {
+    a[i] = __builtin_bit_cast(__bf16, A[lane * 8 + i]);
+    b[i] = __builtin_bit_cast(__bf16, B[lane * 8 + i]);
+  }
+  for (int r = 0; r < 16; r++) c[r] = C[lane * 16 + r];
+  c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+  for (int r = 0; r < 16; r++) out[lane * 16 + r] = c[r];
+}
+
+// Not part of the product ABI (debug / test hook).
+extern "C" int hamsm_selftest_mfma_bf16(hamsm_ctx *c, const unsigned short *hA, const unsigned short *hB, const float *hC,
+                                        float *h_out) {
+  CTX(c);
+  const size_t nab = sizeof(unsigned short) * 64 * 8, nc = sizeof(float) * 64 * 16;
+  int rc = hamsm_ensure_scratch(c, 2 * 1024 + 2 * 4096);
+  if (rc) return rc;
+  char *b = (char *)c->scratch;
+  HIPCHK(c, hipMemcpyAsync(b, hA, nab, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(b + 1024, hB, nab, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(b + 2048, hC, nc, hipMemcpyHostToDevice, c->stream));
+  hipLaunchKernelGGL(k_selftest_bf16, dim3(1), dim3(64), 0, c->stream, (const unsigned short *)b, (const unsigned short *)(b + 1024),
+                     (const float *)(b + 2048), (float *)(b + 2048 + 4096));
+  HIPCHK(c, hipGetLastError());
+  HIPCHK(c, hipMemcpyAsync(h_out, b + 2048 + 4096, nc, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
   return HAMSM_OK;
 }

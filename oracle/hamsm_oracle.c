@@ -513,6 +513,18 @@ int hamsm_assign(hamsm_ctx *c, const void *X, int dt, int64_t ldx, const double 
   return rc;
 }
 
+int hamsm_labels_to_host(hamsm_ctx *c, const int32_t *pa, const int32_t *ch, int64_t n, int64_t *h_child, int64_t *h_pairs) {
+  CTX(c);
+  for (int64_t i = 0; i < n; i++) {
+    if (h_child) h_child[i] = ch[i];
+    if (h_pairs) {
+      h_pairs[2 * i] = pa[i];
+      h_pairs[2 * i + 1] = ch[i];
+    }
+  }
+  return HAMSM_OK;
+}
+
 int hamsm_predict_host(hamsm_ctx *c, const void *X, int dt, const double *p, int64_t n, int32_t *labels,
                        int32_t *seen) {
   CTX(c);

@@ -218,7 +218,7 @@ def test_bench_two_rank_flow_on_cpu(tmp_path, oracle_lib):
     import json
     import subprocess
 
-    env = dict(os.environ, HAMSM_BENCH_BACKEND="gloo", OMP_NUM_THREADS="1")
+    env = dict(os.environ, HAMSM_BENCH_BACKEND="gloo", OMP_NUM_THREADS="1", HAMSM_BENCH_ALLOW_FALLBACK="1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1",
            "--workload", "tiny", "--lib", _build_oracle()]
@@ -229,4 +229,18 @@ def test_bench_two_rank_flow_on_cpu(tmp_path, oracle_lib):
     out = json.loads(lines[0])
     assert out["n_gpus"] == 2 and out["scaling"] == "weak" and out["unit"] == "frames/s" and out["value"] > 0
     assert "cpu_baseline" not in out and out["config"]["parallelism"] == "iteration-sharded x2"
-    assert "torch.distributed" in r.stderr  # the stand-in was used (the oracle cannot create a communicator)
+    assert "torch.distributed" in r.stderr  # the stand-in was used (the oracle cannot create a communicator) ...
+    assert out["config"]["exchange"].startswith("torch-fallback")   # ... and the line says so
+    # without the explicit permission a run whose RCCL communicator cannot be created stops instead of measuring a stand-in
+    env.pop("HAMSM_BENCH_ALLOW_FALLBACK")
+    cmd[cmd.index("--master-port") + 1] = str(_free_port())
+    r2 = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=600)
+    assert r2.returncode != 0 and "refusing to fall back" in r2.stderr
+    # strong scaling (BASELINE config 4's shape of run): the workload's frames split over the ranks, rank 0 trains on all
+    env["HAMSM_BENCH_ALLOW_FALLBACK"] = "1"
+    cmd[cmd.index("--master-port") + 1] = str(_free_port())
+    r3 = subprocess.run(cmd + ["--scaling", "strong"], capture_output=True, text=True, env=env, timeout=600)
+    assert r3.returncode == 0, r3.stderr[-2000:]
+    o3 = json.loads([ln for ln in r3.stdout.splitlines() if ln.startswith("{")][0])
+    assert o3["scaling"] == "strong" and o3["config"]["frames_total"] == out["config"]["frames_total"] // 2
+    assert "every rank's iterations" in o3["config"]["training"]

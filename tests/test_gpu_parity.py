@@ -775,6 +775,105 @@ def test_rccl_collectives_on_one_rank_communicator(hip_lib):
             assert np.array_equal(Cm, C2) and np.array_equal(csq, csq2) and np.array_equal(cnt, cnt2)
         assert h.num_centroids(2) == 0
         assert np.array_equal(h.predict_host(X, p), before)
+        # gather_to_root: ncclSend / ncclRecv in one group (rank 0 sends to itself here)
+        d_r = h.zeros(v.size, np.float64)
+        h.gather_to_root(d_v, v.nbytes, d_r, [v.nbytes], 0)
+        h.sync()
+        assert np.array_equal(d_r.to_host(), v)
+        # a second communicator on a context that has one is refused; a failed / absent one leaves a 1-rank context
+        with pytest.raises(_abi.HamsmError):
+            h.comm_init(1, 0, h.comm_unique_id())
         h.comm_destroy()
+        assert h.lib.hamsm_allreduce_sum_f64(h.ctx, d_v.ptr, 10) == 0   # no communicator, one rank: a no-op
     finally:
         h.close()
+
+
+def test_bf16_mfma_accumulation_error_is_within_the_certificates_premise(hip_h):
+    """the bf16 x 3 ranking pass is certified with a bound that charges every v_mfma_f32_32x32x16_bf16
+    17 roundings at unit roundoff 2^-22 (assign.hip, launch_sorted: c1 / c2).  This measures the instruction itself:
+    one MFMA per trial on adversarial operands -- products that cancel to (almost) nothing, 2^60 of dynamic range inside one
+    dot product, accumulators far above and far below the products -- against exact arithmetic (bf16 x bf16 products and
+    their sums are exact in float64 here), and asserts  |error| <= 17 * 2^-22 * (sum |a_k b_k| + |c|)  for all 1024 outputs of
+    every trial; it also reports how much of that premise the hardware actually uses."""
+    lib = hip_h.lib
+    fn = lib.hamsm_selftest_mfma_bf16
+    fn.restype = ctypes.c_int
+    fn.argtypes = [ctypes.c_void_p] * 5
+    rng = np.random.default_rng(2026)
+
+    def to_bf16(x):   # round-to-nearest-even float32 -> bf16 bit pattern
+        u = np.asarray(x, dtype=np.float32).view(np.uint32).astype(np.uint64)
+        return (((u + 0x7FFF + ((u >> 16) & 1)) >> 16) & 0xFFFF).astype(np.uint16)
+
+    def bf16_val(b):
+        return (b.astype(np.uint32) << 16).view(np.float32).astype(np.float64)
+
+    def run(A_bits, B_bits, C):
+        out = np.empty((64, 16), dtype=np.float32)
+        A_bits, B_bits, C = np.ascontiguousarray(A_bits), np.ascontiguousarray(B_bits), np.ascontiguousarray(C, dtype=np.float32)
+        assert fn(hip_h.ctx, A_bits.ctypes.data, B_bits.ctypes.data, C.ctypes.data, out.ctypes.data) == 0
+        return out
+
+    # operand layout (a lane holds 8 consecutive k of one row / column): lane l -> index l % 32, k = 8 (l / 32) + i.  The
+    # (row, column) of every accumulator register is CALIBRATED with two probe instructions, not assumed.
+    lanes = np.arange(64)
+    Arow = np.zeros((64, 8), np.float32)
+    Arow[lanes < 32, 0] = (lanes[lanes < 32] + 1)
+    ones = np.zeros((64, 8), np.float32)
+    ones[lanes < 32, 0] = 1.0
+    zero_c = np.zeros((64, 16), np.float32)
+    row_of = (run(to_bf16(Arow), to_bf16(ones), zero_c) - 1).astype(int)
+    col_of = (run(to_bf16(ones), to_bf16(Arow), zero_c) - 1).astype(int)
+    assert sorted(set(map(tuple, np.stack([row_of.ravel(), col_of.ravel()], 1)))) == [(r, c) for r in range(32) for c in range(32)]
+
+    def exact(A_bits, B_bits, C):
+        a = bf16_val(A_bits).reshape(2, 32, 8).transpose(1, 0, 2).reshape(32, 16)     # [row][k]
+        b = bf16_val(B_bits).reshape(2, 32, 8).transpose(1, 0, 2).reshape(32, 16)     # [col][k]
+        prod = a[:, None, :] * b[None, :, :]                                           # exact in float64
+        mag = np.abs(prod).sum(-1)
+        # exact sum of 16 float64 values of <= 16 significant bits each spanning < 2^100: use Python fractions on demand
+        from fractions import Fraction
+        ex = np.empty((32, 32))
+        for r in range(32):
+            for c in range(32):
+                ex[r, c] = float(sum((Fraction(float(v)) for v in prod[r, c]), Fraction(float(C[np.nonzero((row_of == r) & (col_of == c))][0]))))
+        return ex, mag
+
+    worst = 0.0
+    for trial in range(12):
+        kind = trial % 4
+        a = rng.normal(size=(64, 8))
+        b = rng.normal(size=(64, 8))
+        C = rng.normal(size=(64, 16))
+        if kind == 0:      # cancellation: b pairs (k, k+1) negate each other up to one bf16 ulp
+            a[:, 1::2] = a[:, 0::2]
+            b[:, 1::2] = -b[:, 0::2] * (1 + 2.0 ** -8)
+            C *= 1e-6
+        elif kind == 1:    # 2^60 of dynamic range across k, accumulator tiny
+            a *= 2.0 ** rng.integers(-30, 30, size=(64, 8))
+            C *= 2.0 ** -40
+        elif kind == 2:    # accumulator 2^20 above the products (they must not vanish beyond the bound)
+            C *= 2.0 ** 20
+        else:              # accumulator cancels the dot product
+            pass
+        A_bits, B_bits = to_bf16(a), to_bf16(b)
+        if kind == 3:
+            ex0, _ = exact(A_bits, B_bits, np.zeros((64, 16), np.float32))
+            C = np.empty((64, 16), np.float32)
+            for l in range(64):
+                for r in range(16):
+                    C[l, r] = -ex0[row_of[l, r], col_of[l, r]] * (1 + 2.0 ** -12)
+        C = C.astype(np.float32)
+        out = run(A_bits, B_bits, C)
+        ex, mag = exact(A_bits, B_bits, C)
+        got = np.empty((32, 32))
+        cabs = np.empty((32, 32))
+        got[row_of, col_of] = out
+        cabs[row_of, col_of] = np.abs(C.astype(np.float64))
+        err = np.abs(got - ex)
+        budget = 17 * 2.0 ** -22 * (mag + cabs)
+        assert np.all(err <= budget), (trial, float((err / budget).max()))
+        worst = max(worst, float((err / np.maximum(budget, 1e-300)).max()))
+    print(f"bf16 MFMA: worst error / assumed per-instruction budget = {worst:.4f}")
+    assert worst <= 1.0
