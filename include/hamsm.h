@@ -183,10 +183,28 @@ int hamsm_cluster_stats(hamsm_ctx *ctx, const int32_t *d_labels, const double *d
 int hamsm_group_by_label(hamsm_ctx *ctx, const int32_t *d_labels, int64_t n, int nstates, int32_t *d_order,
                          int64_t *h_indptr);
 
+/* ---- a12 on the device (organize_stratified, _clustering.py:920-1142): the flux matrix never has to visit the host.
+ * hamsm_pattern_csr: the sparsity pattern of a dense n x n matrix as CSR (h_indptr[n+1], h_indices[cap]) -- the input of the
+ *   strongly-connected-components search (utils.py:21-84).  h_indices == NULL: count only (*h_nnz and h_indptr are filled).
+ * hamsm_np_sum: what `np.sum(a)` returns for `count` doubles laid out contiguously in a's MEMORY order, bit for bit: numpy's
+ *   reduction walks memory in chunks of its buffer size (8192 elements), sums every chunk pairwise (blocks of <= 128 with 8
+ *   interleaved partial sums, larger blocks split at n/2 rounded down to a multiple of 8) and adds the chunk sums in order --
+ *   the divisor of `fluxMatrix / np.sum(fluxMatrix)` (:1121).  (That fluxMatrix is the result of `a[perm, :][:, perm]`, which
+ *   numpy lays out column-major: the sum is taken over the TRANSPOSED permuted matrix, hamsm_permute_scale(transpose = 1).)
+ * hamsm_permute_scale: d_out[i][j] = d_F[perm[i]][perm[j]] / divisor  (`fluxMatrix[perm][:, perm] / sum`, :1117-1121;
+ *   divisor 1.0 = permutation only; transpose != 0: d_out[i][j] = d_F[perm[j]][perm[i]] / divisor).  d_out must not alias d_F. */
+int hamsm_pattern_csr(hamsm_ctx *ctx, const double *d_F, int nstates, int64_t *h_indptr, int32_t *h_indices, int64_t cap,
+                      int64_t *h_nnz);
+int hamsm_np_sum(hamsm_ctx *ctx, const double *d_A, int64_t count, double *h_out);
+int hamsm_permute_scale(hamsm_ctx *ctx, const double *d_F, int nstates, const int32_t *h_perm, double *d_out, double divisor,
+                        int transpose);
+
 /* ---- a13 feed: row-normalised transition matrix as CSR (AnalysisMixin.get_Tmatrix,
  *      _analysis.py:23-79): zero rows -> self loop, target rows -> uniform over basis.
  *      d_F is nstates^2 (already organised).  Outputs are HOST arrays: h_indptr[nstates+1],
- *      h_indices/h_data capacity `cap`; *h_nnz receives the count (returns HAMSM_ENOMEM if > cap). */
+ *      h_indices/h_data capacity `cap`; *h_nnz receives the count (returns HAMSM_ENOMEM if > cap).
+ *      h_indices == NULL and h_data == NULL: count only -- h_indptr and *h_nnz are filled, so that the caller can size the
+ *      arrays exactly instead of reserving nstates^2 entries.                                                           */
 int hamsm_tmatrix_csr(hamsm_ctx *ctx, const double *d_F, int nstates, const int32_t *h_basis, int nb,
                       const int32_t *h_target, int nt, int64_t *h_indptr, int32_t *h_indices,
                       double *h_data, int64_t cap, int64_t *h_nnz);

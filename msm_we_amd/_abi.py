@@ -59,6 +59,9 @@ SYMBOLS = {
     "hamsm_scale": (_int, [_vp, _vp, _i64, _f64]),
     "hamsm_cluster_stats": (_int, [_vp, _vp, _vp, _i64, _int, _vp, _vp, _vp, _vp]),
     "hamsm_group_by_label": (_int, [_vp, _vp, _i64, _int, _vp, _vp]),
+    "hamsm_pattern_csr": (_int, [_vp, _vp, _int, _vp, _vp, _i64, _vp]),
+    "hamsm_np_sum": (_int, [_vp, _vp, _i64, _vp]),
+    "hamsm_permute_scale": (_int, [_vp, _vp, _int, _vp, _vp, _f64, _int]),
     "hamsm_tmatrix_csr": (_int, [_vp, _vp, _int, _vp, _int, _vp, _int, _vp, _vp, _vp, _i64, _vp]),
     "hamsm_train_prepass": (_int, [_vp, _vp, _i64, _vp, _i64, _vp, _vp]),
     "hamsm_train_build_rows": (_int, [_vp, _vp, _i64, _vp, _vp, _vp, _vp]),
@@ -419,15 +422,38 @@ class Hamsm:
     def tmatrix_csr(self, d_F, nstates, basis_idx, target_idx):
         b = np.ascontiguousarray(basis_idx, dtype=np.int32)
         t = np.ascontiguousarray(target_idx, dtype=np.int32)
-        cap = int(nstates) * int(nstates)
         indptr = np.empty(nstates + 1, dtype=np.int64)
-        indices = np.empty(cap, dtype=np.int32)
-        data = np.empty(cap, dtype=np.float64)
         nnz = _i64(0)
-        self._ck(self.lib.hamsm_tmatrix_csr(self.ctx, _dp(d_F), int(nstates), _hp(b), len(b), _hp(t), len(t),
-                                            _hp(indptr), _hp(indices), _hp(data), cap, C.byref(nnz)))
+        # count pass, then arrays of exactly that size (not nstates^2: 300 MB of host buffers at 5002 states)
+        self._ck(self.lib.hamsm_tmatrix_csr(self.ctx, _dp(d_F), int(nstates), _hp(b), len(b), _hp(t), len(t), _hp(indptr), None,
+                                            None, 0, C.byref(nnz)))
         k = nnz.value
-        return indptr, indices[:k].copy(), data[:k].copy()
+        indices = np.empty(max(k, 1), dtype=np.int32)
+        data = np.empty(max(k, 1), dtype=np.float64)
+        self._ck(self.lib.hamsm_tmatrix_csr(self.ctx, _dp(d_F), int(nstates), _hp(b), len(b), _hp(t), len(t),
+                                            _hp(indptr), _hp(indices), _hp(data), max(k, 1), C.byref(nnz)))
+        return indptr, indices[:k], data[:k]
+
+    def pattern_csr(self, d_F, nstates):
+        """sparsity pattern of a dense device matrix: (indptr int64[n+1], indices int32[nnz])"""
+        indptr = np.empty(nstates + 1, dtype=np.int64)
+        nnz = _i64(0)
+        self._ck(self.lib.hamsm_pattern_csr(self.ctx, _dp(d_F), int(nstates), _hp(indptr), None, 0, C.byref(nnz)))
+        k = nnz.value
+        indices = np.empty(max(k, 1), dtype=np.int32)
+        if k:
+            self._ck(self.lib.hamsm_pattern_csr(self.ctx, _dp(d_F), int(nstates), _hp(indptr), _hp(indices), k, C.byref(nnz)))
+        return indptr, indices[:k]
+
+    def np_sum(self, d_A, count) -> float:
+        v = _f64(0.0)
+        self._ck(self.lib.hamsm_np_sum(self.ctx, _dp(d_A), int(count), C.byref(v)))
+        return v.value
+
+    def permute_scale(self, d_F, nstates, perm, d_out, divisor=1.0, transpose=False):
+        pm = np.ascontiguousarray(perm, dtype=np.int32)
+        assert pm.shape == (nstates,)
+        self._ck(self.lib.hamsm_permute_scale(self.ctx, _dp(d_F), int(nstates), _hp(pm), _dp(d_out), float(divisor), int(transpose)))
 
     def train_prepass(self, d_pcoord, n, iter_offsets, d_bin):
         offs = np.ascontiguousarray(iter_offsets, dtype=np.int64)

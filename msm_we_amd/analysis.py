@@ -124,33 +124,47 @@ def inverse_iteration(guess, matrix, mu=1):
 
 
 class AnalysisMixin:
-    Tmatrix = None
+    Tmatrix_csr = None
     pSS = None
     lagtime = None
     JtargetSS = None
     dense_eig_max = 128  # states; above this the eigenvector seed comes from ARPACK on the CSR matrix (300 states: 4 ms vs 190 ms)
 
+    @property
+    def Tmatrix(self):
+        """dense (n, n) transition matrix as in the reference (`_analysis.py:79`); built from the CSR matrix the device
+        produced the first time it is read"""
+        d = self.__dict__.get("_Tmatrix_dense")
+        if d is None and self.Tmatrix_csr is not None:
+            d = self.Tmatrix_csr.toarray()
+            self.__dict__["_Tmatrix_dense"] = d
+        return d
+
+    @Tmatrix.setter
+    def Tmatrix(self, value):
+        self.__dict__["_Tmatrix_dense"] = value
+        self.Tmatrix_csr = None
+
     def get_Tmatrix(self):
-        """`_analysis.py:23-79` on the device: row-normalise, zero rows -> self loop, target rows ->
-        uniform over the basis; returned as CSR (kept in ``Tmatrix_csr``) and, for API parity, dense."""
+        """`_analysis.py:23-79` on the device: row-normalise, zero rows -> self loop, target rows -> uniform over the basis,
+        straight from the organised flux matrix in HBM; the result is CSR (`Tmatrix_csr`, sized by a count pass) and the
+        dense `Tmatrix` of the reference is derived from it on first access."""
         h = self.h
-        F = np.ascontiguousarray(self.fluxMatrix, dtype=np.float64)
-        n = F.shape[0]
-        d_F = h.to_device(F)
+        d_F = self._matrix_device("fluxMatrix")
+        n = int(d_F.shape[0])
         indptr, indices, data = h.tmatrix_csr(d_F, n, self.indBasis, self.indTargets)
-        d_F.free()
         self.Tmatrix_csr = sp.csr_matrix((data, indices, indptr), shape=(n, n))
-        self.Tmatrix = self.Tmatrix_csr.toarray()
+        self.__dict__["_Tmatrix_dense"] = None
 
     def _T_csr(self):
-        T = getattr(self, "Tmatrix_csr", None)
-        if T is None or T.shape != np.shape(self.Tmatrix):
+        T = self.Tmatrix_csr
+        if T is None:
             T = sp.csr_matrix(self.Tmatrix)
         return T
 
     def get_steady_state_algebraic(self, max_iters=1000, check_negative=True, set=True):
         """`_analysis.py:193-282`"""
-        n = self.Tmatrix.shape[0]
+        n = self._T_csr().shape[0]
         pSS = None
         if n > self.dense_eig_max:
             # dense eig is O(n^3) with a large constant (1 s at 670 states, 5 s at 2600); ARPACK on the device-built CSR

@@ -42,6 +42,30 @@ def find_connected_sets(C, directed=True):
     return sorted(cc, key=lambda x: -len(x))
 
 
+def connected_sets_from_pattern(indptr, indices, n, extra_edge=None):
+    """`find_connected_sets` on a CSR sparsity pattern (built on the device, `hamsm_pattern_csr`) -- optionally with one more
+    edge, inserted in sorted position so that the graph handed to scipy is the one the dense path hands it"""
+    import scipy.sparse as sp
+    import scipy.sparse.csgraph as csgraph
+
+    indptr = np.asarray(indptr, dtype=np.int64)
+    indices = np.asarray(indices, dtype=np.int32)
+    if extra_edge is not None:
+        r, c = extra_edge
+        row = indices[indptr[r]: indptr[r + 1]]
+        k = int(np.searchsorted(row, c))
+        if k == len(row) or row[k] != c:
+            indices = np.insert(indices, int(indptr[r]) + k, c)
+            indptr = indptr.copy()
+            indptr[r + 1:] += 1
+    Cs = sp.csr_matrix((np.ones(len(indices), dtype=np.int8), indices, indptr.astype(np.int32)), shape=(n, n))
+    nc, lab = csgraph.connected_components(Cs, directed=True, connection="strong")
+    order = np.argsort(lab)
+    cuts = np.concatenate([[0], np.cumsum(np.bincount(lab[order]))])
+    cc = [np.sort(order[cuts[i]: cuts[i + 1]]) for i in range(nc)]
+    return sorted(cc, key=lambda x: -len(x))
+
+
 class ClusteringMixin:
     n_clusters = None
     clusters = None
@@ -716,10 +740,12 @@ class ClusteringMixin:
     def organize_stratified(self, use_ray=True, progress_bar=None):
         """`_clustering.py:920-1142`: keep the largest strongly-connected set, delete the other
         centroids, re-discretize, re-build the flux matrix, sort states by mean pcoord."""
-        fmatrix_original = self.fluxMatrixRaw.copy()
-        fmatrix = self.fluxMatrixRaw.copy()
-        fmatrix[-1, -2] = 1.0  # recycling edge target -> basis (:938)
-        connected_sets = find_connected_sets(fmatrix, directed=True)
+        # the raw flux matrix stays where get_fluxMatrix left it (HBM): only its sparsity pattern travels, as CSR
+        h = self.h
+        raw_dev, raw_host = self._matrix_device("fluxMatrixRaw"), self.__dict__.get("_h_fluxMatrixRaw")
+        ns0 = int(raw_dev.shape[0])
+        indptr, indices = h.pattern_csr(raw_dev, ns0)
+        connected_sets = connected_sets_from_pattern(indptr, indices, ns0, extra_edge=(ns0 - 1, ns0 - 2))  # recycling edge (:938)
         start_cleaning_idx = 1
         if len(connected_sets) == 1:
             states_to_remove = np.array([], dtype=int)
@@ -761,17 +787,23 @@ class ClusteringMixin:
         pcoord_sort_indices = self.get_cluster_centers()            # :1106
         self.get_fluxMatrix(*self._fluxMatrixParams, use_ray=use_ray, progress_bar=progress_bar)  # :1108-1115
 
-        fluxMatrix = self.fluxMatrixRaw.copy()
-        fluxMatrix = fluxMatrix[pcoord_sort_indices, :]
-        fluxMatrix = fluxMatrix[:, pcoord_sort_indices]
-        self.fluxMatrix = fluxMatrix / np.sum(fluxMatrix)  # :1121
-        self.fluxMatrixRaw = fmatrix_original              # :1123
+        # `fluxMatrix = fluxMatrixRaw[perm][:, perm] / np.sum(...)` (:1117-1121) on the device: gather, numpy's own pairwise
+        # sum (hamsm_np_sum reproduces np.sum bit for bit), true division
+        n = self.n_clusters + 2
+        d_new = self._matrix_device("fluxMatrixRaw")
+        d_org = h.alloc((n, n), np.float64)
+        # numpy lays `a[perm, :][:, perm]` out column-major and np.sum walks memory: the sum is taken over the transpose
+        h.permute_scale(d_new, n, pcoord_sort_indices, d_org, 1.0, transpose=True)
+        total = h.np_sum(d_org, n * n)
+        h.permute_scale(d_new, n, pcoord_sort_indices, d_org, total)
+        self._set_matrix_device("fluxMatrix", d_org)
+        self.__dict__["_d_fluxMatrixRaw"], self.__dict__["_h_fluxMatrixRaw"] = raw_dev, raw_host  # :1123 the pre-clean matrix
         self.indBasis = np.array([self.n_clusters])
         self.indTargets = np.array([self.n_clusters + 1])
         self.nBins = self.n_clusters + 2
         self.update_sorted_cluster_centers()
         self.cluster_mapping = {x: x for x in range(self.n_clusters + 2)}
 
-        fm = self.fluxMatrix.copy()
-        fm[-1, -2] = 1.0
-        assert len(find_connected_sets(fm, directed=True)[start_cleaning_idx:]) == 0, "Still not clean after cleaning!"
+        indptr, indices = h.pattern_csr(d_org, n)
+        assert len(connected_sets_from_pattern(indptr, indices, n, extra_edge=(n - 1, n - 2))[start_cleaning_idx:]) == 0, \
+            "Still not clean after cleaning!"

@@ -333,6 +333,7 @@ extern "C" int hamsm_tmatrix_csr(hamsm_ctx *c, const double *F, int ns, const in
   for (int i = 0; i < ns; i++) indptr[i + 1] = indptr[i] + cnt[i];
   int64_t nnz = indptr[ns];
   *nnz_out = nnz;
+  if (!indices && !data) return HAMSM_OK;  // count only
   if (nnz > cap) return hamsm_fail(c, HAMSM_ENOMEM, "csr capacity %lld too small for %lld", (long long)cap, (long long)nnz);
   HIPCHK(c, hipMemcpyAsync(d_ip, indptr, sizeof(int64_t) * (ns + 1), hipMemcpyHostToDevice, c->stream));
   int32_t *d_idx = nullptr;
@@ -348,5 +349,117 @@ extern "C" int hamsm_tmatrix_csr(hamsm_ctx *c, const double *F, int ns, const in
   hipFree(d_idx);
   hipFree(d_dat);
   if (e != hipSuccess) return hamsm_fail(c, HAMSM_EDEVICE, "tmatrix_csr: %s", hipGetErrorString(e));
+  return HAMSM_OK;
+}
+
+// ---- a12 on the device ------------------------------------------------------------------------------------------------------
+__global__ void k_prow(const double *__restrict__ F, int ns, int64_t *nnz) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= ns) return;
+  const double *row = F + (size_t)i * ns;
+  int64_t c = 0;
+  for (int j = 0; j < ns; j++) c += row[j] != 0.0;
+  nnz[i] = c;
+}
+__global__ void k_pfill(const double *__restrict__ F, int ns, const int64_t *__restrict__ indptr, int32_t *indices) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= ns) return;
+  const double *row = F + (size_t)i * ns;
+  int64_t o = indptr[i];
+  for (int j = 0; j < ns; j++)
+    if (row[j] != 0.0) indices[o++] = j;
+}
+
+extern "C" int hamsm_pattern_csr(hamsm_ctx *c, const double *F, int ns, int64_t *indptr, int32_t *indices, int64_t cap,
+                                 int64_t *nnz_out) {
+  CTX(c);
+  if (ns <= 0 || !indptr || !nnz_out) return hamsm_fail(c, HAMSM_EINVAL, "pattern_csr: arguments");
+  const size_t o_ip = (sizeof(int64_t) * ns + 255) & ~(size_t)255;
+  int rc = hamsm_ensure_scratch(c, o_ip + sizeof(int64_t) * (ns + 1));
+  if (rc) return rc;
+  int64_t *d_nnz = (int64_t *)c->scratch, *d_ip = (int64_t *)((char *)c->scratch + o_ip);
+  hipLaunchKernelGGL(k_prow, dim3((ns + 63) / 64), dim3(64), 0, c->stream, F, ns, d_nnz);
+  HIPCHK(c, hipGetLastError());
+  std::vector<int64_t> cnt(ns);
+  hipError_t e = hipMemcpyAsync(cnt.data(), d_nnz, sizeof(int64_t) * ns, hipMemcpyDeviceToHost, c->stream);
+  hipError_t es = hipStreamSynchronize(c->stream);
+  if (e != hipSuccess || es != hipSuccess) return hamsm_fail(c, HAMSM_EDEVICE, "pattern_csr: read-back");
+  indptr[0] = 0;
+  for (int i = 0; i < ns; i++) indptr[i + 1] = indptr[i] + cnt[i];
+  const int64_t nnz = indptr[ns];
+  *nnz_out = nnz;
+  if (!indices) return HAMSM_OK;
+  if (nnz > cap) return hamsm_fail(c, HAMSM_ENOMEM, "csr capacity %lld too small for %lld", (long long)cap, (long long)nnz);
+  if (nnz == 0) return HAMSM_OK;
+  int32_t *d_idx = nullptr;
+  HIPCHK(c, hipMemcpyAsync(d_ip, indptr, sizeof(int64_t) * (ns + 1), hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMalloc((void **)&d_idx, sizeof(int32_t) * (size_t)nnz));
+  hipLaunchKernelGGL(k_pfill, dim3((ns + 63) / 64), dim3(64), 0, c->stream, F, ns, d_ip, d_idx);
+  e = hipGetLastError();
+  if (e == hipSuccess) e = hipMemcpyAsync(indices, d_idx, sizeof(int32_t) * nnz, hipMemcpyDeviceToHost, c->stream);
+  es = hipStreamSynchronize(c->stream);
+  hipFree(d_idx);
+  if (e != hipSuccess || es != hipSuccess) return hamsm_fail(c, HAMSM_EDEVICE, "pattern_csr: %s", hipGetErrorString(e != hipSuccess ? e : es));
+  return HAMSM_OK;
+}
+
+// np.sum over a whole array = numpy's reduction loop: the elements in MEMORY order, in chunks of the ufunc buffer size (8192
+// elements, numpy's default `np.getbufsize()`), every chunk summed pairwise (np_pairwise: blocks of <= 128 with 8 partial sums,
+// larger blocks halved at a multiple of 8) and the chunk sums added one after the other to a running total that starts at 0
+// (checked against numpy 2.2 on C- and F-ordered matrices of 34^2 .. 1002^2 elements: identical bits).
+#define NP_BUFSIZE 8192
+__global__ void k_npsum_chunks(const double *__restrict__ a, long long n, double *__restrict__ part) {
+  const long long k = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long long off = k * NP_BUFSIZE;
+  if (off >= n) return;
+  part[k] = np_pairwise(a + off, n - off < NP_BUFSIZE ? n - off : NP_BUFSIZE);
+}
+__global__ void k_npsum_total(const double *__restrict__ part, long long nchunks, double *__restrict__ out) {
+  if (blockIdx.x || threadIdx.x) return;
+  double t = 0.0;
+  for (long long k = 0; k < nchunks; k++) t = t + part[k];
+  *out = t;
+}
+
+extern "C" int hamsm_np_sum(hamsm_ctx *c, const double *a, int64_t n, double *h_out) {
+  CTX(c);
+  if (!h_out) return hamsm_fail(c, HAMSM_EINVAL, "np_sum: out");
+  if (n <= 0) {
+    *h_out = 0.0;
+    return HAMSM_OK;
+  }
+  const long long nch = (n + NP_BUFSIZE - 1) / NP_BUFSIZE;
+  int rc = hamsm_ensure_scratch(c, sizeof(double) * (size_t)(nch + 1));
+  if (rc) return rc;
+  double *part = (double *)c->scratch;
+  hipLaunchKernelGGL(k_npsum_chunks, dim3((unsigned)((nch + 63) / 64)), dim3(64), 0, c->stream, a, (long long)n, part);
+  hipLaunchKernelGGL(k_npsum_total, dim3(1), dim3(64), 0, c->stream, part, nch, part + nch);
+  HIPCHK(c, hipGetLastError());
+  hipError_t e = hipMemcpyAsync(h_out, part + nch, sizeof(double), hipMemcpyDeviceToHost, c->stream);
+  hipError_t es = hipStreamSynchronize(c->stream);
+  if (e != hipSuccess || es != hipSuccess) return hamsm_fail(c, HAMSM_EDEVICE, "np_sum: read-back");
+  return HAMSM_OK;
+}
+
+__global__ void k_permute_scale(const double *__restrict__ F, int ns, const int32_t *__restrict__ perm, double *__restrict__ out,
+                                double div, int transpose) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x, i = blockIdx.y;
+  if (j >= ns) return;
+  const double v = transpose ? F[(size_t)perm[j] * ns + perm[i]] : F[(size_t)perm[i] * ns + perm[j]];
+  out[(size_t)i * ns + j] = div == 1.0 ? v : v / div;  // true division (:1121)
+}
+
+extern "C" int hamsm_permute_scale(hamsm_ctx *c, const double *F, int ns, const int32_t *h_perm, double *out, double div,
+                                   int transpose) {
+  CTX(c);
+  if (ns <= 0 || !h_perm || F == out) return hamsm_fail(c, HAMSM_EINVAL, "permute_scale: arguments");
+  for (int i = 0; i < ns; i++)
+    if (h_perm[i] < 0 || h_perm[i] >= ns) return hamsm_fail(c, HAMSM_EINVAL, "permute_scale: perm[%d] = %d", i, h_perm[i]);
+  int rc = hamsm_ensure_scratch(c, sizeof(int32_t) * ns);
+  if (rc) return rc;
+  HIPCHK(c, hipMemcpyAsync(c->scratch, h_perm, sizeof(int32_t) * ns, hipMemcpyHostToDevice, c->stream));
+  hipLaunchKernelGGL(k_permute_scale, dim3((ns + 255) / 256, ns), dim3(256), 0, c->stream, F, ns, (const int32_t *)c->scratch, out, div, transpose);
+  HIPCHK(c, hipGetLastError());
+  HIPCHK(c, hipStreamSynchronize(c->stream));  // h_perm is the caller's
   return HAMSM_OK;
 }

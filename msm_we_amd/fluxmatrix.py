@@ -15,10 +15,46 @@ log = logging.getLogger("msm_we_amd")
 __all__ = ["FluxMatrixMixin"]
 
 
+def _lazy_matrix(name):
+    """`model.<name>`: a dense (n, n) float64 host array as in the reference -- kept on the device (`_d_<name>`) by the steps
+    that produce it and copied to the host the first time somebody reads it.  Assigning a host array drops the device copy."""
+    host, dev = "_h_" + name, "_d_" + name
+
+    def get(self):
+        v = self.__dict__.get(host)
+        if v is None and self.__dict__.get(dev) is not None:
+            d = self.__dict__[dev]
+            v = np.empty(d.shape, dtype=np.float64)
+            self.h.d2h(v, d)
+            self.__dict__[host] = v
+        return v
+
+    def set_(self, value):
+        self.__dict__[host] = value
+        self.__dict__[dev] = None
+
+    return property(get, set_)
+
+
 class FluxMatrixMixin:
-    fluxMatrixRaw = None
-    fluxMatrix = None
+    fluxMatrixRaw = _lazy_matrix("fluxMatrixRaw")
+    fluxMatrix = _lazy_matrix("fluxMatrix")
     flux_mode = 1  # 1 = deterministic (bit-identical to the per-iteration dense sums); 0 = f64 atomics
+
+    def _matrix_device(self, name):
+        """the device copy of `fluxMatrixRaw` / `fluxMatrix` (uploaded when only a host array exists, e.g. after unpickling)"""
+        d = self.__dict__.get("_d_" + name)
+        if d is None:
+            v = self.__dict__.get("_h_" + name)
+            if v is None:
+                raise RuntimeError(f"{name} has not been computed")
+            d = self.h.to_device(np.ascontiguousarray(v, dtype=np.float64))
+            self.__dict__["_d_" + name] = d
+        return d
+
+    def _set_matrix_device(self, name, d_buf):
+        self.__dict__["_d_" + name] = d_buf
+        self.__dict__["_h_" + name] = None
 
     def get_fluxMatrix(self, n_lag, first_iter=1, last_iter=None, iters_to_use=None, use_ray=False,
                        result_batch_size=5, progress_bar=None):
@@ -47,10 +83,7 @@ class FluxMatrixMixin:
             nI = int(d_n.to_host()[0])
             d_n.free()
         h.scale(d_F, ns * ns, float(nI))  # :342
-        F = np.empty((ns, ns))
-        h.d2h(F, d_F)
-        d_F.free()
-        self.fluxMatrixRaw = F
+        self._set_matrix_device("fluxMatrixRaw", d_F)   # stays in HBM; `self.fluxMatrixRaw` copies it out on first read
 
     def _flux_device(self, iters):
         """Sum of the per-iteration flux matrices of `iters` as a device (K+2)^2 buffer (caller frees)."""

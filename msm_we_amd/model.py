@@ -92,7 +92,11 @@ class modelWE(DataMixin, ClusteringMixin, FluxMatrixMixin, AnalysisMixin):
     _DEVICE_STATE = ("_h", "_store", "_d_parent", "_d_child", "_dtrajs_cache", "_pairs_cache")
 
     def __getstate__(self):
+        for name in ("fluxMatrixRaw", "fluxMatrix"):   # device-resident matrices: copied out before the handles are dropped
+            if self.__dict__.get("_d_" + name) is not None:
+                getattr(self, name)
         d = dict(self.__dict__)
+        d["_d_fluxMatrixRaw"] = d["_d_fluxMatrix"] = None
         if d.get("_d_child") is not None:
             dtr, pairs = self._labels_host()
             d["_dtrajs_plain"], d["_pairs_plain"] = dtr, pairs

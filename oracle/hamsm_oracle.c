@@ -651,15 +651,61 @@ int hamsm_tmatrix_csr(hamsm_ctx *c, const double *F, int ns, const int32_t *basi
         if (out == 0.0 && j == i) v = 1.0;   /* :60-61 */
       }
       if (v != 0.0) {
-        if (nnz >= cap) return fail(c, HAMSM_ENOMEM, "csr capacity %lld too small", (long long)cap);
-        indices[nnz] = j;
-        data[nnz] = v;
+        if (indices || data) { /* (both NULL: count only) */
+          if (nnz >= cap) return fail(c, HAMSM_ENOMEM, "csr capacity %lld too small", (long long)cap);
+          indices[nnz] = j;
+          data[nnz] = v;
+        }
         nnz++;
       }
     }
     indptr[i + 1] = nnz;
   }
   *nnz_out = nnz;
+  return HAMSM_OK;
+}
+
+/* --- a12 on the device: see include/hamsm.h */
+int hamsm_pattern_csr(hamsm_ctx *c, const double *F, int ns, int64_t *indptr, int32_t *indices, int64_t cap, int64_t *nnz_out) {
+  CTX(c);
+  if (ns <= 0 || !indptr || !nnz_out) return fail(c, HAMSM_EINVAL, "pattern_csr: arguments");
+  int64_t nnz = 0;
+  indptr[0] = 0;
+  for (int i = 0; i < ns; i++) {
+    for (int j = 0; j < ns; j++)
+      if (F[(size_t)i * ns + j] != 0.0) {
+        if (indices) {
+          if (nnz >= cap) return fail(c, HAMSM_ENOMEM, "csr capacity %lld too small", (long long)cap);
+          indices[nnz] = j;
+        }
+        nnz++;
+      }
+    indptr[i + 1] = nnz;
+  }
+  *nnz_out = nnz;
+  return HAMSM_OK;
+}
+
+/* numpy's pairwise summation (numpy/_core/src/umath/loops_utils.h.src, DOUBLE_pairwise_sum) for a contiguous run */
+int hamsm_np_sum(hamsm_ctx *c, const double *a, int64_t n, double *out) {
+  CTX(c);
+  if (!out) return fail(c, HAMSM_EINVAL, "np_sum: out");
+  double t = 0.0; /* numpy's reduction loop: chunks of the ufunc buffer size (8192), each pairwise, added in order */
+  for (int64_t off = 0; off < n; off += 8192) t = t + np_pairwise(a + off, n - off < 8192 ? n - off : 8192);
+  *out = t;
+  return HAMSM_OK;
+}
+
+int hamsm_permute_scale(hamsm_ctx *c, const double *F, int ns, const int32_t *perm, double *out, double div, int transpose) {
+  CTX(c);
+  if (ns <= 0 || !perm || F == out) return fail(c, HAMSM_EINVAL, "permute_scale: arguments");
+  for (int i = 0; i < ns; i++)
+    if (perm[i] < 0 || perm[i] >= ns) return fail(c, HAMSM_EINVAL, "permute_scale: perm[%d] = %d", i, perm[i]);
+  for (int i = 0; i < ns; i++)
+    for (int j = 0; j < ns; j++) {
+      const double v = transpose ? F[(size_t)perm[j] * ns + perm[i]] : F[(size_t)perm[i] * ns + perm[j]];
+      out[(size_t)i * ns + j] = div == 1.0 ? v : v / div;
+    }
   return HAMSM_OK;
 }
 
