@@ -105,6 +105,7 @@ struct hamsm_ctx {
   double *flux_part = nullptr;  // per-XCD partial flux matrices (flux.hip)
   size_t flux_part_bytes = 0;
   int flux_xcd = 1;             // HAMSM_FLUX_XCD=0: one matrix, device-scope atomics
+  int flux_xcd_checked = 0;     // the per-XCD path has been compared with the single-matrix kernel once (flux.hip)
   std::vector<char> h_stage;  // host staging for small asynchronous H2D copies (lives as long as the ctx)
   void *h_pinned = nullptr;  // small pinned staging buffer
   size_t h_pinned_bytes = 0;
