@@ -431,7 +431,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", default="c3", choices=["c2", "c3", "c5s", "tiny"])
     ap.add_argument("--iters", type=int, default=0, help="override iterations per rank (debug)")
-    ap.add_argument("--flux-mode", type=int, default=0, help="0 = f64 atomics, 1 = deterministic sort-based")
+    ap.add_argument("--flux-mode", type=int, default=1, help="1 = deterministic sort-based (the product default), 0 = f64 atomics")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-iters", type=int, default=32)
     ap.add_argument("--cpu-cores", type=int, default=min(16, os.cpu_count() or 1), help="processes of the all-cores CPU leg")
