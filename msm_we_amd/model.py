@@ -77,7 +77,7 @@ class modelWE(DataMixin, ClusteringMixin, FluxMatrixMixin, AnalysisMixin):
         new = cls.__new__(cls)
         memo[id(self)] = new
         for k, v in self.__dict__.items():
-            if k in ("_h", "_store", "_source", "_d_parent", "_d_child"):
+            if k in ("_h", "_store", "_train_store", "_source", "_d_parent", "_d_child"):
                 new.__dict__[k] = v  # shared, read-only: discretization allocates fresh label buffers
             elif k in ("_dtrajs_cache", "_pairs_cache"):
                 new.__dict__[k] = None  # host views of the shared device labels: rebuilt on first access
@@ -89,7 +89,7 @@ class modelWE(DataMixin, ClusteringMixin, FluxMatrixMixin, AnalysisMixin):
     #    plugin, ray.put at _clustering.py:1165-1176).  The pickle holds plain NumPy / Python state: no context, no
     #    device buffers; the discretization is materialised (`dtrajs`, `pair_dtrajs` as host arrays).  After loading,
     #    `attach(h)` binds a context; frames are re-staged from the iteration source on first use. -----------------------
-    _DEVICE_STATE = ("_h", "_store", "_d_parent", "_d_child", "_dtrajs_cache", "_pairs_cache")
+    _DEVICE_STATE = ("_h", "_store", "_train_store", "_d_parent", "_d_child", "_dtrajs_cache", "_pairs_cache")
 
     def __getstate__(self):
         for name in ("fluxMatrixRaw", "fluxMatrix"):   # device-resident matrices: copied out before the handles are dropped
