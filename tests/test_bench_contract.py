@@ -26,3 +26,10 @@ def test_bench_line_has_the_contract_keys():
     assert set(out["cpu_baseline"]) >= {"value", "unit", "cores", "kind", "sample"} and out["cpu_baseline"]["kind"] == "port"
     assert out["cpu_baseline"]["cores"] == 1 and out["cpu_baseline"]["all_cores"]["cores"] == 2
     assert "solve" in out and "full_pipeline" in out
+    # round 2: the dominant kernels are on the line, the product-default flux mode is what is timed, both modes are reported,
+    # the exchange path is named, PMC bytes are labelled as committed (not measured in the run), the ingest leg ran
+    stages = {e["stage"] for e in out["roofline_by_kernel"]}
+    assert {"training steps", "assign (2 launches)", "k-means++ seeding", "flux matrix"} <= stages
+    assert out["config"]["flux_mode"] == "deterministic" and set(out["flux_ms"]) == {"atomic", "deterministic"}
+    assert out["config"]["exchange"].startswith("none") and "traffic_source" in out["roofline"] and out["labels_to_host_ms"] >= 0
+    assert set(out["ingest"]) == {"npz_files", "in_memory"} and out["ingest"]["npz_files"]["GBps"] > 0
