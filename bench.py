@@ -339,6 +339,50 @@ def full_pipeline(m, cfg, seed, flux_mode):
             "validation_JtargetSS": [float(v.JtargetSS) for v in m.validation_models]}
 
 
+def pmc_kernel_bytes(name_part):
+    """(2 x FETCH_SIZE + WRITE_SIZE) x 1024 per dispatch of the kernel whose name contains `name_part`, from the committed
+    r02 PMC summary (C3 workload); None when absent"""
+    path = os.path.join(ROOT, "profiles", "r02_pmc_summary.csv")
+    if not os.path.exists(path):
+        return None
+    v = {}
+    for line in open(path).read().splitlines()[1:]:
+        k, c, _, x = line.rsplit(",", 3)
+        if name_part in k:
+            v[c] = float(x)
+    if "FETCH_SIZE" not in v or "WRITE_SIZE" not in v:
+        return None
+    return (2.0 * v["FETCH_SIZE"] + v["WRITE_SIZE"]) * 1024.0
+
+
+def step_roofline(cfg, n_iters, n_seg, e_ms, e_n, m_ms, e_events_ms):
+    """`roofline` of the bench line = the DOMINANT kernel of the timed step: k_step_assign, the E-step of a training step
+    (48 % of all kernel time, profiles/r02_bench_c3_kernel_stats.csv; with its M-step 78 %).  One launch serves the batches of the
+    two strata that share a queue: algorithmic flops = 2 strata x n_b x K_s x D x 2 (2 K_s D per row), n_b = the
+    rows of one WE iteration that fall into one stratum outside basis / target; duration = every 128th launch on the library's
+    queue, in this run: by the device's 100 MHz clock from the first wave's entry to the last wave's exit (`avg_launch_ms`,
+    what rocprofv3's kernel trace reports: 9.9 us in profiles/r02_bench_c3_kernel_stats.csv), and event to event
+    (`avg_launch_ms_hip_events`: the same launch INCLUDING its kernel boundary, ~3 us more -- an event pair cannot bracket a
+    10 us kernel any tighter)."""
+    S, K_s, D = cfg.S, cfg.K_s, cfg.D
+    strata_per_launch = 2 if S >= 2 else 1
+    n_b = cfg.segs_per_iter * (1.0 - 0.1 / S) / S
+    flops = strata_per_launch * n_b * 2.0 * K_s * D
+    bytes_alg = strata_per_launch * n_b * (D * 4 + 4)         # rows read + labels; centroid fragments are L2-resident
+    e_ms = e_ms or float("nan")
+    tf = flops / (e_ms * 1e-3) / 1e12
+    traffic = pmc_kernel_bytes("k_step_assign") if (cfg.name == "c3") else None
+    return {"bound": "mfma", "achieved": tf, "peak": PEAK_F64_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": tf / PEAK_F64_MFMA_TFLOPS,
+            "traffic": traffic,
+            "traffic_source": "profiles/r02_pmc_summary.csv (committed rocprofv3 --pmc passes of this workload; not measured in this "
+                              "run)" if traffic is not None else None,
+            "kernel": "k_step_assign (v_mfma_f64_16x16x4_f64), the E-step of one training step for the two strata of a queue",
+            "avg_launch_ms": e_ms, "avg_launch_ms_hip_events": e_events_ms, "launches_sampled": e_n, "flop_per_launch": flops,
+            "algorithmic_bytes_per_launch": bytes_alg, "m_step_avg_launch_ms_hip_events": m_ms,
+            "note": "latency-bound: ~2 500-row batches, 2 x n_iterations dependent launches per queue (DESIGN.md 5.3, 5.3a); the "
+                    "assignment kernels have their own object, roofline_assign"}
+
+
 def roofline_by_kernel(cfg, n_iters, n_seg, timers, steps, assign_tflops, assign_peak, assign_avg_ms):
     """One entry per stage of the timed step, from the HIP-event stage timers of THIS run (the library brackets every launch
     group with events on its stream): device milliseconds per step, the algorithmic work of SURVEY.md §8d, and the fraction
@@ -538,6 +582,8 @@ def main():
         one_step(m, cfg, seed, args.flux_mode)
     barrier()
     h.timers(reset=True)
+    if hasattr(h, "step_kernel_ms"):
+        h.step_kernel_ms(0, reset=True)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         one_step(m, cfg, seed, args.flux_mode)
@@ -551,6 +597,9 @@ def main():
         elapsed = float(t.item())
 
     timers = h.timers()   # HIP events on the library's stream around every kernel (lazy: no sync on the launch path)
+    e_ms, e_n = h.step_kernel_ms(0)   # the dominant kernel, live: events around every 128th k_step_assign / k_step_update launch
+    m_ms, m_n = h.step_kernel_ms(1)
+    e_dev_ms, _ = h.step_kernel_ms(2)  # ... and by the device clock (first wave in -> last wave out, no launch boundary)
     # what the reference's post-condition adds when the caller wants host arrays (not part of the timed step: `dtrajs` /
     # `pair_dtrajs` are materialised on first access): 2 x N int32 labels D2H + the per-iteration views
     t0 = time.perf_counter()
@@ -625,15 +674,16 @@ def main():
                                 "all the data" if train_on == "all" else
                                 "rank 0 trains on its own block of iterations only (iters_to_use); --train-on all gathers every shard")
                    if world > 1 else "all resident iterations", "exchange": exchange},
-        "roofline": {"bound": "mfma", "achieved": tflops, "peak": peak, "unit": "TFLOP/s",
-                     "frac": tflops / peak, "traffic": pmc_traffic(cfg, n_iters),
-                     "traffic_source": "committed rocprofv3 --pmc passes of this workload under profiles/ (r02_pmc_summary.csv, else "
-                                       "r01_m_pmc_summary.csv); not measured in this run" if pmc_traffic(cfg, n_iters) is not None else None,
-                     "kernel": kernel, "arithmetic": arithmetic,
-                     "f64_mfma_peak": PEAK_F64_MFMA_TFLOPS, "frac_of_f64_peak": tflops / PEAK_F64_MFMA_TFLOPS, **extra,
-                     "avg_launch_ms": assign_avg_ms, "last_launch_ms": assign_ms,
-                     "algorithmic_GBps": bytes_alg / (assign_avg_ms * 1e-3) / 1e9,
-                     "hbm_frac": bytes_alg / (assign_avg_ms * 1e-3) / 1e9 / PEAK_HBM_GBS},
+        "roofline": step_roofline(cfg, n_iters, n_seg, e_dev_ms or e_ms, e_n, m_ms, e_ms),
+        "roofline_assign": {"bound": "mfma", "achieved": tflops, "peak": peak, "unit": "TFLOP/s",
+                            "frac": tflops / peak, "traffic": pmc_traffic(cfg, n_iters),
+                            "traffic_source": "committed rocprofv3 --pmc passes of this workload under profiles/ (r02_pmc_summary.csv, "
+                                              "else r01_m_pmc_summary.csv); not measured in this run" if pmc_traffic(cfg, n_iters) is not None else None,
+                            "kernel": kernel, "arithmetic": arithmetic,
+                            "f64_mfma_peak": PEAK_F64_MFMA_TFLOPS, "frac_of_f64_peak": tflops / PEAK_F64_MFMA_TFLOPS, **extra,
+                            "avg_launch_ms": assign_avg_ms, "last_launch_ms": assign_ms,
+                            "algorithmic_GBps": bytes_alg / (assign_avg_ms * 1e-3) / 1e9,
+                            "hbm_frac": bytes_alg / (assign_avg_ms * 1e-3) / 1e9 / PEAK_HBM_GBS},
         "stage_seconds_per_step": {k: v / args.steps for k, v in timers.items()},
         "roofline_by_kernel": roofline_by_kernel(cfg, n_iters, n_seg, timers, args.steps, tflops, peak, assign_avg_ms),
         "labels_to_host_ms": labels_to_host_ms,

@@ -345,6 +345,12 @@ int hamsm_bcast_model(hamsm_ctx *ctx, int root);
 /* ---- timers: seconds of device time per stage since the last reset, measured with HIP events on
  *      the library's stream.  h_out[8]: assign, flux, stats, seed, step, reassign, prepass, other */
 int hamsm_timers(hamsm_ctx *ctx, double *h_out, int reset);
+/* mean duration (ms) of the two training kernels, sampled at every 128th launch pair on the context's queue (sampling starts
+ * with the first call of this function on a context) since
+ * the last reset: which = 0 the E-step (k_step_assign), 1 the M-step (k_step_update) -- event to event, i.e. including the
+ * launch boundary --, 2 the E-step by the device's 100 MHz clock (first wave in to last wave out: what a kernel trace reports);
+ * *h_samples (nullable) = pairs sampled.                                                                                   */
+int hamsm_step_kernel_ms(hamsm_ctx *ctx, int which, double *h_ms, int64_t *h_samples, int reset);
 /* last kernel-only duration (ms) of the named stage: 0 assign, 1 flux, 4 step                    */
 int hamsm_last_kernel_ms(hamsm_ctx *ctx, int stage, double *h_ms);
 

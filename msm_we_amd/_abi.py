@@ -83,6 +83,7 @@ SYMBOLS = {
     "hamsm_gather_to_root": (_int, [_vp, _vp, _sz, _vp, _vp, _int]),
     "hamsm_bcast_model": (_int, [_vp, _int]),
     "hamsm_timers": (_int, [_vp, _vp, _int]),
+    "hamsm_step_kernel_ms": (_int, [_vp, _int, _vp, _vp, _int]),
     "hamsm_last_kernel_ms": (_int, [_vp, _int, _vp]),
 }
 
@@ -577,6 +578,12 @@ class Hamsm:
         out = np.zeros(8)
         self._ck(self.lib.hamsm_timers(self.ctx, _hp(out), int(reset)))
         return dict(zip(("assign", "flux", "stats", "seed", "step", "reassign", "prepass", "other"), out))
+
+    def step_kernel_ms(self, which, reset=False):
+        """(mean ms, samples) of the E-step (0) / M-step (1) training kernel over the sampled launches"""
+        v, n = _f64(0.0), _i64(0)
+        self._ck(self.lib.hamsm_step_kernel_ms(self.ctx, int(which), C.byref(v), C.byref(n), int(reset)))
+        return v.value, n.value
 
     def last_kernel_ms(self, stage) -> float:
         v = _f64(0.0)

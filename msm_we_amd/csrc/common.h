@@ -18,6 +18,7 @@
 
 #define HAMSM_MAX_NDIM 8
 #define HAMSM_MAX_STRATA 4096
+#define HAMSM_KS_SLOTS 1024  // sampled training launches between two reads of hamsm_step_kernel_ms
 #define POT_LANES 1024  // strided partial sums of k-means++ potentials (oracle: POT_LANES, POT_GROUP = 32)
 #define SCAN_CHUNK 64   // chunked cumulative sum (oracle: SCAN_CHUNK)
 
@@ -118,6 +119,18 @@ struct hamsm_ctx {
   hipEvent_t ev_cur0 = nullptr;
   double timers[ST_N] = {0};
   double last_ms[ST_N] = {0};
+  // sampled per-launch durations of the two training kernels (every 64th launch group of queue 0: events around the E-step
+  // and the M-step launch), for the bench line's roofline of the dominant kernel
+  struct KSample {
+    hipEvent_t e0, e1, e2;
+  };
+  std::vector<KSample> ks_pending;
+  std::vector<hipEvent_t> ks_free;  // recycled events of resolved samples
+  unsigned long long *ks_stamps = nullptr;  // device [4096][2]: first-wave-in / last-wave-out stamps of the sampled E-step launches
+  double ks_dev_sum_ms = 0.0;               // ... summed kernel-only durations (100 MHz clock)
+  double ks_sum_ms[2] = {0, 0};
+  long long ks_n[2] = {0, 0};
+  long long ks_tick = 0;
   size_t seed_g_budget = (size_t)4 << 30;  // bytes of Gram matrices resident at once (HAMSM_SEED_G_MB): 56 strata of 3072 rows
   unsigned long long *h_und = nullptr;  // pinned [S]: undecided counts of the last filtered assign
   int filter_skip = 0;     // calls left that bypass the ranking pass (it settled < 3/4 of the frames last time)

@@ -143,6 +143,16 @@ extern "C" void hamsm_destroy(hamsm_ctx *c) {
     hipEventDestroy(p.e1);
   }
   for (auto e : c->ev_free) hipEventDestroy(e);
+  for (auto &k : c->ks_pending) {
+    hipEventDestroy(k.e0);
+    hipEventDestroy(k.e1);
+    hipEventDestroy(k.e2);
+  }
+  for (auto e : c->ks_free) hipEventDestroy(e);
+  release(c->ks_free);
+  release(c->ks_pending);
+  hipFree(c->ks_stamps);
+  c->ks_stamps = nullptr;
   for (int i = 0; i < 3; i++) {
     if (c->side_stream[i]) hipStreamDestroy(c->side_stream[i]);
     if (c->ev_join[i]) hipEventDestroy(c->ev_join[i]);
@@ -391,6 +401,45 @@ extern "C" int hamsm_timers(hamsm_ctx *c, double *out, int reset) {
     for (int i = 0; i < ST_N; i++) c->timers[i] = 0;
   return HAMSM_OK;
 }
+// mean duration (ms) of the sampled launches of the training kernels since the last reset: which = 0 k_step_assign, 1 k_step_update
+extern "C" int hamsm_step_kernel_ms(hamsm_ctx *c, int which, double *ms, int64_t *samples, int reset) {
+  CTX(c);
+  if (which < 0 || which > 2 || !ms) return hamsm_fail(c, HAMSM_EINVAL, "step_kernel_ms: which");
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  if (c->ks_stamps && !c->ks_pending.empty()) {
+    std::vector<unsigned long long> st(2 * c->ks_pending.size());
+    HIPCHK(c, hipMemcpy(st.data(), c->ks_stamps, sizeof(unsigned long long) * st.size(), hipMemcpyDeviceToHost));
+    for (size_t i = 0; i < c->ks_pending.size(); i++)
+      if (st[2 * i + 1] > st[2 * i]) c->ks_dev_sum_ms += (double)(st[2 * i + 1] - st[2 * i]) * 1e-5;  // 10 ns ticks
+  }
+  for (auto &k : c->ks_pending) {
+    float a = 0.f, b = 0.f;
+    if (hipEventElapsedTime(&a, k.e0, k.e1) == hipSuccess && hipEventElapsedTime(&b, k.e1, k.e2) == hipSuccess) {
+      c->ks_sum_ms[0] += a;
+      c->ks_sum_ms[1] += b;
+      c->ks_n[0]++;
+      c->ks_n[1]++;
+    }
+    c->ks_free.push_back(k.e0);
+    c->ks_free.push_back(k.e1);
+    c->ks_free.push_back(k.e2);
+  }
+  c->ks_pending.clear();
+  // (re)arm the stamp slots: sampling is on from the first call of this function on
+  if (!c->ks_stamps) HIPCHK(c, hipMalloc((void **)&c->ks_stamps, sizeof(unsigned long long) * 2 * HAMSM_KS_SLOTS));
+  {
+    std::vector<unsigned long long> init(2 * HAMSM_KS_SLOTS);
+    for (int i = 0; i < HAMSM_KS_SLOTS; i++) init[2 * i] = ~0ull, init[2 * i + 1] = 0ull;
+    HIPCHK(c, hipMemcpy(c->ks_stamps, init.data(), sizeof(unsigned long long) * init.size(), hipMemcpyHostToDevice));
+  }
+  // which = 2: the E-step's duration by the device clock (first wave in -> last wave out), without the launch boundary
+  if (which == 2) *ms = c->ks_n[0] ? c->ks_dev_sum_ms / (double)c->ks_n[0] : 0.0;
+  else *ms = c->ks_n[which] ? c->ks_sum_ms[which] / (double)c->ks_n[which] : 0.0;
+  if (samples) *samples = c->ks_n[which == 2 ? 0 : which];
+  if (reset) c->ks_sum_ms[0] = c->ks_sum_ms[1] = c->ks_dev_sum_ms = 0.0, c->ks_n[0] = c->ks_n[1] = 0;
+  return HAMSM_OK;
+}
+
 extern "C" int hamsm_last_kernel_ms(hamsm_ctx *c, int stage, double *ms) {
   CTX(c);
   if (stage < 0 || stage >= ST_N) return hamsm_fail(c, HAMSM_EINVAL, "bad stage");

@@ -1052,9 +1052,11 @@ __device__ __forceinline__ StepDev load_step(const StepDev *steps, const StepPac
 // the low-count test of the stratum's previous step (the counts are final since that step's M-step).
 template <typename XT, int KS, int JB, int RT, bool BYVAL>
 __global__ __launch_bounds__(256) void k_step_assign(const StepDev *__restrict__ steps, const StepPack pk, int64_t ldx, int D,
-                                                     double ratio) {
+                                                     double ratio, unsigned long long *stamp) {
   SPROF_ID
   SPROF(0, 0)
+  // sampled launches (stamp != null, every 64th): first wave in / last wave out on the 100 MHz clock = the kernel's own duration
+  if (stamp && threadIdx.x == 0) atomicMin(&stamp[0], (unsigned long long)wall_clock64());
   constexpr int RW = 16 * RT;  // rows per workgroup
   const StepDev sdesc = load_step<BYVAL>(steps, pk, blockIdx.y);
   const StepG st(sdesc);
@@ -1280,6 +1282,7 @@ __global__ __launch_bounds__(256) void k_step_assign(const StepDev *__restrict__
   SPROF(0, 7)
 #endif
   SPROF_FLUSH(0)
+  if (stamp && threadIdx.x == 0) atomicMax(&stamp[1], (unsigned long long)wall_clock64());
 }
 
 // members m0 .. m0+W-1 of a sorted member list held in the wave's LDS strip (srow[q] = batch row, swl[q] = weight of
@@ -2230,13 +2233,40 @@ static void launch_step_kernels(hamsm_ctx *c, hipStream_t q, const StepDev *d_st
                                 long long max_nb, int maxK, int64_t ldx, double ratio, bool any_perm) {
   constexpr int JB = KS <= 4 ? 8 : (KS <= 8 ? 4 : (KS <= 16 ? 2 : 1));
   dim3 ga((unsigned)((max_nb + 16 * RT - 1) / (16 * RT)), (unsigned)ny);
-  hipLaunchKernelGGL((k_step_assign<XT, KS, JB, RT, BYVAL>), ga, dim3(256), 0, q, d_steps, pk, ldx, c->D, ratio);
+  // every 128th launch group of the context's own queue is sampled: events around the E-step and the M-step launch, and the
+  // E-step's own first-wave-in / last-wave-out stamps (slots prepared in bulk by hamsm_step_kernel_ms(reset))
+  const bool sample = q == c->stream && c->ks_stamps && (c->ks_tick++ & 127) == 0 && c->ks_pending.size() < HAMSM_KS_SLOTS;
+  hamsm_ctx::KSample ks{nullptr, nullptr, nullptr};
+  unsigned long long *stamp = nullptr;
+  if (sample) {
+    stamp = c->ks_stamps + 2 * c->ks_pending.size();
+    auto ev = [&]() {
+      if (!c->ks_free.empty()) {
+        hipEvent_t e = c->ks_free.back();
+        c->ks_free.pop_back();
+        return e;
+      }
+      hipEvent_t e = nullptr;
+      hipEventCreate(&e);
+      return e;
+    };
+    ks.e0 = ev();
+    ks.e1 = ev();
+    ks.e2 = ev();
+    hipEventRecord(ks.e0, q);
+  }
+  hipLaunchKernelGGL((k_step_assign<XT, KS, JB, RT, BYVAL>), ga, dim3(256), 0, q, d_steps, pk, ldx, c->D, ratio, stamp);
+  if (sample) hipEventRecord(ks.e1, q);
   size_t lds = sizeof(int) * (4 * UPD_LIST);
   dim3 gu((unsigned)((maxK + 3) / 4), (unsigned)ny);
   if (c->D <= 64)
     hipLaunchKernelGGL((k_step_update<XT, 1, BYVAL>), gu, dim3(256), lds, q, d_steps, pk, ldx, c->D, c->KS);
   else
     hipLaunchKernelGGL((k_step_update<XT, 2, BYVAL>), gu, dim3(256), lds, q, d_steps, pk, ldx, c->D, c->KS);
+  if (sample) {
+    hipEventRecord(ks.e2, q);
+    c->ks_pending.push_back(ks);
+  }
   if (any_perm)
     hipLaunchKernelGGL((k_step_reassign<XT, BYVAL>), dim3((unsigned)ny), dim3(256), 0, q, d_steps, pk, ldx, c->D, c->KS, ratio);
 }

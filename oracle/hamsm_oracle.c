@@ -1192,6 +1192,14 @@ int hamsm_timers(hamsm_ctx *c, double *out, int reset) {
   memset(out, 0, sizeof(double) * 8);
   return HAMSM_OK;
 }
+int hamsm_step_kernel_ms(hamsm_ctx *c, int which, double *ms, int64_t *samples, int reset) {
+  CTX(c);
+  (void)which;
+  (void)reset;
+  if (ms) *ms = 0.0; /* no kernels here */
+  if (samples) *samples = 0;
+  return HAMSM_OK;
+}
 int hamsm_last_kernel_ms(hamsm_ctx *c, int stage, double *ms) {
   CTX(c);
   (void)c, (void)stage;

@@ -23,6 +23,7 @@ def test_bench_line_has_the_contract_keys():
     assert out["vs_baseline"] is None and out["n_gpus"] == 1 and out["steps"] == 1 and out["scaling"] == "weak"
     assert out["unit"] == "frames/s" and out["data"] == "synthetic" and out["dtype"] == "f64" and "workload" in out["config"]
     assert set(out["roofline"]) >= {"bound", "achieved", "peak", "unit", "frac", "traffic"} and out["roofline"]["bound"] == "mfma"
+    assert "k_step_assign" in out["roofline"]["kernel"] and set(out["roofline_assign"]) >= {"bound", "achieved", "peak", "frac"}
     assert set(out["cpu_baseline"]) >= {"value", "unit", "cores", "kind", "sample"} and out["cpu_baseline"]["kind"] == "port"
     assert out["cpu_baseline"]["cores"] == 1 and out["cpu_baseline"]["all_cores"]["cores"] == 2
     assert "solve" in out and "full_pipeline" in out
@@ -31,5 +32,5 @@ def test_bench_line_has_the_contract_keys():
     stages = {e["stage"] for e in out["roofline_by_kernel"]}
     assert {"training steps", "assign (2 launches)", "k-means++ seeding", "flux matrix"} <= stages
     assert out["config"]["flux_mode"] == "deterministic" and set(out["flux_ms"]) == {"atomic", "deterministic"}
-    assert out["config"]["exchange"].startswith("none") and "traffic_source" in out["roofline"] and out["labels_to_host_ms"] >= 0
+    assert out["config"]["exchange"].startswith("none") and "traffic_source" in out["roofline_assign"] and out["labels_to_host_ms"] >= 0
     assert set(out["ingest"]) == {"npz_files", "in_memory"} and out["ingest"]["npz_files"]["GBps"] > 0
