@@ -128,6 +128,16 @@ def load_golden(case):
     return g, meta
 
 
+def check_committor(m, g):
+    """`get_committor` (_analysis.py:527-606; dense matmul iteration in the reference, CSR mat-vec here) against the reference's
+    vector: same iteration count by construction of the stopping rule, values to 1e-12"""
+    if "committor" not in g.files:
+        return
+    m.get_committor()
+    assert m.q.shape == g["committor"].shape
+    np.testing.assert_allclose(m.q, g["committor"], rtol=1e-12, atol=1e-15)
+
+
 def check_cluster_structures(m, g):
     """f4: `update_cluster_structures` on the organised model against the reference's: clusters in the order the reference
     first meets them, per cluster the same segments (iteration, segment), weights, pcoords and coordinates -- or the same

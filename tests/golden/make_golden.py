@@ -228,6 +228,13 @@ def run_case(case):
     model.get_steady_state_target_flux()
     out["JtargetSS"] = np.float64(model.JtargetSS)
 
+    # --- committor (_analysis.py:527-606) on the organised model ---------------------------------------------------------
+    try:
+        model.get_committor()
+        out["committor"] = np.asarray(model.q, dtype=np.float64)
+    except Exception as e:  # noqa: BLE001
+        out["committor_error"] = np.array(f"{type(e).__name__}: {e}"[:300])
+
     # --- f4: update_cluster_structures (_clustering.py:1398-1526) on the organised model -----------------------------------
     try:
         model.update_cluster_structures(build_pcoord_cache=True)

@@ -6,7 +6,7 @@ import ctypes
 import numpy as np
 import pytest
 
-from conftest import GOLDEN_CASES, build_model, check_block_validation, check_cluster_structures, load_golden
+from conftest import GOLDEN_CASES, build_model, check_block_validation, check_cluster_structures, check_committor, load_golden
 
 pytestmark = pytest.mark.gpu
 
@@ -631,6 +631,7 @@ def test_pipeline_on_reference_goldens(hip_h, case):
     np.testing.assert_allclose(m.pSS, g["pSS"], rtol=1e-6, atol=1e-300)
     m.get_steady_state_target_flux()
     assert abs(m.JtargetSS - float(g["JtargetSS"])) <= 1e-6 * float(g["JtargetSS"])
+    check_committor(m, g)  # a13
     check_cluster_structures(m, g)  # f4
     check_block_validation(m, g)  # a14: the reference's own validation groups
     # atomic-mode flux agrees with the deterministic one to 1e-12

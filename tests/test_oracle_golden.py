@@ -7,7 +7,7 @@ Bars: labels / indices identical; centroids and counts bit-identical; flux, T bi
 import numpy as np
 import pytest
 
-from conftest import GOLDEN_CASES, build_model, check_block_validation, check_cluster_structures, load_golden
+from conftest import GOLDEN_CASES, build_model, check_block_validation, check_cluster_structures, check_committor, load_golden
 
 
 @pytest.mark.parametrize("planned", [True, False], ids=["planned", "stepwise"])
@@ -63,6 +63,7 @@ def test_pipeline_matches_reference(oracle_h, case, planned):
     np.testing.assert_allclose(m.pSS, g["pSS"], rtol=1e-6, atol=1e-300)
     m.get_steady_state_target_flux()
     assert abs(m.JtargetSS - float(g["JtargetSS"])) <= 1e-6 * float(g["JtargetSS"])
+    check_committor(m, g)  # a13
     check_cluster_structures(m, g)  # f4
     check_block_validation(m, g)  # a14, against the reference's own groups
 
@@ -174,6 +175,7 @@ def check_c3_shaped(h, g, meta):
     np.testing.assert_allclose(m.pSS, g["pSS"], rtol=1e-6, atol=1e-300)
     m.get_steady_state_target_flux()
     assert abs(m.JtargetSS - float(g["JtargetSS"])) <= 1e-6 * float(g["JtargetSS"])
+    check_committor(m, g)
     check_cluster_structures(m, g)
     check_block_validation(m, g)
 
