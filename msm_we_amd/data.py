@@ -271,34 +271,50 @@ class DataMixin:
     # -- staging: one pass over the iterations, host work overlapped with the uploads --------------
     STAGE_CHUNK_BYTES = 64 << 20  # host bytes per upload block
 
-    def _chunk_host(self, its, mode):
-        """host side of one block of iterations (runs on the reader thread): arrays ready to upload"""
-        Xp, Xc, p0, p1, w = [], [], [], [], []
+    def _iteration_host(self, it, mode):
+        """host side of one iteration: (Xp, Xc, p0, p1, w) ready for the upload slab"""
+        d = self._load(it)
+        n = len(d["w"])
+        X = []
+        for which, key in (("parent", "Xp"), ("child", "Xc")):
+            if mode == "device_featurizer":
+                x = np.asarray(d[which]).reshape(n, -1)           # raw coordinates, featurized in HBM
+            elif key in d and which not in d:
+                x = np.asarray(d[key])                            # already featurized by the source
+                if mode == "host" and self.coordinates is not None and type(self.coordinates).__name__ != "Coordinates":
+                    x = self.coordinates.transform(np.asarray(x, dtype=np.float64))
+            elif mode == "device_pca":
+                x = self.processCoordinates(np.asarray(d[which], dtype=np.float64))   # raw features, projected in HBM
+            else:
+                x = self._featurize(d[which])
+            X.append(x)
+        return (X[0], X[1], np.asarray(d["p0"], dtype=np.float64).reshape(n, -1)[:, : self.pcoord_ndim],
+                np.asarray(d["p1"], dtype=np.float64).reshape(n, -1)[:, : self.pcoord_ndim], np.asarray(d["w"], dtype=np.float64))
+
+    def _fill_slab(self, its, mode, slab, up_dtype):
+        """reader thread: iterations `its` written straight into a page-locked slab (one copy, no intermediate concatenation).
+        -> (rows, nan_parent, nan_child, fits): `fits` is False when a value does not survive the slab's dtype"""
+        o, fits = 0, True
+        nan = [[], []]
         for it in its:
-            d = self._load(it)
-            n = len(d["w"])
-            for which, key, out in (("parent", "Xp", Xp), ("child", "Xc", Xc)):
-                if mode == "device_featurizer":
-                    X = np.asarray(d[which]).reshape(n, -1)           # raw coordinates, featurized in HBM
-                elif key in d and which not in d:
-                    X = np.asarray(d[key])                            # already featurized by the source
-                    if mode == "host" and self.coordinates is not None and type(self.coordinates).__name__ != "Coordinates":
-                        X = self.coordinates.transform(np.asarray(X, dtype=np.float64))
-                elif mode == "device_pca":
-                    X = self.processCoordinates(np.asarray(d[which], dtype=np.float64))   # raw features, projected in HBM
-                else:
-                    X = self._featurize(d[which])
-                out.append(X)
-            p0.append(np.asarray(d["p0"], dtype=np.float64).reshape(n, -1)[:, : self.pcoord_ndim])
-            p1.append(np.asarray(d["p1"], dtype=np.float64).reshape(n, -1)[:, : self.pcoord_ndim])
-            w.append(np.asarray(d["w"], dtype=np.float64))
-        cat = lambda v: np.concatenate(v) if len(v) > 1 else np.asarray(v[0])  # noqa: E731
-        return cat(Xp), cat(Xc), cat(p0), cat(p1), cat(w)
+            blk = self._iteration_host(it, mode)
+            n = len(blk[4])
+            for side in range(2):
+                x = blk[side]
+                dst = slab["X"][side][o: o + n]
+                dst[...] = x                                  # (casts when the dtypes differ)
+                nan[side].append(np.isnan(x).any(axis=1))
+                if x.dtype != up_dtype and up_dtype == np.float32 and fits:
+                    fits = bool(np.array_equal(dst.astype(x.dtype), x, equal_nan=True))
+            slab["p0"][o: o + n], slab["p1"][o: o + n], slab["w"][o: o + n] = blk[2], blk[3], blk[4]
+            o += n
+        cat = lambda v: np.concatenate(v) if v else np.zeros(0, dtype=bool)  # noqa: E731
+        return o, cat(nan[0]), cat(nan[1]), fits
 
     def stage_iterations(self):
         """Featurize and upload iterations 1..maxIter once.  Idempotent.  One pass: a reader thread loads and featurizes
-        block k+1 (`processCoordinates` is user code and stays on the host) while block k travels -- copied into one of two
-        page-locked slabs and uploaded on the context's copy stream -- and while the device turns the uploaded block into
+        block k+1 (`processCoordinates` is user code and stays on the host) straight into one of two page-locked slabs while
+        block k travels from the other on the context's copy stream -- and while the device turns the uploaded block into
         features where that is its job: the shipped distance featurizer (`hamsm_featurize_dist`) and / or a fitted PCA's
         transform (`hamsm_project`; `reduceCoordinates`, _dimensionality.py:37-66).  Any other `coordinates.transform` runs on
         the host.  Frames are stored float32 when that loses nothing (WESTPA's auxdata/coord is float32), else float64."""
@@ -315,14 +331,14 @@ class DataMixin:
             raise NotImplementedError("device featurizer + a non-linear coordinates.transform")
         mode = "device_featurizer" if feat is not None else ("device_pca" if lin is not None else "host")
         its = list(range(1, self.maxIter + 1))
+        if not its:
+            raise ValueError("no complete iteration to stage (get_iterations found none)")
         sizes = np.array([len(self._load(i)["w"]) for i in its], dtype=np.int64) if len(getattr(self, "numSegments", ())) != len(its) \
             else np.asarray(self.numSegments, dtype=np.int64)
         offsets = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)
         N = int(offsets[-1])
-        # first block: fixes the widths and the storage type
-        first = self._chunk_host(its[:1], mode)
-        raw_w = first[0].shape[1]
-        ndim = first[2].shape[1]
+        first = self._iteration_host(its[0], mode)     # fixes the widths
+        raw_w, ndim = first[0].shape[1], first[2].shape[1]
         row_bytes = 2 * raw_w * first[0].dtype.itemsize + 16 * ndim + 8
         per_chunk = max(1, int(self.STAGE_CHUNK_BYTES // max(1, row_bytes * max(1, int(sizes.mean())))))
         chunks = [its[i: i + per_chunk] for i in range(0, len(its), per_chunk)]
@@ -331,16 +347,17 @@ class DataMixin:
         def run(up_dtype):
             """one streaming pass with the uploaded blocks stored as `up_dtype`; returns None when a block does not fit it"""
             up_dt = _abi.F32 if up_dtype == np.float32 else _abi.F64
+            raw = mid = None
             if mode == "host":
                 D, x_dt = raw_w, up_dt
                 Xd = [h.alloc(max(N, 1) * D, up_dtype) for _ in range(2)]
-                raw = None
             else:
                 D = (len(feat[1]) if feat is not None else raw_w) if lin is None else lin[0].shape[0]
                 x_dt = _abi.F64
                 Xd = [h.alloc(max(N, 1) * D, np.float64) for _ in range(2)]
                 raw = [h.alloc(max(rows_max, 1) * raw_w, up_dtype) for _ in range(2)]       # uploaded block, parent / child
-                mid = [h.alloc(max(rows_max, 1) * len(feat[1]), np.float64) for _ in range(2)] if feat is not None and lin is not None else None
+                if feat is not None and lin is not None:
+                    mid = [h.alloc(max(rows_max, 1) * len(feat[1]), np.float64) for _ in range(2)]
             d_p0, d_p1, d_w = h.alloc(max(N, 1) * ndim, np.float64), h.alloc(max(N, 1) * ndim, np.float64), h.alloc(max(N, 1), np.float64)
             slabs = [dict(X=[h.pinned((rows_max, raw_w), up_dtype) for _ in range(2)], p0=h.pinned((rows_max, ndim), np.float64),
                           p1=h.pinned((rows_max, ndim), np.float64), w=h.pinned(rows_max, np.float64)) for _ in range(2)]
@@ -349,35 +366,29 @@ class DataMixin:
             ok = True
             try:
                 with ThreadPoolExecutor(1) as pool:
-                    fut = pool.submit(lambda: first if chunks[0] == its[:1] else self._chunk_host(chunks[0], mode))
+                    fut = pool.submit(self._fill_slab, chunks[0], mode, slabs[0], up_dtype)
                     for k, ch in enumerate(chunks):
-                        blk = fut.result()
+                        n, nan_p, nan_c, fits = fut.result()          # slab k & 1 holds block k
+                        h.copy_sync()                                 # block k-1 has left the other slab ...
+                        if mode != "host":
+                            h.sync()                                  # ... and the kernels that read its raw upload are done
                         if k + 1 < len(chunks):
-                            fut = pool.submit(self._chunk_host, chunks[k + 1], mode)
-                        f0, f1 = int(offsets[ch[0] - 1]), int(offsets[ch[-1]])
-                        n = f1 - f0
+                            fut = pool.submit(self._fill_slab, chunks[k + 1], mode, slabs[(k + 1) & 1], up_dtype)
+                        if not fits:
+                            ok = False
+                            if k + 1 < len(chunks):
+                                fut.result()
+                            break
+                        f0 = int(offsets[ch[0] - 1])
+                        assert n == int(offsets[ch[-1]]) - f0
                         if n == 0:
                             continue
                         sl = slabs[k & 1]
-                        h.copy_sync()   # the slab's previous upload (block k-2) is done -- and so is block k-1's
-                        if mode != "host":
-                            h.sync()    # ... and the kernels that read the raw blocks
+                        nan[0][f0: f0 + n], nan[1][f0: f0 + n] = nan_p, nan_c
+                        w_all[f0: f0 + n] = sl["w"][:n]
                         for side in range(2):
-                            X = blk[side]
-                            nan[side][f0:f1] = np.isnan(X).any(axis=1)
-                            if X.dtype != up_dtype:
-                                Xc_ = X.astype(up_dtype)
-                                if up_dtype == np.float32 and not np.array_equal(Xc_.astype(X.dtype), X, equal_nan=True):
-                                    ok = False
-                                    break
-                                X = Xc_
-                            sl["X"][side][:n] = X
                             dst = Xd[side].offset(f0 * D) if mode == "host" else raw[side]
                             h.h2d_async(dst, sl["X"][side], n * raw_w * np.dtype(up_dtype).itemsize)
-                        if not ok:
-                            break
-                        sl["p0"][:n], sl["p1"][:n], sl["w"][:n] = blk[2], blk[3], blk[4]
-                        w_all[f0:f1] = blk[4]
                         h.h2d_async(d_p0.offset(f0 * ndim), sl["p0"], n * ndim * 8)
                         h.h2d_async(d_p1.offset(f0 * ndim), sl["p1"], n * ndim * 8)
                         h.h2d_async(d_w.offset(f0), sl["w"], n * 8)
@@ -395,9 +406,9 @@ class DataMixin:
                     h.sync()
             finally:
                 for sl in slabs:
-                    for a in (*sl["X"], sl["p0"], sl["p1"], sl["w"]):
-                        h.free_pinned(a)
-                for bufs in (raw, mid if mode != "host" else None):
+                    for a_ in (*sl["X"], sl["p0"], sl["p1"], sl["w"]):
+                        h.free_pinned(a_)
+                for bufs in (raw, mid):
                     for b_ in bufs or ():
                         b_.free()
             if not ok:
