@@ -200,7 +200,7 @@ def build_model(h, g, meta, seed_forcing=True, planned=True, source=None, mapper
     m.set_iteration_source(source if source is not None else InMemorySource(golden_iterations(g)))
     m.initialize(["golden.h5"], {"coords": None, "nAtoms": meta["D"], "coord_ndim": 1}, "golden",
                  basis_pcoord_bounds=meta["basis"], target_pcoord_bounds=meta["target"], tau=meta["tau"],
-                 pcoord_ndim=1, use_weights_in_clustering=meta["use_weights"],
+                 pcoord_ndim=meta.get("pcoord_ndim", 1), use_weights_in_clustering=meta["use_weights"],
                  dim_reduce_method=meta.get("dim_reduce", "none"))
     m.get_iterations()
     m.get_coordSet(m.maxIter)
@@ -238,6 +238,8 @@ def build_model(h, g, meta, seed_forcing=True, planned=True, source=None, mapper
     h.kmeans_seed_multi = seed_multi
     m.speculative_training = planned
     bm = RectilinearBinMapper([np.array(meta["boundaries"], dtype=np.float32)])
+    if meta.get("grid2d"):
+        bm = RectilinearBinMapper([np.array(b, dtype=np.float32) for b in meta["boundaries_nd"]])
     if meta.get("voronoi"):
         from msm_we_amd.binning import VoronoiBinMapper, euclidean_dfunc
 
@@ -246,7 +248,8 @@ def build_model(h, g, meta, seed_forcing=True, planned=True, source=None, mapper
         bm = VoronoiBinMapper(mapper_dfunc or euclidean_dfunc, np.array(meta["voronoi"], dtype=np.float32))
     try:
         m.cluster_coordinates(meta["K_s"], streaming=True, use_ray=True, stratified=True, user_bin_mapper=bm,
-                              random_state=meta["seed"], store_validation_model=True)
+                              random_state=meta["seed"], store_validation_model=True,
+                              **({"first_cluster_iter": meta["first_iter"]} if meta.get("first_iter", 1) != 1 else {}))
     finally:
         h.kmeans_seed = orig
         h.kmeans_seed_multi = orig_multi
@@ -256,4 +259,4 @@ def build_model(h, g, meta, seed_forcing=True, planned=True, source=None, mapper
     return m, state
 
 
-GOLDEN_CASES = ["c1p_d10", "c1p_d30", "c1p_d10_weighted", "gap_d10", "sparse_d10", "voronoi_d10", "nan_d10"]
+GOLDEN_CASES = ["c1p_d10", "c1p_d30", "c1p_d10_weighted", "gap_d10", "sparse_d10", "voronoi_d10", "nan_d10", "grid2d_d10", "late_start_d10"]

@@ -46,6 +46,12 @@ CASES = {
     # 30 and the parent frames of the basis-bound segments of iteration 20 are NaN -- weight 0 in the flux matrix, their
     # iterations lost for training (AssertionError swallowed, `_clustering.py:693-705`), discretized by pcoord alone
     "nan_d10": dict(cfg="c1p_d10", nan_child_in_target=[12, 30], nan_parent_in_basis=[20]),
+    # two progress coordinates, a 3 x 2 rectilinear grid (row-major bin index, `find_nearest_bin`'s meshgrid of bin centres,
+    # `_clustering.py:1367-1381`), strict 2-D basis / target boxes (`msm_we.py:462-527`); one grid cell is never visited
+    "grid2d_d10": dict(cfg="c1p_d10", grid2d=True),
+    # training / flux restricted to later iterations: `first_cluster_iter` (`_clustering.py:640-651`) and `first_iter` of
+    # get_fluxMatrix (`_fluxmatrix.py:205-215`), as HAMSMDriver's `first_analysis_iter` sets them (hamsm_driver.py:122-131)
+    "late_start_d10": dict(cfg="c1p_d10", first_iter=7),
     # C3-SHAPED slice: BASELINE config 3's geometry -- D = 30, 4 strata x 250 clusters, 10 000 segments
     # per iteration, the bench generator's own seed -- over 12 iterations.  Inputs are NOT stored (the tests regenerate
     # them from the seed with msm_we_amd.synthetic, 29 MB); outputs are stored compactly (labels int16, flux as COO).
@@ -65,6 +71,15 @@ def build_inputs(case):
             for key, xkey in (("p0", "Xp"), ("p1", "Xc")):
                 m = np.floor(d[key][:, 0]) == s
                 d[key][m, 0] += 1.0
+        if spec.get("grid2d"):
+            # second progress coordinate: the sign pattern of two features, in {-1.5, -0.5, 0.5, 1.5}; the cell
+            # (first coordinate in [1, 2), second >= 0) is emptied -> a never-visited bin
+            for key, xkey in (("p0", "Xp"), ("p1", "Xc")):
+                q = (d[xkey][:, 0] > 0).astype(np.float64) + (d[xkey][:, 1] > 0).astype(np.float64) * 0.5 - 0.75
+                q = q * 2.0
+                hole = (np.floor(d[key][:, 0]) == 1) & (q >= 0)
+                q[hole] = -q[hole] - 0.25
+                d[key] = np.concatenate([d[key], q[:, None]], axis=1)
         if it in spec.get("nan_child_in_target", ()):
             d["Xc"][d["p1"][:, 0] > cfg.S - 0.05] = np.nan
         if it in spec.get("nan_parent_in_basis", ()):
@@ -160,6 +175,12 @@ def run_case(case):
     Model.seg_weights = {}
     model = Model()
     basis, target = synthetic.basis_target_bounds(cfg.S)
+    ndim = 1
+    if spec.get("grid2d"):
+        ndim = 2
+        basis = np.array([[-np.inf, 0.05], [-np.inf, np.inf]])
+        target = np.array([[cfg.S - 0.05, np.inf], [-2.0, 2.0]])
+    first_it = int(spec.get("first_iter", 1))
     model.initialize(
         ["in-memory.h5"],
         {"coords": np.zeros((cfg.D, 1)), "nAtoms": cfg.D, "coord_ndim": 1},
@@ -168,7 +189,7 @@ def run_case(case):
         target_pcoord_bounds=target,
         dim_reduce_method=spec.get("dim_reduce", "none"),
         tau=1e-9,
-        pcoord_ndim=1,
+        pcoord_ndim=ndim,
         use_weights_in_clustering=bool(spec.get("use_weights", False)),
     )
     model.get_iterations()
@@ -181,6 +202,8 @@ def run_case(case):
         out["pca_ndim"] = np.int64(model.ndim)
         out["pca_n_samples_seen"] = np.int64(model.coordinates.n_samples_seen_)
     bm = ref_harness.RectilinearBinMapper([synthetic.strata_boundaries(cfg.S)])
+    if spec.get("grid2d"):
+        bm = ref_harness.RectilinearBinMapper([np.array([0, 1, 2, np.inf], dtype=np.float32), np.array([-np.inf, 0, np.inf], dtype=np.float32)])
     if "voronoi" in spec:
         from msm_we_amd.binning import euclidean_dfunc
 
@@ -188,6 +211,7 @@ def run_case(case):
     model.cluster_coordinates(
         n_clusters=cfg.K_s, streaming=True, use_ray=True, stratified=True,
         user_bin_mapper=bm, random_state=seed, store_validation_model=True,
+        **({"first_cluster_iter": first_it} if first_it != 1 else {}),
     )
     out["remap_post_cluster"] = np.array([model.clusters.we_remap[b] for b in range(bm.nbins)], dtype=np.int64)
     out["n_clusters_post_cluster"] = np.int64(model.n_clusters)
@@ -203,72 +227,77 @@ def run_case(case):
     out["target_bins_post_cluster"] = np.array(sorted(model.clusters.target_bins), dtype=np.int64)
     out["basis_bins_post_cluster"] = np.array(sorted(model.clusters.basis_bins), dtype=np.int64)
 
-    model.get_fluxMatrix(0, first_iter=1, last_iter=model.maxIter, use_ray=True)
+    model.get_fluxMatrix(0, first_iter=first_it, last_iter=model.maxIter, use_ray=True)
     out["fluxMatrixRaw"] = model.fluxMatrixRaw.copy()
 
-    model.organize_fluxMatrix(use_ray=True)
-    out["fluxMatrix"] = model.fluxMatrix.copy()
-    out["n_clusters_clean"] = np.int64(model.n_clusters)
-    out["remap_clean"] = np.array([model.clusters.we_remap[b] for b in range(bm.nbins)], dtype=np.int64)
-    for b, m in enumerate(model.clusters.cluster_models):
-        if hasattr(m, "cluster_centers_"):
-            out[f"centers_clean_{b}"] = m.cluster_centers_.copy()
-    out["dtrajs_clean"] = np.concatenate(model.dtrajs).astype(np.int64)
-    out["pairs_clean"] = np.concatenate([np.array(p) for p in model.pair_dtrajs]).astype(np.int64)
-    out["targetRMSD_centers"] = np.asarray(model.targetRMSD_centers, dtype=np.float64)
-    out["targetRMSD_minmax"] = np.asarray(model.targetRMSD_minmax, dtype=np.float64)
-    out["all_centers"] = np.asarray(model.all_centers, dtype=np.float64)
-    out["indBasis"] = np.asarray(model.indBasis)
-    out["indTargets"] = np.asarray(model.indTargets)
-    # fluxMatrixRaw of the cleaned model before the pcoord sort (recomputed: organize restores the pre-clean one)
-    model.get_Tmatrix()
-    out["Tmatrix"] = model.Tmatrix.copy()
-    model.get_steady_state()
-    out["pSS"] = np.asarray(model.pSS).copy()
-    model.get_steady_state_target_flux()
-    out["JtargetSS"] = np.float64(model.JtargetSS)
+    try:  # (the reference's own limits are recorded, not hidden: e.g. two pcoord dimensions fail in update_sorted_cluster_centers)
+        model.organize_fluxMatrix(use_ray=True)
+        out["fluxMatrix"] = model.fluxMatrix.copy()
+        out["n_clusters_clean"] = np.int64(model.n_clusters)
+        out["remap_clean"] = np.array([model.clusters.we_remap[b] for b in range(bm.nbins)], dtype=np.int64)
+        for b, m in enumerate(model.clusters.cluster_models):
+            if hasattr(m, "cluster_centers_"):
+                out[f"centers_clean_{b}"] = m.cluster_centers_.copy()
+        out["dtrajs_clean"] = np.concatenate(model.dtrajs).astype(np.int64)
+        out["pairs_clean"] = np.concatenate([np.array(p) for p in model.pair_dtrajs]).astype(np.int64)
+        out["targetRMSD_centers"] = np.asarray(model.targetRMSD_centers, dtype=np.float64)
+        out["targetRMSD_minmax"] = np.asarray(model.targetRMSD_minmax, dtype=np.float64)
+        out["all_centers"] = np.asarray(model.all_centers, dtype=np.float64)
+        out["indBasis"] = np.asarray(model.indBasis)
+        out["indTargets"] = np.asarray(model.indTargets)
+        # fluxMatrixRaw of the cleaned model before the pcoord sort (recomputed: organize restores the pre-clean one)
+        model.get_Tmatrix()
+        out["Tmatrix"] = model.Tmatrix.copy()
+        model.get_steady_state()
+        out["pSS"] = np.asarray(model.pSS).copy()
+        model.get_steady_state_target_flux()
+        out["JtargetSS"] = np.float64(model.JtargetSS)
 
-    # --- committor (_analysis.py:527-606) on the organised model ---------------------------------------------------------
-    try:
-        model.get_committor()
-        out["committor"] = np.asarray(model.q, dtype=np.float64)
+        # --- committor (_analysis.py:527-606) on the organised model ---------------------------------------------------------
+        try:
+            model.get_committor()
+            out["committor"] = np.asarray(model.q, dtype=np.float64)
+        except Exception as e:  # noqa: BLE001
+            out["committor_error"] = np.array(f"{type(e).__name__}: {e}"[:300])
+
+        # --- f4: update_cluster_structures (_clustering.py:1398-1526) on the organised model -----------------------------------
+        try:
+            model.update_cluster_structures(build_pcoord_cache=True)
+            keys = list(model.cluster_structures.keys())
+            out["ucs_keys"] = np.array(keys, dtype=np.int64)
+            out["ucs_counts"] = np.array([len(model.cluster_structures[k]) for k in keys], dtype=np.int64)
+            out["ucs_weights"] = np.concatenate([np.asarray(model.cluster_structure_weights[k], dtype=np.float64) for k in keys])
+            out["ucs_coord_sums"] = np.array([np.sum(np.asarray(model.cluster_structures[k], dtype=np.float64)) for k in keys])
+            out["ucs_first_coord"] = np.stack([np.asarray(model.cluster_structures[k][0], dtype=np.float64).ravel() for k in keys])
+            out["ucs_iter_seg"] = np.concatenate([np.array([[a, b] for a, b, _ in model.structure_iteration_segments[k]], dtype=np.int64)
+                                                  for k in keys])
+            out["ucs_pcoords"] = np.concatenate([np.asarray(model.pcoord_cache[k], dtype=np.float64).reshape(len(model.pcoord_cache[k]), -1)
+                                                 for k in keys])
+        except Exception as e:  # noqa: BLE001
+            out["ucs_error"] = np.array(f"{type(e).__name__}: {e}"[:300])
+
+        # --- a14: do_block_validation (msm_we.py:884-1009): per group flux matrix -> clean -> T -> steady state -> J ----------
+        groups, blocks = spec.get("block_validation", (2, 4))
+        try:
+            model.do_block_validation(cross_validation_groups=groups, cross_validation_blocks=blocks, use_ray=True)
+            out["bv_ok"] = np.bool_(True)
+            out["bv_groups_blocks"] = np.array([groups, blocks], dtype=np.int64)
+            for g, (its_g, vm) in enumerate(zip(model.validation_iterations, model.validation_models)):
+                out[f"bv_iters_{g}"] = np.array(list(its_g), dtype=np.int64)
+                out[f"bv_fluxMatrixRaw_{g}"] = np.asarray(vm.fluxMatrixRaw, dtype=np.float64)
+                out[f"bv_fluxMatrix_{g}"] = np.asarray(vm.fluxMatrix, dtype=np.float64)
+                out[f"bv_n_clusters_{g}"] = np.int64(vm.n_clusters)
+                out[f"bv_dtrajs_{g}"] = np.concatenate(vm.dtrajs).astype(np.int64)
+                out[f"bv_pSS_{g}"] = np.asarray(vm.pSS, dtype=np.float64)
+                out[f"bv_JtargetSS_{g}"] = np.float64(vm.JtargetSS)
+                out[f"bv_remap_{g}"] = np.array([vm.clusters.we_remap[b] for b in range(bm.nbins)], dtype=np.int64)
+        except Exception as e:  # noqa: BLE001 -- recorded: the tests then expect the same failure class
+            out["bv_ok"] = np.bool_(False)
+            out["bv_error"] = np.array(f"{type(e).__name__}: {e}"[:500])
     except Exception as e:  # noqa: BLE001
-        out["committor_error"] = np.array(f"{type(e).__name__}: {e}"[:300])
-
-    # --- f4: update_cluster_structures (_clustering.py:1398-1526) on the organised model -----------------------------------
-    try:
-        model.update_cluster_structures(build_pcoord_cache=True)
-        keys = list(model.cluster_structures.keys())
-        out["ucs_keys"] = np.array(keys, dtype=np.int64)
-        out["ucs_counts"] = np.array([len(model.cluster_structures[k]) for k in keys], dtype=np.int64)
-        out["ucs_weights"] = np.concatenate([np.asarray(model.cluster_structure_weights[k], dtype=np.float64) for k in keys])
-        out["ucs_coord_sums"] = np.array([np.sum(np.asarray(model.cluster_structures[k], dtype=np.float64)) for k in keys])
-        out["ucs_first_coord"] = np.stack([np.asarray(model.cluster_structures[k][0], dtype=np.float64).ravel() for k in keys])
-        out["ucs_iter_seg"] = np.concatenate([np.array([[a, b] for a, b, _ in model.structure_iteration_segments[k]], dtype=np.int64)
-                                              for k in keys])
-        out["ucs_pcoords"] = np.concatenate([np.asarray(model.pcoord_cache[k], dtype=np.float64).reshape(len(model.pcoord_cache[k]), -1)
-                                             for k in keys])
-    except Exception as e:  # noqa: BLE001
-        out["ucs_error"] = np.array(f"{type(e).__name__}: {e}"[:300])
-
-    # --- a14: do_block_validation (msm_we.py:884-1009): per group flux matrix -> clean -> T -> steady state -> J ----------
-    groups, blocks = spec.get("block_validation", (2, 4))
-    try:
-        model.do_block_validation(cross_validation_groups=groups, cross_validation_blocks=blocks, use_ray=True)
-        out["bv_ok"] = np.bool_(True)
-        out["bv_groups_blocks"] = np.array([groups, blocks], dtype=np.int64)
-        for g, (its_g, vm) in enumerate(zip(model.validation_iterations, model.validation_models)):
-            out[f"bv_iters_{g}"] = np.array(list(its_g), dtype=np.int64)
-            out[f"bv_fluxMatrixRaw_{g}"] = np.asarray(vm.fluxMatrixRaw, dtype=np.float64)
-            out[f"bv_fluxMatrix_{g}"] = np.asarray(vm.fluxMatrix, dtype=np.float64)
-            out[f"bv_n_clusters_{g}"] = np.int64(vm.n_clusters)
-            out[f"bv_dtrajs_{g}"] = np.concatenate(vm.dtrajs).astype(np.int64)
-            out[f"bv_pSS_{g}"] = np.asarray(vm.pSS, dtype=np.float64)
-            out[f"bv_JtargetSS_{g}"] = np.float64(vm.JtargetSS)
-            out[f"bv_remap_{g}"] = np.array([vm.clusters.we_remap[b] for b in range(bm.nbins)], dtype=np.int64)
-    except Exception as e:  # noqa: BLE001 -- recorded: the tests then expect the same failure class
-        out["bv_ok"] = np.bool_(False)
-        out["bv_error"] = np.array(f"{type(e).__name__}: {e}"[:500])
+        if "fluxMatrix" in out and "pSS" in out:
+            raise
+        out["organize_error"] = np.array(f"{type(e).__name__}: {e}"[:300])
 
     # --- training log ----------------------------------------------------------------------
     out["fit_bin"] = np.array([f["bin"] for f in log["fit"]], dtype=np.int64)
@@ -290,7 +319,9 @@ def run_case(case):
     sizes = np.array([iters[i]["w"].shape[0] for i in its], dtype=np.int64)
     out["in_offsets"] = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)
     meta = dict(
-        case=case, seed=seed, voronoi=spec.get("voronoi"), gen_seed=cfg.seed, segs_per_iter=cfg.segs_per_iter, D=cfg.D,
+        case=case, seed=seed, voronoi=spec.get("voronoi"), grid2d=bool(spec.get("grid2d")), first_iter=first_it,
+        pcoord_ndim=ndim, boundaries_nd=[[float(x) for x in b] for b in bm.boundaries] if hasattr(bm, "boundaries") else None,
+        gen_seed=cfg.seed, segs_per_iter=cfg.segs_per_iter, D=cfg.D,
         S=int(bm.nbins), K_s=cfg.K_s,
         n_iters=cfg.n_iters, maxIter=int(model.maxIter),
         tau=1e-9, use_weights=bool(spec.get("use_weights", False)), dim_reduce=spec.get("dim_reduce", "none"),
@@ -307,8 +338,8 @@ def run_case(case):
     path = os.path.join(HERE, f"{case}.npz")
     np.savez_compressed(path, **out)
     print(
-        f"{case}: K={out['n_clusters_post_cluster']} -> clean {out['n_clusters_clean']}, "
-        f"{len(log['fit'])} partial_fits, J={out['JtargetSS']:.6e}, file {os.path.getsize(path)/1e6:.2f} MB"
+        f"{case}: K={out['n_clusters_post_cluster']} -> clean {out.get('n_clusters_clean', out.get('organize_error'))}, "
+        f"{len(log['fit'])} partial_fits, J={float(out.get('JtargetSS', np.nan)):.6e}, file {os.path.getsize(path)/1e6:.2f} MB"
     )
 
 

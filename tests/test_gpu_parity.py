@@ -618,8 +618,13 @@ def test_pipeline_on_reference_goldens(hip_h, case):
             assert np.array_equal(cm._counts, g[f"counts_post_cluster_{b}"])
     assert np.array_equal(np.concatenate(m.dtrajs), g["dtrajs_post_cluster"])
     assert np.array_equal(np.concatenate(m.pair_dtrajs), g["pairs_post_cluster"])
-    m.get_fluxMatrix(0, first_iter=1, last_iter=m.maxIter, use_ray=True)
+    m.get_fluxMatrix(0, first_iter=meta.get("first_iter", 1), last_iter=m.maxIter, use_ray=True)
     assert np.array_equal(m.fluxMatrixRaw, g["fluxMatrixRaw"])
+    if "organize_error" in g.files:   # the reference stops here (tests/test_oracle_golden.py): same exception
+        with pytest.raises(Exception) as ei:
+            m.organize_fluxMatrix(use_ray=True)
+        assert type(ei.value).__name__ == str(g["organize_error"]).split(":")[0]
+        return
     m.organize_fluxMatrix(use_ray=True)
     assert m.n_clusters == int(g["n_clusters_clean"])
     assert np.array_equal(np.concatenate(m.dtrajs), g["dtrajs_clean"])

@@ -38,9 +38,16 @@ def test_pipeline_matches_reference(oracle_h, case, planned):
     assert sorted(m.clusters.target_bins) == list(g["target_bins_post_cluster"])
     assert sorted(m.clusters.basis_bins) == list(g["basis_bins_post_cluster"])
 
-    m.get_fluxMatrix(0, first_iter=1, last_iter=m.maxIter, use_ray=True)
+    m.get_fluxMatrix(0, first_iter=meta.get("first_iter", 1), last_iter=m.maxIter, use_ray=True)
     assert np.array_equal(m.fluxMatrixRaw, g["fluxMatrixRaw"])
 
+    if "organize_error" in g.files:
+        # where the reference itself stops (two pcoord dimensions: `update_sorted_cluster_centers` cannot place the bin centres,
+        # _clustering.py:1606) this build stops with the same exception
+        with pytest.raises(Exception) as ei:
+            m.organize_fluxMatrix(use_ray=True)
+        assert type(ei.value).__name__ == str(g["organize_error"]).split(":")[0]
+        return
     m.organize_fluxMatrix(use_ray=True)
     assert m.n_clusters == int(g["n_clusters_clean"])
     assert [m.clusters.we_remap[b] for b in range(meta["S"])] == list(g["remap_clean"])
