@@ -642,7 +642,7 @@ def test_pipeline_on_reference_goldens(hip_h, case):
     # atomic-mode flux agrees with the deterministic one to 1e-12
     m2, _ = build_model(hip_h, g, meta)
     m2.flux_mode = 0
-    m2.get_fluxMatrix(0, first_iter=1, last_iter=m2.maxIter)
+    m2.get_fluxMatrix(0, first_iter=meta.get("first_iter", 1), last_iter=m2.maxIter)
     np.testing.assert_allclose(m2.fluxMatrixRaw, g["fluxMatrixRaw"], rtol=1e-12, atol=1e-300)
 
 
