@@ -5,9 +5,9 @@
  * references it; the product library is msm_we_amd/csrc (HIP, gfx950).
  *
  * Pinning: checked against golden vectors produced by the real reference
- * (jdrusso/msm_we 0.1.28.dev1 + scikit-learn 1.7.2) in tests/golden/*.npz -- labels identical,
+ * (jdrusso/msm_we 0.1.28.dev1 + scikit-learn 1.7.2) in tests/golden/ (.npz files) -- labels identical,
  * centroids to 1e-12, flux/T/pSS/J to 1e-6 -- and against the reference's own NTL9 fixtures
- * (tests/golden/ntl9/*.npy) for the transition-matrix stage.
+ * (tests/golden/ntl9/, .npy files) for the transition-matrix stage.
  *
  * Arithmetic contract shared with the HIP library (bit-for-bit):
  *  - dot(x, c) = fma chain over ascending feature index from +0.0 (what OpenBLAS dgemm computes
@@ -807,6 +807,7 @@ int hamsm_train_prepass(hamsm_ctx *c, const double *p, int64_t n, const int64_t 
 int hamsm_train_build_rows(hamsm_ctx *c, const int32_t *bin, int64_t n, const int32_t *call_remap, int32_t *rows,
                            int64_t *counts, int64_t *starts) {
   CTX(c);
+  if (!c->st || c->S < 1) return fail(c, HAMSM_EINVAL, "set_geometry first");
   memset(counts, 0, sizeof(int64_t) * (size_t)c->S);
   for (int64_t i = 0; i < n; i++)
     if (bin[i] >= 0) counts[call_remap[bin[i]]]++;
