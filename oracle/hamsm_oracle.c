@@ -816,7 +816,8 @@ int hamsm_train_build_rows(hamsm_ctx *c, const int32_t *bin, int64_t n, const in
     starts[s] = acc;
     acc += counts[s];
   }
-  int64_t *fill = (int64_t *)calloc((size_t)c->S, sizeof(int64_t));
+  const size_t nS = c->S > 0 ? (size_t)c->S : 1;
+  int64_t *fill = (int64_t *)calloc(nS, sizeof(int64_t));
   int64_t rank = 0; /* position in the basis/target-filtered list (:874); applied to the unfiltered rows (:892-896) */
   for (int64_t i = 0; i < n; i++)
     if (bin[i] >= 0) {
