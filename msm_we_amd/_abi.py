@@ -11,7 +11,7 @@ import os
 
 import numpy as np
 
-__all__ = ["Hamsm", "HamsmError", "load", "library_path", "F32", "F64", "SYMBOLS"]
+__all__ = ["Hamsm", "HamsmError", "HamsmRangeError", "HamsmUnfitError", "load", "library_path", "F32", "F64", "SYMBOLS"]
 
 F32, F64 = 0, 1
 _HERE = os.path.dirname(os.path.abspath(__file__))
@@ -92,6 +92,19 @@ class HamsmError(RuntimeError):
     def __init__(self, code, msg):
         super().__init__(f"hamsm error {code}: {msg}")
         self.code = code
+
+
+class HamsmRangeError(HamsmError, ValueError):
+    """HAMSM_ERANGE: a label / bin outside its range -- where the reference gets a ValueError from scipy's coo_matrix
+    (`_fluxmatrix.py:143-158`; quirk Q9 makes cleaned models hit it) or from the bin mapper"""
+
+
+class HamsmUnfitError(HamsmError, AssertionError):
+    """HAMSM_EUNFIT: a frame maps to a stratum without centroids -- the reference's `assert hasattr(..., "cluster_centers_")`
+    (`stratified_clustering.py:187-189`)"""
+
+
+_ERROR_CLASSES = {-5: HamsmRangeError, -4: HamsmUnfitError}
 
 
 def library_path() -> str:
@@ -195,7 +208,7 @@ class Hamsm:
 
     def _ck(self, rc):
         if rc != 0:
-            raise HamsmError(rc, self.lib.hamsm_last_error(self.ctx).decode(errors="replace"))
+            raise _ERROR_CLASSES.get(rc, HamsmError)(rc, self.lib.hamsm_last_error(self.ctx).decode(errors="replace"))
 
     def close(self):
         if getattr(self, "ctx", None):

@@ -1,0 +1,109 @@
+"""Differential fuzz against the REAL reference: tests/golden/fuzz_pack.npz holds what jdrusso/msm_we produced on 64 small random
+WE-shaped inputs (tests/golden/make_fuzz.py: random iterations / segments / features / strata / clusters per stratum, sample
+weights on and off, a stratum emptied in some, a Voronoi mapper in one of five) -- including where the reference itself stops.  Inputs are regenerated from the
+recorded generator parameters; this package (host logic on the oracle here, on the HIP library under -m gpu) must reproduce
+every discrete observable: remap, fitted strata, all labels before and after cleaning, both flux matrices bit for bit; steady
+state / target flux to 1e-6; and the same exception class at the same stage where the reference fails."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, _Golden, build_model
+from msm_we_amd import synthetic
+
+PACK = np.load(os.path.join(GOLDEN, "fuzz_pack.npz"))
+N_CASES = int(PACK["n_cases"])
+
+
+def _case(i):
+    pre = f"c{i:02d}_"
+    spec = json.loads(str(PACK[pre + "meta"]))
+    cfg = synthetic.WEConfig("fuzz", spec["gen_seed"], spec["n_iters"], spec["segs"], spec["D"], spec["S"], spec["K_s"])
+    lat = synthetic.latent_centres(cfg)
+    parts = []
+    for it in range(1, cfg.n_iters + 1):
+        d = synthetic.make_iteration(cfg, it, lat)
+        if spec["drop_stratum"] >= 0:
+            for key in ("p0", "p1"):
+                m = np.floor(d[key][:, 0]) == spec["drop_stratum"]
+                d[key][m, 0] += 1.0
+        parts.append(d)
+    g = _Golden({k[len(pre):]: PACK[k] for k in PACK.files if k.startswith(pre)})
+    for k in ("Xp", "Xc", "p0", "p1", "w"):
+        g["in_" + k] = np.concatenate([p[k] for p in parts])
+    g["in_offsets"] = np.concatenate([[0], np.cumsum([len(p["w"]) for p in parts])]).astype(np.int64)
+    if "pp_n" in g:
+        cuts = np.cumsum(g["pp_n"])[:-1]
+        g["pp_indices"] = np.split(g["pp_indices"], cuts)
+        g["pp_centers"] = np.split(g["pp_centers"], cuts)
+    basis, target = synthetic.basis_target_bounds(cfg.S)
+    meta = dict(case=f"fuzz_{i:02d}", D=cfg.D, S=cfg.S, K_s=cfg.K_s, seed=spec["seed"], tau=1e-9, use_weights=spec["use_weights"],
+                basis=basis.tolist(), target=target.tolist(), boundaries=[float(x) for x in synthetic.strata_boundaries(cfg.S)],
+                maxIter=spec["maxIter"], voronoi=[[c] for c in spec["voronoi"]] if spec.get("voronoi") else None)
+    return g, meta, spec
+
+
+def check_fuzz_case(h, i):
+    g, meta, spec = _case(i)
+    stage, err_cls = spec["stage"], None
+    if "error" in g:
+        stage, err_cls, _ = str(g["error"]).split("|", 2)
+
+    def expect_failure(fn):
+        import builtins
+
+        with pytest.raises(Exception) as ei:
+            fn()
+        # the same exception class a caller of the reference would have to catch (library status codes are mapped onto the
+        # reference's classes: HAMSM_ERANGE is-a ValueError, HAMSM_EUNFIT is-a AssertionError)
+        assert isinstance(ei.value, getattr(builtins, err_cls)), (type(ei.value).__mro__, err_cls)
+
+    if stage == "cluster":
+        expect_failure(lambda: build_model(h, g, meta))
+        return
+    m, st = build_model(h, g, meta)
+    assert st["forced"] <= meta["S"]
+    assert m.maxIter == meta["maxIter"]
+    assert [m.clusters.we_remap[b] for b in range(meta["S"])] == list(g["remap_post"])
+    assert m.n_clusters == int(g["n_clusters_post"])
+    assert [cm.fitted for cm in m.clusters.cluster_models] == list(g["fitted"])
+    assert np.array_equal(np.concatenate(m.dtrajs), g["dtrajs_post"])
+    assert np.array_equal(np.concatenate([p[:, 0] for p in m.pair_dtrajs]), g["parents_post"])
+    if stage == "flux":
+        expect_failure(lambda: m.get_fluxMatrix(0, first_iter=1, last_iter=m.maxIter))
+        return
+    m.get_fluxMatrix(0, first_iter=1, last_iter=m.maxIter)
+    assert np.array_equal(m.fluxMatrixRaw, g["fluxMatrixRaw"])
+    if stage == "organize":
+        expect_failure(lambda: m.organize_fluxMatrix())
+        return
+    m.organize_fluxMatrix()
+    assert m.n_clusters == int(g["n_clusters_clean"])
+    assert [m.clusters.we_remap[b] for b in range(meta["S"])] == list(g["remap_clean"])
+    assert np.array_equal(np.concatenate(m.dtrajs), g["dtrajs_clean"])
+    assert np.array_equal(m.fluxMatrix, g["fluxMatrix"])
+
+    def solve():
+        m.get_Tmatrix()
+        m.get_steady_state()
+        m.get_steady_state_target_flux()
+
+    if stage == "solve":
+        expect_failure(solve)
+        return
+    solve()
+    np.testing.assert_allclose(m.pSS, g["pSS"], rtol=1e-6, atol=1e-300)
+    assert abs(m.JtargetSS - float(g["J"])) <= 1e-6 * abs(float(g["J"])) + 1e-300
+
+
+@pytest.mark.parametrize("i", range(N_CASES))
+def test_fuzz_case_matches_reference_oracle(oracle_h, i):
+    check_fuzz_case(oracle_h, i)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("i", range(N_CASES))
+def test_fuzz_case_matches_reference_hip(hip_h, i):
+    check_fuzz_case(hip_h, i)
