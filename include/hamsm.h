@@ -74,9 +74,10 @@ int hamsm_sync(hamsm_ctx *ctx);
 /* ---- model state (replaces the attributes of StratifiedClusters / modelWE that predict() reads:
  *      stratified_clustering.py:61-99, msm_we.py:301-347,398-444) ------------------------------ */
 /* D features per frame (after featurize+project), pcoord dimensionality, number of WE bins.
- * LIMIT: D <= 128 (the distance kernels keep a frame's features as 4-wide MFMA k-steps in registers, instantiated for up to
- * 32 k-steps): hamsm_set_geometry returns HAMSM_ENOTSUP beyond that.  Wider raw features (the flattening featurizer on a
- * few hundred atoms) go through `dimReduce("pca")`: hamsm_project reduces them in HBM at staging time.                     */
+ * D <= 128: the kernels keep a frame's features as 4-wide MFMA k-steps in registers (instantiated for up to 32 k-steps).
+ * 128 < D <= 16384: the generic kernels (run-time k-step count; no f32 ranking pass, no persistent launch) -- same results,
+ * lower rates.  Beyond: HAMSM_ENOTSUP.  k-means++ seeding of a batch of more than 3072 rows keeps its
+ * candidates' rows in LDS: L * (D + 1057) * 8 bytes must fit 160 KB (L = 2 + ln K candidates), else HAMSM_ENOTSUP.         */
 int hamsm_set_geometry(hamsm_ctx *ctx, int D, int pcoord_ndim, int n_strata);
 /* RectilinearBinMapper: per dimension n_bounds[d] float32 boundaries, concatenated in h_bounds.
  * bin_mapper.assign call sites: stratified_clustering.py:134, _clustering.py:877.                */

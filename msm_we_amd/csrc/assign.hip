@@ -392,6 +392,81 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void k_assign_sorted(SortArgs g) {
   APROF_END
 }
 
+// ---- more than 128 features -------------------------------------------------------------------------
+// The kernels above keep a frame's features as KS (<= 32) MFMA k-steps in registers and stage the workgroup's rows in
+// LDS: both stop scaling at D = 128.  This form serves larger D (e.g. the flattened distance-matrix featurizer of the
+// reference's notebooks: 816 features) with KS = ceil(D / 4) a run-time value: one wave owns a 16-frame tile and sweeps
+// the stratum's centroid tiles four at a time; per k-step it loads one frame operand (reused by the four centroid
+// tiles) and four fragments of Bpack.  Same arithmetic as k_assign_sorted: the MFMA's k-ascending accumulation,
+// d = fma(-2, dot, csq), first minimum.  No f32 ranking pass in front of it.
+template <typename XT>
+__global__ __launch_bounds__(256) void k_assign_generic(SortArgs g, int KS) {
+  int s = 0;
+  {
+    const long long blk = blockIdx.x;
+    if (blk >= g.blkbase[g.S]) return;
+    while (g.blkbase[s + 1] <= blk) s++;
+  }
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, kq = lane >> 4;
+  const long long p0 = g.base[s] + (long long)(blockIdx.x - g.blkbase[s]) * g.FRB + wv * 16;  // (FRB = 64: a tile per wave)
+  const long long pend = g.end ? g.end[s] : g.base[s + 1];
+  if (p0 >= pend) return;  // wave-uniform; the kernel has no barrier
+  const bool ok = p0 + (lane & 15) < pend;
+  const long long fr = g.perm[ok ? p0 + (lane & 15) : pend - 1];
+  const XT *xr = (const XT *)g.X + fr * g.ldx;
+  const StratumDev sd = g.table[s];
+  const int njt = (sd.K + 15) >> 4, D = g.D;
+  const double inf = __builtin_huge_val();
+  double bd = inf;
+  int bj = 0x7fffffff;
+  for (int jt0 = 0; jt0 < njt; jt0 += 4) {
+    const double *bp[4];
+#pragma unroll
+    for (int u = 0; u < 4; u++) bp[u] = sd.Bpack + (size_t)(jt0 + u < njt ? jt0 + u : njt - 1) * KS * 64 + lane;
+    v4f64 acc[4];
+#pragma unroll
+    for (int u = 0; u < 4; u++) acc[u] = (v4f64){0.0, 0.0, 0.0, 0.0};
+    for (int ks0 = 0; ks0 < KS; ks0 += 4) {  // 4 k-steps of operands in flight
+      double xa[4], b[4][4];
+#pragma unroll
+      for (int i = 0; i < 4; i++) {  // unconditional loads at clamped positions; what lies past KS / D is deselected below
+        const int ks = ks0 + i < KS ? ks0 + i : KS - 1, k = ks * 4 + kq;
+        xa[i] = (double)xr[k < D ? k : D - 1];
+#pragma unroll
+        for (int u = 0; u < 4; u++) b[i][u] = bp[u][(size_t)ks * 64];
+      }
+#pragma unroll
+      for (int i = 0; i < 4; i++) {
+        const bool in = ks0 + i < KS;
+        const double a = (in && (ks0 + i) * 4 + kq < D) ? xa[i] : 0.0;  // fma(0, 0, acc) == acc
+#pragma unroll
+        for (int u = 0; u < 4; u++) acc[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(in ? b[i][u] : 0.0, a, acc[u], 0, 0, 0);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      if (jt0 + u >= njt) continue;
+      const int j0 = (jt0 + u) * 16 + kq;
+#pragma unroll
+      for (int q = 0; q < 4; q++) {  // a lane's centroids ascend (q, then tile): strict < keeps its lowest index
+        const double d = __builtin_fma(-2.0, acc[u][q], sd.csq[j0 + 4 * q]);
+        const bool lt = d < bd;
+        bd = lt ? d : bd;
+        bj = lt ? j0 + 4 * q : bj;
+      }
+    }
+  }
+#pragma unroll
+  for (int off = 16; off <= 32; off <<= 1) {  // lanes l, l^16, l^32, l^48 hold the same frame
+    const double d2 = __shfl_xor(bd, off, 64);
+    const int j2 = __shfl_xor(bj, off, 64);
+    const bool take = (d2 < bd) || (d2 == bd && j2 < bj);
+    bd = take ? d2 : bd;
+    bj = take ? j2 : bj;
+  }
+  if (lane < 16 && ok) g.labels[fr] = sd.off + (bj == 0x7fffffff ? 0 : bj);  // stratified_clustering.py:195
+}
+
 // ---- f32 filter in front of the exact kernel ---------------------------------------------------------
 // The label is an argmin: it needs the ORDER of the distances, not their values.  v_mfma_f32_32x32x2_f32 sustains
 // 3x the rate of the f64 MFMA on this part (tools/mfma_f32_rate.hip: 145 vs 47.5 TFLOP/s), so the first pass ranks
@@ -843,7 +918,8 @@ static int launch_sorted(hamsm_ctx *c, const AssignArgs &a) {
   const int S = c->S, KS = c->KS;
   // the ranking pass is bypassed for a few calls after one in which it settled less than 3/4 of the frames (data full of
   // near ties: both passes would then cost more than the exact one alone); the labels are the same either way
-  const bool filt = c->assign_filter != 0 && !(c->filter_skip > 0 && c->filter_skip--);
+  const bool generic = KS > 32;  // more than 128 features: k_assign_generic, no ranking pass
+  const bool filt = !generic && c->assign_filter != 0 && !(c->filter_skip > 0 && c->filter_skip--);
   c->filter_ran = 0;
   size_t off = 0;
   auto take = [&](size_t bytes) {
@@ -883,6 +959,7 @@ static int launch_sorted(hamsm_ctx *c, const AssignArgs &a) {
              (long long *)(b + o_base), (long long *)(b + o_blk), 0, FRB_MAX, nullptr};
   // frames per workgroup: as many as keep the staged rows within ~64 KB (2 workgroups per CU)
   while (g.FRB > 64 && (size_t)g.FRB * a.D * sizeof(XT) > 64 * 1024) g.FRB >>= 1;
+  if (generic) g.FRB = 64;
   const int FRB_exact = g.FRB;
   FiltArgs f{};
   c->filter_cnt2 = nullptr;
@@ -956,6 +1033,12 @@ static int launch_sorted(hamsm_ctx *c, const AssignArgs &a) {
     if (!c->h_und) HIPCHK(c, hipHostMalloc((void **)&c->h_und, sizeof(unsigned long long) * S));
     HIPCHK(c, hipMemcpyAsync(c->h_und, f.cnt2, sizeof(unsigned long long) * S, hipMemcpyDeviceToHost, c->stream));
     c->filter_ran = 1;
+  }
+  if (generic) {
+    unsigned grid = (unsigned)((n + 63) / 64 + S);  // upper bound; surplus workgroups exit at once
+    hipLaunchKernelGGL(k_assign_generic<XT>, dim3(grid), dim3(256), 0, c->stream, g, KS);
+    HIPCHK(c, hipGetLastError());
+    return HAMSM_OK;
   }
   switch (KS) {
 #define CASE(KSV) \

@@ -17,6 +17,7 @@
 #include "../../include/hamsm.h"
 
 #define HAMSM_MAX_NDIM 8
+#define HAMSM_MAX_D 16384  // features per frame (more than 128: the generic kernels)
 #define HAMSM_MAX_STRATA 4096
 #define HAMSM_KS_SLOTS 1024  // sampled training launches between two reads of hamsm_step_kernel_ms
 #define POT_LANES 1024  // strided partial sums of k-means++ potentials (oracle: POT_LANES, POT_GROUP = 32)

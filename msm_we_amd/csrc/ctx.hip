@@ -453,7 +453,7 @@ extern "C" int hamsm_set_geometry(hamsm_ctx *c, int D, int ndim, int S) {
   CTX(c);
   if (D < 1 || ndim < 1 || ndim > HAMSM_MAX_NDIM || S < 1 || S > HAMSM_MAX_STRATA)
     return hamsm_fail(c, HAMSM_EINVAL, "bad geometry D=%d ndim=%d S=%d", D, ndim, S);
-  if (D > 128) return hamsm_fail(c, HAMSM_ENOTSUP, "D=%d > 128 features is not supported yet", D);
+  if (D > HAMSM_MAX_D) return hamsm_fail(c, HAMSM_ENOTSUP, "D=%d features: at most %d are supported", D, HAMSM_MAX_D);
   HIPCHK(c, hipSetDevice(c->device));
   HIPCHK(c, hipStreamSynchronize(c->stream));
   c->filter_skip = 0;  // a new model: the ranking pass gets its chance again
@@ -476,11 +476,12 @@ extern "C" int hamsm_set_geometry(hamsm_ctx *c, int D, int ndim, int S) {
   }
   free_strata(c);
   c->D = D;
-  // k-steps of 4 features; rounded up to a value the kernels are instantiated for (zero padded)
+  // k-steps of 4 features; rounded up to a value the kernels are instantiated for (zero padded).  More than 128
+  // features: KS = ceil(D / 4) exactly, a run-time value of the generic kernels (k_assign_generic, k_step_*_generic)
   {
     static const int ks_list[] = {1, 2, 3, 4, 6, 8, 12, 16, 24, 32};
     int need = (D + 3) / 4;
-    c->KS = 32;
+    c->KS = need;
     for (int v : ks_list)
       if (v >= need) {
         c->KS = v;

@@ -1,0 +1,34 @@
+"""One full step (training + discretization + flux) of a WIDE-feature workload through the generic kernels (D > 128):
+HAMSM_WIDE_D features (default 816, the notebooks' flattened distance matrix), 4 strata x 100 clusters, 60 iterations of
+4000 segments.  Prints the stage timers; run on the GPU box."""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))))
+import numpy as np
+import bench
+from msm_we_amd import _abi, synthetic
+from msm_we_amd.data import DeviceStore
+
+D = int(os.environ.get("HAMSM_WIDE_D", "816"))
+cfg = synthetic.WEConfig("wide", 9, 60, 4000, D, 4, 100)
+n_it = cfg.n_iters
+Xp, Xc, p0, p1, w, offs = bench.make_shard(cfg, 1, n_it)
+h = _abi.Hamsm()
+store = DeviceStore.from_host(h, Xp, Xc, p0, p1, w, offs)
+m = bench.new_model(h, cfg, store, n_it)
+bench.one_step(m, cfg, 1337, 0)
+h.timers(reset=True)
+h.sync()
+t0 = time.perf_counter()
+reps = 3
+for _ in range(reps):
+    bench.one_step(m, cfg, 1337, 0)
+h.sync()
+dt = (time.perf_counter() - t0) / reps
+tm = {k: v / reps * 1e3 for k, v in h.timers().items()}
+frames = 2 * n_it * cfg.segs_per_iter
+print(f"D={D} S={cfg.S} K_s={cfg.K_s}: {dt * 1e3:.1f} ms per step of {frames} frames ({frames / dt / 1e6:.2f} M frames/s); stage ms: "
+      + ", ".join(f"{k} {v:.2f}" for k, v in tm.items()), flush=True)
+# assign: algorithmic flops 2 * frames-in-strata * K_s * D
+fl = 2.0 * frames * cfg.K_s * D
+print(f"assign: {fl / (tm['assign'] * 1e-3) / 1e12:.2f} TFLOP/s f64 (algorithmic), {frames * D * 4 / (tm['assign'] * 1e-3) / 1e9:.0f} GB/s of frames")
+h.close()

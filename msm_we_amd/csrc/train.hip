@@ -308,10 +308,10 @@ __global__ __launch_bounds__(SEED_T) void k_seed(const SeedItem *__restrict__ it
   const GAS double *itu = gp(it.u);
   const long long n = it.n;
   const int K = it.K, L = it.L;
-  double *crow = sm;                         // [LMAX][D] candidate rows
-  double *part = crow + SEED_LMAX * D;       // [LMAX][SEED_T] per-thread partial potentials
-  double *grp = part + SEED_LMAX * SEED_T;   // [LMAX][SEED_T/SEED_GROUP]
-  double *pots = grp + SEED_LMAX * (SEED_T / SEED_GROUP);  // [LMAX]
+  double *crow = sm;                         // [L][D] candidate rows
+  double *part = crow + (size_t)L * D;       // [L][SEED_T] per-thread partial potentials
+  double *grp = part + L * SEED_T;           // [L][SEED_T/SEED_GROUP]
+  double *pots = grp + L * (SEED_T / SEED_GROUP);  // [L]
   __shared__ long long cid[SEED_LMAX];
   __shared__ double s_pot;
   __shared__ int s_best;
@@ -908,7 +908,12 @@ extern "C" int hamsm_kmeans_seed_multi(hamsm_ctx *c, int n_items, const int32_t 
       HIPCHK(c, hipLaunchKernel(fn, dim3((unsigned)ng), dim3(SEED_TL), args, lds_fast, c->stream));
     }
   } else {
-    size_t lds = sizeof(double) * ((size_t)SEED_LMAX * D + (size_t)SEED_LMAX * SEED_T + SEED_LMAX * (SEED_T / SEED_GROUP) + SEED_LMAX);
+    int Lmax = 1;
+    for (int i = 0; i < n_items; i++) Lmax = h_L[i] > Lmax ? h_L[i] : Lmax;
+    size_t lds = sizeof(double) * (size_t)Lmax * ((size_t)D + SEED_T + SEED_T / SEED_GROUP + 1);
+    if (lds > 160 * 1024 - 256)
+      return hamsm_fail(c, HAMSM_ENOTSUP, "k-means++ seeding of a batch of more than %d rows with %d candidates of %d features needs %zu B of LDS",
+                        SEED_NLDS, Lmax, D, lds);
     HIPCHK(c, hipFuncSetAttribute((const void *)k_seed, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(k_seed, dim3((unsigned)n_items), dim3(SEED_T), lds, c->stream, (const SeedItem *)(b + o_items), D);
   }
@@ -1498,6 +1503,7 @@ __global__ __launch_bounds__(256) void k_step_reassign(const StepDev *__restrict
   __shared__ double shd[4];
   __shared__ int shi[4];
   __shared__ int lj[256], lr[256];
+  __shared__ __attribute__((aligned(16))) double rowbuf[4][512];  // rows of more than 128 features, per wave
   double mx = -inf;
   for (int j = tid; j < st.K; j += 256) mx = st.counts[j] > mx ? st.counts[j] : mx;
   mx = block_max_f64(mx, shd);
@@ -1549,6 +1555,43 @@ __global__ __launch_bounds__(256) void k_step_reassign(const StepDev *__restrict
       const int jc = lj[e];
       const long long r = lr[e];
       const long long f = st.rows ? (long long)st.rows[r] : r;
+      if (D > 128) {  // (generic form: rows longer than two features per lane; 512 at a time through the wave's LDS strip)
+        double a = 0.0;
+        for (int c0 = 0; c0 < D; c0 += 512) {
+          const int nc = D - c0 < 512 ? D - c0 : 512;
+          double vk[8];
+#pragma unroll
+          for (int i = 0; i < 8; i++) {
+            const int k = c0 + lane + 64 * i;
+            vk[i] = (double)X[f * ldx + (k < D ? k : D - 1)];
+          }
+#pragma unroll
+          for (int i = 0; i < 8; i++) {
+            const int k = c0 + lane + 64 * i;
+            if (k < D) {
+              st.C[(size_t)jc * D + k] = vk[i];  // :1667
+              st.Bpack[((size_t)(jc >> 4) * KS + (k >> 2)) * 64 + (k & 3) * 16 + (jc & 15)] = vk[i];
+              rowbuf[wv][lane + 64 * i] = vk[i];
+            }
+          }
+          __builtin_amdgcn_wave_barrier();  // (the strip is the wave's own: LDS accesses of one wave complete in order)
+          if (lane == 0) {
+            int i = 0;
+            for (; i + 1 < nc; i += 2) {
+              const double2 t = *(const double2 *)&rowbuf[wv][i];
+              a = __builtin_fma(t.x, t.x, a);
+              a = __builtin_fma(t.y, t.y, a);
+            }
+            if (i < nc) a = __builtin_fma(rowbuf[wv][i], rowbuf[wv][i], a);
+          }
+          __builtin_amdgcn_wave_barrier();
+        }
+        if (lane == 0) {
+          st.csq[jc] = a;
+          st.counts[jc] = new_count;
+        }
+        continue;
+      }
       double v[2];
 #pragma unroll
       for (int h = 0; h < 2; h++) {
@@ -1571,6 +1614,273 @@ __global__ __launch_bounds__(256) void k_step_reassign(const StepDev *__restrict
     }
     base += total;
     __syncthreads();
+  }
+}
+
+// ---- more than 128 features: generic training kernels ---------------------------------------------------
+// k_step_assign / k_step_update keep a row's features in registers as KS <= 32 k-steps and hand the batch to the M-step
+// as an f64 copy; past D = 128 neither fits.  These forms take KS = ceil(D / 4) at run time (hamsm_set_geometry):
+// same descriptors, same report / halt / reason protocol, same arithmetic and orders (MFMA k-ascending dot products,
+// d = fma(-2, dot, csq), first minimum; c*count, += x*w in sample order, *1/count; ||c||^2 as an ascending fma chain),
+// so the results are bit-identical to the oracle's as well.  Correct first, not speed-of-light: DESIGN.md §5.6.
+//
+// E-step: one workgroup per 16 batch rows, the stratum's centroid tiles dealt over its 4 waves, operands straight from L2.
+template <typename XT>
+__global__ __launch_bounds__(256) void k_step_assign_generic(const StepDev *__restrict__ steps, int64_t ldx, int D, int KS,
+                                                             double ratio) {
+  const StepDev sdesc = load_step<false>(steps, StepPack{}, blockIdx.y);
+  const StepG st(sdesc);
+  const long long r0 = (long long)blockIdx.x * 16;
+  if (r0 >= st.n_b) return;
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, kq = lane >> 4;
+  const double inf = __builtin_huge_val();
+  __shared__ double shd[4];
+  __shared__ int shi[4];
+  if (blockIdx.x == 0 && (st.flags & 6) && st.idx < *gp(sdesc.halt)) {
+    // the tests that ride on the E-step (see k_step_assign): low counts of the stratum's previous step (flags & 4,
+    // _kmeans.py:1645), a zero count before this one (flags & 2, :2037); either finding stops the chain here
+    int z = 0;
+    double mx = -inf;
+    for (int j = tid; j < st.K; j += 256) {
+      const double cj = st.counts[j];
+      z |= (cj == 0.0);
+      mx = cj > mx ? cj : mx;
+    }
+    int any_low = 0;
+    if (st.flags & 4) {
+      mx = block_max_f64(mx, shd);
+      const double thr = ratio * mx;
+      int low = 0;
+      for (int j = tid; j < st.K; j += 256) low += st.counts[j] < thr;
+      low = block_sum_i32(low, shi);
+      if (tid == 0 && low) gp(sdesc.prev_report)[1] = low;
+      any_low = low;
+    }
+    const int any_z = __syncthreads_or((st.flags & 2) ? z : 0);
+    if (tid == 0) {
+      if (any_low) {
+        *gp(sdesc.halt) = st.idx;
+        *gp(sdesc.reason) = HAMSM_STOP_LOW;
+      } else if (any_z) {
+        st.report[0] = 1;
+        *gp(sdesc.halt) = st.idx;
+        *gp(sdesc.reason) = HAMSM_STOP_ZERO;
+      }
+    }
+  }
+  // centroids are the MFMA's A operand, the 16 batch rows its B operand: lane l accumulates, for batch row l&15, the
+  // centroids (l>>4) + 4q of a tile.  Wave w owns the tiles w, w + 4, ...; two at a time, 8 k-steps of operands in flight
+  const long long r = r0 + (lane & 15);
+  const bool ok = r < st.n_b;
+  const long long rc = ok ? r : st.n_b - 1;
+  const long long f = st.rows ? (long long)st.rows[rc] : rc;
+  const GAS XT *xr = (const GAS XT *)st.X + f * ldx;
+  const int njt = (st.K + 15) >> 4;
+  double bd = inf;
+  int bj = 0x7fffffff;
+  for (int jt0 = wv; jt0 < njt; jt0 += 8) {
+    const bool two = jt0 + 4 < njt;
+    const GAS double *bp0 = st.Bpack + (size_t)jt0 * KS * 64 + lane;
+    const GAS double *bp1 = st.Bpack + (size_t)(two ? jt0 + 4 : jt0) * KS * 64 + lane;
+    v4f64 acc0 = (v4f64){0.0, 0.0, 0.0, 0.0}, acc1 = acc0;
+    constexpr int U = 8;  // k-steps of operands in flight (measured at D = 816, K_s = 100: 8 -> 39 us per launch, 16 -> 46 us)
+    for (int ks0 = 0; ks0 < KS; ks0 += U) {
+      double xa[U], b0[U], b1[U];
+#pragma unroll
+      for (int i = 0; i < U; i++) {  // unconditional loads at clamped positions; what lies past KS / D is deselected below
+        const int ks = ks0 + i < KS ? ks0 + i : KS - 1, k = ks * 4 + kq;
+        xa[i] = (double)xr[k < D ? k : D - 1];
+        b0[i] = bp0[(size_t)ks * 64];
+        b1[i] = bp1[(size_t)ks * 64];
+      }
+#pragma unroll
+      for (int i = 0; i < U; i++) {
+        const bool in = ks0 + i < KS;
+        const double a = (in && (ks0 + i) * 4 + kq < D) ? xa[i] : 0.0;  // fma(0, 0, acc) == acc
+        acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(in ? b0[i] : 0.0, a, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(in ? b1[i] : 0.0, a, acc1, 0, 0, 0);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < 2; u++) {
+      if (u == 1 && !two) continue;
+      const int j0 = (jt0 + 4 * u) * 16 + kq;
+#pragma unroll
+      for (int q = 0; q < 4; q++) {
+        const double d = __builtin_fma(-2.0, u ? acc1[q] : acc0[q], st.csq[j0 + 4 * q]);
+        const bool lt = d < bd;  // a lane's centroids ascend (q, then tile), so strict < keeps its lowest j
+        bd = lt ? d : bd;
+        bj = lt ? j0 + 4 * q : bj;
+      }
+    }
+  }
+#pragma unroll
+  for (int off = 16; off <= 32; off <<= 1) {  // lanes l, l^16, l^32, l^48 hold the same batch row
+    const double d2 = __shfl_xor(bd, off, 64);
+    const int j2 = __shfl_xor(bj, off, 64);
+    const bool take = (d2 < bd) || (d2 == bd && j2 < bj);
+    bd = take ? d2 : bd;
+    bj = take ? j2 : bj;
+  }
+  __shared__ double sd[4][16];
+  __shared__ int sj[4][16];
+  if (lane < 16) {
+    sd[wv][lane] = bd;
+    sj[wv][lane] = bj;
+  }
+  __syncthreads();
+  if (tid < 16 && r0 + tid < st.n_b) {
+    double d = sd[0][tid];
+    int j = sj[0][tid];
+#pragma unroll
+    for (int w = 1; w < 4; w++) {
+      const double d2 = sd[w][tid];
+      const int j2 = sj[w][tid];
+      const bool take = (d2 < d) || (d2 == d && j2 < j);
+      d = take ? d2 : d;
+      j = take ? j2 : j;
+    }
+    if (j == 0x7fffffff) j = 0;  // all-NaN row: label 0 like the oracle
+    const long long rr = r0 + tid;
+    st.labels[rr] = j;
+    __hip_atomic_fetch_or(&st.mbits[(size_t)j * sdesc.wstride + (rr >> 6)], 1ull << (rr & 63), __ATOMIC_RELAXED,
+                          __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+
+// M-step: one workgroup per centroid, a thread per feature (1024 features per pass over the member list, 4 per thread).
+// Wave 0 expands the centroid's membership bitmap, 64 words at a time, into an LDS list of frame indices (and weights);
+// all threads then add the members in sample order, reading the frames where they lie (no f64 copy of the batch).
+#define UPDG_BLK 4096
+template <typename XT>
+__global__ __launch_bounds__(256) void k_step_update_generic(const StepDev *__restrict__ steps, int64_t ldx, int D, int KS) {
+  const StepDev sdesc = load_step<false>(steps, StepPack{}, blockIdx.y);
+  const StepG st(sdesc);
+  const int j = blockIdx.x;
+  if (j >= st.K || st.idx >= *gp(sdesc.halt)) return;  // (block-uniform)
+  __shared__ int sfr[UPDG_BLK];     // frame index of the block's m-th member
+  __shared__ __attribute__((aligned(16))) double swl[UPDG_BLK];  // its weight
+  __shared__ int s_blk;
+  __shared__ double s_wsum;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int nw = (int)((st.n_b + 63) >> 6);
+  GAS unsigned long long *mb = st.mbits + (size_t)j * sdesc.wstride;
+  const bool weighted = st.wf != nullptr;
+  const GAS XT *X = (const GAS XT *)st.X;
+  const double cnt0 = st.counts[j];
+  double wsum = 0.0, cnt1 = 0.0, alpha = 0.0;
+  long long total = 0;
+  const int nfc = (D + 1023) / 1024;
+  for (int fc = 0; fc < nfc; fc++) {
+    const bool first = fc == 0, last = fc == nfc - 1;
+    // c = c*count; c += x*w in sample order; count += wsum; c *= 1/count  (_k_means_minibatch.pyx:80-104)
+    double acc[4];
+    int kk[4];
+#pragma unroll
+    for (int h = 0; h < 4; h++) {
+      const int k = fc * 1024 + tid + 256 * h;
+      kk[h] = k < D ? k : D - 1;  // (threads past D carry a copy that is never stored)
+      acc[h] = st.C[(size_t)j * D + kk[h]] * cnt0;
+    }
+    for (int wb = 0; wb < nw; wb += 64) {  // (wstride is a multiple of 64: the words stay inside the centroid's row)
+      __syncthreads();                     // the previous block's list has been consumed
+      if (tid < 64) {
+        const unsigned long long w = mb[wb + lane];
+        if (last && w) mb[wb + lane] = 0ull;  // ready for the stratum's next step
+        const int pc = __popcll(w);
+        int inc = pc;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+          const int t = __shfl_up(inc, off, 64);
+          inc += lane >= off ? t : 0;
+        }
+        unsigned long long t = w;
+        int idx = inc - pc;
+        while (t) {
+          const int bit = __builtin_ctzll(t);
+          t &= t - 1;
+          sfr[idx++] = (wb + lane) * 64 + bit;  // the batch row, for now
+        }
+        if (lane == 63) s_blk = inc;
+      }
+      __syncthreads();
+      const int blk = s_blk;
+      for (int m = tid; m < blk; m += 256) {
+        const long long r = sfr[m];
+        const long long f = st.rows ? (long long)st.rows[r] : r;
+        sfr[m] = (int)f;
+        if (weighted) swl[m] = st.wf[f];
+      }
+      __syncthreads();
+      if (first && weighted && tid == 0)
+        for (int m = 0; m < blk; m++) wsum = wsum + swl[m];  // sample order (pyx:80-85)
+      for (int m0 = 0; m0 < blk; m0 += 8) {  // 8 member rows in flight
+        XT xv[8][4];
+#pragma unroll
+        for (int q = 0; q < 8; q++) {
+          const size_t fo = (size_t)sfr[m0 + q < blk ? m0 + q : blk - 1] * ldx;
+#pragma unroll
+          for (int h = 0; h < 4; h++) xv[q][h] = X[fo + kk[h]];
+        }
+#pragma unroll
+        for (int q = 0; q < 8; q++) {
+          const double wq = weighted ? swl[m0 + q < blk ? m0 + q : blk - 1] : 1.0;
+#pragma unroll
+          for (int h = 0; h < 4; h++) {
+            const double nv = acc[h] + (double)xv[q][h] * wq;
+            acc[h] = (m0 + q < blk) ? nv : acc[h];
+          }
+        }
+      }
+      if (first) total += blk;
+    }
+    if (first) {
+      if (total == 0) return;  // no member: centre unchanged (pyx:105-108); nothing to clear either
+      if (weighted) {
+        if (tid == 0) s_wsum = wsum;
+        __syncthreads();
+        wsum = s_wsum;
+      } else {
+        wsum = (double)total;  // the sum of `total` ones is exactly that
+      }
+      if (!(wsum > 0)) {  // pyx:87 / :105-108: centre unchanged; the bitmap is still to be cleared
+        for (int wi = tid; wi < nw; wi += 256) mb[wi] = 0ull;
+        return;
+      }
+      cnt1 = cnt0 + wsum;
+      alpha = 1.0 / cnt1;
+    }
+#pragma unroll
+    for (int h = 0; h < 4; h++) {
+      const int k = fc * 1024 + tid + 256 * h;
+      if (k < D) {
+        const double v = acc[h] * alpha;
+        st.C[(size_t)j * D + k] = v;
+        st.Bpack[((size_t)(j >> 4) * KS + (k >> 2)) * 64 + (k & 3) * 16 + (j & 15)] = v;
+      }
+    }
+  }
+  // ||c||^2 as an fma chain over ascending k (oracle sqnorm_chain): the new row comes back through LDS, 4096 features at a
+  // time (one coalesced round trip; a single thread loading it element by element would expose D memory latencies)
+  double a = 0.0;
+  for (int c0 = 0; c0 < D; c0 += UPDG_BLK) {
+    __syncthreads();  // the workgroup's stores to the row are visible to its loads (same CU); swl is free again
+    const int nc = D - c0 < UPDG_BLK ? D - c0 : UPDG_BLK;
+    for (int i = tid; i < nc; i += 256) swl[i] = st.C[(size_t)j * D + c0 + i];
+    __syncthreads();
+    if (tid == 0) {
+      int i = 0;
+      for (; i + 1 < nc; i += 2) {
+        const double2 t = *(const double2 *)&swl[i];
+        a = __builtin_fma(t.x, t.x, a);
+        a = __builtin_fma(t.y, t.y, a);
+      }
+      if (i < nc) a = __builtin_fma(swl[i], swl[i], a);
+    }
+  }
+  if (tid == 0) {
+    st.counts[j] = cnt1;
+    st.csq[j] = a;
   }
 }
 
@@ -2296,6 +2606,15 @@ static void launch_step_rt(hamsm_ctx *c, hipStream_t q, const StepDev *d_steps, 
 template <typename XT>
 static int launch_steps(hamsm_ctx *c, hipStream_t q, const StepDev *d_steps, const StepPack &pk, int ny, long long max_nb,
                         int maxK, int64_t ldx, double ratio, bool any_perm) {
+  if (c->KS > 32) {  // more than 128 features: descriptors always in memory, one queue (run_steps)
+    if (!d_steps) return hamsm_fail(c, HAMSM_EINVAL, "generic training kernels take their descriptors from memory");
+    hipLaunchKernelGGL(k_step_assign_generic<XT>, dim3((unsigned)((max_nb + 15) / 16), (unsigned)ny), dim3(256), 0, q, d_steps, ldx,
+                       c->D, c->KS, ratio);
+    hipLaunchKernelGGL(k_step_update_generic<XT>, dim3((unsigned)maxK, (unsigned)ny), dim3(256), 0, q, d_steps, ldx, c->D, c->KS);
+    if (any_perm)
+      hipLaunchKernelGGL((k_step_reassign<XT, false>), dim3((unsigned)ny), dim3(256), 0, q, d_steps, pk, ldx, c->D, c->KS, ratio);
+    return HAMSM_OK;
+  }
   switch (c->KS) {
 #define CASE(KSV)                                                                               \
   case KSV:                                                                                     \
@@ -2335,7 +2654,7 @@ static int run_steps(hamsm_ctx *c, const void *X, int dt, int64_t ldx, const int
                      int32_t *h_report, int64_t *h_resume, int32_t *h_reason, int want_zero_flag,
                      int32_t **labels_of_first) {
   const size_t esz = dt == HAMSM_F32 ? 4 : 8;
-  if (c->D > 128) return hamsm_fail(c, HAMSM_ENOTSUP, "training supports at most 128 features (D=%d)", c->D);
+  const bool generic = c->KS > 32;  // more than 128 features (k_step_*_generic)
   int64_t lab_hi = 0, nb_max = 0;
   for (int64_t i = 0; i < n_steps; i++) {
     const hamsm_step &s = h_steps[i];
@@ -2362,7 +2681,7 @@ static int run_steps(hamsm_ctx *c, const void *X, int dt, int64_t ldx, const int
   const int nslot = c->S < 65535 ? c->S : 65535;
   const size_t xg_row = sizeof(double) * 4 * (size_t)c->KS;
   const size_t nb_pad = ((size_t)nb_max + 63) & ~(size_t)63;  // whole E-step tiles (up to 4 x 16 rows)
-  size_t o_xg = take(xg_row * (size_t)nslot * nb_pad);
+  size_t o_xg = take(generic ? 0 : xg_row * (size_t)nslot * nb_pad);  // (the generic M-step reads the frames in place)
   int Kmax = 0;
   for (int s = 0; s < c->S; s++) Kmax = c->st[s].K > Kmax ? c->st[s].K : Kmax;
   const int wstride = (int)((((nb_max + 63) >> 6) + 63) & ~(int64_t)63);  // bitmap words per centroid
@@ -2489,7 +2808,7 @@ static int run_steps(hamsm_ctx *c, const void *X, int dt, int64_t ldx, const int
     for (int64_t q = gstart[g]; q < gstart[g + 1]; q++)
       if (++cnt[h_steps[q].stratum % n_lanes] > PACK_NY) n_lanes = 1;
   }
-  if (gstart.size() <= 2 || c->S < 2 || nslot != c->S || !d_rows) n_lanes = 1;  // (labels scratch is per step only with row lists)
+  if (gstart.size() <= 2 || c->S < 2 || nslot != c->S || !d_rows || generic) n_lanes = 1;  // (labels scratch is per step only with row lists)
   hipStream_t lanes[4] = {c->stream, nullptr, nullptr, nullptr};
   if (n_lanes > 1) {
     if (!c->ev_fork) HIPCHK(c, hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
@@ -2525,7 +2844,7 @@ static int run_steps(hamsm_ctx *c, const void *X, int dt, int64_t ldx, const int
       ny = (int)mine.size();
       if (ny == 0 || max_nb <= 0) continue;
       const StepDev *dptr = d_steps + i;
-      if (ny <= PACK_NY) {
+      if (ny <= PACK_NY && !generic) {
         dptr = nullptr;  // descriptors by value
         for (int q = 0; q < ny; q++) pk.s[q] = sd[mine[q]];
         pk.n_next = 0;

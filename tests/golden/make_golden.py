@@ -56,6 +56,9 @@ CASES = {
     # per iteration, the bench generator's own seed -- over 12 iterations.  Inputs are NOT stored (the tests regenerate
     # them from the seed with msm_we_amd.synthetic, 29 MB); outputs are stored compactly (labels int16, flux as COO).
     "c3s": dict(cfg=synthetic.WEConfig("c3s", 3, 12, 10000, 30, 4, 250), compact=True, block_validation=(2, 2)),
+    # more than 128 features per frame (the notebooks' flattened distance-matrix featurizers reach 816): 160 features, no
+    # dimensionality reduction -- the library's generic kernels (run-time k-step count).  Inputs regenerated from the seed.
+    "wide_d160": dict(cfg=synthetic.WEConfig("wide_d160", 11, 20, 128, 160, 2, 25), compact=True),
 }
 
 

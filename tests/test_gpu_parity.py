@@ -61,7 +61,9 @@ def test_mfma_f64_is_an_fma_chain(hip_h):
 
 @pytest.mark.parametrize("D,S,K_s,dtype", [(10, 1, 200, np.float32), (30, 4, 250, np.float32), (13, 12, 25, np.float64),
                                           (64, 4, 77, np.float32), (3, 2, 5, np.float64), (128, 2, 40, np.float32),
-                                          (20, 3, 33, np.float32)])
+                                          (20, 3, 33, np.float32),
+                                          # more than 128 features: the generic kernel (run-time k-step count)
+                                          (129, 2, 40, np.float32), (200, 3, 70, np.float64), (816, 2, 100, np.float32)])
 def test_assign_matches_oracle(hip_h, oracle_h, D, S, K_s, dtype):
     n = 5003  # not a multiple of the chunk or tile size
     outs = []
@@ -471,7 +473,13 @@ def _train_inputs(rng, n, D, S, dtype):
                                                        (3, np.float64, True, False, 25, 3000),     # KS = 1
                                                        # general (global-memory) seeding kernel: L = 9 candidates / > 3072 rows
                                                        (10, np.float32, False, False, 1100, 4000),
-                                                       (30, np.float32, True, False, 40, 9000)])
+                                                       (30, np.float32, True, False, 40, 9000),
+                                                       # more than 128 features: generic E-/M-step; Gram and general seeding;
+                                                       # 1100 features = two passes of the M-step over the member list
+                                                       (200, np.float32, True, False, 25, 3000),
+                                                       (816, np.float64, False, True, 25, 3000),
+                                                       (150, np.float32, True, False, 40, 9000),
+                                                       (1100, np.float32, True, False, 25, 3000)])
 def test_training_primitives_match_oracle(hip_h, oracle_h, D, dtype, weighted, sub, K, n):
     """prepass, row lists, k-means++ seeding, three minibatch steps and a reassignment: every
     intermediate bit-identical between the HIP library and the oracle."""
@@ -521,7 +529,8 @@ def test_training_primitives_match_oracle(hip_h, oracle_h, D, dtype, weighted, s
 
 
 @pytest.mark.parametrize("D,dtype,weighted,K", [(30, np.float32, False, 250), (70, np.float64, True, 600),
-                                                (10, np.float32, True, 40)])
+                                                (10, np.float32, True, 40),
+                                                (200, np.float32, True, 250), (1100, np.float32, False, 40)])  # generic kernels
 def test_fused_run_with_reseeding_matches_oracle(hip_h, oracle_h, D, dtype, weighted, K):
     """hamsm_minibatch_run with the low-count rule on the device: re-seeding from permutation heads (K spanning several
     256-centroid chunks, rows of more than 64 features, weights), and every way a stratum's chain can stop --
@@ -594,7 +603,7 @@ def test_fused_run_with_reseeding_matches_oracle(hip_h, oracle_h, D, dtype, weig
         assert list(a["reason"]) == [0, oracle_h.STOP_LOW, oracle_h.STOP_UNUSED, oracle_h.STOP_ZERO, oracle_h.STOP_CAP]
     for k in ("report", "resume", "reason"):
         assert np.array_equal(a[k], g[k]), (k, a[k], g[k])
-    assert a["report"][0, 1] > 1  # stratum 0: re-seeded on the device (more low counts than stratum 4's head held)
+    assert a["report"][0, 1] > (1 if D <= 128 else 0)  # stratum 0: re-seeded on the device (more low counts than stratum 4's head held)
     for s in range(S):
         for i, (x, y) in enumerate(zip(a[f"c{s}"], g[f"c{s}"])):
             assert np.array_equal(x, y), (s, i)
@@ -686,6 +695,14 @@ def test_c3_shaped_slice_on_reference_golden(hip_h):
 
     g, meta = load_golden("c3s")
     check_c3_shaped(hip_h, g, meta)
+
+
+def test_more_than_128_features_on_reference_golden(hip_h):
+    """golden wide_d160: 160 features per frame -- the generic kernels (k_assign_generic, k_step_*_generic), HIP library"""
+    from test_oracle_golden import check_c3_shaped
+
+    g, meta = load_golden("wide_d160")
+    check_c3_shaped(hip_h, g, meta, n_states=50)
 
 
 def test_pca_pipeline_on_reference_golden(hip_h, oracle_h):

@@ -158,13 +158,13 @@ def test_pca_pipeline_matches_reference(oracle_h):
     assert abs(m.JtargetSS - float(g["JtargetSS"])) <= 1e-6 * float(g["JtargetSS"])
 
 
-def check_c3_shaped(h, g, meta):
+def check_c3_shaped(h, g, meta, n_states=1000):
     """BASELINE config 3's geometry (D = 30, 4 strata x 250 clusters, 10 000 segments per iteration, the bench generator's
     seed) over 12 iterations against the REAL reference's outputs for exactly these inputs (golden c3s; inputs regenerated
     from the seed): every label of both passes, every centroid table, both flux matrices, T's input and the block-validation
     groups identical; steady state / target flux within 1e-6 rel.  No k-means++ seeding is teacher-forced here."""
     m, st = build_model(h, g, meta, seed_forcing=False)
-    assert m.n_clusters == int(g["n_clusters_post_cluster"]) == 1000
+    assert m.n_clusters == int(g["n_clusters_post_cluster"]) == n_states
     for b, cm in enumerate(m.clusters.cluster_models):
         assert np.array_equal(cm.cluster_centers_, g[f"centers_post_cluster_{b}"])
         assert np.array_equal(cm._counts, g[f"counts_post_cluster_{b}"])
@@ -190,6 +190,14 @@ def check_c3_shaped(h, g, meta):
 def test_c3_shaped_slice_matches_reference(oracle_h):
     g, meta = load_golden("c3s")
     check_c3_shaped(oracle_h, g, meta)
+
+
+def test_more_than_128_features_match_reference(oracle_h):
+    """golden wide_d160: 160 features per frame, no dimensionality reduction (the notebooks' flattened distance-matrix
+    featurizers are wider still) -- the same end-to-end comparison against the real reference's outputs"""
+    g, meta = load_golden("wide_d160")
+    assert meta["D"] == 160
+    check_c3_shaped(oracle_h, g, meta, n_states=50)
 
 
 def plain_euclid(coordvec, centers):
