@@ -79,6 +79,7 @@ struct hamsm_ctx {
   int train_persist = 0;  // HAMSM_TRAIN_PERSIST=1: planned training passes run as ONE persistent launch (measured slower than the
                           // multi-kernel path on every shape tried -- DESIGN.md §5.3a -- and therefore off; kept as a tested alternative)
   int persist_wpx = 64;   // workgroups per XCD of that launch (HAMSM_PERSIST_WPX, 8 XCDs: grid = 8 x this)
+  int generic_stage_kb = 150;  // D > 128: the E-step stages its 16 rows in LDS while they fit this (HAMSM_GENERIC_STAGE_KB; 0 = never)
   // hamsm_malloc / hamsm_free keep released blocks for reuse (hipMalloc costs ~1 ms per 40 MB block and hipFree
   // synchronises the device; every use of a block is ordered on `stream`, so reuse needs no synchronisation)
   std::unordered_map<void *, size_t> blk_live;

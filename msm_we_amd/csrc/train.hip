@@ -1625,12 +1625,15 @@ __global__ __launch_bounds__(256) void k_step_reassign(const StepDev *__restrict
 // so the results are bit-identical to the oracle's as well.  Correct first, not speed-of-light: DESIGN.md §5.6.
 //
 // E-step: one workgroup per 16 batch rows, the stratum's centroid tiles dealt over its 4 waves, operands straight from L2.
-template <typename XT>
+template <typename XT, int RT, bool STAGE>
 __global__ __launch_bounds__(256) void k_step_assign_generic(const StepDev *__restrict__ steps, int64_t ldx, int D, int KS,
                                                              double ratio) {
+  static_assert(STAGE || RT == 1, "several row tiles share the staged rows");
+  extern __shared__ __attribute__((aligned(16))) unsigned char xs_raw[];  // STAGE: the workgroup's rows, [16 RT][DS] XT
   const StepDev sdesc = load_step<false>(steps, StepPack{}, blockIdx.y);
   const StepG st(sdesc);
-  const long long r0 = (long long)blockIdx.x * 16;
+  constexpr int RW = 16 * RT;  // rows per workgroup
+  const long long r0 = (long long)blockIdx.x * RW;
   if (r0 >= st.n_b) return;
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, kq = lane >> 4;
   const double inf = __builtin_huge_val();
@@ -1668,37 +1671,91 @@ __global__ __launch_bounds__(256) void k_step_assign_generic(const StepDev *__re
       }
     }
   }
-  // centroids are the MFMA's A operand, the 16 batch rows its B operand: lane l accumulates, for batch row l&15, the
-  // centroids (l>>4) + 4q of a tile.  Wave w owns the tiles w, w + 4, ...; two at a time, 8 k-steps of operands in flight
-  const long long r = r0 + (lane & 15);
-  const bool ok = r < st.n_b;
-  const long long rc = ok ? r : st.n_b - 1;
-  const long long f = st.rows ? (long long)st.rows[rc] : rc;
-  const GAS XT *xr = (const GAS XT *)st.X + f * ldx;
+  // centroids are the MFMA's A operand, 16 batch rows its B operand: lane l accumulates, for batch row l&15 of a row tile,
+  // the centroids (l>>4) + 4q of a centroid tile.  Wave w owns the centroid tiles w, w + 4, ...: two at a time against the
+  // workgroup's RT row tiles (every fragment of Bpack it loads serves RT MFMAs), 8 k-steps of operands in flight
+  long long f[RT];
+  bool ok[RT];
+#pragma unroll
+  for (int rt = 0; rt < RT; rt++) {
+    const long long r = r0 + rt * 16 + (lane & 15);
+    ok[rt] = r < st.n_b;
+    const long long rc = ok[rt] ? r : st.n_b - 1;  // (rows past the batch repeat its last row; nothing of them is kept)
+    f[rt] = st.rows ? (long long)st.rows[rc] : rc;
+  }
+  const GAS XT *xr = (const GAS XT *)st.X + f[0] * ldx;  // (!STAGE: RT == 1)
+  const int DS = D | 1;  // odd row stride: the 16 rows of a fragment read fall into different banks
+  XT *xs = (XT *)xs_raw;
+  if constexpr (STAGE) {
+    // all four waves need all rows (each sweeps its own centroid tiles): gathered once, coalesced (wave w: rows 4 RT w ...,
+    // a lane per feature), 8 loads in flight per lane
+    constexpr int RPW = RW / 4;
+#pragma unroll 1
+    for (int rr = 0; rr < RPW; rr++) {
+      const int row = wv * RPW + rr, tile = row >> 4;
+      long long fsel = f[0];
+#pragma unroll
+      for (int t = 1; t < RT; t++) fsel = tile == t ? f[t] : fsel;
+      const long long fr = __shfl(fsel, row & 15, 64);  // (lane l holds the frame of row l & 15 of every tile)
+      const GAS XT *src = (const GAS XT *)st.X + fr * ldx;
+      for (int k0 = 0; k0 < D; k0 += 64 * 8) {
+        XT v[8];
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+          const int k = k0 + lane + 64 * i;
+          v[i] = src[k < D ? k : D - 1];
+        }
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+          const int k = k0 + lane + 64 * i;
+          if (k < D) xs[row * DS + k] = v[i];
+        }
+      }
+    }
+    __syncthreads();
+  }
+  const XT *xl = xs + (lane & 15) * DS;
   const int njt = (st.K + 15) >> 4;
-  double bd = inf;
-  int bj = 0x7fffffff;
+  double bd[RT];
+  int bj[RT];
+#pragma unroll
+  for (int rt = 0; rt < RT; rt++) {
+    bd[rt] = inf;
+    bj[rt] = 0x7fffffff;
+  }
   for (int jt0 = wv; jt0 < njt; jt0 += 8) {
     const bool two = jt0 + 4 < njt;
     const GAS double *bp0 = st.Bpack + (size_t)jt0 * KS * 64 + lane;
     const GAS double *bp1 = st.Bpack + (size_t)(two ? jt0 + 4 : jt0) * KS * 64 + lane;
-    v4f64 acc0 = (v4f64){0.0, 0.0, 0.0, 0.0}, acc1 = acc0;
-    constexpr int U = 8;  // k-steps of operands in flight (measured at D = 816, K_s = 100: 8 -> 39 us per launch, 16 -> 46 us)
+    v4f64 acc0[RT], acc1[RT];
+#pragma unroll
+    for (int rt = 0; rt < RT; rt++) acc0[rt] = acc1[rt] = (v4f64){0.0, 0.0, 0.0, 0.0};
+    constexpr int U = 8;  // k-steps of operands in flight (measured at D = 816, K_s = 100, RT = 1: 8 -> 39 us per launch, 16 -> 46 us)
     for (int ks0 = 0; ks0 < KS; ks0 += U) {
-      double xa[U], b0[U], b1[U];
+      double xa[RT][U], b0[U], b1[U];
 #pragma unroll
       for (int i = 0; i < U; i++) {  // unconditional loads at clamped positions; what lies past KS / D is deselected below
         const int ks = ks0 + i < KS ? ks0 + i : KS - 1, k = ks * 4 + kq;
-        xa[i] = (double)xr[k < D ? k : D - 1];
+        const int kc = k < D ? k : D - 1;
+        if constexpr (STAGE) {
+#pragma unroll
+          for (int rt = 0; rt < RT; rt++) xa[rt][i] = (double)xl[rt * 16 * DS + kc];
+        } else {
+          xa[0][i] = (double)xr[kc];
+        }
         b0[i] = bp0[(size_t)ks * 64];
         b1[i] = bp1[(size_t)ks * 64];
       }
 #pragma unroll
       for (int i = 0; i < U; i++) {
-        const bool in = ks0 + i < KS;
-        const double a = (in && (ks0 + i) * 4 + kq < D) ? xa[i] : 0.0;  // fma(0, 0, acc) == acc
-        acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(in ? b0[i] : 0.0, a, acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(in ? b1[i] : 0.0, a, acc1, 0, 0, 0);
+        const bool in = ks0 + i < KS, inx = in && (ks0 + i) * 4 + kq < D;
+        const double v0 = in ? b0[i] : 0.0, v1 = in ? b1[i] : 0.0;
+#pragma unroll
+        for (int rt = 0; rt < RT; rt++) {
+          const double a = inx ? xa[rt][i] : 0.0;  // fma(0, 0, acc) == acc
+          acc0[rt] = __builtin_amdgcn_mfma_f64_16x16x4f64(v0, a, acc0[rt], 0, 0, 0);
+          acc1[rt] = __builtin_amdgcn_mfma_f64_16x16x4f64(v1, a, acc1[rt], 0, 0, 0);
+        }
       }
     }
 #pragma unroll
@@ -1707,29 +1764,38 @@ __global__ __launch_bounds__(256) void k_step_assign_generic(const StepDev *__re
       const int j0 = (jt0 + 4 * u) * 16 + kq;
 #pragma unroll
       for (int q = 0; q < 4; q++) {
-        const double d = __builtin_fma(-2.0, u ? acc1[q] : acc0[q], st.csq[j0 + 4 * q]);
-        const bool lt = d < bd;  // a lane's centroids ascend (q, then tile), so strict < keeps its lowest j
-        bd = lt ? d : bd;
-        bj = lt ? j0 + 4 * q : bj;
+        const double cq = st.csq[j0 + 4 * q];
+#pragma unroll
+        for (int rt = 0; rt < RT; rt++) {
+          const double d = __builtin_fma(-2.0, u ? acc1[rt][q] : acc0[rt][q], cq);
+          const bool lt = d < bd[rt];  // a lane's centroids ascend (q, then tile), so strict < keeps its lowest j
+          bd[rt] = lt ? d : bd[rt];
+          bj[rt] = lt ? j0 + 4 * q : bj[rt];
+        }
       }
     }
   }
+  __shared__ double sd[4][RW];
+  __shared__ int sj[4][RW];
 #pragma unroll
-  for (int off = 16; off <= 32; off <<= 1) {  // lanes l, l^16, l^32, l^48 hold the same batch row
-    const double d2 = __shfl_xor(bd, off, 64);
-    const int j2 = __shfl_xor(bj, off, 64);
-    const bool take = (d2 < bd) || (d2 == bd && j2 < bj);
-    bd = take ? d2 : bd;
-    bj = take ? j2 : bj;
-  }
-  __shared__ double sd[4][16];
-  __shared__ int sj[4][16];
-  if (lane < 16) {
-    sd[wv][lane] = bd;
-    sj[wv][lane] = bj;
+  for (int rt = 0; rt < RT; rt++) {
+    double d = bd[rt];
+    int j = bj[rt];
+#pragma unroll
+    for (int off = 16; off <= 32; off <<= 1) {  // lanes l, l^16, l^32, l^48 hold the same batch row
+      const double d2 = __shfl_xor(d, off, 64);
+      const int j2 = __shfl_xor(j, off, 64);
+      const bool take = (d2 < d) || (d2 == d && j2 < j);
+      d = take ? d2 : d;
+      j = take ? j2 : j;
+    }
+    if (lane < 16) {
+      sd[wv][rt * 16 + lane] = d;
+      sj[wv][rt * 16 + lane] = j;
+    }
   }
   __syncthreads();
-  if (tid < 16 && r0 + tid < st.n_b) {
+  if (tid < RW && r0 + tid < st.n_b) {
     double d = sd[0][tid];
     int j = sj[0][tid];
 #pragma unroll
@@ -1850,6 +1916,7 @@ __global__ __launch_bounds__(256) void k_step_update_generic(const StepDev *__re
       cnt1 = cnt0 + wsum;
       alpha = 1.0 / cnt1;
     }
+    if (nfc == 1) __syncthreads();  // (every thread is done with the weights: swl takes the new row for the chain below)
 #pragma unroll
     for (int h = 0; h < 4; h++) {
       const int k = fc * 1024 + tid + 256 * h;
@@ -1857,25 +1924,34 @@ __global__ __launch_bounds__(256) void k_step_update_generic(const StepDev *__re
         const double v = acc[h] * alpha;
         st.C[(size_t)j * D + k] = v;
         st.Bpack[((size_t)(j >> 4) * KS + (k >> 2)) * 64 + (k & 3) * 16 + (j & 15)] = v;
+        if (nfc == 1) swl[k] = v;
       }
     }
   }
-  // ||c||^2 as an fma chain over ascending k (oracle sqnorm_chain): the new row comes back through LDS, 4096 features at a
-  // time (one coalesced round trip; a single thread loading it element by element would expose D memory latencies)
+  // ||c||^2 as an fma chain over ascending k (oracle sqnorm_chain): the new row goes through LDS (left there by a single
+  // pass; else read back 4096 features at a time, one coalesced round trip -- a single thread loading it element by element
+  // would expose D memory latencies)
   double a = 0.0;
   for (int c0 = 0; c0 < D; c0 += UPDG_BLK) {
     __syncthreads();  // the workgroup's stores to the row are visible to its loads (same CU); swl is free again
     const int nc = D - c0 < UPDG_BLK ? D - c0 : UPDG_BLK;
-    for (int i = tid; i < nc; i += 256) swl[i] = st.C[(size_t)j * D + c0 + i];
-    __syncthreads();
+    if (nfc > 1) {  // (a single pass left the row in swl already)
+      for (int i = tid; i < nc; i += 256) swl[i] = st.C[(size_t)j * D + c0 + i];
+      __syncthreads();
+    }
     if (tid == 0) {
       int i = 0;
-      for (; i + 1 < nc; i += 2) {
-        const double2 t = *(const double2 *)&swl[i];
-        a = __builtin_fma(t.x, t.x, a);
-        a = __builtin_fma(t.y, t.y, a);
+      for (; i + 15 < nc; i += 16) {  // 8 LDS reads in flight ahead of the 16 dependent fmas
+        double2 t[8];
+#pragma unroll
+        for (int q = 0; q < 8; q++) t[q] = *(const double2 *)&swl[i + 2 * q];
+#pragma unroll
+        for (int q = 0; q < 8; q++) {
+          a = __builtin_fma(t[q].x, t[q].x, a);
+          a = __builtin_fma(t[q].y, t[q].y, a);
+        }
       }
-      if (i < nc) a = __builtin_fma(swl[i], swl[i], a);
+      for (; i < nc; i++) a = __builtin_fma(swl[i], swl[i], a);
     }
   }
   if (tid == 0) {
@@ -2608,8 +2684,30 @@ static int launch_steps(hamsm_ctx *c, hipStream_t q, const StepDev *d_steps, con
                         int maxK, int64_t ldx, double ratio, bool any_perm) {
   if (c->KS > 32) {  // more than 128 features: descriptors always in memory, one queue (run_steps)
     if (!d_steps) return hamsm_fail(c, HAMSM_EINVAL, "generic training kernels take their descriptors from memory");
-    hipLaunchKernelGGL(k_step_assign_generic<XT>, dim3((unsigned)((max_nb + 15) / 16), (unsigned)ny), dim3(256), 0, q, d_steps, ldx,
-                       c->D, c->KS, ratio);
+    // the E-step's rows in LDS while they fit; 2 or 4 row tiles per workgroup (every Bpack fragment then serves 2 / 4 MFMAs)
+    // once the launch is large enough
+    const size_t row_bytes = sizeof(XT) * 16 * (size_t)(c->D | 1), cap = (size_t)c->generic_stage_kb * 1024;
+    const long long tiles = (max_nb + 15) / 16 * ny;
+    const char *rt_s = getenv("HAMSM_GENERIC_RT");  // (tests / experiments force a tile count)
+    // (measured at D = 816, 4 x 100 centroids, 500 row tiles per launch: RT = 1 / 2 / 4 -> 18.7 / 24.9 / 24.9 ms per pass -- the
+    // kernel runs at the f64 MFMA rate there and fewer, fatter workgroups only lose occupancy; hence >= 1024 workgroups kept)
+    int rt = rt_s ? atoi(rt_s) : (tiles >= 4 * 1024 ? 4 : (tiles >= 2 * 1024 ? 2 : 1));
+    while (rt > 1 && rt * row_bytes > cap) rt >>= 1;
+    rt = rt >= 4 ? 4 : (rt >= 2 ? 2 : 1);
+    const dim3 ge((unsigned)((max_nb + 16 * rt - 1) / (16 * rt)), (unsigned)ny);
+    const void *kfn = (const void *)k_step_assign_generic<XT, 1, false>;
+    size_t xs_bytes = 0;
+    if (row_bytes <= cap) {
+      xs_bytes = rt * row_bytes;
+      kfn = rt == 4 ? (const void *)k_step_assign_generic<XT, 4, true>
+                    : (rt == 2 ? (const void *)k_step_assign_generic<XT, 2, true> : (const void *)k_step_assign_generic<XT, 1, true>);
+      HIPCHK(c, hipFuncSetAttribute(kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)xs_bytes));
+    }
+    {
+      int D_ = c->D, KS_ = c->KS;
+      void *args[] = {(void *)&d_steps, (void *)&ldx, (void *)&D_, (void *)&KS_, (void *)&ratio};
+      HIPCHK(c, hipLaunchKernel(kfn, ge, dim3(256), args, xs_bytes, q));
+    }
     hipLaunchKernelGGL(k_step_update_generic<XT>, dim3((unsigned)maxK, (unsigned)ny), dim3(256), 0, q, d_steps, ldx, c->D, c->KS);
     if (any_perm)
       hipLaunchKernelGGL((k_step_reassign<XT, false>), dim3((unsigned)ny), dim3(256), 0, q, d_steps, pk, ldx, c->D, c->KS, ratio);

@@ -227,3 +227,32 @@ def test_persistent_training_launch_equals_multikernel_path(hip_lib, monkeypatch
     for a, b in zip(out[0][0] + out[0][1], out[1][0] + out[1][1]):
         assert np.array_equal(a, b)
     assert out[0][2] == out[1][2] and np.array_equal(out[0][3], out[1][3])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("stage_kb,rt,outliers", [("150", "1", False), ("0", "", False), ("150", "2", True), ("150", "4", False),
+                                                  ("150", "", True)])
+def test_wide_feature_training_matches_oracle(hip_lib, oracle_h, stage_kb, rt, outliers, monkeypatch):
+    """more than 128 features per frame (the generic kernels, run-time k-step count): planned training through the model,
+    with the E-step's rows staged in LDS (1, 2, 4 row tiles per workgroup, or the library's choice) and read straight from
+    memory, and with reassignments (outliers) on the way"""
+    from msm_we_amd import _abi
+
+    monkeypatch.setenv("HAMSM_GENERIC_STAGE_KB", stage_kb)  # read when the context is created
+    if rt:
+        monkeypatch.setenv("HAMSM_GENERIC_RT", rt)
+    h = _abi.Hamsm(lib=hip_lib, device=0)
+    try:
+        cfg = synthetic.WEConfig("w5", 8, 5, 3000, 200, 4, 30)
+        g = _run(h, cfg, 30, True, outliers=outliers)
+        o = _run(oracle_h, cfg, 30, True, outliers=outliers)
+        assert g[0].training_path == o[0].training_path
+        assert np.array_equal(g[1], o[1])
+        for x, y in zip(g[2] + g[3], o[2] + o[3]):
+            assert np.array_equal(x, y)
+        s = _run(h, cfg, 30, False, outliers=outliers)  # stepwise on the device: same result
+        assert np.array_equal(g[1], s[1])
+        for x, y in zip(g[2] + g[3], s[2] + s[3]):
+            assert np.array_equal(x, y)
+    finally:
+        h.close()
