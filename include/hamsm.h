@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define HAMSM_ABI_VERSION 4
+#define HAMSM_ABI_VERSION 5
 
 #define HAMSM_OK 0
 #define HAMSM_EINVAL (-1)   /* bad argument / call order                                         */
@@ -121,6 +121,25 @@ int hamsm_classify(hamsm_ctx *ctx, const double *d_pcoord, int64_t n, int apply_
  * d_X holds n rows of Draw raw features (x_dtype, row stride ldx); d_Y is [n][d] float64.  Needs no geometry.      */
 int hamsm_project(hamsm_ctx *ctx, const void *d_X, int x_dtype, int64_t ldx, int64_t n, int Draw,
                   const double *h_mean, const double *h_W, int d, const double *h_scale, double *d_Y);
+
+/* ---- f3: streaming PCA FIT by covariance accumulation.  The reference fits scikit-learn's IncrementalPCA one
+ * iteration at a time (`do_pca` / `do_full_pca`, _dimensionality.py:69-108, driven by :171-241: a forked process and an SVD of
+ * (components + batch) x features per iteration).  These three calls replace that loop by one pass over the same features:
+ *   hamsm_pca_begin(D)                      zero the sums
+ *   hamsm_pca_accumulate(d_X, ...) ...      any number of blocks of n rows x D raw features (x_dtype, row stride ldx)
+ *   hamsm_pca_finish(&n, shift, S1, S2)     n = rows seen; shift[D] = the first row seen; S1[a] = sum_f z_a(f);
+ *                                           S2[a][b] = sum_f z_a(f) z_b(f)  (full symmetric [D][D]),  z(f) = x(f) - shift
+ * from which the caller forms mean = shift + S1/n, cov = (S2 - S1 S1^T / n) / (n - 1) and its eigenvectors (the D x D
+ * eigen-solve is host work, msm_we_amd/pca.py).  Opt-in (`modelWE.pca_fit = "device"`): IncrementalPCA with a component cap
+ * truncates at every batch, so its result is not a function of the covariance -- the default fit stays the reference's own.
+ * Order (bit-identical across the two libraries): per accumulate call the n rows are cut into G strips of L rows,
+ *   Dp = 32 ceil((D+1)/32),  G = max(1, min(8192, ceil(n/512), floor(2^25 / Dp^2))),  L = 4 ceil(ceil(n/G)/4);
+ * per strip and pair a <= b the products are accumulated in row order as one fma chain from 0; the strips' sums are added in
+ * strip order inside groups of 64 consecutive strips, the groups' sums in group order, and that total is added to the
+ * running sum.  Needs no geometry.                                                                                     */
+int hamsm_pca_begin(hamsm_ctx *ctx, int Draw);
+int hamsm_pca_accumulate(hamsm_ctx *ctx, const void *d_X, int x_dtype, int64_t ldx, int64_t n);
+int hamsm_pca_finish(hamsm_ctx *ctx, int64_t *n_total, double *h_shift, double *h_S1, double *h_S2);
 
 /* ---- a1: the distance-to-reference featurizer the reference ships with its tests (`processCoordinates`,
  * tests/test_msm_we.py:19-36: MDAnalysis `distances.dist(frame_atoms, reference_atoms)[2]` per frame; contract

@@ -20,7 +20,7 @@ _vp, _i32, _i64, _f64, _sz = C.c_void_p, C.c_int32, C.c_int64, C.c_double, C.c_s
 _int = C.c_int
 
 # name -> (restype, argtypes); kept in the order of include/hamsm.h
-ABI_VERSION = 4  # HAMSM_ABI_VERSION of include/hamsm.h
+ABI_VERSION = 5  # HAMSM_ABI_VERSION of include/hamsm.h
 
 SYMBOLS = {
     "hamsm_abi_version": (_int, []),
@@ -52,6 +52,9 @@ SYMBOLS = {
     "hamsm_classify": (_int, [_vp, _vp, _i64, _int, _vp, _vp]),
     "hamsm_project": (_int, [_vp, _vp, _int, _i64, _i64, _int, _vp, _vp, _int, _vp, _vp]),
     "hamsm_featurize_dist": (_int, [_vp, _vp, _int, _i64, _i64, _int, _vp, _int, _vp, _vp, _i64]),
+    "hamsm_pca_begin": (_int, [_vp, _int]),
+    "hamsm_pca_accumulate": (_int, [_vp, _vp, _int, _i64, _i64]),
+    "hamsm_pca_finish": (_int, [_vp, _vp, _vp, _vp, _vp]),
     "hamsm_assign": (_int, [_vp, _vp, _int, _i64, _vp, _i64, _vp, _vp]),
     "hamsm_labels_to_host": (_int, [_vp, _vp, _vp, _i64, _vp, _vp]),
     "hamsm_predict_host": (_int, [_vp, _vp, _int, _vp, _i64, _vp, _vp]),
@@ -373,6 +376,22 @@ class Hamsm:
         self._ck(self.lib.hamsm_project(self.ctx, _dp(d_X), int(x_dtype), int(ldx), int(n), int(Draw), _hp(mean), _hp(W), int(d),
                                         _hp(scale), _dp(d_Y)))
         return d_Y
+
+    def pca_begin(self, Draw):
+        """start a streaming PCA fit over rows of `Draw` raw features (hamsm.h f3)"""
+        self._pca_D = int(Draw)
+        self._ck(self.lib.hamsm_pca_begin(self.ctx, int(Draw)))
+
+    def pca_accumulate(self, d_X, x_dtype, ldx, n):
+        self._ck(self.lib.hamsm_pca_accumulate(self.ctx, _dp(d_X), int(x_dtype), int(ldx), int(n)))
+
+    def pca_finish(self):
+        """-> (n, shift [D], S1 [D], S2 [D][D]): sums of the rows seen, shifted by the first one"""
+        D = self._pca_D
+        n = C.c_int64(0)
+        shift, S1, S2 = np.empty(D), np.empty(D), np.empty((D, D))
+        self._ck(self.lib.hamsm_pca_finish(self.ctx, C.byref(n), _hp(shift), _hp(S1), _hp(S2)))
+        return int(n.value), shift, S1, S2
 
     def featurize_dist(self, d_coords, c_dtype, ldc, n, n_atoms, idx, ref, d_X=None):
         """per-atom distance to a reference structure (the reference's test featurizer): -> DevBuf [n][len(idx)] float64"""

@@ -108,6 +108,9 @@ struct hamsm_ctx {
   double *flux_part = nullptr;  // per-XCD partial flux matrices (flux.hip)
   size_t flux_part_bytes = 0;
   int flux_xcd = 1;             // HAMSM_FLUX_XCD=0: one matrix, device-scope atomics
+  double *pca_S2 = nullptr, *pca_mu0 = nullptr;  // streaming PCA fit (pca.hip): running sums [Dp][Dp], shift [Dp]
+  int pca_D = 0;
+  int64_t pca_n = 0;
   int flux_xcd_checked = 0;     // the per-XCD path has been compared with the single-matrix kernel once (flux.hip)
   std::vector<char> h_stage;  // host staging for small asynchronous H2D copies (lives as long as the ctx)
   void *h_pinned = nullptr;  // small pinned staging buffer
@@ -165,6 +168,7 @@ int hamsm_ctx_check(hamsm_ctx *c, const char *fn);
       return hamsm_fail((c), HAMSM_EDEVICE, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); \
   } while (0)
 
+void hamsm_pca_release(hamsm_ctx *c);
 int hamsm_take_frame_bins(hamsm_ctx *c, const char *what);  // external mapper: consume the bins named for this call
 int hamsm_ensure_scratch(hamsm_ctx *c, size_t bytes);
 int hamsm_ensure_scratch2(hamsm_ctx *c, size_t bytes);

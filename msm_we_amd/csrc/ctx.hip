@@ -129,6 +129,7 @@ extern "C" void hamsm_destroy(hamsm_ctx *c) {
   release(c->host_live);
   for (auto &kv : c->blk_live) hipFree(kv.first);  // device memory dies with its context
   free_strata(c);
+  hamsm_pca_release(c);
   hipFree(c->d_bounds);
   hipFree(c->d_centers);
   hipFree(c->d_ext_bins_own);

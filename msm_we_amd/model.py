@@ -254,12 +254,15 @@ class modelWE(DataMixin, ClusteringMixin, FluxMatrixMixin, AnalysisMixin):
 
         if last_iter is None:
             last_iter = self.maxIter
-        rough_ipca = iPCA()
         if first_rough_iter is None:
             total = last_iter
             rough_iters = range(1, total, rough_stride) if total > 100 else range(total // 2, total)  # :150-158
         else:
             rough_iters = range(first_rough_iter, last_iter, rough_stride)
+        if getattr(self, "pca_fit", "host") == "device":
+            return self._dimReduce_device(rough_iters, range(first_iter, last_iter, fine_stride), variance_cutoff,
+                                          (last_iter - first_iter) // fine_stride - 1)
+        rough_ipca = iPCA()
         for iteration in rough_iters:  # do_pca, :69-82
             iter_coords = self.get_iter_coordinates(iteration)
             if iter_coords.shape[0] == 0:
@@ -284,6 +287,49 @@ class modelWE(DataMixin, ClusteringMixin, FluxMatrixMixin, AnalysisMixin):
             ipca.partial_fit(self.processCoordinates(iter_coords))
             extra = used
         self.coordinates = ipca
+        self.ndim = components_for_var
+
+    pca_fit = "host"  # "device": exact PCA from covariance sums accumulated in HBM (pca.py); "host": the reference's IncrementalPCA
+
+    def _pca_sums(self, iterations):
+        """the features of `iterations` (what `do_pca` hands to partial_fit, _dimensionality.py:69-82) streamed through
+        hamsm_pca_accumulate: -> (n, shift, S1, S2)"""
+        h = self.h
+        buf, cap, started = None, 0, False
+        try:
+            for it in iterations:
+                iter_coords = self.get_iter_coordinates(it)
+                if iter_coords.shape[0] == 0:
+                    continue
+                X = np.ascontiguousarray(self.processCoordinates(iter_coords), dtype=np.float64)
+                n, D = X.shape
+                if not started:
+                    h.pca_begin(D)
+                    started = True
+                if n * D > cap:
+                    if buf is not None:
+                        buf.free()
+                    cap = max(n * D, 2 * cap)
+                    buf = h.alloc(cap, np.float64)
+                h.sync()                      # the previous block has been consumed
+                h.h2d(buf, X)
+                h.pca_accumulate(buf, _abi.F64, D, n)
+            if not started:
+                raise ValueError("no coordinates to fit the PCA on")
+            return h.pca_finish()
+        finally:
+            if buf is not None:
+                buf.free()
+
+    def _dimReduce_device(self, rough_iters, fine_iters, variance_cutoff, comp_cap):
+        """the reference's two-stage scheme (`_dimensionality.py:139-241`) with exact PCA in both stages: the rough subset decides
+        how many components explain `variance_cutoff` (:192-200), all iterations give the components"""
+        from .pca import CovariancePCA
+
+        rough = CovariancePCA().fit_from_sums(*self._pca_sums(rough_iters))
+        components_for_var = int(np.argmax(np.cumsum(rough.explained_variance_ratio_) > variance_cutoff) + 1)
+        components_for_var = min(components_for_var, comp_cap)
+        self.coordinates = CovariancePCA(n_components=components_for_var).fit_from_sums(*self._pca_sums(fine_iters))
         self.ndim = components_for_var
 
     # msm_we.py:588-882, without the rich table / Ray bootstrap

@@ -59,6 +59,9 @@ struct hamsm_ctx {
   int32_t *ext_own;         /* copy of host-supplied bins */
   int ext_set;
   stratum_t *st;
+  double *pca_S2, *pca_mu0; /* streaming PCA fit: running sums [Dp][Dp] (a <= b), shift [Dp] */
+  int pca_D;
+  int64_t pca_n;
 };
 
 static int fail(hamsm_ctx *c, int code, const char *fmt, ...) {
@@ -157,8 +160,11 @@ void hamsm_destroy(hamsm_ctx *c) {
   }
   free(c->centers);
   free(c->ext_own);
+  free(c->pca_S2);
+  free(c->pca_mu0);
   c->centers = NULL;
   c->ext_own = NULL;
+  c->pca_S2 = c->pca_mu0 = NULL;
   for (size_t i = 0; i < c->n_blocks; i++) free(c->blocks[i]); /* "device" memory dies with its context, as hipFree'd */
   free(c->blocks);
   c->blocks = NULL;
@@ -732,6 +738,97 @@ int hamsm_project(hamsm_ctx *c, const void *X, int dt, int64_t ldx, int64_t n, i
       Y[i * d + j] = a;
     }
   free(m);
+  return HAMSM_OK;
+}
+
+/* --- f3: streaming PCA fit by covariance accumulation (opt-in replacement of the IncrementalPCA loop of
+ *     _dimensionality.py:69-108, 171-241; include/hamsm.h states the order).  The sums of the shifted features
+ *     z = x - (first row), with a ones column carrying S1: per call G strips of L rows, per strip and pair a <= b one fma
+ *     chain over the rows, strips added in order inside groups of 64, groups added in order, the call's total added to the
+ *     running sum. */
+int hamsm_pca_begin(hamsm_ctx *c, int Draw) {
+  CTX(c);
+  if (Draw < 1 || Draw > 16384) return fail(c, HAMSM_EINVAL, "pca_begin: %d features", Draw);
+  free(c->pca_S2);
+  free(c->pca_mu0);
+  const int Dp = (Draw + 1 + 31) & ~31;
+  c->pca_S2 = (double *)calloc((size_t)Dp * Dp, sizeof(double));
+  c->pca_mu0 = (double *)calloc((size_t)Dp, sizeof(double));
+  if (!c->pca_S2 || !c->pca_mu0) return fail(c, HAMSM_ENOMEM, "pca sums");
+  c->pca_D = Draw;
+  c->pca_n = 0;
+  return HAMSM_OK;
+}
+
+int hamsm_pca_accumulate(hamsm_ctx *c, const void *X, int dt, int64_t ldx, int64_t n) {
+  CTX(c);
+  if (!c->pca_S2) return fail(c, HAMSM_EINVAL, "pca_accumulate before pca_begin");
+  if (dt != HAMSM_F32 && dt != HAMSM_F64) return fail(c, HAMSM_EINVAL, "bad x_dtype");
+  const int D = c->pca_D, Dp = (D + 1 + 31) & ~31;
+  if (ldx < D) return fail(c, HAMSM_EINVAL, "ldx < D");
+  if (n <= 0) return HAMSM_OK;
+  if (c->pca_n == 0)
+    for (int a = 0; a < D; a++) c->pca_mu0[a] = xval(X, dt, a);
+  int64_t G = (n + 511) / 512;
+  const int64_t cap = ((int64_t)1 << 25) / ((int64_t)Dp * Dp);
+  if (G > 8192) G = 8192;
+  if (G > cap) G = cap;
+  if (G < 1) G = 1;
+  int64_t L = (n + G - 1) / G;
+  L = (L + 3) & ~(int64_t)3;
+  double *z = (double *)malloc(sizeof(double) * (size_t)L * (D + 1)); /* a strip's shifted rows, feature-major */
+  double *T = (double *)malloc(sizeof(double) * (size_t)(D + 1) * (D + 1)); /* the call's total */
+  double *Q = (double *)malloc(sizeof(double) * (size_t)(D + 1) * (D + 1)); /* the current group of 64 strips */
+  if (!z || !T || !Q) {
+    free(z);
+    free(T);
+    free(Q);
+    return fail(c, HAMSM_ENOMEM, "pca strip");
+  }
+  for (int64_t g = 0; g < G; g++) {
+    const int64_t f0 = g * L, fend = f0 + L < n ? f0 + L : n, m = fend > f0 ? fend - f0 : 0;
+    for (int a = 0; a <= D; a++)
+      for (int64_t f = 0; f < m; f++) z[(size_t)a * L + f] = a < D ? xval(X, dt, (f0 + f) * ldx + a) - c->pca_mu0[a] : 1.0;
+    for (int a = 0; a <= D; a++)
+      for (int b = a; b <= D; b++) {
+        double acc = 0.0;
+        const double *za = z + (size_t)a * L, *zb = z + (size_t)b * L;
+        for (int64_t f = 0; f < m; f++) acc = __builtin_fma(za[f], zb[f], acc);
+        double *q = &Q[(size_t)a * (D + 1) + b];
+        *q = g % 64 == 0 ? acc : *q + acc;
+      }
+    if (g % 64 == 63 || g == G - 1) /* the group is complete: its sum joins the call's total, groups in order */
+      for (int a = 0; a <= D; a++)
+        for (int b = a; b <= D; b++) {
+          double *t = &T[(size_t)a * (D + 1) + b];
+          *t = g < 64 ? Q[(size_t)a * (D + 1) + b] : *t + Q[(size_t)a * (D + 1) + b];
+        }
+  }
+  for (int a = 0; a <= D; a++)
+    for (int b = a; b <= D; b++) c->pca_S2[(size_t)a * Dp + b] = c->pca_S2[(size_t)a * Dp + b] + T[(size_t)a * (D + 1) + b];
+  free(z);
+  free(T);
+  free(Q);
+  c->pca_n += n;
+  return HAMSM_OK;
+}
+
+int hamsm_pca_finish(hamsm_ctx *c, int64_t *n_total, double *h_shift, double *h_S1, double *h_S2) {
+  CTX(c);
+  if (!c->pca_S2) return fail(c, HAMSM_EINVAL, "pca_finish before pca_begin");
+  const int D = c->pca_D, Dp = (D + 1 + 31) & ~31;
+  if (n_total) *n_total = c->pca_n;
+  for (int a = 0; a < D; a++) {
+    if (h_shift) h_shift[a] = c->pca_mu0[a];
+    if (h_S1) h_S1[a] = c->pca_S2[(size_t)a * Dp + D];
+    if (h_S2)
+      for (int b = 0; b < D; b++) h_S2[(size_t)a * D + b] = a <= b ? c->pca_S2[(size_t)a * Dp + b] : c->pca_S2[(size_t)b * Dp + a];
+  }
+  free(c->pca_S2);
+  free(c->pca_mu0);
+  c->pca_S2 = c->pca_mu0 = NULL;
+  c->pca_D = 0;
+  c->pca_n = 0;
   return HAMSM_OK;
 }
 
