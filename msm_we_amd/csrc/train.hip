@@ -2753,6 +2753,8 @@ static int run_steps(hamsm_ctx *c, const void *X, int dt, int64_t ldx, const int
                      int32_t **labels_of_first) {
   const size_t esz = dt == HAMSM_F32 ? 4 : 8;
   const bool generic = c->KS > 32;  // more than 128 features (k_step_*_generic)
+  timespec ts_in;
+  clock_gettime(CLOCK_MONOTONIC, &ts_in);
   int64_t lab_hi = 0, nb_max = 0;
   for (int64_t i = 0; i < n_steps; i++) {
     const hamsm_step &s = h_steps[i];
@@ -2966,8 +2968,9 @@ static int run_steps(hamsm_ctx *c, const void *X, int dt, int64_t ldx, const int
   }
   if (dbg_enq) {
     clock_gettime(CLOCK_MONOTONIC, &ts1);
-    fprintf(stderr, "[hamsm] enqueued %zu launch groups on %d queue(s) in %.3f ms\n", gstart.size() - 1, n_lanes,
-            (ts1.tv_sec - ts0.tv_sec) * 1e3 + (ts1.tv_nsec - ts0.tv_nsec) * 1e-6);
+    fprintf(stderr, "[hamsm] enqueued %zu launch groups on %d queue(s) in %.3f ms (%.3f ms of preparation before the first launch)\n",
+            gstart.size() - 1, n_lanes, (ts1.tv_sec - ts0.tv_sec) * 1e3 + (ts1.tv_nsec - ts0.tv_nsec) * 1e-6,
+            (ts0.tv_sec - ts_in.tv_sec) * 1e3 + (ts0.tv_nsec - ts_in.tv_nsec) * 1e-6);
   }
   for (int l = 1; l < n_lanes; l++) {
     HIPCHK(c, hipEventRecord(c->ev_join[l - 1], lanes[l]));
@@ -2988,6 +2991,12 @@ static int run_steps(hamsm_ctx *c, const void *X, int dt, int64_t ldx, const int
     hipError_t es = hipStreamSynchronize(c->stream);  // always: `sd` and `hw` are locals the copies above read / write
     if (e == hipSuccess) e = es;
     if (e != hipSuccess) return hamsm_fail(c, HAMSM_EDEVICE, "minibatch_run read-back: %s", hipGetErrorString(e));
+    if (getenv("HAMSM_DEBUG_ENQUEUE")) {
+      timespec ts_out;
+      clock_gettime(CLOCK_MONOTONIC, &ts_out);
+      fprintf(stderr, "[hamsm] run_steps: %.3f ms from entry to the results on the host\n",
+              (ts_out.tv_sec - ts_in.tv_sec) * 1e3 + (ts_out.tv_nsec - ts_in.tv_nsec) * 1e-6);
+    }
     if (h_resume && h_reason) {
       // stop word -> first step of the stratum that was not applied
       for (int s = 0; s < c->S; s++) {
