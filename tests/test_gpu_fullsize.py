@@ -336,3 +336,64 @@ def test_c5_shape_assign_million_rows_equals_oracle(c5_trained, hip_lib, monkeyp
         assert np.array_equal(lab, ref)
     finally:
         h.close()
+
+
+def test_wide_features_train_assign_flux_at_size(hip_lib, oracle_h):
+    """D = 816 (the notebooks' flattened distance matrix, no dimensionality reduction): 40 iterations x 4000 segments through the
+    generic kernels -- the oracle on a sample of both discretization passes, strata never mix, the counts add up, a second run
+    is bit-identical, the flux matrix equals np.add.at on the labels, planned == stepwise training."""
+    from msm_we_amd import _abi
+
+    cfg = synthetic.WEConfig("wide816", 9, 40, 4000, 816, 4, 100)
+    d = _shard(cfg, cfg.n_iters)
+    h = _abi.Hamsm(lib=hip_lib)
+    try:
+        m, store = _model(h, cfg, d)
+        bm = RectilinearBinMapper([synthetic.strata_boundaries(cfg.S)])
+        m.cluster_coordinates(cfg.K_s, streaming=True, use_ray=True, stratified=True, user_bin_mapper=bm, random_state=5)
+        assert m.n_clusters == 400
+        n = store.N
+        child = np.concatenate(m.dtrajs)
+        parent = np.concatenate([p[:, 0] for p in m.pair_dtrajs])
+        rng = np.random.default_rng(2)
+        _check_assign_sample(oracle_h, h, cfg, d["Xc"][:n], d["p1"][:n], child.astype(np.int32), rng, n_sample=1500)
+        _check_assign_sample(oracle_h, h, cfg, d["Xp"][:n], d["p0"][:n], parent.astype(np.int32), rng, n_sample=1500)
+        free = (d["p1"][:n, 0] >= 0.05) & (d["p1"][:n, 0] <= cfg.S - 0.05)
+        s_of = np.minimum(np.floor(d["p1"][:n, 0].astype(np.float32)), cfg.S - 1).astype(int)
+        assert np.array_equal(child[free] // cfg.K_s, s_of[free])
+        # (counts do not add up to the rows seen here: sparse clusters are re-seeded on the way, _kmeans.py:1643-1673)
+        assert all(cm.n_steps_ == cfg.n_iters for cm in m.clusters.cluster_models)
+        m.get_fluxMatrix(0, first_iter=1, last_iter=m.maxIter)
+        K = m.n_clusters
+        lo = cfg.segs_per_iter  # iterations 2 .. maxIter-1 (quirk Q6), overrides of _fluxmatrix.py:135-137
+        a, b = parent[lo:n].copy(), child[lo:n].copy()
+        b[d["p1"][lo:n, 0] > cfg.S - 0.05] = K + 1
+        a[d["p0"][lo:n, 0] < 0.05] = K
+        b[d["p1"][lo:n, 0] < 0.05] = K
+        F = np.zeros((K + 2) * (K + 2))
+        np.add.at(F, a * (K + 2) + b, d["w"][lo:n])
+        F = F.reshape(K + 2, K + 2) / (m.maxIter - 2)
+        np.testing.assert_allclose(m.fluxMatrixRaw, F, rtol=1e-11, atol=1e-18)
+        cents = [cm.cluster_centers_.copy() for cm in m.clusters.cluster_models]
+        for planned in (True, False):
+            m2, _ = _model(h, cfg, d)
+            m2._store = store
+            m2.speculative_training = planned
+            m2.cluster_coordinates(cfg.K_s, streaming=True, use_ray=True, stratified=True, user_bin_mapper=bm, random_state=5)
+            assert m2.training_path == ("planned" if planned else "stepwise") or planned
+            for a, b in zip(cents, m2.clusters.cluster_models):
+                assert np.array_equal(a, b.cluster_centers_)
+            assert np.array_equal(np.concatenate(m2.dtrajs), child)
+        # the first 6 iterations through the oracle as well: centroids, counts and labels bit for bit
+        d6 = {k: (v[: 6 * cfg.segs_per_iter] if k != "offsets" else v[:7]) for k, v in d.items()}
+        res = []
+        for hh in (oracle_h, h):
+            m6, _ = _model(hh, cfg, d6)
+            m6.cluster_coordinates(cfg.K_s, streaming=True, use_ray=True, stratified=True, user_bin_mapper=bm, random_state=5)
+            res.append(([cm.cluster_centers_.copy() for cm in m6.clusters.cluster_models], [cm._counts.copy() for cm in m6.clusters.cluster_models],
+                        np.concatenate(m6.dtrajs)))
+        for x, y in zip(res[0][0] + res[0][1], res[1][0] + res[1][1]):
+            assert np.array_equal(x, y)
+        assert np.array_equal(res[0][2], res[1][2])
+    finally:
+        h.close()
