@@ -476,7 +476,10 @@ __global__ __launch_bounds__(256) void k_assign_generic(SortArgs g, int KS) {
 //     E = 2^-22 ((2 D + 8) ||x|| max_j ||c_j|| + (D + 5) max_j |csq_j|)
 // bounds: rounding the centroids, csq (and f64 frames) to f32; the D + 2 roundings of the accumulation under the
 // standard model, with unit roundoff 2^-22 instead of 2^-24 so that truncating or reordered accumulation inside the
-// matrix unit is covered; and the (2^-53-scale) rounding of the f64 chain itself.  If the two distances differ by more
+// matrix unit is covered; and the (2^-53-scale) rounding of the f64 chain itself.  (The ranked values additionally carry their
+// accumulator register's number in their 4 low mantissa bits -- the maximum then knows its own index, 3 ranking instructions
+// per value instead of 4 --: s moves by < 16 ulp <= 2^-19 |s|, i.e. E grows by 2^-22 (16 ||x|| max ||c|| + 8 max |csq|); the
+// launch constants c1 / c2 include it.)  If the two distances differ by more
 // than 2 E (x 1.01), the f64 argmin is that centroid, ties included, and the label is final.  Otherwise -- near ties,
 // NaN / inf anywhere, overflow of the f32 range -- the frame goes to a list and the exact f64 kernel decides, as
 // before.  Labels are bit-identical to the exact kernel's by construction; the tests compare both with the oracle.
@@ -494,7 +497,7 @@ struct FiltArgs {
   const unsigned *bnd;      // [S][2] bit patterns of upper bounds of max ||c||^2 and max |csq| (f32)
   int32_t *perm2;           // [n] undecided frames; stratum s fills from base[s]
   unsigned long long *cnt2; // [S]
-  float c1, c2;             // 2.02 * 2^-22 * (2 D + 8), 2.02 * 2^-22 * (D + 5)
+  float c1, c2;             // 2.02 * 2^-22 * (2 D + 24), 2.02 * 2^-22 * (D + 13)  (f32 form; the index bits included)
   int DS;                   // row stride of the staged frames in floats (>= D, == 2 mod 4: conflict-free operand reads)
   int G;                    // centroid tiles per LDS group
   unsigned magic;           // 2^24 / d + 1, d = loads per staged row: division by multiplication
@@ -516,7 +519,9 @@ __global__ __launch_bounds__(64) void k_pack_f32(const StratumDev *__restrict__ 
     double v = 0.0;
     if (live && k < D) v = sd.Bpack[((size_t)(j >> 4) * KS + (k >> 2)) * 64 + (k & 3) * 16 + (j & 15)];
     n2 += v * v;
-    if (k == D) v = -0.5 * cs;  // (-inf past K: such a row never ranks first)
+    // (past K: a finite -3e38, which never ranks first.  Not -inf: the ranked values carry index bits in their low mantissa
+    // bits, which would turn an infinity into a signalling NaN, and v_med3_f32 does not keep a runner-up through NaNs)
+    if (k == D) v = live ? -0.5 * cs : -3.0e38;
     A[((size_t)jt * KH + ks) * 64 + lane] = (float)v;
   }
   n2 += __shfl_xor(n2, 32, 64);
@@ -807,9 +812,11 @@ __global__ __launch_bounds__(FILT_NW(KS) * 64) __attribute__((amdgpu_waves_per_e
     auto rank = [&](const v16f32 &acc, int tile) {
       const float before = M1;
 #pragma unroll
-      for (int r = 0; r < 16; r++) {  // ascending centroid index: strict > keeps the lowest
-        const float v = acc[r];
-        Jr = v > M1 ? r : Jr;
+      for (int r = 0; r < 16; r++) {
+        // the accumulator register's number rides in the 4 low mantissa bits of the value (one v_and_or_b32): the maximum then
+        // carries its own index and the ranking is 3 instructions per value instead of 4.  The values move by < 16 ulp
+        // (counted in the bound: c1 / c2 below); +-inf turns into NaN and the frame goes to the exact kernel, like every NaN
+        const float v = __uint_as_float((__float_as_uint(acc[r]) & 0xfffffff0u) | (unsigned)r);
         M2 = __builtin_amdgcn_fmed3f(M1, M2, v);
         M1 = __builtin_amdgcn_fmed3f(M1, v, pinf);  // max(M1, v)
       }
@@ -839,12 +846,15 @@ __global__ __launch_bounds__(FILT_NW(KS) * 64) __attribute__((amdgpu_waves_per_e
     APROF(2)
     if (!live) continue;
     // -> centroid index; then lanes l and l ^ 32 (same frame, the other half of each tile's centroids) are merged
+    Jr = (int)(__float_as_uint(M1) & 15u);
     int j = Jt * 32 + 8 * (Jr >> 2) + 4 * (lane >> 5) + (Jr & 3);
     {
       const float M1o = __shfl_xor(M1, 32, 64), M2o = __shfl_xor(M2, 32, 64);
       const int jo = __shfl_xor(j, 32, 64);
       const bool take = (M1o > M1) || (M1o == M1 && jo < j);
+      const bool poisoned = M2 != M2 || M2o != M2o;  // (fmax drops a NaN: a runner-up that is not a number must stay one)
       M2 = take ? __builtin_fmaxf(M2o, M1) : __builtin_fmaxf(M2, M1o);
+      M2 = poisoned ? __builtin_nanf("") : M2;
       j = take ? jo : j;
       M1 = take ? M1o : M1;
     }
@@ -1002,11 +1012,13 @@ static int launch_sorted(hamsm_ctx *c, const AssignArgs &a) {
     if (bf) {  // per 16 slots: 6 MFMAs x (16 products + 1 accumulate) roundings, taken FOUR times (unit roundoff 2^-22 as in the
                // f32 form: truncating or reordered accumulation inside the matrix unit is covered); + the dropped terms (16 u)
                // + rounding of c and of f64 frames to f32 (1 u each)
-      f.c1 = 4.04f * (float)(18 + 408 * KB) / 16777216.0f;
-      f.c2 = 2.02f * (float)(408 * KB + 1) / 16777216.0f;
+               // + the index bits in the ranked values (s moves by < 16 ulp <= 2^-19 |s|, |s| <= ||x|| ||c|| + |csq| / 2; E bounds
+               // d = -2 s: 64 u ||x|| ||c|| + 32 u |csq|)
+      f.c1 = 4.04f * (float)(50 + 408 * KB) / 16777216.0f;
+      f.c2 = 2.02f * (float)(408 * KB + 33) / 16777216.0f;
     } else {
-      f.c1 = 2.02f * (float)(2 * a.D + 8) / 4194304.0f;
-      f.c2 = 2.02f * (float)(a.D + 5) / 4194304.0f;
+      f.c1 = 2.02f * (float)(2 * a.D + 24) / 4194304.0f;   // (+ 16 and + 8 units of 2^-22 for the index bits: E bounds d = -2 s)
+      f.c2 = 2.02f * (float)(a.D + 13) / 4194304.0f;
     }
     c->filter_cnt2 = f.cnt2;
     if (tmax > 0 && bf)
