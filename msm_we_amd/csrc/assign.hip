@@ -646,7 +646,7 @@ __global__ __launch_bounds__(FILT_NW(KS) * 64) __attribute__((amdgpu_waves_per_e
   const float thr_0 = f.c2 * __uint_as_float(f.bnd[2 * s + 1]) + 1e-30f;
   const int nfw = (int)((pend - p0) < g.FRB ? (pend - p0) : g.FRB);  // frames of this workgroup
   const int NB = g.FRB / (32 * NW);                                   // tiles per wave
-  const float ninf = -__builtin_huge_valf(), pinf = __builtin_huge_valf();
+  const float ninf = -__builtin_huge_valf();
   // frame indices of a tile: lane l < 32 holds row l (clamped inside the workgroup's range: such rows are never stored)
   auto load_fidx = [&](int ti) {
     const int i = ti * 32 + (lane & 31);
@@ -817,8 +817,13 @@ __global__ __launch_bounds__(FILT_NW(KS) * 64) __attribute__((amdgpu_waves_per_e
         // carries its own index and the ranking is 3 instructions per value instead of 4.  The values move by < 16 ulp
         // (counted in the bound: c1 / c2 below); +-inf turns into NaN and the frame goes to the exact kernel, like every NaN
         const float v = __uint_as_float((__float_as_uint(acc[r]) & 0xfffffff0u) | (unsigned)r);
-        M2 = __builtin_amdgcn_fmed3f(M1, M2, v);
-        M1 = __builtin_amdgcn_fmed3f(M1, v, pinf);  // max(M1, v)
+        // (written as instructions: through the builtins the compiler canonicalises v first -- it comes from integer
+        // instructions and could be a signalling NaN -- which costs a fourth instruction per value)
+        float m2n, m1n;
+        asm("v_med3_f32 %0, %1, %2, %3" : "=v"(m2n) : "v"(M1), "v"(M2), "v"(v));
+        asm("v_max_f32 %0, %1, %2" : "=v"(m1n) : "v"(M1), "v"(v));
+        M2 = m2n;
+        M1 = m1n;
       }
       Jt = M1 > before ? tile : Jt;
     };
