@@ -628,18 +628,31 @@ def main():
     tflops = flops / (assign_avg_ms * 1e-3) / 1e12
     K = cfg.K_s * cfg.S
     extra = {}
-    if os.environ.get("HAMSM_ASSIGN_FILTER", "1") != "0" and os.environ.get("HAMSM_FILTER_BF16", "1") != "0" and cfg.D <= 32:
-        # every f32 product is formed as 6 bf16 products (3 x 3 pieces, the 3 smallest dropped): the roof of an algorithmic
-        # flop on this path is the bf16 MFMA peak / 6
-        peak = PEAK_BF16_MFMA_TFLOPS / 6.0
+    # which form of the ranking pass the last assign ran (library hook; the CPU rehearsal has none): 2 = bf16 x 3 with 6 piece
+    # products, 3 = the light bf16 form with 3
+    form = None
+    if hasattr(h.lib, "hamsm_debug_filter_form"):
+        try:
+            h.lib.hamsm_debug_filter_form.restype = ctypes.c_int
+            h.lib.hamsm_debug_filter_form.argtypes = [ctypes.c_void_p]
+            form = int(h.lib.hamsm_debug_filter_form(h.ctx))
+        except (AttributeError, OSError):
+            form = None
+    if form in (2, 3) or (form is None and os.environ.get("HAMSM_ASSIGN_FILTER", "1") != "0"
+                          and os.environ.get("HAMSM_FILTER_BF16", "1") != "0" and cfg.D <= 32):
+        # every f32 product is formed from bf16 piece products (operands = exact sums of three bf16 pieces): 6 of the 9 in the full
+        # form, 3 in the light form that goes first (wider bound, more frames left to the exact kernel): the roof of an algorithmic
+        # flop on this path is the bf16 MFMA peak / products
+        products = 3.0 if form == 3 else 6.0
+        peak = PEAK_BF16_MFMA_TFLOPS / products
         blocks = (cfg.D + 16) // 16
-        executed = flops * (6.0 * 16 * blocks / cfg.D) * (((cfg.K_s + 31) // 32) * 32 / cfg.K_s)
+        executed = flops * (products * 16 * blocks / cfg.D) * (((cfg.K_s + 31) // 32) * 32 / cfg.K_s)
         extra = {"bf16_mfma_peak": PEAK_BF16_MFMA_TFLOPS, "executed_bf16_TFLOPs": executed / (assign_avg_ms * 1e-3) / 1e12,
-                 "frac_of_f32_mfma_peak": tflops / PEAK_F32_MFMA_TFLOPS}
-        kernel = ("k_assign_filter (v_mfma_f32_32x32x16_bf16, f32 operands as three exact bf16 pieces) + k_assign_sorted "
-                  "(v_mfma_f64_16x16x4_f64) on the undecided frames")
-        arithmetic = ("centroids ranked on the bf16 matrix unit with f32-equivalent accuracy; a label is final only if the gap "
-                      "exceeds a proven bound on the difference to the f64 contract, otherwise the exact f64 kernel decides: "
+                 "frac_of_f32_mfma_peak": tflops / PEAK_F32_MFMA_TFLOPS, "bf16_products_per_f32_product": products}
+        kernel = (f"k_assign_filter (v_mfma_f32_32x32x16_bf16, f32 operands as three exact bf16 pieces, {int(products)} piece products) "
+                  "+ k_assign_sorted (v_mfma_f64_16x16x4_f64) on the undecided frames")
+        arithmetic = ("centroids ranked on the bf16 matrix unit; a label is final only if the gap exceeds a proven bound on the "
+                      "difference to the f64 contract (dropped piece products included), otherwise the exact f64 kernel decides: "
                       "labels identical to the f64 contract")
     elif os.environ.get("HAMSM_ASSIGN_FILTER", "1") != "0":
         peak = PEAK_F32_MFMA_TFLOPS

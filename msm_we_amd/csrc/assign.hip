@@ -501,6 +501,7 @@ struct FiltArgs {
   int DS;                   // row stride of the staged frames in floats (>= D, == 2 mod 4: conflict-free operand reads)
   int G;                    // centroid tiles per LDS group
   unsigned magic;           // 2^24 / d + 1, d = loads per staged row: division by multiplication
+  int lite;                 // bf16 form: only the products x1c1, x1c2, x2c1 (the bound c1 / c2 is the wider one)
 };
 
 __global__ __launch_bounds__(64) void k_pack_f32(const StratumDev *__restrict__ table, const FiltDev *__restrict__ ft,
@@ -620,6 +621,7 @@ __global__ __launch_bounds__(FILT_NW(KS) * 64) __attribute__((amdgpu_waves_per_e
   typedef const v4f32 __attribute__((address_space(1))) *gv4p;
   typedef XT xt2 __attribute__((ext_vector_type(2)));
   const int DS = f.DS, D = g.D, G = f.G;
+  const bool lite = BF && f.lite != 0;
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   // which stratum?  one vector load of the block offsets (a scalar walk is a chain of dependent global loads)
   int s = 0;
@@ -796,9 +798,11 @@ __global__ __launch_bounds__(FILT_NW(KS) * 64) __attribute__((amdgpu_waves_per_e
                        c3 = __builtin_bit_cast(v8bf16, aq[(m * 3 + 2) * 64]);
           const v8bf16 x1 = __builtin_bit_cast(v8bf16, bp[m][0]), x2 = __builtin_bit_cast(v8bf16, bp[m][1]),
                        x3 = __builtin_bit_cast(v8bf16, bp[m][2]);
-          acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(c1, x3, acc, 0, 0, 0);
-          acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(c2, x2, acc, 0, 0, 0);
-          acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(c3, x1, acc, 0, 0, 0);
+          if (!lite) {  // (wave-uniform) the 2^-14-level terms
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(c1, x3, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(c2, x2, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(c3, x1, acc, 0, 0, 0);
+          }
           acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(c1, x2, acc, 0, 0, 0);
           acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(c2, x1, acc, 0, 0, 0);
           acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(c1, x1, acc, 0, 0, 0);
@@ -936,6 +940,7 @@ static int launch_sorted(hamsm_ctx *c, const AssignArgs &a) {
   const bool generic = KS > 32;  // more than 128 features: k_assign_generic, no ranking pass
   const bool filt = !generic && c->assign_filter != 0 && !(c->filter_skip > 0 && c->filter_skip--);
   c->filter_ran = 0;
+  c->filter_form = 0;
   size_t off = 0;
   auto take = [&](size_t bytes) {
     size_t o = off;
@@ -1014,6 +1019,18 @@ static int launch_sorted(hamsm_ctx *c, const AssignArgs &a) {
     f.bnd = (const unsigned *)(b + o_zero + sizeof(long long) * S);
     f.perm2 = (int32_t *)(b + o_perm2);
     f.magic = (1u << 24) / (unsigned)(((a.D & 1) == 0 && (a.ldx & 1) == 0 && ((uintptr_t)a.X & (2 * sizeof(XT) - 1)) == 0) ? a.D / 2 : a.D) + 1;
+    // the lighter bf16 form first (3 of the 6 products) unless it stepped aside (it settled < 31/32 of the frames of a recent call)
+    const bool lite = bf && (c->filter_lite == 2 || (c->filter_lite == 1 && !(c->filter_lite_skip > 0 && c->filter_lite_skip--)));
+    f.lite = lite ? 1 : 0;
+    c->filter_form = bf ? (lite ? 3 : 2) : 1;
+    if (lite) {
+      // 3 MFMAs x 17 roundings per 16 slots, taken four times (204 KB); dropped: x1c3, x2c2, x3c1 (each < 2^-14 |x_k||c_k|: pieces
+      // are truncations to 8 significant bits) and the three smaller ones (< 2^-20 together): s off by < 3.02 x 2^-14 ||x|| ||c||,
+      // d = -2 s by twice that = 6186 u (u = 2^-24); the csq slot (frame side exactly 1) loses c3: < 2^-14 |csq| / 2 in s = 1024 u |csq|
+      // in d; + rounding of c and of f64 frames to f32 (2 u), + the index bits (64 u, 32 u)
+      f.c1 = 2.02f * (float)(6186 + 2 * (2 + 204 * KB) + 64) / 16777216.0f;
+      f.c2 = 2.02f * (float)(1024 + 204 * KB + 1 + 32) / 16777216.0f;
+    } else
     if (bf) {  // per 16 slots: 6 MFMAs x (16 products + 1 accumulate) roundings, taken FOUR times (unit roundoff 2^-22 as in the
                // f32 form: truncating or reordered accumulation inside the matrix unit is covered); + the dropped terms (16 u)
                // + rounding of c and of f64 frames to f32 (1 u each)
@@ -1066,6 +1083,13 @@ static int launch_sorted(hamsm_ctx *c, const AssignArgs &a) {
   return hamsm_fail(c, HAMSM_ENOTSUP, "KS=%d", KS);
 }
 
+// Not part of the product ABI (test / bench hook): the form of the ranking pass the last hamsm_assign ran
+// (0 exact kernel only, 1 f32, 2 bf16 x 3 with 6 products, 3 bf16 with 3 products).
+extern "C" int hamsm_debug_filter_form(hamsm_ctx *c) {
+  CTX(c);
+  return c->filter_form;
+}
+
 // Not part of the product ABI (test hook): frames the last filtered hamsm_assign handed to the exact kernel.
 extern "C" long long hamsm_debug_filter_undecided(hamsm_ctx *c) {
   CTX(c);
@@ -1098,7 +1122,10 @@ extern "C" int hamsm_assign(hamsm_ctx *c, const void *X, int dt, int64_t ldx, co
   if (c->filter_ran) {
     unsigned long long und = 0;
     for (int s = 0; s < c->S; s++) und += c->h_und[s];
-    if (n >= 4096 && und * 4 > (unsigned long long)n) c->filter_skip = 7;
+    if (c->filter_form == 3) {
+      // the light form left more than 1/32 of the frames to the exact kernel: the full form for the next calls
+      if (n >= 4096 && und * 32 > (unsigned long long)n) c->filter_lite_skip = 7;
+    } else if (n >= 4096 && und * 4 > (unsigned long long)n) c->filter_skip = 7;
   }
   return rc;
 }

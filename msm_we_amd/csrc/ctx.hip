@@ -63,6 +63,7 @@ extern "C" int hamsm_create(int device, hamsm_ctx **out) {
   if (const char *v = getenv("HAMSM_FILTER_BF16")) c->filter_bf16 = atoi(v) != 0;
   if (const char *v = getenv("HAMSM_FLUX_XCD")) c->flux_xcd = atoi(v) != 0;
   if (const char *v = getenv("HAMSM_ASSIGN_FILTER")) c->assign_filter = atoi(v) != 0;
+  if (const char *v = getenv("HAMSM_FILTER_LITE")) c->filter_lite = atoi(v) < 0 ? 0 : (atoi(v) > 2 ? 2 : atoi(v));
   if (const char *v = getenv("HAMSM_FILTER_NB")) c->filter_nb = atoi(v) < 1 ? 1 : (atoi(v) > 16 ? 16 : atoi(v));
   if (const char *v = getenv("HAMSM_FILTER_LDS_KB")) c->filter_lds_kb = atoi(v) < 40 ? 40 : (atoi(v) > 150 ? 150 : atoi(v));
   if (const char *v = getenv("HAMSM_TRAIN_PERSIST")) c->train_persist = atoi(v) != 0;
@@ -459,6 +460,7 @@ extern "C" int hamsm_set_geometry(hamsm_ctx *c, int D, int ndim, int S) {
   HIPCHK(c, hipSetDevice(c->device));
   HIPCHK(c, hipStreamSynchronize(c->stream));
   c->filter_skip = 0;  // a new model: the ranking pass gets its chance again
+  c->filter_lite_skip = 0;
   c->filter_cnt2 = nullptr;
   if (S != c->S) {
     hipHostFree(c->h_und);

@@ -236,7 +236,72 @@ def test_assign_filter_steps_aside_on_data_full_of_ties(hip_h, oracle_h):
     for a, b in zip(outs[0][0], outs[1][0]):
         assert np.array_equal(a, b)
     und = outs[1][1]
-    assert und[0] > n // 2 and und[1:8] == [-1] * 7 and und[8] == und[0] and und[9] == -1, und
+    # (D <= 32: the light bf16 form goes first, then the full one, then the exact kernel alone for 7 calls)
+    assert und[0] > n // 2 and und[1] == und[0] and und[2:9] == [-1] * 7 and und[9] == und[0], und
+
+
+def _filter_form(h):
+    fn = h.lib.hamsm_debug_filter_form
+    fn.restype = ctypes.c_int
+    fn.argtypes = [ctypes.c_void_p]
+    return fn(h.ctx)
+
+
+@pytest.mark.parametrize("lite,form", [("0", 2), ("2", 3)])
+def test_assign_bf16_forms_of_the_ranking_pass(hip_lib, oracle_h, monkeypatch, lite, form):
+    """HAMSM_FILTER_LITE=2 / 0: the bf16 ranking pass with 3 of the 6 piece products (wider bound) / with all 6, forced; the
+    labels are the oracle's either way, on separated data (almost) everything is certified, on engineered near ties nothing is"""
+    from msm_we_amd import _abi
+
+    monkeypatch.setenv("HAMSM_FILTER_LITE", lite)
+    h = _abi.Hamsm(lib=hip_lib, device=0)
+    try:
+        for D, K_s, dtype in ((30, 250, np.float32), (32, 33, np.float64), (5, 7, np.float32), (17, 100, np.float32)):
+            labs = []
+            for hh in (oracle_h, h):
+                rng = np.random.default_rng(4)
+                cents = _setup(hh, D, 3, K_s, rng)
+                X, p = _frames(rng, 6000, D, 3, dtype)
+                for i in range(0, 2000):   # on / next to bisectors of two centroids
+                    c = cents[min(int(p[i, 0]), 2)]
+                    a, b = rng.integers(0, len(c), 2)
+                    X[i] = (0.5 * (c[a] + c[b]) + (rng.integers(-2, 3) * 1e-7) * (c[a] - c[b])).astype(dtype)
+                X[2000, 0] = np.nan
+                X[2001] *= dtype(1e18)
+                labs.append(hh.predict_host(X, p))
+            assert np.array_equal(labs[0], labs[1])
+            assert _filter_form(h) == form
+            assert 1000 <= _undecided(h) < 2600
+    finally:
+        h.close()
+
+
+def test_light_ranking_form_steps_aside_for_the_full_one(hip_h, oracle_h):
+    """frames whose two nearest centroids differ by more than the full bf16 x 3 bound but less than the light form's: the light
+    form leaves them to the exact kernel, more than 1/32 of the call -> the next 7 calls run the full form, which certifies them"""
+    D, K_s, n = 12, 40, 6000
+    outs = []
+    for h in (oracle_h, hip_h):
+        rng = np.random.default_rng(35)
+        cents = _setup(h, D, 1, K_s, rng)[0]
+        X, p = _frames(rng, n, D, 1, np.float32)
+        p[:] = 0.5
+        for i in range(0, n, 2):
+            a, b = rng.choice(K_s, 2, replace=False)
+            v = cents[a] - cents[b]
+            X[i] = (0.5 * (cents[a] + cents[b]) + 0.04 / (2 * (v @ v)) * v).astype(np.float32)   # distance gap 0.04
+        labs, forms, und = [], [], []
+        for _ in range(9):
+            labs.append(h.predict_host(X, p))
+            if h is hip_h:
+                forms.append(_filter_form(h))
+                und.append(_undecided(h))
+        outs.append((labs, forms, und))
+    for a, b in zip(outs[0][0], outs[1][0]):
+        assert np.array_equal(a, b)
+    forms, und = outs[1][1:]
+    assert forms == [3] + [2] * 7 + [3], forms
+    assert und[0] > n // 4 and max(und[1:8]) < n // 8 and und[8] == und[0], und
 
 
 def test_assign_f32_form_of_the_ranking_pass(hip_lib, oracle_h, monkeypatch):
