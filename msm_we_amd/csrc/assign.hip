@@ -952,7 +952,13 @@ static int launch_sorted(hamsm_ctx *c, const AssignArgs &a) {
   // filter: f32 fragments of the centroids, undecided-frame lists and the second set of block offsets
   size_t o_perm2 = 0, o_zero = 0, o_end2 = 0, o_blk2 = 0, o_ft = 0, o_A = 0;
   const int KH = a.D == 4 * KS ? 2 * KS + 1 : 2 * KS;  // feature slots of the f32 fragments, in pairs: the features, the csq slot, padding
-  const bool bf = c->filter_bf16 != 0 && KS <= 8;        // bf16 x 3 form of the ranking pass (D <= 32; measured slower at D = 64, K_s = 1250)
+  // bf16 forms of the ranking pass: D <= 32 both (full: f32-equivalent; light: 3 of 6 piece products, goes first unless it stepped
+  // aside); 32 < D <= 64 only the light one (measured at D = 64, K_s = 1250, fragments swept through LDS in groups: f32 form
+  // 29.2 ms per 2 x 10 M rows, full bf16 31.6, light bf16 26.8) -- when that steps aside there, the f32 form takes over.
+  // HAMSM_FILTER_BF16=2 allows the full bf16 form up to D = 64 as well (experiments).
+  const bool lite_ok = filt && c->filter_bf16 != 0 && KS <= 16 &&
+                       (c->filter_lite == 2 || (c->filter_lite == 1 && !(c->filter_lite_skip > 0 && c->filter_lite_skip--)));
+  const bool bf = c->filter_bf16 != 0 && (KS <= 8 || (KS <= 16 && (lite_ok || c->filter_bf16 == 2)));        // bf16 x 3 form of the ranking pass (D <= 32; measured slower at D = 64, K_s = 1250)
   const int KBmin = (4 * KS + 13) / 16, KB = (a.D + 16) / 16;  // bf16 form: blocks of 16 slots
   const int aug = bf ? KB - KBmin : KH - 2 * KS;
   const int TW = bf ? KB * 3 * 256 : KH * 64;            // 32-bit words of fragments per centroid tile
@@ -1020,7 +1026,7 @@ static int launch_sorted(hamsm_ctx *c, const AssignArgs &a) {
     f.perm2 = (int32_t *)(b + o_perm2);
     f.magic = (1u << 24) / (unsigned)(((a.D & 1) == 0 && (a.ldx & 1) == 0 && ((uintptr_t)a.X & (2 * sizeof(XT) - 1)) == 0) ? a.D / 2 : a.D) + 1;
     // the lighter bf16 form first (3 of the 6 products) unless it stepped aside (it settled < 31/32 of the frames of a recent call)
-    const bool lite = bf && (c->filter_lite == 2 || (c->filter_lite == 1 && !(c->filter_lite_skip > 0 && c->filter_lite_skip--)));
+    const bool lite = bf && lite_ok;
     f.lite = lite ? 1 : 0;
     c->filter_form = bf ? (lite ? 3 : 2) : 1;
     if (lite) {

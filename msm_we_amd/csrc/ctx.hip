@@ -60,7 +60,7 @@ extern "C" int hamsm_create(int device, hamsm_ctx **out) {
   memset(&c->mapper, 0, sizeof c->mapper);
   if (const char *v = getenv("HAMSM_ASSIGN_W")) c->assign_waves = atoi(v) == 8 ? 8 : 4;
   if (const char *v = getenv("HAMSM_SEED_G_MB")) c->seed_g_budget = (size_t)(atoi(v) < 1 ? 1 : atoi(v)) << 20;
-  if (const char *v = getenv("HAMSM_FILTER_BF16")) c->filter_bf16 = atoi(v) != 0;
+  if (const char *v = getenv("HAMSM_FILTER_BF16")) c->filter_bf16 = atoi(v) < 0 ? 0 : (atoi(v) > 2 ? 2 : atoi(v));
   if (const char *v = getenv("HAMSM_FLUX_XCD")) c->flux_xcd = atoi(v) != 0;
   if (const char *v = getenv("HAMSM_ASSIGN_FILTER")) c->assign_filter = atoi(v) != 0;
   if (const char *v = getenv("HAMSM_FILTER_LITE")) c->filter_lite = atoi(v) < 0 ? 0 : (atoi(v) > 2 ? 2 : atoi(v));

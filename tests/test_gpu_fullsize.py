@@ -300,15 +300,18 @@ def test_c5_shape_training_equals_oracle(c5_trained):
                          np.concatenate([p[:, 0] for p in a.pair_dtrajs]).astype(np.int32), rng, 3000)
 
 
-@pytest.mark.parametrize("variant", ["default", "small_lds_groups", "large_lds_groups", "exact_only"])
+@pytest.mark.parametrize("variant", ["default", "small_lds_groups", "large_lds_groups", "bf16_full_form", "exact_only"])
 def test_c5_shape_assign_million_rows_equals_oracle(c5_trained, hip_lib, monkeypatch, variant):
-    """hamsm_assign over 1.2 M rows at D = 64, 4 x 1250: the f32 form of the ranking pass (the bf16 x 3 form exists for D <= 32
-    only) with the centroid fragments swept through the LDS in groups -- default budget, 40 KB groups, 150 KB groups -- and the
-    exact f64 kernel alone: all labels equal each other's, and the oracle's on 4000 random rows"""
+    """hamsm_assign over 1.2 M rows at D = 64, 4 x 1250, the centroid fragments swept through the LDS in groups: the light bf16 form
+    (default at this width), the f32 form with 40 KB and 150 KB groups, the full bf16 x 3 form, and the exact f64 kernel alone:
+    all labels equal each other's, and the oracle's on 4000 random rows"""
     from msm_we_amd import _abi
 
     cfg, d_small, hs, res, bm = c5_trained
-    env = {"default": {}, "small_lds_groups": {"HAMSM_FILTER_LDS_KB": "40"}, "large_lds_groups": {"HAMSM_FILTER_LDS_KB": "150"},
+    env = {"default": {},   # (the light bf16 form, fragments swept through LDS in groups)
+           "small_lds_groups": {"HAMSM_FILTER_LDS_KB": "40", "HAMSM_FILTER_BF16": "0"},    # f32 form
+           "large_lds_groups": {"HAMSM_FILTER_LDS_KB": "150", "HAMSM_FILTER_BF16": "0"},   # f32 form
+           "bf16_full_form": {"HAMSM_FILTER_BF16": "2", "HAMSM_FILTER_LITE": "0"},
            "exact_only": {"HAMSM_ASSIGN_FILTER": "0"}}[variant]
     for k, v in env.items():
         monkeypatch.setenv(k, v)
