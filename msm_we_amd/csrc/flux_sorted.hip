@@ -25,6 +25,22 @@ struct FluxArgs {
 __global__ void k_flux_keys(MapperDev m, FluxArgs g, const int64_t *__restrict__ offs, int64_t n_iters,
                             unsigned long long *keys, double *vals) {
   int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  // iteration of the workgroup's first segment by bisection, once; its other segments walk forward from there (an iteration
+  // holds thousands of segments: at most a step or two) instead of 256 bisections of ~10 dependent loads each
+  __shared__ long long s_it0;
+  if (threadIdx.x == 0) {
+    const int64_t i0 = g.i0 + (int64_t)blockIdx.x * blockDim.x;
+    int64_t lo = 0, hi = n_iters;
+    if (offs) {
+      while (hi - lo > 1) {
+        int64_t mid = (lo + hi) >> 1;
+        if (offs[mid] <= i0) lo = mid;
+        else hi = mid;
+      }
+    }
+    s_it0 = lo;
+  }
+  __syncthreads();
   if (j >= g.n) return;
   int64_t i = g.i0 + j;
   double q0[HAMSM_MAX_NDIM], q1[HAMSM_MAX_NDIM];
@@ -47,14 +63,9 @@ __global__ void k_flux_keys(MapperDev m, FluxArgs g, const int64_t *__restrict__
     vals[j] = g.w[i];
   }
   // iteration of segment i: last t with offs[t] <= i
-  int64_t lo = 0, hi = n_iters;
-  if (offs) {
-    while (hi - lo > 1) {
-      int64_t mid = (lo + hi) >> 1;
-      if (offs[mid] <= i) lo = mid;
-      else hi = mid;
-    }
-  }
+  int64_t lo = s_it0;
+  if (offs)
+    while (lo + 1 < n_iters && offs[lo + 1] <= i) lo++;
   keys[j] = cell * (unsigned long long)n_iters + (unsigned long long)lo;
 }
 
