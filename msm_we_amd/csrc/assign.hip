@@ -502,6 +502,8 @@ struct FiltArgs {
   int G;                    // centroid tiles per LDS group
   unsigned magic;           // 2^24 / d + 1, d = loads per staged row: division by multiplication
   int lite;                 // bf16 form: only the products x1c1, x1c2, x2c1 (the bound c1 / c2 is the wider one)
+  int dbuf;                 // bf16 form, fragments in groups: two LDS buffers of G tiles each, filled by global_load_lds while the
+                            // other one is swept; the light form then keeps 2 of the 3 pieces in LDS
 };
 
 __global__ __launch_bounds__(64) void k_pack_f32(const StratumDev *__restrict__ table, const FiltDev *__restrict__ ft,
@@ -622,6 +624,9 @@ __global__ __launch_bounds__(FILT_NW(KS) * 64) __attribute__((amdgpu_waves_per_e
   typedef XT xt2 __attribute__((ext_vector_type(2)));
   const int DS = f.DS, D = g.D, G = f.G;
   const bool lite = BF && f.lite != 0;
+  const bool dbuf = BF && f.dbuf != 0;
+  const int NP = dbuf && lite ? 2 : 3;           // bf16 form: pieces per 16-slot block held in LDS
+  const int TWr = BF ? KB * NP * 256 : TW;       // words of fragments per centroid tile in LDS
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   // which stratum?  one vector load of the block offsets (a scalar walk is a chain of dependent global loads)
   int s = 0;
@@ -654,12 +659,30 @@ __global__ __launch_bounds__(FILT_NW(KS) * 64) __attribute__((amdgpu_waves_per_e
     const int i = ti * 32 + (lane & 31);
     return g.perm[p0 + (i < nfw ? i : nfw - 1)];
   };
-  if (oneg) {
+  // bf16 form with the fragments in groups: a group = G tiles of KB x NP chunks of 1 KB (one (tile, block, piece): 64 lanes x 16 B,
+  // exactly what one global_load_lds_dwordx4 of a wave writes, lane-linear); wave w issues the chunks w, w + NW, ...
+  typedef float __attribute__((address_space(3))) *lfp;
+  auto glds_group = [&](int g0, int buf) {
+    const int gcn = (njt - g0) < G ? (njt - g0) : G, nch = gcn * KB * NP;
+    for (int ch = wv; ch < nch; ch += NW) {
+      const int t = ch / (KB * NP), r = ch - t * (KB * NP), m = r / NP, q = r - m * NP;
+      const gcfp srcA = Ag + ((size_t)((g0 + t) * KB + m) * 3 + q) * 256 + lane * 4;
+      float *dst = As + (size_t)buf * G * TWr + (size_t)ch * 256;  // (wave-uniform)
+      __builtin_amdgcn_global_load_lds(srcA, (lfp)dst, 16, 0, 0);
+    }
+  };
+  int cur_buf = 0;
+  if (dbuf) {
+    glds_group(0, 0);  // (a stratum whose fragments fit one buffer: its only group)
+  } else if (oneg) {
     const int tot0 = njt * TW;
     for (int e = tid * 4; e < tot0; e += NT * 4) *(v4f32 *)(As + e) = *(gv4p)(Ag + e);
   }
   int fcur = load_fidx(wv), fnext = load_fidx(wv + NW);
-  if (oneg) __syncthreads();
+  if (dbuf) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+  } else if (oneg) __syncthreads();
   APROF(0)
   // row staging of ONE tile by ONE wave, split into issue (global loads into registers) and commit (writes to the wave's
   // slab).  Units are pairs of features when the rows allow 2-element loads.
@@ -794,8 +817,8 @@ __global__ __launch_bounds__(FILT_NW(KS) * 64) __attribute__((amdgpu_waves_per_e
         const v4u32 *aq = (const v4u32 *)ap;  // (ap = tile base + lane * 4 words in this form)
 #pragma unroll
         for (int m = 0; m < KB; m++) {
-          const v8bf16 c1 = __builtin_bit_cast(v8bf16, aq[(m * 3 + 0) * 64]), c2 = __builtin_bit_cast(v8bf16, aq[(m * 3 + 1) * 64]),
-                       c3 = __builtin_bit_cast(v8bf16, aq[(m * 3 + 2) * 64]);
+          const v8bf16 c1 = __builtin_bit_cast(v8bf16, aq[(m * NP + 0) * 64]), c2 = __builtin_bit_cast(v8bf16, aq[(m * NP + 1) * 64]),
+                       c3 = __builtin_bit_cast(v8bf16, aq[(m * NP + (lite ? 1 : 2)) * 64]);  // (light form: never multiplied)
           const v8bf16 x1 = __builtin_bit_cast(v8bf16, bp[m][0]), x2 = __builtin_bit_cast(v8bf16, bp[m][1]),
                        x3 = __builtin_bit_cast(v8bf16, bp[m][2]);
           if (!lite) {  // (wave-uniform) the 2^-14-level terms
@@ -833,23 +856,35 @@ __global__ __launch_bounds__(FILT_NW(KS) * 64) __attribute__((amdgpu_waves_per_e
     };
     for (int g0 = 0; g0 < njt; g0 += G) {
       const int gc = (njt - g0) < G ? (njt - g0) : G;
-      if (!oneg) {
+      bool has_next = false;
+      if (!oneg && !dbuf) {
         __syncthreads();  // the previous group's fragments are no longer read
         const gcfp srcA = Ag + (size_t)g0 * TW;
         const int tot = gc * TW;
         for (int e = tid * 4; e < tot; e += NT * 4) *(v4f32 *)(As + e) = *(gv4p)(srcA + e);
         __syncthreads();
+      } else if (dbuf && !oneg) {
+        // the group after this one -- the next of this frame tile, or the first of the wave's next tile -- travels into the
+        // other buffer while this one is swept (its last readers passed the barrier that ended the previous group)
+        has_next = g0 + G < njt || b + 1 < NB;
+        if (has_next) glds_group(g0 + G < njt ? g0 + G : 0, cur_buf ^ 1);
       }
-      if (!live) continue;
-      // two accumulators in rotation: the matrix unit works on tile t + 1 while the vector unit ranks tile t
-      const float *ap = As + (BF ? lane * 4 : lane);
-      v16f32 accA = chain(ap), accB;
-      for (int jt = 0; jt < gc; jt += 2) {
-        const bool b1 = jt + 1 < gc, b2 = jt + 2 < gc;  // wave-uniform
-        if (b1) accB = chain(ap + (size_t)(jt + 1) * TW);
-        rank(accA, g0 + jt);
-        if (b2) accA = chain(ap + (size_t)(jt + 2) * TW);
-        if (b1) rank(accB, g0 + jt + 1);
+      if (live) {
+        // two accumulators in rotation: the matrix unit works on tile t + 1 while the vector unit ranks tile t
+        const float *ap = As + (dbuf && !oneg ? (size_t)cur_buf * G * TWr : 0) + (BF ? lane * 4 : lane);
+        v16f32 accA = chain(ap), accB;
+        for (int jt = 0; jt < gc; jt += 2) {
+          const bool b1 = jt + 1 < gc, b2 = jt + 2 < gc;  // wave-uniform
+          if (b1) accB = chain(ap + (size_t)(jt + 1) * TWr);
+          rank(accA, g0 + jt);
+          if (b2) accA = chain(ap + (size_t)(jt + 2) * TWr);
+          if (b1) rank(accB, g0 + jt + 1);
+        }
+      }
+      if (has_next) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's part of the next group has landed ...
+        __syncthreads();                                   // ... everybody's has, and nobody reads the current buffer any more
+        cur_buf ^= 1;
       }
     }
     APROF(2)
@@ -920,7 +955,7 @@ template <typename XT, int KS>
 static int launch_filter_ks(hamsm_ctx *c, SortArgs g, FiltArgs f, int TW, int aug, bool bf) {
   constexpr int NW = FILT_NW(KS), FB = 32 * NW;
   const int FRB = g.FRB;  // FB * blocks per workgroup
-  size_t lds = sizeof(float) * (size_t)FB * f.DS + sizeof(float) * (size_t)f.G * TW + 16;
+  size_t lds = sizeof(float) * (size_t)FB * f.DS + sizeof(float) * (size_t)f.G * TW * (f.dbuf ? 2 : 1) + 16;  // (TW: words per tile in LDS)
   if (lds > 160 * 1024) return hamsm_fail(c, HAMSM_ENOTSUP, "assign filter needs %zu B of LDS", lds);
   const void *kern = bf ? (aug ? (const void *)k_assign_filter<XT, KS, 1, true> : (const void *)k_assign_filter<XT, KS, 0, true>)
                         : (aug ? (const void *)k_assign_filter<XT, KS, 1, false> : (const void *)k_assign_filter<XT, KS, 0, false>);
@@ -962,6 +997,7 @@ static int launch_sorted(hamsm_ctx *c, const AssignArgs &a) {
   const int KBmin = (4 * KS + 13) / 16, KB = (a.D + 16) / 16;  // bf16 form: blocks of 16 slots
   const int aug = bf ? KB - KBmin : KH - 2 * KS;
   const int TW = bf ? KB * 3 * 256 : KH * 64;            // 32-bit words of fragments per centroid tile
+  int tw_lds = TW;                                        // ... and as held in LDS (light bf16 form in two buffers: 2 pieces)
   std::vector<size_t> tile0(S + 1, 0);
   int tmax = 0;
   if (filt) {
@@ -1001,6 +1037,16 @@ static int launch_sorted(hamsm_ctx *c, const AssignArgs &a) {
     long long room = (long long)(bf && c->filter_lds_kb < 112 ? 112 : c->filter_lds_kb) * 1024 - (long long)(sizeof(float) * (size_t)FB * f.DS);
     f.G = room > 0 ? (int)(room / (long long)(sizeof(float) * TW)) : 0;
     f.G = f.G < 2 ? 2 : (f.G > tmax ? (tmax > 0 ? tmax : 1) : f.G & ~1);
+    if (bf && f.G < tmax && c->filter_dbuf) {
+      // bf16 form and the largest stratum's fragments do not fit at once: two buffers filled by global_load_lds, the next group
+      // in flight while the current one is swept; all of the CU's LDS (one workgroup per CU either way); the light form keeps
+      // 2 of the 3 pieces there
+      f.dbuf = 1;
+      tw_lds = KB * (lite_ok ? 2 : 3) * 256;
+      room = 156LL * 1024 - (long long)(sizeof(float) * (size_t)FB * f.DS);
+      f.G = (int)(room / (2LL * (long long)sizeof(float) * tw_lds));
+      f.G = f.G < 2 ? 2 : (f.G > tmax ? tmax : f.G & ~1);
+    }
   }
   HIPCHK(c, hipMemsetAsync(b + o_cnt, 0, sizeof(long long) * S, c->stream));
   unsigned gridc = (unsigned)((n + 255) / 256 < 2048 ? (n + 255) / 256 : 2048);
@@ -1057,7 +1103,7 @@ static int launch_sorted(hamsm_ctx *c, const AssignArgs &a) {
                          a.D);
     switch (KS) {
 #define CASE(KSV) \
-  case KSV: rc = launch_filter_ks<XT, KSV>(c, g, f, TW, aug, bf); break;
+  case KSV: rc = launch_filter_ks<XT, KSV>(c, g, f, tw_lds, aug, bf); break;
       CASE(1) CASE(2) CASE(3) CASE(4) CASE(6) CASE(8) CASE(12) CASE(16) CASE(24) CASE(32)
 #undef CASE
       default: return hamsm_fail(c, HAMSM_ENOTSUP, "KS=%d", KS);

@@ -145,6 +145,7 @@ struct hamsm_ctx {
   int filter_lite = 1;     // bf16 form: 3 of the 6 products first (x1c1, x1c2, x2c1: 2^-14-level terms dropped, bound 4x wider); steps
                            // aside for 7 calls when it settles < 31/32 of the frames (HAMSM_FILTER_LITE=0: never, =2: always)
   int filter_lite_skip = 0;
+  int filter_dbuf = 1;     // bf16 form with fragment groups: double-buffered LDS filled by global_load_lds (HAMSM_FILTER_DBUF=0: single buffer)
   int filter_form = 0;     // what the last assign ran: 0 exact only, 1 f32, 2 bf16 x 3 (6 products), 3 bf16 lite (3 products)
   int filter_lds_kb = 72;  // LDS budget of a filter workgroup (HAMSM_FILTER_LDS_KB)
   int assign_filter = 1;   // f32-MFMA filter in front of the exact f64 distance kernel (HAMSM_ASSIGN_FILTER=0: exact kernel only)

@@ -64,6 +64,7 @@ extern "C" int hamsm_create(int device, hamsm_ctx **out) {
   if (const char *v = getenv("HAMSM_FLUX_XCD")) c->flux_xcd = atoi(v) != 0;
   if (const char *v = getenv("HAMSM_ASSIGN_FILTER")) c->assign_filter = atoi(v) != 0;
   if (const char *v = getenv("HAMSM_FILTER_LITE")) c->filter_lite = atoi(v) < 0 ? 0 : (atoi(v) > 2 ? 2 : atoi(v));
+  if (const char *v = getenv("HAMSM_FILTER_DBUF")) c->filter_dbuf = atoi(v) != 0;
   if (const char *v = getenv("HAMSM_FILTER_NB")) c->filter_nb = atoi(v) < 1 ? 1 : (atoi(v) > 16 ? 16 : atoi(v));
   if (const char *v = getenv("HAMSM_FILTER_LDS_KB")) c->filter_lds_kb = atoi(v) < 40 ? 40 : (atoi(v) > 150 ? 150 : atoi(v));
   if (const char *v = getenv("HAMSM_TRAIN_PERSIST")) c->train_persist = atoi(v) != 0;

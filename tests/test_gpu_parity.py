@@ -276,6 +276,34 @@ def test_assign_bf16_forms_of_the_ranking_pass(hip_lib, oracle_h, monkeypatch, l
         h.close()
 
 
+@pytest.mark.parametrize("lite,dbuf", [("2", "1"), ("0", "1"), ("2", "0"), ("1", "1")])
+def test_bf16_ranking_with_fragment_groups(hip_lib, oracle_h, monkeypatch, lite, dbuf):
+    """more centroids than one LDS buffer holds (1000 and 1500 per stratum at D <= 32): the bf16 forms sweep the fragments in groups
+    -- two buffers filled by global_load_lds while the other is swept (the light form keeps 2 of the 3 pieces there), or the single
+    buffer between barriers (HAMSM_FILTER_DBUF=0) -- a small stratum beside a large one, ragged frame counts, engineered near ties"""
+    from msm_we_amd import _abi
+
+    monkeypatch.setenv("HAMSM_FILTER_LITE", lite)
+    monkeypatch.setenv("HAMSM_FILTER_DBUF", dbuf)
+    h = _abi.Hamsm(lib=hip_lib, device=0)
+    try:
+        for D, Ks, n in ((30, [1000, 40, 1500], 30011), (20, [700, 700, 33], 9000)):
+            labs = []
+            for hh in (oracle_h, h):
+                rng = np.random.default_rng(14)
+                cents = _setup(hh, D, 3, Ks, rng)
+                X, p = _frames(rng, n, D, 3, np.float32)
+                for i in range(0, 1500):
+                    c = cents[min(int(p[i, 0]), 2)]
+                    a, b = rng.integers(0, len(c), 2)
+                    X[i] = (0.5 * (c[a] + c[b]) + (rng.integers(-2, 3) * 1e-7) * (c[a] - c[b])).astype(np.float32)
+                labs.append(hh.predict_host(X, p))
+            assert np.array_equal(labs[0], labs[1])
+            assert _filter_form(h) in (2, 3) and 700 <= _undecided(h) < 2500
+    finally:
+        h.close()
+
+
 def test_light_ranking_form_steps_aside_for_the_full_one(hip_h, oracle_h):
     """frames whose two nearest centroids differ by more than the full bf16 x 3 bound but less than the light form's: the light
     form leaves them to the exact kernel, more than 1/32 of the call -> the next 7 calls run the full form, which certifies them"""
