@@ -33,6 +33,8 @@ def case_spec(i):
                 drop_stratum=int(rng.integers(0, S)) if S > 2 and rng.random() < 0.3 else -1)
     # one case in five bins with a Voronoi mapper (Euclidean distance to S random centres) instead of the unit intervals
     spec["voronoi"] = sorted(float(np.float32(x)) for x in rng.uniform(0.0, S + 0.5, size=S)) if S > 1 and rng.random() < 0.2 else None
+    if i >= 64:  # cases 64 ..: frames of more than 128 features (the library's generic kernels)
+        spec["D"] = int(rng.integers(129, 320))
     return spec
 
 
@@ -120,7 +122,7 @@ def run(i, msm_we, skk, sc):
 
 
 if __name__ == "__main__":
-    n = int(sys.argv[1]) if len(sys.argv) > 1 else 64
+    n = int(sys.argv[1]) if len(sys.argv) > 1 else 72
     import logging
 
     msm_we = ref_harness.load_reference()

@@ -1,4 +1,4 @@
-"""Differential fuzz against the REAL reference: tests/golden/fuzz_pack.npz holds what jdrusso/msm_we produced on 64 small random
+"""Differential fuzz against the REAL reference: tests/golden/fuzz_pack.npz holds what jdrusso/msm_we produced on 72 small random
 WE-shaped inputs (tests/golden/make_fuzz.py: random iterations / segments / features / strata / clusters per stratum, sample
 weights on and off, a stratum emptied in some, a Voronoi mapper in one of five) -- including where the reference itself stops.  Inputs are regenerated from the
 recorded generator parameters; this package (host logic on the oracle here, on the HIP library under -m gpu) must reproduce
