@@ -463,10 +463,11 @@ class ClusteringMixin:
             steps["perm_off"], steps["n_perm"] = -1, 0
             # speculative draws, per model in step order (models own their RandomState here; shared ones never predict)
             perms, off, drawn = [], 0, {b: [] for b in sel}
-            for i in np.nonzero(steps["flags"] & 1)[0]:
+            # (only the tests of strata whose last test found low counts carry a permutation: usually none)
+            want = [b for b in sel if predict[b]] if not shared_rng else []
+            tested = np.nonzero((steps["flags"] & 1).astype(bool) & np.isin(steps["stratum"], want))[0] if want else ()
+            for i in tested:
                 b = int(steps["stratum"][i])
-                if not predict[b] or shared_rng:
-                    continue
                 m = models[b]
                 nb_i = int(steps["n_b"][i])
                 drawn[b].append((int(i), m._random_state.get_state()))
