@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define HAMSM_ABI_VERSION 5
+#define HAMSM_ABI_VERSION 6
 
 #define HAMSM_OK 0
 #define HAMSM_EINVAL (-1)   /* bad argument / call order                                         */
@@ -69,6 +69,11 @@ int hamsm_malloc_host(hamsm_ctx *ctx, size_t bytes, void **h_out);
 int hamsm_free_host(hamsm_ctx *ctx, void *h_ptr);
 int hamsm_memcpy_h2d_async(hamsm_ctx *ctx, void *d_dst, const void *h_src, size_t bytes);
 int hamsm_copy_sync(hamsm_ctx *ctx);
+/* float32 frames already resident in HBM widened to float64, exactly (d_dst[i] = (double)d_src[i], i < count; the buffers must
+ * not overlap).  Staging starts in float32 (WESTPA's auxdata/coord, augmentation_driver.py:173-180; the reference up-casts to
+ * float64 on load, _data.py:265,565) and switches to float64 in the middle of its one pass when a block holds a value float32
+ * cannot carry: what was uploaded before is converted where it lies instead of being read again.  Runs on the compute stream. */
+int hamsm_widen_f32(hamsm_ctx *ctx, const float *d_src, double *d_dst, int64_t count);
 int hamsm_sync(hamsm_ctx *ctx);
 
 /* ---- model state (replaces the attributes of StratifiedClusters / modelWE that predict() reads:

@@ -20,7 +20,7 @@ _vp, _i32, _i64, _f64, _sz = C.c_void_p, C.c_int32, C.c_int64, C.c_double, C.c_s
 _int = C.c_int
 
 # name -> (restype, argtypes); kept in the order of include/hamsm.h
-ABI_VERSION = 5  # HAMSM_ABI_VERSION of include/hamsm.h
+ABI_VERSION = 6  # HAMSM_ABI_VERSION of include/hamsm.h
 
 SYMBOLS = {
     "hamsm_abi_version": (_int, []),
@@ -37,6 +37,7 @@ SYMBOLS = {
     "hamsm_free_host": (_int, [_vp, _vp]),
     "hamsm_memcpy_h2d_async": (_int, [_vp, _vp, _vp, _sz]),
     "hamsm_copy_sync": (_int, [_vp]),
+    "hamsm_widen_f32": (_int, [_vp, _vp, _vp, _i64]),
     "hamsm_sync": (_int, [_vp]),
     "hamsm_set_geometry": (_int, [_vp, _int, _int, _int]),
     "hamsm_set_mapper_rectilinear": (_int, [_vp, _vp, _vp]),
@@ -285,6 +286,10 @@ class Hamsm:
 
     def copy_sync(self):
         self._ck(self.lib.hamsm_copy_sync(self.ctx))
+
+    def widen_f32(self, d_src, d_dst, count):
+        """float32 frames resident in HBM -> float64 (exact), on the compute stream"""
+        self._ck(self.lib.hamsm_widen_f32(self.ctx, _dp(d_src), _dp(d_dst), int(count)))
 
     def zeros(self, shape, dtype) -> DevBuf:
         b = self.alloc(shape, dtype)

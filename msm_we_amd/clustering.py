@@ -711,13 +711,15 @@ class ClusteringMixin:
         order, indptr = h.group_by_label(d_child, n, ns)
         it_of = np.searchsorted(offs, order, side="right")       # 1-based iteration of every grouped segment
         seg_of = order - offs[it_of - 1]
-        coords, weights, pcs = {}, {}, {}
-        for it in range(1, last + 1):
-            # (`get_iter_coordinates` drops NaN rows, and the reference indexes what remains by segment number, :1466-1493:
-            # kept as it is -- an IndexError, or rows shifted by one, where an iteration has NaN coordinates)
-            coords[it] = self.get_iter_coordinates(it)
-            weights[it] = self.seg_weights[it]
-            pcs[it] = self.pcoord1List
+        coords, weights, pcs, west, segind = {}, {}, {}, {}, {}
+        with self._source_session():
+            for it in range(1, last + 1):
+                # (`get_iter_coordinates` drops NaN rows, and the reference indexes what remains by segment number, :1466-1493:
+                # kept as it is -- an IndexError, or rows shifted by one, where an iteration has NaN coordinates)
+                coords[it] = self.get_iter_coordinates(it)
+                weights[it] = self.seg_weights[it]
+                pcs[it] = self.pcoord1List
+                west[it], segind[it] = self.westList, self.segindList   # provenance: file index / segment id inside that file
         cluster_structures, cluster_structure_weights, structure_iteration_segments = {}, {}, {}
         pcoord_cache = {} if build_pcoord_cache else None
         # keys appear in the order in which the reference first meets each cluster (dict insertion order)
@@ -729,7 +731,9 @@ class ClusteringMixin:
                 raise Exception("This dtraj point was in a removed cluster -- this should never happen!")
             cluster_structures[c] = [coords[int(i)][int(s)] for i, s in zip(its, segs)]
             cluster_structure_weights[c] = [weights[int(i)][int(s)] for i, s in zip(its, segs)]
-            structure_iteration_segments[c] = [[int(i), int(s), self.fileList[0]] for i, s in zip(its, segs)]
+            # `[iteration, segindList[seg], fileList[westList[seg]]]` (:1499-1503)
+            structure_iteration_segments[c] = [[int(i), int(segind[int(i)][int(s)]), self.fileList[int(west[int(i)][int(s)])]]
+                                               for i, s in zip(its, segs)]
             if build_pcoord_cache:
                 pcoord_cache[c] = [pcs[int(i)][int(s)] for i, s in zip(its, segs)]
         self.cluster_structures = cluster_structures

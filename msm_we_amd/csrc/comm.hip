@@ -90,6 +90,10 @@ extern "C" int hamsm_bcast(hamsm_ctx *c, void *b, size_t bytes, int root) {
   return HAMSM_OK;
 }
 
+// Every rank must enter the send / recv group below with the same picture, or the ranks that did enter it wait for ever for
+// the one that returned early.  So the arguments are cross-checked COLLECTIVELY first: one small max-all-reduce over
+// [table, -table, complaint] -- the tables agree iff max(t_r) == -max(-t_r) for every r -- and either every rank goes on or
+// every rank returns the same error.
 extern "C" int hamsm_gather_to_root(hamsm_ctx *c, const void *d_send, size_t send_bytes, void *d_recv, const int64_t *h_recv_bytes,
                                     int root) {
   CTX(c);
@@ -98,19 +102,61 @@ extern "C" int hamsm_gather_to_root(hamsm_ctx *c, const void *d_send, size_t sen
     return HAMSM_OK;
   }
   if (!c->comm) return hamsm_fail(c, HAMSM_EINVAL, "comm not initialised");
-  if (root < 0 || root >= c->nranks || !h_recv_bytes) return hamsm_fail(c, HAMSM_EINVAL, "gather_to_root: root / sizes");
-  if ((int64_t)send_bytes != h_recv_bytes[c->rank]) return hamsm_fail(c, HAMSM_EINVAL, "gather_to_root: send size disagrees with the size table");
+  const int R = c->nranks;
   ncclComm_t cm = (ncclComm_t)c->comm;
+  int64_t complaint = 0;  // what THIS rank finds wrong with its own arguments (bit set)
+  if (root < 0 || root >= R) complaint |= 1;
+  if (!h_recv_bytes) complaint |= 2;
+  else if ((int64_t)send_bytes != h_recv_bytes[c->rank]) complaint |= 4;
+  if (h_recv_bytes)
+    for (int r = 0; r < R; r++)
+      if (h_recv_bytes[r] < 0) complaint |= 8;
+  if (send_bytes && !d_send) complaint |= 16;
+  size_t total = 0;
+  if (h_recv_bytes)
+    for (int r = 0; r < R; r++) total += (size_t)(h_recv_bytes[r] > 0 ? h_recv_bytes[r] : 0);
+  if (c->rank == root && total && !d_recv) complaint |= 32;
+  std::vector<int64_t> v(2 * R + 2);
+  for (int r = 0; r < R; r++) {
+    v[r] = h_recv_bytes ? h_recv_bytes[r] : 0;
+    v[R + r] = -v[r];
+  }
+  v[2 * R] = complaint;
+  v[2 * R + 1] = -(int64_t)root;  // with its twin below: every rank names the same root
+  v.push_back((int64_t)root);
+  int rc = hamsm_ensure_scratch(c, sizeof(int64_t) * v.size());
+  if (rc) return rc;
+  HIPCHK(c, hipMemcpyAsync(c->scratch, v.data(), sizeof(int64_t) * v.size(), hipMemcpyHostToDevice, c->stream));
+  NCCLCHK(c, ncclAllReduce(c->scratch, c->scratch, v.size(), ncclInt64, ncclMax, cm, c->stream));
+  HIPCHK(c, hipMemcpyAsync(v.data(), c->scratch, sizeof(int64_t) * v.size(), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  if (v[2 * R])
+    return hamsm_fail(c, HAMSM_EINVAL, "gather_to_root: a rank's arguments are inconsistent (largest flag word over all ranks %lld, here %lld: "
+                      "1 root, 2 no size table, 4 send size != table[rank], 8 negative size, 16 null send buffer, 32 null receive buffer "
+                      "on the root)", (long long)v[2 * R],
+                      (long long)complaint);
+  if (v[2 * R + 2] != -v[2 * R + 1]) return hamsm_fail(c, HAMSM_EINVAL, "gather_to_root: the ranks name different roots");
+  for (int r = 0; r < R; r++)
+    if (v[r] != -v[R + r]) return hamsm_fail(c, HAMSM_EINVAL, "gather_to_root: the ranks hold different size tables (entry %d)", r);
+  ncclResult_t first = ncclSuccess;
   NCCLCHK(c, ncclGroupStart());
-  if (send_bytes) ncclSend(d_send, send_bytes, ncclChar, root, cm, c->stream);
+  if (send_bytes) {
+    ncclResult_t r_ = ncclSend(d_send, send_bytes, ncclChar, root, cm, c->stream);
+    if (first == ncclSuccess) first = r_;
+  }
   if (c->rank == root) {
     size_t off = 0;
-    for (int r = 0; r < c->nranks; r++) {
-      if (h_recv_bytes[r]) ncclRecv((char *)d_recv + off, (size_t)h_recv_bytes[r], ncclChar, r, cm, c->stream);
+    for (int r = 0; r < R; r++) {
+      if (h_recv_bytes[r]) {
+        ncclResult_t r_ = ncclRecv((char *)d_recv + off, (size_t)h_recv_bytes[r], ncclChar, r, cm, c->stream);
+        if (first == ncclSuccess) first = r_;
+      }
       off += (size_t)h_recv_bytes[r];
     }
   }
-  NCCLCHK(c, ncclGroupEnd());
+  ncclResult_t end = ncclGroupEnd();  // (always closed, also after a failed call inside it)
+  if (first != ncclSuccess) return hamsm_fail(c, HAMSM_EDEVICE, "gather_to_root: ncclSend / ncclRecv failed: %s", ncclGetErrorString(first));
+  if (end != ncclSuccess) return hamsm_fail(c, HAMSM_EDEVICE, "gather_to_root: ncclGroupEnd failed: %s", ncclGetErrorString(end));
   return HAMSM_OK;
 }
 
@@ -137,16 +183,21 @@ extern "C" int hamsm_bcast_model(hamsm_ctx *c, int root) {
     }
     t.K = Ks[s];
   }
+  ncclResult_t first = ncclSuccess;
   NCCLCHK(c, ncclGroupStart());
   for (int s = 0; s < S; s++) {
     Stratum &t = c->st[s];
     if (t.K == 0) continue;
     ncclComm_t cm = (ncclComm_t)c->comm;
-    ncclBroadcast(t.C, t.C, (size_t)t.K * c->D, ncclDouble, root, cm, c->stream);
-    ncclBroadcast(t.csq, t.csq, (size_t)t.K, ncclDouble, root, cm, c->stream);
-    ncclBroadcast(t.counts, t.counts, (size_t)t.K, ncclDouble, root, cm, c->stream);
+    ncclResult_t r3[3] = {ncclBroadcast(t.C, t.C, (size_t)t.K * c->D, ncclDouble, root, cm, c->stream),
+                          ncclBroadcast(t.csq, t.csq, (size_t)t.K, ncclDouble, root, cm, c->stream),
+                          ncclBroadcast(t.counts, t.counts, (size_t)t.K, ncclDouble, root, cm, c->stream)};
+    for (ncclResult_t r_ : r3)
+      if (first == ncclSuccess) first = r_;
   }
-  NCCLCHK(c, ncclGroupEnd());
+  ncclResult_t end = ncclGroupEnd();
+  if (first != ncclSuccess) return hamsm_fail(c, HAMSM_EDEVICE, "bcast_model: ncclBroadcast failed: %s", ncclGetErrorString(first));
+  if (end != ncclSuccess) return hamsm_fail(c, HAMSM_EDEVICE, "bcast_model: ncclGroupEnd failed: %s", ncclGetErrorString(end));
   for (int s = 0; s < S; s++) {
     // re-pack the MFMA B fragments locally from the broadcast rows, keeping the broadcast ||c||^2
     Stratum &t = c->st[s];

@@ -292,6 +292,31 @@ extern "C" int hamsm_copy_sync(hamsm_ctx *c) {
   if (c->copy_stream) HIPCHK(c, hipStreamSynchronize(c->copy_stream));
   return HAMSM_OK;
 }
+// HBM-bound stream: 4 B in, 8 B out per element; four elements per thread (one 16-byte load, two 16-byte stores) while
+// both pointers are 16-byte aligned, grid-stride so that any count fits one launch
+__global__ void k_widen_f32(const float *__restrict__ src, double *__restrict__ dst, int64_t n) {
+  int64_t stride = (int64_t)gridDim.x * blockDim.x, t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  int64_t n4 = (((uintptr_t)src | (uintptr_t)dst) & 15) ? 0 : n / 4;
+  for (int64_t i = t; i < n4; i += stride) {
+    float4 v = reinterpret_cast<const float4 *>(src)[i];
+    reinterpret_cast<double2 *>(dst)[2 * i] = make_double2((double)v.x, (double)v.y);
+    reinterpret_cast<double2 *>(dst)[2 * i + 1] = make_double2((double)v.z, (double)v.w);
+  }
+  for (int64_t i = 4 * n4 + t; i < n; i += stride) dst[i] = (double)src[i];
+}
+extern "C" int hamsm_widen_f32(hamsm_ctx *c, const float *d_src, double *d_dst, int64_t count) {
+  CTX(c);
+  if (count < 0 || (count > 0 && (!d_src || !d_dst))) return hamsm_fail(c, HAMSM_EINVAL, "widen_f32: null buffer or negative count");
+  if (count == 0) return HAMSM_OK;
+  const char *s0 = (const char *)d_src, *d0 = (const char *)d_dst;
+  if (s0 < d0 + 8 * count && d0 < s0 + 4 * count) return hamsm_fail(c, HAMSM_EINVAL, "widen_f32: source and destination overlap");
+  int64_t blocks = (count / 4 + 255) / 256;
+  if (blocks < 1) blocks = 1;
+  if (blocks > 256 * 64) blocks = 256 * 64;  // 64 workgroups per CU, then the grid strides
+  hipLaunchKernelGGL(k_widen_f32, dim3((unsigned)blocks), dim3(256), 0, c->stream, d_src, d_dst, count);
+  HIPCHK(c, hipGetLastError());
+  return HAMSM_OK;
+}
 extern "C" int hamsm_memset(hamsm_ctx *c, void *d, int b, size_t n) {
   CTX(c);
   HIPCHK(c, hipMemsetAsync(d, b, n, c->stream));

@@ -20,7 +20,7 @@ import numpy as np
 
 from . import _abi
 
-__all__ = ["DataMixin", "InMemorySource", "NpzDirectorySource", "WestpaH5Source", "DeviceStore"]
+__all__ = ["DataMixin", "InMemorySource", "NpzDirectorySource", "WestpaH5Source", "DeviceStore", "resolve_object"]
 
 
 class InMemorySource:
@@ -73,50 +73,112 @@ class NpzDirectorySource:
         return cls(directory)
 
 
+def resolve_object(spec):
+    """``westpa.core.extloader.get_object``: 'package.module.attribute' -> object (objects pass through; westpa's own
+    loader is used where WESTPA is installed)."""
+    if not isinstance(spec, str):
+        return spec
+    try:
+        from westpa.core import extloader
+
+        return extloader.get_object(spec)
+    except ImportError:
+        import importlib
+
+        module, _, attr = spec.rpartition(".")
+        if not module:
+            raise ValueError(f"{spec!r} is not of the form package.module.attribute")
+        return getattr(importlib.import_module(module), attr)
+
+
 class WestpaH5Source:
     """WESTPA ``west.h5`` reader for the layout the reference consumes (``_data.py:853-916, 283-300``; written by
     ``augmentation_driver.py:173-180``): ``iterations/iter_%08d/{seg_index['weight'], pcoord (nSeg, pcoord_len, ndim),
-    auxdata/<auxpath> (nSeg, 2, nAtoms, 3) float32}``.  The file is opened once and every iteration is read exactly once per
-    pass (the reference re-opens it per iteration and appends segment by segment).  Several files (the reference's
-    ``fileList``) are read one after the other, iterations concatenated segment-wise like ``load_iter_data`` does.
+    auxdata/<auxpath> (nSeg, 2, nAtoms, 3) float32}``.  Several files (the reference's ``fileList``) are read one after the
+    other, an iteration's segments concatenated file by file like ``load_iter_data`` does; ``west`` / ``segind`` carry every
+    segment's file index and its index inside that file (the reference's ``westList`` / ``segindList``, ``_data.py:893-895``).
+
+    Files are open only while somebody reads: a single ``load`` / ``iterations`` call opens and closes them like the reference
+    does (``_data.py:853, 918``), and a pass over many iterations wraps itself in ``with source.session():`` so that the files are
+    opened once per pass, not per iteration (``DataMixin`` does this for ``get_iterations``, ``get_coordSet``, ``dimReduce`` and
+    ``stage_iterations``).  No handle outlives the pass: WESTPA and the restart driver can reopen ``west.h5`` for writing, and
+    the source -- and a model that holds it -- pickles (paths only).
     Needs h5py, an optional dependency (absent in the build image: the tests run this class against a stand-in module)."""
 
     def __init__(self, path, auxpath="coord", pcoord_ndim=1):
+        self._h5py()
+        self.paths = [path] if isinstance(path, (str, bytes)) or hasattr(path, "__fspath__") else list(path)
+        self.auxpath, self.ndim = auxpath, pcoord_ndim
+        self._files, self._depth = None, 0
+
+    @staticmethod
+    def _h5py():
         try:
             import h5py
         except ImportError as e:
             raise ImportError("WestpaH5Source needs h5py") from e
-        self.paths = [path] if isinstance(path, (str, bytes)) or hasattr(path, "__fspath__") else list(path)
-        self.auxpath, self.ndim = auxpath, pcoord_ndim
-        self._files = [h5py.File(p, "r") for p in self.paths]
+        return h5py
+
+    def session(self):
+        """context manager: the files stay open until the outermost session ends"""
+        return _H5Session(self)
 
     def close(self):
-        for f in self._files:
+        for f in self._files or ():
             f.close()
-        self._files = []
+        self._files = None
+
+    def __getstate__(self):
+        d = dict(self.__dict__)
+        d["_files"], d["_depth"] = None, 0
+        return d
 
     def iterations(self):
-        its = None
-        for f in self._files:
-            here = {int(k.split("_")[1]) for k in f["iterations"].keys()}
-            its = here if its is None else its | here
-        return sorted(its or ())
+        with self.session():
+            its = None
+            for f in self._files:
+                here = {int(k.split("_")[1]) for k in f["iterations"].keys()}
+                its = here if its is None else its | here
+            return sorted(its or ())
 
     def load(self, n):
         key = "iterations/iter_%08d" % int(n)
         parts = []
-        for f in self._files:
-            if key not in f:
-                continue
-            g = f[key]
-            pc = np.asarray(g["pcoord"][:])
-            co = np.asarray(g["auxdata/" + self.auxpath][:])
-            parts.append(dict(parent=co[:, 0], child=co[:, -1], p0=pc[:, 0, : self.ndim].astype(np.float64),
-                              p1=pc[:, -1, : self.ndim].astype(np.float64),
-                              w=np.asarray(g["seg_index"]["weight"], dtype=np.float64)))
+        with self.session():
+            for file_idx, f in enumerate(self._files):
+                if key not in f:
+                    continue
+                g = f[key]
+                pc = np.asarray(g["pcoord"][:])
+                co = np.asarray(g["auxdata/" + self.auxpath][:])
+                parts.append(dict(parent=co[:, 0], child=co[:, -1], p0=pc[:, 0, : self.ndim].astype(np.float64),
+                                  p1=pc[:, -1, : self.ndim].astype(np.float64),
+                                  w=np.asarray(g["seg_index"]["weight"], dtype=np.float64),
+                                  west=np.full(len(pc), file_idx, dtype=int), segind=np.arange(len(pc), dtype=int)))
         if not parts:
             raise KeyError(key)
         return parts[0] if len(parts) == 1 else {k: np.concatenate([p[k] for p in parts]) for k in parts[0]}
+
+
+class _H5Session:
+    def __init__(self, src):
+        self.src = src
+
+    def __enter__(self):
+        s = self.src
+        if s._files is None:
+            h5py = s._h5py()
+            s._files = [h5py.File(p, "r") for p in s.paths]
+        s._depth += 1
+        return s
+
+    def __exit__(self, *exc):
+        s = self.src
+        s._depth -= 1
+        if s._depth <= 0:
+            s._depth = 0
+            s.close()
+        return False
 
 
 class DeviceStore:
@@ -180,7 +242,27 @@ class DataMixin:
             X = self.coordinates.transform(X)
         return np.ascontiguousarray(X, dtype=np.float64)
 
+    # -- a1: the user's featurizer.  The reference's idiom is a class patch, `modelWE.processCoordinates = f`
+    #    (docs/usage.rst:41-60; hamsm_driver.py:100-103) -- that still works here (or a subclass).  `set_featurizer` binds one to
+    #    THIS model instead, without a class of its own, so that the model stays picklable (restart_driver.py:1142 pickles the
+    #    plugin's model): a dotted path is what the pickle carries, resolved again on first use after loading. ---------------------
+    _featurizer = None
+    _featurizer_spec = None
+
+    def set_featurizer(self, featurizer):
+        """`featurizer(model, coords) -> (n, D)`: a callable, or its 'package.module.function' path (west.cfg's
+        `featurization`)"""
+        self._featurizer_spec = featurizer if isinstance(featurizer, str) else None
+        self._featurizer = resolve_object(featurizer)
+        self._store = None
+        self._train_store = None
+
     def processCoordinates(self, coords):
+        f = self._featurizer
+        if f is None and self._featurizer_spec is not None:
+            f = self._featurizer = resolve_object(self._featurizer_spec)
+        if f is not None:
+            return f(self, coords)
         # default featurizer = the notebook's: flatten (examples/hamsm_construction.ipynb cell 9)
         return coords.reshape(coords.shape[0], -1)
 
@@ -188,12 +270,20 @@ class DataMixin:
         d = self._source.load(int(n_iter))
         return d
 
+    def _source_session(self):
+        """a pass over many iterations: sources that hold files (WestpaH5Source) keep them open for its duration only"""
+        import contextlib
+
+        sess = getattr(getattr(self, "_source", None), "session", None)
+        return sess() if callable(sess) else contextlib.nullcontext()
+
     # -- the reference's loader hooks ---------------------------------------------------------
     def get_iterations(self):
         # `_data.py:934-993`: an iteration counts only if the following one exists (:860-866)
-        its = self._source.iterations()
-        complete = [i for i in its if (i + 1) in set(its)]
-        self.numSegments = np.array([len(self._load(i)["w"]) for i in complete], dtype=float)
+        with self._source_session():
+            its = self._source.iterations()
+            complete = [i for i in its if (i + 1) in set(its)]
+            self.numSegments = np.array([len(self._load(i)["w"]) for i in complete], dtype=float)
         self.maxIter = self.numSegments.size
 
     def load_iter_data(self, n_iter):
@@ -201,8 +291,9 @@ class DataMixin:
         d = self._load(n_iter)
         n = len(d["w"])
         self.n_iter = n_iter
-        self.westList = np.zeros(n, dtype=int)
-        self.segindList = np.arange(n, dtype=int)
+        # provenance of every segment (`_data.py:893-895`): index into `fileList`, index inside that file
+        self.westList = np.asarray(d["west"], dtype=int) if "west" in d else np.zeros(n, dtype=int)
+        self.segindList = np.asarray(d["segind"], dtype=int) if "segind" in d else np.arange(n, dtype=int)
         self.seg_weights[n_iter] = np.asarray(d["w"], dtype=np.float64).copy()
         self.weightList = np.asarray(d["w"], dtype=np.float64).copy()
         self.nSeg = n
@@ -245,11 +336,12 @@ class DataMixin:
         total = int(sum(self.numSegments[:last_iter]))
         pcoordSet = np.full((total, self.pcoord_ndim), np.nan)
         pos = 0
-        for i in range(1, last_iter + 1):
-            d = self._load(i)
-            n = len(d["w"])
-            pcoordSet[pos : pos + n] = np.asarray(d["p1"], dtype=np.float64).reshape(n, -1)[:, : self.pcoord_ndim]
-            pos += n
+        with self._source_session():
+            for i in range(1, last_iter + 1):
+                d = self._load(i)
+                n = len(d["w"])
+                pcoordSet[pos : pos + n] = np.asarray(d["p1"], dtype=np.float64).reshape(n, -1)[:, : self.pcoord_ndim]
+                pos += n
         self.pcoordSet = pcoordSet
         self.first_iter = 1
         self.last_iter = last_iter
@@ -291,13 +383,14 @@ class DataMixin:
         return (X[0], X[1], np.asarray(d["p0"], dtype=np.float64).reshape(n, -1)[:, : self.pcoord_ndim],
                 np.asarray(d["p1"], dtype=np.float64).reshape(n, -1)[:, : self.pcoord_ndim], np.asarray(d["w"], dtype=np.float64))
 
-    def _fill_slab(self, its, mode, slab, up_dtype):
+    def _fill_slab(self, its, mode, slab, up_dtype, preloaded=None):
         """reader thread: iterations `its` written straight into a page-locked slab (one copy, no intermediate concatenation).
+        `preloaded`: {iteration: its host block} for blocks that are in memory already.
         -> (rows, nan_parent, nan_child, fits): `fits` is False when a value does not survive the slab's dtype"""
         o, fits = 0, True
         nan = [[], []]
         for it in its:
-            blk = self._iteration_host(it, mode)
+            blk = preloaded[it] if preloaded and it in preloaded else self._iteration_host(it, mode)
             n = len(blk[4])
             for side in range(2):
                 x = blk[side]
@@ -312,12 +405,15 @@ class DataMixin:
         return o, cat(nan[0]), cat(nan[1]), fits
 
     def stage_iterations(self):
-        """Featurize and upload iterations 1..maxIter once.  Idempotent.  One pass: a reader thread loads and featurizes
-        block k+1 (`processCoordinates` is user code and stays on the host) straight into one of two page-locked slabs while
-        block k travels from the other on the context's copy stream -- and while the device turns the uploaded block into
-        features where that is its job: the shipped distance featurizer (`hamsm_featurize_dist`) and / or a fitted PCA's
-        transform (`hamsm_project`; `reduceCoordinates`, _dimensionality.py:37-66).  Any other `coordinates.transform` runs on
-        the host.  Frames are stored float32 when that loses nothing (WESTPA's auxdata/coord is float32), else float64."""
+        """Featurize and upload iterations 1..maxIter once.  Idempotent.  ONE pass over the source: a reader thread loads and
+        featurizes block k+1 (`processCoordinates` is user code and stays on the host) straight into one of two page-locked
+        slabs while block k travels from the other on the context's copy stream -- and while the device turns the uploaded
+        block into features where that is its job: the shipped distance featurizer (`hamsm_featurize_dist`) and / or a fitted
+        PCA's transform (`hamsm_project`; `reduceCoordinates`, _dimensionality.py:37-66).  Any other `coordinates.transform`
+        runs on the host.  Frames are stored float32 when that loses nothing (WESTPA's auxdata/coord is float32), else
+        float64: the first iteration decides how the pass starts, and if a later block holds a value float32 cannot carry the
+        pass switches in place -- what is in HBM already is widened there (`hamsm_widen_f32`, exact) and that one block is
+        filled again; nothing else is read twice."""
         if getattr(self, "_store", None) is not None:
             return self._store
         import time
@@ -333,52 +429,77 @@ class DataMixin:
         its = list(range(1, self.maxIter + 1))
         if not its:
             raise ValueError("no complete iteration to stage (get_iterations found none)")
-        sizes = np.array([len(self._load(i)["w"]) for i in its], dtype=np.int64) if len(getattr(self, "numSegments", ())) != len(its) \
-            else np.asarray(self.numSegments, dtype=np.int64)
-        offsets = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)
-        N = int(offsets[-1])
-        first = self._iteration_host(its[0], mode)     # fixes the widths
-        raw_w, ndim = first[0].shape[1], first[2].shape[1]
-        row_bytes = 2 * raw_w * first[0].dtype.itemsize + 16 * ndim + 8
-        per_chunk = max(1, int(self.STAGE_CHUNK_BYTES // max(1, row_bytes * max(1, int(sizes.mean())))))
-        chunks = [its[i: i + per_chunk] for i in range(0, len(its), per_chunk)]
-        rows_max = int(max(offsets[c[-1]] - offsets[c[0] - 1] for c in chunks))
+        with self._source_session():
+            sizes = np.array([len(self._load(i)["w"]) for i in its], dtype=np.int64) if len(getattr(self, "numSegments", ())) != len(its) \
+                else np.asarray(self.numSegments, dtype=np.int64)
+            offsets = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)
+            N = int(offsets[-1])
+            first = self._iteration_host(its[0], mode)     # fixes the widths and the dtype the pass starts in; reused as block 0
+            preloaded = {its[0]: first}
+            raw_w, ndim = first[0].shape[1], first[2].shape[1]
+            row_bytes = 2 * raw_w * first[0].dtype.itemsize + 16 * ndim + 8
+            per_chunk = max(1, int(self.STAGE_CHUNK_BYTES // max(1, row_bytes * max(1, int(sizes.mean())))))
+            chunks = [its[i: i + per_chunk] for i in range(0, len(its), per_chunk)]
+            rows_max = int(max(offsets[c[-1]] - offsets[c[0] - 1] for c in chunks))
+            f32_exact = lambda x: x.dtype == np.float32 or bool(  # noqa: E731
+                np.array_equal(np.asarray(x, dtype=np.float32).astype(x.dtype), x, equal_nan=True))
+            up_dtype = np.float32 if all(f32_exact(np.asarray(x)) for x in first[:2]) else np.float64
+            D = raw_w if mode == "host" else ((len(feat[1]) if feat is not None else raw_w) if lin is None else lin[0].shape[0])
+            n_all = max(N, 1)
 
-        def run(up_dtype):
-            """one streaming pass with the uploaded blocks stored as `up_dtype`; returns None when a block does not fit it"""
-            up_dt = _abi.F32 if up_dtype == np.float32 else _abi.F64
+            def alloc_slabs(dt):
+                return [dict(X=[h.pinned((rows_max, raw_w), dt) for _ in range(2)], p0=h.pinned((rows_max, ndim), np.float64),
+                             p1=h.pinned((rows_max, ndim), np.float64), w=h.pinned(rows_max, np.float64)) for _ in range(2)]
+
+            def free_slabs(slabs_):
+                for sl_ in slabs_:
+                    for a_ in (*sl_["X"], sl_["p0"], sl_["p1"], sl_["w"]):
+                        h.free_pinned(a_)
+
             raw = mid = None
-            if mode == "host":
-                D, x_dt = raw_w, up_dt
-                Xd = [h.alloc(max(N, 1) * D, up_dtype) for _ in range(2)]
-            else:
-                D = (len(feat[1]) if feat is not None else raw_w) if lin is None else lin[0].shape[0]
-                x_dt = _abi.F64
-                Xd = [h.alloc(max(N, 1) * D, np.float64) for _ in range(2)]
+            Xd = [h.alloc(n_all * D, up_dtype if mode == "host" else np.float64) for _ in range(2)]
+            if mode != "host":
                 raw = [h.alloc(max(rows_max, 1) * raw_w, up_dtype) for _ in range(2)]       # uploaded block, parent / child
                 if feat is not None and lin is not None:
                     mid = [h.alloc(max(rows_max, 1) * len(feat[1]), np.float64) for _ in range(2)]
-            d_p0, d_p1, d_w = h.alloc(max(N, 1) * ndim, np.float64), h.alloc(max(N, 1) * ndim, np.float64), h.alloc(max(N, 1), np.float64)
-            slabs = [dict(X=[h.pinned((rows_max, raw_w), up_dtype) for _ in range(2)], p0=h.pinned((rows_max, ndim), np.float64),
-                          p1=h.pinned((rows_max, ndim), np.float64), w=h.pinned(rows_max, np.float64)) for _ in range(2)]
+            d_p0, d_p1, d_w = h.alloc(n_all * ndim, np.float64), h.alloc(n_all * ndim, np.float64), h.alloc(n_all, np.float64)
+            slabs = alloc_slabs(up_dtype)
             nan = [np.zeros(N, dtype=bool), np.zeros(N, dtype=bool)]
             w_all = np.empty(N)
-            ok = True
+            widened = False
+            done = False
             try:
                 with ThreadPoolExecutor(1) as pool:
-                    fut = pool.submit(self._fill_slab, chunks[0], mode, slabs[0], up_dtype)
+                    fut = pool.submit(self._fill_slab, chunks[0], mode, slabs[0], up_dtype, preloaded)
                     for k, ch in enumerate(chunks):
                         n, nan_p, nan_c, fits = fut.result()          # slab k & 1 holds block k
                         h.copy_sync()                                 # block k-1 has left the other slab ...
                         if mode != "host":
                             h.sync()                                  # ... and the kernels that read its raw upload are done
+                        if not fits:
+                            # float32 cannot carry this block: the rest of the pass runs in float64.  Blocks 0..k-1 are exact in
+                            # float32 and are widened where they lie; block k is filled again (its slab held rounded values)
+                            f0 = int(offsets[ch[0] - 1])
+                            h.sync()
+                            if mode == "host":
+                                for side in range(2):
+                                    wide = h.alloc(n_all * D, np.float64)
+                                    if f0:
+                                        h.widen_f32(Xd[side], wide, f0 * D)
+                                    h.sync()
+                                    Xd[side].free()
+                                    Xd[side] = wide
+                            else:
+                                for b_ in raw:
+                                    b_.free()
+                                raw = [h.alloc(max(rows_max, 1) * raw_w, np.float64) for _ in range(2)]
+                            free_slabs(slabs)
+                            up_dtype, widened = np.float64, True
+                            slabs = alloc_slabs(up_dtype)
+                            n, nan_p, nan_c, fits = self._fill_slab(ch, mode, slabs[k & 1], up_dtype, preloaded)
                         if k + 1 < len(chunks):
                             fut = pool.submit(self._fill_slab, chunks[k + 1], mode, slabs[(k + 1) & 1], up_dtype)
-                        if not fits:
-                            ok = False
-                            if k + 1 < len(chunks):
-                                fut.result()
-                            break
+                        up_dt = _abi.F32 if up_dtype == np.float32 else _abi.F64
                         f0 = int(offsets[ch[0] - 1])
                         assert n == int(offsets[ch[-1]]) - f0
                         if n == 0:
@@ -404,27 +525,22 @@ class DataMixin:
                                     h.project(src, src_dt, src_w, n, lin[0], lin[1], lin[2], d_Y=Xd[side].offset(f0 * D))
                     h.copy_sync()
                     h.sync()
+                    done = True
             finally:
-                for sl in slabs:
-                    for a_ in (*sl["X"], sl["p0"], sl["p1"], sl["w"]):
-                        h.free_pinned(a_)
+                free_slabs(slabs)
                 for bufs in (raw, mid):
                     for b_ in bufs or ():
                         b_.free()
-            if not ok:
-                for b_ in (*Xd, d_p0, d_p1, d_w):
-                    b_.free()
-                return None
-            store = DeviceStore(h, D, ndim, x_dt, offsets, Xd[0], Xd[1], d_p0, d_p1, d_w)
-            store.mark_nan_segments(nan[0], nan[1], w_all)
-            return store
-
-        store = run(np.float32)      # float32 storage / upload when it is exact (checked block by block) ...
-        if store is None:
-            store = run(np.float64)  # ... else once more in float64
+                if not done:
+                    for b_ in (*Xd, d_p0, d_p1, d_w):
+                        b_.free()
+        x_dt = (_abi.F32 if up_dtype == np.float32 else _abi.F64) if mode == "host" else _abi.F64
+        store = DeviceStore(h, D, ndim, x_dt, offsets, Xd[0], Xd[1], d_p0, d_p1, d_w)
+        store.mark_nan_segments(nan[0], nan[1], w_all)
         self._store = store
         nbytes = N * (2 * raw_w * (4 if store.x_dtype == _abi.F32 and mode == "host" else first[0].dtype.itemsize) + 16 * ndim + 8)
-        self.ingest_stats = {"seconds": time.perf_counter() - t_start, "bytes": int(nbytes), "blocks": len(chunks), "mode": mode}
+        self.ingest_stats = {"seconds": time.perf_counter() - t_start, "bytes": int(nbytes), "blocks": len(chunks), "mode": mode,
+                             "widened_mid_pass": widened}
         return self._store
 
     def set_distance_featurizer(self, atom_indices, reference_positions):

@@ -103,6 +103,8 @@ class modelWE(DataMixin, ClusteringMixin, FluxMatrixMixin, AnalysisMixin):
         for k in self._DEVICE_STATE:
             if k in d:
                 d[k] = None
+        if d.get("_featurizer_spec") is not None:
+            d["_featurizer"] = None   # travels by name (`set_featurizer`), resolved again on first use
         return d
 
     def __setstate__(self, d):
@@ -244,6 +246,10 @@ class modelWE(DataMixin, ClusteringMixin, FluxMatrixMixin, AnalysisMixin):
         number of components that explain `variance_cutoff`, then the fit with that many components over all
         iterations -- on the host; the fitted map is applied to every frame on the device at staging time
         (`hamsm_project`).  TICA / VAMP need deeptime (not in the image)."""
+        with self._source_session():    # one pass (two for PCA) over the source: its files are open for that long only
+            return self._dimReduce(first_iter, first_rough_iter, last_iter, rough_stride, fine_stride, variance_cutoff)
+
+    def _dimReduce(self, first_iter, first_rough_iter, last_iter, rough_stride, fine_stride, variance_cutoff):
         if self.dimReduceMethod == "none":
             self.ndim = int(3 * self.nAtoms)
             self.coordinates = self.Coordinates()

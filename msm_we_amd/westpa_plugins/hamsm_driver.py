@@ -23,7 +23,6 @@ Differences, all forced by the environment: ``westpa`` is imported lazily (``wes
 """
 from __future__ import annotations
 
-import importlib
 import logging
 import os
 
@@ -43,17 +42,9 @@ def _pstatus(msg):
 
 def _get_object(spec):
     """``westpa.core.extloader.get_object``: 'pkg.module.attr' -> object (objects pass through)."""
-    if not isinstance(spec, str):
-        return spec
-    try:
-        from westpa.core import extloader
+    from ..data import resolve_object
 
-        return extloader.get_object(spec)
-    except ImportError:
-        module, _, attr = spec.rpartition(".")
-        if not module:
-            raise ValueError(f"{spec!r} is not of the form package.module.attribute")
-        return getattr(importlib.import_module(module), attr)
+    return resolve_object(spec)
 
 
 class HAMSMDriver:
@@ -108,12 +99,14 @@ class HAMSMDriver:
         cfg = self.plugin_config
         self.data_manager.hamsm_model = None  # :87
         featurizer = _get_object(cfg.get("featurization"))  # :99-103
-        model_cls = type("modelWE", (modelWE,), {}) if featurizer is not None else modelWE
-        if featurizer is not None:
-            model_cls.processCoordinates = featurizer  # the reference patches the class; a subclass keeps the patch local
-            self.data_manager.processCoordinates = featurizer
         self.data_manager.close_backing()  # :105
-        model = model_cls(device=self.device)
+        model = modelWE(device=self.device)
+        if featurizer is not None:
+            # the reference patches the CLASS (`msm_we.modelWE.processCoordinates = featurizer`, :101); here the featurizer is
+            # bound to this model alone, by its dotted path where the config gave one, so that the model the later plugins
+            # pickle (restart_driver.py:1142) is an importable class carrying a name, not a function object
+            model.set_featurizer(cfg.get("featurization"))
+            self.data_manager.processCoordinates = featurizer
         model.set_iteration_source(self._iteration_source())
         pcoord_ndim = len(cfg.get("basis_pcoord_bounds"))
         model.build_analyze_model(
@@ -137,6 +130,9 @@ class HAMSMDriver:
             allow_validation_failure=True,  # :135
             cross_validation_groups=self.cross_validation_groups,
         )
+        release = getattr(getattr(model, "_source", None), "close", None)
+        if callable(release):
+            release()  # no handle on west.h5 outlives the build: WESTPA / the restart driver reopen the file for writing
         _pstatus(f"Storing built haMSM on {self.data_manager}")
         self.data_manager.hamsm_model = model  # :141-142
         return model

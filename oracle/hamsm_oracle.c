@@ -218,6 +218,15 @@ int hamsm_copy_sync(hamsm_ctx *c) {
   CTX(c);
   return HAMSM_OK;
 }
+/* float32 -> float64 is exact: the staged frames of the reference are float32 on disk, float64 in memory (_data.py:265,565) */
+int hamsm_widen_f32(hamsm_ctx *c, const float *src, double *dst, int64_t count) {
+  CTX(c);
+  if (count < 0 || (count > 0 && (!src || !dst))) return fail(c, HAMSM_EINVAL, "widen_f32: null buffer or negative count");
+  if (count > 0 && (const char *)src < (const char *)dst + 8 * count && (const char *)dst < (const char *)src + 4 * count)
+    return fail(c, HAMSM_EINVAL, "widen_f32: source and destination overlap");
+  for (int64_t i = 0; i < count; i++) dst[i] = (double)src[i];
+  return HAMSM_OK;
+}
 int hamsm_memcpy_h2d(hamsm_ctx *c, void *d, const void *h, size_t n) {
   CTX(c);
   (void)c;

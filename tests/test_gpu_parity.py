@@ -896,6 +896,17 @@ def test_rccl_collectives_on_one_rank_communicator(hip_lib):
         h.gather_to_root(d_v, v.nbytes, d_r, [v.nbytes], 0)
         h.sync()
         assert np.array_equal(d_r.to_host(), v)
+        # arguments that disagree are found by the collective check in front of the group (every rank returns the same error
+        # instead of some of them waiting inside it), and the communicator stays usable
+        for bad in (dict(send=v.nbytes - 8, table=[v.nbytes], root=0, match="inconsistent"),
+                    dict(send=v.nbytes, table=[v.nbytes], root=1, match="inconsistent"),
+                    dict(send=0, table=[-8], root=0, match="inconsistent")):
+            with pytest.raises(_abi.HamsmError, match=bad["match"]):
+                h.gather_to_root(d_v, bad["send"], d_r, bad["table"], bad["root"])
+        h.memset(d_r, 0, v.nbytes)
+        h.gather_to_root(d_v, v.nbytes, d_r, [v.nbytes], 0)
+        h.sync()
+        assert np.array_equal(d_r.to_host(), v)
         # a second communicator on a context that has one is refused; a failed / absent one leaves a 1-rank context
         with pytest.raises(_abi.HamsmError):
             h.comm_init(1, 0, h.comm_unique_id())

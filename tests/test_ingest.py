@@ -43,17 +43,25 @@ class _FakeDataset:
 
 
 def _fake_h5py(files):
-    opened = []
+    opened, live = [], []
 
     class File(_FakeNode):
         def __init__(self, path, mode="r"):
             super().__init__(files[path])
+            assert mode == "r"
             opened.append(path)
+            live.append(path)
 
         def close(self):
-            pass
+            live.remove(self_path(self))
 
-    return types.SimpleNamespace(File=File, opened=opened)
+        def __reduce__(self):   # like h5py objects: refuses to be pickled
+            raise TypeError("h5py objects cannot be pickled")
+
+    def self_path(f):
+        return next(p for p in live if files[p].keys() == f.keys() and dict.__eq__(files[p], f))
+
+    return types.SimpleNamespace(File=File, opened=opened, live=live)
 
 
 def _west_h5_tree(iters, n_atoms, split=None):
@@ -79,21 +87,59 @@ def test_westpa_h5_source_reads_the_reference_layout(oracle_h, monkeypatch):
     fake = _fake_h5py({"west.h5": _west_h5_tree(iters, 10)})
     monkeypatch.setitem(sys.modules, "h5py", fake)
     src = data.WestpaH5Source("west.h5", auxpath="coord", pcoord_ndim=1)
-    assert src.iterations() == sorted(iters) and fake.opened == ["west.h5"]     # opened once, not per iteration
-    d7 = src.load(7)
+    assert fake.opened == []                                                   # nothing is opened before somebody reads
+    assert src.iterations() == sorted(iters) and fake.opened == ["west.h5"] and fake.live == []
+    d7 = src.load(7)                                                           # a single read opens and closes (_data.py:853, 918)
+    assert fake.opened == ["west.h5"] * 2 and fake.live == []
     assert d7["parent"].shape == (len(iters[7]["w"]), 10, 3) and d7["parent"].dtype == np.float32
     assert np.array_equal(d7["child"].reshape(-1, 30), iters[7]["Xc"]) and np.array_equal(d7["w"], iters[7]["w"])
+    assert np.array_equal(d7["west"], np.zeros(len(d7["w"]), dtype=int)) and np.array_equal(d7["segind"], np.arange(len(d7["w"])))
+    with src.session():                                                        # a pass: opened once, not per iteration
+        for it in (1, 2, 3):
+            src.load(it)
+        assert fake.opened == ["west.h5"] * 3 and fake.live == ["west.h5"]
+    assert fake.live == []
+    n_open = len(fake.opened)
     m, st = build_model(oracle_h, g, meta, source=src)     # flatten featurizer (the notebook's) over (nSeg, 10, 3)
     assert np.array_equal(np.concatenate(m.dtrajs), g["dtrajs_post_cluster"])
     assert m._store.x_dtype == 0 and m.ingest_stats["mode"] == "host"
+    # the whole build opened the file a handful of times (once per pass), never per iteration, and holds no handle afterwards:
+    # WESTPA / the restart driver can reopen west.h5 for writing, and the model pickles with its source (paths only)
+    assert len(fake.opened) - n_open <= 6 and fake.live == []
+    import pickle
+
+    m2 = pickle.loads(pickle.dumps(m))
+    assert m2._source.paths == ["west.h5"] and m2._source._files is None
+    m2.attach(oracle_h)                                      # re-stages from the unpickled source
+    assert fake.live == []
+    m2.load_iter_data(7)
+    assert np.array_equal(m2.clusters.predict(iters[7]["Xc"]), np.concatenate(m.dtrajs)[m._store.offsets[6]: m._store.offsets[7]])
     # two files, every iteration's segments split between them (the reference's fileList: segments are concatenated)
     fake2 = _fake_h5py({"a.h5": _west_h5_tree(iters, 10, lambda n: slice(0, n // 2)),
                         "b.h5": _west_h5_tree(iters, 10, lambda n: slice(n // 2, None))})
     monkeypatch.setitem(sys.modules, "h5py", fake2)
     src2 = data.WestpaH5Source(["a.h5", "b.h5"])
-    assert np.array_equal(src2.load(3)["child"].reshape(-1, 30), iters[3]["Xc"])
-    src.close()
-    src2.close()
+    d3 = src2.load(3)
+    n3 = len(iters[3]["w"])
+    assert np.array_equal(d3["child"].reshape(-1, 30), iters[3]["Xc"]) and fake2.live == []
+    # provenance of every segment: file index and index inside that file (`westList` / `segindList`, _data.py:893-895)
+    assert np.array_equal(d3["west"], np.r_[np.zeros(n3 // 2, dtype=int), np.ones(n3 - n3 // 2, dtype=int)])
+    assert np.array_equal(d3["segind"], np.r_[np.arange(n3 // 2), np.arange(n3 - n3 // 2)])
+    m3, _ = build_model(oracle_h, g, meta, source=src2)
+    m3.fileList = ["a.h5", "b.h5"]
+    assert np.array_equal(np.concatenate(m3.dtrajs), g["dtrajs_post_cluster"])
+    m3.update_cluster_structures()
+    # `[iteration, segindList[seg], fileList[westList[seg]]]` (_clustering.py:1499-1503): every record names the file its
+    # segment came from and the segment's index in THAT file; the structure stored with it is that segment's
+    seen = set()
+    for c, recs in m3.structure_iteration_segments.items():
+        for (it, seg, f), xyz in zip(recs, m3.cluster_structures[c]):
+            half = len(iters[it]["w"]) // 2
+            pos = seg if f == "a.h5" else half + seg
+            assert f in ("a.h5", "b.h5") and (seg < half if f == "a.h5" else seg < len(iters[it]["w"]) - half)
+            assert np.array_equal(np.asarray(xyz).reshape(-1), iters[it]["Xc"][pos].astype(np.float64))
+            seen.add(f)
+    assert seen == {"a.h5", "b.h5"} and fake2.live == []
 
 
 def test_h5_source_without_h5py_says_so(monkeypatch):
@@ -131,3 +177,76 @@ def test_staging_falls_back_to_float64_when_float32_would_lose_bits(oracle_h):
     its[23]["Xc"][5, 2] += 1e-12        # one value that float32 cannot hold, late in the run
     m, _ = build_model(oracle_h, g, meta, source=InMemorySource(its), seed_forcing=False)
     assert m._store.x_dtype == 1 and m._store.Xc.to_host().reshape(-1, 10)[m._store.offsets[22] + 5, 2] == its[23]["Xc"][5, 2]
+
+
+@pytest.mark.parametrize("late_iteration", [1, 23])
+def test_staging_switches_to_float64_in_the_middle_of_its_one_pass(oracle_h, monkeypatch, late_iteration):
+    """a value float32 cannot hold, met in block k of many: blocks 0..k-1 are widened where they lie (hamsm_widen_f32), block k
+    is filled again, no iteration before it is loaded twice -- and the result is the all-float64 staging's"""
+    from msm_we_amd.model import modelWE
+
+    g, meta = load_golden("c1p_d10")
+    its = {k: {a: np.array(b, dtype=np.float64 if a in ("Xp", "Xc") else b.dtype) for a, b in v.items()}
+           for k, v in golden_iterations(g).items()}
+    its[late_iteration]["Xp"][3, 1] += 1e-12
+
+    class Counting(InMemorySource):
+        def __init__(self, d):
+            super().__init__(d)
+            self.loads = {}
+
+        def load(self, n):
+            self.loads[int(n)] = self.loads.get(int(n), 0) + 1
+            return super().load(n)
+
+    monkeypatch.setattr(modelWE, "STAGE_CHUNK_BYTES", 3 * 128 * (2 * 10 * 8 + 24))   # ~3 iterations per block
+    src = Counting(its)
+    m = modelWE(h=oracle_h)
+    m.set_iteration_source(src)
+    m.initialize(["mem"], dict(coords=None, nAtoms=10, coord_ndim=1), "t", basis_pcoord_bounds=meta["basis"],
+                 target_pcoord_bounds=meta["target"], dim_reduce_method="none", tau=1.0, pcoord_ndim=1)
+    m.get_iterations()
+    m.dimReduce()
+    src.loads.clear()
+    st = m.stage_iterations()
+    assert st.x_dtype == 1 and m.ingest_stats["blocks"] > 10
+    assert m.ingest_stats["widened_mid_pass"] == (late_iteration > 3)      # (iteration 1 decides before the pass starts)
+    # one pass: the first iteration is loaded once (it fixes widths and dtype and is reused as block 0), the iterations of the
+    # block that did not fit twice, everything else once
+    twice = [k for k, v in src.loads.items() if v > 1]
+    assert max(src.loads.values()) <= 2 and len(twice) <= 3 and all(abs(k - late_iteration) <= 3 for k in twice)
+    if late_iteration > 3:
+        assert src.loads[1] == 1
+    X = np.concatenate([its[i]["Xp"] for i in sorted(its) if i <= m.maxIter])
+    assert np.array_equal(st.Xp.to_host().reshape(-1, 10), X)
+    assert np.array_equal(st.Xc.to_host().reshape(-1, 10), np.concatenate([its[i]["Xc"] for i in sorted(its) if i <= m.maxIter]))
+
+
+def _widen_case(h):
+    rng = np.random.default_rng(5)
+    for n in (0, 1, 3, 4, 1023, 70001):
+        x = rng.standard_normal(n + 1).astype(np.float32)
+        x[: min(n, 3)] = [np.nan, np.inf, -0.0][: min(n, 3)]
+        for shift in (0, 1):                      # aligned and unaligned source
+            src = h.to_device(x)
+            dst = h.alloc(max(n, 1), np.float64)
+            h.widen_f32(src.offset(shift), dst, n)
+            h.sync()
+            got = dst.to_host()[:n]
+            want = x[shift: shift + n].astype(np.float64)
+            assert np.array_equal(got.view(np.uint64), want.view(np.uint64))
+            src.free()
+            dst.free()
+    a = h.alloc(16, np.float64)
+    with pytest.raises(Exception, match="overlap"):
+        h.widen_f32(a, a, 8)
+    a.free()
+
+
+def test_widen_f32_oracle(oracle_h):
+    _widen_case(oracle_h)
+
+
+@pytest.mark.gpu
+def test_widen_f32_hip(hip_h):
+    _widen_case(hip_h)

@@ -150,6 +150,24 @@ def _plugin_case(h, monkeypatch):
     assert np.array_equal(model.fluxMatrix, g["fluxMatrix"])
     assert abs(model.JtargetSS / float(g["JtargetSS"]) - 1) < 1e-6
     assert len(model.validation_models) == 2 and all(v.JtargetSS > 0 for v in model.validation_models)
+    # what the later plugins do with this object (restart_driver.py:1142: `pickle.dump(model, ...)`): the plugin's model is an
+    # importable class that carries its featurizer by NAME
+    assert type(model) is mm.modelWE and model._featurizer_spec == f"{__name__}.flatten_featurizer"
+    blob = pickle.dumps(model, protocol=4)
+    assert b"flatten_featurizer" in blob
+    m2 = pickle.loads(blob)
+    assert type(m2) is mm.modelWE and m2._featurizer is None and m2._h is None
+    xyz = np.arange(24.0).reshape(2, 4, 3)
+    assert np.array_equal(m2.processCoordinates(xyz), xyz.reshape(2, 12)) and m2._featurizer is flatten_featurizer
+    assert np.array_equal(m2.fluxMatrix, model.fluxMatrix) and np.array_equal(m2.pSS, model.pSS)
+    m2.attach(h)
+    it = 5
+    m2.load_iter_data(it)
+    assert np.array_equal(m2.clusters.predict(golden_iterations(g)[it]["Xc"]), model.dtrajs[it - 1])
+    # a featurizer given as an object (not a path) is carried as that object: picklable iff the function is importable
+    m3 = mm.modelWE(h)
+    m3.set_featurizer(flatten_featurizer)
+    assert pickle.loads(pickle.dumps(m3))._featurizer is flatten_featurizer
 
 
 def test_westpa_plugin_shim_oracle(oracle_h, monkeypatch):
