@@ -14,6 +14,7 @@
 #include <time.h>
 
 typedef double v4f64 __attribute__((ext_vector_type(4)));
+typedef int v4i32 __attribute__((ext_vector_type(4)));
 
 // Pointers that arrive inside a descriptor are generic to the compiler (flat_load/flat_atomic, which tie up both
 // memory counters); every one of them is device memory, so the kernels address them as such.
@@ -947,6 +948,9 @@ extern "C" int hamsm_kmeans_seed(hamsm_ctx *c, int s, const void *X, int dt, int
 }
 
 // ---- minibatch steps ------------------------------------------------------------------------------
+struct SuspEntry {  // look-ahead blocks: batch row r is nearest to j1, j2 or j3 (-1: none), whichever the centroids of its step say
+  int r, j1, j2, j3;
+};
 struct StepDev {
   const void *X;         // frame 0 of the step's call
   const int32_t *rows;   // batch row list (nullable = identity)
@@ -971,6 +975,38 @@ struct StepDev {
   int32_t *halt;         // the stratum's stop word: steps with idx >= *halt are not applied
   int32_t *reason;       // HAMSM_STOP_* of the stratum
 };
+// look-ahead blocks (k_step_assign_ahead / k_step_update_ahead): what a step of a block carries besides its StepDev
+// (kept apart: the step-by-step kernels take their descriptors by value and every byte of them is on the launch path)
+struct AheadDev {
+  int pos, pad_;              // position of the step among its stratum's steps of the block (0 = the block's first); < 0: not in a block
+  double *slot;               // [1] largest centroid displacement (Euclidean, against the block's snapshot) after this step
+  const double *prev_slot;    // the slot of the stratum's previous step in the block (null at position 0)
+  const double *ref_slot;     // a slot of the previous block: what this step's bound is derived from (null: bound 0)
+  double ref_scale;           //   bound = ref_scale * *ref_slot
+  double *bound;              // [1] the bound the E-step used (read back by the M-step that checks it)
+  double *Csnap;              // [K][D] the stratum's centroids at the block's start
+  SuspEntry *tab;             // [AHEAD_TAB_CAP] rows the bound cannot decide, with their candidate centroids
+  int32_t *cnt;               // [4]: entries appended to `tab`; flags of rows the block cannot serve (1 table full, 2 open row at
+                              //      position 0, 4 not finite, 8 list of open rows full); open rows appended to `hl`
+  // open rows: more than three candidates.  Their distance to EVERY centroid is evaluated exactly, one step ahead: the wave
+  // that has just updated centroid j (the M-step of the stratum's previous step in the block) computes the contract's d(x, c_j)
+  // for the next step's open rows; the next step's waves take the first minimum over j.
+  int32_t *hl;                // [hcap] this step's open rows
+  double *hd;                 // [hcap][kst] their distances, written by the previous step's M-step
+  double *td;                 // [AHEAD_TAB_CAP][3] the distances of the table's candidates, written by the previous step's M-step
+  const int32_t *nx_cnt;      // the stratum's NEXT step in the block (null at the block's last position): its counters,
+  const int32_t *nx_hl;       //   its open rows,
+  const double *nx_Xg;        //   its batch copy,
+  double *nx_hd;              //   where the open rows' distances go,
+  const SuspEntry *nx_tab;    //   its table
+  double *nx_td;              //   and where its candidates' distances go
+  int hcap, kst;              // most open rows per step (by the row length: they wait in LDS); row stride of hd
+};
+struct AheadPack {
+  AheadDev a[4];
+};
+#define AHEAD_TAB_CAP 256
+#define HAMSM_STOP_AHEAD 100  // internal: a look-ahead block was given up at this step; run_steps relaunches from it itself
 // what the next call's E-step will gather: its lines are pulled towards this XCD's L2 while this call computes
 struct StepNext {
   const void *X;
@@ -1039,6 +1075,17 @@ template <bool BYVAL>
 __device__ __forceinline__ StepDev load_step(const StepDev *steps, const StepPack &pk, unsigned i) {
   if constexpr (BYVAL) return pk.s[i];  // scalar loads from the kernel-argument segment
   static_assert(sizeof(StepDev) % 8 == 0, "StepDev is copied as 64-bit words");
+  union {
+    StepDev d;
+    unsigned long long w[sizeof(StepDev) / 8];
+  } u;
+  const GAS unsigned long long *src = (const GAS unsigned long long *)(steps + i);
+#pragma unroll
+  for (unsigned q = 0; q < sizeof(StepDev) / 8; q++) u.w[q] = src[q];
+  return u.d;
+}
+
+__device__ __forceinline__ StepDev load_step_mem(const StepDev *steps, unsigned i) {
   union {
     StepDev d;
     unsigned long long w[sizeof(StepDev) / 8];
@@ -1440,6 +1487,654 @@ __global__ __launch_bounds__(256) void k_step_update(const StepDev *__restrict__
   SPROF(1, 5)
 #endif
   SPROF_FLUSH(1)
+}
+
+// ---- look-ahead blocks -----------------------------------------------------------------------------------------
+// The chain E(t) -> M(t) -> E(t+1) -> ... is what bounds a training pass: two dependent launches per WE iteration.  But the
+// centroids of a stratum move less and less (by ~1/count per step), and a label is an argmin: it survives any displacement that is
+// small against the gap between a row's nearest and second-nearest centroid.  So the E-steps of G consecutive iterations of a
+// stratum run in ONE launch (k_step_assign_ahead) against the centroids as they stand at the block's start, and the chain that is
+// left is one launch per iteration (k_step_update_ahead).
+//
+// Certificate.  Write S = |x|, R_j = |x - c_j| for the centroids at the block's start, and let every centroid have moved by at
+// most B (Euclidean) when step s is applied.  The contract's distances are d_j = csq_j - 2 x.c_j (f64 fma chains), i.e.
+// R_j^2 - S^2 up to a rounding error of at most g (2S + R_j)^2, g = (D + 6) 2^-53.  Centroid j cannot be the argmin of step s if
+//     (R_j - B)^2 - g' (..)  >  (R_1 + B)^2 + g' (..)   <=   R_j^2 - R_1^2 > 2 B (R_1 + R_j) + k [(2S + R_j + B)^2 + (2S + R_1 + B)^2],
+// with R_j > 2B, where 1 is the nearest centroid at the block's start and k = 2^-38 covers every rounding above, and the 2^-40
+// by which the ranked values are perturbed (below), many times over.  The left side grows faster in R_j than the right once
+// R_j > 2B, so the centroids are tested in order of distance: the second-nearest passes -> the label is FINAL and the row joins
+// its centroid's membership bitmap as in the step-by-step E-step; else the first that passes ends the row's list of CANDIDATES
+// (2 or 3 of them: the row is undecided and goes to the step's table); a fourth candidate, a row or a distance that is not
+// finite, or a full table make the block unservable from that step on (`cnt[1]`).  Exact ties of the step-by-step rule (first
+// minimum wins) are undecided rows here, B = 0 included.
+// Ranking: the sweep keeps each lane's four smallest distances in order with a min / max network (7 instructions per
+// distance); the centroid's index rides in the 12 low mantissa bits of the value (a relative change below 2^-40, charged to k).
+//
+// The bound B of position s is a GUESS made when the block is launched: alpha x (s / s') x the displacement the stratum's
+// previous block measured at position s'.  The M-step of position s checks it against the displacement the block has really
+// seen so far (`slot`, maintained by the M-steps: each adds the largest |c_new - c_snapshot| of the centroids it moved, and
+// carries its predecessor's value for those it did not) -- and checks `cnt[1]`.  If either fails the stratum's chain stops at
+// that step with HAMSM_STOP_AHEAD, nothing of it applied, and run_steps relaunches from there, the failed step exact.
+// Undecided and open rows are decided one step ahead, by the waves that own the centroids: a wave that has just updated
+// centroid j (the M-step of the stratum's previous step in the block) evaluates the contract's distance d(x, c_j) -- an fma chain
+// in ascending feature order against the row it holds in registers / LDS -- for the next step's open rows and for the entries
+// of the next step's table that name j, and leaves them in memory; the next step's waves only compare (first minimum wins).
+// No wave ever reads another wave's centroid while it may be changing.  A block's first step needs none of this: its E-step
+// ran against the very centroids its M-step sees, so its labels are the step-by-step rule's, taken exactly.
+// Everything else -- membership in sample order, the update, counts, ||c||^2, the low-count tests, the stop protocol -- is the
+// step-by-step path's, so the results are the same bits.
+#define AHEAD_KAPPA 3.637978807091713e-12   // 2^-38
+#define AHEAD_EPS 9.5367431640625e-07       // 2^-20
+#define AHEAD_BIG 1e300                     // "no such centroid" (finite: the index bits must not turn an infinity into a NaN)
+#define AHEAD_STRIP 2048                    // ints of LDS per wave of the M-step (8 KB: the member list, or undecided rows)
+#define AHEAD_HX 896                        // doubles of LDS per wave for the next step's open rows (60 KB per workgroup in all)
+#define AHEAD_HCAP 32                       // most open rows per step
+#define AHEAD_KMAX 4096                     // centroids per stratum the 12 index bits can name
+
+__device__ __forceinline__ double f64_min(double a, double b) {
+  double r;
+  asm("v_min_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+__device__ __forceinline__ double f64_max(double a, double b) {
+  double r;
+  asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+// k1 <= k2 <= k3 <= k4 keep the four smallest keys seen
+__device__ __forceinline__ void top4_insert(double k, double &k1, double &k2, double &k3, double &k4) {
+  double t;
+  t = f64_min(k, k1), k = f64_max(k, k1), k1 = t;
+  t = f64_min(k, k2), k = f64_max(k, k2), k2 = t;
+  t = f64_min(k, k3), k = f64_max(k, k3), k3 = t;
+  k4 = f64_min(k, k4);
+}
+__device__ __forceinline__ double key_of(double d, int j) {
+  return __hiloint2double(__double2hiint(d), (int)(((unsigned)__double2loint(d) & 0xFFFFF000u) | (unsigned)j));
+}
+__device__ __forceinline__ int key_index(double k) { return __double2loint(k) & 0xFFF; }
+
+template <typename XT, int KS, int JB>
+__global__ __launch_bounds__(256) void k_step_assign_ahead(const StepDev *__restrict__ steps, const AheadDev *__restrict__ aheads,
+                                                           const int *__restrict__ ylist, int64_t ldx, int D) {
+  const int yi = ((const GAS int *)ylist)[blockIdx.y];
+  const StepDev sdesc = load_step_mem(steps, (unsigned)yi);
+  const GAS AheadDev *ahp = gp(aheads + yi);
+  const StepG st(sdesc);
+  const long long r0 = (long long)blockIdx.x * 16;
+  if (r0 >= st.n_b) return;
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const GAS XT *X = (const GAS XT *)st.X;
+  // the bound of this position (every workgroup derives the same value; workgroup 0 records it for the M-step)
+  const double *ref_slot = ahp->ref_slot;
+  const double ref_scale = ahp->ref_scale;
+  double B = 0.0;
+  if (ref_slot) B = ref_scale * *gp(ref_slot);
+  const long long r = r0 + (lane & 15);
+  const long long rc = r < st.n_b ? r : st.n_b - 1;
+  const long long f = st.rows ? (long long)st.rows[rc] : rc;
+  const int njt = (st.K + 15) >> 4;
+  const double inf = __builtin_huge_val();
+  double b[JB][KS], cs[JB][4];
+  auto load_group = [&](int t0) {
+#pragma unroll
+    for (int u = 0; u < JB; u++) {
+      const int jt = t0 + 4 * u < njt ? t0 + 4 * u : njt - 1;
+#pragma unroll
+      for (int q = 0; q < 4; q++) cs[u][q] = st.csq[jt * 16 + (lane >> 4) + 4 * q];
+#pragma unroll
+      for (int ks = 0; ks < KS; ks++) b[u][ks] = st.Bpack[((size_t)jt * KS + ks) * 64 + lane];
+    }
+  };
+  load_group(wv);
+  double a[KS];
+#pragma unroll
+  for (int ks = 0; ks < KS; ks++) {
+    const int k = ks * 4 + (lane >> 4);
+    a[ks] = (double)X[f * ldx + (k < D ? k : D - 1)];
+  }
+  __shared__ double sk[4][4][16];
+  __shared__ int snan[4];
+  if (ahp->pos == 0) {
+    // the block's first step: these ARE the centroids its M-step will see -- the step-by-step E-step's rule, exactly
+    double bd = inf;
+    int bi = 0x7fffffff;
+    for (int t0 = wv; t0 < njt; t0 += 4 * JB) {
+      if (t0 != wv) load_group(t0);
+#pragma unroll
+      for (int u = 0; u < JB; u++) {
+        const int jt = t0 + 4 * u;
+        if (jt < njt) {
+          v4f64 acc = (v4f64){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+          for (int ks = 0; ks < KS; ks++) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(b[u][ks], a[ks], acc, 0, 0, 0);
+          const int j0 = jt * 16 + (lane >> 4);
+#pragma unroll
+          for (int q = 0; q < 4; q++) {
+            const double d = __builtin_fma(-2.0, acc[q], cs[u][q]);
+            const bool lt = d < bd;
+            bd = lt ? d : bd;
+            bi = lt ? j0 + 4 * q : bi;
+          }
+        }
+      }
+    }
+    if (wv == 1) {
+#pragma unroll
+      for (int ks = 0; ks < KS; ks++) st.Xg[(size_t)r * (4 * KS) + ks * 4 + (lane >> 4)] = a[ks];
+    }
+#pragma unroll
+    for (int off = 16; off <= 32; off <<= 1) {
+      const double d2 = __shfl_xor(bd, off, 64);
+      const int j2 = __shfl_xor(bi, off, 64);
+      const bool take = (d2 < bd) || (d2 == bd && j2 < bi);
+      bd = take ? d2 : bd;
+      bi = take ? j2 : bi;
+    }
+    double *sdv = &sk[0][0][0];       // [4][16] as one array (the ranking arrays are free on this path)
+    int *sji = (int *)&sk[1][0][0];   // [4][16]
+    if (lane < 16) {
+      sdv[wv * 16 + lane] = bd;
+      sji[wv * 16 + lane] = bi;
+    }
+    __syncthreads();
+    if (blockIdx.x == 0 && tid == 0) *gp(ahp->bound) = 0.0;
+    if (tid < 16 && r0 + tid < st.n_b) {
+      double d = sdv[tid];
+      int j = sji[tid];
+#pragma unroll
+      for (int w = 1; w < 4; w++) {
+        const double d2 = sdv[w * 16 + tid];
+        const int j2 = sji[w * 16 + tid];
+        const bool take = (d2 < d) || (d2 == d && j2 < j);
+        d = take ? d2 : d;
+        j = take ? j2 : j;
+      }
+      if (j == 0x7fffffff) j = 0;  // all-NaN row: label 0 like the oracle
+      const long long rr = r0 + tid;
+      __hip_atomic_fetch_or(&st.mbits[(size_t)j * sdesc.wstride + (rr >> 6)], 1ull << (rr & 63), __ATOMIC_RELAXED,
+                            __HIP_MEMORY_SCOPE_AGENT);
+    }
+    return;
+  }
+  double k1 = AHEAD_BIG, k2 = AHEAD_BIG, k3 = AHEAD_BIG, k4 = AHEAD_BIG;
+  bool odd = false;  // a distance that is not a number
+  for (int t0 = wv; t0 < njt; t0 += 4 * JB) {
+    if (t0 != wv) load_group(t0);
+#pragma unroll
+    for (int u = 0; u < JB; u++) {
+      const int jt = t0 + 4 * u;
+      if (jt < njt) {
+        v4f64 acc = (v4f64){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int ks = 0; ks < KS; ks++) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(b[u][ks], a[ks], acc, 0, 0, 0);
+        const int j0 = jt * 16 + (lane >> 4);
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+          // (rows of the last tile past K carry csq = +inf: they rank as "no such centroid")
+          const double d = __builtin_fma(-2.0, acc[q], f64_min(cs[u][q], AHEAD_BIG));
+          odd = odd || (d != d);
+          top4_insert(key_of(d, j0 + 4 * q), k1, k2, k3, k4);
+        }
+      }
+    }
+  }
+  // the batch rows as f64 for the M-step (wave 1 writes, as in the step-by-step E-step)
+  if (wv == 1) {
+#pragma unroll
+    for (int ks = 0; ks < KS; ks++) st.Xg[(size_t)r * (4 * KS) + ks * 4 + (lane >> 4)] = a[ks];
+  }
+  // |x|^2 of the lane's row (features past D were read at the clamped index: not counted)
+  double x2 = 0.0;
+#pragma unroll
+  for (int ks = 0; ks < KS; ks++) {
+    const int k = ks * 4 + (lane >> 4);
+    x2 = k < D ? __builtin_fma(a[ks], a[ks], x2) : x2;
+  }
+  x2 += __shfl_xor(x2, 16, 64);
+  x2 += __shfl_xor(x2, 32, 64);
+  // lanes l, l^16, l^32, l^48 hold the same batch row: merge their four best
+#pragma unroll
+  for (int off = 16; off <= 32; off <<= 1) {
+    const double e1 = __shfl_xor(k1, off, 64), e2 = __shfl_xor(k2, off, 64), e3 = __shfl_xor(k3, off, 64), e4 = __shfl_xor(k4, off, 64);
+    top4_insert(e1, k1, k2, k3, k4);
+    top4_insert(e2, k1, k2, k3, k4);
+    top4_insert(e3, k1, k2, k3, k4);
+    top4_insert(e4, k1, k2, k3, k4);
+  }
+  const unsigned long long oddm = __ballot(odd);
+  if (lane < 16) {
+    sk[wv][0][lane] = k1;
+    sk[wv][1][lane] = k2;
+    sk[wv][2][lane] = k3;
+    sk[wv][3][lane] = k4;
+  }
+  if (lane == 0) snan[wv] = (int)((oddm | (oddm >> 16) | (oddm >> 32) | (oddm >> 48)) & 0xFFFF);  // by batch row
+  __syncthreads();
+  if (blockIdx.x == 0 && tid == 0) *gp(ahp->bound) = B;
+  if (tid < 16 && r0 + tid < st.n_b) {
+    k1 = sk[0][0][tid], k2 = sk[0][1][tid], k3 = sk[0][2][tid], k4 = sk[0][3][tid];
+#pragma unroll
+    for (int w = 1; w < 4; w++) {
+#pragma unroll
+      for (int q = 0; q < 4; q++) top4_insert(sk[w][q][tid], k1, k2, k3, k4);
+    }
+    const bool row_odd = ((snan[0] | snan[1] | snan[2] | snan[3]) >> tid) & 1;
+    const long long rr = r0 + tid;
+    GAS int32_t *cnt = gp(ahp->cnt);
+    const double S = __builtin_sqrt(x2);
+    const double D1 = k1 + x2, R1 = __builtin_sqrt(D1 > 0.0 ? D1 : 0.0);
+    // true when the centroid ranked with key kj cannot become the argmin under any displacement <= B of every centroid
+    auto out_of_reach = [&](double kj) {
+      if (kj >= 1e299) return true;  // no such centroid
+      const double Dj = kj + x2, Rj = __builtin_sqrt(Dj > 0.0 ? Dj : 0.0);
+      const double u = 2.0 * S + Rj + B, v = 2.0 * S + R1 + B;
+      const double need = 2.0 * B * (R1 + Rj) * (1.0 + AHEAD_EPS) + AHEAD_KAPPA * (u * u + v * v);
+      return (Rj > 2.0 * B * (1.0 + AHEAD_EPS) + AHEAD_EPS * (S + Rj)) && (Dj - D1 > need);
+    };
+    const bool finite = !row_odd && (x2 < inf) && (k1 > -1e299) && (k1 < 1e299) && (B < inf);
+    const int j1 = key_index(k1), j2 = key_index(k2), j3 = key_index(k3);
+    if (finite && out_of_reach(k2)) {
+      // (result unused: a non-returning atomic)
+      __hip_atomic_fetch_or(&st.mbits[(size_t)j1 * sdesc.wstride + (rr >> 6)], 1ull << (rr & 63), __ATOMIC_RELAXED,
+                            __HIP_MEMORY_SCOPE_AGENT);
+    } else if (finite && (out_of_reach(k3) || out_of_reach(k4))) {
+      const bool three = !out_of_reach(k3);
+      const int at = __hip_atomic_fetch_add(&cnt[0], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (at < AHEAD_TAB_CAP) {
+        GAS int *e = (GAS int *)gp(ahp->tab) + 4 * at;
+        e[0] = (int)rr;
+        e[1] = j1;
+        e[2] = j2;
+        e[3] = three ? j3 : -1;
+      } else {
+        __hip_atomic_fetch_or(&cnt[1], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    } else if (finite) {
+      // an open row (a fourth candidate): every centroid's exact distance, by the M-step of the stratum's previous step
+      const int at = __hip_atomic_fetch_add(&cnt[2], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (at < ahp->hcap) gp(ahp->hl)[at] = (int)rr;
+      else __hip_atomic_fetch_or(&cnt[1], 8, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    } else {
+      __hip_atomic_fetch_or(&cnt[1], finite ? 2 : 4, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+}
+
+// M-step of a look-ahead block: k_step_update plus (i) the check of the block's bound, (ii) the low-count / zero-count tests
+// that ride on the E-step in the step-by-step path (here every workgroup evaluates them, they all see the same counts),
+// (iii) the rows the E-step left undecided or open, by the distances the previous step's waves left behind, (iv) the
+// displacement bookkeeping, (v) this centroid's distances to the NEXT step's open rows and to the rows of the next step's
+// table that name it.  One wave per centroid, descriptors in the kernel arguments.
+#define AHEAD_ITEMS 64  // rows of the next step a wave evaluates in one round (lane = row)
+template <typename XT, int H>
+__global__ __launch_bounds__(256) void k_step_update_ahead(const StepPack pk, const AheadPack ap, int64_t ldx, int D, int KS,
+                                                           double ratio) {
+  const StepDev sdesc = pk.s[blockIdx.y];
+  const AheadDev ah = ap.a[blockIdx.y];
+  const StepG st(sdesc);
+  if ((int)blockIdx.x * 4 >= st.K) return;
+  extern __shared__ int lds_i[];
+  __shared__ double shd[4];
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  int *list = lds_i + wv * AHEAD_STRIP;
+  unsigned *srow = (unsigned *)list;
+  double *swl = (double *)(list + UPD_SC);
+  const GAS double *Xg = st.Xg;
+  const int ldg = 4 * KS;
+  const int j = blockIdx.x * 4 + wv;
+  const bool active = j < st.K;
+  const int jc = active ? j : st.K - 1;  // (idle waves of the last workgroup load what the last centroid's wave loads; they store nothing)
+  const double inf = __builtin_huge_val();
+  GAS unsigned long long *mb = st.mbits + (size_t)jc * sdesc.wstride;
+  // round trip 1: everything whose address is known from the descriptor
+  const int hv = *gp(sdesc.halt);
+  const unsigned long long w0 = mb[lane];
+  const double cnt0 = st.counts[jc];
+  const double csq0 = st.csq[jc];
+  double c0[H], sn[H];
+#pragma unroll
+  for (int h = 0; h < H; h++) {
+    const int k = lane + 64 * h;
+    c0[h] = st.C[(size_t)jc * D + (k < D ? k : D - 1)];
+    sn[h] = 0.0;
+  }
+  const GAS double *snap = gp((const double *)ah.Csnap);
+  if (ah.pos > 0) {
+#pragma unroll
+    for (int h = 0; h < H; h++) {
+      const int k = lane + 64 * h;
+      sn[h] = snap[(size_t)jc * D + (k < D ? k : D - 1)];
+    }
+  }
+  const double seen = ah.prev_slot ? *gp(ah.prev_slot) : 0.0;
+  const double bound = *gp((const double *)ah.bound);
+  const GAS int32_t *cnt = gp((const int32_t *)ah.cnt);
+  const int n_und = cnt[0], unserved = cnt[1];
+  int n_open = cnt[2];
+  n_open = n_open < ah.hcap ? n_open : ah.hcap;
+  const int r_open = gp((const int32_t *)ah.hl)[lane & (AHEAD_HCAP - 1)];
+  // this step's table: an entry per lane, with the candidates' distances the previous step's waves left behind
+  const GAS v4i32 *tab = (const GAS v4i32 *)gp(ah.tab);
+  const GAS double *td = gp((const double *)ah.td);
+  v4i32 ent = tab[lane];  // (entries past n_und are never looked at)
+  double td0 = td[3 * lane], td1 = td[3 * lane + 1], td2 = td[3 * lane + 2];
+  // the next step's rows this wave owes a distance to: its open rows, then the entries of its table that name this centroid.
+  // Lists now, rows into LDS behind them: both round trips overlap with this step's own
+  int n_nx = 0, n_nt = 0;
+  if (ah.nx_cnt) {
+    n_nt = gp(ah.nx_cnt)[0];
+    n_nx = gp(ah.nx_cnt)[2];
+  }
+  n_nx = n_nx < ah.hcap ? n_nx : ah.hcap;
+  n_nt = n_nt < AHEAD_TAB_CAP ? n_nt : AHEAD_TAB_CAP;
+  const int DPH = (D + 1) & ~1;
+  const int cap = AHEAD_HX / DPH;  // rows the LDS holds per round (>= hcap)
+  double *hx = (double *)(lds_i + 4 * AHEAD_STRIP) + wv * AHEAD_HX;
+  int *meta = lds_i + 4 * AHEAD_STRIP + 2 * 4 * AHEAD_HX + wv * (2 * AHEAD_ITEMS);  // per item: where its distance goes, its row
+  const GAS double *nXg = gp(ah.nx_Xg);
+  const GAS v4i32 *ntab = (const GAS v4i32 *)gp(ah.nx_tab);
+  int n_items = 0;  // items of the first round: staged in LDS now, evaluated at the end
+  // stage rows `cnt_` (row numbers by lane, in `rows_l`) at item slots [at, at + cnt_): all lanes load a row's features
+  auto stage = [&](int rows_l, int cnt_, int at) {
+    for (int h0 = 0; h0 < cnt_; h0 += 4) {
+      double t[4][H];
+#pragma unroll
+      for (int q = 0; q < 4; q++) {
+        const int rq = __shfl(rows_l, h0 + q < cnt_ ? h0 + q : cnt_ - 1, 64);
+#pragma unroll
+        for (int h = 0; h < H; h++) {
+          const int k = lane + 64 * h;
+          t[q][h] = nXg[(size_t)rq * ldg + (k < D ? k : D - 1)];
+        }
+      }
+#pragma unroll
+      for (int q = 0; q < 4; q++)
+        if (h0 + q < cnt_) {
+#pragma unroll
+          for (int h = 0; h < H; h++) {
+            const int k = lane + 64 * h;
+            if (k < D) hx[(at + h0 + q) * DPH + k] = t[q][h];
+          }
+        }
+    }
+  };
+  if (active && n_nx > 0) {
+    const int r_nx = gp(ah.nx_hl)[lane & (AHEAD_HCAP - 1)];
+    stage(r_nx, n_nx, 0);
+    if (lane < n_nx) {
+      meta[2 * lane] = -1 - lane;  // an open row: its distance goes to nx_hd[lane][j]
+      meta[2 * lane + 1] = 0;
+    }
+    n_items = n_nx;
+  }
+  int nt_done = 0;  // entries of the next table looked at so far
+  if (active && n_nt > 0) {
+    // the first 64 entries of the next step's table (the later ones, and what does not fit the LDS, wait for the end)
+    const v4i32 e = ntab[lane];
+    const int slot = (lane < n_nt) ? (e.y == j ? 0 : (e.z == j ? 1 : (e.w == j ? 2 : -1))) : -1;
+    const unsigned long long mm = __ballot(slot >= 0);
+    const int mine = __popcll(mm);
+    const int room = (cap < AHEAD_ITEMS ? cap : AHEAD_ITEMS) - n_items;
+    if (mine <= room) {
+      const int rank = __popcll(mm & ((1ull << lane) - 1));
+      // compact the rows of my entries to lanes 0 .. mine-1
+      if (slot >= 0) {
+        meta[2 * (n_items + rank)] = 3 * lane + slot;  // where the distance goes: nx_td[3 * entry + slot]
+        meta[2 * (n_items + rank) + 1] = e.x;
+      }
+      const int rows_l = lane < mine ? meta[2 * (n_items + lane) + 1] : 0;
+      if (mine) stage(rows_l, mine, n_items);
+      n_items += mine;
+      nt_done = n_nt < 64 ? n_nt : 64;
+    }
+  }
+  double cj_t = -inf;  // this thread's share of the stratum's counts, for the tests
+  int z_t = 0;
+  if (st.flags & 6)
+    for (int q = tid; q < st.K; q += 256) {
+      const double cq = st.counts[q];
+      z_t |= (cq == 0.0);
+      cj_t = cq > cj_t ? cq : cj_t;
+    }
+  if (st.idx >= hv) return;  // the stratum's chain stopped before this step
+  // (i) the block's premises for this step
+  if ((!(seen <= bound) || unserved) && ratio >= 0.0) {  // (ratio < 0: timing experiments that ignore the premises -- wrong results)
+    if (blockIdx.x == 0 && tid == 0) {
+      *gp(sdesc.halt) = st.idx;
+      *gp(sdesc.reason) = HAMSM_STOP_AHEAD;
+    }
+    return;
+  }
+  // (ii) _kmeans.py:1645 for the stratum's previous step / :2037 before this one (k_step_assign's block, evaluated by everybody)
+  if (st.flags & 6) {
+    double mx = cj_t;
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+      const double o = __shfl_xor(mx, off, 64);
+      mx = o > mx ? o : mx;
+    }
+    if (lane == 0) shd[wv] = mx;
+    __syncthreads();
+    mx = shd[0];
+#pragma unroll
+    for (int w = 1; w < 4; w++) mx = shd[w] > mx ? shd[w] : mx;
+    int any_low = 0;
+    if (st.flags & 4) {
+      const double thr = ratio * mx;
+      int low = 0;
+      for (int q = tid; q < st.K; q += 256) low += st.counts[q] < thr;
+      if (low && blockIdx.x == 0)
+        __hip_atomic_fetch_add((GAS int32_t *)gp(sdesc.prev_report) + 1, low, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      any_low = __syncthreads_or(low);
+    }
+    const int any_z = __syncthreads_or((st.flags & 2) ? z_t : 0);
+    if (any_low || any_z) {
+      if (blockIdx.x == 0 && tid == 0) {
+        if (any_low) {
+          *gp(sdesc.halt) = st.idx;
+          *gp(sdesc.reason) = HAMSM_STOP_LOW;
+        } else {
+          st.report[0] = 1;
+          *gp(sdesc.halt) = st.idx;
+          *gp(sdesc.reason) = HAMSM_STOP_ZERO;
+        }
+      }
+      return;
+    }
+  }
+  GAS double *slot = gp(ah.slot);
+  if (blockIdx.x == 0 && tid == 0 && ah.pos > 0)  // centroids that do not move at this step keep the displacement seen so far
+    __hip_atomic_fetch_max((GAS unsigned long long *)slot, (unsigned long long)__double_as_longlong(seen), __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_AGENT);
+  if (!active) return;
+  if (ah.pos == 0) {  // the block's snapshot: this centroid as it stands before the block's first update
+#pragma unroll
+    for (int h = 0; h < H; h++) {
+      const int k = lane + 64 * h;
+      sn[h] = c0[h];
+      if (k < D) ((GAS double *)snap)[(size_t)j * D + k] = c0[h];
+    }
+  }
+  unsigned long long w = w0;
+  // (iii-a) open rows: first minimum over all centroids of the distances the previous step's waves left behind
+  for (int h = 0; h < n_open; h++) {
+    const GAS double *hd = gp((const double *)ah.hd) + (size_t)h * ah.kst;
+    double bd = inf;
+    int bj = 0x7fffffff;
+    for (int q = lane; q < st.K; q += 64) {  // (a lane's centroids ascend: strict < keeps its lowest index)
+      const double dq = hd[q];
+      const bool lt = dq < bd;
+      bd = lt ? dq : bd;
+      bj = lt ? q : bj;
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+      const double d2 = __shfl_xor(bd, off, 64);
+      const int j2 = __shfl_xor(bj, off, 64);
+      const bool take = (d2 < bd) || (d2 == bd && j2 < bj);
+      bd = take ? d2 : bd;
+      bj = take ? j2 : bj;
+    }
+    if (bj == 0x7fffffff) bj = 0;  // (no distance is a number: label 0 like the step-by-step rule)
+    const int rh = __shfl(r_open, h, 64);
+    if (bj == j && lane == (rh >> 6)) w |= 1ull << (rh & 63);
+  }
+  // (iii-b) undecided rows: the first minimum among the entry's candidates, by the distances left behind
+  {
+    const int nt = n_und < AHEAD_TAB_CAP ? n_und : AHEAD_TAB_CAP;
+    for (int base = 0; base < nt; base += 64) {
+      if (base) {
+        ent = tab[base + lane];
+        td0 = td[3 * (base + lane)], td1 = td[3 * (base + lane) + 1], td2 = td[3 * (base + lane) + 2];
+      }
+      // ascending centroid index is not the entry's order: strictly smaller, or equal with the lower index, replaces
+      double bd = td0;
+      int bj = ent.y;
+      bool take = (td1 < bd) || (td1 == bd && ent.z < bj) || (bd != bd && td1 == td1);
+      bd = take ? td1 : bd;
+      bj = take ? ent.z : bj;
+      take = ent.w >= 0 && ((td2 < bd) || (td2 == bd && ent.w < bj) || (bd != bd && td2 == td2));
+      bd = take ? td2 : bd;
+      bj = take ? ent.w : bj;
+      unsigned long long mm = __ballot(base + lane < nt && bj == j);
+      while (mm) {
+        const int src = __builtin_ctzll(mm);
+        mm &= mm - 1;
+        const int rr = __shfl(ent.x, src, 64);
+        if (lane == (rr >> 6)) w |= 1ull << (rr & 63);
+      }
+    }
+  }
+  // (the rest is k_step_update; batches of a look-ahead block have at most 4096 rows: one block of bitmap words)
+  if (w0) mb[lane] = 0ull;
+  const bool weighted = st.wf != nullptr;
+  double acc[H];
+#pragma unroll
+  for (int h = 0; h < H; h++) acc[h] = c0[h] * cnt0;
+  double wsum = 0.0;
+  const int pc = __popcll(w);
+  int inc = pc;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const int t = __shfl_up(inc, off, 64);
+    inc += lane >= off ? t : 0;
+  }
+  const int excl = inc - pc, blk = __shfl(inc, 63, 64);
+  for (int p0 = 0; p0 < blk; p0 += UPD_SC) {
+    {
+      unsigned long long t = w;
+      int idx = excl - p0;
+      while (t) {
+        const int bit = __builtin_ctzll(t);
+        t &= t - 1;
+        if (idx >= 0 && idx < UPD_SC) srow[idx] = (unsigned)(lane * 64 + bit);
+        idx++;
+      }
+    }
+    const int np = blk - p0 < UPD_SC ? blk - p0 : UPD_SC;
+    for (int m0 = 0; m0 < np; m0 += 64 / H) {
+      const int cm = np - m0 < 64 / H ? np - m0 : 64 / H;
+      if (weighted) {
+        if (lane < cm) {
+          const long long r = srow[m0 + lane];
+          swl[lane] = st.wf[st.rows ? (long long)st.rows[r] : r];
+        }
+        for (int q = 0; q < cm; q++) wsum = wsum + swl[q];
+      }
+      if (cm <= 16 / H) upd_add_listed<16 / H, H>(acc, Xg, ldg, srow + m0, swl, weighted, 0, cm, D, lane);
+      else if (cm <= 32 / H) upd_add_listed<32 / H, H>(acc, Xg, ldg, srow + m0, swl, weighted, 0, cm, D, lane);
+      else upd_add_listed<64 / H, H>(acc, Xg, ldg, srow + m0, swl, weighted, 0, cm, D, lane);
+    }
+  }
+  if (!weighted) wsum = (double)blk;
+  const bool moved = blk > 0 && wsum > 0;  // (no member, or no weight: centre unchanged, pyx:87 / :105-108)
+  const bool owes = n_items > 0 || nt_done < n_nt;
+  if (!moved && !owes) return;
+  double *vb = (double *)list;
+  double a = csq0;
+  if (moved) {
+    const double cnt1 = cnt0 + wsum;
+    const double alpha = 1.0 / cnt1;
+    double v[H], dsq = 0.0;
+#pragma unroll
+    for (int h = 0; h < H; h++) {
+      const int k = lane + 64 * h;
+      v[h] = acc[h] * alpha;
+      if (k < D) {
+        st.C[(size_t)j * D + k] = v[h];
+        st.Bpack[((size_t)(j >> 4) * KS + (k >> 2)) * 64 + (k & 3) * 16 + (j & 15)] = v[h];
+        const double t = v[h] - sn[h];
+        dsq += t * t;
+      }
+    }
+    if (lane == 0) st.counts[j] = cnt1;
+    // (iv) how far this centroid now is from the block's snapshot (any summation order: the factor covers it; NaN and inf
+    // stay what they are and fail the next step's check)
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) dsq += __shfl_xor(dsq, off, 64);
+    if (lane == 0) {
+      const double disp = __builtin_sqrt(dsq) * (1.0 + AHEAD_EPS);
+      __hip_atomic_fetch_max((GAS unsigned long long *)slot, (unsigned long long)__double_as_longlong(disp), __ATOMIC_RELAXED,
+                             __HIP_MEMORY_SCOPE_AGENT);
+    }
+#pragma unroll
+    for (int h = 0; h < H; h++) vb[lane + 64 * h] = v[h];
+    a = 0.0;
+    for (int k = 0; k + 1 < D; k += 2) {
+      const double2 t = *(const double2 *)&vb[k];
+      a = __builtin_fma(t.x, t.x, a);
+      a = __builtin_fma(t.y, t.y, a);
+    }
+    if (D & 1) a = __builtin_fma(vb[D - 1], vb[D - 1], a);
+    if (lane == 0) st.csq[j] = a;
+  } else {
+#pragma unroll
+    for (int h = 0; h < H; h++) vb[lane + 64 * h] = c0[h];
+  }
+  // (v) what the next step needs of this centroid as it now stands: lane = row, the contract's chain over ascending k --
+  // dot = fma(c_k, x_k, dot) from +0.0, what the matrix unit accumulates for this (row, centroid) pair in k_step_assign --
+  // then d = fma(-2, dot, csq)
+  auto evaluate = [&](int n_it) {
+    const int it = lane < n_it ? lane : 0;
+    const double *xs = hx + it * DPH;
+    double dot = 0.0;
+    for (int k = 0; k < D; k++) dot = __builtin_fma(vb[k], xs[k], dot);
+    const double dl = __builtin_fma(-2.0, dot, a);
+    if (lane < n_it) {
+      const int m = meta[2 * lane];
+      if (m < 0) gp(ah.nx_hd)[(size_t)(-1 - m) * ah.kst + j] = dl;
+      else gp(ah.nx_td)[m] = dl;
+    }
+  };
+  if (n_items) evaluate(n_items);
+  // what did not fit the first round: the rest of the next step's table, `cap` rows at a time
+  for (int base = nt_done; base < n_nt; base += 64) {
+    const v4i32 e = ntab[base + lane];
+    const int slot = (base + lane < n_nt) ? (e.y == j ? 0 : (e.z == j ? 1 : (e.w == j ? 2 : -1))) : -1;
+    unsigned long long mm = __ballot(slot >= 0);
+    while (mm) {
+      // the first `cap` of the entries still open
+      unsigned long long take = 0;
+      int got = 0;
+      unsigned long long t = mm;
+      while (t && got < cap && got < AHEAD_ITEMS) {
+        take |= t & (~t + 1);
+        t &= t - 1;
+        got++;
+      }
+      mm &= ~take;
+      const bool in = (take >> lane) & 1;
+      const int rank = __popcll(take & ((1ull << lane) - 1));
+      if (in) {
+        meta[2 * rank] = 3 * (base + lane) + slot;
+        meta[2 * rank + 1] = e.x;
+      }
+      const int rows_l = lane < got ? meta[2 * lane + 1] : 0;
+      stage(rows_l, got, 0);
+      evaluate(got);
+    }
+  }
 }
 
 // block-wide reductions over 256 threads (4 waves); every thread gets the result
@@ -2746,6 +3441,24 @@ static int launch_persist(hamsm_ctx *c, const StepDev *d_steps, const int *d_cof
   return HAMSM_OK;
 }
 
+// the E-steps of one look-ahead block (descriptors in memory: a throughput kernel, one dependent load does not matter)
+template <typename XT>
+static int launch_assign_ahead(hamsm_ctx *c, hipStream_t q, const StepDev *d_steps, const AheadDev *d_aheads, const int *d_ylist,
+                               int ny, long long max_nb, int64_t ldx) {
+  if (ny <= 0 || max_nb <= 0) return HAMSM_OK;
+  const dim3 grid((unsigned)((max_nb + 15) / 16), (unsigned)ny);
+  switch (c->KS) {
+#define CASE(KSV, JBV)                                                                                                  \
+  case KSV:                                                                                                             \
+    hipLaunchKernelGGL((k_step_assign_ahead<XT, KSV, JBV>), grid, dim3(256), 0, q, d_steps, d_aheads, d_ylist, ldx, c->D); \
+    break;
+    CASE(1, 8) CASE(2, 8) CASE(3, 8) CASE(4, 8) CASE(6, 4) CASE(8, 4) CASE(12, 2) CASE(16, 2) CASE(24, 1) CASE(32, 1)
+#undef CASE
+    default: return hamsm_fail(c, HAMSM_ENOTSUP, "look-ahead E-step: KS=%d", c->KS);
+  }
+  return HAMSM_OK;
+}
+
 // steps [0,n): consecutive steps of distinct strata share launches (grid.y)
 static int run_steps(hamsm_ctx *c, const void *X, int dt, int64_t ldx, const int32_t *d_rows, const double *d_w,
                      const hamsm_step *h_steps, int64_t n_steps, double ratio, const int32_t *h_perm, int64_t n_perm_total,
@@ -2781,11 +3494,31 @@ static int run_steps(hamsm_ctx *c, const void *X, int dt, int64_t ldx, const int
   const int nslot = c->S < 65535 ? c->S : 65535;
   const size_t xg_row = sizeof(double) * 4 * (size_t)c->KS;
   const size_t nb_pad = ((size_t)nb_max + 63) & ~(size_t)63;  // whole E-step tiles (up to 4 x 16 rows)
-  size_t o_xg = take(generic ? 0 : xg_row * (size_t)nslot * nb_pad);  // (the generic M-step reads the frames in place)
+  // look-ahead blocks (k_step_assign_ahead): a planned pass with row lists, a scratch slot per stratum, batches of at most 4096
+  // rows (one block of bitmap words per centroid), at most 128 features.  Every position of a block has its own batch copy,
+  // bitmaps and table of undecided rows; steps of the step-by-step path use position 0's.
+  const bool ahead_can0 = c->ahead && c->ahead_gmax >= 1 && !generic && d_rows && h_report && nslot == c->S && nb_max > 0 &&
+                         nb_max <= 4096 && !c->train_persist;  // (and at most AHEAD_KMAX centroids per stratum: below)
   int Kmax = 0;
   for (int s = 0; s < c->S; s++) Kmax = c->st[s].K > Kmax ? c->st[s].K : Kmax;
+  const bool ahead_can = ahead_can0 && Kmax <= AHEAD_KMAX;
+  const int npos = ahead_can ? c->ahead_gmax : 1;
+  size_t o_xg = take(generic ? 0 : xg_row * (size_t)nslot * npos * nb_pad);  // (the generic M-step reads the frames in place)
   const int wstride = (int)((((nb_max + 63) >> 6) + 63) & ~(int64_t)63);  // bitmap words per centroid
-  size_t o_mb = take(sizeof(unsigned long long) * (size_t)nslot * Kmax * wstride);
+  const size_t mb_bytes = sizeof(unsigned long long) * (size_t)nslot * npos * Kmax * wstride;
+  size_t o_mb = take(mb_bytes);
+  const size_t ah_words = ahead_can ? (size_t)n_steps : 0;  // per step: displacement slot, bound, two counters
+  const int ah_kst = (Kmax + 63) & ~63;
+  const int ah_dp = (c->D + 1) & ~1;
+  int ah_hcap = AHEAD_HX / ah_dp < AHEAD_HCAP ? AHEAD_HX / ah_dp : AHEAD_HCAP;  // (>= 7: D <= 128)
+  if (const char *v = getenv("HAMSM_AHEAD_HCAP")) ah_hcap = atoi(v) < ah_hcap ? (atoi(v) < 0 ? 0 : atoi(v)) : ah_hcap;  // (experiments)
+  size_t o_slot = take(sizeof(double) * 2 * ah_words), o_cnt = take(sizeof(int32_t) * 4 * ah_words),
+         o_hl = take(ahead_can ? sizeof(int32_t) * AHEAD_HCAP * (size_t)nslot * npos : 0),
+         o_hd = take(ahead_can ? sizeof(double) * AHEAD_HCAP * (size_t)ah_kst * nslot * npos : 0),
+         o_td = take(ahead_can ? sizeof(double) * 3 * AHEAD_TAB_CAP * (size_t)nslot * npos : 0),
+         o_tab = take(ahead_can ? sizeof(SuspEntry) * AHEAD_TAB_CAP * (size_t)nslot * npos : 0),
+         o_csnap = take(ahead_can ? sizeof(double) * (size_t)c->S * Kmax * c->D : 0), o_ylist = take(sizeof(int) * ah_words),
+         o_ah = take(sizeof(AheadDev) * ah_words);
   // persistent pass: control block (registration, error word, one barrier counter per stratum) and the strata's chains
   const size_t ctl_bytes = (sizeof(PersistCtl) + sizeof(unsigned) * (size_t)c->S + 15) & ~(size_t)15;
   size_t o_ctl = take(ctl_bytes), o_coff = take(sizeof(int) * ((size_t)c->S + 1)), o_cidx = take(sizeof(int) * (size_t)n_steps);
@@ -2844,8 +3577,8 @@ static int run_steps(hamsm_ctx *c, const void *X, int dt, int64_t ldx, const int
         used[h_steps[j0].stratum] = 1;
         // scratch slot = the stratum itself: chains of different strata run concurrently on different queues
         const size_t slot = nslot == c->S ? (size_t)h_steps[j0].stratum : (size_t)(j0 - i0);
-        sd[j0].Xg = (double *)(b + o_xg + slot * nb_pad * xg_row);
-        sd[j0].mbits = (unsigned long long *)(b + o_mb) + slot * Kmax * wstride;
+        sd[j0].Xg = (double *)(b + o_xg + slot * npos * nb_pad * xg_row);
+        sd[j0].mbits = (unsigned long long *)(b + o_mb) + slot * npos * Kmax * wstride;
         sd[j0].wstride = wstride;
         j0++;
       }
@@ -2861,7 +3594,7 @@ static int run_steps(hamsm_ctx *c, const void *X, int dt, int64_t ldx, const int
   HIPCHK(c, hipMemsetAsync(b + o_halt + sizeof(int32_t) * c->S, 0, sizeof(int32_t) * c->S, c->stream));
   if (n_perm_total > 0)
     HIPCHK(c, hipMemcpyAsync(b + o_perm, h_perm, sizeof(int32_t) * (size_t)n_perm_total, hipMemcpyHostToDevice, c->stream));
-  HIPCHK(c, hipMemsetAsync(b + o_mb, 0, sizeof(unsigned long long) * (size_t)nslot * Kmax * wstride, c->stream));
+  HIPCHK(c, hipMemsetAsync(b + o_mb, 0, mb_bytes, c->stream));
   const StepDev *d_steps = (const StepDev *)(b + o_steps);
   // One persistent launch for the whole run (§5.3a) when the run is a planned pass (row lists, a scratch slot per stratum,
   // more than one launch group) of at most 64 features, when HAMSM_TRAIN_PERSIST=1 asks for it (off by default: §5.3a).
@@ -2898,7 +3631,18 @@ static int run_steps(hamsm_ctx *c, const void *X, int dt, int64_t ldx, const int
     } else
       return hamsm_fail(c, HAMSM_EDEVICE, "persistent training kernel: a barrier timed out (ctl.err=%u)", perr);
   }
+  // what each stratum's chain has come to: taken from the stop words after every pass over the launches.  A pass ends for a
+  // stratum when all its steps are applied or a prediction of the host's plan failed (HAMSM_STOP_*: reported to the caller),
+  // or when a look-ahead block was given up (HAMSM_STOP_AHEAD: never reported; the next pass relaunches from that step).
+  std::vector<int32_t> fin_halt(c->S, 0x7f7f7f7f), fin_reason(c->S, 0);
   if (!persist_done) {
+  std::vector<int64_t> from(c->S, 0);  // steps of stratum s below from[s] are applied
+  std::vector<char> live(c->S, 1);
+  bool ahead_on = ahead_can && gstart.size() > 2;
+  int ahead_fails = 0;
+  const bool dbg_enq = getenv("HAMSM_DEBUG_ENQUEUE") != nullptr;
+  const bool dbg_ahead = getenv("HAMSM_DEBUG_AHEAD") != nullptr;
+  for (int pass = 0;; pass++) {
   hamsm_timer_begin(c);
   // lanes: stratum s always runs on queue s % n_lanes, so every stratum's chain stays ordered; a lane's part of a
   // launch group travels by value (<= PACK_NY strata) -- otherwise one queue and descriptors in memory
@@ -2909,6 +3653,159 @@ static int run_steps(hamsm_ctx *c, const void *X, int dt, int64_t ldx, const int
       if (++cnt[h_steps[q].stratum % n_lanes] > PACK_NY) n_lanes = 1;
   }
   if (gstart.size() <= 2 || c->S < 2 || nslot != c->S || !d_rows || generic) n_lanes = 1;  // (labels scratch is per step only with row lists)
+  auto runs = [&](int64_t q) { return live[h_steps[q].stratum] && q >= from[h_steps[q].stratum]; };
+  auto lane_of = [&](int64_t q) { return n_lanes > 1 ? h_steps[q].stratum % n_lanes : 0; };
+  // ---- plan the look-ahead blocks of this pass (host only; fills the steps' block fields before they are uploaded) ------
+  // per lane: the first `n0` launch groups step by step (a relaunch after a given-up block: none), then blocks of 1, 2, 4, ...
+  // groups (a block of one group measures the displacement its successor's bounds are derived from).  A block ends after a
+  // group that carries a re-seeding (its centroids jump) and never holds a first step after seeding.
+  struct Block {
+    size_t g0, g1;        // launch groups [g0, g1)
+    int y0, y1;           // its steps in `ylist`
+    long long max_nb;
+  };
+  const size_t NG = gstart.size() - 1;
+  std::vector<std::vector<Block>> blocks(n_lanes);
+  std::vector<int> ylist;
+  std::vector<int> block_of(NG * (size_t)n_lanes, -1);  // [g * n_lanes + l] -> index into blocks[l]
+  std::vector<AheadDev> ahd(ahead_can ? (size_t)n_steps : 0);
+  if (ahead_can)
+    for (int64_t i = 0; i < n_steps; i++) {  // (a relaunch plans afresh: back to position 0's buffers of the stratum)
+      memset(&ahd[i], 0, sizeof(AheadDev));
+      ahd[i].pos = -1;
+      const size_t slot = (size_t)h_steps[i].stratum;
+      sd[i].Xg = (double *)(b + o_xg + slot * npos * nb_pad * xg_row);
+      sd[i].mbits = (unsigned long long *)(b + o_mb) + slot * npos * Kmax * wstride;
+    }
+  if (ahead_on) {
+    for (int l = 0; l < n_lanes; l++) {
+      int seen_groups = 0, gsz = 1;
+      const int n0 = pass == 0 ? c->ahead_n0 : 0;
+      std::vector<std::vector<int64_t>> prev(c->S);  // the previous block's steps, by stratum, in position order
+      bool have_prev = false;
+      size_t g = 0;
+      while (g < NG) {
+        std::vector<int64_t> mine;
+        for (int64_t q = gstart[g]; q < gstart[g + 1]; q++)
+          if (runs(q) && lane_of(q) == l && h_steps[q].n_b > 0) mine.push_back(q);
+        if (mine.empty()) {
+          g++;
+          continue;
+        }
+        bool first_flag = false;
+        for (int64_t q : mine) first_flag = first_flag || (h_steps[q].flags & HAMSM_STEP_FIRST);
+        if (seen_groups < n0 || first_flag) {
+          seen_groups++;
+          have_prev = false;
+          g++;
+          continue;
+        }
+        // form a block of up to G groups from g on
+        int G = have_prev ? gsz : 1;
+        G = G > npos ? npos : G;
+        std::vector<std::vector<int64_t>> cur(c->S);
+        size_t ge = g;
+        int taken = 0;
+        long long max_nb = 0;
+        bool stop_after = false;
+        while (ge < NG && taken < G && !stop_after) {
+          std::vector<int64_t> m2;
+          bool ff = false;
+          for (int64_t q = gstart[ge]; q < gstart[ge + 1]; q++)
+            if (runs(q) && lane_of(q) == l && h_steps[q].n_b > 0) {
+              m2.push_back(q);
+              ff = ff || (h_steps[q].flags & HAMSM_STEP_FIRST);
+              stop_after = stop_after || sd[q].perm;
+            }
+          if (ff) break;  // (a first step after seeding: step by step)
+          bool fits = true;
+          for (int64_t q : m2) {
+            const int y = h_steps[q].stratum;
+            // a position beyond 0 needs a slot of the previous block to derive its bound from
+            if (!cur[y].empty() && (!have_prev || prev[y].empty())) fits = false;
+          }
+          if (!fits) break;
+          for (int64_t q : m2) {
+            cur[h_steps[q].stratum].push_back(q);
+            max_nb = h_steps[q].n_b > max_nb ? h_steps[q].n_b : max_nb;
+          }
+          if (!m2.empty()) taken++;
+          ge++;
+        }
+        if (ge == g) {  // nothing could be taken (cannot happen: the first group always fits); step by step
+          seen_groups++;
+          have_prev = false;
+          g++;
+          continue;
+        }
+        Block bk{g, ge, (int)ylist.size(), 0, max_nb};
+        for (int y = 0; y < c->S; y++)
+          for (size_t p_ = 0; p_ < cur[y].size(); p_++) {
+            const int64_t q = cur[y][p_];
+            AheadDev &d = ahd[q];
+            const size_t reg = (size_t)y * npos + p_;
+            d.pos = (int)p_;
+            sd[q].Xg = (double *)(b + o_xg + reg * nb_pad * xg_row);
+            sd[q].mbits = (unsigned long long *)(b + o_mb) + reg * Kmax * wstride;
+            d.slot = (double *)(b + o_slot) + 2 * q;
+            d.bound = (double *)(b + o_slot) + 2 * q + 1;
+            d.prev_slot = p_ ? (const double *)(b + o_slot) + 2 * cur[y][p_ - 1] : nullptr;
+            d.ref_slot = nullptr;
+            d.ref_scale = 0.0;
+            if (p_) {
+              const size_t nref = p_ < prev[y].size() ? p_ : prev[y].size();
+              d.ref_slot = (const double *)(b + o_slot) + 2 * prev[y][nref - 1];
+              d.ref_scale = c->ahead_alpha * (double)p_ / (double)nref;
+            }
+            d.Csnap = (double *)(b + o_csnap) + (size_t)y * Kmax * c->D;
+            d.tab = (SuspEntry *)(b + o_tab) + reg * AHEAD_TAB_CAP;
+            d.cnt = (int32_t *)(b + o_cnt) + 4 * q;
+            d.hl = (int32_t *)(b + o_hl) + reg * AHEAD_HCAP;
+            d.hd = (double *)(b + o_hd) + reg * AHEAD_HCAP * ah_kst;
+            d.td = (double *)(b + o_td) + reg * 3 * AHEAD_TAB_CAP;
+            d.hcap = ah_hcap;
+            d.kst = ah_kst;
+            d.nx_tab = nullptr;
+            d.nx_td = nullptr;
+            d.nx_cnt = nullptr;
+            d.nx_hl = nullptr;
+            d.nx_Xg = nullptr;
+            d.nx_hd = nullptr;
+            if (p_) {  // the previous step of the stratum evaluates this step's open rows
+              AheadDev &pv = ahd[cur[y][p_ - 1]];
+              pv.nx_cnt = d.cnt;
+              pv.nx_hl = d.hl;
+              pv.nx_Xg = sd[q].Xg;
+              pv.nx_hd = d.hd;
+              pv.nx_tab = d.tab;
+              pv.nx_td = d.td;
+            }
+            ylist.push_back((int)q);
+          }
+        bk.y1 = (int)ylist.size();
+        for (size_t gg = g; gg < ge; gg++) block_of[gg * n_lanes + l] = (int)blocks[l].size();
+        blocks[l].push_back(bk);
+        c->ahead_stat[0]++;
+        c->ahead_stat[1] += bk.y1 - bk.y0;
+        prev.swap(cur);
+        have_prev = true;
+        gsz = taken >= gsz ? (2 * gsz > npos ? npos : 2 * gsz) : gsz;
+        seen_groups += taken;
+        g = ge;
+      }
+    }
+  }
+  if (pass > 0 || ahead_on) {
+    HIPCHK(c, hipMemcpyAsync(b + o_steps, sd.data(), sizeof(StepDev) * n_steps, hipMemcpyHostToDevice, c->stream));
+    if (ahead_can) {
+      HIPCHK(c, hipMemsetAsync(b + o_slot, 0, sizeof(double) * 2 * ah_words, c->stream));
+      HIPCHK(c, hipMemsetAsync(b + o_cnt, 0, sizeof(int32_t) * 4 * ah_words, c->stream));
+      if (!ylist.empty()) {
+        HIPCHK(c, hipMemcpyAsync(b + o_ylist, ylist.data(), sizeof(int) * ylist.size(), hipMemcpyHostToDevice, c->stream));
+        HIPCHK(c, hipMemcpyAsync(b + o_ah, ahd.data(), sizeof(AheadDev) * ahd.size(), hipMemcpyHostToDevice, c->stream));
+      }
+    }
+  }
   hipStream_t lanes[4] = {c->stream, nullptr, nullptr, nullptr};
   if (n_lanes > 1) {
     if (!c->ev_fork) HIPCHK(c, hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
@@ -2924,7 +3821,6 @@ static int run_steps(hamsm_ctx *c, const void *X, int dt, int64_t ldx, const int
   }
   StepPack pk;
   memset(&pk, 0, sizeof(pk));
-  const bool dbg_enq = getenv("HAMSM_DEBUG_ENQUEUE") != nullptr;
   timespec ts0, ts1;
   if (dbg_enq) clock_gettime(CLOCK_MONOTONIC, &ts0);
   for (size_t g = 0; g + 1 < gstart.size(); g++) {
@@ -2935,7 +3831,7 @@ static int run_steps(hamsm_ctx *c, const void *X, int dt, int64_t ldx, const int
       bool any_perm = false;
       std::vector<int64_t> mine;
       for (int64_t q = i; q < j; q++) {
-        if (n_lanes > 1 && h_steps[q].stratum % n_lanes != l) continue;
+        if (!runs(q) || lane_of(q) != l) continue;
         mine.push_back(q);
         any_perm = any_perm || sd[q].perm;
         if (h_steps[q].n_b > max_nb) max_nb = h_steps[q].n_b;
@@ -2943,7 +3839,78 @@ static int run_steps(hamsm_ctx *c, const void *X, int dt, int64_t ldx, const int
       }
       ny = (int)mine.size();
       if (ny == 0 || max_nb <= 0) continue;
+      const int bi = ahead_on ? block_of[g * n_lanes + l] : -1;
+      if (bi >= 0) {
+        // a group inside a look-ahead block: the block's E-steps go first (one launch for all its groups), then one M-step
+        // launch per group, descriptors by value
+        const Block &bk = blocks[l][bi];
+        if (bk.g0 == g) {
+          rc = (dt == HAMSM_F32) ? launch_assign_ahead<float>(c, lanes[l], d_steps, (const AheadDev *)(b + o_ah), (const int *)(b + o_ylist) + bk.y0, bk.y1 - bk.y0, bk.max_nb, ldx)
+                                 : launch_assign_ahead<double>(c, lanes[l], d_steps, (const AheadDev *)(b + o_ah), (const int *)(b + o_ylist) + bk.y0, bk.y1 - bk.y0, bk.max_nb, ldx);
+          if (rc) {
+            hipDeviceSynchronize();
+            return rc;
+          }
+        }
+        std::vector<int64_t> in_block;
+        for (int64_t q : mine)
+          if (ahd[q].pos >= 0) in_block.push_back(q);
+        // (steps with no rows take no part in a block and launch nothing, as in the step-by-step path)
+        const size_t lds = sizeof(int) * (4 * AHEAD_STRIP) + sizeof(double) * (4 * AHEAD_HX) + sizeof(int) * (4 * 2 * AHEAD_ITEMS);
+        static const bool unsafe_timing = getenv("HAMSM_AHEAD_UNSAFE_TIMING") != nullptr;  // (experiments only: wrong results)
+        const double ratio_m = unsafe_timing ? -1.0 : ratio;
+        for (size_t c0_ = 0; c0_ < in_block.size(); c0_ += PACK_NY) {  // (descriptors by value: PACK_NY strata per launch)
+        const int nyb = (int)(in_block.size() - c0_ < PACK_NY ? in_block.size() - c0_ : PACK_NY);
+        bool any_perm = false;
+        AheadPack apk;
+        for (int q = 0; q < nyb; q++) {
+          pk.s[q] = sd[in_block[c0_ + q]];
+          apk.a[q] = ahd[in_block[c0_ + q]];
+          any_perm = any_perm || pk.s[q].perm;
+        }
+        for (int q = nyb; q < PACK_NY; q++) apk.a[q] = apk.a[0];
+        pk.n_next = 0;
+        const dim3 gu((unsigned)((maxK + 3) / 4), (unsigned)nyb);
+        if (dt == HAMSM_F32) {
+          if (c->D <= 64) hipLaunchKernelGGL((k_step_update_ahead<float, 1>), gu, dim3(256), lds, lanes[l], pk, apk, ldx, c->D, c->KS, ratio_m);
+          else hipLaunchKernelGGL((k_step_update_ahead<float, 2>), gu, dim3(256), lds, lanes[l], pk, apk, ldx, c->D, c->KS, ratio_m);
+          if (any_perm) hipLaunchKernelGGL((k_step_reassign<float, true>), dim3((unsigned)nyb), dim3(256), 0, lanes[l], d_steps, pk, ldx, c->D, c->KS, ratio);
+        } else {
+          if (c->D <= 64) hipLaunchKernelGGL((k_step_update_ahead<double, 1>), gu, dim3(256), lds, lanes[l], pk, apk, ldx, c->D, c->KS, ratio_m);
+          else hipLaunchKernelGGL((k_step_update_ahead<double, 2>), gu, dim3(256), lds, lanes[l], pk, apk, ldx, c->D, c->KS, ratio_m);
+          if (any_perm) hipLaunchKernelGGL((k_step_reassign<double, true>), dim3((unsigned)nyb), dim3(256), 0, lanes[l], d_steps, pk, ldx, c->D, c->KS, ratio);
+        }
+        }
+        continue;
+      }
+      c->ahead_stat[5] += ny;
       const StepDev *dptr = d_steps + i;
+      const bool contiguous = (int64_t)mine.size() == j - i;  // (a relaunch may run only some strata of a group)
+      if (!contiguous && (ny > PACK_NY || generic)) {
+        // only some strata of a group that travels by descriptors in memory: PACK_NY of them per launch, by value
+        for (size_t c0_ = 0; c0_ < mine.size() && !rc; c0_ += PACK_NY) {
+          const int nyc = (int)(mine.size() - c0_ < PACK_NY ? mine.size() - c0_ : PACK_NY);
+          long long mnb = 0;
+          int mK = 0;
+          bool ap = false;
+          for (int q = 0; q < nyc; q++) {
+            const int64_t sq = mine[c0_ + q];
+            pk.s[q] = sd[sq];
+            ap = ap || sd[sq].perm;
+            mnb = h_steps[sq].n_b > mnb ? h_steps[sq].n_b : mnb;
+            mK = c->st[h_steps[sq].stratum].K > mK ? c->st[h_steps[sq].stratum].K : mK;
+          }
+          pk.n_next = 0;
+          if (mnb <= 0) continue;
+          rc = (dt == HAMSM_F32) ? launch_steps<float>(c, lanes[l], nullptr, pk, nyc, mnb, mK, ldx, ratio, ap)
+                                 : launch_steps<double>(c, lanes[l], nullptr, pk, nyc, mnb, mK, ldx, ratio, ap);
+        }
+        if (rc) {
+          hipDeviceSynchronize();
+          return rc;
+        }
+        continue;
+      }
       if (ny <= PACK_NY && !generic) {
         dptr = nullptr;  // descriptors by value
         for (int q = 0; q < ny; q++) pk.s[q] = sd[mine[q]];
@@ -2952,7 +3919,7 @@ static int run_steps(hamsm_ctx *c, const void *X, int dt, int64_t ldx, const int
           // the same strata of the next group, in the same positions
           int nn = 0;
           for (int64_t q = j; q < gstart[g + 2] && nn < ny; q++) {
-            if (n_lanes > 1 && h_steps[q].stratum % n_lanes != l) continue;
+            if (!runs(q) || lane_of(q) != l) continue;
             pk.nx[nn++] = StepNext{sd[q].X, sd[q].rows, sd[q].n_b};
           }
           pk.n_next = nn;
@@ -2977,18 +3944,72 @@ static int run_steps(hamsm_ctx *c, const void *X, int dt, int64_t ldx, const int
     HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_join[l - 1], 0));
   }
   for (int64_t i : tail_checks)
-    hipLaunchKernelGGL(k_step_check, dim3(1), dim3(256), 0, c->stream, d_steps + i, ratio, (int)n_steps);
+    if (runs(i)) hipLaunchKernelGGL(k_step_check, dim3(1), dim3(256), 0, c->stream, d_steps + i, ratio, (int)n_steps);
   hamsm_timer_end(c, ST_STEP);
-  }  // !persist_done
   if (hipError_t le = hipGetLastError(); le != hipSuccess) {
     hipDeviceSynchronize();
     return hamsm_fail(c, HAMSM_EDEVICE, "step launches: %s", hipGetErrorString(le));
   }
-  if (h_report) {
+  if (!h_report) break;  // (the stepwise entry point: one step, no stop protocol)
+  // where every chain stands
+  std::vector<int32_t> hw(2 * (size_t)c->S);
+  {
+    hipError_t e = hipMemcpyAsync(hw.data(), b + o_halt, sizeof(int32_t) * 2 * c->S, hipMemcpyDeviceToHost, c->stream);
+    hipError_t es = hipStreamSynchronize(c->stream);  // always: `sd`, `ylist` and `hw` are locals the copies above read / write
+    if (e == hipSuccess) e = es;
+    if (e != hipSuccess) return hamsm_fail(c, HAMSM_EDEVICE, "minibatch_run read-back: %s", hipGetErrorString(e));
+  }
+  bool again = false;
+  for (int s_ = 0; s_ < c->S; s_++) {
+    if (!live[s_]) continue;
+    if (hw[c->S + s_] == HAMSM_STOP_AHEAD) {
+      // a look-ahead block was given up at step hw[s_] (nothing of that step applied): relaunch this stratum from there
+      from[s_] = hw[s_];
+      again = true;
+      ahead_fails++;
+      c->ahead_stat[2]++;
+      if (dbg_ahead) {
+        const AheadDev &d = ahd[hw[s_]];
+        double sb[2] = {0, 0}, seen = 0;
+        int32_t cn[4] = {0, 0, 0, 0};
+        hipMemcpy(sb, d.slot, sizeof(sb), hipMemcpyDeviceToHost);
+        hipMemcpy(cn, d.cnt, sizeof(cn), hipMemcpyDeviceToHost);
+        if (d.prev_slot) hipMemcpy(&seen, d.prev_slot, sizeof(double), hipMemcpyDeviceToHost);
+        fprintf(stderr, "[hamsm] look-ahead block of stratum %d given up at step %d (pass %d): position %d, displacement seen %.6g, "
+                "bound %.6g, undecided rows %d, open rows %d, unserved flags %d\n", s_, (int)hw[s_], pass, d.pos, seen, sb[1], cn[0], cn[2], cn[1]);
+      }
+    } else {
+      fin_halt[s_] = hw[s_];
+      fin_reason[s_] = hw[c->S + s_];
+      live[s_] = 0;
+    }
+  }
+  if (!again) break;
+  c->ahead_stat[4]++;
+  if (ahead_fails > 8 + (int)(n_steps / 128)) ahead_on = false;  // this data does not hold still: step by step from here
+  // the given-up blocks left their later positions' bitmaps and tables behind
+  HIPCHK(c, hipMemsetAsync(b + o_mb, 0, mb_bytes, c->stream));
+  for (int s_ = 0; s_ < c->S; s_++)
+    if (live[s_]) {
+      const int32_t never = 0x7f7f7f7f, zero = 0;
+      HIPCHK(c, hipMemcpyAsync(b + o_halt + sizeof(int32_t) * s_, &never, sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
+      HIPCHK(c, hipMemcpyAsync(b + o_halt + sizeof(int32_t) * (c->S + s_), &zero, sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
+    }
+  HIPCHK(c, hipStreamSynchronize(c->stream));  // (`never` / `zero` are locals)
+  }  // passes
+  }  // !persist_done
+  else if (h_report) {
     std::vector<int32_t> hw(2 * (size_t)c->S);
+    HIPCHK(c, hipMemcpyAsync(hw.data(), b + o_halt, sizeof(int32_t) * 2 * c->S, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    for (int s_ = 0; s_ < c->S; s_++) {
+      fin_halt[s_] = hw[s_];
+      fin_reason[s_] = hw[c->S + s_];
+    }
+  }
+  if (h_report) {
     hipError_t e = hipMemcpyAsync(h_report, b + o_rep, sizeof(int32_t) * 2 * n_steps, hipMemcpyDeviceToHost, c->stream);
-    if (e == hipSuccess) e = hipMemcpyAsync(hw.data(), b + o_halt, sizeof(int32_t) * 2 * c->S, hipMemcpyDeviceToHost, c->stream);
-    hipError_t es = hipStreamSynchronize(c->stream);  // always: `sd` and `hw` are locals the copies above read / write
+    hipError_t es = hipStreamSynchronize(c->stream);
     if (e == hipSuccess) e = es;
     if (e != hipSuccess) return hamsm_fail(c, HAMSM_EDEVICE, "minibatch_run read-back: %s", hipGetErrorString(e));
     if (getenv("HAMSM_DEBUG_ENQUEUE")) {
@@ -3000,16 +4021,35 @@ static int run_steps(hamsm_ctx *c, const void *X, int dt, int64_t ldx, const int
     if (h_resume && h_reason) {
       // stop word -> first step of the stratum that was not applied
       for (int s = 0; s < c->S; s++) {
-        h_reason[s] = hw[c->S + s];
+        h_reason[s] = fin_reason[s];
         h_resume[s] = n_steps;
       }
       for (int64_t i = n_steps - 1; i >= 0; i--) {
         const int s = h_steps[i].stratum;
-        if (i >= hw[s]) h_resume[s] = i;
+        if (i >= fin_halt[s]) h_resume[s] = i;
       }
     }
   } else {
     HIPCHK(c, hipStreamSynchronize(c->stream));  // the descriptor upload reads from the local `sd`
+  }
+  return HAMSM_OK;
+}
+
+// (debug hooks, outside the ABI) look-ahead blocks: knobs and counters of a context
+extern "C" int hamsm_debug_set_ahead(hamsm_ctx *c, int on, int n0, int gmax, double alpha) {
+  CTX(c);
+  c->ahead = on != 0;
+  if (n0 >= 1) c->ahead_n0 = n0;
+  if (gmax >= 1) c->ahead_gmax = gmax > 16 ? 16 : gmax;
+  if (alpha >= 1.0) c->ahead_alpha = alpha;
+  return HAMSM_OK;
+}
+// out[6]: blocks launched, steps inside them, blocks given up, (unused), relaunch passes, steps run step by step; reset != 0 zeroes
+extern "C" int hamsm_debug_ahead_stats(hamsm_ctx *c, long long *out, int reset) {
+  CTX(c);
+  for (int i = 0; i < 6; i++) {
+    if (out) out[i] = c->ahead_stat[i];
+    if (reset) c->ahead_stat[i] = 0;
   }
   return HAMSM_OK;
 }
