@@ -79,16 +79,16 @@ struct hamsm_ctx {
   int train_persist = 0;  // HAMSM_TRAIN_PERSIST=1: planned training passes run as ONE persistent launch (measured slower than the
                           // multi-kernel path on every shape tried -- DESIGN.md §5.3a -- and therefore off; kept as a tested alternative)
   int persist_wpx = 64;   // workgroups per XCD of that launch (HAMSM_PERSIST_WPX, 8 XCDs: grid = 8 x this)
-  // look-ahead E-steps (train.hip): the E-steps of a block of consecutive iterations run in ONE launch
-  // against the centroids as they stand at the block's start; a row's label is final when no centroid displacement
-  // within a bound can change its argmin, the few other rows are decided exactly by the M-step that consumes them, and
-  // every M-step checks the bound against the displacement the block has really seen.  Results are those of the
-  // step-by-step path bit for bit.  HAMSM_TRAIN_AHEAD=0: off.
-  int ahead = 1;
-  int ahead_n0 = 48;        // iterations of a pass that run step by step before the first block (HAMSM_AHEAD_N0)
-  int ahead_gmax = 16;      // most iterations per block (HAMSM_AHEAD_G, <= 16)
-  double ahead_alpha = 1.5; // displacement allowed at position s = alpha x what the previous block saw there (HAMSM_AHEAD_ALPHA)
-  long long ahead_stat[6] = {0, 0, 0, 0, 0, 0};  // blocks launched, steps inside them, blocks given up, undecided rows, relaunches, steps classic
+  // pipelined training (train.hip; an experiment, OFF by default -- HAMSM_TRAIN_AHEAD=1): ONE launch per WE
+  // iteration -- the M-step of iteration i beside the E-step of iteration i + 2, which runs against centroids two updates old.
+  // A label is final only where a displacement bound proves that no update can change its argmin; the other rows are decided
+  // exactly, one step ahead, by the waves that own the candidate centroids; every M-step checks the bound against the
+  // displacement really seen.  Bit-identical to the step-by-step path; measured slower on the bench's data.
+  int ahead = 0;
+  int ahead_n0 = 200;       // iterations of a pass that run step by step before the first segment (HAMSM_AHEAD_N0)
+  int ahead_gmax = 16;      // segments hold at most 64 x this many iterations (HAMSM_AHEAD_G)
+  double ahead_alpha = 3.0; // displacement allowed = alpha x the latest measurement (HAMSM_AHEAD_ALPHA)
+  long long ahead_stat[6] = {0, 0, 0, 0, 0, 0};  // segments, steps inside them, premises failed, -, relaunch passes, steps run step by step
   int generic_stage_kb = 150;  // D > 128: the E-step stages its 16 rows in LDS while they fit this (HAMSM_GENERIC_STAGE_KB; 0 = never)
   // hamsm_malloc / hamsm_free keep released blocks for reuse (hipMalloc costs ~1 ms per 40 MB block and hipFree
   // synchronises the device; every use of a block is ordered on `stream`, so reuse needs no synchronisation)

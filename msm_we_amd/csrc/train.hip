@@ -984,7 +984,11 @@ struct AheadDev {
   const double *ref_slot;     // a slot of the previous block: what this step's bound is derived from (null: bound 0)
   double ref_scale;           //   bound = ref_scale * *ref_slot
   double *bound;              // [1] the bound the E-step used (read back by the M-step that checks it)
-  double *Csnap;              // [K][D] the stratum's centroids at the block's start
+  // the step's M-step reads the stratum's tables where its StepDev points (C, counts, csq) and writes ALL of them, moved or
+  // not, to these: the E-step of a later iteration may be reading the old ones in the same launch (two buffers, alternating)
+  double *C_out, *counts_out, *csq_out, *Bpack_out;
+  int disp_in, pad2_;         // what `slot` measures: 1 = against the tables this step read (the next step's labels were taken
+                              // one update ago), 0 = against what C_out held before (two updates ago: the pipeline's steady state)
   SuspEntry *tab;             // [AHEAD_TAB_CAP] rows the bound cannot decide, with their candidate centroids
   int32_t *cnt;               // [4]: entries appended to `tab`; flags of rows the block cannot serve (1 table full, 2 open row at
                               //      position 0, 4 not finite, 8 list of open rows full); open rows appended to `hl`
@@ -1489,46 +1493,38 @@ __global__ __launch_bounds__(256) void k_step_update(const StepDev *__restrict__
   SPROF_FLUSH(1)
 }
 
-// ---- look-ahead blocks -----------------------------------------------------------------------------------------
+// ---- pipelined training: the E-step two iterations ahead (an experiment, off by default) --------------------------
 // The chain E(t) -> M(t) -> E(t+1) -> ... is what bounds a training pass: two dependent launches per WE iteration.  But the
 // centroids of a stratum move less and less (by ~1/count per step), and a label is an argmin: it survives any displacement that is
-// small against the gap between a row's nearest and second-nearest centroid.  So the E-steps of G consecutive iterations of a
-// stratum run in ONE launch (k_step_assign_ahead) against the centroids as they stand at the block's start, and the chain that is
-// left is one launch per iteration (k_step_update_ahead).
+// small against the gap between a row's nearest and second-nearest centroid.  So ONE launch per iteration (k_step_pipe) holds the
+// M-step of iteration i and, beside it, the E-step of iteration i + 2 against the centroid tables that M-step READS (it writes
+// the stratum's other set of tables: two sets, alternating) -- labels are two updates old when they are used.
 //
-// Certificate.  Write S = |x|, R_j = |x - c_j| for the centroids at the block's start, and let every centroid have moved by at
-// most B (Euclidean) when step s is applied.  The contract's distances are d_j = csq_j - 2 x.c_j (f64 fma chains), i.e.
-// R_j^2 - S^2 up to a rounding error of at most g (2S + R_j)^2, g = (D + 6) 2^-53.  Centroid j cannot be the argmin of step s if
+// Certificate.  Write S = |x|, R_j = |x - c_j| for the centroids the E-step saw, and let every centroid have moved by at most B
+// (Euclidean) when the labels are used.  The contract's distances are d_j = csq_j - 2 x.c_j (f64 fma chains), i.e.
+// R_j^2 - S^2 up to a rounding error of at most g (2S + R_j)^2, g = (D + 6) 2^-53.  Centroid j cannot be the argmin then if
 //     (R_j - B)^2 - g' (..)  >  (R_1 + B)^2 + g' (..)   <=   R_j^2 - R_1^2 > 2 B (R_1 + R_j) + k [(2S + R_j + B)^2 + (2S + R_1 + B)^2],
-// with R_j > 2B, where 1 is the nearest centroid at the block's start and k = 2^-38 covers every rounding above, and the 2^-40
-// by which the ranked values are perturbed (below), many times over.  The left side grows faster in R_j than the right once
-// R_j > 2B, so the centroids are tested in order of distance: the second-nearest passes -> the label is FINAL and the row joins
-// its centroid's membership bitmap as in the step-by-step E-step; else the first that passes ends the row's list of CANDIDATES
-// (2 or 3 of them: the row is undecided and goes to the step's table); a fourth candidate, a row or a distance that is not
-// finite, or a full table make the block unservable from that step on (`cnt[1]`).  Exact ties of the step-by-step rule (first
-// minimum wins) are undecided rows here, B = 0 included.
+// with R_j > 2B, where 1 is the nearest centroid the E-step saw and k = 2^-38 covers every rounding above, and the 2^-40 by which
+// the ranked values are perturbed (below), many times over.  The left side grows faster in R_j than the right once R_j > 2B, so
+// the centroids are tested in order of distance: the second-nearest passes -> the label is FINAL and the row joins its
+// centroid's membership bitmap as in the step-by-step E-step; else the first that passes ends the row's list of CANDIDATES (2 or
+// 3 of them: the row is undecided and goes to the step's table); a fourth candidate makes the row OPEN (its distance to every
+// centroid will be needed); a row or a distance that is not finite, a full table or a full list of open rows make the step
+// unservable (`cnt[1]`).  Exact ties of the step-by-step rule (first minimum wins) are undecided rows here.
 // Ranking: the sweep keeps each lane's four smallest distances in order with a min / max network (7 instructions per
 // distance); the centroid's index rides in the 12 low mantissa bits of the value (a relative change below 2^-40, charged to k).
 //
-// The bound B of position s is a GUESS made when the block is launched: alpha x (s / s') x the displacement the stratum's
-// previous block measured at position s'.  The M-step of position s checks it against the displacement the block has really
-// seen so far (`slot`, maintained by the M-steps: each adds the largest |c_new - c_snapshot| of the centroids it moved, and
-// carries its predecessor's value for those it did not) -- and checks `cnt[1]`.  If either fails the stratum's chain stops at
-// that step with HAMSM_STOP_AHEAD, nothing of it applied, and run_steps relaunches from there, the failed step exact.
-// Undecided and open rows are decided one step ahead, by the waves that own the centroids: a wave that has just updated
-// centroid j (the M-step of the stratum's previous step in the block) evaluates the contract's distance d(x, c_j) -- an fma chain
-// in ascending feature order against the row it holds in registers / LDS -- for the next step's open rows and for the entries
-// of the next step's table that name j, and leaves them in memory; the next step's waves only compare (first minimum wins).
-// No wave ever reads another wave's centroid while it may be changing.  A block's first step needs none of this: its E-step
-// ran against the very centroids its M-step sees, so its labels are the step-by-step rule's, taken exactly.
-// Everything else -- membership in sample order, the update, counts, ||c||^2, the low-count tests, the stop protocol -- is the
-// step-by-step path's, so the results are the same bits.
+// The bound B is a GUESS made when the E-step is launched: alpha x the displacement the latest finished M-step measured.  The
+// M-step that uses the labels checks it against the displacement really seen (`slot`: the M-step before it took the largest
+// |c_new - c_as_the_E-step_saw_it| over all centroids -- the other set of tables holds exactly those old rows) and checks
+// `cnt[1]`.  If either fails the stratum's chain stops at that step with HAMSM_STOP_AHEAD, nothing of it applied, and run_steps
+// relaunches from there (the tables brought home first), the first two steps of the new segment with exact labels.
 #define AHEAD_KAPPA 3.637978807091713e-12   // 2^-38
 #define AHEAD_EPS 9.5367431640625e-07       // 2^-20
 #define AHEAD_BIG 1e300                     // "no such centroid" (finite: the index bits must not turn an infinity into a NaN)
 #define AHEAD_STRIP 2048                    // ints of LDS per wave of the M-step (8 KB: the member list, or undecided rows)
 #define AHEAD_HX 896                        // doubles of LDS per wave for the next step's open rows (60 KB per workgroup in all)
-#define AHEAD_HCAP 32                       // most open rows per step
+#define AHEAD_HCAP 32                       // most open rows per step (fewer for long rows: they wait in LDS)
 #define AHEAD_KMAX 4096                     // centroids per stratum the 12 index bits can name
 
 __device__ __forceinline__ double f64_min(double a, double b) {
@@ -1555,13 +1551,12 @@ __device__ __forceinline__ double key_of(double d, int j) {
 __device__ __forceinline__ int key_index(double k) { return __double2loint(k) & 0xFFF; }
 
 template <typename XT, int KS, int JB>
-__global__ __launch_bounds__(256) void k_step_assign_ahead(const StepDev *__restrict__ steps, const AheadDev *__restrict__ aheads,
-                                                           const int *__restrict__ ylist, int64_t ldx, int D) {
-  const int yi = ((const GAS int *)ylist)[blockIdx.y];
+__device__ __forceinline__ void ahead_assign(const StepDev *__restrict__ steps, const AheadDev *__restrict__ aheads, const int yi,
+                                             const unsigned bx, int64_t ldx, int D) {
   const StepDev sdesc = load_step_mem(steps, (unsigned)yi);
   const GAS AheadDev *ahp = gp(aheads + yi);
   const StepG st(sdesc);
-  const long long r0 = (long long)blockIdx.x * 16;
+  const long long r0 = (long long)bx * 16;
   if (r0 >= st.n_b) return;
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const GAS XT *X = (const GAS XT *)st.X;
@@ -1595,6 +1590,7 @@ __global__ __launch_bounds__(256) void k_step_assign_ahead(const StepDev *__rest
   }
   __shared__ double sk[4][4][16];
   __shared__ int snan[4];
+  GAS int32_t *cnt = gp(ahp->cnt);
   if (ahp->pos == 0) {
     // the block's first step: these ARE the centroids its M-step will see -- the step-by-step E-step's rule, exactly
     double bd = inf;
@@ -1638,7 +1634,7 @@ __global__ __launch_bounds__(256) void k_step_assign_ahead(const StepDev *__rest
       sji[wv * 16 + lane] = bi;
     }
     __syncthreads();
-    if (blockIdx.x == 0 && tid == 0) *gp(ahp->bound) = 0.0;
+    if (bx == 0 && tid == 0) *gp(ahp->bound) = 0.0;
     if (tid < 16 && r0 + tid < st.n_b) {
       double d = sdv[tid];
       int j = sji[tid];
@@ -1711,7 +1707,7 @@ __global__ __launch_bounds__(256) void k_step_assign_ahead(const StepDev *__rest
   }
   if (lane == 0) snan[wv] = (int)((oddm | (oddm >> 16) | (oddm >> 32) | (oddm >> 48)) & 0xFFFF);  // by batch row
   __syncthreads();
-  if (blockIdx.x == 0 && tid == 0) *gp(ahp->bound) = B;
+  if (bx == 0 && tid == 0) *gp(ahp->bound) = B;
   if (tid < 16 && r0 + tid < st.n_b) {
     k1 = sk[0][0][tid], k2 = sk[0][1][tid], k3 = sk[0][2][tid], k4 = sk[0][3][tid];
 #pragma unroll
@@ -1721,7 +1717,6 @@ __global__ __launch_bounds__(256) void k_step_assign_ahead(const StepDev *__rest
     }
     const bool row_odd = ((snan[0] | snan[1] | snan[2] | snan[3]) >> tid) & 1;
     const long long rr = r0 + tid;
-    GAS int32_t *cnt = gp(ahp->cnt);
     const double S = __builtin_sqrt(x2);
     const double D1 = k1 + x2, R1 = __builtin_sqrt(D1 > 0.0 ? D1 : 0.0);
     // true when the centroid ranked with key kj cannot become the argmin under any displacement <= B of every centroid
@@ -1761,6 +1756,12 @@ __global__ __launch_bounds__(256) void k_step_assign_ahead(const StepDev *__rest
   }
 }
 
+template <typename XT, int KS, int JB>
+__global__ __launch_bounds__(256) void k_step_assign_ahead(const StepDev *__restrict__ steps, const AheadDev *__restrict__ aheads,
+                                                           const int *__restrict__ ylist, int64_t ldx, int D) {
+  ahead_assign<XT, KS, JB>(steps, aheads, ((const GAS int *)ylist)[blockIdx.y], blockIdx.x, ldx, D);
+}
+
 // M-step of a look-ahead block: k_step_update plus (i) the check of the block's bound, (ii) the low-count / zero-count tests
 // that ride on the E-step in the step-by-step path (here every workgroup evaluates them, they all see the same counts),
 // (iii) the rows the E-step left undecided or open, by the distances the previous step's waves left behind, (iv) the
@@ -1768,13 +1769,10 @@ __global__ __launch_bounds__(256) void k_step_assign_ahead(const StepDev *__rest
 // table that name it.  One wave per centroid, descriptors in the kernel arguments.
 #define AHEAD_ITEMS 64  // rows of the next step a wave evaluates in one round (lane = row)
 template <typename XT, int H>
-__global__ __launch_bounds__(256) void k_step_update_ahead(const StepPack pk, const AheadPack ap, int64_t ldx, int D, int KS,
-                                                           double ratio) {
-  const StepDev sdesc = pk.s[blockIdx.y];
-  const AheadDev ah = ap.a[blockIdx.y];
+__device__ __forceinline__ void ahead_update(const StepDev &sdesc, const AheadDev &ah, const unsigned bx, int64_t ldx, int D, int KS,
+                                             double ratio, int *lds_i) {
   const StepG st(sdesc);
-  if ((int)blockIdx.x * 4 >= st.K) return;
-  extern __shared__ int lds_i[];
+  if ((int)bx * 4 >= st.K) return;
   __shared__ double shd[4];
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   int *list = lds_i + wv * AHEAD_STRIP;
@@ -1782,7 +1780,7 @@ __global__ __launch_bounds__(256) void k_step_update_ahead(const StepPack pk, co
   double *swl = (double *)(list + UPD_SC);
   const GAS double *Xg = st.Xg;
   const int ldg = 4 * KS;
-  const int j = blockIdx.x * 4 + wv;
+  const int j = bx * 4 + wv;
   const bool active = j < st.K;
   const int jc = active ? j : st.K - 1;  // (idle waves of the last workgroup load what the last centroid's wave loads; they store nothing)
   const double inf = __builtin_huge_val();
@@ -1792,20 +1790,17 @@ __global__ __launch_bounds__(256) void k_step_update_ahead(const StepPack pk, co
   const unsigned long long w0 = mb[lane];
   const double cnt0 = st.counts[jc];
   const double csq0 = st.csq[jc];
+  GAS double *C_out = gp(ah.C_out);
   double c0[H], sn[H];
 #pragma unroll
   for (int h = 0; h < H; h++) {
     const int k = lane + 64 * h;
     c0[h] = st.C[(size_t)jc * D + (k < D ? k : D - 1)];
-    sn[h] = 0.0;
+    sn[h] = C_out[(size_t)jc * D + (k < D ? k : D - 1)];  // this centroid two updates ago (steady state)
   }
-  const GAS double *snap = gp((const double *)ah.Csnap);
-  if (ah.pos > 0) {
+  if (ah.disp_in) {
 #pragma unroll
-    for (int h = 0; h < H; h++) {
-      const int k = lane + 64 * h;
-      sn[h] = snap[(size_t)jc * D + (k < D ? k : D - 1)];
-    }
+    for (int h = 0; h < H; h++) sn[h] = c0[h];
   }
   const double seen = ah.prev_slot ? *gp(ah.prev_slot) : 0.0;
   const double bound = *gp((const double *)ah.bound);
@@ -1898,9 +1893,9 @@ __global__ __launch_bounds__(256) void k_step_update_ahead(const StepPack pk, co
       cj_t = cq > cj_t ? cq : cj_t;
     }
   if (st.idx >= hv) return;  // the stratum's chain stopped before this step
-  // (i) the block's premises for this step
-  if ((!(seen <= bound) || unserved) && ratio >= 0.0) {  // (ratio < 0: timing experiments that ignore the premises -- wrong results)
-    if (blockIdx.x == 0 && tid == 0) {
+  // (i) the premises of this step's labels
+  if (!(seen <= bound) || unserved) {
+    if (bx == 0 && tid == 0) {
       *gp(sdesc.halt) = st.idx;
       *gp(sdesc.reason) = HAMSM_STOP_AHEAD;
     }
@@ -1924,13 +1919,13 @@ __global__ __launch_bounds__(256) void k_step_update_ahead(const StepPack pk, co
       const double thr = ratio * mx;
       int low = 0;
       for (int q = tid; q < st.K; q += 256) low += st.counts[q] < thr;
-      if (low && blockIdx.x == 0)
+      if (low && bx == 0)
         __hip_atomic_fetch_add((GAS int32_t *)gp(sdesc.prev_report) + 1, low, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       any_low = __syncthreads_or(low);
     }
     const int any_z = __syncthreads_or((st.flags & 2) ? z_t : 0);
     if (any_low || any_z) {
-      if (blockIdx.x == 0 && tid == 0) {
+      if (bx == 0 && tid == 0) {
         if (any_low) {
           *gp(sdesc.halt) = st.idx;
           *gp(sdesc.reason) = HAMSM_STOP_LOW;
@@ -1944,18 +1939,7 @@ __global__ __launch_bounds__(256) void k_step_update_ahead(const StepPack pk, co
     }
   }
   GAS double *slot = gp(ah.slot);
-  if (blockIdx.x == 0 && tid == 0 && ah.pos > 0)  // centroids that do not move at this step keep the displacement seen so far
-    __hip_atomic_fetch_max((GAS unsigned long long *)slot, (unsigned long long)__double_as_longlong(seen), __ATOMIC_RELAXED,
-                           __HIP_MEMORY_SCOPE_AGENT);
   if (!active) return;
-  if (ah.pos == 0) {  // the block's snapshot: this centroid as it stands before the block's first update
-#pragma unroll
-    for (int h = 0; h < H; h++) {
-      const int k = lane + 64 * h;
-      sn[h] = c0[h];
-      if (k < D) ((GAS double *)snap)[(size_t)j * D + k] = c0[h];
-    }
-  }
   unsigned long long w = w0;
   // (iii-a) open rows: first minimum over all centroids of the distances the previous step's waves left behind
   for (int h = 0; h < n_open; h++) {
@@ -2049,48 +2033,46 @@ __global__ __launch_bounds__(256) void k_step_update_ahead(const StepPack pk, co
   }
   if (!weighted) wsum = (double)blk;
   const bool moved = blk > 0 && wsum > 0;  // (no member, or no weight: centre unchanged, pyx:87 / :105-108)
-  const bool owes = n_items > 0 || nt_done < n_nt;
-  if (!moved && !owes) return;
   double *vb = (double *)list;
   double a = csq0;
-  if (moved) {
-    const double cnt1 = cnt0 + wsum;
+  {
+    const double cnt1 = moved ? cnt0 + wsum : cnt0;
     const double alpha = 1.0 / cnt1;
     double v[H], dsq = 0.0;
+    GAS double *Bp_out = gp(ah.Bpack_out);
 #pragma unroll
     for (int h = 0; h < H; h++) {
       const int k = lane + 64 * h;
-      v[h] = acc[h] * alpha;
+      v[h] = moved ? acc[h] * alpha : c0[h];
       if (k < D) {
-        st.C[(size_t)j * D + k] = v[h];
-        st.Bpack[((size_t)(j >> 4) * KS + (k >> 2)) * 64 + (k & 3) * 16 + (j & 15)] = v[h];
+        C_out[(size_t)j * D + k] = v[h];
+        Bp_out[((size_t)(j >> 4) * KS + (k >> 2)) * 64 + (k & 3) * 16 + (j & 15)] = v[h];
         const double t = v[h] - sn[h];
         dsq += t * t;
       }
     }
-    if (lane == 0) st.counts[j] = cnt1;
-    // (iv) how far this centroid now is from the block's snapshot (any summation order: the factor covers it; NaN and inf
-    // stay what they are and fail the next step's check)
+    if (lane == 0) gp(ah.counts_out)[j] = cnt1;
+    // (iv) how far this centroid now is from where the next step's labels were taken (any summation order: the factor covers
+    // it; NaN and inf stay what they are and fail the next step's check)
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) dsq += __shfl_xor(dsq, off, 64);
-    if (lane == 0) {
+    if (lane == 0 && dsq != 0.0) {
       const double disp = __builtin_sqrt(dsq) * (1.0 + AHEAD_EPS);
       __hip_atomic_fetch_max((GAS unsigned long long *)slot, (unsigned long long)__double_as_longlong(disp), __ATOMIC_RELAXED,
                              __HIP_MEMORY_SCOPE_AGENT);
     }
 #pragma unroll
     for (int h = 0; h < H; h++) vb[lane + 64 * h] = v[h];
-    a = 0.0;
-    for (int k = 0; k + 1 < D; k += 2) {
-      const double2 t = *(const double2 *)&vb[k];
-      a = __builtin_fma(t.x, t.x, a);
-      a = __builtin_fma(t.y, t.y, a);
+    if (moved) {
+      a = 0.0;
+      for (int k = 0; k + 1 < D; k += 2) {
+        const double2 t = *(const double2 *)&vb[k];
+        a = __builtin_fma(t.x, t.x, a);
+        a = __builtin_fma(t.y, t.y, a);
+      }
+      if (D & 1) a = __builtin_fma(vb[D - 1], vb[D - 1], a);
     }
-    if (D & 1) a = __builtin_fma(vb[D - 1], vb[D - 1], a);
-    if (lane == 0) st.csq[j] = a;
-  } else {
-#pragma unroll
-    for (int h = 0; h < H; h++) vb[lane + 64 * h] = c0[h];
+    if (lane == 0) gp(ah.csq_out)[j] = a;
   }
   // (v) what the next step needs of this centroid as it now stands: lane = row, the contract's chain over ascending k --
   // dot = fma(c_k, x_k, dot) from +0.0, what the matrix unit accumulates for this (row, centroid) pair in k_step_assign --
@@ -2135,6 +2117,17 @@ __global__ __launch_bounds__(256) void k_step_update_ahead(const StepPack pk, co
       evaluate(got);
     }
   }
+}
+
+// one launch of the pipeline: blockIdx.y < n_m -> the M-step of a step whose labels are complete (descriptors by value);
+// the other rows of the grid -> E-steps of later steps (descriptors in memory), against tables no M-step of this launch writes
+template <typename XT, int KS, int JB, int H>
+__global__ __launch_bounds__(256) void k_step_pipe(const StepPack pk, const AheadPack ap, int n_m, const StepDev *__restrict__ steps,
+                                                   const AheadDev *__restrict__ aheads, const int *__restrict__ ylist, int64_t ldx,
+                                                   int D, double ratio) {
+  extern __shared__ int lds_i[];
+  if ((int)blockIdx.y < n_m) ahead_update<XT, H>(pk.s[blockIdx.y], ap.a[blockIdx.y], blockIdx.x, ldx, D, KS, ratio, lds_i);
+  else ahead_assign<XT, KS, JB>(steps, aheads, ((const GAS int *)ylist)[blockIdx.y - n_m], blockIdx.x, ldx, D);
 }
 
 // block-wide reductions over 256 threads (4 waves); every thread gets the result
@@ -3459,6 +3452,41 @@ static int launch_assign_ahead(hamsm_ctx *c, hipStream_t q, const StepDev *d_ste
   return HAMSM_OK;
 }
 
+// end of a pipelined segment whose last M-step wrote the alternate tables: they go home -- unless the stratum's chain stopped
+// inside the segment (then the alternate tables may be the OLDER ones; the host sorts that out once it knows where it stopped)
+__global__ void k_tables_home(const int32_t *__restrict__ halt, int last_idx, const double *__restrict__ sC, double *__restrict__ dC,
+                              size_t nC, const double *__restrict__ sq, double *__restrict__ dq, const double *__restrict__ sn,
+                              double *__restrict__ dn, size_t nk, const double *__restrict__ sB, double *__restrict__ dB, size_t nB) {
+  if (*halt <= last_idx) return;
+  const size_t stride = (size_t)gridDim.x * blockDim.x, t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  for (size_t i = t; i < nC; i += stride) dC[i] = sC[i];
+  for (size_t i = t; i < nk; i += stride) {
+    dq[i] = sq[i];
+    dn[i] = sn[i];
+  }
+  for (size_t i = t; i < nB; i += stride) dB[i] = sB[i];
+}
+
+// one launch of the pipeline: n_m M-steps (by value) and n_e E-steps (descriptors in memory)
+template <typename XT>
+static int launch_pipe(hamsm_ctx *c, hipStream_t q, const StepPack &pk, const AheadPack &apk, int n_m, int maxK, const StepDev *d_sde,
+                       const AheadDev *d_aheads, const int *d_ylist, int n_e, long long e_nb, int64_t ldx, double ratio) {
+  const unsigned gx_m = (unsigned)((maxK + 3) / 4), gx_e = (unsigned)((e_nb + 15) / 16);
+  const dim3 grid(gx_m > gx_e ? gx_m : gx_e, (unsigned)(n_m + n_e));
+  const size_t lds = sizeof(int) * (4 * AHEAD_STRIP) + sizeof(double) * (4 * AHEAD_HX) + sizeof(int) * (4 * 2 * AHEAD_ITEMS);
+  switch (c->KS) {
+#define CASE(KSV, JBV, HV)                                                                                                  \
+  case KSV:                                                                                                                 \
+    hipLaunchKernelGGL((k_step_pipe<XT, KSV, JBV, HV>), grid, dim3(256), lds, q, pk, apk, n_m, d_sde, d_aheads, d_ylist, ldx, \
+                       c->D, ratio);                                                                                        \
+    break;
+    CASE(1, 8, 1) CASE(2, 8, 1) CASE(3, 8, 1) CASE(4, 8, 1) CASE(6, 4, 1) CASE(8, 4, 1) CASE(12, 2, 1) CASE(16, 2, 1) CASE(24, 1, 2) CASE(32, 1, 2)
+#undef CASE
+    default: return hamsm_fail(c, HAMSM_ENOTSUP, "pipelined training: KS=%d", c->KS);
+  }
+  return HAMSM_OK;
+}
+
 // steps [0,n): consecutive steps of distinct strata share launches (grid.y)
 static int run_steps(hamsm_ctx *c, const void *X, int dt, int64_t ldx, const int32_t *d_rows, const double *d_w,
                      const hamsm_step *h_steps, int64_t n_steps, double ratio, const int32_t *h_perm, int64_t n_perm_total,
@@ -3502,7 +3530,7 @@ static int run_steps(hamsm_ctx *c, const void *X, int dt, int64_t ldx, const int
   int Kmax = 0;
   for (int s = 0; s < c->S; s++) Kmax = c->st[s].K > Kmax ? c->st[s].K : Kmax;
   const bool ahead_can = ahead_can0 && Kmax <= AHEAD_KMAX;
-  const int npos = ahead_can ? c->ahead_gmax : 1;
+  const int npos = ahead_can ? 4 : 1;  // a step's E-step output lives until its M-step, two launches later: four rotating regions
   size_t o_xg = take(generic ? 0 : xg_row * (size_t)nslot * npos * nb_pad);  // (the generic M-step reads the frames in place)
   const int wstride = (int)((((nb_max + 63) >> 6) + 63) & ~(int64_t)63);  // bitmap words per centroid
   const size_t mb_bytes = sizeof(unsigned long long) * (size_t)nslot * npos * Kmax * wstride;
@@ -3517,8 +3545,9 @@ static int run_steps(hamsm_ctx *c, const void *X, int dt, int64_t ldx, const int
          o_hd = take(ahead_can ? sizeof(double) * AHEAD_HCAP * (size_t)ah_kst * nslot * npos : 0),
          o_td = take(ahead_can ? sizeof(double) * 3 * AHEAD_TAB_CAP * (size_t)nslot * npos : 0),
          o_tab = take(ahead_can ? sizeof(SuspEntry) * AHEAD_TAB_CAP * (size_t)nslot * npos : 0),
-         o_csnap = take(ahead_can ? sizeof(double) * (size_t)c->S * Kmax * c->D : 0), o_ylist = take(sizeof(int) * ah_words),
-         o_ah = take(sizeof(AheadDev) * ah_words);
+         o_ylist = take(sizeof(int) * ah_words),
+         o_ah = take(sizeof(AheadDev) * ah_words), o_sde = take(sizeof(StepDev) * ah_words), o_tail = take(sizeof(StepDev) * (size_t)c->S),
+         o_alt = take(ahead_can ? sizeof(double) * (size_t)c->S * ((size_t)((Kmax + 15) & ~15) * (c->D + 2 + c->KS * 4)) : 0);
   // persistent pass: control block (registration, error word, one barrier counter per stratum) and the strata's chains
   const size_t ctl_bytes = (sizeof(PersistCtl) + sizeof(unsigned) * (size_t)c->S + 15) & ~(size_t)15;
   size_t o_ctl = take(ctl_bytes), o_coff = take(sizeof(int) * ((size_t)c->S + 1)), o_cidx = take(sizeof(int) * (size_t)n_steps);
@@ -3655,109 +3684,122 @@ static int run_steps(hamsm_ctx *c, const void *X, int dt, int64_t ldx, const int
   if (gstart.size() <= 2 || c->S < 2 || nslot != c->S || !d_rows || generic) n_lanes = 1;  // (labels scratch is per step only with row lists)
   auto runs = [&](int64_t q) { return live[h_steps[q].stratum] && q >= from[h_steps[q].stratum]; };
   auto lane_of = [&](int64_t q) { return n_lanes > 1 ? h_steps[q].stratum % n_lanes : 0; };
-  // ---- plan the look-ahead blocks of this pass (host only; fills the steps' block fields before they are uploaded) ------
-  // per lane: the first `n0` launch groups step by step (a relaunch after a given-up block: none), then blocks of 1, 2, 4, ...
-  // groups (a block of one group measures the displacement its successor's bounds are derived from).  A block ends after a
-  // group that carries a re-seeding (its centroids jump) and never holds a first step after seeding.
-  struct Block {
-    size_t g0, g1;        // launch groups [g0, g1)
-    int y0, y1;           // its steps in `ylist`
-    long long max_nb;
+  auto lane_of_stratum = [&](int y) { return n_lanes > 1 ? y % n_lanes : 0; };
+  // ---- plan the pipelined segments of this pass (host only; fills the steps' look-ahead fields before they are uploaded) ----
+  // Per lane: the first `n0` launch groups step by step (a relaunch after a failed premise: none), then SEGMENTS: maximal runs
+  // of launch groups in which the lane's strata are the same, every step has rows, none is a first step after seeding and
+  // none carries a re-seeding (its centroids jump).  A segment of groups a .. z runs as
+  //     E{a exact}   M{a}   E{a+1 exact, a+2}   M{a+1} + E{a+3}   M{a+2} + E{a+4}   ...   M{z-1}   M{z}
+  // -- from the fourth launch on ONE launch per WE iteration: the M-step of iteration i beside the E-step of iteration i + 2,
+  // which reads the centroid tables that M-step reads (it writes the other buffer).  Labels of i + 2 are therefore two updates
+  // old when they are used; M{i} measures exactly that displacement for M{i+1} to check, and evaluates the rows iteration
+  // i + 1 left undecided or open against the centroids it has just written.
+  struct PipeOp {     // one launch of a lane
+    size_t g;         // issued when the launch loop reaches this group (the M part's group; for E-only launches: the next M's)
+    int order;        // position among the launches issued at the same group
+    std::vector<int64_t> m;  // steps whose M-step runs (the lane's steps of one group), possibly none
+    int y0, y1;       // E part: ylist[y0 .. y1)
+    long long e_nb;   // largest batch of the E part
   };
   const size_t NG = gstart.size() - 1;
-  std::vector<std::vector<Block>> blocks(n_lanes);
+  std::vector<std::vector<PipeOp>> ops(n_lanes);
   std::vector<int> ylist;
-  std::vector<int> block_of(NG * (size_t)n_lanes, -1);  // [g * n_lanes + l] -> index into blocks[l]
+  std::vector<char> in_seg(NG * (size_t)n_lanes, 0);  // [g * n_lanes + l]: the lane's steps of this group run inside a segment
   std::vector<AheadDev> ahd(ahead_can ? (size_t)n_steps : 0);
+  std::vector<char> out_alt((size_t)n_steps, 0);      // the step's M-step writes the alternate tables (else the stratum's own)
+  struct CopyBack {
+    size_t g;
+    int y;
+    int64_t q;  // the segment's last step of the stratum
+  };
+  std::vector<CopyBack> copy_back;  // after this group's launches the stratum's alternate tables go home
+  const size_t kp = (size_t)((Kmax + 15) & ~15);
+  const size_t alt_stride = kp * c->D + 2 * kp + kp * c->KS * 4;  // doubles per stratum: C, csq, counts, Bpack
+  auto altC = [&](int y) { return (double *)(b + o_alt) + (size_t)y * alt_stride; };
+  auto altCsq = [&](int y) { return altC(y) + kp * c->D; };
+  auto altCnt = [&](int y) { return altCsq(y) + kp; };
+  auto altBp = [&](int y) { return altCnt(y) + kp; };
   if (ahead_can)
-    for (int64_t i = 0; i < n_steps; i++) {  // (a relaunch plans afresh: back to position 0's buffers of the stratum)
+    for (int64_t i = 0; i < n_steps; i++) {  // (a relaunch plans afresh: back to region 0 of the stratum, tables at home)
       memset(&ahd[i], 0, sizeof(AheadDev));
       ahd[i].pos = -1;
+      const Stratum &t = c->st[h_steps[i].stratum];
       const size_t slot = (size_t)h_steps[i].stratum;
       sd[i].Xg = (double *)(b + o_xg + slot * npos * nb_pad * xg_row);
       sd[i].mbits = (unsigned long long *)(b + o_mb) + slot * npos * Kmax * wstride;
+      sd[i].C = t.C;
+      sd[i].counts = t.counts;
+      sd[i].csq = t.csq;
+      sd[i].Bpack = t.Bpack;
     }
+  // the E-steps read their descriptors from memory: one array of StepDev copies whose table pointers name the buffer the
+  // E-step reads (the M-step's copy of the same step, sent by value, names the buffer IT reads)
+  std::vector<StepDev> sdE(ahead_can ? (size_t)n_steps : 0);
   if (ahead_on) {
     for (int l = 0; l < n_lanes; l++) {
-      int seen_groups = 0, gsz = 1;
+      int seen_groups = 0;
       const int n0 = pass == 0 ? c->ahead_n0 : 0;
-      std::vector<std::vector<int64_t>> prev(c->S);  // the previous block's steps, by stratum, in position order
-      bool have_prev = false;
+      // the lane's steps per group, and whether the group may be part of a segment
+      std::vector<std::vector<int64_t>> mine(NG);
+      std::vector<char> ok(NG, 0);
+      for (size_t g = 0; g < NG; g++) {
+        bool good = true;
+        for (int64_t q = gstart[g]; q < gstart[g + 1]; q++)
+          if (runs(q) && lane_of(q) == l) {
+            mine[g].push_back(q);
+            good = good && h_steps[q].n_b > 0 && !(h_steps[q].flags & HAMSM_STEP_FIRST) && !sd[q].perm;
+          }
+        ok[g] = good && !mine[g].empty();
+      }
+      auto same_strata = [&](size_t g1, size_t g2) {
+        if (mine[g1].size() != mine[g2].size()) return false;
+        for (size_t k = 0; k < mine[g1].size(); k++)
+          if (h_steps[mine[g1][k]].stratum != h_steps[mine[g2][k]].stratum) return false;
+        return true;
+      };
       size_t g = 0;
       while (g < NG) {
-        std::vector<int64_t> mine;
-        for (int64_t q = gstart[g]; q < gstart[g + 1]; q++)
-          if (runs(q) && lane_of(q) == l && h_steps[q].n_b > 0) mine.push_back(q);
-        if (mine.empty()) {
+        if (mine[g].empty()) {
           g++;
           continue;
         }
-        bool first_flag = false;
-        for (int64_t q : mine) first_flag = first_flag || (h_steps[q].flags & HAMSM_STEP_FIRST);
-        if (seen_groups < n0 || first_flag) {
+        if (seen_groups < n0 || !ok[g]) {
           seen_groups++;
-          have_prev = false;
           g++;
           continue;
         }
-        // form a block of up to G groups from g on
-        int G = have_prev ? gsz : 1;
-        G = G > npos ? npos : G;
-        std::vector<std::vector<int64_t>> cur(c->S);
+        // the segment's groups (those of the lane that are not empty), at most `seg_max`
+        std::vector<size_t> G_;
         size_t ge = g;
-        int taken = 0;
-        long long max_nb = 0;
-        bool stop_after = false;
-        while (ge < NG && taken < G && !stop_after) {
-          std::vector<int64_t> m2;
-          bool ff = false;
-          for (int64_t q = gstart[ge]; q < gstart[ge + 1]; q++)
-            if (runs(q) && lane_of(q) == l && h_steps[q].n_b > 0) {
-              m2.push_back(q);
-              ff = ff || (h_steps[q].flags & HAMSM_STEP_FIRST);
-              stop_after = stop_after || sd[q].perm;
-            }
-          if (ff) break;  // (a first step after seeding: step by step)
-          bool fits = true;
-          for (int64_t q : m2) {
-            const int y = h_steps[q].stratum;
-            // a position beyond 0 needs a slot of the previous block to derive its bound from
-            if (!cur[y].empty() && (!have_prev || prev[y].empty())) fits = false;
+        while (ge < NG && (int)G_.size() < c->ahead_gmax * 64) {
+          if (mine[ge].empty()) {
+            ge++;
+            continue;
           }
-          if (!fits) break;
-          for (int64_t q : m2) {
-            cur[h_steps[q].stratum].push_back(q);
-            max_nb = h_steps[q].n_b > max_nb ? h_steps[q].n_b : max_nb;
-          }
-          if (!m2.empty()) taken++;
+          if (!ok[ge] || !same_strata(g, ge)) break;
+          G_.push_back(ge);
           ge++;
         }
-        if (ge == g) {  // nothing could be taken (cannot happen: the first group always fits); step by step
-          seen_groups++;
-          have_prev = false;
-          g++;
+        if (G_.size() < 4) {  // too short to pay for the three launches of a start
+          seen_groups += (int)G_.size();
+          g = G_.empty() ? g + 1 : G_.back() + 1;
           continue;
         }
-        Block bk{g, ge, (int)ylist.size(), 0, max_nb};
-        for (int y = 0; y < c->S; y++)
-          for (size_t p_ = 0; p_ < cur[y].size(); p_++) {
-            const int64_t q = cur[y][p_];
+        const int n = (int)G_.size(), ny = (int)mine[g].size();
+        for (int k = 0; k < n; k++) in_seg[G_[k] * n_lanes + l] = 1;
+        // per step: regions, buffers, slots
+        for (int k = 0; k < n; k++)
+          for (int q_ = 0; q_ < ny; q_++) {
+            const int64_t q = mine[G_[k]][q_];
+            const int y = h_steps[q].stratum;
+            const Stratum &t = c->st[y];
             AheadDev &d = ahd[q];
-            const size_t reg = (size_t)y * npos + p_;
-            d.pos = (int)p_;
+            const size_t reg = (size_t)y * npos + (size_t)(k & 3);
+            d.pos = (k <= 1) ? 0 : 1;  // the segment's first two steps take their labels exactly
             sd[q].Xg = (double *)(b + o_xg + reg * nb_pad * xg_row);
             sd[q].mbits = (unsigned long long *)(b + o_mb) + reg * Kmax * wstride;
             d.slot = (double *)(b + o_slot) + 2 * q;
             d.bound = (double *)(b + o_slot) + 2 * q + 1;
-            d.prev_slot = p_ ? (const double *)(b + o_slot) + 2 * cur[y][p_ - 1] : nullptr;
-            d.ref_slot = nullptr;
-            d.ref_scale = 0.0;
-            if (p_) {
-              const size_t nref = p_ < prev[y].size() ? p_ : prev[y].size();
-              d.ref_slot = (const double *)(b + o_slot) + 2 * prev[y][nref - 1];
-              d.ref_scale = c->ahead_alpha * (double)p_ / (double)nref;
-            }
-            d.Csnap = (double *)(b + o_csnap) + (size_t)y * Kmax * c->D;
             d.tab = (SuspEntry *)(b + o_tab) + reg * AHEAD_TAB_CAP;
             d.cnt = (int32_t *)(b + o_cnt) + 4 * q;
             d.hl = (int32_t *)(b + o_hl) + reg * AHEAD_HCAP;
@@ -3765,14 +3807,40 @@ static int run_steps(hamsm_ctx *c, const void *X, int dt, int64_t ldx, const int
             d.td = (double *)(b + o_td) + reg * 3 * AHEAD_TAB_CAP;
             d.hcap = ah_hcap;
             d.kst = ah_kst;
-            d.nx_tab = nullptr;
-            d.nx_td = nullptr;
-            d.nx_cnt = nullptr;
-            d.nx_hl = nullptr;
-            d.nx_Xg = nullptr;
-            d.nx_hd = nullptr;
-            if (p_) {  // the previous step of the stratum evaluates this step's open rows
-              AheadDev &pv = ahd[cur[y][p_ - 1]];
+            // tables: M{k} reads buffer k & 1 (0 = the stratum's own), writes the other
+            const bool in_alt = k & 1;
+            sd[q].C = in_alt ? altC(y) : t.C;
+            sd[q].counts = in_alt ? altCnt(y) : t.counts;
+            sd[q].csq = in_alt ? altCsq(y) : t.csq;
+            sd[q].Bpack = in_alt ? altBp(y) : t.Bpack;
+            d.C_out = in_alt ? t.C : altC(y);
+            d.counts_out = in_alt ? t.counts : altCnt(y);
+            d.csq_out = in_alt ? t.csq : altCsq(y);
+            d.Bpack_out = in_alt ? t.Bpack : altBp(y);
+            out_alt[q] = !in_alt;
+            d.disp_in = k <= 1;  // labels of k + 1 are one update old for k = 1 (and exact for k = 0), two from then on
+            // labels of step k were taken against the tables M{k-2} read (k >= 3), M{k-1} read (k = 2), or its own (k <= 1)
+            sdE[q] = sd[q];
+            if (k >= 2) {
+              const bool e_alt = (k == 2) ? ((k - 1) & 1) : ((k - 2) & 1);
+              sdE[q].C = e_alt ? altC(y) : t.C;
+              sdE[q].counts = e_alt ? altCnt(y) : t.counts;
+              sdE[q].csq = e_alt ? altCsq(y) : t.csq;
+              sdE[q].Bpack = e_alt ? altBp(y) : t.Bpack;
+              // the premise M{k} checks: what M{k-1} measured <= what the E-step assumed
+              const int64_t qp = mine[G_[k - 1]][q_];
+              d.prev_slot = (const double *)(b + o_slot) + 2 * qp;
+              // the E-step's guess: alpha x the latest measurement at its launch, scaled to the updates its labels will be old
+              //   k = 2: launched after M{0} (one update measured), labels one update old
+              //   k = 3: launched with M{1}: latest = M{0}'s (one update), labels two updates old
+              //   k = 4: launched with M{2}: latest = M{1}'s (one update), labels two updates old
+              //   k >= 5: launched with M{k-2}: latest = M{k-3}'s (two updates), labels two updates old
+              const int kr = (k == 2) ? 0 : (k == 3 ? 0 : k - 3);
+              const int64_t qr = mine[G_[kr]][q_];
+              d.ref_slot = (const double *)(b + o_slot) + 2 * qr;
+              d.ref_scale = c->ahead_alpha * ((k == 3 || k == 4) ? 2.0 : 1.0);
+              // M{k-1} evaluates this step's undecided and open rows
+              AheadDev &pv = ahd[qp];
               pv.nx_cnt = d.cnt;
               pv.nx_hl = d.hl;
               pv.nx_Xg = sd[q].Xg;
@@ -3780,18 +3848,44 @@ static int run_steps(hamsm_ctx *c, const void *X, int dt, int64_t ldx, const int
               pv.nx_tab = d.tab;
               pv.nx_td = d.td;
             }
-            ylist.push_back((int)q);
           }
-        bk.y1 = (int)ylist.size();
-        for (size_t gg = g; gg < ge; gg++) block_of[gg * n_lanes + l] = (int)blocks[l].size();
-        blocks[l].push_back(bk);
+        // the launches
+        auto e_list = [&](std::initializer_list<int> ks, int &y0, int &y1, long long &nb) {
+          y0 = (int)ylist.size();
+          nb = 0;
+          for (int k : ks)
+            if (k < n)
+              for (int64_t q : mine[G_[k]]) {
+                ylist.push_back((int)q);
+                nb = h_steps[q].n_b > nb ? h_steps[q].n_b : nb;
+              }
+          y1 = (int)ylist.size();
+        };
+        {
+          PipeOp o{G_[0], 0, {}, 0, 0, 0};
+          e_list({0}, o.y0, o.y1, o.e_nb);
+          ops[l].push_back(o);
+        }
+        {
+          PipeOp o{G_[0], 1, mine[G_[0]], 0, 0, 0};
+          ops[l].push_back(o);
+        }
+        {
+          PipeOp o{G_[1], 0, {}, 0, 0, 0};
+          e_list({1, 2}, o.y0, o.y1, o.e_nb);
+          ops[l].push_back(o);
+        }
+        for (int k = 1; k < n; k++) {
+          PipeOp o{G_[k], 1, mine[G_[k]], 0, 0, 0};
+          e_list({k + 2}, o.y0, o.y1, o.e_nb);
+          ops[l].push_back(o);
+        }
+        if ((n - 1) % 2 == 0)  // M{n-1} reads buffer (n-1) & 1 = 0 and writes the alternate: bring the tables home
+          for (int64_t q : mine[G_[n - 1]]) copy_back.push_back({G_[n - 1], h_steps[q].stratum, q});
         c->ahead_stat[0]++;
-        c->ahead_stat[1] += bk.y1 - bk.y0;
-        prev.swap(cur);
-        have_prev = true;
-        gsz = taken >= gsz ? (2 * gsz > npos ? npos : 2 * gsz) : gsz;
-        seen_groups += taken;
-        g = ge;
+        c->ahead_stat[1] += (long long)n * ny;
+        seen_groups += n;
+        g = G_.back() + 1;
       }
     }
   }
@@ -3803,6 +3897,16 @@ static int run_steps(hamsm_ctx *c, const void *X, int dt, int64_t ldx, const int
       if (!ylist.empty()) {
         HIPCHK(c, hipMemcpyAsync(b + o_ylist, ylist.data(), sizeof(int) * ylist.size(), hipMemcpyHostToDevice, c->stream));
         HIPCHK(c, hipMemcpyAsync(b + o_ah, ahd.data(), sizeof(AheadDev) * ahd.size(), hipMemcpyHostToDevice, c->stream));
+        HIPCHK(c, hipMemcpyAsync(b + o_sde, sdE.data(), sizeof(StepDev) * sdE.size(), hipMemcpyHostToDevice, c->stream));
+        // the alternate tables start as copies of the stratum's own (what matters is the padding: +inf in csq, zeros in the
+        // fragments; every live row is written by the first M-step that writes them)
+        for (int y = 0; y < c->S; y++) {
+          const Stratum &t = c->st[y];
+          if (t.K == 0 || !live[y]) continue;
+          const size_t kq = (size_t)((t.K + 15) & ~15);
+          HIPCHK(c, hipMemcpyAsync(altCsq(y), t.csq, sizeof(double) * kq, hipMemcpyDeviceToDevice, c->stream));
+          HIPCHK(c, hipMemcpyAsync(altBp(y), t.Bpack, sizeof(double) * kq * c->KS * 4, hipMemcpyDeviceToDevice, c->stream));
+        }
       }
     }
   }
@@ -3839,48 +3943,48 @@ static int run_steps(hamsm_ctx *c, const void *X, int dt, int64_t ldx, const int
       }
       ny = (int)mine.size();
       if (ny == 0 || max_nb <= 0) continue;
-      const int bi = ahead_on ? block_of[g * n_lanes + l] : -1;
-      if (bi >= 0) {
-        // a group inside a look-ahead block: the block's E-steps go first (one launch for all its groups), then one M-step
-        // launch per group, descriptors by value
-        const Block &bk = blocks[l][bi];
-        if (bk.g0 == g) {
-          rc = (dt == HAMSM_F32) ? launch_assign_ahead<float>(c, lanes[l], d_steps, (const AheadDev *)(b + o_ah), (const int *)(b + o_ylist) + bk.y0, bk.y1 - bk.y0, bk.max_nb, ldx)
-                                 : launch_assign_ahead<double>(c, lanes[l], d_steps, (const AheadDev *)(b + o_ah), (const int *)(b + o_ylist) + bk.y0, bk.y1 - bk.y0, bk.max_nb, ldx);
+      if (ahead_on && in_seg[g * n_lanes + l]) {
+        // a group inside a pipelined segment: the launches planned for it, in order
+        const double ratio_m = ratio;
+        for (const PipeOp &o : ops[l]) {
+          if (o.g != g) continue;
+          const int n_e = o.y1 - o.y0;
+          const int *d_yl = (const int *)(b + o_ylist) + o.y0;
+          if (o.m.empty()) {
+            rc = (dt == HAMSM_F32) ? launch_assign_ahead<float>(c, lanes[l], (const StepDev *)(b + o_sde), (const AheadDev *)(b + o_ah), d_yl, n_e, o.e_nb, ldx)
+                                   : launch_assign_ahead<double>(c, lanes[l], (const StepDev *)(b + o_sde), (const AheadDev *)(b + o_ah), d_yl, n_e, o.e_nb, ldx);
+          } else {
+            for (size_t c0_ = 0; c0_ < o.m.size() && !rc; c0_ += PACK_NY) {  // (descriptors by value: PACK_NY strata per launch)
+              const int n_m = (int)(o.m.size() - c0_ < PACK_NY ? o.m.size() - c0_ : PACK_NY);
+              AheadPack apk;
+              int mK = 0;
+              for (int q = 0; q < n_m; q++) {
+                pk.s[q] = sd[o.m[c0_ + q]];
+                apk.a[q] = ahd[o.m[c0_ + q]];
+                mK = pk.s[q].K > mK ? pk.s[q].K : mK;
+              }
+              for (int q = n_m; q < PACK_NY; q++) apk.a[q] = apk.a[0];
+              pk.n_next = 0;
+              const bool with_e = c0_ == 0 && n_e > 0;
+              rc = (dt == HAMSM_F32) ? launch_pipe<float>(c, lanes[l], pk, apk, n_m, mK, (const StepDev *)(b + o_sde), (const AheadDev *)(b + o_ah),
+                                                          d_yl, with_e ? n_e : 0, with_e ? o.e_nb : 0, ldx, ratio_m)
+                                     : launch_pipe<double>(c, lanes[l], pk, apk, n_m, mK, (const StepDev *)(b + o_sde), (const AheadDev *)(b + o_ah),
+                                                           d_yl, with_e ? n_e : 0, with_e ? o.e_nb : 0, ldx, ratio_m);
+            }
+          }
           if (rc) {
             hipDeviceSynchronize();
             return rc;
           }
         }
-        std::vector<int64_t> in_block;
-        for (int64_t q : mine)
-          if (ahd[q].pos >= 0) in_block.push_back(q);
-        // (steps with no rows take no part in a block and launch nothing, as in the step-by-step path)
-        const size_t lds = sizeof(int) * (4 * AHEAD_STRIP) + sizeof(double) * (4 * AHEAD_HX) + sizeof(int) * (4 * 2 * AHEAD_ITEMS);
-        static const bool unsafe_timing = getenv("HAMSM_AHEAD_UNSAFE_TIMING") != nullptr;  // (experiments only: wrong results)
-        const double ratio_m = unsafe_timing ? -1.0 : ratio;
-        for (size_t c0_ = 0; c0_ < in_block.size(); c0_ += PACK_NY) {  // (descriptors by value: PACK_NY strata per launch)
-        const int nyb = (int)(in_block.size() - c0_ < PACK_NY ? in_block.size() - c0_ : PACK_NY);
-        bool any_perm = false;
-        AheadPack apk;
-        for (int q = 0; q < nyb; q++) {
-          pk.s[q] = sd[in_block[c0_ + q]];
-          apk.a[q] = ahd[in_block[c0_ + q]];
-          any_perm = any_perm || pk.s[q].perm;
-        }
-        for (int q = nyb; q < PACK_NY; q++) apk.a[q] = apk.a[0];
-        pk.n_next = 0;
-        const dim3 gu((unsigned)((maxK + 3) / 4), (unsigned)nyb);
-        if (dt == HAMSM_F32) {
-          if (c->D <= 64) hipLaunchKernelGGL((k_step_update_ahead<float, 1>), gu, dim3(256), lds, lanes[l], pk, apk, ldx, c->D, c->KS, ratio_m);
-          else hipLaunchKernelGGL((k_step_update_ahead<float, 2>), gu, dim3(256), lds, lanes[l], pk, apk, ldx, c->D, c->KS, ratio_m);
-          if (any_perm) hipLaunchKernelGGL((k_step_reassign<float, true>), dim3((unsigned)nyb), dim3(256), 0, lanes[l], d_steps, pk, ldx, c->D, c->KS, ratio);
-        } else {
-          if (c->D <= 64) hipLaunchKernelGGL((k_step_update_ahead<double, 1>), gu, dim3(256), lds, lanes[l], pk, apk, ldx, c->D, c->KS, ratio_m);
-          else hipLaunchKernelGGL((k_step_update_ahead<double, 2>), gu, dim3(256), lds, lanes[l], pk, apk, ldx, c->D, c->KS, ratio_m);
-          if (any_perm) hipLaunchKernelGGL((k_step_reassign<double, true>), dim3((unsigned)nyb), dim3(256), 0, lanes[l], d_steps, pk, ldx, c->D, c->KS, ratio);
-        }
-        }
+        for (const CopyBack &cb : copy_back)
+          if (cb.g == g && lane_of_stratum(cb.y) == l) {
+            const Stratum &t = c->st[cb.y];
+            const size_t kq = (size_t)((t.K + 15) & ~15);
+            hipLaunchKernelGGL(k_tables_home, dim3(32), dim3(256), 0, lanes[l], (const int32_t *)(b + o_halt) + cb.y, (int)cb.q,
+                               (const double *)altC(cb.y), t.C, (size_t)t.K * c->D, (const double *)altCsq(cb.y), t.csq,
+                               (const double *)altCnt(cb.y), t.counts, kq, (const double *)altBp(cb.y), t.Bpack, kq * c->KS * 4);
+          }
         continue;
       }
       c->ahead_stat[5] += ny;
@@ -3943,8 +4047,24 @@ static int run_steps(hamsm_ctx *c, const void *X, int dt, int64_t ldx, const int
     HIPCHK(c, hipEventRecord(c->ev_join[l - 1], lanes[l]));
     HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_join[l - 1], 0));
   }
-  for (int64_t i : tail_checks)
-    if (runs(i)) hipLaunchKernelGGL(k_step_check, dim3(1), dim3(256), 0, c->stream, d_steps + i, ratio, (int)n_steps);
+  {
+    // (a stratum's last step may have run inside a segment, its descriptor naming the alternate tables: the check reads the
+    // stratum's own, where the segment's end has brought them)
+    std::vector<StepDev> tails;
+    for (int64_t i : tail_checks)
+      if (runs(i)) {
+        StepDev d = sd[i];
+        const Stratum &t = c->st[h_steps[i].stratum];
+        d.C = t.C, d.counts = t.counts, d.csq = t.csq, d.Bpack = t.Bpack;
+        tails.push_back(d);
+      }
+    if (!tails.empty()) {
+      HIPCHK(c, hipMemcpyAsync(b + o_tail, tails.data(), sizeof(StepDev) * tails.size(), hipMemcpyHostToDevice, c->stream));
+      for (size_t k = 0; k < tails.size(); k++)
+        hipLaunchKernelGGL(k_step_check, dim3(1), dim3(256), 0, c->stream, (const StepDev *)(b + o_tail) + k, ratio, (int)n_steps);
+      HIPCHK(c, hipStreamSynchronize(c->stream));  // (`tails` is a local)
+    }
+  }
   hamsm_timer_end(c, ST_STEP);
   if (hipError_t le = hipGetLastError(); le != hipSuccess) {
     hipDeviceSynchronize();
@@ -3959,6 +4079,25 @@ static int run_steps(hamsm_ctx *c, const void *X, int dt, int64_t ldx, const int
     if (e == hipSuccess) e = es;
     if (e != hipSuccess) return hamsm_fail(c, HAMSM_EDEVICE, "minibatch_run read-back: %s", hipGetErrorString(e));
   }
+  // a chain that stopped inside a pipelined segment: its tables are where its last applied step wrote them
+  if (ahead_can)
+    for (int s_ = 0; s_ < c->S; s_++) {
+      if (!live[s_] || hw[s_] == 0x7f7f7f7f) continue;
+      int64_t last = -1;
+      for (int64_t q = (int64_t)hw[s_] - 1; q >= from[s_] && q >= 0; q--)
+        if (h_steps[q].stratum == s_ && h_steps[q].n_b > 0) {
+          last = q;
+          break;
+        }
+      if (last >= 0 && ahd[last].pos >= 0 && out_alt[last]) {
+        const Stratum &t = c->st[s_];
+        const size_t kq = (size_t)((t.K + 15) & ~15);
+        HIPCHK(c, hipMemcpyAsync(t.C, altC(s_), sizeof(double) * (size_t)t.K * c->D, hipMemcpyDeviceToDevice, c->stream));
+        HIPCHK(c, hipMemcpyAsync(t.csq, altCsq(s_), sizeof(double) * kq, hipMemcpyDeviceToDevice, c->stream));
+        HIPCHK(c, hipMemcpyAsync(t.counts, altCnt(s_), sizeof(double) * (size_t)t.K, hipMemcpyDeviceToDevice, c->stream));
+        HIPCHK(c, hipMemcpyAsync(t.Bpack, altBp(s_), sizeof(double) * kq * c->KS * 4, hipMemcpyDeviceToDevice, c->stream));
+      }
+    }
   bool again = false;
   for (int s_ = 0; s_ < c->S; s_++) {
     if (!live[s_]) continue;
