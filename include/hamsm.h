@@ -324,7 +324,8 @@ typedef struct hamsm_step {
   int64_t n_b;
   int64_t perm_off;
   int32_t n_perm;
-  int32_t reserved;
+  int32_t n_span; /* optional: the step's row indices are all below this (the frames of its WE iterations); 0 = not stated.
+                     Lets the library run a large call's E-step through the assignment kernels (labels per frame of the span) */
 } hamsm_step;
 
 /* why a stratum's chain of steps stopped (h_reason of hamsm_minibatch_run) */

@@ -536,7 +536,7 @@ class Hamsm:
 
     # -- batched training plan ----------------------------------------------------------------
     STEP_DTYPE = np.dtype([("stratum", "<i4"), ("flags", "<i4"), ("x_off", "<i8"), ("rows_off", "<i8"), ("n_b", "<i8"),
-                           ("perm_off", "<i8"), ("n_perm", "<i4"), ("reserved", "<i4")])
+                           ("perm_off", "<i8"), ("n_perm", "<i4"), ("n_span", "<i4")])
     STOP_NONE, STOP_LOW, STOP_UNUSED, STOP_CAP, STOP_ZERO = 0, 1, 2, 3, 4
 
     def train_build_rows_batched(self, d_bin, group_begin, group_end, call_remap, d_rows):

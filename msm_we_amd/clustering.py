@@ -385,6 +385,7 @@ class ClusteringMixin:
             st = np.zeros(len(gs), dtype=h.STEP_DTYPE)
             st["stratum"], st["flags"] = b, (do & (ratio > 0)).astype(np.int32)
             st["x_off"], st["rows_off"], st["n_b"] = gb[gs], starts[gs, b], nb
+            st["n_span"] = np.minimum(ge[gs] - gb[gs], 2 ** 31 - 1)   # row indices of a call range over its group's frames
             parts.append((gs, np.full(len(gs), b), st, t == 0))
             pred[b] = dict(bs=bs, init=init_size, n_since=int((len(gs) - 1) % period) * bs, nsteps=len(gs))
             first_g[b] = gs[0]

@@ -42,6 +42,10 @@ struct AssignArgs {
   const StratumDev *table;
   int S, D, Kfit;
   int *err;
+  // the training pass's E-step through these kernels (hamsm_assign_rows): the frames are named by a row list that is already
+  // grouped by stratum, with the strata's row counts on the device -- no bucket passes, no adaptive state touched
+  const int32_t *perm_in = nullptr;
+  const unsigned long long *cnt_in = nullptr;
 };
 
 // ---- classify -----------------------------------------------------------------------------------
@@ -973,7 +977,8 @@ static int launch_sorted(hamsm_ctx *c, const AssignArgs &a) {
   // the ranking pass is bypassed for a few calls after one in which it settled less than 3/4 of the frames (data full of
   // near ties: both passes would then cost more than the exact one alone); the labels are the same either way
   const bool generic = KS > 32;  // more than 128 features: k_assign_generic, no ranking pass
-  const bool filt = !generic && c->assign_filter != 0 && !(c->filter_skip > 0 && c->filter_skip--);
+  const bool rows_given = a.perm_in != nullptr;
+  const bool filt = !generic && c->assign_filter != 0 && (rows_given || !(c->filter_skip > 0 && c->filter_skip--));
   c->filter_ran = 0;
   c->filter_form = 0;
   size_t off = 0;
@@ -992,7 +997,7 @@ static int launch_sorted(hamsm_ctx *c, const AssignArgs &a) {
   // 29.2 ms per 2 x 10 M rows, full bf16 31.6, light bf16 26.8) -- when that steps aside there, the f32 form takes over.
   // HAMSM_FILTER_BF16=2 allows the full bf16 form up to D = 64 as well (experiments).
   const bool lite_ok = filt && c->filter_bf16 != 0 && KS <= 16 &&
-                       (c->filter_lite == 2 || (c->filter_lite == 1 && !(c->filter_lite_skip > 0 && c->filter_lite_skip--)));
+                       (c->filter_lite == 2 || (c->filter_lite == 1 && (rows_given || !(c->filter_lite_skip > 0 && c->filter_lite_skip--))));
   const bool bf = c->filter_bf16 != 0 && (KS <= 8 || (KS <= 16 && (lite_ok || c->filter_bf16 == 2)));        // bf16 x 3 form of the ranking pass (D <= 32; measured slower at D = 64, K_s = 1250)
   const int KBmin = (4 * KS + 13) / 16, KB = (a.D + 16) / 16;  // bf16 form: blocks of 16 slots
   const int aug = bf ? KB - KBmin : KH - 2 * KS;
@@ -1048,15 +1053,23 @@ static int launch_sorted(hamsm_ctx *c, const AssignArgs &a) {
       f.G = f.G < 2 ? 2 : (f.G > tmax ? tmax : f.G & ~1);
     }
   }
+  if (rows_given) {
+    g.perm = (int32_t *)a.perm_in;
+    g.cnt = (unsigned long long *)a.cnt_in;
+    hipLaunchKernelGGL(k_sort_offsets, dim3(1), dim3(64), 0, c->stream, g);
+  } else {
   HIPCHK(c, hipMemsetAsync(b + o_cnt, 0, sizeof(long long) * S, c->stream));
   unsigned gridc = (unsigned)((n + 255) / 256 < 2048 ? (n + 255) / 256 : 2048);
   hipLaunchKernelGGL(k_sort_count, dim3(gridc), dim3(256), sizeof(unsigned int) * S, c->stream, c->mapper, g);
   hipLaunchKernelGGL(k_sort_offsets, dim3(1), dim3(64), 0, c->stream, g);
   hipLaunchKernelGGL(k_sort_fill, dim3(gridc), dim3(256), sizeof(unsigned int) * ((S + 1) & ~1) + sizeof(long long) * S,
                      c->stream, g);
+  }
   HIPCHK(c, hipGetLastError());
-  hamsm_timer_end(c, ST_OTHER);   // the three bucket passes
-  hamsm_timer_begin(c);           // ... and the distance kernels proper (ST_ASSIGN, ended by the caller)
+  if (!rows_given) {
+    hamsm_timer_end(c, ST_OTHER);   // the three bucket passes
+    hamsm_timer_begin(c);           // ... and the distance kernels proper (ST_ASSIGN, ended by the caller)
+  }
   if (filt) {
     // (staged in a buffer the ctx owns: an asynchronous copy must never read from a local that dies with this scope)
     c->h_stage.resize(sizeof(FiltDev) * S);
@@ -1116,9 +1129,11 @@ static int launch_sorted(hamsm_ctx *c, const AssignArgs &a) {
     g.blkbase = (long long *)(b + o_blk2);
     hipLaunchKernelGGL(k_sort_offsets2, dim3(1), dim3(64), 0, c->stream, g, f.cnt2, (long long *)(b + o_end2), (long long *)(b + o_blk2));
     HIPCHK(c, hipGetLastError());
-    if (!c->h_und) HIPCHK(c, hipHostMalloc((void **)&c->h_und, sizeof(unsigned long long) * S));
-    HIPCHK(c, hipMemcpyAsync(c->h_und, f.cnt2, sizeof(unsigned long long) * S, hipMemcpyDeviceToHost, c->stream));
-    c->filter_ran = 1;
+    if (!rows_given) {
+      if (!c->h_und) HIPCHK(c, hipHostMalloc((void **)&c->h_und, sizeof(unsigned long long) * S));
+      HIPCHK(c, hipMemcpyAsync(c->h_und, f.cnt2, sizeof(unsigned long long) * S, hipMemcpyDeviceToHost, c->stream));
+      c->filter_ran = 1;
+    }
   }
   if (generic) {
     unsigned grid = (unsigned)((n + 63) / 64 + S);  // upper bound; surplus workgroups exit at once
@@ -1133,6 +1148,18 @@ static int launch_sorted(hamsm_ctx *c, const AssignArgs &a) {
 #undef CASE
   }
   return hamsm_fail(c, HAMSM_ENOTSUP, "KS=%d", KS);
+}
+
+// The training pass's E-step through the assignment kernels (run_steps, train.hip): frames d_perm[.] of X (indices below
+// n_span), grouped by stratum with d_cnt[s] rows each; labels[frame] = label offset of the stratum + nearest centroid, as
+// hamsm_assign writes them.  On the context's stream; no synchronisation, no adaptive state.
+int hamsm_assign_rows(hamsm_ctx *c, const void *X, int dt, int64_t ldx, int64_t n_span, int32_t *d_labels, const int32_t *d_perm,
+                      const unsigned long long *d_cnt) {
+  if (n_span <= 0) return HAMSM_OK;
+  AssignArgs g{X, ldx, nullptr, n_span, d_labels, nullptr, c->d_table, c->S, c->D, c->Kfit, c->d_err};
+  g.perm_in = d_perm;
+  g.cnt_in = d_cnt;
+  return (dt == HAMSM_F32) ? launch_sorted<float>(c, g) : launch_sorted<double>(c, g);
 }
 
 // Not part of the product ABI (test / bench hook): the form of the ranking pass the last hamsm_assign ran

@@ -89,6 +89,12 @@ struct hamsm_ctx {
   int ahead_gmax = 16;      // segments hold at most 64 x this many iterations (HAMSM_AHEAD_G)
   double ahead_alpha = 3.0; // displacement allowed = alpha x the latest measurement (HAMSM_AHEAD_ALPHA)
   long long ahead_stat[6] = {0, 0, 0, 0, 0, 0};  // segments, steps inside them, premises failed, -, relaunch passes, steps run step by step
+  // (experiment, OFF: measured slower) a training call whose E-step is bound by the f64 matrix unit
+  // (>= ranked_min_flop per launch group) can run it through the assignment kernels (ranking pass + exact kernel: same labels;
+  // train.hip run_steps).  HAMSM_TRAIN_RANKED=1: by size, 2: always (tests), 0: never (default)
+  int train_ranked = 0;
+  double ranked_min_flop = 1.0e9;  // (HAMSM_RANKED_MIN_MFLOP)
+  long long ranked_groups = 0;     // launch groups served that way (debug counter)
   int generic_stage_kb = 150;  // D > 128: the E-step stages its 16 rows in LDS while they fit this (HAMSM_GENERIC_STAGE_KB; 0 = never)
   // hamsm_malloc / hamsm_free keep released blocks for reuse (hipMalloc costs ~1 ms per 40 MB block and hipFree
   // synchronises the device; every use of a block is ordered on `stream`, so reuse needs no synchronisation)
@@ -192,6 +198,8 @@ int hamsm_refresh_table(hamsm_ctx *c);                    // rebuilds d_table / 
 int hamsm_check_device_error(hamsm_ctx *c, const char *what);  // reads d_err (syncs the stream)
 int hamsm_stratum_reserve(hamsm_ctx *c, int s, int K);
 int hamsm_pack_stratum(hamsm_ctx *c, int s, const double *d_csq_in);
+int hamsm_assign_rows(hamsm_ctx *c, const void *X, int dt, int64_t ldx, int64_t n_span, int32_t *d_labels, const int32_t *d_perm,
+                      const unsigned long long *d_cnt);  // assign.hip: the E-step of a heavy training call
 void hamsm_timer_begin(hamsm_ctx *c);
 void hamsm_timer_end(hamsm_ctx *c, int stage);
 

@@ -1371,6 +1371,80 @@ __device__ __forceinline__ void upd_add_listed(double (&acc)[H], const GAS doubl
   }
 }
 
+// A large call's E-step runs through the assignment kernels (hamsm_assign_rows: ranking pass with a proven bound + exact f64
+// kernel for what it cannot certify -- the labels are the contract's); this kernel turns its output, labels per
+// FRAME of the call's span, into what the M-step reads: membership bitmaps by batch row, the batch rows as f64, the labels by
+// batch row.  Workgroup 0 of each stratum evaluates the tests that ride on k_step_assign's workgroup 0.
+struct RowsPack {
+  int off[PACK_NY];  // label offset of the step's stratum (labels of the span carry it)
+};
+template <typename XT>
+__global__ __launch_bounds__(256) void k_rows_to_bits(const StepPack pk, const RowsPack rp, const int32_t *__restrict__ span_labels,
+                                                      int64_t ldx, int D, int KS, double ratio) {
+  const StepDev sdesc = pk.s[blockIdx.y];
+  const StepG st(sdesc);
+  const long long r0 = (long long)blockIdx.x * 64;
+  if (r0 >= st.n_b) return;
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  __shared__ double sd4[4];
+  if (blockIdx.x == 0 && (st.flags & 6) && st.idx < *gp(sdesc.halt)) {
+    // (k_step_assign's block: `counts < ratio * max(counts)` for the stratum's previous step, `(counts == 0).any()` before this one)
+    const double inf = __builtin_huge_val();
+    const GAS int32_t *prev = gp(sdesc.prev_report);
+    int z = 0;
+    double mx = -inf;
+    for (int j = tid; j < st.K; j += 256) {
+      double cj = st.counts[j];
+      z |= (cj == 0.0);
+      mx = cj > mx ? cj : mx;
+    }
+    int any_low = 0;
+    if (st.flags & 4) {
+#pragma unroll
+      for (int off = 32; off >= 1; off >>= 1) {
+        double o = __shfl_xor(mx, off, 64);
+        mx = o > mx ? o : mx;
+      }
+      if (lane == 0) sd4[wv] = mx;
+      __syncthreads();
+      mx = sd4[0];
+#pragma unroll
+      for (int w = 1; w < 4; w++) mx = sd4[w] > mx ? sd4[w] : mx;
+      const double thr = ratio * mx;
+      int low = 0;
+      for (int j = tid; j < st.K; j += 256) low += st.counts[j] < thr;
+      if (low) __hip_atomic_fetch_add((GAS int32_t *)prev + 1, low, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      any_low = __syncthreads_or(low);
+    }
+    const int any_z = __syncthreads_or((st.flags & 2) ? z : 0);
+    if (tid == 0) {
+      if (any_low) {
+        *gp(sdesc.halt) = st.idx;
+        *gp(sdesc.reason) = HAMSM_STOP_LOW;
+      } else if (any_z) {
+        st.report[0] = 1;
+        *gp(sdesc.halt) = st.idx;
+        *gp(sdesc.reason) = HAMSM_STOP_ZERO;
+      }
+    }
+  }
+  // four threads per batch row
+  const long long r = r0 + (tid >> 2);
+  const int part = tid & 3;
+  if (r >= st.n_b) return;
+  const long long f = st.rows ? (long long)st.rows[r] : r;
+  const GAS XT *X = (const GAS XT *)st.X;
+  const int ldg = 4 * KS;
+  for (int k = part; k < ldg; k += 4) st.Xg[(size_t)r * ldg + k] = k < D ? (double)X[f * ldx + k] : 0.0;
+  if (part == 0) {
+    int j = ((const GAS int32_t *)gp(span_labels))[f] - rp.off[blockIdx.y];
+    j = (j >= 0 && j < st.K) ? j : 0;
+    st.labels[r] = j;
+    __hip_atomic_fetch_or(&st.mbits[(size_t)j * sdesc.wstride + (r >> 6)], 1ull << (r & 63), __ATOMIC_RELAXED,
+                          __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+
 // M-step: one wave per centroid.  Round trip 1 fetches the centroid's membership bitmap (one word per lane), its count
 // and its row; the set bits ARE the members in ascending sample order (no list to sort, no cap on the cluster size):
 // each lane expands its word into the wave's LDS strip at the position given by a prefix sum of the popcounts.
@@ -1522,8 +1596,8 @@ __global__ __launch_bounds__(256) void k_step_update(const StepDev *__restrict__
 #define AHEAD_KAPPA 3.637978807091713e-12   // 2^-38
 #define AHEAD_EPS 9.5367431640625e-07       // 2^-20
 #define AHEAD_BIG 1e300                     // "no such centroid" (finite: the index bits must not turn an infinity into a NaN)
-#define AHEAD_STRIP 2048                    // ints of LDS per wave of the M-step (8 KB: the member list, or undecided rows)
-#define AHEAD_HX 896                        // doubles of LDS per wave for the next step's open rows (60 KB per workgroup in all)
+#define AHEAD_STRIP 1536                    // ints of LDS per wave of the M-step (6 KB: the member list and its weights, then the new row)
+#define AHEAD_HX 640                        // doubles of LDS per wave for the next step's rows (46 KB per workgroup in all: three per CU)
 #define AHEAD_HCAP 32                       // most open rows per step (fewer for long rows: they wait in LDS)
 #define AHEAD_KMAX 4096                     // centroids per stratum the 12 index bits can name
 
@@ -3345,6 +3419,17 @@ static void launch_step_kernels(hamsm_ctx *c, hipStream_t q, const StepDev *d_st
     hipLaunchKernelGGL((k_step_reassign<XT, BYVAL>), dim3((unsigned)ny), dim3(256), 0, q, d_steps, pk, ldx, c->D, c->KS, ratio);
 }
 
+// the M-step (and the device re-seeding) of steps whose E-step ran through the assignment kernels; descriptors by value
+template <typename XT>
+static void launch_update_only(hamsm_ctx *c, hipStream_t q, const StepPack &pk, int ny, int maxK, int64_t ldx, double ratio, bool any_perm) {
+  const size_t lds = sizeof(int) * (4 * UPD_LIST);
+  const dim3 gu((unsigned)((maxK + 3) / 4), (unsigned)ny);
+  if (c->D <= 64) hipLaunchKernelGGL((k_step_update<XT, 1, true>), gu, dim3(256), lds, q, (const StepDev *)nullptr, pk, ldx, c->D, c->KS);
+  else hipLaunchKernelGGL((k_step_update<XT, 2, true>), gu, dim3(256), lds, q, (const StepDev *)nullptr, pk, ldx, c->D, c->KS);
+  if (any_perm)
+    hipLaunchKernelGGL((k_step_reassign<XT, true>), dim3((unsigned)ny), dim3(256), 0, q, (const StepDev *)nullptr, pk, ldx, c->D, c->KS, ratio);
+}
+
 // row tiles per E-step workgroup: as many as the registers allow (RT * KS <= 32) while the launch keeps >= 128 workgroups
 template <typename XT, int KS, bool BYVAL>
 static void launch_step_rt(hamsm_ctx *c, hipStream_t q, const StepDev *d_steps, const StepPack &pk, int ny, long long max_nb,
@@ -3508,12 +3593,52 @@ static int run_steps(hamsm_ctx *c, const void *X, int dt, int64_t ldx, const int
     int64_t hi = (d_rows ? s.rows_off : 0) + s.n_b;
     if (hi > lab_hi) lab_hi = hi;
   }
+  // launch groups = maximal runs of distinct strata
+  std::vector<int64_t> gstart;
+  {
+    std::vector<char> used(c->S);
+    int64_t i0 = 0;
+    while (i0 < n_steps) {
+      std::fill(used.begin(), used.end(), 0);
+      int64_t j0 = i0;
+      while (j0 < n_steps && !used[h_steps[j0].stratum] && j0 - i0 < 65535) used[h_steps[j0++].stratum] = 1;
+      gstart.push_back(i0);
+      i0 = j0;
+    }
+    gstart.push_back(n_steps);
+  }
+  // Groups whose E-step is heavy enough to be bound by the f64 matrix unit run it through the assignment kernels instead
+  // (hamsm_assign_rows: ranking on the bf16 / f32 matrix unit under a proven bound, exact f64 kernel for the rest -- the same
+  // labels): the group's strata ascend, their row lists lie back to back, the steps share one frame
+  // span and say how long it is (`n_span`).  Such a pass keeps to one queue (the assignment kernels have one scratch arena).
+  std::vector<char> ranked(gstart.size() - 1, 0);
+  bool any_ranked = false;
+  int64_t span_max = 0;
+  if (c->train_ranked && !generic && d_rows && h_report && c->assign_filter && c->have_mapper)
+    for (size_t g = 0; g + 1 < gstart.size(); g++) {
+      const int64_t i = gstart[g], j = gstart[g + 1];
+      bool good = h_steps[i].n_span > 0;
+      double flop = 0;
+      for (int64_t q = i; q < j && good; q++) {
+        const hamsm_step &st_ = h_steps[q];
+        good = st_.n_b > 0 && st_.x_off == h_steps[i].x_off && st_.n_span == h_steps[i].n_span && !(st_.flags & HAMSM_STEP_FIRST);
+        if (q > i) good = good && st_.stratum > h_steps[q - 1].stratum && st_.rows_off == h_steps[q - 1].rows_off + h_steps[q - 1].n_b;
+        flop += 2.0 * (double)st_.n_b * c->st[st_.stratum].K * c->D;
+      }
+      if (good && (c->train_ranked == 2 || flop >= c->ranked_min_flop)) {
+        ranked[g] = 1;
+        any_ranked = true;
+        span_max = h_steps[i].n_span > span_max ? h_steps[i].n_span : span_max;
+      }
+    }
   size_t off = 0;
   auto take = [&](size_t bytes) {
     size_t o = off;
     off = (off + bytes + 255) & ~(size_t)255;
     return o;
   };
+  size_t o_gcnt = take(any_ranked ? sizeof(unsigned long long) * (size_t)c->S * (gstart.size() - 1) : 0),
+         o_lspan = take(sizeof(int32_t) * (size_t)span_max);
   size_t o_steps = take(sizeof(StepDev) * n_steps), o_rep = take(sizeof(int32_t) * 2 * n_steps),
          o_lab = take(sizeof(int32_t) * (size_t)lab_hi), o_halt = take(sizeof(int32_t) * 2 * (size_t)c->S),
          o_perm = take(sizeof(int32_t) * (size_t)(n_perm_total > 0 ? n_perm_total : 1));
@@ -3538,7 +3663,7 @@ static int run_steps(hamsm_ctx *c, const void *X, int dt, int64_t ldx, const int
   const size_t ah_words = ahead_can ? (size_t)n_steps : 0;  // per step: displacement slot, bound, two counters
   const int ah_kst = (Kmax + 63) & ~63;
   const int ah_dp = (c->D + 1) & ~1;
-  int ah_hcap = AHEAD_HX / ah_dp < AHEAD_HCAP ? AHEAD_HX / ah_dp : AHEAD_HCAP;  // (>= 7: D <= 128)
+  int ah_hcap = AHEAD_HX / ah_dp < AHEAD_HCAP ? AHEAD_HX / ah_dp : AHEAD_HCAP;  // (>= 5: D <= 128)
   if (const char *v = getenv("HAMSM_AHEAD_HCAP")) ah_hcap = atoi(v) < ah_hcap ? (atoi(v) < 0 ? 0 : atoi(v)) : ah_hcap;  // (experiments)
   size_t o_slot = take(sizeof(double) * 2 * ah_words), o_cnt = take(sizeof(int32_t) * 4 * ah_words),
          o_hl = take(ahead_can ? sizeof(int32_t) * AHEAD_HCAP * (size_t)nslot * npos : 0),
@@ -3594,27 +3719,26 @@ static int run_steps(hamsm_ctx *c, const void *X, int dt, int64_t ldx, const int
   }
   for (int s = 0; s < c->S; s++)
     if (last_of[s] >= 0 && (sd[last_of[s]].flags & 1) && !sd[last_of[s]].perm) tail_checks.push_back(last_of[s]);
-  // launch groups = maximal runs of distinct strata; member-list slot = position inside the run
-  std::vector<int64_t> gstart;
-  {
-    std::vector<char> used(c->S);
-    int64_t i0 = 0;
-    while (i0 < n_steps) {
-      std::fill(used.begin(), used.end(), 0);
-      int64_t j0 = i0;
-      while (j0 < n_steps && !used[h_steps[j0].stratum] && j0 - i0 < 65535) {
-        used[h_steps[j0].stratum] = 1;
-        // scratch slot = the stratum itself: chains of different strata run concurrently on different queues
-        const size_t slot = nslot == c->S ? (size_t)h_steps[j0].stratum : (size_t)(j0 - i0);
-        sd[j0].Xg = (double *)(b + o_xg + slot * npos * nb_pad * xg_row);
-        sd[j0].mbits = (unsigned long long *)(b + o_mb) + slot * npos * Kmax * wstride;
-        sd[j0].wstride = wstride;
-        j0++;
-      }
-      gstart.push_back(i0);
-      i0 = j0;
+  // member-list slot of a step = its stratum (chains of different strata run concurrently on different queues), else its
+  // position inside its launch group
+  for (size_t g = 0; g + 1 < gstart.size(); g++)
+    for (int64_t j0 = gstart[g]; j0 < gstart[g + 1]; j0++) {
+      const size_t slot = nslot == c->S ? (size_t)h_steps[j0].stratum : (size_t)(j0 - gstart[g]);
+      sd[j0].Xg = (double *)(b + o_xg + slot * npos * nb_pad * xg_row);
+      sd[j0].mbits = (unsigned long long *)(b + o_mb) + slot * npos * Kmax * wstride;
+      sd[j0].wstride = wstride;
     }
-    gstart.push_back(n_steps);
+  if (any_ranked) {
+    // the strata's row counts of every group (what the assignment kernels' bucket passes would have counted)
+    rc = hamsm_refresh_table(c);
+    if (rc) return rc;
+    c->h_stage.assign(sizeof(unsigned long long) * (size_t)c->S * (gstart.size() - 1), 0);
+    unsigned long long *gc = (unsigned long long *)c->h_stage.data();
+    for (size_t g = 0; g + 1 < gstart.size(); g++)
+      if (ranked[g])
+        for (int64_t q = gstart[g]; q < gstart[g + 1]; q++) gc[g * c->S + h_steps[q].stratum] = (unsigned long long)h_steps[q].n_b;
+    HIPCHK(c, hipMemcpyAsync(b + o_gcnt, gc, c->h_stage.size(), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));  // (hamsm_assign_rows re-uses the staging vector)
   }
   if (labels_of_first) *labels_of_first = sd[0].labels;
   HIPCHK(c, hipMemcpyAsync(b + o_steps, sd.data(), sizeof(StepDev) * n_steps, hipMemcpyHostToDevice, c->stream));
@@ -3681,7 +3805,7 @@ static int run_steps(hamsm_ctx *c, const void *X, int dt, int64_t ldx, const int
     for (int64_t q = gstart[g]; q < gstart[g + 1]; q++)
       if (++cnt[h_steps[q].stratum % n_lanes] > PACK_NY) n_lanes = 1;
   }
-  if (gstart.size() <= 2 || c->S < 2 || nslot != c->S || !d_rows || generic) n_lanes = 1;  // (labels scratch is per step only with row lists)
+  if (gstart.size() <= 2 || c->S < 2 || nslot != c->S || !d_rows || generic || any_ranked) n_lanes = 1;  // (labels scratch is per step only with row lists)
   auto runs = [&](int64_t q) { return live[h_steps[q].stratum] && q >= from[h_steps[q].stratum]; };
   auto lane_of = [&](int64_t q) { return n_lanes > 1 ? h_steps[q].stratum % n_lanes : 0; };
   auto lane_of_stratum = [&](int y) { return n_lanes > 1 ? y % n_lanes : 0; };
@@ -3990,6 +4114,46 @@ static int run_steps(hamsm_ctx *c, const void *X, int dt, int64_t ldx, const int
       c->ahead_stat[5] += ny;
       const StepDev *dptr = d_steps + i;
       const bool contiguous = (int64_t)mine.size() == j - i;  // (a relaunch may run only some strata of a group)
+      if (ranked[g] && contiguous && n_lanes == 1) {
+        // the E-step of the whole group through the assignment kernels, then its outputs in the M-step's form, then the M-steps
+        const hamsm_step &s0 = h_steps[i];
+        rc = hamsm_assign_rows(c, (const char *)X + (size_t)s0.x_off * ldx * esz, dt, ldx, s0.n_span, (int32_t *)(b + o_lspan),
+                               d_rows + s0.rows_off, (const unsigned long long *)(b + o_gcnt) + g * c->S);
+        for (size_t c0_ = 0; c0_ < mine.size() && !rc; c0_ += PACK_NY) {
+          const int nyc = (int)(mine.size() - c0_ < PACK_NY ? mine.size() - c0_ : PACK_NY);
+          RowsPack rp;
+          long long mnb = 0;
+          int mK = 0;
+          bool ap = false;
+          for (int q = 0; q < nyc; q++) {
+            const int64_t sq = mine[c0_ + q];
+            const int y = h_steps[sq].stratum;
+            pk.s[q] = sd[sq];
+            int lo = 0;
+            for (int y2 = 0; y2 < y; y2++) lo += c->st[y2].K;
+            rp.off[q] = lo;
+            ap = ap || sd[sq].perm;
+            mnb = h_steps[sq].n_b > mnb ? h_steps[sq].n_b : mnb;
+            mK = c->st[y].K > mK ? c->st[y].K : mK;
+          }
+          for (int q = nyc; q < PACK_NY; q++) rp.off[q] = 0;
+          pk.n_next = 0;
+          const dim3 gr((unsigned)((mnb + 63) / 64), (unsigned)nyc);
+          if (dt == HAMSM_F32) {
+            hipLaunchKernelGGL(k_rows_to_bits<float>, gr, dim3(256), 0, lanes[l], pk, rp, (const int32_t *)(b + o_lspan), ldx, c->D, c->KS, ratio);
+            launch_update_only<float>(c, lanes[l], pk, nyc, mK, ldx, ratio, ap);
+          } else {
+            hipLaunchKernelGGL(k_rows_to_bits<double>, gr, dim3(256), 0, lanes[l], pk, rp, (const int32_t *)(b + o_lspan), ldx, c->D, c->KS, ratio);
+            launch_update_only<double>(c, lanes[l], pk, nyc, mK, ldx, ratio, ap);
+          }
+        }
+        if (rc) {
+          hipDeviceSynchronize();
+          return rc;
+        }
+        c->ranked_groups++;
+        continue;
+      }
       if (!contiguous && (ny > PACK_NY || generic)) {
         // only some strata of a group that travels by descriptors in memory: PACK_NY of them per launch, by value
         for (size_t c0_ = 0; c0_ < mine.size() && !rc; c0_ += PACK_NY) {
@@ -4174,6 +4338,16 @@ static int run_steps(hamsm_ctx *c, const void *X, int dt, int64_t ldx, const int
   return HAMSM_OK;
 }
 
+// (debug hooks, outside the ABI) the E-step of heavy training calls through the assignment kernels: mode 0 never, 1 by size, 2 always;
+// returns the launch groups served that way since the last call (and resets the count)
+extern "C" long long hamsm_debug_set_ranked(hamsm_ctx *c, int mode, double min_mflop) {
+  if (hamsm_ctx_check(c, __func__)) return -1;
+  if (mode >= 0) c->train_ranked = mode > 2 ? 2 : mode;
+  if (min_mflop > 0) c->ranked_min_flop = min_mflop * 1e6;
+  const long long n = c->ranked_groups;
+  c->ranked_groups = 0;
+  return n;
+}
 // (debug hooks, outside the ABI) look-ahead blocks: knobs and counters of a context
 extern "C" int hamsm_debug_set_ahead(hamsm_ctx *c, int on, int n0, int gmax, double alpha) {
   CTX(c);
