@@ -87,6 +87,7 @@ struct hamsm_ctx {
   int ahead = 0;
   int ahead_n0 = 200;       // iterations of a pass that run step by step before the first segment (HAMSM_AHEAD_N0)
   int ahead_gmax = 16;      // segments hold at most 64 x this many iterations (HAMSM_AHEAD_G)
+  int ahead_rt = 1;         // 16-row tiles per workgroup of the pipelined E-step (HAMSM_AHEAD_RT = 1 | 2; 2 measured slower)
   double ahead_alpha = 3.0; // displacement allowed = alpha x the latest measurement (HAMSM_AHEAD_ALPHA)
   long long ahead_stat[6] = {0, 0, 0, 0, 0, 0};  // segments, steps inside them, premises failed, -, relaunch passes, steps run step by step
   // (experiment, OFF: measured slower) a training call whose E-step is bound by the f64 matrix unit

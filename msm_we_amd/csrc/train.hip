@@ -979,9 +979,10 @@ struct StepDev {
 // (kept apart: the step-by-step kernels take their descriptors by value and every byte of them is on the launch path)
 struct AheadDev {
   int pos, pad_;              // position of the step among its stratum's steps of the block (0 = the block's first); < 0: not in a block
-  double *slot;               // [1] largest centroid displacement (Euclidean, against the block's snapshot) after this step
-  const double *prev_slot;    // the slot of the stratum's previous step in the block (null at position 0)
-  const double *ref_slot;     // a slot of the previous block: what this step's bound is derived from (null: bound 0)
+  double *slot;               // [AHEAD_SLOTS] largest centroid displacement this step's M-step measured, spread over AHEAD_SLOTS words
+                              // (wave j adds to word j % AHEAD_SLOTS: 250 atomic maxima on ONE word cost 10 us); readers take their maximum
+  const double *prev_slot;    // the slots of the stratum's previous step (null: this step's labels are exact, nothing to check)
+  const double *ref_slot;     // the slots this step's bound is derived from (null: bound 0)
   double ref_scale;           //   bound = ref_scale * *ref_slot
   double *bound;              // [1] the bound the E-step used (read back by the M-step that checks it)
   // the step's M-step reads the stratum's tables where its StepDev points (C, counts, csq) and writes ALL of them, moved or
@@ -1010,6 +1011,7 @@ struct AheadPack {
   AheadDev a[4];
 };
 #define AHEAD_TAB_CAP 256
+#define AHEAD_SLOTS 64
 #define HAMSM_STOP_AHEAD 100  // internal: a look-ahead block was given up at this step; run_steps relaunches from it itself
 // what the next call's E-step will gather: its lines are pulled towards this XCD's L2 while this call computes
 struct StepNext {
@@ -1596,8 +1598,8 @@ __global__ __launch_bounds__(256) void k_step_update(const StepDev *__restrict__
 #define AHEAD_KAPPA 3.637978807091713e-12   // 2^-38
 #define AHEAD_EPS 9.5367431640625e-07       // 2^-20
 #define AHEAD_BIG 1e300                     // "no such centroid" (finite: the index bits must not turn an infinity into a NaN)
-#define AHEAD_STRIP 1536                    // ints of LDS per wave of the M-step (6 KB: the member list and its weights, then the new row)
-#define AHEAD_HX 640                        // doubles of LDS per wave for the next step's rows (46 KB per workgroup in all: three per CU)
+#define AHEAD_STRIP 1024                    // ints of LDS per wave of the M-step (4 KB: the member list and its weights, then the new row)
+#define AHEAD_HX 512                        // doubles of LDS per wave for the next step's rows (34 KB per workgroup in all: four per CU)
 #define AHEAD_HCAP 32                       // most open rows per step (fewer for long rows: they wait in LDS)
 #define AHEAD_KMAX 4096                     // centroids per stratum the 12 index bits can name
 
@@ -1624,24 +1626,39 @@ __device__ __forceinline__ double key_of(double d, int j) {
 }
 __device__ __forceinline__ int key_index(double k) { return __double2loint(k) & 0xFFF; }
 
-template <typename XT, int KS, int JB>
+template <typename XT, int KS, int JB, int RT>
 __device__ __forceinline__ void ahead_assign(const StepDev *__restrict__ steps, const AheadDev *__restrict__ aheads, const int yi,
                                              const unsigned bx, int64_t ldx, int D) {
+  // RT tiles of 16 batch rows per workgroup: every centroid fragment a wave pulls through L2 serves RT MFMAs (this E-step
+  // is off the pass's critical chain and bound by that traffic, unlike k_step_assign)
+  constexpr int RW = 16 * RT;
   const StepDev sdesc = load_step_mem(steps, (unsigned)yi);
   const GAS AheadDev *ahp = gp(aheads + yi);
   const StepG st(sdesc);
-  const long long r0 = (long long)bx * 16;
+  const long long r0 = (long long)bx * RW;
   if (r0 >= st.n_b) return;
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const GAS XT *X = (const GAS XT *)st.X;
-  // the bound of this position (every workgroup derives the same value; workgroup 0 records it for the M-step)
+  // the bound of this step (every workgroup derives the same value; workgroup 0 records it for the M-step)
   const double *ref_slot = ahp->ref_slot;
   const double ref_scale = ahp->ref_scale;
   double B = 0.0;
-  if (ref_slot) B = ref_scale * *gp(ref_slot);
-  const long long r = r0 + (lane & 15);
-  const long long rc = r < st.n_b ? r : st.n_b - 1;
-  const long long f = st.rows ? (long long)st.rows[rc] : rc;
+  if (ref_slot) {
+    double m = gp(ref_slot)[lane & (AHEAD_SLOTS - 1)];
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+      const double o = __shfl_xor(m, off, 64);
+      m = (o > m || o != o) ? o : m;  // (a NaN displacement stays a NaN: the bound fails its check)
+    }
+    B = ref_scale * m;
+  }
+  long long f[RT];
+#pragma unroll
+  for (int rt = 0; rt < RT; rt++) {
+    const long long r = r0 + rt * 16 + (lane & 15);
+    const long long rc = r < st.n_b ? r : st.n_b - 1;
+    f[rt] = st.rows ? (long long)st.rows[rc] : rc;
+  }
   const int njt = (st.K + 15) >> 4;
   const double inf = __builtin_huge_val();
   double b[JB][KS], cs[JB][4];
@@ -1656,66 +1673,91 @@ __device__ __forceinline__ void ahead_assign(const StepDev *__restrict__ steps, 
     }
   };
   load_group(wv);
-  double a[KS];
+  double a[RT][KS];
 #pragma unroll
-  for (int ks = 0; ks < KS; ks++) {
-    const int k = ks * 4 + (lane >> 4);
-    a[ks] = (double)X[f * ldx + (k < D ? k : D - 1)];
-  }
-  __shared__ double sk[4][4][16];
-  __shared__ int snan[4];
+  for (int rt = 0; rt < RT; rt++)
+#pragma unroll
+    for (int ks = 0; ks < KS; ks++) {
+      const int k = ks * 4 + (lane >> 4);
+      a[rt][ks] = (double)X[f[rt] * ldx + (k < D ? k : D - 1)];
+    }
+  __shared__ double sk[4][4][RW];
+  __shared__ int snan[4][RT];
   GAS int32_t *cnt = gp(ahp->cnt);
+  // the batch rows as f64 for the M-step: row tile rt is written by wave (rt + 1) & 3 (as in the step-by-step E-step)
+  auto write_rows = [&]() {
+#pragma unroll
+    for (int rt = 0; rt < RT; rt++)
+      if (((rt + 1) & 3) == wv) {
+        const long long r = r0 + rt * 16 + (lane & 15);
+#pragma unroll
+        for (int ks = 0; ks < KS; ks++) st.Xg[(size_t)r * (4 * KS) + ks * 4 + (lane >> 4)] = a[rt][ks];
+      }
+  };
   if (ahp->pos == 0) {
-    // the block's first step: these ARE the centroids its M-step will see -- the step-by-step E-step's rule, exactly
-    double bd = inf;
-    int bi = 0x7fffffff;
+    // the segment's first steps: these ARE the centroids their M-step will see -- the step-by-step E-step's rule, exactly
+    double bd[RT];
+    int bi[RT];
+#pragma unroll
+    for (int rt = 0; rt < RT; rt++) {
+      bd[rt] = inf;
+      bi[rt] = 0x7fffffff;
+    }
     for (int t0 = wv; t0 < njt; t0 += 4 * JB) {
       if (t0 != wv) load_group(t0);
 #pragma unroll
       for (int u = 0; u < JB; u++) {
         const int jt = t0 + 4 * u;
         if (jt < njt) {
-          v4f64 acc = (v4f64){0.0, 0.0, 0.0, 0.0};
+          v4f64 acc[RT];
 #pragma unroll
-          for (int ks = 0; ks < KS; ks++) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(b[u][ks], a[ks], acc, 0, 0, 0);
+          for (int rt = 0; rt < RT; rt++) acc[rt] = (v4f64){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+          for (int ks = 0; ks < KS; ks++)
+#pragma unroll
+            for (int rt = 0; rt < RT; rt++) acc[rt] = __builtin_amdgcn_mfma_f64_16x16x4f64(b[u][ks], a[rt][ks], acc[rt], 0, 0, 0);
           const int j0 = jt * 16 + (lane >> 4);
 #pragma unroll
-          for (int q = 0; q < 4; q++) {
-            const double d = __builtin_fma(-2.0, acc[q], cs[u][q]);
-            const bool lt = d < bd;
-            bd = lt ? d : bd;
-            bi = lt ? j0 + 4 * q : bi;
-          }
+          for (int rt = 0; rt < RT; rt++)
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+              const double d = __builtin_fma(-2.0, acc[rt][q], cs[u][q]);
+              const bool lt = d < bd[rt];
+              bd[rt] = lt ? d : bd[rt];
+              bi[rt] = lt ? j0 + 4 * q : bi[rt];
+            }
         }
       }
     }
-    if (wv == 1) {
+    write_rows();
+    double *sdv = &sk[0][0][0];       // [4][RW] as one array (the ranking arrays are free on this path)
+    int *sji = (int *)&sk[1][0][0];   // [4][RW]
 #pragma unroll
-      for (int ks = 0; ks < KS; ks++) st.Xg[(size_t)r * (4 * KS) + ks * 4 + (lane >> 4)] = a[ks];
-    }
+    for (int rt = 0; rt < RT; rt++) {
+      double d = bd[rt];
+      int j = bi[rt];
 #pragma unroll
-    for (int off = 16; off <= 32; off <<= 1) {
-      const double d2 = __shfl_xor(bd, off, 64);
-      const int j2 = __shfl_xor(bi, off, 64);
-      const bool take = (d2 < bd) || (d2 == bd && j2 < bi);
-      bd = take ? d2 : bd;
-      bi = take ? j2 : bi;
-    }
-    double *sdv = &sk[0][0][0];       // [4][16] as one array (the ranking arrays are free on this path)
-    int *sji = (int *)&sk[1][0][0];   // [4][16]
-    if (lane < 16) {
-      sdv[wv * 16 + lane] = bd;
-      sji[wv * 16 + lane] = bi;
+      for (int off = 16; off <= 32; off <<= 1) {
+        const double d2 = __shfl_xor(d, off, 64);
+        const int j2 = __shfl_xor(j, off, 64);
+        const bool take = (d2 < d) || (d2 == d && j2 < j);
+        d = take ? d2 : d;
+        j = take ? j2 : j;
+      }
+      if (lane < 16) {
+        sdv[wv * RW + rt * 16 + lane] = d;
+        sji[wv * RW + rt * 16 + lane] = j;
+      }
     }
     __syncthreads();
     if (bx == 0 && tid == 0) *gp(ahp->bound) = 0.0;
-    if (tid < 16 && r0 + tid < st.n_b) {
+    if (tid < RW && r0 + tid < st.n_b) {
       double d = sdv[tid];
       int j = sji[tid];
 #pragma unroll
       for (int w = 1; w < 4; w++) {
-        const double d2 = sdv[w * 16 + tid];
-        const int j2 = sji[w * 16 + tid];
+        const double d2 = sdv[w * RW + tid];
+        const int j2 = sji[w * RW + tid];
         const bool take = (d2 < d) || (d2 == d && j2 < j);
         d = take ? d2 : d;
         j = take ? j2 : j;
@@ -1727,70 +1769,89 @@ __device__ __forceinline__ void ahead_assign(const StepDev *__restrict__ steps, 
     }
     return;
   }
-  double k1 = AHEAD_BIG, k2 = AHEAD_BIG, k3 = AHEAD_BIG, k4 = AHEAD_BIG;
-  bool odd = false;  // a distance that is not a number
+  double kk[RT][4];
+  bool odd[RT];  // a distance that is not a number
+#pragma unroll
+  for (int rt = 0; rt < RT; rt++) {
+    kk[rt][0] = kk[rt][1] = kk[rt][2] = kk[rt][3] = AHEAD_BIG;
+    odd[rt] = false;
+  }
   for (int t0 = wv; t0 < njt; t0 += 4 * JB) {
     if (t0 != wv) load_group(t0);
 #pragma unroll
     for (int u = 0; u < JB; u++) {
       const int jt = t0 + 4 * u;
       if (jt < njt) {
-        v4f64 acc = (v4f64){0.0, 0.0, 0.0, 0.0};
+        v4f64 acc[RT];
 #pragma unroll
-        for (int ks = 0; ks < KS; ks++) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(b[u][ks], a[ks], acc, 0, 0, 0);
+        for (int rt = 0; rt < RT; rt++) acc[rt] = (v4f64){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int ks = 0; ks < KS; ks++)
+#pragma unroll
+          for (int rt = 0; rt < RT; rt++) acc[rt] = __builtin_amdgcn_mfma_f64_16x16x4f64(b[u][ks], a[rt][ks], acc[rt], 0, 0, 0);
         const int j0 = jt * 16 + (lane >> 4);
 #pragma unroll
-        for (int q = 0; q < 4; q++) {
-          // (rows of the last tile past K carry csq = +inf: they rank as "no such centroid")
-          const double d = __builtin_fma(-2.0, acc[q], f64_min(cs[u][q], AHEAD_BIG));
-          odd = odd || (d != d);
-          top4_insert(key_of(d, j0 + 4 * q), k1, k2, k3, k4);
-        }
+        for (int rt = 0; rt < RT; rt++)
+#pragma unroll
+          for (int q = 0; q < 4; q++) {
+            // (rows of the last tile past K carry csq = +inf: they rank as "no such centroid")
+            const double d = __builtin_fma(-2.0, acc[rt][q], f64_min(cs[u][q], AHEAD_BIG));
+            odd[rt] = odd[rt] || (d != d);
+            top4_insert(key_of(d, j0 + 4 * q), kk[rt][0], kk[rt][1], kk[rt][2], kk[rt][3]);
+          }
       }
     }
   }
-  // the batch rows as f64 for the M-step (wave 1 writes, as in the step-by-step E-step)
-  if (wv == 1) {
+  write_rows();
+  double x2r[RT];
 #pragma unroll
-    for (int ks = 0; ks < KS; ks++) st.Xg[(size_t)r * (4 * KS) + ks * 4 + (lane >> 4)] = a[ks];
-  }
-  // |x|^2 of the lane's row (features past D were read at the clamped index: not counted)
-  double x2 = 0.0;
+  for (int rt = 0; rt < RT; rt++) {
+    // |x|^2 of the lane's row (features past D were read at the clamped index: not counted)
+    double x2 = 0.0;
 #pragma unroll
-  for (int ks = 0; ks < KS; ks++) {
-    const int k = ks * 4 + (lane >> 4);
-    x2 = k < D ? __builtin_fma(a[ks], a[ks], x2) : x2;
-  }
-  x2 += __shfl_xor(x2, 16, 64);
-  x2 += __shfl_xor(x2, 32, 64);
-  // lanes l, l^16, l^32, l^48 hold the same batch row: merge their four best
+    for (int ks = 0; ks < KS; ks++) {
+      const int k = ks * 4 + (lane >> 4);
+      x2 = k < D ? __builtin_fma(a[rt][ks], a[rt][ks], x2) : x2;
+    }
+    x2 += __shfl_xor(x2, 16, 64);
+    x2 += __shfl_xor(x2, 32, 64);
+    x2r[rt] = x2;
+    // lanes l, l^16, l^32, l^48 hold the same batch row: merge their four best
 #pragma unroll
-  for (int off = 16; off <= 32; off <<= 1) {
-    const double e1 = __shfl_xor(k1, off, 64), e2 = __shfl_xor(k2, off, 64), e3 = __shfl_xor(k3, off, 64), e4 = __shfl_xor(k4, off, 64);
-    top4_insert(e1, k1, k2, k3, k4);
-    top4_insert(e2, k1, k2, k3, k4);
-    top4_insert(e3, k1, k2, k3, k4);
-    top4_insert(e4, k1, k2, k3, k4);
+    for (int off = 16; off <= 32; off <<= 1) {
+      const double e1 = __shfl_xor(kk[rt][0], off, 64), e2 = __shfl_xor(kk[rt][1], off, 64), e3 = __shfl_xor(kk[rt][2], off, 64),
+                   e4 = __shfl_xor(kk[rt][3], off, 64);
+      top4_insert(e1, kk[rt][0], kk[rt][1], kk[rt][2], kk[rt][3]);
+      top4_insert(e2, kk[rt][0], kk[rt][1], kk[rt][2], kk[rt][3]);
+      top4_insert(e3, kk[rt][0], kk[rt][1], kk[rt][2], kk[rt][3]);
+      top4_insert(e4, kk[rt][0], kk[rt][1], kk[rt][2], kk[rt][3]);
+    }
+    const unsigned long long oddm = __ballot(odd[rt]);
+    if (lane < 16) {
+#pragma unroll
+      for (int q = 0; q < 4; q++) sk[wv][q][rt * 16 + lane] = kk[rt][q];
+    }
+    if (lane == 0) snan[wv][rt] = (int)((oddm | (oddm >> 16) | (oddm >> 32) | (oddm >> 48)) & 0xFFFF);  // by batch row
   }
-  const unsigned long long oddm = __ballot(odd);
-  if (lane < 16) {
-    sk[wv][0][lane] = k1;
-    sk[wv][1][lane] = k2;
-    sk[wv][2][lane] = k3;
-    sk[wv][3][lane] = k4;
+  // (wave 0's lanes hold x2 of rows (rt, lane & 15): thread t < RW needs that of row t)
+  __shared__ double sx2[RW];
+  if (wv == 0 && lane < 16) {
+#pragma unroll
+    for (int rt = 0; rt < RT; rt++) sx2[rt * 16 + lane] = x2r[rt];
   }
-  if (lane == 0) snan[wv] = (int)((oddm | (oddm >> 16) | (oddm >> 32) | (oddm >> 48)) & 0xFFFF);  // by batch row
   __syncthreads();
   if (bx == 0 && tid == 0) *gp(ahp->bound) = B;
-  if (tid < 16 && r0 + tid < st.n_b) {
-    k1 = sk[0][0][tid], k2 = sk[0][1][tid], k3 = sk[0][2][tid], k4 = sk[0][3][tid];
+  if (tid < RW && r0 + tid < st.n_b) {
+    double k1 = sk[0][0][tid], k2 = sk[0][1][tid], k3 = sk[0][2][tid], k4 = sk[0][3][tid];
 #pragma unroll
     for (int w = 1; w < 4; w++) {
 #pragma unroll
       for (int q = 0; q < 4; q++) top4_insert(sk[w][q][tid], k1, k2, k3, k4);
     }
-    const bool row_odd = ((snan[0] | snan[1] | snan[2] | snan[3]) >> tid) & 1;
+    const int rt_ = tid >> 4;
+    const bool row_odd = ((snan[0][rt_] | snan[1][rt_] | snan[2][rt_] | snan[3][rt_]) >> (tid & 15)) & 1;
     const long long rr = r0 + tid;
+    const double x2 = sx2[tid];
     const double S = __builtin_sqrt(x2);
     const double D1 = k1 + x2, R1 = __builtin_sqrt(D1 > 0.0 ? D1 : 0.0);
     // true when the centroid ranked with key kj cannot become the argmin under any displacement <= B of every centroid
@@ -1825,15 +1886,15 @@ __device__ __forceinline__ void ahead_assign(const StepDev *__restrict__ steps, 
       if (at < ahp->hcap) gp(ahp->hl)[at] = (int)rr;
       else __hip_atomic_fetch_or(&cnt[1], 8, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     } else {
-      __hip_atomic_fetch_or(&cnt[1], finite ? 2 : 4, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_fetch_or(&cnt[1], 4, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
   }
 }
 
-template <typename XT, int KS, int JB>
+template <typename XT, int KS, int JB, int RT>
 __global__ __launch_bounds__(256) void k_step_assign_ahead(const StepDev *__restrict__ steps, const AheadDev *__restrict__ aheads,
                                                            const int *__restrict__ ylist, int64_t ldx, int D) {
-  ahead_assign<XT, KS, JB>(steps, aheads, ((const GAS int *)ylist)[blockIdx.y], blockIdx.x, ldx, D);
+  ahead_assign<XT, KS, JB, RT>(steps, aheads, ((const GAS int *)ylist)[blockIdx.y], blockIdx.x, ldx, D);
 }
 
 // M-step of a look-ahead block: k_step_update plus (i) the check of the block's bound, (ii) the low-count / zero-count tests
@@ -1842,12 +1903,28 @@ __global__ __launch_bounds__(256) void k_step_assign_ahead(const StepDev *__rest
 // displacement bookkeeping, (v) this centroid's distances to the NEXT step's open rows and to the rows of the next step's
 // table that name it.  One wave per centroid, descriptors in the kernel arguments.
 #define AHEAD_ITEMS 64  // rows of the next step a wave evaluates in one round (lane = row)
+// AHEAD_PROFILE (tools/aheadprof.py): wall-clock stamps of the M part's phases, wave 0 of every workgroup of stratum row 0
+#ifdef AHEAD_PROFILE
+#define APF_N 8
+__device__ unsigned long long g_ahead_prof[64][APF_N];
+extern "C" int hamsm_debug_ahead_profile(unsigned long long *h_out) {
+  return hipMemcpyFromSymbol(h_out, HIP_SYMBOL(g_ahead_prof), sizeof(unsigned long long) * 64 * APF_N) == hipSuccess ? 0 : -1;
+}
+#define APF(slot)                                                                       \
+  {                                                                                     \
+    __builtin_amdgcn_s_waitcnt(0);                                                      \
+    if (blockIdx.y == 0 && bx < 64 && threadIdx.x == 0) g_ahead_prof[bx][slot] = wall_clock64(); \
+  }
+#else
+#define APF(slot)
+#endif
 template <typename XT, int H>
 __device__ __forceinline__ void ahead_update(const StepDev &sdesc, const AheadDev &ah, const unsigned bx, int64_t ldx, int D, int KS,
                                              double ratio, int *lds_i) {
   const StepG st(sdesc);
   if ((int)bx * 4 >= st.K) return;
   __shared__ double shd[4];
+  APF(0)
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   int *list = lds_i + wv * AHEAD_STRIP;
   unsigned *srow = (unsigned *)list;
@@ -1876,7 +1953,15 @@ __device__ __forceinline__ void ahead_update(const StepDev &sdesc, const AheadDe
 #pragma unroll
     for (int h = 0; h < H; h++) sn[h] = c0[h];
   }
-  const double seen = ah.prev_slot ? *gp(ah.prev_slot) : 0.0;
+  double seen = 0.0;
+  if (ah.prev_slot) {
+    seen = gp(ah.prev_slot)[lane & (AHEAD_SLOTS - 1)];
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+      const double o = __shfl_xor(seen, off, 64);
+      seen = (o > seen || o != o) ? o : seen;
+    }
+  }
   const double bound = *gp((const double *)ah.bound);
   const GAS int32_t *cnt = gp((const int32_t *)ah.cnt);
   const int n_und = cnt[0], unserved = cnt[1];
@@ -1897,6 +1982,9 @@ __device__ __forceinline__ void ahead_update(const StepDev &sdesc, const AheadDe
   }
   n_nx = n_nx < ah.hcap ? n_nx : ah.hcap;
   n_nt = n_nt < AHEAD_TAB_CAP ? n_nt : AHEAD_TAB_CAP;
+#if defined(AHEAD_BISECT) && AHEAD_BISECT >= 1  // (timing experiments: wrong results)
+  n_nx = 0, n_nt = 0;
+#endif
   const int DPH = (D + 1) & ~1;
   const int cap = AHEAD_HX / DPH;  // rows the LDS holds per round (>= hcap)
   double *hx = (double *)(lds_i + 4 * AHEAD_STRIP) + wv * AHEAD_HX;
@@ -1967,6 +2055,7 @@ __device__ __forceinline__ void ahead_update(const StepDev &sdesc, const AheadDe
       cj_t = cq > cj_t ? cq : cj_t;
     }
   if (st.idx >= hv) return;  // the stratum's chain stopped before this step
+  APF(1)
   // (i) the premises of this step's labels
   if (!(seen <= bound) || unserved) {
     if (bx == 0 && tid == 0) {
@@ -1976,7 +2065,11 @@ __device__ __forceinline__ void ahead_update(const StepDev &sdesc, const AheadDe
     return;
   }
   // (ii) _kmeans.py:1645 for the stratum's previous step / :2037 before this one (k_step_assign's block, evaluated by everybody)
+#if defined(AHEAD_BISECT) && AHEAD_BISECT >= 3
+  if (false) {
+#else
   if (st.flags & 6) {
+#endif
     double mx = cj_t;
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) {
@@ -2015,6 +2108,10 @@ __device__ __forceinline__ void ahead_update(const StepDev &sdesc, const AheadDe
   GAS double *slot = gp(ah.slot);
   if (!active) return;
   unsigned long long w = w0;
+  APF(2)
+#if defined(AHEAD_BISECT) && AHEAD_BISECT >= 2
+  n_open = 0;
+#endif
   // (iii-a) open rows: first minimum over all centroids of the distances the previous step's waves left behind
   for (int h = 0; h < n_open; h++) {
     const GAS double *hd = gp((const double *)ah.hd) + (size_t)h * ah.kst;
@@ -2040,7 +2137,11 @@ __device__ __forceinline__ void ahead_update(const StepDev &sdesc, const AheadDe
   }
   // (iii-b) undecided rows: the first minimum among the entry's candidates, by the distances left behind
   {
+#if defined(AHEAD_BISECT) && AHEAD_BISECT >= 2
+    const int nt = 0;
+#else
     const int nt = n_und < AHEAD_TAB_CAP ? n_und : AHEAD_TAB_CAP;
+#endif
     for (int base = 0; base < nt; base += 64) {
       if (base) {
         ent = tab[base + lane];
@@ -2066,6 +2167,7 @@ __device__ __forceinline__ void ahead_update(const StepDev &sdesc, const AheadDe
   }
   // (the rest is k_step_update; batches of a look-ahead block have at most 4096 rows: one block of bitmap words)
   if (w0) mb[lane] = 0ull;
+  APF(3)
   const bool weighted = st.wf != nullptr;
   double acc[H];
 #pragma unroll
@@ -2079,6 +2181,7 @@ __device__ __forceinline__ void ahead_update(const StepDev &sdesc, const AheadDe
     inc += lane >= off ? t : 0;
   }
   const int excl = inc - pc, blk = __shfl(inc, 63, 64);
+  APF(5)
   for (int p0 = 0; p0 < blk; p0 += UPD_SC) {
     {
       unsigned long long t = w;
@@ -2090,9 +2193,10 @@ __device__ __forceinline__ void ahead_update(const StepDev &sdesc, const AheadDe
         idx++;
       }
     }
+    APF(6)
     const int np = blk - p0 < UPD_SC ? blk - p0 : UPD_SC;
-    for (int m0 = 0; m0 < np; m0 += 64 / H) {
-      const int cm = np - m0 < 64 / H ? np - m0 : 64 / H;
+    for (int m0 = 0; m0 < np; m0 += 16 / H) {  // (16 / H rows in flight: a quarter of k_step_update's, for the registers of the fused launch)
+      const int cm = np - m0 < 16 / H ? np - m0 : 16 / H;
       if (weighted) {
         if (lane < cm) {
           const long long r = srow[m0 + lane];
@@ -2100,12 +2204,14 @@ __device__ __forceinline__ void ahead_update(const StepDev &sdesc, const AheadDe
         }
         for (int q = 0; q < cm; q++) wsum = wsum + swl[q];
       }
-      if (cm <= 16 / H) upd_add_listed<16 / H, H>(acc, Xg, ldg, srow + m0, swl, weighted, 0, cm, D, lane);
-      else if (cm <= 32 / H) upd_add_listed<32 / H, H>(acc, Xg, ldg, srow + m0, swl, weighted, 0, cm, D, lane);
-      else upd_add_listed<64 / H, H>(acc, Xg, ldg, srow + m0, swl, weighted, 0, cm, D, lane);
+      upd_add_listed<16 / H, H>(acc, Xg, ldg, srow + m0, swl, weighted, 0, cm, D, lane);
     }
   }
   if (!weighted) wsum = (double)blk;
+  APF(4)
+#ifdef AHEAD_PROFILE
+  if (blockIdx.y == 0 && bx < 64 && threadIdx.x == 0) g_ahead_prof[bx][7] = (unsigned long long)blk | ((unsigned long long)n_open << 16) | ((unsigned long long)n_und << 32);
+#endif
   const bool moved = blk > 0 && wsum > 0;  // (no member, or no weight: centre unchanged, pyx:87 / :105-108)
   double *vb = (double *)list;
   double a = csq0;
@@ -2130,10 +2236,14 @@ __device__ __forceinline__ void ahead_update(const StepDev &sdesc, const AheadDe
     // it; NaN and inf stay what they are and fail the next step's check)
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) dsq += __shfl_xor(dsq, off, 64);
+#if defined(AHEAD_BISECT) && AHEAD_BISECT >= 4
+    if (false) {
+#else
     if (lane == 0 && dsq != 0.0) {
+#endif
       const double disp = __builtin_sqrt(dsq) * (1.0 + AHEAD_EPS);
-      __hip_atomic_fetch_max((GAS unsigned long long *)slot, (unsigned long long)__double_as_longlong(disp), __ATOMIC_RELAXED,
-                             __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_fetch_max((GAS unsigned long long *)slot + (j & (AHEAD_SLOTS - 1)), (unsigned long long)__double_as_longlong(disp),
+                             __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 #pragma unroll
     for (int h = 0; h < H; h++) vb[lane + 64 * h] = v[h];
@@ -2195,13 +2305,19 @@ __device__ __forceinline__ void ahead_update(const StepDev &sdesc, const AheadDe
 
 // one launch of the pipeline: blockIdx.y < n_m -> the M-step of a step whose labels are complete (descriptors by value);
 // the other rows of the grid -> E-steps of later steps (descriptors in memory), against tables no M-step of this launch writes
-template <typename XT, int KS, int JB, int H>
-__global__ __launch_bounds__(256) void k_step_pipe(const StepPack pk, const AheadPack ap, int n_m, const StepDev *__restrict__ steps,
+template <typename XT, int KS, int JB, int H, int RT>
+__global__ __launch_bounds__(256, 3) void k_step_pipe(const StepPack pk, const AheadPack ap, int n_m, const StepDev *__restrict__ steps,
                                                    const AheadDev *__restrict__ aheads, const int *__restrict__ ylist, int64_t ldx,
                                                    int D, double ratio) {
   extern __shared__ int lds_i[];
-  if ((int)blockIdx.y < n_m) ahead_update<XT, H>(pk.s[blockIdx.y], ap.a[blockIdx.y], blockIdx.x, ldx, D, KS, ratio, lds_i);
-  else ahead_assign<XT, KS, JB>(steps, aheads, ((const GAS int *)ylist)[blockIdx.y - n_m], blockIdx.x, ldx, D);
+  if ((int)blockIdx.y < n_m) {
+    // (copies: every field is fetched from the kernel-argument segment at once, not where it is first used)
+    const StepDev sd_ = pk.s[blockIdx.y];
+    const AheadDev ah_ = ap.a[blockIdx.y];
+    ahead_update<XT, H>(sd_, ah_, blockIdx.x, ldx, D, KS, ratio, lds_i);
+  } else {
+    ahead_assign<XT, KS, JB, RT>(steps, aheads, ((const GAS int *)ylist)[blockIdx.y - n_m], blockIdx.x, ldx, D);
+  }
 }
 
 // block-wide reductions over 256 threads (4 waves); every thread gets the result
@@ -3528,7 +3644,7 @@ static int launch_assign_ahead(hamsm_ctx *c, hipStream_t q, const StepDev *d_ste
   switch (c->KS) {
 #define CASE(KSV, JBV)                                                                                                  \
   case KSV:                                                                                                             \
-    hipLaunchKernelGGL((k_step_assign_ahead<XT, KSV, JBV>), grid, dim3(256), 0, q, d_steps, d_aheads, d_ylist, ldx, c->D); \
+    hipLaunchKernelGGL((k_step_assign_ahead<XT, KSV, JBV, 1>), grid, dim3(256), 0, q, d_steps, d_aheads, d_ylist, ldx, c->D); \
     break;
     CASE(1, 8) CASE(2, 8) CASE(3, 8) CASE(4, 8) CASE(6, 4) CASE(8, 4) CASE(12, 2) CASE(16, 2) CASE(24, 1) CASE(32, 1)
 #undef CASE
@@ -3556,16 +3672,21 @@ __global__ void k_tables_home(const int32_t *__restrict__ halt, int last_idx, co
 template <typename XT>
 static int launch_pipe(hamsm_ctx *c, hipStream_t q, const StepPack &pk, const AheadPack &apk, int n_m, int maxK, const StepDev *d_sde,
                        const AheadDev *d_aheads, const int *d_ylist, int n_e, long long e_nb, int64_t ldx, double ratio) {
-  const unsigned gx_m = (unsigned)((maxK + 3) / 4), gx_e = (unsigned)((e_nb + 15) / 16);
+  const int rt = c->ahead_rt == 2 && c->KS <= 16 ? 2 : 1;
+  const unsigned gx_m = (unsigned)((maxK + 3) / 4), gx_e = (unsigned)((e_nb + 16 * rt - 1) / (16 * rt));
   const dim3 grid(gx_m > gx_e ? gx_m : gx_e, (unsigned)(n_m + n_e));
   const size_t lds = sizeof(int) * (4 * AHEAD_STRIP) + sizeof(double) * (4 * AHEAD_HX) + sizeof(int) * (4 * 2 * AHEAD_ITEMS);
   switch (c->KS) {
-#define CASE(KSV, JBV, HV)                                                                                                  \
-  case KSV:                                                                                                                 \
-    hipLaunchKernelGGL((k_step_pipe<XT, KSV, JBV, HV>), grid, dim3(256), lds, q, pk, apk, n_m, d_sde, d_aheads, d_ylist, ldx, \
-                       c->D, ratio);                                                                                        \
+#define CASE(KSV, JBV, HV)                                                                                                     \
+  case KSV:                                                                                                                    \
+    if (rt == 2 && KSV <= 16)                                                                                                  \
+      hipLaunchKernelGGL((k_step_pipe<XT, KSV, JBV, HV, (KSV <= 16 ? 2 : 1)>), grid, dim3(256), lds, q, pk, apk, n_m, d_sde, d_aheads, \
+                         d_ylist, ldx, c->D, ratio);                                                                           \
+    else                                                                                                                       \
+      hipLaunchKernelGGL((k_step_pipe<XT, KSV, JBV, HV, 1>), grid, dim3(256), lds, q, pk, apk, n_m, d_sde, d_aheads, d_ylist, ldx, \
+                         c->D, ratio);                                                                                         \
     break;
-    CASE(1, 8, 1) CASE(2, 8, 1) CASE(3, 8, 1) CASE(4, 8, 1) CASE(6, 4, 1) CASE(8, 4, 1) CASE(12, 2, 1) CASE(16, 2, 1) CASE(24, 1, 2) CASE(32, 1, 2)
+    CASE(1, 8, 1) CASE(2, 8, 1) CASE(3, 8, 1) CASE(4, 4, 1) CASE(6, 2, 1) CASE(8, 2, 1) CASE(12, 1, 1) CASE(16, 1, 1) CASE(24, 1, 2) CASE(32, 1, 2)
 #undef CASE
     default: return hamsm_fail(c, HAMSM_ENOTSUP, "pipelined training: KS=%d", c->KS);
   }
@@ -3665,7 +3786,7 @@ static int run_steps(hamsm_ctx *c, const void *X, int dt, int64_t ldx, const int
   const int ah_dp = (c->D + 1) & ~1;
   int ah_hcap = AHEAD_HX / ah_dp < AHEAD_HCAP ? AHEAD_HX / ah_dp : AHEAD_HCAP;  // (>= 5: D <= 128)
   if (const char *v = getenv("HAMSM_AHEAD_HCAP")) ah_hcap = atoi(v) < ah_hcap ? (atoi(v) < 0 ? 0 : atoi(v)) : ah_hcap;  // (experiments)
-  size_t o_slot = take(sizeof(double) * 2 * ah_words), o_cnt = take(sizeof(int32_t) * 4 * ah_words),
+  size_t o_slot = take(sizeof(double) * (AHEAD_SLOTS + 1) * ah_words), o_cnt = take(sizeof(int32_t) * 4 * ah_words),
          o_hl = take(ahead_can ? sizeof(int32_t) * AHEAD_HCAP * (size_t)nslot * npos : 0),
          o_hd = take(ahead_can ? sizeof(double) * AHEAD_HCAP * (size_t)ah_kst * nslot * npos : 0),
          o_td = take(ahead_can ? sizeof(double) * 3 * AHEAD_TAB_CAP * (size_t)nslot * npos : 0),
@@ -3922,8 +4043,8 @@ static int run_steps(hamsm_ctx *c, const void *X, int dt, int64_t ldx, const int
             d.pos = (k <= 1) ? 0 : 1;  // the segment's first two steps take their labels exactly
             sd[q].Xg = (double *)(b + o_xg + reg * nb_pad * xg_row);
             sd[q].mbits = (unsigned long long *)(b + o_mb) + reg * Kmax * wstride;
-            d.slot = (double *)(b + o_slot) + 2 * q;
-            d.bound = (double *)(b + o_slot) + 2 * q + 1;
+            d.slot = (double *)(b + o_slot) + (AHEAD_SLOTS + 1) * q;
+            d.bound = (double *)(b + o_slot) + (AHEAD_SLOTS + 1) * q + AHEAD_SLOTS;
             d.tab = (SuspEntry *)(b + o_tab) + reg * AHEAD_TAB_CAP;
             d.cnt = (int32_t *)(b + o_cnt) + 4 * q;
             d.hl = (int32_t *)(b + o_hl) + reg * AHEAD_HCAP;
@@ -3953,7 +4074,7 @@ static int run_steps(hamsm_ctx *c, const void *X, int dt, int64_t ldx, const int
               sdE[q].Bpack = e_alt ? altBp(y) : t.Bpack;
               // the premise M{k} checks: what M{k-1} measured <= what the E-step assumed
               const int64_t qp = mine[G_[k - 1]][q_];
-              d.prev_slot = (const double *)(b + o_slot) + 2 * qp;
+              d.prev_slot = (const double *)(b + o_slot) + (AHEAD_SLOTS + 1) * qp;
               // the E-step's guess: alpha x the latest measurement at its launch, scaled to the updates its labels will be old
               //   k = 2: launched after M{0} (one update measured), labels one update old
               //   k = 3: launched with M{1}: latest = M{0}'s (one update), labels two updates old
@@ -3961,7 +4082,7 @@ static int run_steps(hamsm_ctx *c, const void *X, int dt, int64_t ldx, const int
               //   k >= 5: launched with M{k-2}: latest = M{k-3}'s (two updates), labels two updates old
               const int kr = (k == 2) ? 0 : (k == 3 ? 0 : k - 3);
               const int64_t qr = mine[G_[kr]][q_];
-              d.ref_slot = (const double *)(b + o_slot) + 2 * qr;
+              d.ref_slot = (const double *)(b + o_slot) + (AHEAD_SLOTS + 1) * qr;
               d.ref_scale = c->ahead_alpha * ((k == 3 || k == 4) ? 2.0 : 1.0);
               // M{k-1} evaluates this step's undecided and open rows
               AheadDev &pv = ahd[qp];
@@ -4016,7 +4137,7 @@ static int run_steps(hamsm_ctx *c, const void *X, int dt, int64_t ldx, const int
   if (pass > 0 || ahead_on) {
     HIPCHK(c, hipMemcpyAsync(b + o_steps, sd.data(), sizeof(StepDev) * n_steps, hipMemcpyHostToDevice, c->stream));
     if (ahead_can) {
-      HIPCHK(c, hipMemsetAsync(b + o_slot, 0, sizeof(double) * 2 * ah_words, c->stream));
+      HIPCHK(c, hipMemsetAsync(b + o_slot, 0, sizeof(double) * (AHEAD_SLOTS + 1) * ah_words, c->stream));
       HIPCHK(c, hipMemsetAsync(b + o_cnt, 0, sizeof(int32_t) * 4 * ah_words, c->stream));
       if (!ylist.empty()) {
         HIPCHK(c, hipMemcpyAsync(b + o_ylist, ylist.data(), sizeof(int) * ylist.size(), hipMemcpyHostToDevice, c->stream));
@@ -4273,11 +4394,14 @@ static int run_steps(hamsm_ctx *c, const void *X, int dt, int64_t ldx, const int
       c->ahead_stat[2]++;
       if (dbg_ahead) {
         const AheadDev &d = ahd[hw[s_]];
-        double sb[2] = {0, 0}, seen = 0;
+        double sb[2] = {0, 0}, seen = 0, sl[AHEAD_SLOTS];
         int32_t cn[4] = {0, 0, 0, 0};
-        hipMemcpy(sb, d.slot, sizeof(sb), hipMemcpyDeviceToHost);
+        hipMemcpy(sb + 1, d.bound, sizeof(double), hipMemcpyDeviceToHost);
         hipMemcpy(cn, d.cnt, sizeof(cn), hipMemcpyDeviceToHost);
-        if (d.prev_slot) hipMemcpy(&seen, d.prev_slot, sizeof(double), hipMemcpyDeviceToHost);
+        if (d.prev_slot) {
+          hipMemcpy(sl, d.prev_slot, sizeof(sl), hipMemcpyDeviceToHost);
+          for (double v_ : sl) seen = (v_ > seen || v_ != v_) ? v_ : seen;
+        }
         fprintf(stderr, "[hamsm] look-ahead block of stratum %d given up at step %d (pass %d): position %d, displacement seen %.6g, "
                 "bound %.6g, undecided rows %d, open rows %d, unserved flags %d\n", s_, (int)hw[s_], pass, d.pos, seen, sb[1], cn[0], cn[2], cn[1]);
       }
