@@ -26,6 +26,8 @@ __all__ = ["DataMixin", "InMemorySource", "NpzDirectorySource", "WestpaH5Source"
 class InMemorySource:
     """Iterations held in a dict {n_iter: dict(Xp, Xc, p0, p1, w)} (e.g. from msm_we_amd.synthetic)."""
 
+    parallel_safe = True   # `load` may be called from several threads at once (staging's reader pool)
+
     def __init__(self, iters: dict):
         self._iters = iters
 
@@ -42,6 +44,7 @@ class NpzDirectorySource:
     Files are memory-mapped lazily, one iteration at a time."""
 
     PATTERN = "iter_%08d.npz"
+    parallel_safe = True   # every `load` opens its own file
 
     def __init__(self, directory):
         import os
@@ -383,26 +386,55 @@ class DataMixin:
         return (X[0], X[1], np.asarray(d["p0"], dtype=np.float64).reshape(n, -1)[:, : self.pcoord_ndim],
                 np.asarray(d["p1"], dtype=np.float64).reshape(n, -1)[:, : self.pcoord_ndim], np.asarray(d["w"], dtype=np.float64))
 
-    def _fill_slab(self, its, mode, slab, up_dtype, preloaded=None):
-        """reader thread: iterations `its` written straight into a page-locked slab (one copy, no intermediate concatenation).
+    STAGE_READERS = None  # reader threads per block; None: up to 8 where the source and the featurizer allow it, else 1
+
+    def _stage_readers(self):
+        """how many threads may load / featurize iterations at once: the source must say it is safe (`parallel_safe`: the in-memory
+        and per-iteration-file sources; not the HDF5 one, h5py handles are not) and `processCoordinates` must be the built-in
+        flattening (user code is called from one thread, as the reference calls it)"""
+        if self.STAGE_READERS is not None:
+            return max(1, int(self.STAGE_READERS))
+        import os
+
+        builtin = type(self).processCoordinates is DataMixin.processCoordinates and self._featurizer is None and self._featurizer_spec is None
+        if not (getattr(self._source, "parallel_safe", False) and builtin):
+            return 1
+        return max(1, min(8, (os.cpu_count() or 2) - 1))
+
+    def _fill_slab(self, its, mode, slab, up_dtype, preloaded=None, pool=None):
+        """reader thread: iterations `its` written straight into a page-locked slab (one copy, no intermediate concatenation);
+        with a `pool`, several iterations are loaded at once, each into its own rows (their counts are known beforehand).
         `preloaded`: {iteration: its host block} for blocks that are in memory already.
         -> (rows, nan_parent, nan_child, fits): `fits` is False when a value does not survive the slab's dtype"""
-        o, fits = 0, True
-        nan = [[], []]
-        for it in its:
+
+        def one(it, o, n_expected):
             blk = preloaded[it] if preloaded and it in preloaded else self._iteration_host(it, mode)
             n = len(blk[4])
+            if n_expected is not None and n != n_expected:
+                raise ValueError(f"iteration {it} holds {n} segments, {n_expected} were announced")
+            fits, nan = True, []
             for side in range(2):
                 x = blk[side]
                 dst = slab["X"][side][o: o + n]
                 dst[...] = x                                  # (casts when the dtypes differ)
-                nan[side].append(np.isnan(x).any(axis=1))
+                nan.append(np.isnan(x).any(axis=1))
                 if x.dtype != up_dtype and up_dtype == np.float32 and fits:
                     fits = bool(np.array_equal(dst.astype(x.dtype), x, equal_nan=True))
             slab["p0"][o: o + n], slab["p1"][o: o + n], slab["w"][o: o + n] = blk[2], blk[3], blk[4]
-            o += n
+            return n, nan[0], nan[1], fits
+
+        sizes = getattr(self, "_stage_sizes", None)
+        if pool is not None and sizes is not None and len(its) > 1:
+            offs = np.concatenate([[0], np.cumsum([sizes[it] for it in its])]).astype(np.int64)
+            res = list(pool.map(lambda a: one(a[0], int(a[1]), int(a[2])), zip(its, offs[:-1], np.diff(offs))))
+        else:
+            res, o = [], 0
+            for it in its:
+                r = one(it, o, None)
+                res.append(r)
+                o += r[0]
         cat = lambda v: np.concatenate(v) if v else np.zeros(0, dtype=bool)  # noqa: E731
-        return o, cat(nan[0]), cat(nan[1]), fits
+        return sum(r[0] for r in res), cat([r[1] for r in res]), cat([r[2] for r in res]), all(r[3] for r in res)
 
     def stage_iterations(self):
         """Featurize and upload iterations 1..maxIter once.  Idempotent.  ONE pass over the source: a reader thread loads and
@@ -468,9 +500,12 @@ class DataMixin:
             w_all = np.empty(N)
             widened = False
             done = False
+            n_readers = self._stage_readers()
+            readers = ThreadPoolExecutor(n_readers) if n_readers > 1 else None
+            self._stage_sizes = {it: int(sizes[k]) for k, it in enumerate(its)}
             try:
                 with ThreadPoolExecutor(1) as pool:
-                    fut = pool.submit(self._fill_slab, chunks[0], mode, slabs[0], up_dtype, preloaded)
+                    fut = pool.submit(self._fill_slab, chunks[0], mode, slabs[0], up_dtype, preloaded, readers)
                     for k, ch in enumerate(chunks):
                         n, nan_p, nan_c, fits = fut.result()          # slab k & 1 holds block k
                         h.copy_sync()                                 # block k-1 has left the other slab ...
@@ -496,9 +531,9 @@ class DataMixin:
                             free_slabs(slabs)
                             up_dtype, widened = np.float64, True
                             slabs = alloc_slabs(up_dtype)
-                            n, nan_p, nan_c, fits = self._fill_slab(ch, mode, slabs[k & 1], up_dtype, preloaded)
+                            n, nan_p, nan_c, fits = self._fill_slab(ch, mode, slabs[k & 1], up_dtype, preloaded, readers)
                         if k + 1 < len(chunks):
-                            fut = pool.submit(self._fill_slab, chunks[k + 1], mode, slabs[(k + 1) & 1], up_dtype)
+                            fut = pool.submit(self._fill_slab, chunks[k + 1], mode, slabs[(k + 1) & 1], up_dtype, None, readers)
                         up_dt = _abi.F32 if up_dtype == np.float32 else _abi.F64
                         f0 = int(offsets[ch[0] - 1])
                         assert n == int(offsets[ch[-1]]) - f0
@@ -527,6 +562,9 @@ class DataMixin:
                     h.sync()
                     done = True
             finally:
+                if readers is not None:
+                    readers.shutdown(wait=True)
+                self._stage_sizes = None
                 free_slabs(slabs)
                 for bufs in (raw, mid):
                     for b_ in bufs or ():
@@ -540,7 +578,7 @@ class DataMixin:
         self._store = store
         nbytes = N * (2 * raw_w * (4 if store.x_dtype == _abi.F32 and mode == "host" else first[0].dtype.itemsize) + 16 * ndim + 8)
         self.ingest_stats = {"seconds": time.perf_counter() - t_start, "bytes": int(nbytes), "blocks": len(chunks), "mode": mode,
-                             "widened_mid_pass": widened}
+                             "widened_mid_pass": widened, "readers": n_readers}
         return self._store
 
     def set_distance_featurizer(self, atom_indices, reference_positions):

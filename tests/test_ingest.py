@@ -250,3 +250,32 @@ def test_widen_f32_oracle(oracle_h):
 @pytest.mark.gpu
 def test_widen_f32_hip(hip_h):
     _widen_case(hip_h)
+
+
+def test_reader_pool_stages_the_same_arrays(oracle_h, tmp_path, monkeypatch):
+    """several iterations of a block loaded at once (each into its own rows of the pinned slab): same store as one reader;
+    user featurizers and sources that do not declare `parallel_safe` keep to one thread"""
+    from msm_we_amd.model import modelWE
+
+    g, meta = load_golden("nan_d10")
+    src = NpzDirectorySource.export(InMemorySource(golden_iterations(g)), tmp_path / "iters")
+    monkeypatch.setattr(modelWE, "STAGE_CHUNK_BYTES", 7 * 128 * (2 * 10 * 4 + 24))
+    stores = []
+    for readers in (1, 5):
+        monkeypatch.setattr(modelWE, "STAGE_READERS", readers)
+        m, _ = build_model(oracle_h, g, meta, source=src)
+        st = m._store
+        assert m.ingest_stats["readers"] == readers and m.ingest_stats["blocks"] > 3
+        stores.append([st.Xp.to_host(), st.Xc.to_host(), st.p0.to_host(), st.p1.to_host(), st.w.to_host(), st.w_flux.to_host(),
+                       np.concatenate(m.dtrajs)])
+    for a, b in zip(*stores):
+        assert np.array_equal(a, b, equal_nan=True)
+    monkeypatch.setattr(modelWE, "STAGE_READERS", None)
+    m = modelWE(h=oracle_h)
+    m.set_iteration_source(src)
+    assert m._stage_readers() >= 1 and (m._stage_readers() > 1) == ((__import__("os").cpu_count() or 2) > 2)
+    m.set_featurizer(lambda self, c: c.reshape(c.shape[0], -1))
+    assert m._stage_readers() == 1                      # user code is called from one thread
+    m2 = modelWE(h=oracle_h)
+    m2.set_iteration_source(type("Plain", (), {"iterations": lambda s: [1], "load": lambda s, n: {}})())
+    assert m2._stage_readers() == 1                     # the source did not say it may be read from several threads
