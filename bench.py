@@ -341,8 +341,10 @@ def full_pipeline(m, cfg, seed, flux_mode):
 
 def pmc_kernel_bytes(name_part):
     """(2 x FETCH_SIZE + WRITE_SIZE) x 1024 per dispatch of the kernel whose name contains `name_part`, from the committed
-    r02 PMC summary (C3 workload); None when absent"""
-    path = os.path.join(ROOT, "profiles", "r02_pmc_summary.csv")
+    r03 PMC summary (C3 workload); None when absent"""
+    path = os.path.join(ROOT, "profiles", "r03_pmc_summary.csv")
+    if not os.path.exists(path):
+        path = os.path.join(ROOT, "profiles", "r02_pmc_summary.csv")
     if not os.path.exists(path):
         return None
     v = {}
@@ -357,11 +359,11 @@ def pmc_kernel_bytes(name_part):
 
 def step_roofline(cfg, n_iters, n_seg, e_ms, e_n, m_ms, e_events_ms):
     """`roofline` of the bench line = the DOMINANT kernel of the timed step: k_step_assign, the E-step of a training step
-    (48 % of all kernel time, profiles/r02_bench_c3_kernel_stats.csv; with its M-step 78 %).  One launch serves the batches of the
+    (48 % of all kernel time, profiles/r03_bench_c3_kernel_stats.csv; with its M-step 78 %).  One launch serves the batches of the
     two strata that share a queue: algorithmic flops = 2 strata x n_b x K_s x D x 2 (2 K_s D per row), n_b = the
     rows of one WE iteration that fall into one stratum outside basis / target; duration = every 128th launch on the library's
     queue, in this run: by the device's 100 MHz clock from the first wave's entry to the last wave's exit (`avg_launch_ms`,
-    what rocprofv3's kernel trace reports: 9.9 us in profiles/r02_bench_c3_kernel_stats.csv), and event to event
+    what rocprofv3's kernel trace reports: 9.2 us in profiles/r03_bench_c3_kernel_stats.csv), and event to event
     (`avg_launch_ms_hip_events`: the same launch INCLUDING its kernel boundary, ~3 us more -- an event pair cannot bracket a
     10 us kernel any tighter)."""
     S, K_s, D = cfg.S, cfg.K_s, cfg.D
@@ -374,7 +376,7 @@ def step_roofline(cfg, n_iters, n_seg, e_ms, e_n, m_ms, e_events_ms):
     traffic = pmc_kernel_bytes("k_step_assign") if (cfg.name == "c3") else None
     return {"bound": "mfma", "achieved": tf, "peak": PEAK_F64_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": tf / PEAK_F64_MFMA_TFLOPS,
             "traffic": traffic,
-            "traffic_source": "profiles/r02_pmc_summary.csv (committed rocprofv3 --pmc passes of this workload; not measured in this "
+            "traffic_source": "profiles/r03_pmc_summary.csv (committed rocprofv3 --pmc passes of this workload; not measured in this "
                               "run)" if traffic is not None else None,
             "kernel": "k_step_assign (v_mfma_f64_16x16x4_f64), the E-step of one training step for the two strata of a queue",
             "avg_launch_ms": e_ms, "avg_launch_ms_hip_events": e_events_ms, "launches_sampled": e_n, "flop_per_launch": flops,
@@ -450,9 +452,10 @@ def pmc_traffic(cfg, n_iters):
     """HBM bytes per assign launch (ranking pass + exact pass) from the committed rocprofv3 PMC passes of this same workload
     (profiles/r01_m_pmc_summary.csv: separate --pmc FETCH_SIZE / WRITE_SIZE runs; FETCH_SIZE doubled as
     MI355X_MICROARCH.md prescribes for gfx950, calibrated here on k_sort_count's 80 MB pcoord read)."""
-    path = os.path.join(ROOT, "profiles", "r02_pmc_summary.csv")
-    if not os.path.exists(path):
-        path = os.path.join(ROOT, "profiles", "r01_m_pmc_summary.csv")
+    path = os.path.join(ROOT, "profiles", "r03_pmc_summary.csv")
+    for older in ("r02_pmc_summary.csv", "r01_m_pmc_summary.csv"):
+        if not os.path.exists(path):
+            path = os.path.join(ROOT, "profiles", older)
     if cfg.name != "c3" or n_iters != cfg.n_iters or not os.path.exists(path):
         return None
     filt = os.environ.get("HAMSM_ASSIGN_FILTER", "1") != "0"
@@ -690,7 +693,7 @@ def main():
         "roofline": step_roofline(cfg, n_iters, n_seg, e_dev_ms or e_ms, e_n, m_ms, e_ms),
         "roofline_assign": {"bound": "mfma", "achieved": tflops, "peak": peak, "unit": "TFLOP/s",
                             "frac": tflops / peak, "traffic": pmc_traffic(cfg, n_iters),
-                            "traffic_source": "committed rocprofv3 --pmc passes of this workload under profiles/ (r02_pmc_summary.csv, "
+                            "traffic_source": "committed rocprofv3 --pmc passes of this workload under profiles/ (r03_pmc_summary.csv, "
                                               "else r01_m_pmc_summary.csv); not measured in this run" if pmc_traffic(cfg, n_iters) is not None else None,
                             "kernel": kernel, "arithmetic": arithmetic,
                             "f64_mfma_peak": PEAK_F64_MFMA_TFLOPS, "frac_of_f64_peak": tflops / PEAK_F64_MFMA_TFLOPS, **extra,
