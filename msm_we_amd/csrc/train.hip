@@ -1923,7 +1923,6 @@ __device__ __forceinline__ void ahead_update(const StepDev &sdesc, const AheadDe
                                              double ratio, int *lds_i) {
   const StepG st(sdesc);
   if ((int)bx * 4 >= st.K) return;
-  __shared__ double shd[4];
   APF(0)
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   int *list = lds_i + wv * AHEAD_STRIP;
@@ -2046,10 +2045,12 @@ __device__ __forceinline__ void ahead_update(const StepDev &sdesc, const AheadDe
       nt_done = n_nt < 64 ? n_nt : 64;
     }
   }
-  double cj_t = -inf;  // this thread's share of the stratum's counts, for the tests
+  // the stratum's counts for the tests: every WAVE reads all of them (K / 64 loads per lane) and decides for itself -- the
+  // same counts, the same verdict everywhere, no barrier
+  double cj_t = -inf;
   int z_t = 0;
   if (st.flags & 6)
-    for (int q = tid; q < st.K; q += 256) {
+    for (int q = lane; q < st.K; q += 64) {
       const double cq = st.counts[q];
       z_t |= (cq == 0.0);
       cj_t = cq > cj_t ? cq : cj_t;
@@ -2064,7 +2065,7 @@ __device__ __forceinline__ void ahead_update(const StepDev &sdesc, const AheadDe
     }
     return;
   }
-  // (ii) _kmeans.py:1645 for the stratum's previous step / :2037 before this one (k_step_assign's block, evaluated by everybody)
+  // (ii) _kmeans.py:1645 for the stratum's previous step / :2037 before this one (k_step_assign's block, evaluated by every wave)
 #if defined(AHEAD_BISECT) && AHEAD_BISECT >= 3
   if (false) {
 #else
@@ -2076,21 +2077,18 @@ __device__ __forceinline__ void ahead_update(const StepDev &sdesc, const AheadDe
       const double o = __shfl_xor(mx, off, 64);
       mx = o > mx ? o : mx;
     }
-    if (lane == 0) shd[wv] = mx;
-    __syncthreads();
-    mx = shd[0];
-#pragma unroll
-    for (int w = 1; w < 4; w++) mx = shd[w] > mx ? shd[w] : mx;
     int any_low = 0;
     if (st.flags & 4) {
       const double thr = ratio * mx;
       int low = 0;
-      for (int q = tid; q < st.K; q += 256) low += st.counts[q] < thr;
-      if (low && bx == 0)
+      for (int q = lane; q < st.K; q += 64) low += st.counts[q] < thr;
+#pragma unroll
+      for (int off = 32; off >= 1; off >>= 1) low += __shfl_xor(low, off, 64);
+      if (low && bx == 0 && wv == 0 && lane == 0)
         __hip_atomic_fetch_add((GAS int32_t *)gp(sdesc.prev_report) + 1, low, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      any_low = __syncthreads_or(low);
+      any_low = low;
     }
-    const int any_z = __syncthreads_or((st.flags & 2) ? z_t : 0);
+    const int any_z = (st.flags & 2) ? (__ballot(z_t != 0) != 0ull) : 0;
     if (any_low || any_z) {
       if (bx == 0 && tid == 0) {
         if (any_low) {
@@ -2112,28 +2110,48 @@ __device__ __forceinline__ void ahead_update(const StepDev &sdesc, const AheadDe
 #if defined(AHEAD_BISECT) && AHEAD_BISECT >= 2
   n_open = 0;
 #endif
-  // (iii-a) open rows: first minimum over all centroids of the distances the previous step's waves left behind
-  for (int h = 0; h < n_open; h++) {
-    const GAS double *hd = gp((const double *)ah.hd) + (size_t)h * ah.kst;
-    double bd = inf;
-    int bj = 0x7fffffff;
+  // (iii-a) open rows: first minimum over all centroids of the distances the previous step's waves left behind.  Four rows'
+  // values are requested together (one round trip per four rows), then reduced
+  for (int h0 = 0; h0 < n_open; h0 += 4) {
+    double bd[4];
+    int bj[4];
+#pragma unroll
+    for (int q4 = 0; q4 < 4; q4++) {
+      bd[q4] = inf;
+      bj[q4] = 0x7fffffff;
+    }
     for (int q = lane; q < st.K; q += 64) {  // (a lane's centroids ascend: strict < keeps its lowest index)
-      const double dq = hd[q];
-      const bool lt = dq < bd;
-      bd = lt ? dq : bd;
-      bj = lt ? q : bj;
+      double dq[4];
+#pragma unroll
+      for (int q4 = 0; q4 < 4; q4++) {
+        const int h = h0 + q4 < n_open ? h0 + q4 : n_open - 1;
+        dq[q4] = gp((const double *)ah.hd)[(size_t)h * ah.kst + q];
+      }
+#pragma unroll
+      for (int q4 = 0; q4 < 4; q4++) {
+        const bool lt = dq[q4] < bd[q4];
+        bd[q4] = lt ? dq[q4] : bd[q4];
+        bj[q4] = lt ? q : bj[q4];
+      }
     }
 #pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) {
-      const double d2 = __shfl_xor(bd, off, 64);
-      const int j2 = __shfl_xor(bj, off, 64);
-      const bool take = (d2 < bd) || (d2 == bd && j2 < bj);
-      bd = take ? d2 : bd;
-      bj = take ? j2 : bj;
+    for (int q4 = 0; q4 < 4; q4++) {
+      double d = bd[q4];
+      int jm = bj[q4];
+#pragma unroll
+      for (int off = 32; off >= 1; off >>= 1) {
+        const double d2 = __shfl_xor(d, off, 64);
+        const int j2 = __shfl_xor(jm, off, 64);
+        const bool take = (d2 < d) || (d2 == d && j2 < jm);
+        d = take ? d2 : d;
+        jm = take ? j2 : jm;
+      }
+      if (jm == 0x7fffffff) jm = 0;  // (no distance is a number: label 0 like the step-by-step rule)
+      if (h0 + q4 < n_open) {
+        const int rh = __shfl(r_open, h0 + q4, 64);
+        if (jm == j && lane == (rh >> 6)) w |= 1ull << (rh & 63);
+      }
     }
-    if (bj == 0x7fffffff) bj = 0;  // (no distance is a number: label 0 like the step-by-step rule)
-    const int rh = __shfl(r_open, h, 64);
-    if (bj == j && lane == (rh >> 6)) w |= 1ull << (rh & 63);
   }
   // (iii-b) undecided rows: the first minimum among the entry's candidates, by the distances left behind
   {
