@@ -96,6 +96,8 @@ struct hamsm_ctx {
   int train_ranked = 0;
   double ranked_min_flop = 1.0e9;  // (HAMSM_RANKED_MIN_MFLOP)
   long long ranked_groups = 0;     // launch groups served that way (debug counter)
+  int train_graph = 0;      // HAMSM_TRAIN_GRAPH=1 (experiment): a training pass's launches captured into one hipGraph
+  bool capturing = false;   // ... while its stream capture is open (no event timing inside)
   int generic_stage_kb = 150;  // D > 128: the E-step stages its 16 rows in LDS while they fit this (HAMSM_GENERIC_STAGE_KB; 0 = never)
   // hamsm_malloc / hamsm_free keep released blocks for reuse (hipMalloc costs ~1 ms per 40 MB block and hipFree
   // synchronises the device; every use of a block is ordered on `stream`, so reuse needs no synchronisation)

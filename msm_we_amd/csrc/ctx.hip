@@ -72,6 +72,7 @@ extern "C" int hamsm_create(int device, hamsm_ctx **out) {
   if (const char *v = getenv("HAMSM_GENERIC_STAGE_KB")) c->generic_stage_kb = atoi(v) < 0 ? 0 : (atoi(v) > 150 ? 150 : atoi(v));
   if (const char *v = getenv("HAMSM_TRAIN_RANKED")) c->train_ranked = atoi(v) < 0 ? 0 : (atoi(v) > 2 ? 2 : atoi(v));
   if (const char *v = getenv("HAMSM_RANKED_MIN_MFLOP")) c->ranked_min_flop = atof(v) > 0 ? atof(v) * 1e6 : c->ranked_min_flop;
+  if (const char *v = getenv("HAMSM_TRAIN_GRAPH")) c->train_graph = atoi(v) != 0;
   if (const char *v = getenv("HAMSM_TRAIN_AHEAD")) c->ahead = atoi(v) != 0;
   if (const char *v = getenv("HAMSM_AHEAD_RT")) c->ahead_rt = atoi(v) == 2 ? 2 : 1;
   if (const char *v = getenv("HAMSM_AHEAD_N0")) c->ahead_n0 = atoi(v) < 1 ? 1 : atoi(v);

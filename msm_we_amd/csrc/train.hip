@@ -3517,7 +3517,7 @@ static void launch_step_kernels(hamsm_ctx *c, hipStream_t q, const StepDev *d_st
   dim3 ga((unsigned)((max_nb + 16 * RT - 1) / (16 * RT)), (unsigned)ny);
   // every 128th launch group of the context's own queue is sampled: events around the E-step and the M-step launch, and the
   // E-step's own first-wave-in / last-wave-out stamps (slots prepared in bulk by hamsm_step_kernel_ms(reset))
-  const bool sample = q == c->stream && c->ks_stamps && (c->ks_tick++ & 127) == 0 && c->ks_pending.size() < HAMSM_KS_SLOTS;
+  const bool sample = q == c->stream && !c->capturing && c->ks_stamps && (c->ks_tick++ & 127) == 0 && c->ks_pending.size() < HAMSM_KS_SLOTS;
   hamsm_ctx::KSample ks{nullptr, nullptr, nullptr};
   unsigned long long *stamp = nullptr;
   if (sample) {
@@ -4174,6 +4174,16 @@ static int run_steps(hamsm_ctx *c, const void *X, int dt, int64_t ldx, const int
     }
   }
   hipStream_t lanes[4] = {c->stream, nullptr, nullptr, nullptr};
+  // HAMSM_TRAIN_GRAPH=1 (experiment): the pass's launches are captured into a hipGraph -- the side queues join
+  // the capture through the fork / join events -- instantiated and launched once, instead of being enqueued one by one
+  const bool graph = c->train_graph && pass == 0 && !ahead_on && !any_ranked && !generic && gstart.size() > 2;
+  timespec tg0, tg1, tg2, tg3;
+  if (graph) {
+    HIPCHK(c, hipStreamSynchronize(c->stream));  // (uploads above done: the capture holds kernels only)
+    clock_gettime(CLOCK_MONOTONIC, &tg0);
+    HIPCHK(c, hipStreamBeginCapture(c->stream, hipStreamCaptureModeRelaxed));
+  }
+  c->capturing = graph;
   if (n_lanes > 1) {
     if (!c->ev_fork) HIPCHK(c, hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
     HIPCHK(c, hipEventRecord(c->ev_fork, c->stream));
@@ -4349,6 +4359,26 @@ static int run_steps(hamsm_ctx *c, const void *X, int dt, int64_t ldx, const int
   for (int l = 1; l < n_lanes; l++) {
     HIPCHK(c, hipEventRecord(c->ev_join[l - 1], lanes[l]));
     HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_join[l - 1], 0));
+  }
+  c->capturing = false;
+  if (graph) {
+    hipGraph_t gr = nullptr;
+    hipGraphExec_t ge = nullptr;
+    HIPCHK(c, hipStreamEndCapture(c->stream, &gr));
+    clock_gettime(CLOCK_MONOTONIC, &tg1);
+    HIPCHK(c, hipGraphInstantiate(&ge, gr, nullptr, nullptr, 0));
+    clock_gettime(CLOCK_MONOTONIC, &tg2);
+    HIPCHK(c, hipGraphLaunch(ge, c->stream));
+    clock_gettime(CLOCK_MONOTONIC, &tg3);
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    timespec tg4;
+    clock_gettime(CLOCK_MONOTONIC, &tg4);
+    auto ms = [](const timespec &a, const timespec &b_) { return (b_.tv_sec - a.tv_sec) * 1e3 + (b_.tv_nsec - a.tv_nsec) * 1e-6; };
+    if (dbg_enq)
+      fprintf(stderr, "[hamsm] training pass as a hipGraph: capture %.2f ms, instantiate %.2f ms, launch call %.2f ms, device %.2f ms\n",
+              ms(tg0, tg1), ms(tg1, tg2), ms(tg2, tg3), ms(tg3, tg4));
+    hipGraphExecDestroy(ge);
+    hipGraphDestroy(gr);
   }
   {
     // (a stratum's last step may have run inside a segment, its descriptor naming the alternate tables: the check reads the
