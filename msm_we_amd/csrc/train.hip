@@ -4368,11 +4368,21 @@ static int run_steps(hamsm_ctx *c, const void *X, int dt, int64_t ldx, const int
     clock_gettime(CLOCK_MONOTONIC, &tg1);
     HIPCHK(c, hipGraphInstantiate(&ge, gr, nullptr, nullptr, 0));
     clock_gettime(CLOCK_MONOTONIC, &tg2);
+    hipEvent_t eg0 = nullptr, eg1 = nullptr;
+    hipEventCreate(&eg0);
+    hipEventCreate(&eg1);
+    hipEventRecord(eg0, c->stream);
     HIPCHK(c, hipGraphLaunch(ge, c->stream));
+    hipEventRecord(eg1, c->stream);
     clock_gettime(CLOCK_MONOTONIC, &tg3);
     HIPCHK(c, hipStreamSynchronize(c->stream));
     timespec tg4;
     clock_gettime(CLOCK_MONOTONIC, &tg4);
+    float dev_ms = 0.f;
+    hipEventElapsedTime(&dev_ms, eg0, eg1);
+    hipEventDestroy(eg0);
+    hipEventDestroy(eg1);
+    if (dbg_enq) fprintf(stderr, "[hamsm] ... the graph on the device, event to event: %.2f ms\n", dev_ms);
     auto ms = [](const timespec &a, const timespec &b_) { return (b_.tv_sec - a.tv_sec) * 1e3 + (b_.tv_nsec - a.tv_nsec) * 1e-6; };
     if (dbg_enq)
       fprintf(stderr, "[hamsm] training pass as a hipGraph: capture %.2f ms, instantiate %.2f ms, launch call %.2f ms, device %.2f ms\n",
