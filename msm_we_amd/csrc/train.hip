@@ -1981,9 +1981,6 @@ __device__ __forceinline__ void ahead_update(const StepDev &sdesc, const AheadDe
   }
   n_nx = n_nx < ah.hcap ? n_nx : ah.hcap;
   n_nt = n_nt < AHEAD_TAB_CAP ? n_nt : AHEAD_TAB_CAP;
-#if defined(AHEAD_BISECT) && AHEAD_BISECT >= 1  // (timing experiments: wrong results)
-  n_nx = 0, n_nt = 0;
-#endif
   const int DPH = (D + 1) & ~1;
   const int cap = AHEAD_HX / DPH;  // rows the LDS holds per round (>= hcap)
   double *hx = (double *)(lds_i + 4 * AHEAD_STRIP) + wv * AHEAD_HX;
@@ -2066,11 +2063,7 @@ __device__ __forceinline__ void ahead_update(const StepDev &sdesc, const AheadDe
     return;
   }
   // (ii) _kmeans.py:1645 for the stratum's previous step / :2037 before this one (k_step_assign's block, evaluated by every wave)
-#if defined(AHEAD_BISECT) && AHEAD_BISECT >= 3
-  if (false) {
-#else
   if (st.flags & 6) {
-#endif
     double mx = cj_t;
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) {
@@ -2107,9 +2100,6 @@ __device__ __forceinline__ void ahead_update(const StepDev &sdesc, const AheadDe
   if (!active) return;
   unsigned long long w = w0;
   APF(2)
-#if defined(AHEAD_BISECT) && AHEAD_BISECT >= 2
-  n_open = 0;
-#endif
   // (iii-a) open rows: first minimum over all centroids of the distances the previous step's waves left behind.  Four rows'
   // values are requested together (one round trip per four rows), then reduced
   for (int h0 = 0; h0 < n_open; h0 += 4) {
@@ -2155,11 +2145,7 @@ __device__ __forceinline__ void ahead_update(const StepDev &sdesc, const AheadDe
   }
   // (iii-b) undecided rows: the first minimum among the entry's candidates, by the distances left behind
   {
-#if defined(AHEAD_BISECT) && AHEAD_BISECT >= 2
-    const int nt = 0;
-#else
     const int nt = n_und < AHEAD_TAB_CAP ? n_und : AHEAD_TAB_CAP;
-#endif
     for (int base = 0; base < nt; base += 64) {
       if (base) {
         ent = tab[base + lane];
@@ -2254,11 +2240,7 @@ __device__ __forceinline__ void ahead_update(const StepDev &sdesc, const AheadDe
     // it; NaN and inf stay what they are and fail the next step's check)
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) dsq += __shfl_xor(dsq, off, 64);
-#if defined(AHEAD_BISECT) && AHEAD_BISECT >= 4
-    if (false) {
-#else
     if (lane == 0 && dsq != 0.0) {
-#endif
       const double disp = __builtin_sqrt(dsq) * (1.0 + AHEAD_EPS);
       __hip_atomic_fetch_max((GAS unsigned long long *)slot + (j & (AHEAD_SLOTS - 1)), (unsigned long long)__double_as_longlong(disp),
                              __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
