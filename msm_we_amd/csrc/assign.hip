@@ -616,8 +616,12 @@ __global__ void k_sort_offsets2(SortArgs g, const unsigned long long *cnt2, long
 // registers.  Why it matters: a wave that streams MFMAs monopolises its SIMD's issue port (tools/mfma_corun.hip), so
 // every instruction between two sweeps is dead time for the matrix unit unless it is short -- barriers made it long.
 // (More centroid tiles than fit in LDS: the fragment groups are exchanged between barriers; the waves then walk in step.)
-template <typename XT, int KS, int AUGX, bool BF>
-__global__ __launch_bounds__(FILT_NW(KS) * 64) __attribute__((amdgpu_waves_per_eu(BF ? 2 : (KS <= 8 ? 3 : 2)))) void k_assign_filter(SortArgs g, FiltArgs f) {
+// FORM: 0 = f32 fragments (v_mfma_f32_32x32x2_f32), 1 = bf16 x 3 with all six piece products, 2 = bf16 x 3, light (three products).
+// (A template parameter, not a flag: with the light form chosen at run time the compiler kept both MFMA chains in one loop body,
+// joined by branches, accumulator copies and s_nop padding.)
+template <typename XT, int KS, int AUGX, int FORM>
+__global__ __launch_bounds__(FILT_NW(KS) * 64) __attribute__((amdgpu_waves_per_eu(FORM ? 2 : (KS <= 8 ? 3 : 2)))) void k_assign_filter(SortArgs g, FiltArgs f) {
+  constexpr bool BF = FORM != 0, lite = FORM == 2;
   constexpr int NW = FILT_NW(KS), NT = NW * 64, KH = 2 * KS + AUGX;
   constexpr int KB = (4 * KS + 13) / 16 + AUGX;            // bf16 form: blocks of 16 feature slots (features, csq slot, padding)
   constexpr int TW = BF ? KB * 3 * 256 : KH * 64;         // 32-bit words of fragments per centroid tile
@@ -627,7 +631,6 @@ __global__ __launch_bounds__(FILT_NW(KS) * 64) __attribute__((amdgpu_waves_per_e
   typedef const v4f32 __attribute__((address_space(1))) *gv4p;
   typedef XT xt2 __attribute__((ext_vector_type(2)));
   const int DS = f.DS, D = g.D, G = f.G;
-  const bool lite = BF && f.lite != 0;
   const bool dbuf = BF && f.dbuf != 0;
   const int NP = dbuf && lite ? 2 : 3;           // bf16 form: pieces per 16-slot block held in LDS
   const int TWr = BF ? KB * NP * 256 : TW;       // words of fragments per centroid tile in LDS
@@ -647,7 +650,7 @@ __global__ __launch_bounds__(FILT_NW(KS) * 64) __attribute__((amdgpu_waves_per_e
   const gcfp Ag = (gcfp)f.ft[s].A;
   const int njt = (sd.K + 31) >> 5;
   const bool oneg = njt <= G;  // all fragments of the stratum fit: loaded once
-  float *Xw = (float *)smem + (size_t)wv * 32 * DS;   // [NW][32][DS]: this wave's slab
+  float *Xw = (float *)smem + (size_t)wv * 32 * DS;   // [NW][32][DS]: this wave's slab (f32 form; the bf16 form has none: DS = 0)
   float *As = (float *)smem + (size_t)NW * 32 * DS;   // [G][KH][64]
   const long long base_s = g.base[s];
   const long long p0 = base_s + (long long)(blockIdx.x - g.blkbase[s]) * g.FRB;
@@ -676,14 +679,16 @@ __global__ __launch_bounds__(FILT_NW(KS) * 64) __attribute__((amdgpu_waves_per_e
     }
   };
   int cur_buf = 0;
-  if (dbuf) {
+  // (bf16 form, all fragments at once: the same chunks in one flight -- with three pieces per block the LDS image is the global one)
+  const bool glds0 = dbuf || (BF && oneg);
+  if (glds0) {
     glds_group(0, 0);  // (a stratum whose fragments fit one buffer: its only group)
   } else if (oneg) {
     const int tot0 = njt * TW;
     for (int e = tid * 4; e < tot0; e += NT * 4) *(v4f32 *)(As + e) = *(gv4p)(Ag + e);
   }
   int fcur = load_fidx(wv), fnext = load_fidx(wv + NW);
-  if (dbuf) {
+  if (glds0) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
   } else if (oneg) __syncthreads();
@@ -742,14 +747,64 @@ __global__ __launch_bounds__(FILT_NW(KS) * 64) __attribute__((amdgpu_waves_per_e
       }
     }
   };
-  if (pre) issue(fcur);
+  // bf16 form: no slab at all.  Lane l's operand is 8 consecutive features per 16-slot block of ITS row (slots 16 m + 8 (l / 32)
+  // + i): it loads exactly those from global memory, 4 at a time where both half-waves stay inside the row, and keeps the next
+  // tile's raw values in registers during the sweep.
+  typedef XT xt4u __attribute__((ext_vector_type(4), aligned(sizeof(XT))));
+  XT rw[BF ? 8 * KB : 1];
+  auto issue_rows = [&](int fi) {  // fi: the frame of this lane's row
+    const XT *rp = src + (int64_t)fi * g.ldx;
+    const int h8 = 8 * (lane >> 5);
+#pragma unroll
+    for (int m = 0; m < (BF ? KB : 0); m++)
+#pragma unroll
+      for (int jq = 0; jq < 2; jq++) {
+        const int k0 = 16 * m + 4 * jq;
+        if (k0 + 8 + 3 < D) {  // (wave-uniform)
+          const xt4u v = *(const xt4u *)(rp + k0 + h8);
+#pragma unroll
+          for (int i = 0; i < 4; i++) rw[8 * m + 4 * jq + i] = v[i];
+        } else {
+#pragma unroll
+          for (int i = 0; i < 4; i++) {  // (slots past the row arrive as zeros: nothing downstream looks at slot numbers)
+            const int k = k0 + h8 + i;
+            const XT v = rp[k < D ? k : 0];
+            rw[8 * m + 4 * jq + i] = k < D ? v : (XT)0;
+          }
+        }
+      }
+  };
+  // slot D of the operand is the constant 1 (the csq term): its bf16 pattern, OR-ed into piece 1 of whichever word holds it
+  unsigned onew[BF ? KB : 1][4];
+#pragma unroll
+  for (int m = 0; m < (BF ? KB : 0); m++)
+#pragma unroll
+    for (int w = 0; w < 4; w++) {
+      const int ke = 16 * m + 8 * (lane >> 5) + 2 * w;
+      onew[m][w] = (ke == D ? 0x3f80u : 0u) | (ke + 1 == D ? 0x3f800000u : 0u);
+    }
+  constexpr bool RPRE = BF && KS <= 8;  // (wider rows: 8 KB values per lane parked across the sweep no longer fit the register file)
+  if constexpr (RPRE) issue_rows(fcur);
+  else if (!BF && pre) issue(fcur);
   // a tile's label store is held back until the NEXT tile's loads have been issued: stores count in vmcnt, and every wait
   // for a load (the prefetched rows, the frame indices) otherwise also waits for the acknowledgement of a store issued a
   // moment ago (~6 k cycles per tile)
+  // The undecided rows of a tile likewise: ONE returning atomic per tile reserves their places (lane 0, for the whole wave), and
+  // both its result and the stores that need it are first touched a tile later, at the same point (a wave that waits for a
+  // device-scope atomic right where it issues it stands still for ~1.5 us per tile).
   int pend_fr = -1, pend_lab = 0;
+  unsigned long long und_mask = 0, und_pos = 0;
+  int und_fr = 0;
   auto flush = [&]() {
     if (pend_fr >= 0) g.labels[pend_fr] = pend_lab;
     pend_fr = -1;
+    if (und_mask) {  // (wave-uniform)
+      const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)und_pos), hi = __builtin_amdgcn_readfirstlane((unsigned)(und_pos >> 32));
+      const long long pos = (long long)(((unsigned long long)hi << 32) | lo);
+      if ((und_mask >> lane) & 1ull)
+        f.perm2[base_s + pos + (long long)__builtin_popcountll(und_mask & ((1ull << lane) - 1ull))] = und_fr;
+      und_mask = 0;
+    }
   };
   for (int b = 0; b < NB; b++) {
     const int ti = wv + NW * b;
@@ -761,33 +816,35 @@ __global__ __launch_bounds__(FILT_NW(KS) * 64) __attribute__((amdgpu_waves_per_e
     const int lr = lane & 31;
     const bool ok = lr < nft;
     if (live) {
-      if (pre) commit();
-      else stage_sync(fcur);
+      if constexpr (!BF) {
+        if (pre) commit();
+        else stage_sync(fcur);
+      } else if constexpr (!RPRE) issue_rows(fcur);
       APROF(4)
       // this wave's frame tile as the B operand: lane l carries frame l % 32, slots 2 ks + l / 32 (slot D = 1: the csq term)
       const float *xr = Xw + (size_t)lr * DS;
       if constexpr (BF) {
+        // pieces by truncation: piece 1 = the upper half of the f32 pattern, piece 2 = the upper half of the exact remainder, ...;
+        // two slots share a word, picked by ONE v_perm_b32 from the two patterns.  A value that is not finite leaves a NaN in
+        // piece 2 (inf - inf; NaN - x), hence a NaN in every score of its row: the row goes to the exact kernel.
+        // Slots past the row were loaded as zeros; the constant slot comes from onew.
 #pragma unroll
         for (int m = 0; m < KB; m++)
 #pragma unroll
-          for (int i2 = 0; i2 < 8; i2++) {
-            const int k = 16 * m + 8 * (lane >> 5) + i2;
-            float v = xr[k < D ? k : 0];
-            asm volatile("" : "+v"(v));
-            v = k < D ? v : 0.f;
-            xn2 = __builtin_fmaf(v, v, xn2);
-            v = k == D ? 1.f : v;
-            unsigned p1, p2, p3;
-            bf16_split3(v, p1, p2, p3);
-            if (i2 & 1) {
-              bp[m][0][i2 >> 1] |= p1;
-              bp[m][1][i2 >> 1] |= p2;
-              bp[m][2][i2 >> 1] |= p3;
-            } else {
-              bp[m][0][i2 >> 1] = p1 >> 16;
-              bp[m][1][i2 >> 1] = p2 >> 16;
-              bp[m][2][i2 >> 1] = p3 >> 16;
+          for (int w = 0; w < 4; w++) {
+            float r0[2], r1[2], r2[2];
+#pragma unroll
+            for (int i = 0; i < 2; i++) {
+              const float v = (float)rw[8 * m + 2 * w + i];
+              xn2 = __builtin_fmaf(v, v, xn2);
+              r0[i] = v;
+              r1[i] = v - __uint_as_float(__float_as_uint(v) & 0xffff0000u);
+              if constexpr (!lite) r2[i] = r1[i] - __uint_as_float(__float_as_uint(r1[i]) & 0xffff0000u);
             }
+            bp[m][0][w] = __builtin_amdgcn_perm(__float_as_uint(r0[1]), __float_as_uint(r0[0]), 0x07060302u) | onew[m][w];
+            bp[m][1][w] = __builtin_amdgcn_perm(__float_as_uint(r1[1]), __float_as_uint(r1[0]), 0x07060302u);
+            if constexpr (!lite) bp[m][2][w] = __builtin_amdgcn_perm(__float_as_uint(r2[1]), __float_as_uint(r2[0]), 0x07060302u);
+            else bp[m][2][w] = 0u;
           }
       } else {
 #pragma unroll
@@ -806,7 +863,10 @@ __global__ __launch_bounds__(FILT_NW(KS) * 64) __attribute__((amdgpu_waves_per_e
     const int fthis = fcur;
     fcur = fnext;
     if (b + 2 < NB) fnext = load_fidx(ti + 2 * NW);
-    if (pre && b + 1 < NB && nfw - (ti + NW) * 32 > 0) issue(fcur);  // the next tile's rows travel during this sweep
+    if (b + 1 < NB && nfw - (ti + NW) * 32 > 0) {  // the next tile's rows travel during this sweep
+      if constexpr (RPRE) issue_rows(fcur);
+      else if (!BF && pre) issue(fcur);
+    }
     flush();  // (the youngest memory operation before the sweep: acknowledged long before the next wait)
     APROF(1)
     // ranking state: largest s, largest s among the other centroids, and where the largest was found: Jt = centroid
@@ -814,9 +874,9 @@ __global__ __launch_bounds__(FILT_NW(KS) * 64) __attribute__((amdgpu_waves_per_e
     float M1 = ninf, M2 = ninf;
     int Jr = 0, Jt = 0;
     auto chain = [&](const float *ap) {
-      v16f32 acc;
+      v16f32 acc, zero;
 #pragma unroll
-      for (int r = 0; r < 16; r++) acc[r] = 0.f;
+      for (int r = 0; r < 16; r++) zero[r] = 0.f;
       if constexpr (BF) {
         const v4u32 *aq = (const v4u32 *)ap;  // (ap = tile base + lane * 4 words in this form)
 #pragma unroll
@@ -825,16 +885,20 @@ __global__ __launch_bounds__(FILT_NW(KS) * 64) __attribute__((amdgpu_waves_per_e
                        c3 = __builtin_bit_cast(v8bf16, aq[(m * NP + (lite ? 1 : 2)) * 64]);  // (light form: never multiplied)
           const v8bf16 x1 = __builtin_bit_cast(v8bf16, bp[m][0]), x2 = __builtin_bit_cast(v8bf16, bp[m][1]),
                        x3 = __builtin_bit_cast(v8bf16, bp[m][2]);
-          if (!lite) {  // (wave-uniform) the 2^-14-level terms
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(c1, x3, acc, 0, 0, 0);
+          // (either way the first product of the chain takes the CONSTANT zero as its accumulator operand: a zeroed register
+          // file entry per accumulator element is 16 vector moves per chain)
+          if constexpr (!lite) {  // the 2^-14-level terms
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(c1, x3, m == 0 ? zero : acc, 0, 0, 0);
             acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(c2, x2, acc, 0, 0, 0);
             acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(c3, x1, acc, 0, 0, 0);
-          }
-          acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(c1, x2, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(c1, x2, acc, 0, 0, 0);
+          } else
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(c1, x2, m == 0 ? zero : acc, 0, 0, 0);
           acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(c2, x1, acc, 0, 0, 0);
           acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(c1, x1, acc, 0, 0, 0);
         }
       } else {
+        acc = zero;
 #pragma unroll
         for (int ks = 0; ks < KH; ks++) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ap[ks * 64], bx[ks], acc, 0, 0, 0);
       }
@@ -906,14 +970,19 @@ __global__ __launch_bounds__(FILT_NW(KS) * 64) __attribute__((amdgpu_waves_per_e
       j = take ? jo : j;
       M1 = take ? M1o : M1;
     }
-    if (lane < 32 && ok) {
+    {
       const float thr = thr_x * __builtin_sqrtf(xn2) + thr_0;
-      if (2.f * (M1 - M2) > thr) {  // d = -2 s
+      const bool mine = lane < 32 && ok;
+      const bool sure = mine && 2.f * (M1 - M2) > thr;  // d = -2 s  (every NaN: the comparison is false)
+      if (sure) {
         pend_fr = fthis;
         pend_lab = sd.off + j;  // stratified_clustering.py:195
-      } else {  // (also every NaN: the comparison is false)
-        const unsigned long long pos = atomicAdd(&f.cnt2[s], 1ull);
-        f.perm2[base_s + (long long)pos] = fthis;
+      }
+      const unsigned long long um = __ballot(mine && !sure);
+      if (um) {  // (wave-uniform; the previous tile's were stored by the flush before this sweep)
+        und_mask = um;
+        und_fr = fthis;
+        if (lane == 0) und_pos = atomicAdd(&f.cnt2[s], (unsigned long long)__builtin_popcountll(um));
       }
     }
     APROF(3)
@@ -961,8 +1030,9 @@ static int launch_filter_ks(hamsm_ctx *c, SortArgs g, FiltArgs f, int TW, int au
   const int FRB = g.FRB;  // FB * blocks per workgroup
   size_t lds = sizeof(float) * (size_t)FB * f.DS + sizeof(float) * (size_t)f.G * TW * (f.dbuf ? 2 : 1) + 16;  // (TW: words per tile in LDS)
   if (lds > 160 * 1024) return hamsm_fail(c, HAMSM_ENOTSUP, "assign filter needs %zu B of LDS", lds);
-  const void *kern = bf ? (aug ? (const void *)k_assign_filter<XT, KS, 1, true> : (const void *)k_assign_filter<XT, KS, 0, true>)
-                        : (aug ? (const void *)k_assign_filter<XT, KS, 1, false> : (const void *)k_assign_filter<XT, KS, 0, false>);
+  const void *kern = !bf      ? (aug ? (const void *)k_assign_filter<XT, KS, 1, 0> : (const void *)k_assign_filter<XT, KS, 0, 0>)
+                     : !f.lite ? (aug ? (const void *)k_assign_filter<XT, KS, 1, 1> : (const void *)k_assign_filter<XT, KS, 0, 1>)
+                               : (aug ? (const void *)k_assign_filter<XT, KS, 1, 2> : (const void *)k_assign_filter<XT, KS, 0, 2>);
   HIPCHK(c, hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   unsigned grid = (unsigned)((g.n + FRB - 1) / FRB + c->S);  // upper bound; surplus workgroups exit at once
   void *args[] = {(void *)&g, (void *)&f};
@@ -1031,7 +1101,7 @@ static int launch_sorted(hamsm_ctx *c, const AssignArgs &a) {
   FiltArgs f{};
   c->filter_cnt2 = nullptr;
   if (filt) {
-    f.DS = a.D + ((6 - (a.D & 3)) & 3);
+    f.DS = bf ? 0 : a.D + ((6 - (a.D & 3)) & 3);  // (bf16 form: rows go from global memory straight into operand registers)
     const int FB = 32 * FILT_NW(KS);
     // blocks per workgroup: enough to amortise the prologue, few enough that the grid still fills the chip ~8 times
     int NB = (int)(n / ((long long)FB * 256 * 2 * 8));
