@@ -358,6 +358,8 @@ class ClusteringMixin:
         clusters._activate()
         # per bin: the calls that fit it, in order; bookkeeping of MiniBatchKMeans predicted in closed form
         # (_kmeans.py:2029-2043: with no empty centroid, do_reassign fires every ceil(10K / batch_size) steps)
+        # (only the scalars the seedings need are formed here: the per-step arrays of each stratum are built below, while the
+        # device is already seeding)
         pred, parts = {}, []
         first_g = np.full(len(models), G, dtype=np.int64)
         for b in np.nonzero(fit.any(axis=0))[0]:
@@ -366,11 +368,11 @@ class ClusteringMixin:
             if m.fitted:
                 return False  # continuing a fitted model: take the stepwise path
             gs = np.nonzero(fit[:, b])[0]
-            nb = counts[gs, b]
+            nb0 = int(counts[gs[0], b])
             K = m.n_clusters
-            if nb[0] < K:
-                raise ValueError(f"n_samples={int(nb[0])} should be >= n_clusters={K}.")  # _kmeans.py:875-879
-            bs = int(min(m.batch_size, nb[0]))
+            if nb0 < K:
+                raise ValueError(f"n_samples={nb0} should be >= n_clusters={K}.")  # _kmeans.py:875-879
+            bs = int(min(m.batch_size, nb0))
             init_size = m.init_size
             if init_size is None:
                 init_size = 3 * bs
@@ -378,16 +380,9 @@ class ClusteringMixin:
                     init_size = 3 * K
             elif init_size < K:
                 init_size = 3 * K
-            init_size = int(min(init_size, nb[0]))
+            init_size = int(min(init_size, nb0))
             period = max(1, -(-10 * K // bs))
-            t = np.arange(len(gs))
-            do = (t % period) == 0
-            st = np.zeros(len(gs), dtype=h.STEP_DTYPE)
-            st["stratum"], st["flags"] = b, (do & (ratio > 0)).astype(np.int32)
-            st["x_off"], st["rows_off"], st["n_b"] = gb[gs], starts[gs, b], nb
-            st["n_span"] = np.minimum(ge[gs] - gb[gs], 2 ** 31 - 1)   # row indices of a call range over its group's frames
-            parts.append((gs, np.full(len(gs), b), st, t == 0))
-            pred[b] = dict(bs=bs, init=init_size, n_since=int((len(gs) - 1) % period) * bs, nsteps=len(gs))
+            pred[b] = dict(bs=bs, init=init_size, n_since=int((len(gs) - 1) % period) * bs, nsteps=len(gs), gs=gs, period=period)
             first_g[b] = gs[0]
         # seeding draws in the stepwise order: by first call, then bin (shared RandomState streams stay in sync)
         seeds = []
@@ -414,6 +409,15 @@ class ClusteringMixin:
         # before every step
         z = list(zip(*seeds))
         h.kmeans_seed_multi(z[0], store.Xc, store.x_dtype, store.D, z[1], d_rows, z[2], z[3], d_w, z[4], z[5], z[6], z[7], z[8])
+        for b, pb in pred.items():  # the steps of every stratum, call by call
+            gs, period = pb.pop("gs"), pb.pop("period")
+            t = np.arange(len(gs))
+            do = (t % period) == 0
+            st = np.zeros(len(gs), dtype=h.STEP_DTYPE)
+            st["stratum"], st["flags"] = b, (do & (ratio > 0)).astype(np.int32)
+            st["x_off"], st["rows_off"], st["n_b"] = gb[gs], starts[gs, b], counts[gs, b]
+            st["n_span"] = np.minimum(ge[gs] - gb[gs], 2 ** 31 - 1)   # row indices of a call range over its group's frames
+            parts.append((gs, np.full(len(gs), b), st, t == 0))
 
         def undo():
             for k, r in rs_objs.items():

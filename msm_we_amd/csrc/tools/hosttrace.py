@@ -38,7 +38,7 @@ prev = T0
 agg = {}
 for n, a, b in log:
     agg.setdefault(n, [0, 0.0]); agg[n][0] += 1; agg[n][1] += b - a
-    if b - a > 2e-4 or a - prev > 2e-4:
+    if b - a > 5e-5 or a - prev > 5e-5:
         print(f"  +{1e3 * (a - T0):7.2f} ms  gap {1e3 * (a - prev):6.2f}  {n:28s} {1e3 * (b - a):7.3f} ms")
     prev = b
 print("totals:", {k: (v[0], round(1e3 * v[1], 2)) for k, v in sorted(agg.items(), key=lambda kv: -kv[1][1])[:14]})

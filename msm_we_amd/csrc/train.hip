@@ -1052,6 +1052,29 @@ __device__ unsigned long long g_step_prof[2][SPROF_WG][8];
 extern "C" int hamsm_debug_step_profile(unsigned long long *h_out) {
   return hipMemcpyFromSymbol(h_out, HIP_SYMBOL(g_step_prof), sizeof(unsigned long long) * 2 * SPROF_WG * 8) == hipSuccess ? 0 : -1;
 }
+#elif defined(STEP_TRACE)
+// STEP_TRACE: the wall-clock time at which every launch of the two training kernels started (first workgroup), in launch
+// order per kernel: shows bubbles in the launch stream without a profiler attached (tools/steptrace.py)
+#define STRACE_N 32768
+__device__ unsigned long long g_step_trace[2][STRACE_N];
+__device__ unsigned g_step_trace_n[2];
+#define SPROF_ID
+#define SPROF(k, slot)                                                           \
+  if (slot == 0 && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) {     \
+    const unsigned i_ = atomicAdd(&g_step_trace_n[k], 1u);                       \
+    if (i_ < STRACE_N) g_step_trace[k][i_] = wall_clock64();                     \
+  }
+#define SPROF_W(k, slot)
+#define SPROF_FLUSH(k)
+extern "C" int hamsm_debug_step_trace(unsigned long long *h_out, unsigned *h_n, int reset) {
+  if (h_out && hipMemcpyFromSymbol(h_out, HIP_SYMBOL(g_step_trace), sizeof(unsigned long long) * 2 * STRACE_N) != hipSuccess) return -1;
+  if (h_n && hipMemcpyFromSymbol(h_n, HIP_SYMBOL(g_step_trace_n), sizeof(unsigned) * 2) != hipSuccess) return -1;
+  if (reset) {
+    const unsigned z[2] = {0, 0};
+    if (hipMemcpyToSymbol(HIP_SYMBOL(g_step_trace_n), z, sizeof(z)) != hipSuccess) return -1;
+  }
+  return 0;
+}
 #else
 #define SPROF_ID
 #define SPROF(k, slot)
