@@ -25,6 +25,7 @@
 // forms of this kernel are in the history (chunk-local buckets with L2-streamed fragments: 7.1 ms; 16-lane DPP
 // argmin: 4.8 ms) -- see DESIGN.md §5.1 for what each step bought.
 #include "common.h"
+#include <type_traits>
 #include <vector>
 
 typedef double v4f64 __attribute__((ext_vector_type(4)));
@@ -607,7 +608,8 @@ __global__ void k_sort_offsets2(SortArgs g, const unsigned long long *cnt2, long
   }
 }
 
-#define FILT_NW(KS) ((KS) <= 8 ? 8 : ((KS) <= 16 ? 4 : 2))
+// waves per workgroup (the bf16 forms keep no row slab in LDS: eight waves share a fragment group up to 64 features)
+#define FILT_NW(KS, FORM) ((KS) <= 8 ? 8 : ((KS) <= 16 ? ((FORM) ? 8 : 4) : 2))
 #define FILT_NB_MAX 16
 // A workgroup serves 32 NW NB consecutive frames of its stratum; wave w owns the frame tiles w, w + NW, ... and is
 // AUTONOMOUS: it gathers its tile's rows into a private LDS slab, reads them back as the B operand, sweeps all centroid
@@ -620,9 +622,9 @@ __global__ void k_sort_offsets2(SortArgs g, const unsigned long long *cnt2, long
 // (A template parameter, not a flag: with the light form chosen at run time the compiler kept both MFMA chains in one loop body,
 // joined by branches, accumulator copies and s_nop padding.)
 template <typename XT, int KS, int AUGX, int FORM>
-__global__ __launch_bounds__(FILT_NW(KS) * 64) __attribute__((amdgpu_waves_per_eu(FORM ? 2 : (KS <= 8 ? 3 : 2)))) void k_assign_filter(SortArgs g, FiltArgs f) {
+__global__ __launch_bounds__(FILT_NW(KS, FORM) * 64) __attribute__((amdgpu_waves_per_eu(FORM ? 2 : (KS <= 8 ? 3 : 2)))) void k_assign_filter(SortArgs g, FiltArgs f) {
   constexpr bool BF = FORM != 0, lite = FORM == 2;
-  constexpr int NW = FILT_NW(KS), NT = NW * 64, KH = 2 * KS + AUGX;
+  constexpr int NW = FILT_NW(KS, FORM), NT = NW * 64, KH = 2 * KS + AUGX;
   constexpr int KB = (4 * KS + 13) / 16 + AUGX;            // bf16 form: blocks of 16 feature slots (features, csq slot, padding)
   constexpr int TW = BF ? KB * 3 * 256 : KH * 64;         // 32-bit words of fragments per centroid tile
   APROF_INIT
@@ -940,13 +942,84 @@ __global__ __launch_bounds__(FILT_NW(KS) * 64) __attribute__((amdgpu_waves_per_e
       if (live) {
         // two accumulators in rotation: the matrix unit works on tile t + 1 while the vector unit ranks tile t
         const float *ap = As + (dbuf && !oneg ? (size_t)cur_buf * G * TWr : 0) + (BF ? lane * 4 : lane);
-        v16f32 accA = chain(ap), accB;
-        for (int jt = 0; jt < gc; jt += 2) {
-          const bool b1 = jt + 1 < gc, b2 = jt + 2 < gc;  // wave-uniform
-          if (b1) accB = chain(ap + (size_t)(jt + 1) * TWr);
-          rank(accA, g0 + jt);
-          if (b2) accA = chain(ap + (size_t)(jt + 2) * TWr);
-          if (b1) rank(accB, g0 + jt + 1);
+        if constexpr (BF && KS > 8) {
+          // ... and, where a workgroup per CU leaves ONE wave on a SIMD (wide rows: the fragments take the LDS), in this wave's
+          // own instruction order: each MFMA of tile t + 1 is followed by its share of the 48 ranking instructions of tile t (an
+          // MFMA occupies the issue port for 8 of its 32 cycles; a lone wave that issues a chain back to back sits on the port for
+          // the whole chain and then ranks with the matrix unit idle).  Scheduling fences keep the order; the fragments of the next
+          // 16-slot block are requested one block ahead.  (With two waves on a SIMD -- KS <= 8 -- the other wave fills the gaps
+          // and the issue port, not the matrix unit, is the limit: measured the same either way.)
+          constexpr int NS = lite ? 3 : 6, NM = KB * NS;
+          constexpr int AI[6] = {0, 1, 2, 0, 1, 0}, BI[6] = {2, 1, 0, 1, 0, 0};  // full: c1x3 c2x2 c3x1 c1x2 c2x1 c1x1; light: the last three
+          struct Frag {
+            v4u32 c[lite ? 2 : 3];
+          };
+          auto load_frag = [&](const float *apt, int m) {
+            Frag fr;
+            const v4u32 *aq = (const v4u32 *)apt;
+#pragma unroll
+            for (int q = 0; q < (lite ? 2 : 3); q++) fr.c[q] = aq[(m * NP + q) * 64];
+            return fr;
+          };
+          v16f32 zero;
+#pragma unroll
+          for (int r = 0; r < 16; r++) zero[r] = 0.f;
+          Frag cur = load_frag(ap, 0);
+          // MFMAs of tile jt into accN (fragments of its first block already in cur); RANK: the values of accP (tile jt - 1) in between
+          auto step = [&](auto rank_tag, v16f32 &accN, const v16f32 &accP, int jt) {
+            constexpr bool RANK = decltype(rank_tag)::value;
+            const float *apt = ap + (size_t)jt * TWr;
+            const bool more = jt + 1 < gc;  // wave-uniform
+            const float before = M1;
+#pragma unroll
+            for (int m = 0; m < KB; m++) {
+              Frag nxt = cur;
+              if (m + 1 < KB) nxt = load_frag(apt, m + 1);
+              else if (more) nxt = load_frag(apt + TWr, 0);
+#pragma unroll
+              for (int st = 0; st < NS; st++) {
+                const int q = m * NS + st, sel = lite ? st + 3 : st;
+                accN = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(v8bf16, cur.c[AI[sel]]), __builtin_bit_cast(v8bf16, bp[m][BI[sel]]),
+                                                               q == 0 ? zero : accN, 0, 0, 0);
+                if constexpr (RANK) {
+                  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                  for (int r = 16 * q / NM; r < 16 * (q + 1) / NM; r++) {
+                    const float v = __uint_as_float((__float_as_uint(accP[r]) & 0xfffffff0u) | (unsigned)r);  // (see rank)
+                    float m2n, m1n;
+                    asm volatile("v_med3_f32 %0, %1, %2, %3" : "=v"(m2n) : "v"(M1), "v"(M2), "v"(v));
+                    asm volatile("v_max_f32 %0, %1, %2" : "=v"(m1n) : "v"(M1), "v"(v));
+                    M2 = m2n;
+                    M1 = m1n;
+                  }
+                  __builtin_amdgcn_sched_barrier(0);
+                }
+              }
+              cur = nxt;
+            }
+            if constexpr (RANK) Jt = M1 > before ? g0 + jt - 1 : Jt;
+          };
+          v16f32 accA, accB;
+          step(std::false_type{}, accA, accA, 0);
+          int jt = 1;
+          for (; jt + 1 < gc; jt += 2) {
+            step(std::true_type{}, accB, accA, jt);
+            step(std::true_type{}, accA, accB, jt + 1);
+          }
+          if (jt < gc) {
+            step(std::true_type{}, accB, accA, jt);
+            rank(accB, g0 + jt);
+          } else
+            rank(accA, g0 + jt - 1);
+        } else {
+          v16f32 accA = chain(ap), accB;
+          for (int jt = 0; jt < gc; jt += 2) {
+            const bool b1 = jt + 1 < gc, b2 = jt + 2 < gc;  // wave-uniform
+            if (b1) accB = chain(ap + (size_t)(jt + 1) * TWr);
+            rank(accA, g0 + jt);
+            if (b2) accA = chain(ap + (size_t)(jt + 2) * TWr);
+            if (b1) rank(accB, g0 + jt + 1);
+          }
         }
       }
       if (has_next) {
@@ -1026,7 +1099,7 @@ static int launch_sorted_ks(hamsm_ctx *c, SortArgs g) {
 
 template <typename XT, int KS>
 static int launch_filter_ks(hamsm_ctx *c, SortArgs g, FiltArgs f, int TW, int aug, bool bf) {
-  constexpr int NW = FILT_NW(KS), FB = 32 * NW;
+  const int NW = bf ? FILT_NW(KS, 1) : FILT_NW(KS, 0), FB = 32 * NW;
   const int FRB = g.FRB;  // FB * blocks per workgroup
   size_t lds = sizeof(float) * (size_t)FB * f.DS + sizeof(float) * (size_t)f.G * TW * (f.dbuf ? 2 : 1) + 16;  // (TW: words per tile in LDS)
   if (lds > 160 * 1024) return hamsm_fail(c, HAMSM_ENOTSUP, "assign filter needs %zu B of LDS", lds);
@@ -1102,7 +1175,7 @@ static int launch_sorted(hamsm_ctx *c, const AssignArgs &a) {
   c->filter_cnt2 = nullptr;
   if (filt) {
     f.DS = bf ? 0 : a.D + ((6 - (a.D & 3)) & 3);  // (bf16 form: rows go from global memory straight into operand registers)
-    const int FB = 32 * FILT_NW(KS);
+    const int FB = 32 * (bf ? FILT_NW(KS, 1) : FILT_NW(KS, 0));
     // blocks per workgroup: enough to amortise the prologue, few enough that the grid still fills the chip ~8 times
     int NB = (int)(n / ((long long)FB * 256 * 2 * 8));
     NB = NB < 1 ? 1 : (NB > c->filter_nb ? c->filter_nb : NB);
