@@ -3,9 +3,11 @@
 // Bit-identical to the reference's arithmetic: per iteration the COO->dense conversion adds duplicate
 // (start, end) pairs in segment order, and the per-iteration matrices are added in ascending
 // iteration order (_fluxmatrix.py:143-146, 325-327; oracle hamsm_flux_accumulate).  Realised as a
-// stable radix sort of the segments by (cell, iteration) (rocPRIM, the one library primitive used),
-// then two hand-written passes: per (cell, iteration) run an in-order partial sum, per cell an
-// in-order sum of those partials on top of the value already in F.
+// stable radix sort of the segments by cell (rocPRIM, the one library primitive used) -- the segments
+// arrive in ascending iteration, so a stable sort on the cell bits alone leaves every cell's segments in
+// (iteration, segment) order; the key carries the iteration in its low bits, which the sort skips --
+// then hand-written passes: per (cell, iteration) run an in-order partial sum, per cell an in-order sum
+// of those partials on top of the value already in F.  Keys are 32-bit when cell and iteration fit.
 #include <cstring>
 #include <vector>
 #include <hip/hip_runtime.h>
@@ -22,8 +24,9 @@ struct FluxArgs {
   int *err;
 };
 
-__global__ void k_flux_keys(MapperDev m, FluxArgs g, const int64_t *__restrict__ offs, int64_t n_iters,
-                            unsigned long long *keys, double *vals) {
+template <typename KT>
+__global__ void k_flux_keys(MapperDev m, FluxArgs g, const int64_t *__restrict__ offs, int64_t n_iters, int ib,
+                            KT *keys, double *vals) {
   int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   // iteration of the workgroup's first segment by bisection, once; its other segments walk forward from there (an iteration
   // holds thousands of segments: at most a step or two) instead of 256 bisections of ~10 dependent loads each
@@ -66,18 +69,19 @@ __global__ void k_flux_keys(MapperDev m, FluxArgs g, const int64_t *__restrict__
   int64_t lo = s_it0;
   if (offs)
     while (lo + 1 < n_iters && offs[lo + 1] <= i) lo++;
-  keys[j] = cell * (unsigned long long)n_iters + (unsigned long long)lo;
+  keys[j] = (KT)((cell << ib) | (unsigned long long)lo);
 }
 
 // pass 1: every (cell, iteration) run is summed in segment order (stable sort) by the thread at its first element, which also
 // raises the run's flag; pass 2 (after an exclusive scan of the flags) packs the run sums, in order, into a dense array -- a
 // cell's partials become CONTIGUOUS -- and pass 3 adds each cell's partials in ascending iteration on top of F.  (Walking the
 // runs in place, `e += len[e]`, was a chain of up to n_iterations dependent loads per cell: 1.5 ms of the 2.2 ms at C3.)
-__global__ void k_flux_parts(const unsigned long long *__restrict__ ks, const double *__restrict__ ws, int64_t n,
+template <typename KT>
+__global__ void k_flux_parts(const KT *__restrict__ ks, const double *__restrict__ ws, int64_t n,
                              double *part, int32_t *flag) {
   int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (j >= n) return;
-  const unsigned long long k = ks[j];
+  const KT k = ks[j];
   if (j > 0 && ks[j - 1] == k) {  // not the first element of its (cell, iteration) run
     flag[j] = 0;
     return;
@@ -92,23 +96,25 @@ __global__ void k_flux_parts(const unsigned long long *__restrict__ ks, const do
   flag[j] = 1;
 }
 
-__global__ void k_flux_pack(const unsigned long long *__restrict__ ks, const double *__restrict__ part,
+template <typename KT>
+__global__ void k_flux_pack(const KT *__restrict__ ks, const double *__restrict__ part,
                             const int32_t *__restrict__ flag, const int32_t *__restrict__ pos, int64_t n,
-                            unsigned long long n_iters, double *cpart, unsigned long long *ccell, int32_t *total) {
+                            int ib, double *cpart, KT *ccell, int32_t *total) {
   int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (j >= n) return;
   if (flag[j]) {
     cpart[pos[j]] = part[j];
-    ccell[pos[j]] = ks[j] / n_iters;
+    ccell[pos[j]] = ks[j] >> ib;
   }
   if (j == n - 1) *total = pos[j] + flag[j];
 }
 
-__global__ void k_flux_cells(const unsigned long long *__restrict__ ccell, const double *__restrict__ cpart,
+template <typename KT>
+__global__ void k_flux_cells(const KT *__restrict__ ccell, const double *__restrict__ cpart,
                              const int32_t *__restrict__ total, double *F) {
   const int64_t m = (int64_t)blockIdx.x * blockDim.x + threadIdx.x, M = *total;
   if (m >= M) return;
-  const unsigned long long cell = ccell[m];
+  const KT cell = ccell[m];
   if (m > 0 && ccell[m - 1] == cell) return;  // not the first partial of its cell
   // the run's end first (the cells are sorted: gallop, then bisect), so that the additions below run over a KNOWN range and
   // their loads do not wait for each other (a hot cell -- basis -> basis, anything -> target -- has one partial per iteration)
@@ -136,18 +142,14 @@ __global__ void k_flux_cells(const unsigned long long *__restrict__ ccell, const
   F[cell] = acc;
 }
 
-int hamsm_flux_sorted(hamsm_ctx *c, const MapperDev &m, const FluxArgs &g, const int64_t *d_offs, int64_t n_iters) {
+template <typename KT>
+static int flux_sorted_run(hamsm_ctx *c, const MapperDev &m, const FluxArgs &g, const int64_t *d_offs, int64_t n_iters, int ib, int cb) {
   const int64_t n = g.n;
-  if (!d_offs) n_iters = 1;
-  if (n > 0x7fffffffLL) return hamsm_fail(c, HAMSM_ENOTSUP, "deterministic flux: more than 2^31 segments per call");
-  unsigned long long maxkey = (unsigned long long)(g.K + 2) * (g.K + 2) * (unsigned long long)n_iters;
-  int bits = 1;
-  while (bits < 64 && (maxkey >> bits)) bits++;
   size_t temp_sort = 0, temp_scan = 0;
-  unsigned long long *nullk = nullptr;
+  KT *nullk = nullptr;
   double *nullv = nullptr;
   int32_t *nulli = nullptr;
-  hipError_t e = rocprim::radix_sort_pairs(nullptr, temp_sort, nullk, nullk, nullv, nullv, (size_t)n, 0, bits, c->stream);
+  hipError_t e = rocprim::radix_sort_pairs(nullptr, temp_sort, nullk, nullk, nullv, nullv, (size_t)n, ib, ib + cb, c->stream);
   if (e != hipSuccess) return hamsm_fail(c, HAMSM_EDEVICE, "radix_sort_pairs(size): %s", hipGetErrorString(e));
   e = rocprim::exclusive_scan(nullptr, temp_scan, nulli, nulli, 0, (size_t)n, rocprim::plus<int32_t>(), c->stream);
   if (e != hipSuccess) return hamsm_fail(c, HAMSM_EDEVICE, "exclusive_scan(size): %s", hipGetErrorString(e));
@@ -158,25 +160,38 @@ int hamsm_flux_sorted(hamsm_ctx *c, const MapperDev &m, const FluxArgs &g, const
   int rc = hamsm_ensure_scratch(c, need);
   if (rc) return rc;
   char *base = (char *)c->scratch;
-  unsigned long long *k_in = (unsigned long long *)base, *k_out = (unsigned long long *)(base + a8);
+  KT *k_in = (KT *)base, *k_out = (KT *)(base + a8);
   double *v_in = (double *)(base + 2 * a8), *v_out = (double *)(base + 3 * a8), *part = (double *)(base + 4 * a8);
   int32_t *flag = (int32_t *)(base + 5 * a8), *pos = (int32_t *)(base + 5 * a8 + a4), *total = (int32_t *)(base + 5 * a8 + 2 * a4);
   void *temp = base + 5 * a8 + 2 * a4 + 256;
   unsigned grid = (unsigned)((n + 255) / 256);
-  hipLaunchKernelGGL(k_flux_keys, dim3(grid), dim3(256), 0, c->stream, m, g, d_offs, n_iters, k_in, v_in);
-  e = rocprim::radix_sort_pairs(temp, temp_bytes, k_in, k_out, v_in, v_out, (size_t)n, 0, bits, c->stream);
+  hipLaunchKernelGGL(k_flux_keys<KT>, dim3(grid), dim3(256), 0, c->stream, m, g, d_offs, n_iters, ib, k_in, v_in);
+  // (stable, and only over the cell bits: the iteration bits below them are already in ascending order)
+  e = rocprim::radix_sort_pairs(temp, temp_bytes, k_in, k_out, v_in, v_out, (size_t)n, ib, ib + cb, c->stream);
   if (e != hipSuccess) return hamsm_fail(c, HAMSM_EDEVICE, "radix_sort_pairs: %s", hipGetErrorString(e));
-  hipLaunchKernelGGL(k_flux_parts, dim3(grid), dim3(256), 0, c->stream, k_out, v_out, n, part, flag);
+  hipLaunchKernelGGL(k_flux_parts<KT>, dim3(grid), dim3(256), 0, c->stream, k_out, v_out, n, part, flag);
   e = rocprim::exclusive_scan(temp, temp_bytes, flag, pos, 0, (size_t)n, rocprim::plus<int32_t>(), c->stream);
   if (e != hipSuccess) return hamsm_fail(c, HAMSM_EDEVICE, "exclusive_scan: %s", hipGetErrorString(e));
-  double *cpart = v_in;             // (the unsorted values are dead)
-  unsigned long long *ccell = k_in;  // (so are the unsorted keys)
-  hipLaunchKernelGGL(k_flux_pack, dim3(grid), dim3(256), 0, c->stream, k_out, part, flag, pos, n, (unsigned long long)n_iters, cpart,
-                     ccell, total);
-  hipLaunchKernelGGL(k_flux_cells, dim3(grid), dim3(256), 0, c->stream, ccell, cpart, total, g.F);
+  double *cpart = v_in;  // (the unsorted values are dead)
+  KT *ccell = k_in;      // (so are the unsorted keys)
+  hipLaunchKernelGGL(k_flux_pack<KT>, dim3(grid), dim3(256), 0, c->stream, k_out, part, flag, pos, n, ib, cpart, ccell, total);
+  hipLaunchKernelGGL(k_flux_cells<KT>, dim3(grid), dim3(256), 0, c->stream, ccell, cpart, total, g.F);
   e = hipGetLastError();
   if (e != hipSuccess) return hamsm_fail(c, HAMSM_EDEVICE, "flux_sorted: %s", hipGetErrorString(e));
   return HAMSM_OK;
+}
+
+int hamsm_flux_sorted(hamsm_ctx *c, const MapperDev &m, const FluxArgs &g, const int64_t *d_offs, int64_t n_iters) {
+  if (!d_offs) n_iters = 1;
+  if (g.n > 0x7fffffffLL) return hamsm_fail(c, HAMSM_ENOTSUP, "deterministic flux: more than 2^31 segments per call");
+  // key = cell << ib | iteration: ib bits hold 0 .. n_iters - 1, cb bits hold 0 .. (K + 2)^2 - 1
+  const unsigned long long cells = (unsigned long long)(g.K + 2) * (g.K + 2);
+  int ib = 0, cb = 1;
+  while (ib < 62 && ((unsigned long long)(n_iters - 1) >> ib)) ib++;
+  while (cb < 62 && ((cells - 1) >> cb)) cb++;
+  if (ib + cb > 64) return hamsm_fail(c, HAMSM_ENOTSUP, "deterministic flux: %d cell bits + %d iteration bits", cb, ib);
+  if (ib + cb <= 32) return flux_sorted_run<unsigned>(c, m, g, d_offs, n_iters, ib, cb);
+  return flux_sorted_run<unsigned long long>(c, m, g, d_offs, n_iters, ib, cb);
 }
 
 // ---- f4: stable grouping of segment indices by label -----------------------------------------------------------------------
