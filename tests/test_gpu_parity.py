@@ -191,6 +191,30 @@ def test_assign_random_shapes_hip_equals_oracle(hip_h, oracle_h, seed):
     assert np.array_equal(outs[0], outs[1]), (D, S, K_s, dtype, scale, n)
 
 
+@pytest.mark.parametrize("D,K_s,dtype,pad,shift", [(30, 250, np.float32, 3, 1), (29, 40, np.float32, 0, 3), (33, 70, np.float64, 5, 1),
+                                                  (64, 90, np.float32, 1, 2), (16, 33, np.float32, 0, 1), (7, 9, np.float64, 2, 1)])
+def test_assign_padded_rows_at_an_odd_base(hip_h, oracle_h, D, K_s, dtype, pad, shift):
+    """hamsm_assign on rows with a stride above D whose first element is only element-aligned: the ranking pass reads its
+    operands straight from these rows (4-element loads at 4- or 8-byte alignment, element loads across the row's end)"""
+    from msm_we_amd import _abi
+
+    n, S = 4099, 3
+    outs = []
+    for h in (oracle_h, hip_h):
+        rng = np.random.default_rng(99)
+        _setup(h, D, S, K_s, rng)
+        X, p = _frames(rng, n, D, S, dtype)
+        ldx = D + pad
+        buf = np.full(shift + n * ldx + 8, 1e30, dtype=dtype)     # (anything read past a row would show)
+        buf[shift:shift + n * ldx].reshape(n, ldx)[:, :D] = X
+        d_buf, d_p, d_lab = h.to_device(buf), h.to_device(p), h.alloc(n, np.int32)
+        h.assign(d_buf.offset(shift), _abi.F32 if dtype == np.float32 else _abi.F64, ldx, d_p, n, d_lab)
+        outs.append((d_lab.to_host(), h.predict_host(X, p)))
+    assert np.array_equal(outs[0][0], outs[0][1])   # the oracle agrees with itself on the packed copy
+    assert np.array_equal(outs[1][0], outs[0][0])
+    assert np.array_equal(outs[1][1], outs[0][0])
+
+
 def test_seeding_in_gram_groups(hip_lib, oracle_h, monkeypatch):
     """k-means++ of several strata with room for only two Gram matrices at a time (HAMSM_SEED_G_MB): the strata are seeded in
     groups that share the slots; centroids equal the oracle's"""
