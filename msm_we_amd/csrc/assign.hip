@@ -120,27 +120,36 @@ struct SortArgs {
   const long long *end;  // nullable: [S] one past the stratum's last position in perm (default base[s + 1])
 };
 
-__global__ __launch_bounds__(256) void k_sort_count(MapperDev mp, SortArgs g) {
-  extern __shared__ unsigned int lh[];  // [S]
-  for (int s = threadIdx.x; s < g.S; s += 256) lh[s] = 0;
+// (nbt > 0: the rectilinear mapper's nbt boundaries are staged in LDS, with the remap table and the strata's fitted flags: a
+// frame's stratum is otherwise a chain of five to six dependent loads from L2 behind its coordinate -- 90 us per 10 M frames)
+__global__ __launch_bounds__(256) void k_sort_count(MapperDev mp, SortArgs g, int nbt) {
+  extern __shared__ unsigned int lh[];  // [S] counters | [S] remap | [S] fitted | [nbt] boundaries
+  int *lremap = (int *)lh + g.S, *lfit = lremap + g.S;
+  float *lb = nbt > 0 ? (float *)(lfit + g.S) : nullptr;
+  for (int s = threadIdx.x; s < g.S; s += 256) {
+    lh[s] = 0;
+    lremap[s] = mp.remap[s];
+    lfit[s] = g.table[s].K != 0;
+  }
+  for (int k = threadIdx.x; k < nbt; k += 256) lb[k] = mp.bounds[k];
   __syncthreads();
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < g.n; i += (int64_t)gridDim.x * 256) {
     double pi[HAMSM_MAX_NDIM];
     for (int d = 0; d < mp.ndim; d++) pi[d] = g.pcoord[i * mp.ndim + d];
-    int b = dev_bin_of(mp, pi, i);
+    int b = dev_bin_of_staged(mp, lb, pi, i);
     int code = -1;
     if (b >= g.S) b = -1;  // (an external mapper's bins are the caller's data)
     if (b < 0) {
       dev_set_error(g.err, HAMSM_ERANGE, (int)i, b);
     } else {
-      int s = mp.remap[b];                       // stratified_clustering.py:134-135
+      int s = lremap[b];                         // stratified_clustering.py:134-135
       if (dev_in_box(mp.target, mp.ndim, pi)) {  // :159 target first
         g.labels[i] = g.Kfit + 1;
         if (g.seen) g.seen[s] = 1;
       } else if (dev_in_box(mp.basis, mp.ndim, pi)) {  // :165
         g.labels[i] = g.Kfit;
         if (g.seen) g.seen[g.S + s] = 1;
-      } else if (g.table[s].K == 0) {  // :187-189
+      } else if (!lfit[s]) {  // :187-189
         dev_set_error(g.err, HAMSM_EUNFIT, (int)i, s);
       } else {
         code = s;
@@ -1203,7 +1212,8 @@ static int launch_sorted(hamsm_ctx *c, const AssignArgs &a) {
   } else {
   HIPCHK(c, hipMemsetAsync(b + o_cnt, 0, sizeof(long long) * S, c->stream));
   unsigned gridc = (unsigned)((n + 255) / 256 < 2048 ? (n + 255) / 256 : 2048);
-  hipLaunchKernelGGL(k_sort_count, dim3(gridc), dim3(256), sizeof(unsigned int) * S, c->stream, c->mapper, g);
+  const int nbt = hamsm_mapper_stage_count(c->mapper);
+  hipLaunchKernelGGL(k_sort_count, dim3(gridc), dim3(256), sizeof(unsigned int) * (3 * S + nbt), c->stream, c->mapper, g, nbt);
   hipLaunchKernelGGL(k_sort_offsets, dim3(1), dim3(64), 0, c->stream, g);
   hipLaunchKernelGGL(k_sort_fill, dim3(gridc), dim3(256), sizeof(unsigned int) * ((S + 1) & ~1) + sizeof(long long) * S,
                      c->stream, g);

@@ -245,6 +245,33 @@ __device__ __forceinline__ int dev_bin_of(const MapperDev &m, const double *p, i
   return idx;
 }
 
+// The same for the rectilinear mapper with its boundaries staged in LDS by the caller (lb: all dims' boundaries, as `bounds`): the
+// bisection is a chain of dependent loads per frame and dimension, from LDS instead of L2.  nullptr: dev_bin_of.
+__device__ __forceinline__ int dev_bin_of_staged(const MapperDev &m, const float *lb, const double *p, int64_t i) {
+  if (!lb) return dev_bin_of(m, p, i);
+  int idx = 0;
+  for (int d = 0; d < m.ndim; d++) {
+    const float pf = (float)p[d];
+    const float *b = lb + m.boff[d];
+    int n = m.nb[d], lo = 0, hi = n;
+    while (lo < hi) {
+      const int mid = (lo + hi) >> 1;
+      if (b[mid] <= pf) lo = mid + 1;
+      else hi = mid;
+    }
+    const int j = lo - 1;
+    if (j < 0 || j >= n - 1) return -1;
+    idx = idx * (n - 1) + j;
+  }
+  return idx;
+}
+// boundaries of a rectilinear mapper that a kernel may stage (0: none -- another mapper kind, or too many)
+static inline int hamsm_mapper_stage_count(const MapperDev &m) {
+  if (m.kind != MAPPER_RECT) return 0;
+  const int nbt = m.boff[m.ndim - 1] + m.nb[m.ndim - 1];
+  return nbt <= 4096 ? nbt : 0;
+}
+
 // msm_we.py:480-492 / 515-527: all dims strictly inside, f64
 __device__ __forceinline__ bool dev_in_box(const double (*box)[2], int ndim, const double *p) {
   bool in = true;

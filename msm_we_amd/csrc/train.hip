@@ -26,8 +26,10 @@ __device__ __forceinline__ GAS T *gp(T *p) {
 
 // ---- prepass: raw bin or -1 (basis/target) per frame + per-iteration histogram --------------------
 __global__ void k_prepass(MapperDev m, const double *__restrict__ p, const int64_t *__restrict__ offs, int64_t n_iters,
-                          int S, int32_t *__restrict__ bin, unsigned long long *__restrict__ hist, int *err) {
-  extern __shared__ unsigned int lh[];  // [S]
+                          int S, int32_t *__restrict__ bin, unsigned long long *__restrict__ hist, int *err, int nbt) {
+  extern __shared__ unsigned int lh[];  // [S] | [nbt] boundaries of a rectilinear mapper (searched per frame: from LDS, not L2)
+  float *lb = nbt > 0 ? (float *)(lh + S) : nullptr;
+  for (int k = threadIdx.x; k < nbt; k += blockDim.x) lb[k] = m.bounds[k];
   for (int64_t t = blockIdx.x; t < n_iters; t += gridDim.x) {
     for (int s = threadIdx.x; s < S; s += blockDim.x) lh[s] = 0;
     __syncthreads();
@@ -37,7 +39,7 @@ __global__ void k_prepass(MapperDev m, const double *__restrict__ p, const int64
       int b;
       if (dev_in_box(m.target, m.ndim, pi) || dev_in_box(m.basis, m.ndim, pi)) b = -1;  // _clustering.py:872-874
       else {
-        b = dev_bin_of(m, pi, i);  // :877 (no we_remap)
+        b = dev_bin_of_staged(m, lb, pi, i);  // :877 (no we_remap)
         if (b >= S) b = -1;
         if (b < 0) dev_set_error(err, HAMSM_ERANGE, (int)i, b);
         else atomicAdd(&lh[b], 1u);
@@ -66,8 +68,9 @@ extern "C" int hamsm_train_prepass(hamsm_ctx *c, const double *p, int64_t n, con
   HIPCHK(c, hipMemcpyAsync(d_offs, h_offs, ob, hipMemcpyHostToDevice, c->stream));
   hamsm_timer_begin(c);
   unsigned grid = (unsigned)(n_iters < 4096 ? n_iters : 4096);
-  hipLaunchKernelGGL(k_prepass, dim3(grid), dim3(256), sizeof(unsigned int) * c->S, c->stream, c->mapper, p, d_offs, n_iters,
-                     c->S, bin, d_hist, c->d_err);
+  const int nbt = hamsm_mapper_stage_count(c->mapper);
+  hipLaunchKernelGGL(k_prepass, dim3(grid), dim3(256), sizeof(unsigned int) * (c->S + nbt), c->stream, c->mapper, p, d_offs, n_iters,
+                     c->S, bin, d_hist, c->d_err, nbt);
   hamsm_timer_end(c, ST_PREPASS);
   HIPCHK(c, hipGetLastError());
   HIPCHK(c, hipMemcpyAsync(h_hist, d_hist, hb, hipMemcpyDeviceToHost, c->stream));
