@@ -133,23 +133,88 @@ __global__ __launch_bounds__(BR_T) void k_build_rows(const int32_t *__restrict__
 }
 
 // The same lists by ONE WAVE per call, for calls of up to BR_WAVE_MAX rows (a training call is one WE iteration: ~10^4):
-// 64 rows at a time, positions from ballots (mbcnt = set bits below this lane), no LDS, no barrier; S + 1 coalesced sweeps.
+// 64 rows at a time, positions from ballots (mbcnt = set bits below this lane), no barrier.  Two coalesced sweeps whatever
+// the number of strata: the first counts the rows of every stratum (per-wave counters in LDS, one update per stratum present in
+// a chunk), the second places them behind the strata's starts; the rank of a row among the unfiltered ones is a running count
+// in both.  (The call's remap row is staged in LDS: the stratum of a row is otherwise a dependent load behind its bin.)
 #define BR_WAVE_MAX 65536
+#define BR_SREG 8  // up to this many strata: counters and cursors in registers (no LDS round trip per stratum and chunk)
+template <bool SREG>
 __global__ __launch_bounds__(256) void k_build_rows_wave(const int32_t *__restrict__ bin_all, const long long *__restrict__ range,
                                                          const int32_t *__restrict__ cr_all, int S, long long G,
-                                                         int32_t *__restrict__ rank_all, int32_t *__restrict__ rows_all,
-                                                         long long *__restrict__ counts, long long *__restrict__ starts) {
+                                                         int32_t *__restrict__ rows_all, long long *__restrict__ counts,
+                                                         long long *__restrict__ starts) {
+  extern __shared__ int br_lds[];  // [4 waves][2][S]: counters / cursors, remap row
   const long long g = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (g >= G) return;
   const int lane = threadIdx.x & 63;
+  int *wc = br_lds + (size_t)(threadIdx.x >> 6) * 2 * S, *lcr = wc + S;
   const long long g0 = range[2 * g];
   const int n = (int)(range[2 * g + 1] - g0);
   const int32_t *bin = bin_all + g0, *cr = cr_all + (size_t)g * S;
-  int32_t *rank = rank_all + g0, *rows = rows_all + g0;
+  int32_t *rows = rows_all + g0;
+  for (int s = lane; s < S; s += 64) {
+    wc[s] = 0;
+    lcr[s] = cr[s];
+  }
   auto below = [&](unsigned long long m) {  // set bits of m below this lane
     return (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
   };
   constexpr int U = 8;  // chunks whose loads are in flight together (one chunk at a time exposes a memory round trip each)
+  int rc[BR_SREG];      // (SREG) wave-uniform counters, then cursors
+#pragma unroll
+  for (int s = 0; s < BR_SREG; s++) rc[s] = 0;
+  for (int c0 = 0; c0 < n; c0 += 64 * U) {
+    int bb[U];
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+      const int i = c0 + u * 64 + lane;
+      bb[u] = bin[i < n ? i : n - 1];
+    }
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+      const int i = c0 + u * 64 + lane;
+      const bool v = i < n && bb[u] >= 0;
+      const int sl = lcr[v ? bb[u] : 0];
+      if constexpr (SREG) {
+#pragma unroll
+        for (int s = 0; s < BR_SREG; s++) rc[s] += __builtin_popcountll(__ballot(v && sl == s));
+      } else {
+        unsigned long long todo = __ballot(v);
+        while (todo) {  // (wave-uniform) one counter update per stratum present in the chunk
+          const int l0 = __builtin_amdgcn_readfirstlane(__builtin_ctzll(todo));
+          const int s0 = __builtin_amdgcn_readlane(sl, l0);
+          const unsigned long long ms = __ballot(v && sl == s0);
+          if (lane == l0) wc[s0] += __builtin_popcountll(ms);
+          todo &= ~ms;
+        }
+      }
+    }
+  }
+  // counters -> cursors (exclusive running sum in stratum order), counts and starts out
+  int run = 0;
+  if constexpr (SREG) {
+#pragma unroll
+    for (int s = 0; s < BR_SREG; s++) {
+      const int cnt = rc[s];
+      if (lane == 0 && s < S) {
+        counts[(size_t)g * S + s] = cnt;
+        starts[(size_t)g * S + s] = g0 + run;
+      }
+      rc[s] = run;
+      run += cnt;
+    }
+  } else {
+    for (int s = 0; s < S; s++) {
+      const int cnt = wc[s];  // (LDS broadcast)
+      if (lane == 0) {
+        counts[(size_t)g * S + s] = cnt;
+        starts[(size_t)g * S + s] = g0 + run;
+        wc[s] = run;
+      }
+      run += cnt;
+    }
+  }
   int base = 0;
   for (int c0 = 0; c0 < n; c0 += 64 * U) {
     int bb[U];
@@ -162,39 +227,32 @@ __global__ __launch_bounds__(256) void k_build_rows_wave(const int32_t *__restri
     for (int u = 0; u < U; u++) {
       const int i = c0 + u * 64 + lane;
       const bool v = i < n && bb[u] >= 0;
+      const int sl = lcr[v ? bb[u] : 0];
       const unsigned long long m = __ballot(v);
-      if (v) rank[i] = base + below(m);
+      const int rk = base + below(m);  // rank among the unfiltered rows of the call (:874)
       base += __builtin_popcountll(m);
-    }
-  }
-  int start = 0;
-  for (int s = 0; s < S; s++) {
-    int cnt = 0;
-    for (int c0 = 0; c0 < n; c0 += 64 * U) {
-      int bb[U], rk[U];
+      if constexpr (SREG) {
+        int pos = 0;
 #pragma unroll
-      for (int u = 0; u < U; u++) {
-        const int i = c0 + u * 64 + lane;
-        bb[u] = bin[i < n ? i : n - 1];
-        rk[u] = rank[i < n ? i : n - 1];  // (written by this same lane in the first sweep; unused for filtered rows)
-      }
-      int sl[U];
-#pragma unroll
-      for (int u = 0; u < U; u++) sl[u] = cr[bb[u] >= 0 ? bb[u] : 0];
-#pragma unroll
-      for (int u = 0; u < U; u++) {
-        const int i = c0 + u * 64 + lane;
-        const bool v = i < n && bb[u] >= 0 && sl[u] == s;
-        const unsigned long long m = __ballot(v);
-        if (v) rows[start + cnt + below(m)] = rk[u];
-        cnt += __builtin_popcountll(m);
+        for (int s = 0; s < BR_SREG; s++) {
+          const unsigned long long ms = __ballot(v && sl == s);
+          pos = sl == s ? rc[s] + below(ms) : pos;
+          rc[s] += __builtin_popcountll(ms);
+        }
+        if (v) rows[pos] = rk;  // rows of a stratum in row order
+      } else {
+        unsigned long long todo = m;
+        while (todo) {
+          const int l0 = __builtin_amdgcn_readfirstlane(__builtin_ctzll(todo));
+          const int s0 = __builtin_amdgcn_readlane(sl, l0);
+          const unsigned long long ms = __ballot(v && sl == s0);
+          const int cur = wc[s0];
+          if (v && sl == s0) rows[cur + below(ms)] = rk;  // rows of a stratum in row order
+          if (lane == l0) wc[s0] = cur + __builtin_popcountll(ms);
+          todo &= ~ms;
+        }
       }
     }
-    if (lane == 0) {
-      counts[(size_t)g * S + s] = cnt;
-      starts[(size_t)g * S + s] = g0 + start;
-    }
-    start += cnt;
   }
 }
 
@@ -224,9 +282,9 @@ extern "C" int hamsm_train_build_rows_batched(hamsm_ctx *c, const int32_t *bin, 
   HIPCHK(c, hipMemcpyAsync(b + o_cr, h_cr, sizeof(int32_t) * G * c->S, hipMemcpyHostToDevice, c->stream));
   hamsm_timer_begin(c);
   if (nmax <= BR_WAVE_MAX)
-    hipLaunchKernelGGL(k_build_rows_wave, dim3((unsigned)((G + 3) / 4)), dim3(256), 0, c->stream, bin, (const long long *)(b + o_rg),
-                       (const int32_t *)(b + o_cr), c->S, (long long)G, (int32_t *)(b + o_rank), rows, (long long *)(b + o_cnt),
-                       (long long *)(b + o_st));
+    hipLaunchKernelGGL(c->S <= BR_SREG ? k_build_rows_wave<true> : k_build_rows_wave<false>, dim3((unsigned)((G + 3) / 4)), dim3(256),
+                       sizeof(int) * 8 * c->S, c->stream, bin, (const long long *)(b + o_rg), (const int32_t *)(b + o_cr), c->S,
+                       (long long)G, rows, (long long *)(b + o_cnt), (long long *)(b + o_st));
   else
     hipLaunchKernelGGL(k_build_rows, dim3((unsigned)G), dim3(BR_T), 0, c->stream, bin, (const long long *)(b + o_rg),
                        (const int32_t *)(b + o_cr), c->S, (int32_t *)(b + o_rank), rows, (long long *)(b + o_cnt),
