@@ -9,6 +9,7 @@ are HBM-resident and one launch covers every segment.
 from __future__ import annotations
 
 import logging
+import numbers
 import os
 import sys
 from copy import deepcopy
@@ -349,12 +350,17 @@ class ClusteringMixin:
         use_w = self.use_weights_in_clustering
         d_w = store.w if use_w else None
         # RandomState streams as they were, for the rerun
-        rs_objs = {}
+        # (a stream created here from an integer seed is restored by seeding it again: no copy of its state up front)
+        rs_objs, saved, fresh = {}, {}, {}
         for m in models:
             if "_random_state" not in m.__dict__:
                 m._random_state = _check_random_state(m.random_state)
+                if isinstance(m.random_state, numbers.Integral):
+                    fresh[id(m._random_state)] = m.random_state
             rs_objs[id(m._random_state)] = m._random_state
-        saved = {k: r.get_state() for k, r in rs_objs.items()}
+        for k, r in rs_objs.items():
+            if k not in fresh:
+                saved[k] = r.get_state()
         clusters._activate()
         # per bin: the calls that fit it, in order; bookkeeping of MiniBatchKMeans predicted in closed form
         # (_kmeans.py:2029-2043: with no empty centroid, do_reassign fires every ceil(10K / batch_size) steps)
@@ -421,7 +427,10 @@ class ClusteringMixin:
 
         def undo():
             for k, r in rs_objs.items():
-                r.set_state(saved[k])
+                if k in fresh:
+                    r.seed(fresh[k])
+                else:
+                    r.set_state(saved[k])
             for b in pred:
                 h.set_centroids(b, None)
                 m = models[b]
