@@ -184,8 +184,15 @@ class ClusteringMixin:
                 for b in range(S):
                     clusters.we_remap[b] = int(remap[b])
 
+        old = self.__dict__.get("clusters")
         self.clusters = clusters
         self.clusters.model = self
+        if old is not None and old is not clusters:
+            # the object this call replaces: if the model held the only reference to it (besides its own parts'), its streams go
+            # back for re-use now rather than whenever the cycle collector finds it (StratumKMeans.__del__)
+            if sys.getrefcount(old) <= old._internal_refs() + 2:
+                old._retire_streams()
+        del old
         self.n_clusters = n_clusters * S  # :742 (quirk Q3)
         self.clusters.toggle = False
         self.launch_ray_discretization(progress_bar)
@@ -354,7 +361,7 @@ class ClusteringMixin:
         rs_objs, saved, fresh = {}, {}, {}
         for m in models:
             if "_random_state" not in m.__dict__:
-                m._random_state = _check_random_state(m.random_state)
+                m._random_state = _check_random_state(m.random_state, m)
                 if isinstance(m.random_state, numbers.Integral):
                     fresh[id(m._random_state)] = m.random_state
             rs_objs[id(m._random_state)] = m._random_state
