@@ -145,7 +145,8 @@ class ClusteringMixin:
         if trains_here:
             if iters_to_use is None:  # :640-651
                 iters_to_use = range(first_cluster_iter if first_cluster_iter is not None else 1, t_maxIter)
-            iters_to_use = [int(i) for i in iters_to_use]
+            if not (isinstance(iters_to_use, range) and iters_to_use.step == 1):
+                iters_to_use = [int(i) for i in iters_to_use]
             # a5 planning support: raw bin (or -1 in basis/target) of every frame's PARENT pcoord
             # (:849-852 pcoord0List, quirk Q2) + per-iteration histograms, one pass over p0
             d_bin = h.alloc(tstore.N, np.int32)
@@ -207,7 +208,8 @@ class ClusteringMixin:
         nrows [G,S] (rows per bin after the call's remap) and fit [G,S] (bins fitted by the call)."""
         S = bin_mapper.nbins
         maxIter = self.maxIter if maxIter is None else maxIter
-        its = np.asarray(iters_to_use, dtype=np.int64)
+        its = (np.arange(iters_to_use.start, iters_to_use.stop, dtype=np.int64) if isinstance(iters_to_use, range)
+               else np.asarray(iters_to_use, dtype=np.int64))
         n = len(its)
         ident = np.arange(S, dtype=np.int32)
         valid = its <= maxIter

@@ -67,7 +67,8 @@ class FluxMatrixMixin:
         self.n_lag = n_lag
         self.errorWeight = 0.0
         self.errorCount = 0
-        iters = [int(i) for i in iters_to_use]
+        # (a contiguous range stays a range: a thousand int() calls and run-merging steps cost ~0.1 ms between two launches)
+        iters = iters_to_use if isinstance(iters_to_use, range) and iters_to_use.step == 1 else [int(i) for i in iters_to_use]
         h = self.h
         store = self._store
         K = self.n_clusters
@@ -95,6 +96,13 @@ class FluxMatrixMixin:
         d_F = h.zeros((ns, ns), np.float64)
         # contiguous runs of iterations become single launches
         runs = []
+        if isinstance(iters, range) and iters.step == 1:
+            if len(iters):
+                for it in (iters[0], iters[-1]):
+                    if it < 1 or it > self.maxIter - 1:
+                        raise IndexError(f"iteration {it} has no discretized pairs")  # pair_dtrajs[it-1] (:288)
+                runs.append([iters[0], iters[-1]])
+            iters = ()
         for it in iters:
             if it < 1 or it > self.maxIter - 1:
                 raise IndexError(f"iteration {it} has no discretized pairs")  # pair_dtrajs[it-1] (:288)
