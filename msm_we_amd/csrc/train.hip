@@ -1538,7 +1538,7 @@ __global__ __launch_bounds__(256) void k_rows_to_bits(const StepPack pk, const R
 // (_k_means_minibatch.pyx:59-108).
 #define UPD_LIST 1024
 #define UPD_SC 768  // member rows the strip holds per pass: ints [0, 768); weights of a 64-member chunk: ints [768, 896)
-template <typename XT, int H, bool BYVAL>
+template <typename XT, int H, bool BYVAL, int UPD_NBK>
 __global__ __launch_bounds__(256) void k_step_update(const StepDev *__restrict__ steps, const StepPack pk, int64_t ldx, int D,
                                                      int KS) {
   SPROF_ID
@@ -1575,26 +1575,47 @@ __global__ __launch_bounds__(256) void k_step_update(const StepDev *__restrict__
   for (int h = 0; h < H; h++) acc[h] = c0[h] * cnt0;
   double wsum = 0.0;
   long long total = 0;
-  for (int wb = 0; wb < nw; wb += 64) {  // 4096 batch rows per block of words (one block for batches up to 4096 rows)
-    const unsigned long long w = wb == 0 ? w0 : mb[wb + lane];
-    if (w) mb[wb + lane] = 0ull;  // ready for the stratum's next step
-    const int pc = __popcll(w);
-    int inc = pc;  // inclusive prefix sum over the lanes
+  // The centroid's bitmap row is read 64 words (4096 batch rows) per lane-load; up to UPD_NBK such blocks are taken TOGETHER: their
+  // loads are in flight at once, their members go to the strip in one order (block, lane, bit = sample order) and the member rows
+  // of all of them are then fetched together -- a batch of 12 500 rows (C5) used to walk its four blocks one dependent round trip
+  // after the other, bitmap words and member rows each.  (UPD_NBK = 1 for batches of up to 4096 rows: C3's step is 0.3 us longer
+  // with the grouped form's bookkeeping.)
+  for (int wb0 = 0; wb0 < nw; wb0 += 64 * UPD_NBK) {
+    const int nblk = (nw - wb0 + 63) / 64 < UPD_NBK ? (nw - wb0 + 63) / 64 : UPD_NBK;  // (wave-uniform; >= 1)
+    unsigned long long w[UPD_NBK];
 #pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-      const int t = __shfl_up(inc, off, 64);
-      inc += lane >= off ? t : 0;
+    for (int bk = 0; bk < UPD_NBK; bk++) {
+      w[bk] = 0ull;
+      if (bk < nblk) w[bk] = (wb0 == 0 && bk == 0) ? w0 : mb[wb0 + 64 * bk + lane];
     }
-    const int excl = inc - pc, blk = __shfl(inc, 63, 64);
+    int excl[UPD_NBK], base[UPD_NBK], blk = 0;
+#pragma unroll
+    for (int bk = 0; bk < UPD_NBK; bk++) {
+      excl[bk] = base[bk] = 0;
+      if (bk < nblk) {
+        if (w[bk]) mb[wb0 + 64 * bk + lane] = 0ull;  // ready for the stratum's next step
+        const int pc = __popcll(w[bk]);
+        int inc = pc;  // inclusive prefix sum over the lanes
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+          const int t = __shfl_up(inc, off, 64);
+          inc += lane >= off ? t : 0;
+        }
+        excl[bk] = inc - pc;
+        base[bk] = blk;
+        blk += __shfl(inc, 63, 64);
+      }
+    }
     SPROF_W(1, 2)
     for (int p0 = 0; p0 < blk; p0 += UPD_SC) {
-      {  // this lane's members with index in [p0, p0 + SC) go to the strip, in order
-        unsigned long long t = w;
-        int idx = excl - p0;
+#pragma unroll
+      for (int bk = 0; bk < UPD_NBK; bk++) {  // this lane's members with index in [p0, p0 + SC) go to the strip, in order
+        unsigned long long t = w[bk];
+        int idx = base[bk] + excl[bk] - p0;
         while (t) {
           const int bit = __builtin_ctzll(t);
           t &= t - 1;
-          if (idx >= 0 && idx < UPD_SC) srow[idx] = (unsigned)((wb + lane) * 64 + bit);
+          if (idx >= 0 && idx < UPD_SC) srow[idx] = (unsigned)((wb0 + 64 * bk + lane) * 64 + bit);
           idx++;
         }
       }
@@ -3607,10 +3628,13 @@ static void launch_step_kernels(hamsm_ctx *c, hipStream_t q, const StepDev *d_st
   if (sample) hipEventRecord(ks.e1, q);
   size_t lds = sizeof(int) * (4 * UPD_LIST);
   dim3 gu((unsigned)((maxK + 3) / 4), (unsigned)ny);
-  if (c->D <= 64)
-    hipLaunchKernelGGL((k_step_update<XT, 1, BYVAL>), gu, dim3(256), lds, q, d_steps, pk, ldx, c->D, c->KS);
-  else
-    hipLaunchKernelGGL((k_step_update<XT, 2, BYVAL>), gu, dim3(256), lds, q, d_steps, pk, ldx, c->D, c->KS);
+  if (c->D <= 64) {
+    if (max_nb > 4096) hipLaunchKernelGGL((k_step_update<XT, 1, BYVAL, 4>), gu, dim3(256), lds, q, d_steps, pk, ldx, c->D, c->KS);
+    else hipLaunchKernelGGL((k_step_update<XT, 1, BYVAL, 1>), gu, dim3(256), lds, q, d_steps, pk, ldx, c->D, c->KS);
+  } else {
+    if (max_nb > 4096) hipLaunchKernelGGL((k_step_update<XT, 2, BYVAL, 4>), gu, dim3(256), lds, q, d_steps, pk, ldx, c->D, c->KS);
+    else hipLaunchKernelGGL((k_step_update<XT, 2, BYVAL, 1>), gu, dim3(256), lds, q, d_steps, pk, ldx, c->D, c->KS);
+  }
   if (sample) {
     hipEventRecord(ks.e2, q);
     c->ks_pending.push_back(ks);
@@ -3624,8 +3648,8 @@ template <typename XT>
 static void launch_update_only(hamsm_ctx *c, hipStream_t q, const StepPack &pk, int ny, int maxK, int64_t ldx, double ratio, bool any_perm) {
   const size_t lds = sizeof(int) * (4 * UPD_LIST);
   const dim3 gu((unsigned)((maxK + 3) / 4), (unsigned)ny);
-  if (c->D <= 64) hipLaunchKernelGGL((k_step_update<XT, 1, true>), gu, dim3(256), lds, q, (const StepDev *)nullptr, pk, ldx, c->D, c->KS);
-  else hipLaunchKernelGGL((k_step_update<XT, 2, true>), gu, dim3(256), lds, q, (const StepDev *)nullptr, pk, ldx, c->D, c->KS);
+  if (c->D <= 64) hipLaunchKernelGGL((k_step_update<XT, 1, true, 4>), gu, dim3(256), lds, q, (const StepDev *)nullptr, pk, ldx, c->D, c->KS);
+  else hipLaunchKernelGGL((k_step_update<XT, 2, true, 4>), gu, dim3(256), lds, q, (const StepDev *)nullptr, pk, ldx, c->D, c->KS);
   if (any_perm)
     hipLaunchKernelGGL((k_step_reassign<XT, true>), dim3((unsigned)ny), dim3(256), 0, q, (const StepDev *)nullptr, pk, ldx, c->D, c->KS, ratio);
 }
