@@ -21,7 +21,8 @@
 // hamsm_selftest_mfma() checks that property of the hardware bit for bit.
 //
 // Measured on MI355X (C3: 10 M rows x 30 features, 4 strata x 250 centroids): exact kernel alone 3.5 ms = 42 TFLOP/s f64;
-// ranking pass + exact pass over the undecided 0.002 % 1.39 ms.  Earlier
+// ranking pass + exact pass over the undecided 0.003 % 0.80 ms (the ranking pass is issue-bound on its three vector
+// instructions per ranked value: DESIGN.md §5.1a, "Round 3").  Earlier
 // forms of this kernel are in the history (chunk-local buckets with L2-streamed fragments: 7.1 ms; 16-lane DPP
 // argmin: 4.8 ms) -- see DESIGN.md §5.1 for what each step bought.
 #include "common.h"
