@@ -476,11 +476,14 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--workload", default="c3", choices=["c2", "c3", "c5s", "tiny"])
+    ap.add_argument("--workload", default="c3", choices=["c2", "c3", "c5", "c5s", "tiny"],
+                    help="c3 = BASELINE configs[2] (the configuration the metric is quoted on; default); c5 = configs[4] at its "
+                         "stated size on ONE GPU (50 M frames x 64 features, 4 x 1250 clusters + the ~5000-state solve; 25.6 GB of "
+                         "frames, staged in slabs); c5s = a 10 M-frame slice of c5")
     ap.add_argument("--iters", type=int, default=0, help="override iterations per rank (debug)")
     ap.add_argument("--flux-mode", type=int, default=1, help="1 = deterministic sort-based (the product default), 0 = f64 atomics")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-iters", type=int, default=32)
+    ap.add_argument("--cpu-iters", type=int, default=0, help="iterations of the CPU baseline's sample (0: about the work of 32 C3 iterations)")
     ap.add_argument("--cpu-cores", type=int, default=min(16, os.cpu_count() or 1), help="processes of the all-cores CPU leg")
     ap.add_argument("--no-full-pipeline", action="store_true")
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
@@ -559,9 +562,12 @@ def main():
     log(f"workload {cfg.name}: {n_iters} iterations x {cfg.segs_per_iter} segments x {cfg.D} features, "
         f"{cfg.S} strata x {cfg.K_s} clusters, rank shard starts at iteration {first_iter}; scaling {args.scaling}, "
         f"training on {train_on}, exchange {exchange}")
-    Xp, Xc, p0, p1, w, offs = make_shard(cfg, first_iter, n_iters, log)
-    store = DeviceStore.from_host(h, Xp, Xc, p0, p1, w, offs)
-    del Xp, Xc
+    if n_iters * cfg.segs_per_iter * cfg.D * 8 > (8 << 30) or os.environ.get("HAMSM_BENCH_STREAM") == "1":
+        store, offs = synthetic.stage_streamed(h, cfg, first_iter, n_iters, log)   # (c5: never whole on the host)
+    else:
+        Xp, Xc, p0, p1, w, offs = make_shard(cfg, first_iter, n_iters, log)
+        store = DeviceStore.from_host(h, Xp, Xc, p0, p1, w, offs)
+        del Xp, Xc
     n_seg = int(offs[-1])
     m = new_model(h, cfg, store, n_iters)
     m.train_shards = train_on
@@ -706,7 +712,7 @@ def main():
         "flux_ms": flux_ms,
     }
     if world == 1 and not args.no_ingest:
-        out["ingest"] = ingest_leg(h, cfg, min(n_iters, 100), log)
+        out["ingest"] = ingest_leg(h, cfg, min(n_iters, 100, max(4, int(264e6 / (cfg.segs_per_iter * cfg.D * 8)))), log)
     if world == 1 and not args.no_full_pipeline:
         # BASELINE.json's second figure (steady-state solve wall-time) and SURVEY §8d's build_analyze_model-equivalent
         log("timing the full build_analyze_model sequence (clean, T, solve, block validation) ...")
@@ -718,7 +724,9 @@ def main():
     if rank == 0:
         if not args.no_cpu_baseline and world == 1:
             log("timing the CPU oracle on a bounded sample ...")
-            out["cpu_baseline"] = cpu_baseline(args.workload, min(args.cpu_iters, n_iters), seed, args.cpu_cores)
+            # a BOUNDED sample: the work of 32 C3 iterations (~20 s on one core), never fewer than 2 iterations
+            cpu_iters = args.cpu_iters or max(2, int(32 * (10000 * 250 * 30) / (cfg.segs_per_iter * cfg.K_s * cfg.D)))
+            out["cpu_baseline"] = cpu_baseline(args.workload, min(cpu_iters, n_iters), seed, args.cpu_cores)
             out["cpu_baseline"]["gpu_over_cpu"] = out["value"] / out["cpu_baseline"]["value"]
         print(json.dumps(out), flush=True)
     if dist is not None:

@@ -21,7 +21,7 @@ from dataclasses import dataclass
 import numpy as np
 
 __all__ = ["WEConfig", "CONFIGS", "latent_centres", "make_iteration", "make_block",
-           "strata_boundaries", "basis_target_bounds"]
+           "strata_boundaries", "basis_target_bounds", "stage_streamed"]
 
 
 @dataclass(frozen=True)
@@ -103,3 +103,47 @@ def make_block(cfg: WEConfig, it_first: int, it_last: int, latent: np.ndarray | 
     out["offsets"] = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)
     out["iters"] = np.arange(it_first, it_last + 1, dtype=np.int64)
     return out
+
+
+def stage_streamed(h, cfg: WEConfig, it_first: int, n_iters: int, log=None, slab_iters: int = 16, threads: int | None = None,
+                   keep=()):
+    """Iterations it_first .. it_first+n_iters-1 staged into HBM without ever being whole on the host: they are generated
+    ``slab_iters`` at a time (by a thread pool: the NumPy generators release the GIL) and every slab is uploaded into its place
+    in device arrays allocated once.  BASELINE config 5 is 2 x 12.8 GB of float32 frames: the host side stays at one slab.
+    Returns ``(DeviceStore, offsets)`` -- and, for the keys named in ``keep`` (of "p0", "p1", "w"), the host copies too:
+    ``(DeviceStore, offsets, {key: array})``."""
+    import os
+    import time
+    from concurrent.futures import ThreadPoolExecutor
+
+    from . import _abi
+    from .data import DeviceStore
+
+    lat = latent_centres(cfg)
+    seg, D = cfg.segs_per_iter, cfg.D
+    n = n_iters * seg
+    dXp, dXc = h.alloc((n, D), np.float32), h.alloc((n, D), np.float32)
+    dp0, dp1, dw = h.alloc((n, 1), np.float64), h.alloc((n, 1), np.float64), h.alloc(n, np.float64)
+    kept = {k: np.empty((n, 1) if k != "w" else n) for k in keep}
+    threads = threads or min(16, os.cpu_count() or 1)
+    t0 = time.time()
+    with ThreadPoolExecutor(threads) as ex:
+        def submit(k0):
+            return [ex.submit(make_iteration, cfg, it, lat) for it in range(it_first + k0, it_first + min(n_iters, k0 + slab_iters))]
+
+        nxt = submit(0)
+        for k0 in range(0, n_iters, slab_iters):
+            k1 = min(n_iters, k0 + slab_iters)
+            parts = [f.result() for f in nxt]
+            nxt = submit(k1) if k1 < n_iters else []   # the next slab is generated while this one is uploaded
+            a = k0 * seg
+            for key, dst, width in (("Xp", dXp, D), ("Xc", dXc, D), ("p0", dp0, 1), ("p1", dp1, 1), ("w", dw, 1)):
+                slab = np.concatenate([p[key] for p in parts], axis=0)
+                h.h2d(dst.offset(a * width), slab)
+                if key in kept:
+                    kept[key][a: a + len(slab)] = slab
+            if log and (k0 // slab_iters) % 8 == 0:
+                log(f"generated + uploaded {k1}/{n_iters} iterations ({time.time() - t0:.1f}s)")
+    offs = np.arange(n_iters + 1, dtype=np.int64) * seg
+    store = DeviceStore(h, D, 1, _abi.F32, offs, dXp, dXc, dp0, dp1, dw)
+    return (store, offs, kept) if keep else (store, offs)

@@ -137,6 +137,32 @@ def test_c3_train_assign_full_size(c3_run, oracle_h):
     assert np.array_equal(np.concatenate(m2.dtrajs), child)
 
 
+def test_c3_full_size_training_equals_oracle(c3_run, oracle_lib):
+    """the whole 999-call training pass of BASELINE config 3 (10 M frames, 4 strata x 250, k-means++ on the
+    first call, every low-count re-seeding on the way) on the HIP library against the SAME pass on the oracle (one core,
+    about half a minute): every stratum's centroids, counts, ||c||^2 and bookkeeping bit-identical.  Reference semantics:
+    `_clustering.py:664-716` driving sklearn's `partial_fit` (`_kmeans.py:2203-2301`)."""
+    from msm_we_amd import _abi
+
+    cfg, d, h, m, store, bm = c3_run
+    ho = _abi.Hamsm(lib=oracle_lib)
+    try:
+        mo, _ = _model(ho, cfg, d)
+        mo.launch_ray_discretization = lambda progress_bar=None: None   # 2 x 10 M rows x 250 x 30 on a scalar core: not this test
+        mo.cluster_coordinates(cfg.K_s, streaming=True, use_ray=True, stratified=True, user_bin_mapper=bm, random_state=1337)
+        assert mo.training_path == m.training_path == "planned"
+        assert [mo.clusters.we_remap[b] for b in range(cfg.S)] == [m.clusters.we_remap[b] for b in range(cfg.S)]
+        for s, (ca, cb) in enumerate(zip(m.clusters.cluster_models, mo.clusters.cluster_models)):
+            assert ca.cluster_centers_.shape == (cfg.K_s, cfg.D)
+            assert np.array_equal(ca.cluster_centers_, cb.cluster_centers_), s
+            assert np.array_equal(ca._counts, cb._counts), s
+            assert ca.n_steps_ == cb.n_steps_ == cfg.n_iters
+            assert ca._n_since_last_reassign == cb._n_since_last_reassign
+            assert np.array_equal(h.get_centroids(s)[2], ho.get_centroids(s)[2]), s   # ||c||^2 as the step kernels keep it
+    finally:
+        ho.close()
+
+
 def test_c3_filter_and_exact_kernel_agree_on_every_frame(c3_run, hip_lib, monkeypatch):
     """all 2 x 10 M labels of the default path (f32 ranking + exact recheck of the undecided) equal those of the exact f64
     kernel alone (HAMSM_ASSIGN_FILTER=0), and only a sliver of the frames needed the recheck"""
@@ -400,3 +426,113 @@ def test_wide_features_train_assign_flux_at_size(hip_lib, oracle_h):
         assert np.array_equal(res[0][2], res[1][2])
     finally:
         h.close()
+
+
+# ---- BASELINE config 5 AT ITS STATED SIZE on one GPU: 1000 x 50 000 segments x 64 features, 4 x 1250 clusters ---------------
+# (VERDICT r3 missing #3.  25.6 GB of frames: staged in slabs, never whole on the host; the oracle checks samples of
+# regenerated iterations; the properties -- strata never mix, flux against an independent accumulation, determinism, the
+# ~5000-state solve's fixed-point equations -- cover the rest.)
+@pytest.fixture(scope="module")
+def c5_full(hip_lib):
+    from msm_we_amd import _abi
+
+    cfg = synthetic.CONFIGS["c5"]
+    h = _abi.Hamsm(lib=hip_lib)
+    store, offs, host = synthetic.stage_streamed(h, cfg, 1, cfg.n_iters, keep=("p0", "p1", "w"))
+    m = modelWE(h=h)
+    m.pcoord_ndim = 1
+    basis, target = synthetic.basis_target_bounds(cfg.S)
+    m.basis_pcoord_bounds, m.target_pcoord_bounds, m.tau = basis, target, 1.0
+    m.attach_store(store)
+    m.maxIter = len(offs)
+    m.numSegments = np.diff(offs).astype(float)
+    bm = RectilinearBinMapper([synthetic.strata_boundaries(cfg.S)])
+    m.cluster_coordinates(cfg.K_s, streaming=True, use_ray=True, stratified=True, user_bin_mapper=bm, random_state=1337,
+                          store_validation_model=True)
+    yield cfg, h, m, store, host, bm
+    h.close()
+
+
+def test_c5_full_size_train_assign(c5_full, oracle_h):
+    cfg, h, m, store, host, bm = c5_full
+    n = store.N
+    assert n == 50_000_000 and m.n_clusters == 5000 and m.training_path == "planned"
+    child = np.concatenate(m.dtrajs)
+    parent = np.concatenate([p[:, 0] for p in m.pair_dtrajs])
+    assert len(child) == n
+    p0, p1 = host["p0"][:, 0], host["p1"][:, 0]
+    K = m.n_clusters
+    # basis / target short-circuits and strata never mix (stratified_clustering.py:159-196)
+    for lab, p in ((child, p1), (parent, p0)):
+        tgt, bas = p > cfg.S - 0.05, p < 0.05
+        assert np.all(lab[tgt] == K + 1) and np.all(lab[bas & ~tgt] == K)
+        free = ~(tgt | bas)
+        s_of = np.minimum(np.floor(p.astype(np.float32)), cfg.S - 1).astype(np.int64)
+        assert np.array_equal(lab[free] // cfg.K_s, s_of[free])
+    for cm in m.clusters.cluster_models:
+        assert cm.cluster_centers_.shape == (cfg.K_s, cfg.D) and cm.n_steps_ == cfg.n_iters
+    # the oracle on samples of regenerated iterations, both sides (the frames themselves were never kept on the host)
+    rng = np.random.default_rng(55)
+    lat = synthetic.latent_centres(cfg)
+    oracle_h.set_geometry(cfg.D, 1, cfg.S)
+    oracle_h.set_mapper_rectilinear([synthetic.strata_boundaries(cfg.S)])
+    basis, target = synthetic.basis_target_bounds(cfg.S)
+    oracle_h.set_bounds(basis, target)
+    for s in range(cfg.S):
+        Cm, counts, csq = h.get_centroids(s)
+        oracle_h.set_centroids(s, Cm, csq=csq)
+    for it in rng.choice(np.arange(1, cfg.n_iters + 1), 6, replace=False):
+        d = synthetic.make_iteration(cfg, int(it), lat)
+        a = (int(it) - 1) * cfg.segs_per_iter
+        assert np.array_equal(d["p1"][:, 0], p1[a: a + cfg.segs_per_iter])
+        idx = np.sort(rng.choice(cfg.segs_per_iter, 400, replace=False))
+        assert np.array_equal(oracle_h.predict_host(d["Xc"][idx], d["p1"][idx]), child[a + idx].astype(np.int32))
+        assert np.array_equal(oracle_h.predict_host(d["Xp"][idx], d["p0"][idx]), parent[a + idx].astype(np.int32))
+    # determinism: a second full pass on the resident frames gives bit-identical centroids and labels
+    cents = [cm.cluster_centers_.copy() for cm in m.clusters.cluster_models]
+    m2 = modelWE(h=h)
+    m2.pcoord_ndim = 1
+    m2.basis_pcoord_bounds, m2.target_pcoord_bounds, m2.tau = basis, target, 1.0
+    m2.attach_store(store)
+    m2.maxIter, m2.numSegments = m.maxIter, m.numSegments
+    m2.cluster_coordinates(cfg.K_s, streaming=True, use_ray=True, stratified=True, user_bin_mapper=bm, random_state=1337)
+    for a, b in zip(cents, m2.clusters.cluster_models):
+        assert np.array_equal(a, b.cluster_centers_)
+    assert np.array_equal(np.concatenate(m2.dtrajs), child)
+
+
+def test_c5_full_size_flux_and_solve(c5_full):
+    cfg, h, m, store, host, bm = c5_full
+    n, K = store.N, m.n_clusters
+    child = np.concatenate(m.dtrajs)
+    parent = np.concatenate([p[:, 0] for p in m.pair_dtrajs])
+    m.flux_mode = 1
+    m.get_fluxMatrix(0, first_iter=1, last_iter=m.maxIter)
+    F = m.fluxMatrixRaw.copy()
+    assert F.shape == (K + 2, K + 2) and abs(F.sum() - 1.0) < 1e-11
+    lo = cfg.segs_per_iter  # iterations 2 .. maxIter-1 (quirk Q6), overrides of _fluxmatrix.py:135-137
+    a, b = parent[lo:n].copy(), child[lo:n].copy()
+    p0, p1 = host["p0"][lo:n, 0], host["p1"][lo:n, 0]
+    b[p1 > cfg.S - 0.05] = K + 1
+    a[p0 < 0.05] = K
+    b[p1 < 0.05] = K
+    ref = np.bincount(a * (K + 2) + b, weights=host["w"][lo:n], minlength=(K + 2) * (K + 2)).reshape(K + 2, K + 2) / (m.maxIter - 2)
+    np.testing.assert_allclose(F, ref, rtol=1e-10, atol=1e-18)
+    assert np.array_equal(F == 0, ref == 0)
+    m.get_fluxMatrix(0, first_iter=1, last_iter=m.maxIter)
+    assert np.array_equal(m.fluxMatrixRaw, F)   # the sorted build is deterministic
+    # clean -> T (CSR on the device) -> the ~5000-state steady state on the host: fixed-point equations of _analysis.py:97-191
+    m.organize_fluxMatrix(use_ray=True)
+    m.get_Tmatrix()
+    m.get_steady_state()
+    m.get_steady_state_target_flux()
+    ns = m.Tmatrix.shape[0]
+    assert 4000 < ns <= K + 2 and list(m.indBasis) == [ns - 2] and list(m.indTargets) == [ns - 1]
+    T = m.Tmatrix_csr
+    np.testing.assert_allclose(np.asarray(T.sum(axis=1)).ravel(), 1.0, rtol=1e-12)
+    pi = m.pSS
+    assert abs(pi.sum() - 1.0) < 1e-10 and pi.min() >= 0
+    np.testing.assert_allclose(T.T @ pi, pi, rtol=1e-6, atol=1e-12)
+    nt = [i for i in range(ns) if i != ns - 1]
+    J = float(pi[nt] @ np.asarray(T[nt, ns - 1].todense()).ravel()) / m.tau
+    assert abs(m.JtargetSS - J) <= 1e-9 * abs(J)
