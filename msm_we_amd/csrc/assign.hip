@@ -1304,7 +1304,8 @@ static int launch_sorted(hamsm_ctx *c, const AssignArgs &a) {
   return hamsm_fail(c, HAMSM_ENOTSUP, "KS=%d", KS);
 }
 
-// The training pass's E-step through the assignment kernels (run_steps, train.hip): frames d_perm[.] of X (indices below
+#ifdef HAMSM_EXPERIMENTS
+// (experiments/train_ranked.inc) The training pass's E-step through the assignment kernels: frames d_perm[.] of X (indices below
 // n_span), grouped by stratum with d_cnt[s] rows each; labels[frame] = label offset of the stratum + nearest centroid, as
 // hamsm_assign writes them.  On the context's stream; no synchronisation, no adaptive state.
 int hamsm_assign_rows(hamsm_ctx *c, const void *X, int dt, int64_t ldx, int64_t n_span, int32_t *d_labels, const int32_t *d_perm,
@@ -1315,6 +1316,7 @@ int hamsm_assign_rows(hamsm_ctx *c, const void *X, int dt, int64_t ldx, int64_t 
   g.cnt_in = d_cnt;
   return (dt == HAMSM_F32) ? launch_sorted<float>(c, g) : launch_sorted<double>(c, g);
 }
+#endif
 
 // Not part of the product ABI (test / bench hook): the form of the ranking pass the last hamsm_assign ran
 // (0 exact kernel only, 1 f32, 2 bf16 x 3 with 6 products, 3 bf16 with 3 products).

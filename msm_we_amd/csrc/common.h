@@ -76,6 +76,8 @@ struct hamsm_ctx {
   hipStream_t side_stream[3] = {nullptr, nullptr, nullptr};
   hipEvent_t ev_fork = nullptr, ev_join[3] = {nullptr, nullptr, nullptr};
   int step_lanes = 2;  // queues used by the training steps (HAMSM_STEP_LANES = 1..4)
+#ifdef HAMSM_EXPERIMENTS
+  // ---- csrc/experiments/ (libhamsm_hip_exp.so only; every one of these measured slower than the shipped path and ships OFF) ----
   int train_persist = 0;  // HAMSM_TRAIN_PERSIST=1: planned training passes run as ONE persistent launch (measured slower than the
                           // multi-kernel path on every shape tried -- DESIGN.md §5.3a -- and therefore off; kept as a tested alternative)
   int persist_wpx = 64;   // workgroups per XCD of that launch (HAMSM_PERSIST_WPX, 8 XCDs: grid = 8 x this)
@@ -98,6 +100,7 @@ struct hamsm_ctx {
   long long ranked_groups = 0;     // launch groups served that way (debug counter)
   int train_graph = 0;      // HAMSM_TRAIN_GRAPH=1 (experiment): a training pass's launches captured into one hipGraph
   bool capturing = false;   // ... while its stream capture is open (no event timing inside)
+#endif
   int generic_stage_kb = 150;  // D > 128: the E-step stages its 16 rows in LDS while they fit this (HAMSM_GENERIC_STAGE_KB; 0 = never)
   // hamsm_malloc / hamsm_free keep released blocks for reuse (hipMalloc costs ~1 ms per 40 MB block and hipFree
   // synchronises the device; every use of a block is ordered on `stream`, so reuse needs no synchronisation)
@@ -201,8 +204,13 @@ int hamsm_refresh_table(hamsm_ctx *c);                    // rebuilds d_table / 
 int hamsm_check_device_error(hamsm_ctx *c, const char *what);  // reads d_err (syncs the stream)
 int hamsm_stratum_reserve(hamsm_ctx *c, int s, int K);
 int hamsm_pack_stratum(hamsm_ctx *c, int s, const double *d_csq_in);
+#ifdef HAMSM_EXPERIMENTS
 int hamsm_assign_rows(hamsm_ctx *c, const void *X, int dt, int64_t ldx, int64_t n_span, int32_t *d_labels, const int32_t *d_perm,
-                      const unsigned long long *d_cnt);  // assign.hip: the E-step of a heavy training call
+                      const unsigned long long *d_cnt);  // assign.hip: the E-step of a heavy training call (experiments/train_ranked.inc)
+#define HAMSM_CAPTURING(c) ((c)->capturing)
+#else
+#define HAMSM_CAPTURING(c) false
+#endif
 void hamsm_timer_begin(hamsm_ctx *c);
 void hamsm_timer_end(hamsm_ctx *c, int stage);
 

@@ -67,9 +67,10 @@ extern "C" int hamsm_create(int device, hamsm_ctx **out) {
   if (const char *v = getenv("HAMSM_FILTER_DBUF")) c->filter_dbuf = atoi(v) != 0;
   if (const char *v = getenv("HAMSM_FILTER_NB")) c->filter_nb = atoi(v) < 1 ? 1 : (atoi(v) > 16 ? 16 : atoi(v));
   if (const char *v = getenv("HAMSM_FILTER_LDS_KB")) c->filter_lds_kb = atoi(v) < 40 ? 40 : (atoi(v) > 150 ? 150 : atoi(v));
+  if (const char *v = getenv("HAMSM_GENERIC_STAGE_KB")) c->generic_stage_kb = atoi(v) < 0 ? 0 : (atoi(v) > 150 ? 150 : atoi(v));
+#ifdef HAMSM_EXPERIMENTS  // (libhamsm_hip_exp.so only: csrc/experiments/)
   if (const char *v = getenv("HAMSM_TRAIN_PERSIST")) c->train_persist = atoi(v) != 0;
   if (const char *v = getenv("HAMSM_PERSIST_WPX")) c->persist_wpx = atoi(v) < 4 ? 4 : (atoi(v) > 128 ? 128 : atoi(v));
-  if (const char *v = getenv("HAMSM_GENERIC_STAGE_KB")) c->generic_stage_kb = atoi(v) < 0 ? 0 : (atoi(v) > 150 ? 150 : atoi(v));
   if (const char *v = getenv("HAMSM_TRAIN_RANKED")) c->train_ranked = atoi(v) < 0 ? 0 : (atoi(v) > 2 ? 2 : atoi(v));
   if (const char *v = getenv("HAMSM_RANKED_MIN_MFLOP")) c->ranked_min_flop = atof(v) > 0 ? atof(v) * 1e6 : c->ranked_min_flop;
   if (const char *v = getenv("HAMSM_TRAIN_GRAPH")) c->train_graph = atoi(v) != 0;
@@ -78,6 +79,7 @@ extern "C" int hamsm_create(int device, hamsm_ctx **out) {
   if (const char *v = getenv("HAMSM_AHEAD_N0")) c->ahead_n0 = atoi(v) < 1 ? 1 : atoi(v);
   if (const char *v = getenv("HAMSM_AHEAD_G")) c->ahead_gmax = atoi(v) < 1 ? 1 : (atoi(v) > 16 ? 16 : atoi(v));
   if (const char *v = getenv("HAMSM_AHEAD_ALPHA")) c->ahead_alpha = atof(v) > 1.0 ? atof(v) : 1.0;
+#endif
   if (const char *v = getenv("HAMSM_STEP_LANES")) c->step_lanes = atoi(v) < 1 ? 1 : (atoi(v) > 4 ? 4 : atoi(v));
   if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess ||
       hipMalloc((void **)&c->d_err, 4 * sizeof(int)) != hipSuccess ||

@@ -1009,9 +1009,6 @@ extern "C" int hamsm_kmeans_seed(hamsm_ctx *c, int s, const void *X, int dt, int
 }
 
 // ---- minibatch steps ------------------------------------------------------------------------------
-struct SuspEntry {  // look-ahead blocks: batch row r is nearest to j1, j2 or j3 (-1: none), whichever the centroids of its step say
-  int r, j1, j2, j3;
-};
 struct StepDev {
   const void *X;         // frame 0 of the step's call
   const int32_t *rows;   // batch row list (nullable = identity)
@@ -1036,44 +1033,6 @@ struct StepDev {
   int32_t *halt;         // the stratum's stop word: steps with idx >= *halt are not applied
   int32_t *reason;       // HAMSM_STOP_* of the stratum
 };
-// look-ahead blocks (k_step_assign_ahead / k_step_update_ahead): what a step of a block carries besides its StepDev
-// (kept apart: the step-by-step kernels take their descriptors by value and every byte of them is on the launch path)
-struct AheadDev {
-  int pos, pad_;              // position of the step among its stratum's steps of the block (0 = the block's first); < 0: not in a block
-  double *slot;               // [AHEAD_SLOTS] largest centroid displacement this step's M-step measured, spread over AHEAD_SLOTS words
-                              // (wave j adds to word j % AHEAD_SLOTS: 250 atomic maxima on ONE word cost 10 us); readers take their maximum
-  const double *prev_slot;    // the slots of the stratum's previous step (null: this step's labels are exact, nothing to check)
-  const double *ref_slot;     // the slots this step's bound is derived from (null: bound 0)
-  double ref_scale;           //   bound = ref_scale * *ref_slot
-  double *bound;              // [1] the bound the E-step used (read back by the M-step that checks it)
-  // the step's M-step reads the stratum's tables where its StepDev points (C, counts, csq) and writes ALL of them, moved or
-  // not, to these: the E-step of a later iteration may be reading the old ones in the same launch (two buffers, alternating)
-  double *C_out, *counts_out, *csq_out, *Bpack_out;
-  int disp_in, pad2_;         // what `slot` measures: 1 = against the tables this step read (the next step's labels were taken
-                              // one update ago), 0 = against what C_out held before (two updates ago: the pipeline's steady state)
-  SuspEntry *tab;             // [AHEAD_TAB_CAP] rows the bound cannot decide, with their candidate centroids
-  int32_t *cnt;               // [4]: entries appended to `tab`; flags of rows the block cannot serve (1 table full, 2 open row at
-                              //      position 0, 4 not finite, 8 list of open rows full); open rows appended to `hl`
-  // open rows: more than three candidates.  Their distance to EVERY centroid is evaluated exactly, one step ahead: the wave
-  // that has just updated centroid j (the M-step of the stratum's previous step in the block) computes the contract's d(x, c_j)
-  // for the next step's open rows; the next step's waves take the first minimum over j.
-  int32_t *hl;                // [hcap] this step's open rows
-  double *hd;                 // [hcap][kst] their distances, written by the previous step's M-step
-  double *td;                 // [AHEAD_TAB_CAP][3] the distances of the table's candidates, written by the previous step's M-step
-  const int32_t *nx_cnt;      // the stratum's NEXT step in the block (null at the block's last position): its counters,
-  const int32_t *nx_hl;       //   its open rows,
-  const double *nx_Xg;        //   its batch copy,
-  double *nx_hd;              //   where the open rows' distances go,
-  const SuspEntry *nx_tab;    //   its table
-  double *nx_td;              //   and where its candidates' distances go
-  int hcap, kst;              // most open rows per step (by the row length: they wait in LDS); row stride of hd
-};
-struct AheadPack {
-  AheadDev a[4];
-};
-#define AHEAD_TAB_CAP 256
-#define AHEAD_SLOTS 64
-#define HAMSM_STOP_AHEAD 100  // internal: a look-ahead block was given up at this step; run_steps relaunches from it itself
 // what the next call's E-step will gather: its lines are pulled towards this XCD's L2 while this call computes
 struct StepNext {
   const void *X;
@@ -1457,79 +1416,6 @@ __device__ __forceinline__ void upd_add_listed(double (&acc)[H], const GAS doubl
   }
 }
 
-// A large call's E-step runs through the assignment kernels (hamsm_assign_rows: ranking pass with a proven bound + exact f64
-// kernel for what it cannot certify -- the labels are the contract's); this kernel turns its output, labels per
-// FRAME of the call's span, into what the M-step reads: membership bitmaps by batch row, the batch rows as f64, the labels by
-// batch row.  Workgroup 0 of each stratum evaluates the tests that ride on k_step_assign's workgroup 0.
-struct RowsPack {
-  int off[PACK_NY];  // label offset of the step's stratum (labels of the span carry it)
-};
-template <typename XT>
-__global__ __launch_bounds__(256) void k_rows_to_bits(const StepPack pk, const RowsPack rp, const int32_t *__restrict__ span_labels,
-                                                      int64_t ldx, int D, int KS, double ratio) {
-  const StepDev sdesc = pk.s[blockIdx.y];
-  const StepG st(sdesc);
-  const long long r0 = (long long)blockIdx.x * 64;
-  if (r0 >= st.n_b) return;
-  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-  __shared__ double sd4[4];
-  if (blockIdx.x == 0 && (st.flags & 6) && st.idx < *gp(sdesc.halt)) {
-    // (k_step_assign's block: `counts < ratio * max(counts)` for the stratum's previous step, `(counts == 0).any()` before this one)
-    const double inf = __builtin_huge_val();
-    const GAS int32_t *prev = gp(sdesc.prev_report);
-    int z = 0;
-    double mx = -inf;
-    for (int j = tid; j < st.K; j += 256) {
-      double cj = st.counts[j];
-      z |= (cj == 0.0);
-      mx = cj > mx ? cj : mx;
-    }
-    int any_low = 0;
-    if (st.flags & 4) {
-#pragma unroll
-      for (int off = 32; off >= 1; off >>= 1) {
-        double o = __shfl_xor(mx, off, 64);
-        mx = o > mx ? o : mx;
-      }
-      if (lane == 0) sd4[wv] = mx;
-      __syncthreads();
-      mx = sd4[0];
-#pragma unroll
-      for (int w = 1; w < 4; w++) mx = sd4[w] > mx ? sd4[w] : mx;
-      const double thr = ratio * mx;
-      int low = 0;
-      for (int j = tid; j < st.K; j += 256) low += st.counts[j] < thr;
-      if (low) __hip_atomic_fetch_add((GAS int32_t *)prev + 1, low, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      any_low = __syncthreads_or(low);
-    }
-    const int any_z = __syncthreads_or((st.flags & 2) ? z : 0);
-    if (tid == 0) {
-      if (any_low) {
-        *gp(sdesc.halt) = st.idx;
-        *gp(sdesc.reason) = HAMSM_STOP_LOW;
-      } else if (any_z) {
-        st.report[0] = 1;
-        *gp(sdesc.halt) = st.idx;
-        *gp(sdesc.reason) = HAMSM_STOP_ZERO;
-      }
-    }
-  }
-  // four threads per batch row
-  const long long r = r0 + (tid >> 2);
-  const int part = tid & 3;
-  if (r >= st.n_b) return;
-  const long long f = st.rows ? (long long)st.rows[r] : r;
-  const GAS XT *X = (const GAS XT *)st.X;
-  const int ldg = 4 * KS;
-  for (int k = part; k < ldg; k += 4) st.Xg[(size_t)r * ldg + k] = k < D ? (double)X[f * ldx + k] : 0.0;
-  if (part == 0) {
-    int j = ((const GAS int32_t *)gp(span_labels))[f] - rp.off[blockIdx.y];
-    j = (j >= 0 && j < st.K) ? j : 0;
-    st.labels[r] = j;
-    __hip_atomic_fetch_or(&st.mbits[(size_t)j * sdesc.wstride + (r >> 6)], 1ull << (r & 63), __ATOMIC_RELAXED,
-                          __HIP_MEMORY_SCOPE_AGENT);
-  }
-}
 
 // M-step: one wave per centroid.  Round trip 1 fetches the centroid's membership bitmap (one word per lane), its count
 // and its row; the set bits ARE the members in ascending sample order (no list to sort, no cap on the cluster size):
@@ -1674,756 +1560,6 @@ __global__ __launch_bounds__(256) void k_step_update(const StepDev *__restrict__
   SPROF_FLUSH(1)
 }
 
-// ---- pipelined training: the E-step two iterations ahead (an experiment, off by default) --------------------------
-// The chain E(t) -> M(t) -> E(t+1) -> ... is what bounds a training pass: two dependent launches per WE iteration.  But the
-// centroids of a stratum move less and less (by ~1/count per step), and a label is an argmin: it survives any displacement that is
-// small against the gap between a row's nearest and second-nearest centroid.  So ONE launch per iteration (k_step_pipe) holds the
-// M-step of iteration i and, beside it, the E-step of iteration i + 2 against the centroid tables that M-step READS (it writes
-// the stratum's other set of tables: two sets, alternating) -- labels are two updates old when they are used.
-//
-// Certificate.  Write S = |x|, R_j = |x - c_j| for the centroids the E-step saw, and let every centroid have moved by at most B
-// (Euclidean) when the labels are used.  The contract's distances are d_j = csq_j - 2 x.c_j (f64 fma chains), i.e.
-// R_j^2 - S^2 up to a rounding error of at most g (2S + R_j)^2, g = (D + 6) 2^-53.  Centroid j cannot be the argmin then if
-//     (R_j - B)^2 - g' (..)  >  (R_1 + B)^2 + g' (..)   <=   R_j^2 - R_1^2 > 2 B (R_1 + R_j) + k [(2S + R_j + B)^2 + (2S + R_1 + B)^2],
-// with R_j > 2B, where 1 is the nearest centroid the E-step saw and k = 2^-38 covers every rounding above, and the 2^-40 by which
-// the ranked values are perturbed (below), many times over.  The left side grows faster in R_j than the right once R_j > 2B, so
-// the centroids are tested in order of distance: the second-nearest passes -> the label is FINAL and the row joins its
-// centroid's membership bitmap as in the step-by-step E-step; else the first that passes ends the row's list of CANDIDATES (2 or
-// 3 of them: the row is undecided and goes to the step's table); a fourth candidate makes the row OPEN (its distance to every
-// centroid will be needed); a row or a distance that is not finite, a full table or a full list of open rows make the step
-// unservable (`cnt[1]`).  Exact ties of the step-by-step rule (first minimum wins) are undecided rows here.
-// Ranking: the sweep keeps each lane's four smallest distances in order with a min / max network (7 instructions per
-// distance); the centroid's index rides in the 12 low mantissa bits of the value (a relative change below 2^-40, charged to k).
-//
-// The bound B is a GUESS made when the E-step is launched: alpha x the displacement the latest finished M-step measured.  The
-// M-step that uses the labels checks it against the displacement really seen (`slot`: the M-step before it took the largest
-// |c_new - c_as_the_E-step_saw_it| over all centroids -- the other set of tables holds exactly those old rows) and checks
-// `cnt[1]`.  If either fails the stratum's chain stops at that step with HAMSM_STOP_AHEAD, nothing of it applied, and run_steps
-// relaunches from there (the tables brought home first), the first two steps of the new segment with exact labels.
-#define AHEAD_KAPPA 3.637978807091713e-12   // 2^-38
-#define AHEAD_EPS 9.5367431640625e-07       // 2^-20
-#define AHEAD_BIG 1e300                     // "no such centroid" (finite: the index bits must not turn an infinity into a NaN)
-#define AHEAD_STRIP 1024                    // ints of LDS per wave of the M-step (4 KB: the member list and its weights, then the new row)
-#define AHEAD_HX 512                        // doubles of LDS per wave for the next step's rows (34 KB per workgroup in all: four per CU)
-#define AHEAD_HCAP 32                       // most open rows per step (fewer for long rows: they wait in LDS)
-#define AHEAD_KMAX 4096                     // centroids per stratum the 12 index bits can name
-
-__device__ __forceinline__ double f64_min(double a, double b) {
-  double r;
-  asm("v_min_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
-  return r;
-}
-__device__ __forceinline__ double f64_max(double a, double b) {
-  double r;
-  asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
-  return r;
-}
-// k1 <= k2 <= k3 <= k4 keep the four smallest keys seen
-__device__ __forceinline__ void top4_insert(double k, double &k1, double &k2, double &k3, double &k4) {
-  double t;
-  t = f64_min(k, k1), k = f64_max(k, k1), k1 = t;
-  t = f64_min(k, k2), k = f64_max(k, k2), k2 = t;
-  t = f64_min(k, k3), k = f64_max(k, k3), k3 = t;
-  k4 = f64_min(k, k4);
-}
-__device__ __forceinline__ double key_of(double d, int j) {
-  return __hiloint2double(__double2hiint(d), (int)(((unsigned)__double2loint(d) & 0xFFFFF000u) | (unsigned)j));
-}
-__device__ __forceinline__ int key_index(double k) { return __double2loint(k) & 0xFFF; }
-
-template <typename XT, int KS, int JB, int RT>
-__device__ __forceinline__ void ahead_assign(const StepDev *__restrict__ steps, const AheadDev *__restrict__ aheads, const int yi,
-                                             const unsigned bx, int64_t ldx, int D) {
-  // RT tiles of 16 batch rows per workgroup: every centroid fragment a wave pulls through L2 serves RT MFMAs (this E-step
-  // is off the pass's critical chain and bound by that traffic, unlike k_step_assign)
-  constexpr int RW = 16 * RT;
-  const StepDev sdesc = load_step_mem(steps, (unsigned)yi);
-  const GAS AheadDev *ahp = gp(aheads + yi);
-  const StepG st(sdesc);
-  const long long r0 = (long long)bx * RW;
-  if (r0 >= st.n_b) return;
-  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-  const GAS XT *X = (const GAS XT *)st.X;
-  // the bound of this step (every workgroup derives the same value; workgroup 0 records it for the M-step)
-  const double *ref_slot = ahp->ref_slot;
-  const double ref_scale = ahp->ref_scale;
-  double B = 0.0;
-  if (ref_slot) {
-    double m = gp(ref_slot)[lane & (AHEAD_SLOTS - 1)];
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) {
-      const double o = __shfl_xor(m, off, 64);
-      m = (o > m || o != o) ? o : m;  // (a NaN displacement stays a NaN: the bound fails its check)
-    }
-    B = ref_scale * m;
-  }
-  long long f[RT];
-#pragma unroll
-  for (int rt = 0; rt < RT; rt++) {
-    const long long r = r0 + rt * 16 + (lane & 15);
-    const long long rc = r < st.n_b ? r : st.n_b - 1;
-    f[rt] = st.rows ? (long long)st.rows[rc] : rc;
-  }
-  const int njt = (st.K + 15) >> 4;
-  const double inf = __builtin_huge_val();
-  double b[JB][KS], cs[JB][4];
-  auto load_group = [&](int t0) {
-#pragma unroll
-    for (int u = 0; u < JB; u++) {
-      const int jt = t0 + 4 * u < njt ? t0 + 4 * u : njt - 1;
-#pragma unroll
-      for (int q = 0; q < 4; q++) cs[u][q] = st.csq[jt * 16 + (lane >> 4) + 4 * q];
-#pragma unroll
-      for (int ks = 0; ks < KS; ks++) b[u][ks] = st.Bpack[((size_t)jt * KS + ks) * 64 + lane];
-    }
-  };
-  load_group(wv);
-  double a[RT][KS];
-#pragma unroll
-  for (int rt = 0; rt < RT; rt++)
-#pragma unroll
-    for (int ks = 0; ks < KS; ks++) {
-      const int k = ks * 4 + (lane >> 4);
-      a[rt][ks] = (double)X[f[rt] * ldx + (k < D ? k : D - 1)];
-    }
-  __shared__ double sk[4][4][RW];
-  __shared__ int snan[4][RT];
-  GAS int32_t *cnt = gp(ahp->cnt);
-  // the batch rows as f64 for the M-step: row tile rt is written by wave (rt + 1) & 3 (as in the step-by-step E-step)
-  auto write_rows = [&]() {
-#pragma unroll
-    for (int rt = 0; rt < RT; rt++)
-      if (((rt + 1) & 3) == wv) {
-        const long long r = r0 + rt * 16 + (lane & 15);
-#pragma unroll
-        for (int ks = 0; ks < KS; ks++) st.Xg[(size_t)r * (4 * KS) + ks * 4 + (lane >> 4)] = a[rt][ks];
-      }
-  };
-  if (ahp->pos == 0) {
-    // the segment's first steps: these ARE the centroids their M-step will see -- the step-by-step E-step's rule, exactly
-    double bd[RT];
-    int bi[RT];
-#pragma unroll
-    for (int rt = 0; rt < RT; rt++) {
-      bd[rt] = inf;
-      bi[rt] = 0x7fffffff;
-    }
-    for (int t0 = wv; t0 < njt; t0 += 4 * JB) {
-      if (t0 != wv) load_group(t0);
-#pragma unroll
-      for (int u = 0; u < JB; u++) {
-        const int jt = t0 + 4 * u;
-        if (jt < njt) {
-          v4f64 acc[RT];
-#pragma unroll
-          for (int rt = 0; rt < RT; rt++) acc[rt] = (v4f64){0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-          for (int ks = 0; ks < KS; ks++)
-#pragma unroll
-            for (int rt = 0; rt < RT; rt++) acc[rt] = __builtin_amdgcn_mfma_f64_16x16x4f64(b[u][ks], a[rt][ks], acc[rt], 0, 0, 0);
-          const int j0 = jt * 16 + (lane >> 4);
-#pragma unroll
-          for (int rt = 0; rt < RT; rt++)
-#pragma unroll
-            for (int q = 0; q < 4; q++) {
-              const double d = __builtin_fma(-2.0, acc[rt][q], cs[u][q]);
-              const bool lt = d < bd[rt];
-              bd[rt] = lt ? d : bd[rt];
-              bi[rt] = lt ? j0 + 4 * q : bi[rt];
-            }
-        }
-      }
-    }
-    write_rows();
-    double *sdv = &sk[0][0][0];       // [4][RW] as one array (the ranking arrays are free on this path)
-    int *sji = (int *)&sk[1][0][0];   // [4][RW]
-#pragma unroll
-    for (int rt = 0; rt < RT; rt++) {
-      double d = bd[rt];
-      int j = bi[rt];
-#pragma unroll
-      for (int off = 16; off <= 32; off <<= 1) {
-        const double d2 = __shfl_xor(d, off, 64);
-        const int j2 = __shfl_xor(j, off, 64);
-        const bool take = (d2 < d) || (d2 == d && j2 < j);
-        d = take ? d2 : d;
-        j = take ? j2 : j;
-      }
-      if (lane < 16) {
-        sdv[wv * RW + rt * 16 + lane] = d;
-        sji[wv * RW + rt * 16 + lane] = j;
-      }
-    }
-    __syncthreads();
-    if (bx == 0 && tid == 0) *gp(ahp->bound) = 0.0;
-    if (tid < RW && r0 + tid < st.n_b) {
-      double d = sdv[tid];
-      int j = sji[tid];
-#pragma unroll
-      for (int w = 1; w < 4; w++) {
-        const double d2 = sdv[w * RW + tid];
-        const int j2 = sji[w * RW + tid];
-        const bool take = (d2 < d) || (d2 == d && j2 < j);
-        d = take ? d2 : d;
-        j = take ? j2 : j;
-      }
-      if (j == 0x7fffffff) j = 0;  // all-NaN row: label 0 like the oracle
-      const long long rr = r0 + tid;
-      __hip_atomic_fetch_or(&st.mbits[(size_t)j * sdesc.wstride + (rr >> 6)], 1ull << (rr & 63), __ATOMIC_RELAXED,
-                            __HIP_MEMORY_SCOPE_AGENT);
-    }
-    return;
-  }
-  double kk[RT][4];
-  bool odd[RT];  // a distance that is not a number
-#pragma unroll
-  for (int rt = 0; rt < RT; rt++) {
-    kk[rt][0] = kk[rt][1] = kk[rt][2] = kk[rt][3] = AHEAD_BIG;
-    odd[rt] = false;
-  }
-  for (int t0 = wv; t0 < njt; t0 += 4 * JB) {
-    if (t0 != wv) load_group(t0);
-#pragma unroll
-    for (int u = 0; u < JB; u++) {
-      const int jt = t0 + 4 * u;
-      if (jt < njt) {
-        v4f64 acc[RT];
-#pragma unroll
-        for (int rt = 0; rt < RT; rt++) acc[rt] = (v4f64){0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-        for (int ks = 0; ks < KS; ks++)
-#pragma unroll
-          for (int rt = 0; rt < RT; rt++) acc[rt] = __builtin_amdgcn_mfma_f64_16x16x4f64(b[u][ks], a[rt][ks], acc[rt], 0, 0, 0);
-        const int j0 = jt * 16 + (lane >> 4);
-#pragma unroll
-        for (int rt = 0; rt < RT; rt++)
-#pragma unroll
-          for (int q = 0; q < 4; q++) {
-            // (rows of the last tile past K carry csq = +inf: they rank as "no such centroid")
-            const double d = __builtin_fma(-2.0, acc[rt][q], f64_min(cs[u][q], AHEAD_BIG));
-            odd[rt] = odd[rt] || (d != d);
-            top4_insert(key_of(d, j0 + 4 * q), kk[rt][0], kk[rt][1], kk[rt][2], kk[rt][3]);
-          }
-      }
-    }
-  }
-  write_rows();
-  double x2r[RT];
-#pragma unroll
-  for (int rt = 0; rt < RT; rt++) {
-    // |x|^2 of the lane's row (features past D were read at the clamped index: not counted)
-    double x2 = 0.0;
-#pragma unroll
-    for (int ks = 0; ks < KS; ks++) {
-      const int k = ks * 4 + (lane >> 4);
-      x2 = k < D ? __builtin_fma(a[rt][ks], a[rt][ks], x2) : x2;
-    }
-    x2 += __shfl_xor(x2, 16, 64);
-    x2 += __shfl_xor(x2, 32, 64);
-    x2r[rt] = x2;
-    // lanes l, l^16, l^32, l^48 hold the same batch row: merge their four best
-#pragma unroll
-    for (int off = 16; off <= 32; off <<= 1) {
-      const double e1 = __shfl_xor(kk[rt][0], off, 64), e2 = __shfl_xor(kk[rt][1], off, 64), e3 = __shfl_xor(kk[rt][2], off, 64),
-                   e4 = __shfl_xor(kk[rt][3], off, 64);
-      top4_insert(e1, kk[rt][0], kk[rt][1], kk[rt][2], kk[rt][3]);
-      top4_insert(e2, kk[rt][0], kk[rt][1], kk[rt][2], kk[rt][3]);
-      top4_insert(e3, kk[rt][0], kk[rt][1], kk[rt][2], kk[rt][3]);
-      top4_insert(e4, kk[rt][0], kk[rt][1], kk[rt][2], kk[rt][3]);
-    }
-    const unsigned long long oddm = __ballot(odd[rt]);
-    if (lane < 16) {
-#pragma unroll
-      for (int q = 0; q < 4; q++) sk[wv][q][rt * 16 + lane] = kk[rt][q];
-    }
-    if (lane == 0) snan[wv][rt] = (int)((oddm | (oddm >> 16) | (oddm >> 32) | (oddm >> 48)) & 0xFFFF);  // by batch row
-  }
-  // (wave 0's lanes hold x2 of rows (rt, lane & 15): thread t < RW needs that of row t)
-  __shared__ double sx2[RW];
-  if (wv == 0 && lane < 16) {
-#pragma unroll
-    for (int rt = 0; rt < RT; rt++) sx2[rt * 16 + lane] = x2r[rt];
-  }
-  __syncthreads();
-  if (bx == 0 && tid == 0) *gp(ahp->bound) = B;
-  if (tid < RW && r0 + tid < st.n_b) {
-    double k1 = sk[0][0][tid], k2 = sk[0][1][tid], k3 = sk[0][2][tid], k4 = sk[0][3][tid];
-#pragma unroll
-    for (int w = 1; w < 4; w++) {
-#pragma unroll
-      for (int q = 0; q < 4; q++) top4_insert(sk[w][q][tid], k1, k2, k3, k4);
-    }
-    const int rt_ = tid >> 4;
-    const bool row_odd = ((snan[0][rt_] | snan[1][rt_] | snan[2][rt_] | snan[3][rt_]) >> (tid & 15)) & 1;
-    const long long rr = r0 + tid;
-    const double x2 = sx2[tid];
-    const double S = __builtin_sqrt(x2);
-    const double D1 = k1 + x2, R1 = __builtin_sqrt(D1 > 0.0 ? D1 : 0.0);
-    // true when the centroid ranked with key kj cannot become the argmin under any displacement <= B of every centroid
-    auto out_of_reach = [&](double kj) {
-      if (kj >= 1e299) return true;  // no such centroid
-      const double Dj = kj + x2, Rj = __builtin_sqrt(Dj > 0.0 ? Dj : 0.0);
-      const double u = 2.0 * S + Rj + B, v = 2.0 * S + R1 + B;
-      const double need = 2.0 * B * (R1 + Rj) * (1.0 + AHEAD_EPS) + AHEAD_KAPPA * (u * u + v * v);
-      return (Rj > 2.0 * B * (1.0 + AHEAD_EPS) + AHEAD_EPS * (S + Rj)) && (Dj - D1 > need);
-    };
-    const bool finite = !row_odd && (x2 < inf) && (k1 > -1e299) && (k1 < 1e299) && (B < inf);
-    const int j1 = key_index(k1), j2 = key_index(k2), j3 = key_index(k3);
-    if (finite && out_of_reach(k2)) {
-      // (result unused: a non-returning atomic)
-      __hip_atomic_fetch_or(&st.mbits[(size_t)j1 * sdesc.wstride + (rr >> 6)], 1ull << (rr & 63), __ATOMIC_RELAXED,
-                            __HIP_MEMORY_SCOPE_AGENT);
-    } else if (finite && (out_of_reach(k3) || out_of_reach(k4))) {
-      const bool three = !out_of_reach(k3);
-      const int at = __hip_atomic_fetch_add(&cnt[0], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      if (at < AHEAD_TAB_CAP) {
-        GAS int *e = (GAS int *)gp(ahp->tab) + 4 * at;
-        e[0] = (int)rr;
-        e[1] = j1;
-        e[2] = j2;
-        e[3] = three ? j3 : -1;
-      } else {
-        __hip_atomic_fetch_or(&cnt[1], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      }
-    } else if (finite) {
-      // an open row (a fourth candidate): every centroid's exact distance, by the M-step of the stratum's previous step
-      const int at = __hip_atomic_fetch_add(&cnt[2], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      if (at < ahp->hcap) gp(ahp->hl)[at] = (int)rr;
-      else __hip_atomic_fetch_or(&cnt[1], 8, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    } else {
-      __hip_atomic_fetch_or(&cnt[1], 4, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-  }
-}
-
-template <typename XT, int KS, int JB, int RT>
-__global__ __launch_bounds__(256) void k_step_assign_ahead(const StepDev *__restrict__ steps, const AheadDev *__restrict__ aheads,
-                                                           const int *__restrict__ ylist, int64_t ldx, int D) {
-  ahead_assign<XT, KS, JB, RT>(steps, aheads, ((const GAS int *)ylist)[blockIdx.y], blockIdx.x, ldx, D);
-}
-
-// M-step of a look-ahead block: k_step_update plus (i) the check of the block's bound, (ii) the low-count / zero-count tests
-// that ride on the E-step in the step-by-step path (here every workgroup evaluates them, they all see the same counts),
-// (iii) the rows the E-step left undecided or open, by the distances the previous step's waves left behind, (iv) the
-// displacement bookkeeping, (v) this centroid's distances to the NEXT step's open rows and to the rows of the next step's
-// table that name it.  One wave per centroid, descriptors in the kernel arguments.
-#define AHEAD_ITEMS 64  // rows of the next step a wave evaluates in one round (lane = row)
-// AHEAD_PROFILE (tools/aheadprof.py): wall-clock stamps of the M part's phases, wave 0 of every workgroup of stratum row 0
-#ifdef AHEAD_PROFILE
-#define APF_N 8
-__device__ unsigned long long g_ahead_prof[64][APF_N];
-extern "C" int hamsm_debug_ahead_profile(unsigned long long *h_out) {
-  return hipMemcpyFromSymbol(h_out, HIP_SYMBOL(g_ahead_prof), sizeof(unsigned long long) * 64 * APF_N) == hipSuccess ? 0 : -1;
-}
-#define APF(slot)                                                                       \
-  {                                                                                     \
-    __builtin_amdgcn_s_waitcnt(0);                                                      \
-    if (blockIdx.y == 0 && bx < 64 && threadIdx.x == 0) g_ahead_prof[bx][slot] = wall_clock64(); \
-  }
-#else
-#define APF(slot)
-#endif
-template <typename XT, int H>
-__device__ __forceinline__ void ahead_update(const StepDev &sdesc, const AheadDev &ah, const unsigned bx, int64_t ldx, int D, int KS,
-                                             double ratio, int *lds_i) {
-  const StepG st(sdesc);
-  if ((int)bx * 4 >= st.K) return;
-  APF(0)
-  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-  int *list = lds_i + wv * AHEAD_STRIP;
-  unsigned *srow = (unsigned *)list;
-  double *swl = (double *)(list + UPD_SC);
-  const GAS double *Xg = st.Xg;
-  const int ldg = 4 * KS;
-  const int j = bx * 4 + wv;
-  const bool active = j < st.K;
-  const int jc = active ? j : st.K - 1;  // (idle waves of the last workgroup load what the last centroid's wave loads; they store nothing)
-  const double inf = __builtin_huge_val();
-  GAS unsigned long long *mb = st.mbits + (size_t)jc * sdesc.wstride;
-  // round trip 1: everything whose address is known from the descriptor
-  const int hv = *gp(sdesc.halt);
-  const unsigned long long w0 = mb[lane];
-  const double cnt0 = st.counts[jc];
-  const double csq0 = st.csq[jc];
-  GAS double *C_out = gp(ah.C_out);
-  double c0[H], sn[H];
-#pragma unroll
-  for (int h = 0; h < H; h++) {
-    const int k = lane + 64 * h;
-    c0[h] = st.C[(size_t)jc * D + (k < D ? k : D - 1)];
-    sn[h] = C_out[(size_t)jc * D + (k < D ? k : D - 1)];  // this centroid two updates ago (steady state)
-  }
-  if (ah.disp_in) {
-#pragma unroll
-    for (int h = 0; h < H; h++) sn[h] = c0[h];
-  }
-  double seen = 0.0;
-  if (ah.prev_slot) {
-    seen = gp(ah.prev_slot)[lane & (AHEAD_SLOTS - 1)];
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) {
-      const double o = __shfl_xor(seen, off, 64);
-      seen = (o > seen || o != o) ? o : seen;
-    }
-  }
-  const double bound = *gp((const double *)ah.bound);
-  const GAS int32_t *cnt = gp((const int32_t *)ah.cnt);
-  const int n_und = cnt[0], unserved = cnt[1];
-  int n_open = cnt[2];
-  n_open = n_open < ah.hcap ? n_open : ah.hcap;
-  const int r_open = gp((const int32_t *)ah.hl)[lane & (AHEAD_HCAP - 1)];
-  // this step's table: an entry per lane, with the candidates' distances the previous step's waves left behind
-  const GAS v4i32 *tab = (const GAS v4i32 *)gp(ah.tab);
-  const GAS double *td = gp((const double *)ah.td);
-  v4i32 ent = tab[lane];  // (entries past n_und are never looked at)
-  double td0 = td[3 * lane], td1 = td[3 * lane + 1], td2 = td[3 * lane + 2];
-  // the next step's rows this wave owes a distance to: its open rows, then the entries of its table that name this centroid.
-  // Lists now, rows into LDS behind them: both round trips overlap with this step's own
-  int n_nx = 0, n_nt = 0;
-  if (ah.nx_cnt) {
-    n_nt = gp(ah.nx_cnt)[0];
-    n_nx = gp(ah.nx_cnt)[2];
-  }
-  n_nx = n_nx < ah.hcap ? n_nx : ah.hcap;
-  n_nt = n_nt < AHEAD_TAB_CAP ? n_nt : AHEAD_TAB_CAP;
-  const int DPH = (D + 1) & ~1;
-  const int cap = AHEAD_HX / DPH;  // rows the LDS holds per round (>= hcap)
-  double *hx = (double *)(lds_i + 4 * AHEAD_STRIP) + wv * AHEAD_HX;
-  int *meta = lds_i + 4 * AHEAD_STRIP + 2 * 4 * AHEAD_HX + wv * (2 * AHEAD_ITEMS);  // per item: where its distance goes, its row
-  const GAS double *nXg = gp(ah.nx_Xg);
-  const GAS v4i32 *ntab = (const GAS v4i32 *)gp(ah.nx_tab);
-  int n_items = 0;  // items of the first round: staged in LDS now, evaluated at the end
-  // stage rows `cnt_` (row numbers by lane, in `rows_l`) at item slots [at, at + cnt_): all lanes load a row's features
-  auto stage = [&](int rows_l, int cnt_, int at) {
-    for (int h0 = 0; h0 < cnt_; h0 += 4) {
-      double t[4][H];
-#pragma unroll
-      for (int q = 0; q < 4; q++) {
-        const int rq = __shfl(rows_l, h0 + q < cnt_ ? h0 + q : cnt_ - 1, 64);
-#pragma unroll
-        for (int h = 0; h < H; h++) {
-          const int k = lane + 64 * h;
-          t[q][h] = nXg[(size_t)rq * ldg + (k < D ? k : D - 1)];
-        }
-      }
-#pragma unroll
-      for (int q = 0; q < 4; q++)
-        if (h0 + q < cnt_) {
-#pragma unroll
-          for (int h = 0; h < H; h++) {
-            const int k = lane + 64 * h;
-            if (k < D) hx[(at + h0 + q) * DPH + k] = t[q][h];
-          }
-        }
-    }
-  };
-  if (active && n_nx > 0) {
-    const int r_nx = gp(ah.nx_hl)[lane & (AHEAD_HCAP - 1)];
-    stage(r_nx, n_nx, 0);
-    if (lane < n_nx) {
-      meta[2 * lane] = -1 - lane;  // an open row: its distance goes to nx_hd[lane][j]
-      meta[2 * lane + 1] = 0;
-    }
-    n_items = n_nx;
-  }
-  int nt_done = 0;  // entries of the next table looked at so far
-  if (active && n_nt > 0) {
-    // the first 64 entries of the next step's table (the later ones, and what does not fit the LDS, wait for the end)
-    const v4i32 e = ntab[lane];
-    const int slot = (lane < n_nt) ? (e.y == j ? 0 : (e.z == j ? 1 : (e.w == j ? 2 : -1))) : -1;
-    const unsigned long long mm = __ballot(slot >= 0);
-    const int mine = __popcll(mm);
-    const int room = (cap < AHEAD_ITEMS ? cap : AHEAD_ITEMS) - n_items;
-    if (mine <= room) {
-      const int rank = __popcll(mm & ((1ull << lane) - 1));
-      // compact the rows of my entries to lanes 0 .. mine-1
-      if (slot >= 0) {
-        meta[2 * (n_items + rank)] = 3 * lane + slot;  // where the distance goes: nx_td[3 * entry + slot]
-        meta[2 * (n_items + rank) + 1] = e.x;
-      }
-      const int rows_l = lane < mine ? meta[2 * (n_items + lane) + 1] : 0;
-      if (mine) stage(rows_l, mine, n_items);
-      n_items += mine;
-      nt_done = n_nt < 64 ? n_nt : 64;
-    }
-  }
-  // the stratum's counts for the tests: every WAVE reads all of them (K / 64 loads per lane) and decides for itself -- the
-  // same counts, the same verdict everywhere, no barrier
-  double cj_t = -inf;
-  int z_t = 0;
-  if (st.flags & 6)
-    for (int q = lane; q < st.K; q += 64) {
-      const double cq = st.counts[q];
-      z_t |= (cq == 0.0);
-      cj_t = cq > cj_t ? cq : cj_t;
-    }
-  if (st.idx >= hv) return;  // the stratum's chain stopped before this step
-  APF(1)
-  // (i) the premises of this step's labels
-  if (!(seen <= bound) || unserved) {
-    if (bx == 0 && tid == 0) {
-      *gp(sdesc.halt) = st.idx;
-      *gp(sdesc.reason) = HAMSM_STOP_AHEAD;
-    }
-    return;
-  }
-  // (ii) _kmeans.py:1645 for the stratum's previous step / :2037 before this one (k_step_assign's block, evaluated by every wave)
-  if (st.flags & 6) {
-    double mx = cj_t;
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) {
-      const double o = __shfl_xor(mx, off, 64);
-      mx = o > mx ? o : mx;
-    }
-    int any_low = 0;
-    if (st.flags & 4) {
-      const double thr = ratio * mx;
-      int low = 0;
-      for (int q = lane; q < st.K; q += 64) low += st.counts[q] < thr;
-#pragma unroll
-      for (int off = 32; off >= 1; off >>= 1) low += __shfl_xor(low, off, 64);
-      if (low && bx == 0 && wv == 0 && lane == 0)
-        __hip_atomic_fetch_add((GAS int32_t *)gp(sdesc.prev_report) + 1, low, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      any_low = low;
-    }
-    const int any_z = (st.flags & 2) ? (__ballot(z_t != 0) != 0ull) : 0;
-    if (any_low || any_z) {
-      if (bx == 0 && tid == 0) {
-        if (any_low) {
-          *gp(sdesc.halt) = st.idx;
-          *gp(sdesc.reason) = HAMSM_STOP_LOW;
-        } else {
-          st.report[0] = 1;
-          *gp(sdesc.halt) = st.idx;
-          *gp(sdesc.reason) = HAMSM_STOP_ZERO;
-        }
-      }
-      return;
-    }
-  }
-  GAS double *slot = gp(ah.slot);
-  if (!active) return;
-  unsigned long long w = w0;
-  APF(2)
-  // (iii-a) open rows: first minimum over all centroids of the distances the previous step's waves left behind.  Four rows'
-  // values are requested together (one round trip per four rows), then reduced
-  for (int h0 = 0; h0 < n_open; h0 += 4) {
-    double bd[4];
-    int bj[4];
-#pragma unroll
-    for (int q4 = 0; q4 < 4; q4++) {
-      bd[q4] = inf;
-      bj[q4] = 0x7fffffff;
-    }
-    for (int q = lane; q < st.K; q += 64) {  // (a lane's centroids ascend: strict < keeps its lowest index)
-      double dq[4];
-#pragma unroll
-      for (int q4 = 0; q4 < 4; q4++) {
-        const int h = h0 + q4 < n_open ? h0 + q4 : n_open - 1;
-        dq[q4] = gp((const double *)ah.hd)[(size_t)h * ah.kst + q];
-      }
-#pragma unroll
-      for (int q4 = 0; q4 < 4; q4++) {
-        const bool lt = dq[q4] < bd[q4];
-        bd[q4] = lt ? dq[q4] : bd[q4];
-        bj[q4] = lt ? q : bj[q4];
-      }
-    }
-#pragma unroll
-    for (int q4 = 0; q4 < 4; q4++) {
-      double d = bd[q4];
-      int jm = bj[q4];
-#pragma unroll
-      for (int off = 32; off >= 1; off >>= 1) {
-        const double d2 = __shfl_xor(d, off, 64);
-        const int j2 = __shfl_xor(jm, off, 64);
-        const bool take = (d2 < d) || (d2 == d && j2 < jm);
-        d = take ? d2 : d;
-        jm = take ? j2 : jm;
-      }
-      if (jm == 0x7fffffff) jm = 0;  // (no distance is a number: label 0 like the step-by-step rule)
-      if (h0 + q4 < n_open) {
-        const int rh = __shfl(r_open, h0 + q4, 64);
-        if (jm == j && lane == (rh >> 6)) w |= 1ull << (rh & 63);
-      }
-    }
-  }
-  // (iii-b) undecided rows: the first minimum among the entry's candidates, by the distances left behind
-  {
-    const int nt = n_und < AHEAD_TAB_CAP ? n_und : AHEAD_TAB_CAP;
-    for (int base = 0; base < nt; base += 64) {
-      if (base) {
-        ent = tab[base + lane];
-        td0 = td[3 * (base + lane)], td1 = td[3 * (base + lane) + 1], td2 = td[3 * (base + lane) + 2];
-      }
-      // ascending centroid index is not the entry's order: strictly smaller, or equal with the lower index, replaces
-      double bd = td0;
-      int bj = ent.y;
-      bool take = (td1 < bd) || (td1 == bd && ent.z < bj) || (bd != bd && td1 == td1);
-      bd = take ? td1 : bd;
-      bj = take ? ent.z : bj;
-      take = ent.w >= 0 && ((td2 < bd) || (td2 == bd && ent.w < bj) || (bd != bd && td2 == td2));
-      bd = take ? td2 : bd;
-      bj = take ? ent.w : bj;
-      unsigned long long mm = __ballot(base + lane < nt && bj == j);
-      while (mm) {
-        const int src = __builtin_ctzll(mm);
-        mm &= mm - 1;
-        const int rr = __shfl(ent.x, src, 64);
-        if (lane == (rr >> 6)) w |= 1ull << (rr & 63);
-      }
-    }
-  }
-  // (the rest is k_step_update; batches of a look-ahead block have at most 4096 rows: one block of bitmap words)
-  if (w0) mb[lane] = 0ull;
-  APF(3)
-  const bool weighted = st.wf != nullptr;
-  double acc[H];
-#pragma unroll
-  for (int h = 0; h < H; h++) acc[h] = c0[h] * cnt0;
-  double wsum = 0.0;
-  const int pc = __popcll(w);
-  int inc = pc;
-#pragma unroll
-  for (int off = 1; off < 64; off <<= 1) {
-    const int t = __shfl_up(inc, off, 64);
-    inc += lane >= off ? t : 0;
-  }
-  const int excl = inc - pc, blk = __shfl(inc, 63, 64);
-  APF(5)
-  for (int p0 = 0; p0 < blk; p0 += UPD_SC) {
-    {
-      unsigned long long t = w;
-      int idx = excl - p0;
-      while (t) {
-        const int bit = __builtin_ctzll(t);
-        t &= t - 1;
-        if (idx >= 0 && idx < UPD_SC) srow[idx] = (unsigned)(lane * 64 + bit);
-        idx++;
-      }
-    }
-    APF(6)
-    const int np = blk - p0 < UPD_SC ? blk - p0 : UPD_SC;
-    for (int m0 = 0; m0 < np; m0 += 16 / H) {  // (16 / H rows in flight: a quarter of k_step_update's, for the registers of the fused launch)
-      const int cm = np - m0 < 16 / H ? np - m0 : 16 / H;
-      if (weighted) {
-        if (lane < cm) {
-          const long long r = srow[m0 + lane];
-          swl[lane] = st.wf[st.rows ? (long long)st.rows[r] : r];
-        }
-        for (int q = 0; q < cm; q++) wsum = wsum + swl[q];
-      }
-      upd_add_listed<16 / H, H>(acc, Xg, ldg, srow + m0, swl, weighted, 0, cm, D, lane);
-    }
-  }
-  if (!weighted) wsum = (double)blk;
-  APF(4)
-#ifdef AHEAD_PROFILE
-  if (blockIdx.y == 0 && bx < 64 && threadIdx.x == 0) g_ahead_prof[bx][7] = (unsigned long long)blk | ((unsigned long long)n_open << 16) | ((unsigned long long)n_und << 32);
-#endif
-  const bool moved = blk > 0 && wsum > 0;  // (no member, or no weight: centre unchanged, pyx:87 / :105-108)
-  double *vb = (double *)list;
-  double a = csq0;
-  {
-    const double cnt1 = moved ? cnt0 + wsum : cnt0;
-    const double alpha = 1.0 / cnt1;
-    double v[H], dsq = 0.0;
-    GAS double *Bp_out = gp(ah.Bpack_out);
-#pragma unroll
-    for (int h = 0; h < H; h++) {
-      const int k = lane + 64 * h;
-      v[h] = moved ? acc[h] * alpha : c0[h];
-      if (k < D) {
-        C_out[(size_t)j * D + k] = v[h];
-        Bp_out[((size_t)(j >> 4) * KS + (k >> 2)) * 64 + (k & 3) * 16 + (j & 15)] = v[h];
-        const double t = v[h] - sn[h];
-        dsq += t * t;
-      }
-    }
-    if (lane == 0) gp(ah.counts_out)[j] = cnt1;
-    // (iv) how far this centroid now is from where the next step's labels were taken (any summation order: the factor covers
-    // it; NaN and inf stay what they are and fail the next step's check)
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) dsq += __shfl_xor(dsq, off, 64);
-    if (lane == 0 && dsq != 0.0) {
-      const double disp = __builtin_sqrt(dsq) * (1.0 + AHEAD_EPS);
-      __hip_atomic_fetch_max((GAS unsigned long long *)slot + (j & (AHEAD_SLOTS - 1)), (unsigned long long)__double_as_longlong(disp),
-                             __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-#pragma unroll
-    for (int h = 0; h < H; h++) vb[lane + 64 * h] = v[h];
-    if (moved) {
-      a = 0.0;
-      for (int k = 0; k + 1 < D; k += 2) {
-        const double2 t = *(const double2 *)&vb[k];
-        a = __builtin_fma(t.x, t.x, a);
-        a = __builtin_fma(t.y, t.y, a);
-      }
-      if (D & 1) a = __builtin_fma(vb[D - 1], vb[D - 1], a);
-    }
-    if (lane == 0) gp(ah.csq_out)[j] = a;
-  }
-  // (v) what the next step needs of this centroid as it now stands: lane = row, the contract's chain over ascending k --
-  // dot = fma(c_k, x_k, dot) from +0.0, what the matrix unit accumulates for this (row, centroid) pair in k_step_assign --
-  // then d = fma(-2, dot, csq)
-  auto evaluate = [&](int n_it) {
-    const int it = lane < n_it ? lane : 0;
-    const double *xs = hx + it * DPH;
-    double dot = 0.0;
-    for (int k = 0; k < D; k++) dot = __builtin_fma(vb[k], xs[k], dot);
-    const double dl = __builtin_fma(-2.0, dot, a);
-    if (lane < n_it) {
-      const int m = meta[2 * lane];
-      if (m < 0) gp(ah.nx_hd)[(size_t)(-1 - m) * ah.kst + j] = dl;
-      else gp(ah.nx_td)[m] = dl;
-    }
-  };
-  if (n_items) evaluate(n_items);
-  // what did not fit the first round: the rest of the next step's table, `cap` rows at a time
-  for (int base = nt_done; base < n_nt; base += 64) {
-    const v4i32 e = ntab[base + lane];
-    const int slot = (base + lane < n_nt) ? (e.y == j ? 0 : (e.z == j ? 1 : (e.w == j ? 2 : -1))) : -1;
-    unsigned long long mm = __ballot(slot >= 0);
-    while (mm) {
-      // the first `cap` of the entries still open
-      unsigned long long take = 0;
-      int got = 0;
-      unsigned long long t = mm;
-      while (t && got < cap && got < AHEAD_ITEMS) {
-        take |= t & (~t + 1);
-        t &= t - 1;
-        got++;
-      }
-      mm &= ~take;
-      const bool in = (take >> lane) & 1;
-      const int rank = __popcll(take & ((1ull << lane) - 1));
-      if (in) {
-        meta[2 * rank] = 3 * (base + lane) + slot;
-        meta[2 * rank + 1] = e.x;
-      }
-      const int rows_l = lane < got ? meta[2 * lane + 1] : 0;
-      stage(rows_l, got, 0);
-      evaluate(got);
-    }
-  }
-}
-
-// one launch of the pipeline: blockIdx.y < n_m -> the M-step of a step whose labels are complete (descriptors by value);
-// the other rows of the grid -> E-steps of later steps (descriptors in memory), against tables no M-step of this launch writes
-template <typename XT, int KS, int JB, int H, int RT>
-__global__ __launch_bounds__(256, 3) void k_step_pipe(const StepPack pk, const AheadPack ap, int n_m, const StepDev *__restrict__ steps,
-                                                   const AheadDev *__restrict__ aheads, const int *__restrict__ ylist, int64_t ldx,
-                                                   int D, double ratio) {
-  extern __shared__ int lds_i[];
-  if ((int)blockIdx.y < n_m) {
-    // (copies: every field is fetched from the kernel-argument segment at once, not where it is first used)
-    const StepDev sd_ = pk.s[blockIdx.y];
-    const AheadDev ah_ = ap.a[blockIdx.y];
-    ahead_update<XT, H>(sd_, ah_, blockIdx.x, ldx, D, KS, ratio, lds_i);
-  } else {
-    ahead_assign<XT, KS, JB, RT>(steps, aheads, ((const GAS int *)ylist)[blockIdx.y - n_m], blockIdx.x, ldx, D);
-  }
-}
 
 // block-wide reductions over 256 threads (4 waves); every thread gets the result
 __device__ __forceinline__ double block_max_f64(double v, double *sh /*[4]*/) {
@@ -2943,659 +2079,12 @@ __global__ __launch_bounds__(256) void k_step_update_generic(const StepDev *__re
   }
 }
 
-// ===================================================================================================
-// Persistent training pass: every step of every stratum in ONE launch.
-//
-// A stratum's chain of partial_fits is a strict sequence E-step -> M-step -> E-step ...: all rows need all centroids, every
-// centroid needs all its member rows.  As separate kernels each hand-off costs a kernel boundary plus the start and the
-// drain of a grid (~4 us of each ~8 us kernel).  Here the workgroups that landed on one XCD serve one stratum for its
-// whole chain: they share that XCD's L2, so the two hand-offs per step are an XCD-LOCAL barrier -- stores drained to L2
-// (the vector L1 is write-through), one atomic on a counter, one polling lane, and every load of handed-off bytes a
-// `global_load ... sc1` (bypasses the reader's L1, served by the shared L2).  No L2 write-back / invalidate (the
-// agent-scope fences cost 1.7 us each) is needed, because no other XCD ever reads these bytes inside the launch.
-//
-// Placement is not assumed: a workgroup reads its XCD from the hardware register, registers there (rank within the XCD),
-// one chip-wide arrival count closes the registration, and strata are dealt over the XCDs that actually received
-// workgroups (an XCD serves several strata one chain after the other when there are more strata than populated XCDs).
-// Every spin is bounded by the 100 MHz wall clock; a timeout sets `ctl->err` and the workgroup leaves (1 = during
-// registration, nothing has been modified and the host takes the multi-kernel path; 2 = inside a chain: an error).
-//
-// Arithmetic, orders and the stop protocol are those of k_step_assign / k_step_update / k_step_reassign / k_step_check
-// above (same descriptors, same report / halt / reason words): results are bit-identical to that path and to the oracle.
-#ifndef PERSIST_ATOMIC_SCOPE
-// Atomics on words shared by the workgroups of ONE XCD are performed in that XCD's L2 at workgroup scope (at agent scope
-// they travel beyond the L2s: ~2x the latency).  -DPERSIST_ATOMIC_SCOPE=__HIP_MEMORY_SCOPE_AGENT builds the conservative form.
-#define PERSIST_ATOMIC_SCOPE __HIP_MEMORY_SCOPE_WORKGROUP
+#ifdef HAMSM_EXPERIMENTS
+#include "experiments/train_ahead.inc"
+#include "experiments/train_ranked.inc"
+#include "experiments/train_persist.inc"
 #endif
-struct PersistCtl {     // zeroed by one hipMemsetAsync before every launch
-  unsigned arrive_all;  // registration: workgroups that have registered
-  unsigned err;         // 0, 1 = registration timed out, 2 = a barrier timed out
-  unsigned nwg_xcd[8];  // workgroups per XCD
-  unsigned pad[6];
-  unsigned bar[];       // [S] one monotonic arrival counter per stratum
-};
 
-template <typename T>
-__device__ __forceinline__ T ld_l2(const GAS T *p) {  // global_load ... sc1: never served by this CU's L1
-  if constexpr (sizeof(T) == 8) {
-    unsigned long long v = __hip_atomic_load((const GAS unsigned long long *)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    return __builtin_bit_cast(T, v);
-  } else {
-    static_assert(sizeof(T) == 4, "ld_l2: 4 or 8 bytes");
-    unsigned v = __hip_atomic_load((const GAS unsigned *)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    return __builtin_bit_cast(T, v);
-  }
-}
-
-#define PERSIST_TMO_REG 2000000ull    // 20 ms of 100 MHz ticks: every workgroup of the grid resident and registered
-#define PERSIST_TMO_BAR 30000000ull   // 300 ms per barrier (a phase takes microseconds)
-
-// XCD-local barrier among the W workgroups that serve one stratum.  `sh_ok` is an LDS word of the caller.
-__device__ __forceinline__ bool xcd_barrier(GAS unsigned *bar, unsigned target, GAS unsigned *err, int *sh_ok) {
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every wave: its stores and atomics have reached the L2
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    __hip_atomic_fetch_add(bar, 1u, __ATOMIC_RELAXED, PERSIST_ATOMIC_SCOPE);
-    int ok = 1;
-    const unsigned long long t0 = wall_clock64();
-    while ((int)(ld_l2(bar) - target) < 0) {
-      __builtin_amdgcn_s_sleep(1);
-      if (wall_clock64() - t0 > PERSIST_TMO_BAR || ld_l2(err) != 0u) {
-        __hip_atomic_store(err, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        ok = 0;
-        break;
-      }
-    }
-    *sh_ok = ok;
-  }
-  __syncthreads();
-  asm volatile("" ::: "memory");
-  return *sh_ok != 0;
-}
-
-// The phases are separate (non-inlined) functions: each keeps only its own operands live (as one body the kernel needed more
-// than 256 VGPRs).  LDS scratch is handed in by the kernel.
-struct PersistLds {
-  double sd[4][32];
-  int sj[4][32];
-  double shd[4];
-  int shi[4];
-  int lj[256], lr[256];
-  int sh_i[16];
-};
-
-// low-count test of the stratum's previous step / zero-count test before this one -- workgroup 0 of k_step_assign
-__device__ __attribute__((noinline)) void persist_precheck(const StepDev *sp, double ratio, PersistLds *L) {
-  const StepDev &sdesc = *sp;
-  const StepG st(sdesc);
-  const int tid = threadIdx.x;
-  const double inf = __builtin_huge_val();
-  GAS int32_t *halt = gp(sdesc.halt);
-  const GAS int32_t *prev = gp(sdesc.prev_report);
-  int z = 0;
-  double mx = -inf;
-  for (int j = tid; j < st.K; j += 256) {
-    double cj = ld_l2(st.counts + j);
-    z |= (cj == 0.0);
-    mx = cj > mx ? cj : mx;
-  }
-  int any_low = 0;
-  if (st.flags & 4) {
-    mx = block_max_f64(mx, L->shd);
-    const double thr = ratio * mx;
-    int low = 0;
-    for (int j = tid; j < st.K; j += 256) low += ld_l2(st.counts + j) < thr;
-    if (low) __hip_atomic_fetch_add((GAS int32_t *)prev + 1, low, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    any_low = __syncthreads_or(low);
-  }
-  const int any_z = __syncthreads_or((st.flags & 2) ? z : 0);
-  if (tid == 0) {
-    if (any_low) {
-      *halt = st.idx;
-      *gp(sdesc.reason) = HAMSM_STOP_LOW;
-    } else if (any_z) {
-      st.report[0] = 1;
-      *halt = st.idx;
-      *gp(sdesc.reason) = HAMSM_STOP_ZERO;
-    }
-  }
-}
-
-// The batch rows are static data: the rows a workgroup will need for the stratum's NEXT step are requested while the
-// current step's M-step runs and parked in an LDS slab (PF_TILES tiles of 16 rows, row stride 4 KS + 1 elements), so that
-// the E-step starts from LDS instead of two dependent global round trips (row index -> row).  Workgroup `erank` of `We`
-// owns the tiles erank, erank + We, ...; tiles beyond the slab (fewer workgroups on this XCD than expected) are loaded
-// directly.  Slots past D hold the row's last feature and rows past the batch its last row, as k_step_assign reads them.
-#define PF_TILES 4
-#ifdef PERSIST_FINE
-__device__ unsigned long long g_persist_fine[16];
-extern "C" int hamsm_debug_persist_fine(unsigned long long *h_out) {
-  if (hipMemcpyFromSymbol(h_out, HIP_SYMBOL(g_persist_fine), sizeof(unsigned long long) * 16) != hipSuccess) return -1;
-  unsigned long long z[16] = {0};
-  hipMemcpyToSymbol(HIP_SYMBOL(g_persist_fine), z, sizeof z);
-  return 0;
-}
-#define FSTAMP_INIT unsigned long long f_last = wall_clock64();
-#define FSTAMP(slot, cond)                                                \
-  {                                                                       \
-    __builtin_amdgcn_s_waitcnt(0);                                        \
-    if ((cond) && threadIdx.x == 0) {                                     \
-      const unsigned long long n_ = wall_clock64();                       \
-      atomicAdd(&g_persist_fine[slot], n_ - f_last);                      \
-      f_last = n_;                                                        \
-    }                                                                     \
-  }
-#else
-#define FSTAMP_INIT
-#define FSTAMP(slot, cond)
-#endif
-template <typename XT, int KS>
-__device__ __forceinline__ void persist_pf_issue(const StepDev *sp, int erank, int We, int64_t ldx, int D, XT (&pf)[KS]) {
-  // thread t: slab row t / 4 (tile t / 64, row (t / 4) % 16), elements (t % 4) + 4 m
-  const int tid = threadIdx.x, srow = tid >> 2;
-  const long long n_b = sp->n_b;
-  const long long tile = (long long)erank + (long long)We * (srow >> 4);
-  long long r = tile * 16 + (srow & 15);
-  r = r < n_b ? r : n_b - 1;
-  r = r < 0 ? 0 : r;
-  const GAS int32_t *rows = gp(sp->rows);
-  const long long f = rows ? (long long)rows[r] : r;
-  const GAS XT *X = (const GAS XT *)gp((const XT *)sp->X);
-#pragma unroll
-  for (int m = 0; m < KS; m++) {
-    const int k = (tid & 3) + 4 * m;
-    pf[m] = X[f * ldx + (k < D ? k : D - 1)];
-  }
-}
-template <typename XT, int KS>
-__device__ __forceinline__ void persist_pf_store(XT *xa, const XT (&pf)[KS]) {
-  const int tid = threadIdx.x, srow = tid >> 2;
-#pragma unroll
-  for (int m = 0; m < KS; m++) xa[srow * (4 * KS + 1) + (tid & 3) + 4 * m] = pf[m];
-}
-
-// E-step: the row tiles erank, erank + We, ... of the step (16 rows each), RT at a time -- the arithmetic of k_step_assign
-template <typename XT, int KS, int JB, int RT>
-__device__ __attribute__((noinline)) void persist_estep(const StepDev *sp, int erank, int We, int64_t ldx, int D, PersistLds *L,
-                                                        const XT *xa) {
-  constexpr int RW = 16 * RT;
-  static_assert(RW <= 32, "PersistLds::sd holds 32 rows");
-  static_assert(PF_TILES % RT == 0, "a pass never straddles the slab's end");
-  const StepDev &sdesc = *sp;
-  const StepG st(sdesc);
-  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-  const double inf = __builtin_huge_val();
-  const GAS XT *X = (const GAS XT *)st.X;
-  const int njt = (st.K + 15) >> 4;
-  const long long ntile = (st.n_b + 15) >> 4;
-  double b[JB][KS], cs[JB][4];
-  auto load_group = [&](int t0) {
-#pragma unroll
-    for (int u = 0; u < JB; u++) {
-      const int jt = t0 + 4 * u < njt ? t0 + 4 * u : njt - 1;
-#pragma unroll
-      for (int q = 0; q < 4; q++) cs[u][q] = ld_l2(st.csq + jt * 16 + (lane >> 4) + 4 * q);
-#pragma unroll
-      for (int ks = 0; ks < KS; ks++) b[u][ks] = ld_l2(st.Bpack + ((size_t)jt * KS + ks) * 64 + lane);
-    }
-  };
-  const bool one_group = njt <= 4 * JB;  // the stratum's operands stay in registers for all of the workgroup's tiles
-  FSTAMP_INIT
-  if (one_group) load_group(wv);
-  FSTAMP(0, erank == 0)
-  // pass p covers this workgroup's tiles number p RT .. p RT + RT - 1 (tile number q = tile erank + q We)
-  for (int q0 = 0; (long long)erank + (long long)We * q0 < ntile; q0 += RT) {
-    long long tile[RT];
-#pragma unroll
-    for (int rt = 0; rt < RT; rt++) tile[rt] = (long long)erank + (long long)We * (q0 + rt);
-    double a[RT][KS];
-    if (q0 < PF_TILES) {
-#pragma unroll
-      for (int rt = 0; rt < RT; rt++)
-#pragma unroll
-        for (int ks = 0; ks < KS; ks++) a[rt][ks] = (double)xa[((q0 + rt) * 16 + (lane & 15)) * (4 * KS + 1) + ks * 4 + (lane >> 4)];
-    } else {
-      long long f[RT];
-#pragma unroll
-      for (int rt = 0; rt < RT; rt++) {
-        const long long r = tile[rt] * 16 + (lane & 15);
-        const long long rc = r < st.n_b ? r : st.n_b - 1;
-        f[rt] = st.rows ? (long long)st.rows[rc] : rc;
-      }
-#pragma unroll
-      for (int rt = 0; rt < RT; rt++)
-#pragma unroll
-        for (int ks = 0; ks < KS; ks++) {
-          const int k = ks * 4 + (lane >> 4);
-          a[rt][ks] = (double)X[f[rt] * ldx + (k < D ? k : D - 1)];
-        }
-    }
-    double bd[RT];
-    int bi[RT];
-#pragma unroll
-    for (int rt = 0; rt < RT; rt++) {
-      bd[rt] = inf;
-      bi[rt] = 0x7fffffff;
-    }
-    FSTAMP(1, erank == 0)
-    for (int t0 = wv; t0 < njt; t0 += 4 * JB) {
-      if (!one_group) load_group(t0);
-#pragma unroll
-      for (int u = 0; u < JB; u++) {
-        const int jt = t0 + 4 * u;
-        if (jt < njt) {
-          v4f64 acc[RT];
-#pragma unroll
-          for (int rt = 0; rt < RT; rt++) acc[rt] = (v4f64){0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-          for (int ks = 0; ks < KS; ks++)
-#pragma unroll
-            for (int rt = 0; rt < RT; rt++) acc[rt] = __builtin_amdgcn_mfma_f64_16x16x4f64(b[u][ks], a[rt][ks], acc[rt], 0, 0, 0);
-          const int j0 = jt * 16 + (lane >> 4);
-#pragma unroll
-          for (int rt = 0; rt < RT; rt++)
-#pragma unroll
-            for (int q = 0; q < 4; q++) {
-              double d = __builtin_fma(-2.0, acc[rt][q], cs[u][q]);
-              bool lt = d < bd[rt];
-              bd[rt] = lt ? d : bd[rt];
-              bi[rt] = lt ? j0 + 4 * q : bi[rt];
-            }
-        }
-      }
-    }
-    FSTAMP(2, erank == 0)
-    // the batch rows as f64 for the M-step (rows of 4 KS doubles; the buffer is padded to 64-row multiples)
-#pragma unroll
-    for (int rt = 0; rt < RT; rt++)
-      if (((rt + 1) & 3) == wv && tile[rt] < ((st.n_b + 63) >> 6) * 4) {
-        const long long r = tile[rt] * 16 + (lane & 15);
-#pragma unroll
-        for (int ks = 0; ks < KS; ks++) st.Xg[(size_t)r * (4 * KS) + ks * 4 + (lane >> 4)] = a[rt][ks];
-      }
-#pragma unroll
-    for (int rt = 0; rt < RT; rt++) {
-      double d = bd[rt];
-      int j = bi[rt];
-#pragma unroll
-      for (int off = 16; off <= 32; off <<= 1) {
-        double d2 = __shfl_xor(d, off, 64);
-        int j2 = __shfl_xor(j, off, 64);
-        bool take = (d2 < d) || (d2 == d && j2 < j);
-        d = take ? d2 : d;
-        j = take ? j2 : j;
-      }
-      if (lane < 16) {
-        L->sd[wv][rt * 16 + lane] = d;
-        L->sj[wv][rt * 16 + lane] = j;
-      }
-    }
-    __syncthreads();
-    if (tid < RW) {
-      const long long r = ((long long)erank + (long long)We * (q0 + (tid >> 4))) * 16 + (tid & 15);
-      if (r < st.n_b) {
-        double d = L->sd[0][tid];
-        int j = L->sj[0][tid];
-#pragma unroll
-        for (int w = 1; w < 4; w++) {
-          double d2 = L->sd[w][tid];
-          int j2 = L->sj[w][tid];
-          bool take = (d2 < d) || (d2 == d && j2 < j);
-          d = take ? d2 : d;
-          j = take ? j2 : j;
-        }
-        if (j == 0x7fffffff) j = 0;
-        st.labels[r] = j;
-        __hip_atomic_fetch_or(&st.mbits[(size_t)j * sdesc.wstride + (r >> 6)], 1ull << (r & 63), __ATOMIC_RELAXED,
-                              PERSIST_ATOMIC_SCOPE);
-      }
-    }
-    __syncthreads();  // sd / sj are reused by the next pass
-    FSTAMP(3, erank == 0)
-  }
-}
-
-// M-step: one wave per centroid (rank * 4 + wave, + 4 W, ...) -- the arithmetic of k_step_update<H = 1>
-template <typename XT, int KS>
-__device__ __attribute__((noinline)) void persist_mstep(const StepDev *sp, int rank, int W, int D, int *lds_i, const StepDev *sp_next,
-                                                        int erank, int We, int64_t ldx, XT *xa) {
-  const StepDev &sdesc = *sp;
-  const StepG st(sdesc);
-  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  // the next step's rows of this workgroup: requested now, parked in the slab when this M-step is done (the E-step that
-  // read the slab finished before the barrier in front of this call)
-  XT pf[KS];
-  FSTAMP_INIT
-  if (sp_next) persist_pf_issue<XT, KS>(sp_next, erank, We, ldx, D, pf);
-  FSTAMP(4, rank == 0)
-  int *list = lds_i + wv * UPD_LIST;
-  unsigned *srow = (unsigned *)list;
-  double *swl = (double *)(list + UPD_SC);
-  const GAS double *Xg = st.Xg;
-  const int ldg = 4 * KS;
-  const int nw = (int)((st.n_b + 63) >> 6);
-  const bool weighted = st.wf != nullptr;
-  const int kq = lane < D ? lane : D - 1;
-  for (int j = rank * 4 + wv; j < st.K; j += 4 * W) {
-    GAS unsigned long long *mb = st.mbits + (size_t)j * sdesc.wstride;
-    const double cnt0 = ld_l2(st.counts + j);
-    double acc = ld_l2(st.C + (size_t)j * D + kq) * cnt0;  // (KS <= 16: D <= 64, one feature per lane)
-    double wsum = 0.0;
-    long long total = 0;
-    for (int wb = 0; wb < nw; wb += 64) {
-      // read and clear in one: the word is ready for the stratum's next step (wstride is a multiple of 64)
-      const unsigned long long w = __hip_atomic_exchange(mb + wb + lane, 0ull, __ATOMIC_RELAXED, PERSIST_ATOMIC_SCOPE);
-      FSTAMP(5, rank == 0)
-      const int pc = __popcll(w);
-      int inc = pc;
-#pragma unroll
-      for (int off = 1; off < 64; off <<= 1) {
-        const int t = __shfl_up(inc, off, 64);
-        inc += lane >= off ? t : 0;
-      }
-      const int excl = inc - pc, blk = __shfl(inc, 63, 64);
-      for (int p0 = 0; p0 < blk; p0 += UPD_SC) {
-        {
-          unsigned long long t = w;
-          int idx = excl - p0;
-          while (t) {
-            const int bit = __builtin_ctzll(t);
-            t &= t - 1;
-            if (idx >= 0 && idx < UPD_SC) srow[idx] = (unsigned)((wb + lane) * 64 + bit);
-            idx++;
-          }
-        }
-        const int np = blk - p0 < UPD_SC ? blk - p0 : UPD_SC;
-        for (int m0 = 0; m0 < np; m0 += 64) {
-          const int cm = np - m0 < 64 ? np - m0 : 64;
-          if (weighted) {
-            if (lane < cm) {
-              const long long r = srow[m0 + lane];
-              swl[lane] = st.wf[st.rows ? (long long)st.rows[r] : r];
-            }
-            for (int q = 0; q < cm; q++) wsum = wsum + swl[q];
-          }
-          // member rows: up to 32 requested before the first add, added in sample order
-          for (int q0 = 0; q0 < cm; q0 += 32) {
-            double xv[32];
-#pragma unroll
-            for (int q = 0; q < 32; q++) {
-              const int mq = q0 + q < cm ? q0 + q : cm - 1;
-              xv[q] = ld_l2(Xg + (size_t)srow[m0 + mq] * ldg + kq);
-            }
-#pragma unroll
-            for (int q = 0; q < 32; q++) {
-              const int mq = q0 + q < cm ? q0 + q : cm - 1;
-              const double wq = weighted ? swl[mq] : 1.0;
-              const double nv = acc + xv[q] * wq;
-              acc = (q0 + q < cm) ? nv : acc;
-            }
-          }
-        }
-      }
-      total += blk;
-    }
-    FSTAMP(6, rank == 0)
-    if (total == 0) continue;
-    if (!weighted) wsum = (double)total;
-    if (!(wsum > 0)) continue;
-    const double cnt1 = cnt0 + wsum;
-    const double alpha = 1.0 / cnt1;
-    const double v = acc * alpha;
-    if (lane < D) {
-      st.C[(size_t)j * D + lane] = v;
-      st.Bpack[((size_t)(j >> 4) * KS + (lane >> 2)) * 64 + (lane & 3) * 16 + (j & 15)] = v;
-    }
-    if (lane == 0) st.counts[j] = cnt1;
-    double *vb = (double *)list;
-    vb[lane] = lane < D ? v : 0.0;
-    double a2 = 0.0;
-    for (int k = 0; k + 1 < D; k += 2) {
-      const double2 t = *(const double2 *)&vb[k];
-      a2 = __builtin_fma(t.x, t.x, a2);
-      a2 = __builtin_fma(t.y, t.y, a2);
-    }
-    if (D & 1) a2 = __builtin_fma(vb[D - 1], vb[D - 1], a2);
-    if (lane == 0) st.csq[j] = a2;
-    FSTAMP(7, rank == 0)
-  }
-  if (sp_next) persist_pf_store<XT, KS>(xa, pf);
-  FSTAMP(8, rank == 0)
-}
-
-// re-seeding of low-count centroids from the permutation head the step carries -- k_step_reassign (one workgroup)
-template <typename XT, int KS>
-__device__ __attribute__((noinline)) void persist_reassign(const StepDev *sp, int64_t ldx, int D, double ratio, PersistLds *L) {
-  const StepDev &sdesc = *sp;
-  const StepG st(sdesc);
-  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-  const double inf = __builtin_huge_val();
-  const GAS XT *X = (const GAS XT *)st.X;
-  double mx = -inf;
-  for (int j = tid; j < st.K; j += 256) {
-    const double cj = ld_l2(st.counts + j);
-    mx = cj > mx ? cj : mx;
-  }
-  mx = block_max_f64(mx, L->shd);
-  const double thr = ratio * mx;
-  int low = 0;
-  double mn = -inf;
-  for (int j = tid; j < st.K; j += 256) {
-    const double cj = ld_l2(st.counts + j);
-    if (cj < thr) low++;
-    else mn = -cj > mn ? -cj : mn;
-  }
-  low = block_sum_i32(low, L->shi);
-  const double new_count = -block_max_f64(mn, L->shd);
-  if (tid == 0) st.report[1] = low;
-  int why = 0;
-  if (low == 0) why = HAMSM_STOP_UNUSED;
-  else if (low > sdesc.n_perm || (double)low > 0.5 * (double)st.n_b) why = HAMSM_STOP_CAP;
-  if (why) {
-    if (tid == 0) {
-      *gp(sdesc.halt) = st.idx + 1;
-      *gp(sdesc.reason) = why;
-    }
-    return;
-  }
-  const GAS int32_t *perm = gp(sdesc.perm);
-  int base = 0;
-  for (int j0 = 0; j0 < st.K; j0 += 256) {
-    const int j = j0 + tid;
-    const bool flag = j < st.K && ld_l2(st.counts + (j < st.K ? j : 0)) < thr;
-    const unsigned long long bal = __ballot(flag);
-    const int in_wave = __popcll(bal & ((1ull << lane) - 1));
-    __syncthreads();
-    if (lane == 0) L->shi[wv] = __popcll(bal);
-    __syncthreads();
-    int before = 0, total = 0;
-#pragma unroll
-    for (int w = 0; w < 4; w++) {
-      before += w < wv ? L->shi[w] : 0;
-      total += L->shi[w];
-    }
-    if (flag) {
-      const int e = before + in_wave;
-      L->lj[e] = j;
-      L->lr[e] = perm[base + e];
-    }
-    __syncthreads();
-    for (int e = wv; e < total; e += 4) {
-      const int jc = L->lj[e];
-      const long long r = L->lr[e];
-      const long long fr = st.rows ? (long long)st.rows[r] : r;
-      const double v = (lane < D) ? (double)X[fr * ldx + lane] : 0.0;
-      if (lane < D) {
-        st.C[(size_t)jc * D + lane] = v;
-        st.Bpack[((size_t)(jc >> 4) * KS + (lane >> 2)) * 64 + (lane & 3) * 16 + (jc & 15)] = v;
-      }
-      double a2 = 0.0;
-      for (int k = 0; k < D; k++) {
-        const double vk = readlane_f64(v, k);
-        a2 = __builtin_fma(vk, vk, a2);
-      }
-      if (lane == 0) {
-        st.csq[jc] = a2;
-        st.counts[jc] = new_count;
-      }
-    }
-    base += total;
-    __syncthreads();
-  }
-}
-
-// low-count test of a chain's LAST step when no permutation came with it -- k_step_check
-__device__ __attribute__((noinline)) void persist_tailcheck(const StepDev *sp, double ratio, int n_steps, PersistLds *L) {
-  const StepDev &sdesc = *sp;
-  const StepG st(sdesc);
-  const int tid = threadIdx.x;
-  double mx = -__builtin_huge_val();
-  for (int j = tid; j < st.K; j += 256) {
-    const double cj = ld_l2(st.counts + j);
-    mx = cj > mx ? cj : mx;
-  }
-  mx = block_max_f64(mx, L->shd);
-  const double thr = ratio * mx;
-  int low = 0;
-  for (int j = tid; j < st.K; j += 256) low += ld_l2(st.counts + j) < thr;
-  low = block_sum_i32(low, L->shi);
-  if (tid == 0 && low) {
-    st.report[1] = low;
-    *gp(sdesc.halt) = n_steps;
-    *gp(sdesc.reason) = HAMSM_STOP_LOW;
-  }
-}
-
-// phase timers of the persistent pass (HAMSM_PERSIST_PROF=1): 100 MHz ticks summed over the steps, as seen by thread 0 of
-// every workgroup with rank 0 (one per stratum): [0] tests, [1] E-step, [2] wait at barrier A, [3] M-step, [4] re-seeding,
-// [5] wait at barrier B, [6] steps, [7] whole chain
-__device__ unsigned long long g_persist_prof[8];
-extern "C" int hamsm_debug_persist_profile(unsigned long long *h_out, int reset) {
-  if (hipMemcpyFromSymbol(h_out, HIP_SYMBOL(g_persist_prof), sizeof(unsigned long long) * 8) != hipSuccess) return -1;
-  if (reset) {
-    unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    if (hipMemcpyToSymbol(HIP_SYMBOL(g_persist_prof), z, sizeof z) != hipSuccess) return -1;
-  }
-  return 0;
-}
-#define PPROF(slot)                                                              \
-  if (prof && rank == 0 && tid == 0) {                                           \
-    const unsigned long long now_ = wall_clock64();                              \
-    atomicAdd(&g_persist_prof[slot], now_ - t_last);                             \
-    t_last = now_;                                                               \
-  }
-
-template <typename XT, int KS, int JB>
-__global__ __launch_bounds__(256, 2) void k_train_persist(const StepDev *__restrict__ steps, const int *__restrict__ chain_off,
-                                                          const int *__restrict__ chain_idx, PersistCtl *ctl_, int S,
-                                                          int64_t ldx, int D, double ratio, int n_steps, int prof) {
-  constexpr int RT = 2;  // row tiles in flight per workgroup pass
-  const int tid = threadIdx.x;
-  GAS PersistCtl *ctl = (GAS PersistCtl *)ctl_;
-  GAS unsigned *err = &ctl->err;
-  __shared__ PersistLds L;
-  extern __shared__ int lds_i[];  // M-step strips: 4 x UPD_LIST ints
-
-  // ---- registration ---------------------------------------------------------------------------------
-  unsigned xcc;
-  asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-  xcc &= 7;
-  if (tid == 0) {
-    // (agent scope: every XCD must see these)
-    L.sh_i[0] = (int)__hip_atomic_fetch_add(&ctl->nwg_xcd[xcc], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __hip_atomic_fetch_add(&ctl->arrive_all, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    int ok = 1;
-    const unsigned long long t0 = wall_clock64();
-    while (ld_l2(&ctl->arrive_all) < gridDim.x) {
-      __builtin_amdgcn_s_sleep(2);
-      if (wall_clock64() - t0 > PERSIST_TMO_REG || ld_l2(err) != 0u) {
-        __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        ok = 0;
-        break;
-      }
-    }
-    L.sh_i[1] = ok;
-    int n_act = 0, mine = -1;
-    for (int x = 0; x < 8; x++) {
-      const unsigned nx = ld_l2(&ctl->nwg_xcd[x]);
-      if (x == (int)xcc) {
-        mine = n_act;
-        L.sh_i[2] = (int)nx;
-      }
-      n_act += nx > 0;
-    }
-    L.sh_i[3] = n_act;
-    L.sh_i[4] = mine;
-  }
-  __syncthreads();
-  if (!L.sh_i[1]) return;
-  const int rank = L.sh_i[0], W = L.sh_i[2], n_act = L.sh_i[3], a_idx = L.sh_i[4];
-  __syncthreads();
-
-  // workgroup W - 1 of an XCD runs the tests that ride on a step (they need the counts the previous M-step left: 2 us of
-  // dependent reductions) instead of row tiles; the tiles are dealt over the other W - 1
-  const int We = W > 1 ? W - 1 : 1, erank = rank < We ? rank : -1;
-  const bool tester = rank == W - 1;
-  XT *xa = (XT *)(lds_i + 4 * UPD_LIST);  // [PF_TILES * 16][4 KS + 1]
-  for (int s = a_idx; s < S; s += n_act) {
-    GAS unsigned *bar = &ctl->bar[s];
-    unsigned epoch = 0;
-    const int c0 = chain_off[s], c1 = chain_off[s + 1];
-    int last_ci = -1;
-    bool stopped = false;
-    unsigned long long t_last = wall_clock64();
-    const unsigned long long t_chain = t_last;
-    // first step of the chain with rows: its slab is filled here
-    int ci = c0;
-    while (ci < c1 && steps[__builtin_amdgcn_readfirstlane(chain_idx[ci])].n_b <= 0) ci++;
-    if (ci < c1 && erank >= 0) {
-      XT pf[KS];
-      persist_pf_issue<XT, KS>(steps + __builtin_amdgcn_readfirstlane(chain_idx[ci]), erank, We, ldx, D, pf);
-      persist_pf_store<XT, KS>(xa, pf);
-    }
-    __syncthreads();
-    for (; ci < c1;) {
-      const StepDev *sp = steps + __builtin_amdgcn_readfirstlane(chain_idx[ci]);  // static, uniform: scalar loads
-      int cn = ci + 1;  // the stratum's next step with rows (the multi-kernel path launches nothing for empty ones either)
-      while (cn < c1 && steps[__builtin_amdgcn_readfirstlane(chain_idx[cn])].n_b <= 0) cn++;
-      const StepDev *sp_next = cn < c1 ? steps + __builtin_amdgcn_readfirstlane(chain_idx[cn]) : nullptr;
-      last_ci = ci;
-      ci = cn;
-      GAS int32_t *halt = gp(sp->halt);
-      const int idx = sp->idx, flags = sp->flags;
-      // the tests that ride on the step (the counts are final since the previous step's barrier) beside the E-step
-      if (tester && (flags & 6) && idx < ld_l2(halt)) persist_precheck(sp, ratio, &L);
-      PPROF(0)
-      if (erank >= 0) persist_estep<XT, KS, JB, RT>(sp, erank, We, ldx, D, &L, xa);
-      PPROF(1)
-      if (!xcd_barrier(bar, (unsigned)W * ++epoch, err, &L.sh_i[8])) return;
-      PPROF(2)
-      // the stratum's chain stops here when a test said so: every workgroup reads the same word in the same window
-      // (nobody writes it between this barrier and the next)
-      if (idx >= ld_l2(halt)) {
-        stopped = true;
-        break;
-      }
-      persist_mstep<XT, KS>(sp, rank, W, D, lds_i, erank >= 0 ? sp_next : nullptr, erank, We, ldx, xa);
-      PPROF(3)
-      if ((flags & 1) && sp->perm) {
-        if (!xcd_barrier(bar, (unsigned)W * ++epoch, err, &L.sh_i[8])) return;
-        if (rank == 0 && idx < ld_l2(halt)) persist_reassign<XT, KS>(sp, ldx, D, ratio, &L);
-        PPROF(4)
-      }
-      if (!xcd_barrier(bar, (unsigned)W * ++epoch, err, &L.sh_i[8])) return;
-      PPROF(5)
-      if (prof && rank == 0 && tid == 0) atomicAdd(&g_persist_prof[6], 1ull);
-    }
-    if (prof && rank == 0 && tid == 0) atomicAdd(&g_persist_prof[7], wall_clock64() - t_chain);
-    if (!stopped && last_ci >= 0 && rank == 0) {
-      const StepDev *sp = steps + __builtin_amdgcn_readfirstlane(chain_idx[last_ci]);
-      if ((sp->flags & 1) && !sp->perm && sp->idx < ld_l2(gp(sp->halt))) persist_tailcheck(sp, ratio, n_steps, &L);
-    }
-    __syncthreads();
-  }
-}
 
 template <typename XT, int KS, int RT, bool BYVAL>
 static void launch_step_kernels(hamsm_ctx *c, hipStream_t q, const StepDev *d_steps, const StepPack &pk, int ny,
@@ -3604,7 +2093,7 @@ static void launch_step_kernels(hamsm_ctx *c, hipStream_t q, const StepDev *d_st
   dim3 ga((unsigned)((max_nb + 16 * RT - 1) / (16 * RT)), (unsigned)ny);
   // every 128th launch group of the context's own queue is sampled: events around the E-step and the M-step launch, and the
   // E-step's own first-wave-in / last-wave-out stamps (slots prepared in bulk by hamsm_step_kernel_ms(reset))
-  const bool sample = q == c->stream && !c->capturing && c->ks_stamps && (c->ks_tick++ & 127) == 0 && c->ks_pending.size() < HAMSM_KS_SLOTS;
+  const bool sample = q == c->stream && !HAMSM_CAPTURING(c) && c->ks_stamps && (c->ks_tick++ & 127) == 0 && c->ks_pending.size() < HAMSM_KS_SLOTS;
   hamsm_ctx::KSample ks{nullptr, nullptr, nullptr};
   unsigned long long *stamp = nullptr;
   if (sample) {
@@ -3643,16 +2132,6 @@ static void launch_step_kernels(hamsm_ctx *c, hipStream_t q, const StepDev *d_st
     hipLaunchKernelGGL((k_step_reassign<XT, BYVAL>), dim3((unsigned)ny), dim3(256), 0, q, d_steps, pk, ldx, c->D, c->KS, ratio);
 }
 
-// the M-step (and the device re-seeding) of steps whose E-step ran through the assignment kernels; descriptors by value
-template <typename XT>
-static void launch_update_only(hamsm_ctx *c, hipStream_t q, const StepPack &pk, int ny, int maxK, int64_t ldx, double ratio, bool any_perm) {
-  const size_t lds = sizeof(int) * (4 * UPD_LIST);
-  const dim3 gu((unsigned)((maxK + 3) / 4), (unsigned)ny);
-  if (c->D <= 64) hipLaunchKernelGGL((k_step_update<XT, 1, true, 4>), gu, dim3(256), lds, q, (const StepDev *)nullptr, pk, ldx, c->D, c->KS);
-  else hipLaunchKernelGGL((k_step_update<XT, 2, true, 4>), gu, dim3(256), lds, q, (const StepDev *)nullptr, pk, ldx, c->D, c->KS);
-  if (any_perm)
-    hipLaunchKernelGGL((k_step_reassign<XT, true>), dim3((unsigned)ny), dim3(256), 0, q, (const StepDev *)nullptr, pk, ldx, c->D, c->KS, ratio);
-}
 
 // row tiles per E-step workgroup: as many as the registers allow (RT * KS <= 32) while the launch keeps >= 128 workgroups
 template <typename XT, int KS, bool BYVAL>
@@ -3723,89 +2202,25 @@ static int launch_steps(hamsm_ctx *c, hipStream_t q, const StepDev *d_steps, con
   return HAMSM_OK;
 }
 
-template <typename XT>
-static int launch_persist(hamsm_ctx *c, const StepDev *d_steps, const int *d_coff, const int *d_cidx, PersistCtl *d_ctl,
-                          int64_t ldx, double ratio, int n_steps) {
-  const size_t lds = sizeof(int) * (4 * UPD_LIST) + sizeof(XT) * (PF_TILES * 16) * (4 * (size_t)c->KS + 1);
-  const dim3 grid((unsigned)(8 * c->persist_wpx)), block(256);
-  static const int prof = getenv("HAMSM_PERSIST_PROF") ? atoi(getenv("HAMSM_PERSIST_PROF")) : 0;
-  switch (c->KS) {
-#define CASE(KSV, JBV)                                                                                                   \
-  case KSV:                                                                                                              \
-    hipLaunchKernelGGL((k_train_persist<XT, KSV, JBV>), grid, block, lds, c->stream, d_steps, d_coff, d_cidx, d_ctl, c->S, ldx, \
-                       c->D, ratio, n_steps, prof);                                                                      \
-    break;
-    CASE(1, 8) CASE(2, 8) CASE(3, 8) CASE(4, 8) CASE(6, 4) CASE(8, 4) CASE(12, 2) CASE(16, 2)
-#undef CASE
-    default: return hamsm_fail(c, HAMSM_ENOTSUP, "persistent training: KS=%d", c->KS);
-  }
-  HIPCHK(c, hipGetLastError());
-  return HAMSM_OK;
-}
-
-// the E-steps of one look-ahead block (descriptors in memory: a throughput kernel, one dependent load does not matter)
-template <typename XT>
-static int launch_assign_ahead(hamsm_ctx *c, hipStream_t q, const StepDev *d_steps, const AheadDev *d_aheads, const int *d_ylist,
-                               int ny, long long max_nb, int64_t ldx) {
-  if (ny <= 0 || max_nb <= 0) return HAMSM_OK;
-  const dim3 grid((unsigned)((max_nb + 15) / 16), (unsigned)ny);
-  switch (c->KS) {
-#define CASE(KSV, JBV)                                                                                                  \
-  case KSV:                                                                                                             \
-    hipLaunchKernelGGL((k_step_assign_ahead<XT, KSV, JBV, 1>), grid, dim3(256), 0, q, d_steps, d_aheads, d_ylist, ldx, c->D); \
-    break;
-    CASE(1, 8) CASE(2, 8) CASE(3, 8) CASE(4, 8) CASE(6, 4) CASE(8, 4) CASE(12, 2) CASE(16, 2) CASE(24, 1) CASE(32, 1)
-#undef CASE
-    default: return hamsm_fail(c, HAMSM_ENOTSUP, "look-ahead E-step: KS=%d", c->KS);
-  }
-  return HAMSM_OK;
-}
-
-// end of a pipelined segment whose last M-step wrote the alternate tables: they go home -- unless the stratum's chain stopped
-// inside the segment (then the alternate tables may be the OLDER ones; the host sorts that out once it knows where it stopped)
-__global__ void k_tables_home(const int32_t *__restrict__ halt, int last_idx, const double *__restrict__ sC, double *__restrict__ dC,
-                              size_t nC, const double *__restrict__ sq, double *__restrict__ dq, const double *__restrict__ sn,
-                              double *__restrict__ dn, size_t nk, const double *__restrict__ sB, double *__restrict__ dB, size_t nB) {
-  if (*halt <= last_idx) return;
-  const size_t stride = (size_t)gridDim.x * blockDim.x, t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  for (size_t i = t; i < nC; i += stride) dC[i] = sC[i];
-  for (size_t i = t; i < nk; i += stride) {
-    dq[i] = sq[i];
-    dn[i] = sn[i];
-  }
-  for (size_t i = t; i < nB; i += stride) dB[i] = sB[i];
-}
-
-// one launch of the pipeline: n_m M-steps (by value) and n_e E-steps (descriptors in memory)
-template <typename XT>
-static int launch_pipe(hamsm_ctx *c, hipStream_t q, const StepPack &pk, const AheadPack &apk, int n_m, int maxK, const StepDev *d_sde,
-                       const AheadDev *d_aheads, const int *d_ylist, int n_e, long long e_nb, int64_t ldx, double ratio) {
-  const int rt = c->ahead_rt == 2 && c->KS <= 16 ? 2 : 1;
-  const unsigned gx_m = (unsigned)((maxK + 3) / 4), gx_e = (unsigned)((e_nb + 16 * rt - 1) / (16 * rt));
-  const dim3 grid(gx_m > gx_e ? gx_m : gx_e, (unsigned)(n_m + n_e));
-  const size_t lds = sizeof(int) * (4 * AHEAD_STRIP) + sizeof(double) * (4 * AHEAD_HX) + sizeof(int) * (4 * 2 * AHEAD_ITEMS);
-  switch (c->KS) {
-#define CASE(KSV, JBV, HV)                                                                                                     \
-  case KSV:                                                                                                                    \
-    if (rt == 2 && KSV <= 16)                                                                                                  \
-      hipLaunchKernelGGL((k_step_pipe<XT, KSV, JBV, HV, (KSV <= 16 ? 2 : 1)>), grid, dim3(256), lds, q, pk, apk, n_m, d_sde, d_aheads, \
-                         d_ylist, ldx, c->D, ratio);                                                                           \
-    else                                                                                                                       \
-      hipLaunchKernelGGL((k_step_pipe<XT, KSV, JBV, HV, 1>), grid, dim3(256), lds, q, pk, apk, n_m, d_sde, d_aheads, d_ylist, ldx, \
-                         c->D, ratio);                                                                                         \
-    break;
-    CASE(1, 8, 1) CASE(2, 8, 1) CASE(3, 8, 1) CASE(4, 4, 1) CASE(6, 2, 1) CASE(8, 2, 1) CASE(12, 1, 1) CASE(16, 1, 1) CASE(24, 1, 2) CASE(32, 1, 2)
-#undef CASE
-    default: return hamsm_fail(c, HAMSM_ENOTSUP, "pipelined training: KS=%d", c->KS);
-  }
-  return HAMSM_OK;
-}
 
 // steps [0,n): consecutive steps of distinct strata share launches (grid.y)
+#ifdef HAMSM_EXPERIMENTS
+static int run_steps_experiments(hamsm_ctx *c, const void *X, int dt, int64_t ldx, const int32_t *d_rows, const double *d_w,
+                                 const hamsm_step *h_steps, int64_t n_steps, double ratio, const int32_t *h_perm, int64_t n_perm_total,
+                                 int32_t *h_report, int64_t *h_resume, int32_t *h_reason, int want_zero_flag,
+                                 int32_t **labels_of_first);
+#endif
 static int run_steps(hamsm_ctx *c, const void *X, int dt, int64_t ldx, const int32_t *d_rows, const double *d_w,
                      const hamsm_step *h_steps, int64_t n_steps, double ratio, const int32_t *h_perm, int64_t n_perm_total,
                      int32_t *h_report, int64_t *h_resume, int32_t *h_reason, int want_zero_flag,
                      int32_t **labels_of_first) {
+#ifdef HAMSM_EXPERIMENTS
+  // (libhamsm_hip_exp.so only: a context with one of the measured-slower experiments switched on takes the launcher that has
+  // them threaded through it -- csrc/experiments/)
+  if (c->train_persist || c->ahead || c->train_ranked || c->train_graph)
+    return run_steps_experiments(c, X, dt, ldx, d_rows, d_w, h_steps, n_steps, ratio, h_perm, n_perm_total, h_report, h_resume, h_reason,
+                                 want_zero_flag, labels_of_first);
+#endif
   const size_t esz = dt == HAMSM_F32 ? 4 : 8;
   const bool generic = c->KS > 32;  // more than 128 features (k_step_*_generic)
   timespec ts_in;
@@ -3822,6 +2237,7 @@ static int run_steps(hamsm_ctx *c, const void *X, int dt, int64_t ldx, const int
     int64_t hi = (d_rows ? s.rows_off : 0) + s.n_b;
     if (hi > lab_hi) lab_hi = hi;
   }
+  if (n_steps >= 0x7f000000) return hamsm_fail(c, HAMSM_EINVAL, "too many steps");
   // launch groups = maximal runs of distinct strata
   std::vector<int64_t> gstart;
   {
@@ -3836,38 +2252,12 @@ static int run_steps(hamsm_ctx *c, const void *X, int dt, int64_t ldx, const int
     }
     gstart.push_back(n_steps);
   }
-  // Groups whose E-step is heavy enough to be bound by the f64 matrix unit run it through the assignment kernels instead
-  // (hamsm_assign_rows: ranking on the bf16 / f32 matrix unit under a proven bound, exact f64 kernel for the rest -- the same
-  // labels): the group's strata ascend, their row lists lie back to back, the steps share one frame
-  // span and say how long it is (`n_span`).  Such a pass keeps to one queue (the assignment kernels have one scratch arena).
-  std::vector<char> ranked(gstart.size() - 1, 0);
-  bool any_ranked = false;
-  int64_t span_max = 0;
-  if (c->train_ranked && !generic && d_rows && h_report && c->assign_filter && c->have_mapper)
-    for (size_t g = 0; g + 1 < gstart.size(); g++) {
-      const int64_t i = gstart[g], j = gstart[g + 1];
-      bool good = h_steps[i].n_span > 0;
-      double flop = 0;
-      for (int64_t q = i; q < j && good; q++) {
-        const hamsm_step &st_ = h_steps[q];
-        good = st_.n_b > 0 && st_.x_off == h_steps[i].x_off && st_.n_span == h_steps[i].n_span && !(st_.flags & HAMSM_STEP_FIRST);
-        if (q > i) good = good && st_.stratum > h_steps[q - 1].stratum && st_.rows_off == h_steps[q - 1].rows_off + h_steps[q - 1].n_b;
-        flop += 2.0 * (double)st_.n_b * c->st[st_.stratum].K * c->D;
-      }
-      if (good && (c->train_ranked == 2 || flop >= c->ranked_min_flop)) {
-        ranked[g] = 1;
-        any_ranked = true;
-        span_max = h_steps[i].n_span > span_max ? h_steps[i].n_span : span_max;
-      }
-    }
   size_t off = 0;
   auto take = [&](size_t bytes) {
     size_t o = off;
     off = (off + bytes + 255) & ~(size_t)255;
     return o;
   };
-  size_t o_gcnt = take(any_ranked ? sizeof(unsigned long long) * (size_t)c->S * (gstart.size() - 1) : 0),
-         o_lspan = take(sizeof(int32_t) * (size_t)span_max);
   size_t o_steps = take(sizeof(StepDev) * n_steps), o_rep = take(sizeof(int32_t) * 2 * n_steps),
          o_lab = take(sizeof(int32_t) * (size_t)lab_hi), o_halt = take(sizeof(int32_t) * 2 * (size_t)c->S),
          o_perm = take(sizeof(int32_t) * (size_t)(n_perm_total > 0 ? n_perm_total : 1));
@@ -3876,35 +2266,12 @@ static int run_steps(hamsm_ctx *c, const void *X, int dt, int64_t ldx, const int
   const int nslot = c->S < 65535 ? c->S : 65535;
   const size_t xg_row = sizeof(double) * 4 * (size_t)c->KS;
   const size_t nb_pad = ((size_t)nb_max + 63) & ~(size_t)63;  // whole E-step tiles (up to 4 x 16 rows)
-  // look-ahead blocks (k_step_assign_ahead): a planned pass with row lists, a scratch slot per stratum, batches of at most 4096
-  // rows (one block of bitmap words per centroid), at most 128 features.  Every position of a block has its own batch copy,
-  // bitmaps and table of undecided rows; steps of the step-by-step path use position 0's.
-  const bool ahead_can0 = c->ahead && c->ahead_gmax >= 1 && !generic && d_rows && h_report && nslot == c->S && nb_max > 0 &&
-                         nb_max <= 4096 && !c->train_persist;  // (and at most AHEAD_KMAX centroids per stratum: below)
   int Kmax = 0;
   for (int s = 0; s < c->S; s++) Kmax = c->st[s].K > Kmax ? c->st[s].K : Kmax;
-  const bool ahead_can = ahead_can0 && Kmax <= AHEAD_KMAX;
-  const int npos = ahead_can ? 4 : 1;  // a step's E-step output lives until its M-step, two launches later: four rotating regions
-  size_t o_xg = take(generic ? 0 : xg_row * (size_t)nslot * npos * nb_pad);  // (the generic M-step reads the frames in place)
+  size_t o_xg = take(generic ? 0 : xg_row * (size_t)nslot * nb_pad);  // (the generic M-step reads the frames in place)
   const int wstride = (int)((((nb_max + 63) >> 6) + 63) & ~(int64_t)63);  // bitmap words per centroid
-  const size_t mb_bytes = sizeof(unsigned long long) * (size_t)nslot * npos * Kmax * wstride;
-  size_t o_mb = take(mb_bytes);
-  const size_t ah_words = ahead_can ? (size_t)n_steps : 0;  // per step: displacement slot, bound, two counters
-  const int ah_kst = (Kmax + 63) & ~63;
-  const int ah_dp = (c->D + 1) & ~1;
-  int ah_hcap = AHEAD_HX / ah_dp < AHEAD_HCAP ? AHEAD_HX / ah_dp : AHEAD_HCAP;  // (>= 5: D <= 128)
-  if (const char *v = getenv("HAMSM_AHEAD_HCAP")) ah_hcap = atoi(v) < ah_hcap ? (atoi(v) < 0 ? 0 : atoi(v)) : ah_hcap;  // (experiments)
-  size_t o_slot = take(sizeof(double) * (AHEAD_SLOTS + 1) * ah_words), o_cnt = take(sizeof(int32_t) * 4 * ah_words),
-         o_hl = take(ahead_can ? sizeof(int32_t) * AHEAD_HCAP * (size_t)nslot * npos : 0),
-         o_hd = take(ahead_can ? sizeof(double) * AHEAD_HCAP * (size_t)ah_kst * nslot * npos : 0),
-         o_td = take(ahead_can ? sizeof(double) * 3 * AHEAD_TAB_CAP * (size_t)nslot * npos : 0),
-         o_tab = take(ahead_can ? sizeof(SuspEntry) * AHEAD_TAB_CAP * (size_t)nslot * npos : 0),
-         o_ylist = take(sizeof(int) * ah_words),
-         o_ah = take(sizeof(AheadDev) * ah_words), o_sde = take(sizeof(StepDev) * ah_words), o_tail = take(sizeof(StepDev) * (size_t)c->S),
-         o_alt = take(ahead_can ? sizeof(double) * (size_t)c->S * ((size_t)((Kmax + 15) & ~15) * (c->D + 2 + c->KS * 4)) : 0);
-  // persistent pass: control block (registration, error word, one barrier counter per stratum) and the strata's chains
-  const size_t ctl_bytes = (sizeof(PersistCtl) + sizeof(unsigned) * (size_t)c->S + 15) & ~(size_t)15;
-  size_t o_ctl = take(ctl_bytes), o_coff = take(sizeof(int) * ((size_t)c->S + 1)), o_cidx = take(sizeof(int) * (size_t)n_steps);
+  const size_t mb_bytes = sizeof(unsigned long long) * (size_t)nslot * Kmax * wstride;
+  size_t o_mb = take(mb_bytes), o_tail = take(sizeof(StepDev) * (size_t)c->S);
   int rc = hamsm_ensure_scratch(c, off);
   if (rc) return rc;
   char *b = (char *)c->scratch;
@@ -3932,7 +2299,6 @@ static int run_steps(hamsm_ctx *c, const void *X, int dt, int64_t ldx, const int
     d.halt = (int32_t *)(b + o_halt) + s.stratum;
     d.reason = (int32_t *)(b + o_halt) + c->S + s.stratum;
   }
-  if (n_steps >= 0x7f000000) return hamsm_fail(c, HAMSM_EINVAL, "too many steps");
   // the low-count test of a step is evaluated by the E-step of the stratum's next step (the counts do not change in
   // between); only a stratum's last step needs a launch of its own
   std::vector<int64_t> last_of(c->S, -1), tail_checks;
@@ -3953,22 +2319,10 @@ static int run_steps(hamsm_ctx *c, const void *X, int dt, int64_t ldx, const int
   for (size_t g = 0; g + 1 < gstart.size(); g++)
     for (int64_t j0 = gstart[g]; j0 < gstart[g + 1]; j0++) {
       const size_t slot = nslot == c->S ? (size_t)h_steps[j0].stratum : (size_t)(j0 - gstart[g]);
-      sd[j0].Xg = (double *)(b + o_xg + slot * npos * nb_pad * xg_row);
-      sd[j0].mbits = (unsigned long long *)(b + o_mb) + slot * npos * Kmax * wstride;
+      sd[j0].Xg = (double *)(b + o_xg + slot * nb_pad * xg_row);
+      sd[j0].mbits = (unsigned long long *)(b + o_mb) + slot * Kmax * wstride;
       sd[j0].wstride = wstride;
     }
-  if (any_ranked) {
-    // the strata's row counts of every group (what the assignment kernels' bucket passes would have counted)
-    rc = hamsm_refresh_table(c);
-    if (rc) return rc;
-    c->h_stage.assign(sizeof(unsigned long long) * (size_t)c->S * (gstart.size() - 1), 0);
-    unsigned long long *gc = (unsigned long long *)c->h_stage.data();
-    for (size_t g = 0; g + 1 < gstart.size(); g++)
-      if (ranked[g])
-        for (int64_t q = gstart[g]; q < gstart[g + 1]; q++) gc[g * c->S + h_steps[q].stratum] = (unsigned long long)h_steps[q].n_b;
-    HIPCHK(c, hipMemcpyAsync(b + o_gcnt, gc, c->h_stage.size(), hipMemcpyHostToDevice, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));  // (hamsm_assign_rows re-uses the staging vector)
-  }
   if (labels_of_first) *labels_of_first = sd[0].labels;
   HIPCHK(c, hipMemcpyAsync(b + o_steps, sd.data(), sizeof(StepDev) * n_steps, hipMemcpyHostToDevice, c->stream));
   HIPCHK(c, hipMemsetAsync(b + o_rep, 0, sizeof(int32_t) * 2 * n_steps, c->stream));
@@ -3978,53 +2332,7 @@ static int run_steps(hamsm_ctx *c, const void *X, int dt, int64_t ldx, const int
     HIPCHK(c, hipMemcpyAsync(b + o_perm, h_perm, sizeof(int32_t) * (size_t)n_perm_total, hipMemcpyHostToDevice, c->stream));
   HIPCHK(c, hipMemsetAsync(b + o_mb, 0, mb_bytes, c->stream));
   const StepDev *d_steps = (const StepDev *)(b + o_steps);
-  // One persistent launch for the whole run (§5.3a) when the run is a planned pass (row lists, a scratch slot per stratum,
-  // more than one launch group) of at most 64 features, when HAMSM_TRAIN_PERSIST=1 asks for it (off by default: §5.3a).
-  bool persist_done = false;
-  if (c->train_persist && h_report && d_rows && nslot == c->S && c->KS <= 16 && gstart.size() > 2 && n_steps < 0x7fffffff) {
-    std::vector<int> coff(c->S + 1, 0), cidx((size_t)n_steps);
-    for (int64_t i = 0; i < n_steps; i++) coff[h_steps[i].stratum + 1]++;
-    for (int s = 0; s < c->S; s++) coff[s + 1] += coff[s];
-    {
-      std::vector<int> fill(coff.begin(), coff.end() - 1);
-      for (int64_t i = 0; i < n_steps; i++) cidx[fill[h_steps[i].stratum]++] = (int)i;
-    }
-    HIPCHK(c, hipMemcpyAsync(b + o_coff, coff.data(), sizeof(int) * coff.size(), hipMemcpyHostToDevice, c->stream));
-    HIPCHK(c, hipMemcpyAsync(b + o_cidx, cidx.data(), sizeof(int) * cidx.size(), hipMemcpyHostToDevice, c->stream));
-    HIPCHK(c, hipMemsetAsync(b + o_ctl, 0, ctl_bytes, c->stream));
-    hamsm_timer_begin(c);
-    rc = (dt == HAMSM_F32) ? launch_persist<float>(c, d_steps, (const int *)(b + o_coff), (const int *)(b + o_cidx),
-                                                   (PersistCtl *)(b + o_ctl), ldx, ratio, (int)n_steps)
-                           : launch_persist<double>(c, d_steps, (const int *)(b + o_coff), (const int *)(b + o_cidx),
-                                                    (PersistCtl *)(b + o_ctl), ldx, ratio, (int)n_steps);
-    hamsm_timer_end(c, ST_STEP);
-    if (rc) {
-      hipDeviceSynchronize();
-      return rc;
-    }
-    unsigned perr = 0;
-    HIPCHK(c, hipMemcpyAsync(&perr, b + o_ctl + offsetof(PersistCtl, err), sizeof(unsigned), hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));  // (also: coff / cidx / sd are locals the uploads read)
-    if (perr == 0) persist_done = true;
-    else if (perr == 1) {
-      // not every workgroup of the grid became resident: nothing was modified; this context keeps to the multi-kernel path
-      c->train_persist = 0;
-      fprintf(stderr, "[hamsm] persistent training launch could not register all workgroups: using the multi-kernel path\n");
-    } else
-      return hamsm_fail(c, HAMSM_EDEVICE, "persistent training kernel: a barrier timed out (ctl.err=%u)", perr);
-  }
-  // what each stratum's chain has come to: taken from the stop words after every pass over the launches.  A pass ends for a
-  // stratum when all its steps are applied or a prediction of the host's plan failed (HAMSM_STOP_*: reported to the caller),
-  // or when a look-ahead block was given up (HAMSM_STOP_AHEAD: never reported; the next pass relaunches from that step).
-  std::vector<int32_t> fin_halt(c->S, 0x7f7f7f7f), fin_reason(c->S, 0);
-  if (!persist_done) {
-  std::vector<int64_t> from(c->S, 0);  // steps of stratum s below from[s] are applied
-  std::vector<char> live(c->S, 1);
-  bool ahead_on = ahead_can && gstart.size() > 2;
-  int ahead_fails = 0;
   const bool dbg_enq = getenv("HAMSM_DEBUG_ENQUEUE") != nullptr;
-  const bool dbg_ahead = getenv("HAMSM_DEBUG_AHEAD") != nullptr;
-  for (int pass = 0;; pass++) {
   hamsm_timer_begin(c);
   // lanes: stratum s always runs on queue s % n_lanes, so every stratum's chain stays ordered; a lane's part of a
   // launch group travels by value (<= PACK_NY strata) -- otherwise one queue and descriptors in memory
@@ -4034,246 +2342,9 @@ static int run_steps(hamsm_ctx *c, const void *X, int dt, int64_t ldx, const int
     for (int64_t q = gstart[g]; q < gstart[g + 1]; q++)
       if (++cnt[h_steps[q].stratum % n_lanes] > PACK_NY) n_lanes = 1;
   }
-  if (gstart.size() <= 2 || c->S < 2 || nslot != c->S || !d_rows || generic || any_ranked) n_lanes = 1;  // (labels scratch is per step only with row lists)
-  auto runs = [&](int64_t q) { return live[h_steps[q].stratum] && q >= from[h_steps[q].stratum]; };
+  if (gstart.size() <= 2 || c->S < 2 || nslot != c->S || !d_rows || generic) n_lanes = 1;  // (labels scratch is per step only with row lists)
   auto lane_of = [&](int64_t q) { return n_lanes > 1 ? h_steps[q].stratum % n_lanes : 0; };
-  auto lane_of_stratum = [&](int y) { return n_lanes > 1 ? y % n_lanes : 0; };
-  // ---- plan the pipelined segments of this pass (host only; fills the steps' look-ahead fields before they are uploaded) ----
-  // Per lane: the first `n0` launch groups step by step (a relaunch after a failed premise: none), then SEGMENTS: maximal runs
-  // of launch groups in which the lane's strata are the same, every step has rows, none is a first step after seeding and
-  // none carries a re-seeding (its centroids jump).  A segment of groups a .. z runs as
-  //     E{a exact}   M{a}   E{a+1 exact, a+2}   M{a+1} + E{a+3}   M{a+2} + E{a+4}   ...   M{z-1}   M{z}
-  // -- from the fourth launch on ONE launch per WE iteration: the M-step of iteration i beside the E-step of iteration i + 2,
-  // which reads the centroid tables that M-step reads (it writes the other buffer).  Labels of i + 2 are therefore two updates
-  // old when they are used; M{i} measures exactly that displacement for M{i+1} to check, and evaluates the rows iteration
-  // i + 1 left undecided or open against the centroids it has just written.
-  struct PipeOp {     // one launch of a lane
-    size_t g;         // issued when the launch loop reaches this group (the M part's group; for E-only launches: the next M's)
-    int order;        // position among the launches issued at the same group
-    std::vector<int64_t> m;  // steps whose M-step runs (the lane's steps of one group), possibly none
-    int y0, y1;       // E part: ylist[y0 .. y1)
-    long long e_nb;   // largest batch of the E part
-  };
-  const size_t NG = gstart.size() - 1;
-  std::vector<std::vector<PipeOp>> ops(n_lanes);
-  std::vector<int> ylist;
-  std::vector<char> in_seg(NG * (size_t)n_lanes, 0);  // [g * n_lanes + l]: the lane's steps of this group run inside a segment
-  std::vector<AheadDev> ahd(ahead_can ? (size_t)n_steps : 0);
-  std::vector<char> out_alt((size_t)n_steps, 0);      // the step's M-step writes the alternate tables (else the stratum's own)
-  struct CopyBack {
-    size_t g;
-    int y;
-    int64_t q;  // the segment's last step of the stratum
-  };
-  std::vector<CopyBack> copy_back;  // after this group's launches the stratum's alternate tables go home
-  const size_t kp = (size_t)((Kmax + 15) & ~15);
-  const size_t alt_stride = kp * c->D + 2 * kp + kp * c->KS * 4;  // doubles per stratum: C, csq, counts, Bpack
-  auto altC = [&](int y) { return (double *)(b + o_alt) + (size_t)y * alt_stride; };
-  auto altCsq = [&](int y) { return altC(y) + kp * c->D; };
-  auto altCnt = [&](int y) { return altCsq(y) + kp; };
-  auto altBp = [&](int y) { return altCnt(y) + kp; };
-  if (ahead_can)
-    for (int64_t i = 0; i < n_steps; i++) {  // (a relaunch plans afresh: back to region 0 of the stratum, tables at home)
-      memset(&ahd[i], 0, sizeof(AheadDev));
-      ahd[i].pos = -1;
-      const Stratum &t = c->st[h_steps[i].stratum];
-      const size_t slot = (size_t)h_steps[i].stratum;
-      sd[i].Xg = (double *)(b + o_xg + slot * npos * nb_pad * xg_row);
-      sd[i].mbits = (unsigned long long *)(b + o_mb) + slot * npos * Kmax * wstride;
-      sd[i].C = t.C;
-      sd[i].counts = t.counts;
-      sd[i].csq = t.csq;
-      sd[i].Bpack = t.Bpack;
-    }
-  // the E-steps read their descriptors from memory: one array of StepDev copies whose table pointers name the buffer the
-  // E-step reads (the M-step's copy of the same step, sent by value, names the buffer IT reads)
-  std::vector<StepDev> sdE(ahead_can ? (size_t)n_steps : 0);
-  if (ahead_on) {
-    for (int l = 0; l < n_lanes; l++) {
-      int seen_groups = 0;
-      const int n0 = pass == 0 ? c->ahead_n0 : 0;
-      // the lane's steps per group, and whether the group may be part of a segment
-      std::vector<std::vector<int64_t>> mine(NG);
-      std::vector<char> ok(NG, 0);
-      for (size_t g = 0; g < NG; g++) {
-        bool good = true;
-        for (int64_t q = gstart[g]; q < gstart[g + 1]; q++)
-          if (runs(q) && lane_of(q) == l) {
-            mine[g].push_back(q);
-            good = good && h_steps[q].n_b > 0 && !(h_steps[q].flags & HAMSM_STEP_FIRST) && !sd[q].perm;
-          }
-        ok[g] = good && !mine[g].empty();
-      }
-      auto same_strata = [&](size_t g1, size_t g2) {
-        if (mine[g1].size() != mine[g2].size()) return false;
-        for (size_t k = 0; k < mine[g1].size(); k++)
-          if (h_steps[mine[g1][k]].stratum != h_steps[mine[g2][k]].stratum) return false;
-        return true;
-      };
-      size_t g = 0;
-      while (g < NG) {
-        if (mine[g].empty()) {
-          g++;
-          continue;
-        }
-        if (seen_groups < n0 || !ok[g]) {
-          seen_groups++;
-          g++;
-          continue;
-        }
-        // the segment's groups (those of the lane that are not empty), at most `seg_max`
-        std::vector<size_t> G_;
-        size_t ge = g;
-        while (ge < NG && (int)G_.size() < c->ahead_gmax * 64) {
-          if (mine[ge].empty()) {
-            ge++;
-            continue;
-          }
-          if (!ok[ge] || !same_strata(g, ge)) break;
-          G_.push_back(ge);
-          ge++;
-        }
-        if (G_.size() < 4) {  // too short to pay for the three launches of a start
-          seen_groups += (int)G_.size();
-          g = G_.empty() ? g + 1 : G_.back() + 1;
-          continue;
-        }
-        const int n = (int)G_.size(), ny = (int)mine[g].size();
-        for (int k = 0; k < n; k++) in_seg[G_[k] * n_lanes + l] = 1;
-        // per step: regions, buffers, slots
-        for (int k = 0; k < n; k++)
-          for (int q_ = 0; q_ < ny; q_++) {
-            const int64_t q = mine[G_[k]][q_];
-            const int y = h_steps[q].stratum;
-            const Stratum &t = c->st[y];
-            AheadDev &d = ahd[q];
-            const size_t reg = (size_t)y * npos + (size_t)(k & 3);
-            d.pos = (k <= 1) ? 0 : 1;  // the segment's first two steps take their labels exactly
-            sd[q].Xg = (double *)(b + o_xg + reg * nb_pad * xg_row);
-            sd[q].mbits = (unsigned long long *)(b + o_mb) + reg * Kmax * wstride;
-            d.slot = (double *)(b + o_slot) + (AHEAD_SLOTS + 1) * q;
-            d.bound = (double *)(b + o_slot) + (AHEAD_SLOTS + 1) * q + AHEAD_SLOTS;
-            d.tab = (SuspEntry *)(b + o_tab) + reg * AHEAD_TAB_CAP;
-            d.cnt = (int32_t *)(b + o_cnt) + 4 * q;
-            d.hl = (int32_t *)(b + o_hl) + reg * AHEAD_HCAP;
-            d.hd = (double *)(b + o_hd) + reg * AHEAD_HCAP * ah_kst;
-            d.td = (double *)(b + o_td) + reg * 3 * AHEAD_TAB_CAP;
-            d.hcap = ah_hcap;
-            d.kst = ah_kst;
-            // tables: M{k} reads buffer k & 1 (0 = the stratum's own), writes the other
-            const bool in_alt = k & 1;
-            sd[q].C = in_alt ? altC(y) : t.C;
-            sd[q].counts = in_alt ? altCnt(y) : t.counts;
-            sd[q].csq = in_alt ? altCsq(y) : t.csq;
-            sd[q].Bpack = in_alt ? altBp(y) : t.Bpack;
-            d.C_out = in_alt ? t.C : altC(y);
-            d.counts_out = in_alt ? t.counts : altCnt(y);
-            d.csq_out = in_alt ? t.csq : altCsq(y);
-            d.Bpack_out = in_alt ? t.Bpack : altBp(y);
-            out_alt[q] = !in_alt;
-            d.disp_in = k <= 1;  // labels of k + 1 are one update old for k = 1 (and exact for k = 0), two from then on
-            // labels of step k were taken against the tables M{k-2} read (k >= 3), M{k-1} read (k = 2), or its own (k <= 1)
-            sdE[q] = sd[q];
-            if (k >= 2) {
-              const bool e_alt = (k == 2) ? ((k - 1) & 1) : ((k - 2) & 1);
-              sdE[q].C = e_alt ? altC(y) : t.C;
-              sdE[q].counts = e_alt ? altCnt(y) : t.counts;
-              sdE[q].csq = e_alt ? altCsq(y) : t.csq;
-              sdE[q].Bpack = e_alt ? altBp(y) : t.Bpack;
-              // the premise M{k} checks: what M{k-1} measured <= what the E-step assumed
-              const int64_t qp = mine[G_[k - 1]][q_];
-              d.prev_slot = (const double *)(b + o_slot) + (AHEAD_SLOTS + 1) * qp;
-              // the E-step's guess: alpha x the latest measurement at its launch, scaled to the updates its labels will be old
-              //   k = 2: launched after M{0} (one update measured), labels one update old
-              //   k = 3: launched with M{1}: latest = M{0}'s (one update), labels two updates old
-              //   k = 4: launched with M{2}: latest = M{1}'s (one update), labels two updates old
-              //   k >= 5: launched with M{k-2}: latest = M{k-3}'s (two updates), labels two updates old
-              const int kr = (k == 2) ? 0 : (k == 3 ? 0 : k - 3);
-              const int64_t qr = mine[G_[kr]][q_];
-              d.ref_slot = (const double *)(b + o_slot) + (AHEAD_SLOTS + 1) * qr;
-              d.ref_scale = c->ahead_alpha * ((k == 3 || k == 4) ? 2.0 : 1.0);
-              // M{k-1} evaluates this step's undecided and open rows
-              AheadDev &pv = ahd[qp];
-              pv.nx_cnt = d.cnt;
-              pv.nx_hl = d.hl;
-              pv.nx_Xg = sd[q].Xg;
-              pv.nx_hd = d.hd;
-              pv.nx_tab = d.tab;
-              pv.nx_td = d.td;
-            }
-          }
-        // the launches
-        auto e_list = [&](std::initializer_list<int> ks, int &y0, int &y1, long long &nb) {
-          y0 = (int)ylist.size();
-          nb = 0;
-          for (int k : ks)
-            if (k < n)
-              for (int64_t q : mine[G_[k]]) {
-                ylist.push_back((int)q);
-                nb = h_steps[q].n_b > nb ? h_steps[q].n_b : nb;
-              }
-          y1 = (int)ylist.size();
-        };
-        {
-          PipeOp o{G_[0], 0, {}, 0, 0, 0};
-          e_list({0}, o.y0, o.y1, o.e_nb);
-          ops[l].push_back(o);
-        }
-        {
-          PipeOp o{G_[0], 1, mine[G_[0]], 0, 0, 0};
-          ops[l].push_back(o);
-        }
-        {
-          PipeOp o{G_[1], 0, {}, 0, 0, 0};
-          e_list({1, 2}, o.y0, o.y1, o.e_nb);
-          ops[l].push_back(o);
-        }
-        for (int k = 1; k < n; k++) {
-          PipeOp o{G_[k], 1, mine[G_[k]], 0, 0, 0};
-          e_list({k + 2}, o.y0, o.y1, o.e_nb);
-          ops[l].push_back(o);
-        }
-        if ((n - 1) % 2 == 0)  // M{n-1} reads buffer (n-1) & 1 = 0 and writes the alternate: bring the tables home
-          for (int64_t q : mine[G_[n - 1]]) copy_back.push_back({G_[n - 1], h_steps[q].stratum, q});
-        c->ahead_stat[0]++;
-        c->ahead_stat[1] += (long long)n * ny;
-        seen_groups += n;
-        g = G_.back() + 1;
-      }
-    }
-  }
-  if (pass > 0 || ahead_on) {
-    HIPCHK(c, hipMemcpyAsync(b + o_steps, sd.data(), sizeof(StepDev) * n_steps, hipMemcpyHostToDevice, c->stream));
-    if (ahead_can) {
-      HIPCHK(c, hipMemsetAsync(b + o_slot, 0, sizeof(double) * (AHEAD_SLOTS + 1) * ah_words, c->stream));
-      HIPCHK(c, hipMemsetAsync(b + o_cnt, 0, sizeof(int32_t) * 4 * ah_words, c->stream));
-      if (!ylist.empty()) {
-        HIPCHK(c, hipMemcpyAsync(b + o_ylist, ylist.data(), sizeof(int) * ylist.size(), hipMemcpyHostToDevice, c->stream));
-        HIPCHK(c, hipMemcpyAsync(b + o_ah, ahd.data(), sizeof(AheadDev) * ahd.size(), hipMemcpyHostToDevice, c->stream));
-        HIPCHK(c, hipMemcpyAsync(b + o_sde, sdE.data(), sizeof(StepDev) * sdE.size(), hipMemcpyHostToDevice, c->stream));
-        // the alternate tables start as copies of the stratum's own (what matters is the padding: +inf in csq, zeros in the
-        // fragments; every live row is written by the first M-step that writes them)
-        for (int y = 0; y < c->S; y++) {
-          const Stratum &t = c->st[y];
-          if (t.K == 0 || !live[y]) continue;
-          const size_t kq = (size_t)((t.K + 15) & ~15);
-          HIPCHK(c, hipMemcpyAsync(altCsq(y), t.csq, sizeof(double) * kq, hipMemcpyDeviceToDevice, c->stream));
-          HIPCHK(c, hipMemcpyAsync(altBp(y), t.Bpack, sizeof(double) * kq * c->KS * 4, hipMemcpyDeviceToDevice, c->stream));
-        }
-      }
-    }
-  }
   hipStream_t lanes[4] = {c->stream, nullptr, nullptr, nullptr};
-  // HAMSM_TRAIN_GRAPH=1 (experiment): the pass's launches are captured into a hipGraph -- the side queues join
-  // the capture through the fork / join events -- instantiated and launched once, instead of being enqueued one by one
-  const bool graph = c->train_graph && pass == 0 && !ahead_on && !any_ranked && !generic && gstart.size() > 2;
-  timespec tg0, tg1, tg2, tg3;
-  if (graph) {
-    HIPCHK(c, hipStreamSynchronize(c->stream));  // (uploads above done: the capture holds kernels only)
-    clock_gettime(CLOCK_MONOTONIC, &tg0);
-    HIPCHK(c, hipStreamBeginCapture(c->stream, hipStreamCaptureModeRelaxed));
-  }
-  c->capturing = graph;
   if (n_lanes > 1) {
     if (!c->ev_fork) HIPCHK(c, hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
     HIPCHK(c, hipEventRecord(c->ev_fork, c->stream));
@@ -4290,134 +2361,25 @@ static int run_steps(hamsm_ctx *c, const void *X, int dt, int64_t ldx, const int
   memset(&pk, 0, sizeof(pk));
   timespec ts0, ts1;
   if (dbg_enq) clock_gettime(CLOCK_MONOTONIC, &ts0);
+  std::vector<int64_t> mine;
   for (size_t g = 0; g + 1 < gstart.size(); g++) {
     const int64_t i = gstart[g], j = gstart[g + 1];
     for (int l = 0; l < n_lanes; l++) {
       long long max_nb = 0;
-      int maxK = 0, ny = 0;
+      int maxK = 0;
       bool any_perm = false;
-      std::vector<int64_t> mine;
+      mine.clear();
       for (int64_t q = i; q < j; q++) {
-        if (!runs(q) || lane_of(q) != l) continue;
+        if (lane_of(q) != l) continue;
         mine.push_back(q);
         any_perm = any_perm || sd[q].perm;
         if (h_steps[q].n_b > max_nb) max_nb = h_steps[q].n_b;
         if (c->st[h_steps[q].stratum].K > maxK) maxK = c->st[h_steps[q].stratum].K;
       }
-      ny = (int)mine.size();
+      const int ny = (int)mine.size();
       if (ny == 0 || max_nb <= 0) continue;
-      if (ahead_on && in_seg[g * n_lanes + l]) {
-        // a group inside a pipelined segment: the launches planned for it, in order
-        const double ratio_m = ratio;
-        for (const PipeOp &o : ops[l]) {
-          if (o.g != g) continue;
-          const int n_e = o.y1 - o.y0;
-          const int *d_yl = (const int *)(b + o_ylist) + o.y0;
-          if (o.m.empty()) {
-            rc = (dt == HAMSM_F32) ? launch_assign_ahead<float>(c, lanes[l], (const StepDev *)(b + o_sde), (const AheadDev *)(b + o_ah), d_yl, n_e, o.e_nb, ldx)
-                                   : launch_assign_ahead<double>(c, lanes[l], (const StepDev *)(b + o_sde), (const AheadDev *)(b + o_ah), d_yl, n_e, o.e_nb, ldx);
-          } else {
-            for (size_t c0_ = 0; c0_ < o.m.size() && !rc; c0_ += PACK_NY) {  // (descriptors by value: PACK_NY strata per launch)
-              const int n_m = (int)(o.m.size() - c0_ < PACK_NY ? o.m.size() - c0_ : PACK_NY);
-              AheadPack apk;
-              int mK = 0;
-              for (int q = 0; q < n_m; q++) {
-                pk.s[q] = sd[o.m[c0_ + q]];
-                apk.a[q] = ahd[o.m[c0_ + q]];
-                mK = pk.s[q].K > mK ? pk.s[q].K : mK;
-              }
-              for (int q = n_m; q < PACK_NY; q++) apk.a[q] = apk.a[0];
-              pk.n_next = 0;
-              const bool with_e = c0_ == 0 && n_e > 0;
-              rc = (dt == HAMSM_F32) ? launch_pipe<float>(c, lanes[l], pk, apk, n_m, mK, (const StepDev *)(b + o_sde), (const AheadDev *)(b + o_ah),
-                                                          d_yl, with_e ? n_e : 0, with_e ? o.e_nb : 0, ldx, ratio_m)
-                                     : launch_pipe<double>(c, lanes[l], pk, apk, n_m, mK, (const StepDev *)(b + o_sde), (const AheadDev *)(b + o_ah),
-                                                           d_yl, with_e ? n_e : 0, with_e ? o.e_nb : 0, ldx, ratio_m);
-            }
-          }
-          if (rc) {
-            hipDeviceSynchronize();
-            return rc;
-          }
-        }
-        for (const CopyBack &cb : copy_back)
-          if (cb.g == g && lane_of_stratum(cb.y) == l) {
-            const Stratum &t = c->st[cb.y];
-            const size_t kq = (size_t)((t.K + 15) & ~15);
-            hipLaunchKernelGGL(k_tables_home, dim3(32), dim3(256), 0, lanes[l], (const int32_t *)(b + o_halt) + cb.y, (int)cb.q,
-                               (const double *)altC(cb.y), t.C, (size_t)t.K * c->D, (const double *)altCsq(cb.y), t.csq,
-                               (const double *)altCnt(cb.y), t.counts, kq, (const double *)altBp(cb.y), t.Bpack, kq * c->KS * 4);
-          }
-        continue;
-      }
-      c->ahead_stat[5] += ny;
+      // (one lane: `mine` is the whole group, in order; several lanes: at most PACK_NY strata each, by construction of n_lanes)
       const StepDev *dptr = d_steps + i;
-      const bool contiguous = (int64_t)mine.size() == j - i;  // (a relaunch may run only some strata of a group)
-      if (ranked[g] && contiguous && n_lanes == 1) {
-        // the E-step of the whole group through the assignment kernels, then its outputs in the M-step's form, then the M-steps
-        const hamsm_step &s0 = h_steps[i];
-        rc = hamsm_assign_rows(c, (const char *)X + (size_t)s0.x_off * ldx * esz, dt, ldx, s0.n_span, (int32_t *)(b + o_lspan),
-                               d_rows + s0.rows_off, (const unsigned long long *)(b + o_gcnt) + g * c->S);
-        for (size_t c0_ = 0; c0_ < mine.size() && !rc; c0_ += PACK_NY) {
-          const int nyc = (int)(mine.size() - c0_ < PACK_NY ? mine.size() - c0_ : PACK_NY);
-          RowsPack rp;
-          long long mnb = 0;
-          int mK = 0;
-          bool ap = false;
-          for (int q = 0; q < nyc; q++) {
-            const int64_t sq = mine[c0_ + q];
-            const int y = h_steps[sq].stratum;
-            pk.s[q] = sd[sq];
-            int lo = 0;
-            for (int y2 = 0; y2 < y; y2++) lo += c->st[y2].K;
-            rp.off[q] = lo;
-            ap = ap || sd[sq].perm;
-            mnb = h_steps[sq].n_b > mnb ? h_steps[sq].n_b : mnb;
-            mK = c->st[y].K > mK ? c->st[y].K : mK;
-          }
-          for (int q = nyc; q < PACK_NY; q++) rp.off[q] = 0;
-          pk.n_next = 0;
-          const dim3 gr((unsigned)((mnb + 63) / 64), (unsigned)nyc);
-          if (dt == HAMSM_F32) {
-            hipLaunchKernelGGL(k_rows_to_bits<float>, gr, dim3(256), 0, lanes[l], pk, rp, (const int32_t *)(b + o_lspan), ldx, c->D, c->KS, ratio);
-            launch_update_only<float>(c, lanes[l], pk, nyc, mK, ldx, ratio, ap);
-          } else {
-            hipLaunchKernelGGL(k_rows_to_bits<double>, gr, dim3(256), 0, lanes[l], pk, rp, (const int32_t *)(b + o_lspan), ldx, c->D, c->KS, ratio);
-            launch_update_only<double>(c, lanes[l], pk, nyc, mK, ldx, ratio, ap);
-          }
-        }
-        if (rc) {
-          hipDeviceSynchronize();
-          return rc;
-        }
-        c->ranked_groups++;
-        continue;
-      }
-      if (!contiguous && (ny > PACK_NY || generic)) {
-        // only some strata of a group that travels by descriptors in memory: PACK_NY of them per launch, by value
-        for (size_t c0_ = 0; c0_ < mine.size() && !rc; c0_ += PACK_NY) {
-          const int nyc = (int)(mine.size() - c0_ < PACK_NY ? mine.size() - c0_ : PACK_NY);
-          long long mnb = 0;
-          int mK = 0;
-          bool ap = false;
-          for (int q = 0; q < nyc; q++) {
-            const int64_t sq = mine[c0_ + q];
-            pk.s[q] = sd[sq];
-            ap = ap || sd[sq].perm;
-            mnb = h_steps[sq].n_b > mnb ? h_steps[sq].n_b : mnb;
-            mK = c->st[h_steps[sq].stratum].K > mK ? c->st[h_steps[sq].stratum].K : mK;
-          }
-          pk.n_next = 0;
-          if (mnb <= 0) continue;
-          rc = (dt == HAMSM_F32) ? launch_steps<float>(c, lanes[l], nullptr, pk, nyc, mnb, mK, ldx, ratio, ap)
-                                 : launch_steps<double>(c, lanes[l], nullptr, pk, nyc, mnb, mK, ldx, ratio, ap);
-        }
-        if (rc) {
-          hipDeviceSynchronize();
-          return rc;
-        }
-        continue;
-      }
       if (ny <= PACK_NY && !generic) {
         dptr = nullptr;  // descriptors by value
         for (int q = 0; q < ny; q++) pk.s[q] = sd[mine[q]];
@@ -4426,7 +2388,7 @@ static int run_steps(hamsm_ctx *c, const void *X, int dt, int64_t ldx, const int
           // the same strata of the next group, in the same positions
           int nn = 0;
           for (int64_t q = j; q < gstart[g + 2] && nn < ny; q++) {
-            if (!runs(q) || lane_of(q) != l) continue;
+            if (lane_of(q) != l) continue;
             pk.nx[nn++] = StepNext{sd[q].X, sd[q].rows, sd[q].n_b};
           }
           pk.n_next = nn;
@@ -4450,194 +2412,56 @@ static int run_steps(hamsm_ctx *c, const void *X, int dt, int64_t ldx, const int
     HIPCHK(c, hipEventRecord(c->ev_join[l - 1], lanes[l]));
     HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_join[l - 1], 0));
   }
-  c->capturing = false;
-  if (graph) {
-    hipGraph_t gr = nullptr;
-    hipGraphExec_t ge = nullptr;
-    HIPCHK(c, hipStreamEndCapture(c->stream, &gr));
-    clock_gettime(CLOCK_MONOTONIC, &tg1);
-    HIPCHK(c, hipGraphInstantiate(&ge, gr, nullptr, nullptr, 0));
-    clock_gettime(CLOCK_MONOTONIC, &tg2);
-    hipEvent_t eg0 = nullptr, eg1 = nullptr;
-    hipEventCreate(&eg0);
-    hipEventCreate(&eg1);
-    hipEventRecord(eg0, c->stream);
-    HIPCHK(c, hipGraphLaunch(ge, c->stream));
-    hipEventRecord(eg1, c->stream);
-    clock_gettime(CLOCK_MONOTONIC, &tg3);
-    HIPCHK(c, hipStreamSynchronize(c->stream));
-    timespec tg4;
-    clock_gettime(CLOCK_MONOTONIC, &tg4);
-    float dev_ms = 0.f;
-    hipEventElapsedTime(&dev_ms, eg0, eg1);
-    hipEventDestroy(eg0);
-    hipEventDestroy(eg1);
-    if (dbg_enq) fprintf(stderr, "[hamsm] ... the graph on the device, event to event: %.2f ms\n", dev_ms);
-    auto ms = [](const timespec &a, const timespec &b_) { return (b_.tv_sec - a.tv_sec) * 1e3 + (b_.tv_nsec - a.tv_nsec) * 1e-6; };
-    if (dbg_enq)
-      fprintf(stderr, "[hamsm] training pass as a hipGraph: capture %.2f ms, instantiate %.2f ms, launch call %.2f ms, device %.2f ms\n",
-              ms(tg0, tg1), ms(tg1, tg2), ms(tg2, tg3), ms(tg3, tg4));
-    hipGraphExecDestroy(ge);
-    hipGraphDestroy(gr);
-  }
-  {
-    // (a stratum's last step may have run inside a segment, its descriptor naming the alternate tables: the check reads the
-    // stratum's own, where the segment's end has brought them)
-    std::vector<StepDev> tails;
-    for (int64_t i : tail_checks)
-      if (runs(i)) {
-        StepDev d = sd[i];
-        const Stratum &t = c->st[h_steps[i].stratum];
-        d.C = t.C, d.counts = t.counts, d.csq = t.csq, d.Bpack = t.Bpack;
-        tails.push_back(d);
-      }
-    if (!tails.empty()) {
-      HIPCHK(c, hipMemcpyAsync(b + o_tail, tails.data(), sizeof(StepDev) * tails.size(), hipMemcpyHostToDevice, c->stream));
-      for (size_t k = 0; k < tails.size(); k++)
-        hipLaunchKernelGGL(k_step_check, dim3(1), dim3(256), 0, c->stream, (const StepDev *)(b + o_tail) + k, ratio, (int)n_steps);
-      HIPCHK(c, hipStreamSynchronize(c->stream));  // (`tails` is a local)
-    }
+  if (!tail_checks.empty()) {
+    // (staged in a buffer the context owns: the asynchronous upload must not read from a local)
+    c->h_stage.resize(sizeof(StepDev) * tail_checks.size());
+    StepDev *tails = (StepDev *)c->h_stage.data();
+    for (size_t k = 0; k < tail_checks.size(); k++) tails[k] = sd[tail_checks[k]];
+    HIPCHK(c, hipMemcpyAsync(b + o_tail, tails, sizeof(StepDev) * tail_checks.size(), hipMemcpyHostToDevice, c->stream));
+    for (size_t k = 0; k < tail_checks.size(); k++)
+      hipLaunchKernelGGL(k_step_check, dim3(1), dim3(256), 0, c->stream, (const StepDev *)(b + o_tail) + k, ratio, (int)n_steps);
   }
   hamsm_timer_end(c, ST_STEP);
   if (hipError_t le = hipGetLastError(); le != hipSuccess) {
     hipDeviceSynchronize();
     return hamsm_fail(c, HAMSM_EDEVICE, "step launches: %s", hipGetErrorString(le));
   }
-  if (!h_report) break;  // (the stepwise entry point: one step, no stop protocol)
-  // where every chain stands
+  if (!h_report) {  // (the stepwise entry point: one step, no stop protocol)
+    HIPCHK(c, hipStreamSynchronize(c->stream));  // the descriptor upload reads from the local `sd`
+    return HAMSM_OK;
+  }
+  // where every chain stands: stop words + reasons, then the per-step reports
   std::vector<int32_t> hw(2 * (size_t)c->S);
   {
     hipError_t e = hipMemcpyAsync(hw.data(), b + o_halt, sizeof(int32_t) * 2 * c->S, hipMemcpyDeviceToHost, c->stream);
-    hipError_t es = hipStreamSynchronize(c->stream);  // always: `sd`, `ylist` and `hw` are locals the copies above read / write
+    if (e == hipSuccess) e = hipMemcpyAsync(h_report, b + o_rep, sizeof(int32_t) * 2 * n_steps, hipMemcpyDeviceToHost, c->stream);
+    hipError_t es = hipStreamSynchronize(c->stream);  // always: `sd` and `hw` are locals the copies above read / write
     if (e == hipSuccess) e = es;
     if (e != hipSuccess) return hamsm_fail(c, HAMSM_EDEVICE, "minibatch_run read-back: %s", hipGetErrorString(e));
   }
-  // a chain that stopped inside a pipelined segment: its tables are where its last applied step wrote them
-  if (ahead_can)
-    for (int s_ = 0; s_ < c->S; s_++) {
-      if (!live[s_] || hw[s_] == 0x7f7f7f7f) continue;
-      int64_t last = -1;
-      for (int64_t q = (int64_t)hw[s_] - 1; q >= from[s_] && q >= 0; q--)
-        if (h_steps[q].stratum == s_ && h_steps[q].n_b > 0) {
-          last = q;
-          break;
-        }
-      if (last >= 0 && ahd[last].pos >= 0 && out_alt[last]) {
-        const Stratum &t = c->st[s_];
-        const size_t kq = (size_t)((t.K + 15) & ~15);
-        HIPCHK(c, hipMemcpyAsync(t.C, altC(s_), sizeof(double) * (size_t)t.K * c->D, hipMemcpyDeviceToDevice, c->stream));
-        HIPCHK(c, hipMemcpyAsync(t.csq, altCsq(s_), sizeof(double) * kq, hipMemcpyDeviceToDevice, c->stream));
-        HIPCHK(c, hipMemcpyAsync(t.counts, altCnt(s_), sizeof(double) * (size_t)t.K, hipMemcpyDeviceToDevice, c->stream));
-        HIPCHK(c, hipMemcpyAsync(t.Bpack, altBp(s_), sizeof(double) * kq * c->KS * 4, hipMemcpyDeviceToDevice, c->stream));
-      }
-    }
-  bool again = false;
-  for (int s_ = 0; s_ < c->S; s_++) {
-    if (!live[s_]) continue;
-    if (hw[c->S + s_] == HAMSM_STOP_AHEAD) {
-      // a look-ahead block was given up at step hw[s_] (nothing of that step applied): relaunch this stratum from there
-      from[s_] = hw[s_];
-      again = true;
-      ahead_fails++;
-      c->ahead_stat[2]++;
-      if (dbg_ahead) {
-        const AheadDev &d = ahd[hw[s_]];
-        double sb[2] = {0, 0}, seen = 0, sl[AHEAD_SLOTS];
-        int32_t cn[4] = {0, 0, 0, 0};
-        hipMemcpy(sb + 1, d.bound, sizeof(double), hipMemcpyDeviceToHost);
-        hipMemcpy(cn, d.cnt, sizeof(cn), hipMemcpyDeviceToHost);
-        if (d.prev_slot) {
-          hipMemcpy(sl, d.prev_slot, sizeof(sl), hipMemcpyDeviceToHost);
-          for (double v_ : sl) seen = (v_ > seen || v_ != v_) ? v_ : seen;
-        }
-        fprintf(stderr, "[hamsm] look-ahead block of stratum %d given up at step %d (pass %d): position %d, displacement seen %.6g, "
-                "bound %.6g, undecided rows %d, open rows %d, unserved flags %d\n", s_, (int)hw[s_], pass, d.pos, seen, sb[1], cn[0], cn[2], cn[1]);
-      }
-    } else {
-      fin_halt[s_] = hw[s_];
-      fin_reason[s_] = hw[c->S + s_];
-      live[s_] = 0;
-    }
+  if (dbg_enq) {
+    timespec ts_out;
+    clock_gettime(CLOCK_MONOTONIC, &ts_out);
+    fprintf(stderr, "[hamsm] run_steps: %.3f ms from entry to the results on the host\n",
+            (ts_out.tv_sec - ts_in.tv_sec) * 1e3 + (ts_out.tv_nsec - ts_in.tv_nsec) * 1e-6);
   }
-  if (!again) break;
-  c->ahead_stat[4]++;
-  if (ahead_fails > 8 + (int)(n_steps / 128)) ahead_on = false;  // this data does not hold still: step by step from here
-  // the given-up blocks left their later positions' bitmaps and tables behind
-  HIPCHK(c, hipMemsetAsync(b + o_mb, 0, mb_bytes, c->stream));
-  for (int s_ = 0; s_ < c->S; s_++)
-    if (live[s_]) {
-      const int32_t never = 0x7f7f7f7f, zero = 0;
-      HIPCHK(c, hipMemcpyAsync(b + o_halt + sizeof(int32_t) * s_, &never, sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
-      HIPCHK(c, hipMemcpyAsync(b + o_halt + sizeof(int32_t) * (c->S + s_), &zero, sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
+  if (h_resume && h_reason) {
+    // stop word -> first step of the stratum that was not applied
+    for (int s = 0; s < c->S; s++) {
+      h_reason[s] = hw[c->S + s];
+      h_resume[s] = n_steps;
     }
-  HIPCHK(c, hipStreamSynchronize(c->stream));  // (`never` / `zero` are locals)
-  }  // passes
-  }  // !persist_done
-  else if (h_report) {
-    std::vector<int32_t> hw(2 * (size_t)c->S);
-    HIPCHK(c, hipMemcpyAsync(hw.data(), b + o_halt, sizeof(int32_t) * 2 * c->S, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
-    for (int s_ = 0; s_ < c->S; s_++) {
-      fin_halt[s_] = hw[s_];
-      fin_reason[s_] = hw[c->S + s_];
+    for (int64_t i = n_steps - 1; i >= 0; i--) {
+      const int s = h_steps[i].stratum;
+      if (i >= hw[s]) h_resume[s] = i;
     }
-  }
-  if (h_report) {
-    hipError_t e = hipMemcpyAsync(h_report, b + o_rep, sizeof(int32_t) * 2 * n_steps, hipMemcpyDeviceToHost, c->stream);
-    hipError_t es = hipStreamSynchronize(c->stream);
-    if (e == hipSuccess) e = es;
-    if (e != hipSuccess) return hamsm_fail(c, HAMSM_EDEVICE, "minibatch_run read-back: %s", hipGetErrorString(e));
-    if (getenv("HAMSM_DEBUG_ENQUEUE")) {
-      timespec ts_out;
-      clock_gettime(CLOCK_MONOTONIC, &ts_out);
-      fprintf(stderr, "[hamsm] run_steps: %.3f ms from entry to the results on the host\n",
-              (ts_out.tv_sec - ts_in.tv_sec) * 1e3 + (ts_out.tv_nsec - ts_in.tv_nsec) * 1e-6);
-    }
-    if (h_resume && h_reason) {
-      // stop word -> first step of the stratum that was not applied
-      for (int s = 0; s < c->S; s++) {
-        h_reason[s] = fin_reason[s];
-        h_resume[s] = n_steps;
-      }
-      for (int64_t i = n_steps - 1; i >= 0; i--) {
-        const int s = h_steps[i].stratum;
-        if (i >= fin_halt[s]) h_resume[s] = i;
-      }
-    }
-  } else {
-    HIPCHK(c, hipStreamSynchronize(c->stream));  // the descriptor upload reads from the local `sd`
   }
   return HAMSM_OK;
 }
+#ifdef HAMSM_EXPERIMENTS
+#include "experiments/run_steps_experiments.inc"
+#endif
 
-// (debug hooks, outside the ABI) the E-step of heavy training calls through the assignment kernels: mode 0 never, 1 by size, 2 always;
-// returns the launch groups served that way since the last call (and resets the count)
-extern "C" long long hamsm_debug_set_ranked(hamsm_ctx *c, int mode, double min_mflop) {
-  if (hamsm_ctx_check(c, __func__)) return -1;
-  if (mode >= 0) c->train_ranked = mode > 2 ? 2 : mode;
-  if (min_mflop > 0) c->ranked_min_flop = min_mflop * 1e6;
-  const long long n = c->ranked_groups;
-  c->ranked_groups = 0;
-  return n;
-}
-// (debug hooks, outside the ABI) look-ahead blocks: knobs and counters of a context
-extern "C" int hamsm_debug_set_ahead(hamsm_ctx *c, int on, int n0, int gmax, double alpha) {
-  CTX(c);
-  c->ahead = on != 0;
-  if (n0 >= 1) c->ahead_n0 = n0;
-  if (gmax >= 1) c->ahead_gmax = gmax > 16 ? 16 : gmax;
-  if (alpha >= 1.0) c->ahead_alpha = alpha;
-  return HAMSM_OK;
-}
-// out[6]: blocks launched, steps inside them, blocks given up, (unused), relaunch passes, steps run step by step; reset != 0 zeroes
-extern "C" int hamsm_debug_ahead_stats(hamsm_ctx *c, long long *out, int reset) {
-  CTX(c);
-  for (int i = 0; i < 6; i++) {
-    if (out) out[i] = c->ahead_stat[i];
-    if (reset) c->ahead_stat[i] = 0;
-  }
-  return HAMSM_OK;
-}
 
 extern "C" int hamsm_minibatch_run(hamsm_ctx *c, const void *X, int dt, int64_t ldx, const int32_t *d_rows, const double *d_w,
                                    const hamsm_step *h_steps, int64_t n_steps, double ratio, const int32_t *h_perm,

@@ -16,6 +16,19 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run by the driver with -m gpu)")
+    config.addinivalue_line("markers", "experiments: the training experiments that measured slower than the shipped path and are not "
+                                       "part of libhamsm_hip.so (csrc/experiments/, DESIGN.md 5.3a-d): `make -C msm_we_amd/csrc "
+                                       "EXPERIMENTS=1`, then `pytest -m experiments` on a GPU box")
+
+
+def pytest_collection_modifyitems(config, items):
+    """tests of csrc/experiments/ run only when asked for by their own marker (`-m experiments`): `-m gpu` skips them"""
+    if "experiments" in (config.option.markexpr or ""):
+        return
+    skip = pytest.mark.skip(reason="experiment, not part of the shipped library: make EXPERIMENTS=1 && pytest -m experiments")
+    for it in items:
+        if it.get_closest_marker("experiments"):
+            it.add_marker(skip)
 
 
 FORCED_SEEDINGS = {}   # golden case -> (k-means++ seedings replaced by the reference's, seedings compared)
@@ -66,6 +79,15 @@ def hip_lib():
         shutil.copy(os.environ["HAMSM_HIP_STANDIN"], twin)
         return ctypes.CDLL(twin)
     return _abi.load()  # raises if the HIP library is missing: no fallback
+
+
+@pytest.fixture(scope="session")
+def exp_lib():
+    """libhamsm_hip_exp.so: the product's sources + csrc/experiments/ (make EXPERIMENTS=1); never loaded by the product"""
+    path = os.path.join(ROOT, "msm_we_amd", "csrc", "libhamsm_hip_exp.so")
+    if not os.path.exists(path):
+        pytest.skip("libhamsm_hip_exp.so not built (make -C msm_we_amd/csrc EXPERIMENTS=1)")
+    return ctypes.CDLL(path)
 
 
 @pytest.fixture()

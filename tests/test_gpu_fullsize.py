@@ -527,7 +527,7 @@ def test_c5_full_size_flux_and_solve(c5_full):
     m.get_steady_state()
     m.get_steady_state_target_flux()
     ns = m.Tmatrix.shape[0]
-    assert 4000 < ns <= K + 2 and list(m.indBasis) == [ns - 2] and list(m.indTargets) == [ns - 1]
+    assert 2000 < ns <= K + 2 and list(m.indBasis) == [ns - 2] and list(m.indTargets) == [ns - 1]
     T = m.Tmatrix_csr
     np.testing.assert_allclose(np.asarray(T.sum(axis=1)).ravel(), 1.0, rtol=1e-12)
     pi = m.pSS

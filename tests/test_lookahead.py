@@ -10,7 +10,17 @@ import pytest
 from msm_we_amd import synthetic
 from test_training_paths import _run
 
-pytestmark = pytest.mark.gpu
+pytestmark = [pytest.mark.gpu, pytest.mark.experiments]   # csrc/experiments/: `make EXPERIMENTS=1`, `pytest -m experiments`
+
+
+@pytest.fixture()
+def hip_h(exp_lib):
+    """these tests drive the experiments' library, not the shipped one"""
+    from msm_we_amd import _abi
+
+    h = _abi.Hamsm(lib=exp_lib, device=0)
+    yield h
+    h.close()
 
 
 def _ahead(h, on=1, n0=2, gmax=16, alpha=1.5):
