@@ -68,6 +68,8 @@ extern "C" int hamsm_create(int device, hamsm_ctx **out) {
   if (const char *v = getenv("HAMSM_FILTER_NB")) c->filter_nb = atoi(v) < 1 ? 1 : (atoi(v) > 16 ? 16 : atoi(v));
   if (const char *v = getenv("HAMSM_FILTER_LDS_KB")) c->filter_lds_kb = atoi(v) < 40 ? 40 : (atoi(v) > 150 ? 150 : atoi(v));
   if (const char *v = getenv("HAMSM_GENERIC_STAGE_KB")) c->generic_stage_kb = atoi(v) < 0 ? 0 : (atoi(v) > 150 ? 150 : atoi(v));
+  if (const char *v = getenv("HAMSM_STEP_RANKED")) c->step_ranked = atoi(v) < 0 ? 0 : (atoi(v) > 2 ? 2 : atoi(v));
+  if (const char *v = getenv("HAMSM_STEP_RANKED_MFLOP")) c->step_ranked_min_flop = atof(v) > 0 ? atof(v) * 1e6 : c->step_ranked_min_flop;
 #ifdef HAMSM_EXPERIMENTS  // (libhamsm_hip_exp.so only: csrc/experiments/)
   if (const char *v = getenv("HAMSM_TRAIN_PERSIST")) c->train_persist = atoi(v) != 0;
   if (const char *v = getenv("HAMSM_PERSIST_WPX")) c->persist_wpx = atoi(v) < 4 ? 4 : (atoi(v) > 128 ? 128 : atoi(v));

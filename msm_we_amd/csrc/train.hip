@@ -1417,6 +1417,458 @@ __device__ __forceinline__ void upd_add_listed(double (&acc)[H], const GAS doubl
 }
 
 
+// ---- the E-step of MFMA-bound calls: centroids RANKED on the bf16 matrix unit, f64 only where the ranking cannot decide ------------
+// At BASELINE config 5's shape (12 500-row batches x 1250 centroids x 64 features per stratum and call) k_step_assign is bound by
+// the f64 matrix unit (0.47 of its peak, 107 us per launch of two strata) and the training pass is 80 % of the step.  A label is an
+// argmin: it needs the ORDER of the distances.  So, as in hamsm_assign's ranking pass (assign.hip), the scores
+//     s_j = x . c_j - csq_j / 2 = -d_j / 2
+// are formed on v_mfma_f32_32x32x16_bf16 from operands that are exact sums of bf16 pieces (truncation splits, 8 significant bits
+// each; the products x1 c1 + x1 c2 + x2 c1 of the light form: 3 MFMAs per 16 feature slots), every |(-2 s_j) - d_j| is below a
+// PROVEN bound E, and a row's label is final only if its two best scores are further apart than 2 E (x 1.01).  What is new here:
+//   * the fragments are MAINTAINED: the run packs them once (k_rank_pack), then the M-step wave that rewrites centroid j rewrites
+//     its fragment slots (rank_store_row), and so does the device re-seeding -- no conversion pass, no gather on the E-step's path
+//     (that is what sank the composition of DESIGN.md 5.3c and the on-the-fly conversion of round 1);
+//   * the ranking keeps the three best scores and the indices of the best two (4 vector instructions per ranked value).  If the
+//     third-best is out of reach of the best (2 (M1 - M3) > 2 E) but the second is not, the exact argmin is one of TWO known
+//     centroids: the row's thread evaluates the contract's two f64 fma chains itself and takes the first minimum -- 2 x D fmas
+//     instead of a sweep over all K centroids.  Only a row whose three best are within reach of each other, or whose data are not
+//     finite, is swept exactly against every centroid by the workgroup (rare: counted in `rk.stat`);
+//   * the bound's scale max_j ||c_j||^2 cannot be read off a pack kernel (the centroids move every step): a centroid is always a
+//     convex combination of the centroids the run started with and of batch rows it has seen (_k_means_minibatch.pyx:80-104 with
+//     weights >= 0; re-seeding copies a batch row), so max(||c||^2 at the start, ||x||^2 of every row seen so far) bounds it --
+//     kept as f32 bit patterns in RANK_SLOTS words per stratum (atomic max by the E-steps, which compute ||x||^2 anyway).
+// Arithmetic of the exact parts: d = fma(-2, chain, csq), chain = fma over ascending k from +0.0 -- the contract (hamsm.h), what
+// v_mfma_f64_16x16x4_f64 computes in k_step_assign; first strict minimum over ascending j.  Labels are therefore those of
+// k_step_assign bit for bit; tests/test_ranked_training.py compares whole passes with the oracle with this path forced.
+// Layout: a workgroup = 4 waves on RT tiles of 32 batch rows; every wave holds ALL the rows' operand pieces (B operand, from global
+// memory straight into registers, as k_assign_filter does) and sweeps the centroid tiles t = wave, wave + 4, ... whose fragments it
+// streams from L2 (A operand); the four partial top-3 are merged through LDS.  No barrier before that merge.
+#define RANK_SLOTS 64
+struct RankPack {
+  unsigned *apk[PACK_NY];        // [tile32][KB][2 pieces][64 lanes][4 words]: lane l = centroid l % 32, slots 16 m + 8 (l / 32) + i
+  unsigned *bnd[PACK_NY];        // [RANK_SLOTS] f32 bit patterns, max = upper bound of every ||c_j||^2 (and |csq_j|) of the stratum
+  unsigned long long *stat;      // [4] rows certified / settled between two candidates / swept exactly / (unused)   (nullable)
+};
+typedef float v16f32 __attribute__((ext_vector_type(16)));
+typedef __bf16 v8bf16 __attribute__((ext_vector_type(8)));
+typedef unsigned v4u32 __attribute__((ext_vector_type(4)));
+
+// fragment slots of ONE centroid row: lane k < D holds feature k's new value; `csq` (all lanes) its new ||c||^2
+__device__ __forceinline__ void rank_store_row(GAS unsigned short *apk, int KB, int j, int lane, int D, double vk, double csq) {
+  const size_t tile = (size_t)(j >> 5) * KB;
+  const int row = j & 31;
+  auto put = [&](int k, float vf) {
+    const unsigned b0 = __float_as_uint(vf), p1 = b0 & 0xffff0000u;
+    const float r1 = vf - __uint_as_float(p1);
+    const size_t at = (((tile + (k >> 4)) * 2) * 64 + (row + 32 * ((k >> 3) & 1))) * 8 + (k & 7);  // piece 0; piece 1 is 64 * 8 further
+    apk[at] = (unsigned short)(p1 >> 16);
+    apk[at + 512] = (unsigned short)(__float_as_uint(r1) >> 16);
+  };
+  if (lane < D) put(lane, (float)vk);
+  if (lane == 0) put(D, (float)(-0.5 * csq));
+}
+
+// the run's fragments and bounds from the strata's tables (one wave per 32-centroid tile)
+__global__ __launch_bounds__(64) void k_rank_pack(const double *__restrict__ C, const double *__restrict__ csq, int K, int D, int KB,
+                                                  unsigned *__restrict__ apk, unsigned *__restrict__ bnd) {
+  const int jt = blockIdx.x, lane = threadIdx.x, row = lane & 31, h = lane >> 5, j = jt * 32 + row;
+  const bool live = j < K;
+  const double cs = live ? csq[j] : 0.0;
+  double n2 = 0.0;
+  for (int m = 0; m < KB; m++) {
+    unsigned w[2][4];
+    for (int i = 0; i < 8; i++) {
+      const int k = 16 * m + 8 * h + i;
+      const double v = (live && k < D) ? C[(size_t)j * D + k] : 0.0;
+      n2 += v * v;
+      float vf = (float)v;
+      if (k == D) vf = live ? (float)(-0.5 * cs) : -3.0e38f;  // (a row past K never ranks first; finite: its index bits must not make a NaN)
+      const unsigned p1 = __float_as_uint(vf) & 0xffff0000u;
+      const unsigned p2 = __float_as_uint(vf - __uint_as_float(p1)) & 0xffff0000u;
+      if (i & 1) {
+        w[0][i >> 1] |= p1;
+        w[1][i >> 1] |= p2;
+      } else {
+        w[0][i >> 1] = p1 >> 16;
+        w[1][i >> 1] = p2 >> 16;
+      }
+    }
+    for (int q = 0; q < 2; q++)
+      for (int z = 0; z < 4; z++) apk[((((size_t)jt * KB + m) * 2 + q) * 64 + lane) * 4 + z] = w[q][z];
+  }
+  n2 += __shfl_xor(n2, 32, 64);
+  if (h == 0 && live) {  // (non-negative floats order like their bit patterns; NaN patterns sort above +inf and poison the bound)
+    const float a = (float)n2 * 1.000001f, b = __builtin_fabsf((float)cs) * 1.000001f;
+    atomicMax(&bnd[j & (RANK_SLOTS - 1)], __float_as_uint(a > b || !(b == b) ? a : b));
+  }
+}
+
+// (A1 >= A2 >= A3 with the indices of A1, A2) merged with another such triple: the three largest of the six, indices of the two
+// largest; equal values: the lower index first
+__device__ __forceinline__ void rank_merge3(float &A1, float &A2, float &A3, int &ja1, int &ja2, float B1, float B2, float B3, int jb1,
+                                            int jb2) {
+  if (B1 > A1 || (B1 == A1 && jb1 < ja1)) {
+    float t;
+    int u;
+    t = A1, A1 = B1, B1 = t;
+    t = A2, A2 = B2, B2 = t;
+    t = A3, A3 = B3, B3 = t;
+    u = ja1, ja1 = jb1, jb1 = u;
+    u = ja2, ja2 = jb2, jb2 = u;
+  }
+  if (B1 > A2 || (B1 == A2 && jb1 < ja2)) {
+    A3 = __builtin_fmaxf(A2, B2);
+    A2 = B1;
+    ja2 = jb1;
+  } else
+    A3 = __builtin_fmaxf(A3, B1);
+}
+
+template <typename XT, int KB, int RT>
+__global__ __launch_bounds__(256, 2) void k_step_assign_ranked(const StepPack pk, const RankPack rk, int64_t ldx, int D, int KS,
+                                                               double ratio, float c1, float c2, unsigned long long *stamp) {
+  if (stamp && threadIdx.x == 0) atomicMin(&stamp[0], (unsigned long long)wall_clock64());
+  constexpr int RW = 32 * RT;  // rows per workgroup
+  const StepDev sdesc = pk.s[blockIdx.y];
+  const StepG st(sdesc);
+  const long long r0 = (long long)blockIdx.x * RW;
+  if (r0 >= st.n_b) return;
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, row = lane & 31, h = lane >> 5;
+  const GAS XT *X = (const GAS XT *)st.X;
+  const GAS v4u32 *apk = (const GAS v4u32 *)gp(rk.apk[blockIdx.y]);
+  GAS unsigned *bndw = gp(rk.bnd[blockIdx.y]);
+  const float ninf = -__builtin_huge_valf();
+  const double inf = __builtin_huge_val();
+  __shared__ float s_m[4][RW][3];
+  __shared__ int s_j[4][RW][2];
+  __shared__ float s_x[RW];
+  __shared__ int s_full[RW], s_nfull;
+  __shared__ double s_d[4];
+  __shared__ int s_i[4];
+  __shared__ double s_row[64];
+  if (tid == 0) s_nfull = 0;
+  // the rows: lane l carries batch row l % 32 of each tile, the 8 feature slots 16 m + 8 (l / 32) + i of every 16-slot block
+  long long fr[RT];
+#pragma unroll
+  for (int rt = 0; rt < RT; rt++) {
+    const long long r = r0 + rt * 32 + row;
+    const long long rc = r < st.n_b ? r : st.n_b - 1;  // (rows past the batch repeat its last row; nothing of them is kept)
+    fr[rt] = st.rows ? (long long)st.rows[rc] : rc;
+  }
+  unsigned bu = bndw[lane & (RANK_SLOTS - 1)];
+  const int njt = (st.K + 31) >> 5;
+  // this wave's first centroid tile does not depend on the rows: requested before the gather waits for the row indices
+  struct Frag {
+    v4u32 c[KB][2];
+  };
+  auto load_frag = [&](int t) {
+    Frag f;
+    const GAS v4u32 *ap = apk + (size_t)(t < njt ? t : njt - 1) * (KB * 2 * 64) + lane;
+#pragma unroll
+    for (int m = 0; m < KB; m++) {
+      f.c[m][0] = ap[(m * 2 + 0) * 64];
+      f.c[m][1] = ap[(m * 2 + 1) * 64];
+    }
+    return f;
+  };
+  Frag cur = load_frag(wv);
+  typedef XT xt4u __attribute__((ext_vector_type(4), aligned(sizeof(XT))));
+  v4u32 x1[RT][KB], x2[RT][KB];
+  float xn2[RT];
+  const int ldg = 4 * KS;
+#pragma unroll
+  for (int rt = 0; rt < RT; rt++) {
+    const GAS XT *rp = X + fr[rt] * ldx;
+    XT raw[KB][8];
+#pragma unroll
+    for (int m = 0; m < KB; m++) {
+      const int k0 = 16 * m + 8 * h;
+      if (16 * m + 16 <= D) {  // (wave-uniform) both half-waves stay inside the row
+        const xt4u va = *(const GAS xt4u *)(rp + k0), vb = *(const GAS xt4u *)(rp + k0 + 4);
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+          raw[m][i] = va[i];
+          raw[m][4 + i] = vb[i];
+        }
+      } else {
+#pragma unroll
+        for (int i = 0; i < 8; i++) {  // (slots past the row arrive as zeros; the load itself stays inside the row)
+          const int k = k0 + i;
+          const XT v = rp[k < D ? k : D - 1];
+          raw[m][i] = k < D ? v : (XT)0;
+        }
+      }
+    }
+    float q2 = 0.f;
+    const bool copy = ((rt + 1) & 3) == wv;  // the batch rows as f64 for the M-step: tile rt by wave (rt + 1) & 3
+    const long long r = r0 + rt * 32 + row;
+#pragma unroll
+    for (int m = 0; m < KB; m++)
+#pragma unroll
+      for (int w = 0; w < 4; w++) {
+        float a0[2], a1[2];
+#pragma unroll
+        for (int i = 0; i < 2; i++) {
+          const float v = (float)raw[m][2 * w + i];
+          q2 = __builtin_fmaf(v, v, q2);
+          a0[i] = v;
+          a1[i] = v - __uint_as_float(__float_as_uint(v) & 0xffff0000u);
+          const int k = 16 * m + 8 * h + 2 * w + i;
+          if (copy && k < ldg) st.Xg[(size_t)r * ldg + k] = (double)raw[m][2 * w + i];  // (whole tiles of the padded batch: unconditional in r)
+        }
+        // slot D of the operand is the constant 1 (the csq term): its bf16 pattern in piece 1
+        const int ke = 16 * m + 8 * h + 2 * w;
+        const unsigned one = (ke == D ? 0x3f80u : 0u) | (ke + 1 == D ? 0x3f800000u : 0u);
+        x1[rt][m][w] = __builtin_amdgcn_perm(__float_as_uint(a0[1]), __float_as_uint(a0[0]), 0x07060302u) | one;
+        x2[rt][m][w] = __builtin_amdgcn_perm(__float_as_uint(a1[1]), __float_as_uint(a1[0]), 0x07060302u);
+      }
+    q2 += __shfl_xor(q2, 32, 64);
+    xn2[rt] = q2;
+  }
+  if (blockIdx.x == 0 && (st.flags & 6) && st.idx < *gp(sdesc.halt)) {
+    // (k_step_assign's block, unchanged: the stratum's chain is live.)  `counts < ratio * max(counts)` for the stratum's previous
+    // step when the host predicted that none would be low (_kmeans.py:1645), `(counts == 0).any()` before this one (:2037)
+    const GAS int32_t *prev = gp(sdesc.prev_report);
+    int z = 0;
+    double mx = -inf;
+    for (int j = tid; j < st.K; j += 256) {
+      double cj = st.counts[j];
+      z |= (cj == 0.0);
+      mx = cj > mx ? cj : mx;
+    }
+    int any_low = 0;
+    if (st.flags & 4) {
+#pragma unroll
+      for (int off = 32; off >= 1; off >>= 1) {
+        double o = __shfl_xor(mx, off, 64);
+        mx = o > mx ? o : mx;
+      }
+      if (lane == 0) s_d[wv] = mx;
+      __syncthreads();
+      mx = s_d[0];
+#pragma unroll
+      for (int w = 1; w < 4; w++) mx = s_d[w] > mx ? s_d[w] : mx;
+      const double thr = ratio * mx;
+      int low = 0;
+      for (int j = tid; j < st.K; j += 256) low += st.counts[j] < thr;
+      if (low) __hip_atomic_fetch_add((GAS int32_t *)prev + 1, low, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      any_low = __syncthreads_or(low);
+    }
+    const int any_z = __syncthreads_or((st.flags & 2) ? z : 0);
+    if (tid == 0) {
+      if (any_low) {
+        *gp(sdesc.halt) = st.idx;
+        *gp(sdesc.reason) = HAMSM_STOP_LOW;
+      } else if (any_z) {
+        st.report[0] = 1;
+        *gp(sdesc.halt) = st.idx;
+        *gp(sdesc.reason) = HAMSM_STOP_ZERO;
+      }
+    }
+  }
+  // ---- the sweep: three largest scores per row (and half-wave), the tiles of the largest two ----
+  float M1[RT], M2[RT], M3[RT];
+  int J1[RT], J2[RT];
+#pragma unroll
+  for (int rt = 0; rt < RT; rt++) {
+    M1[rt] = M2[rt] = M3[rt] = ninf;
+    J1[rt] = J2[rt] = 0;
+  }
+  v16f32 zero;
+#pragma unroll
+  for (int r = 0; r < 16; r++) zero[r] = 0.f;
+  for (int t = wv; t < njt; t += 4) {
+    const Frag nxt = load_frag(t + 4);  // (clamped; unused past the last tile)
+#pragma unroll
+    for (int rt = 0; rt < RT; rt++) {
+      v16f32 acc;
+#pragma unroll
+      for (int m = 0; m < KB; m++) {
+        const v8bf16 a1 = __builtin_bit_cast(v8bf16, cur.c[m][0]), a2 = __builtin_bit_cast(v8bf16, cur.c[m][1]);
+        const v8bf16 b1 = __builtin_bit_cast(v8bf16, x1[rt][m]), b2 = __builtin_bit_cast(v8bf16, x2[rt][m]);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b2, m == 0 ? zero : acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, b1, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, acc, 0, 0, 0);
+      }
+      const unsigned o1 = __float_as_uint(M1[rt]), o2 = __float_as_uint(M2[rt]);
+#pragma unroll
+      for (int r = 0; r < 16; r++) {
+        // the accumulator register's number rides in the 4 low mantissa bits (the bound charges the 16 ulp): the maxima know
+        // their own index.  Written as instructions: through the builtins the compiler canonicalises v first.
+        const float v = __uint_as_float((__float_as_uint(acc[r]) & 0xfffffff0u) | (unsigned)r);
+        float m3n, m2n, m1n;
+        asm("v_med3_f32 %0, %1, %2, %3" : "=v"(m3n) : "v"(M2[rt]), "v"(M3[rt]), "v"(v));
+        asm("v_med3_f32 %0, %1, %2, %3" : "=v"(m2n) : "v"(M1[rt]), "v"(M2[rt]), "v"(v));
+        asm("v_max_f32 %0, %1, %2" : "=v"(m1n) : "v"(M1[rt]), "v"(v));
+        M3[rt] = m3n;
+        M2[rt] = m2n;
+        M1[rt] = m1n;
+      }
+      // whose tile?  (a value whose bits equal the old maximum's while a larger one arrived in this tile may be the demoted old
+      // maximum or a twin of it from this tile: then both are among the three best, M2 == M3, and the row is never settled
+      // between two candidates)
+      const bool ch1 = __float_as_uint(M1[rt]) != o1, ch2 = __float_as_uint(M2[rt]) != o2;
+      J2[rt] = ch2 ? ((ch1 && __float_as_uint(M2[rt]) == o1) ? J1[rt] : t) : J2[rt];
+      J1[rt] = ch1 ? t : J1[rt];
+    }
+    cur = nxt;
+  }
+  // -> centroid indices; lanes l and l ^ 32 (same row, the other half of every tile's centroids) merged; one triple per wave and row
+#pragma unroll
+  for (int rt = 0; rt < RT; rt++) {
+    const int q1 = (int)(__float_as_uint(M1[rt]) & 15u), q2 = (int)(__float_as_uint(M2[rt]) & 15u);
+    int j1 = J1[rt] * 32 + 8 * (q1 >> 2) + 4 * h + (q1 & 3), j2 = J2[rt] * 32 + 8 * (q2 >> 2) + 4 * h + (q2 & 3);
+    float a1 = M1[rt], a2 = M2[rt], a3 = M3[rt];
+    rank_merge3(a1, a2, a3, j1, j2, __shfl_xor(M1[rt], 32, 64), __shfl_xor(M2[rt], 32, 64), __shfl_xor(M3[rt], 32, 64),
+                __shfl_xor(j1, 32, 64), __shfl_xor(j2, 32, 64));
+    if (lane < 32) {
+      s_m[wv][rt * 32 + row][0] = a1;
+      s_m[wv][rt * 32 + row][1] = a2;
+      s_m[wv][rt * 32 + row][2] = a3;
+      s_j[wv][rt * 32 + row][0] = j1;
+      s_j[wv][rt * 32 + row][1] = j2;
+      if (wv == 0) s_x[rt * 32 + row] = xn2[rt];
+    }
+  }
+  __syncthreads();
+  // ---- one thread per row: certify, or settle between the two candidates exactly ----
+  // the bound's scale: the largest of the stratum's RANK_SLOTS words (as integers: a NaN pattern wins and nothing is certified)
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) {
+    const unsigned o = __shfl_xor(bu, off, 64);
+    bu = o > bu ? o : bu;
+  }
+  const float bnd = __uint_as_float(bu);
+  const float thr_x = c1 * 1.000001f * __builtin_sqrtf(bnd) * 1.000001f, thr_0 = c2 * bnd + 1e-30f;
+  int label = -1, kind = 0;  // kind: 0 certified, 1 settled between two candidates, 2 swept exactly
+  bool full = false;
+  const long long rme = r0 + tid;
+  const bool mine = tid < RW && rme < st.n_b;
+  float xq = 0.f;
+  if (mine) {
+    float a1 = s_m[0][tid][0], a2 = s_m[0][tid][1], a3 = s_m[0][tid][2];
+    int j1 = s_j[0][tid][0], j2 = s_j[0][tid][1];
+#pragma unroll
+    for (int w = 1; w < 4; w++) rank_merge3(a1, a2, a3, j1, j2, s_m[w][tid][0], s_m[w][tid][1], s_m[w][tid][2], s_j[w][tid][0], s_j[w][tid][1]);
+    xq = s_x[tid];
+    const float thr = thr_x * __builtin_sqrtf(xq) + thr_0;
+    // (scores can only be infinite -- and their index bits turn an infinity into a signalling NaN -- if the operands are this large)
+    const bool tame = xq * bnd < 1e36f;
+    if (tame && 2.f * (a1 - a2) > thr && j1 < st.K) {  // d = -2 s; every NaN: the comparison is false
+      label = j1;
+    } else if (tame && 2.f * (a1 - a3) > thr && j1 != j2 && j1 < st.K && j2 < st.K) {
+      const long long f = st.rows ? (long long)st.rows[rme] : rme;
+      const GAS XT *xr = X + f * ldx;
+      const int lo = j1 < j2 ? j1 : j2, hi = j1 < j2 ? j2 : j1;
+      const GAS double *cl = st.C + (size_t)lo * D, *ch = st.C + (size_t)hi * D;
+      double dl = 0.0, dh = 0.0;
+      for (int k0 = 0; k0 < D; k0 += 8) {  // 3 x 8 loads in flight, then the two chains' 8 steps each
+        double xv[8], lv[8], hv[8];
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+          const int k = k0 + i < D ? k0 + i : D - 1;
+          xv[i] = (double)xr[k];
+          lv[i] = cl[k];
+          hv[i] = ch[k];
+        }
+#pragma unroll
+        for (int i = 0; i < 8; i++)
+          if (k0 + i < D) {
+            dl = __builtin_fma(lv[i], xv[i], dl);
+            dh = __builtin_fma(hv[i], xv[i], dh);
+          }
+      }
+      dl = __builtin_fma(-2.0, dl, st.csq[lo]);
+      dh = __builtin_fma(-2.0, dh, st.csq[hi]);
+      label = dl <= dh ? lo : (dh < dl ? hi : -1);  // first strict minimum over ascending j; a NaN: to the exact sweep
+      if (label < 0) full = true;
+      else kind = 1;
+    } else
+      full = true;
+    if (full) s_full[atomicAdd(&s_nfull, 1)] = tid;
+  }
+  // the rows seen so far bound the centroids to come (see the header): wave 0 publishes its largest ||x||^2
+  if (wv == 0) {
+    float mq = mine ? xq * 1.00001f : 0.f;
+    if (RT == 1) mq = lane < 32 ? mq : 0.f;
+    unsigned mu = __float_as_uint(mq);  // (non-negative or NaN: ordered like its bit pattern)
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+      const unsigned o = __shfl_xor(mu, off, 64);
+      mu = o > mu ? o : mu;
+    }
+    if (lane == 0 && mu > bu) atomicMax((unsigned *)&bndw[blockIdx.x & (RANK_SLOTS - 1)], mu);
+  }
+  __syncthreads();
+  // ---- rows the ranking could not narrow down: the contract's distances to EVERY centroid, by the whole workgroup ----
+  const int nfull = s_nfull;
+  for (int e = 0; e < nfull; e++) {
+    const int lr = s_full[e];
+    const long long r = r0 + lr, f = st.rows ? (long long)st.rows[r] : r;
+    if (tid < D) s_row[tid] = (double)X[f * ldx + tid];
+    __syncthreads();
+    double bd = inf;
+    int bj = 0x7fffffff;
+    for (int j = tid; j < st.K; j += 256) {  // a thread's centroids ascend: strict < keeps its lowest index
+      const GAS double *cj = st.C + (size_t)j * D;
+      double dot = 0.0;
+      for (int k0 = 0; k0 < D; k0 += 8) {
+        double cv[8];
+#pragma unroll
+        for (int i = 0; i < 8; i++) cv[i] = cj[k0 + i < D ? k0 + i : D - 1];
+#pragma unroll
+        for (int i = 0; i < 8; i++)
+          if (k0 + i < D) dot = __builtin_fma(cv[i], s_row[k0 + i], dot);
+      }
+      const double d = __builtin_fma(-2.0, dot, st.csq[j]);
+      if (d < bd) {
+        bd = d;
+        bj = j;
+      }
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+      const double d2 = __shfl_xor(bd, off, 64);
+      const int j2 = __shfl_xor(bj, off, 64);
+      const bool take = (d2 < bd) || (d2 == bd && j2 < bj);
+      bd = take ? d2 : bd;
+      bj = take ? j2 : bj;
+    }
+    if (lane == 0) {
+      s_d[wv] = bd;
+      s_i[wv] = bj;
+    }
+    __syncthreads();
+    if (tid == lr) {
+      double d = s_d[0];
+      int j = s_i[0];
+#pragma unroll
+      for (int w = 1; w < 4; w++) {
+        const bool take = (s_d[w] < d) || (s_d[w] == d && s_i[w] < j);
+        d = take ? s_d[w] : d;
+        j = take ? s_i[w] : j;
+      }
+      label = j == 0x7fffffff ? 0 : j;  // all-NaN row: label 0 like the oracle
+    }
+    __syncthreads();
+  }
+  if (mine) {
+    st.labels[rme] = label;
+    // (result unused: a non-returning atomic -- the workgroup does not wait for it)
+    __hip_atomic_fetch_or(&st.mbits[(size_t)label * sdesc.wstride + (rme >> 6)], 1ull << (rme & 63), __ATOMIC_RELAXED,
+                          __HIP_MEMORY_SCOPE_AGENT);
+  }
+  if (wv == 0 && rk.stat) {  // (the rows' threads all sit in wave 0: one add per kind and workgroup)
+    kind = full ? 2 : kind;
+#pragma unroll
+    for (int q = 0; q < 3; q++) {
+      const int n = __popcll(__ballot(mine && kind == q));
+      if (lane == 0 && n) atomicAdd(rk.stat + q, (unsigned long long)n);
+    }
+  }
+  if (stamp && threadIdx.x == 0) atomicMax(&stamp[1], (unsigned long long)wall_clock64());
+}
+
 // M-step: one wave per centroid.  Round trip 1 fetches the centroid's membership bitmap (one word per lane), its count
 // and its row; the set bits ARE the members in ascending sample order (no list to sort, no cap on the cluster size):
 // each lane expands its word into the wave's LDS strip at the position given by a prefix sum of the popcounts.
@@ -1424,9 +1876,10 @@ __device__ __forceinline__ void upd_add_listed(double (&acc)[H], const GAS doubl
 // (_k_means_minibatch.pyx:59-108).
 #define UPD_LIST 1024
 #define UPD_SC 768  // member rows the strip holds per pass: ints [0, 768); weights of a 64-member chunk: ints [768, 896)
+// (`apk` != null -- the ranked E-step's run, below: the wave also rewrites its centroid's bf16 fragments, KB blocks of 16 slots)
 template <typename XT, int H, bool BYVAL, int UPD_NBK>
-__global__ __launch_bounds__(256) void k_step_update(const StepDev *__restrict__ steps, const StepPack pk, int64_t ldx, int D,
-                                                     int KS) {
+__device__ __forceinline__ void step_update_body(const StepDev *__restrict__ steps, const StepPack &pk, int64_t ldx, int D, int KS,
+                                                 GAS unsigned short *apk, int KB) {
   SPROF_ID
   SPROF(1, 0)
   const StepDev sdesc = load_step<BYVAL>(steps, pk, blockIdx.y);
@@ -1553,11 +2006,23 @@ __global__ __launch_bounds__(256) void k_step_update(const StepDev *__restrict__
   }
   if (D & 1) a = __builtin_fma(vb[D - 1], vb[D - 1], a);
   if (lane == 0) st.csq[j] = a;
+  if constexpr (H == 1) {
+    if (apk) rank_store_row(apk, KB, j, lane, D, v[0], a);
+  }
   SPROF_W(1, 5)
 #if defined(STEP_PROFILE) && STEP_PROFILE < 2
   SPROF(1, 5)
 #endif
   SPROF_FLUSH(1)
+}
+template <typename XT, int H, bool BYVAL, int UPD_NBK>
+__global__ __launch_bounds__(256) void k_step_update(const StepDev *__restrict__ steps, const StepPack pk, int64_t ldx, int D,
+                                                     int KS) {
+  step_update_body<XT, H, BYVAL, UPD_NBK>(steps, pk, ldx, D, KS, nullptr, 0);
+}
+template <typename XT, int UPD_NBK>
+__global__ __launch_bounds__(256) void k_step_update_ranked(const StepPack pk, const RankPack rk, int64_t ldx, int D, int KS, int KB) {
+  step_update_body<XT, 1, true, UPD_NBK>(nullptr, pk, ldx, D, KS, (GAS unsigned short *)gp(rk.apk[blockIdx.y]), KB);
 }
 
 
@@ -1612,8 +2077,8 @@ __global__ __launch_bounds__(256) void k_step_check(const StepDev *__restrict__ 
 // row perm[i]; their counts become min(counts[~to_reassign]).  One workgroup per step.  When the prediction behind
 // the permutation fails (nothing low, or more than the rule / the supplied head allows) the stratum's chain stops.
 template <typename XT, bool BYVAL>
-__global__ __launch_bounds__(256) void k_step_reassign(const StepDev *__restrict__ steps, const StepPack pk, int64_t ldx, int D,
-                                                       int KS, double ratio) {
+__device__ __forceinline__ void step_reassign_body(const StepDev *__restrict__ steps, const StepPack &pk, int64_t ldx, int D, int KS,
+                                                   double ratio, GAS unsigned short *apk, int KB) {
   const StepDev sdesc = load_step<BYVAL>(steps, pk, blockIdx.x);
   const StepG st(sdesc);
   if (!(st.flags & 1) || !sdesc.perm || st.idx >= *gp(sdesc.halt)) return;
@@ -1730,10 +2195,21 @@ __global__ __launch_bounds__(256) void k_step_reassign(const StepDev *__restrict
         st.csq[jc] = a;
         st.counts[jc] = new_count;
       }
+      if (apk) rank_store_row(apk, KB, jc, lane, D, v[0], a);  // (the ranked E-step's run: D <= 64, one feature per lane)
     }
     base += total;
     __syncthreads();
   }
+}
+template <typename XT, bool BYVAL>
+__global__ __launch_bounds__(256) void k_step_reassign(const StepDev *__restrict__ steps, const StepPack pk, int64_t ldx, int D,
+                                                       int KS, double ratio) {
+  step_reassign_body<XT, BYVAL>(steps, pk, ldx, D, KS, ratio, nullptr, 0);
+}
+template <typename XT>
+__global__ __launch_bounds__(256) void k_step_reassign_ranked(const StepPack pk, const RankPack rk, int64_t ldx, int D, int KS, double ratio,
+                                                              int KB) {
+  step_reassign_body<XT, true>(nullptr, pk, ldx, D, KS, ratio, (GAS unsigned short *)gp(rk.apk[blockIdx.x]), KB);
 }
 
 // ---- more than 128 features: generic training kernels ---------------------------------------------------
@@ -2203,6 +2679,63 @@ static int launch_steps(hamsm_ctx *c, hipStream_t q, const StepDev *d_steps, con
 }
 
 
+// the ranked form of a launch group (descriptors by value, <= PACK_NY strata): E-step on the bf16 matrix unit, the M-step and the
+// device re-seeding in the forms that also maintain the fragments
+template <typename XT>
+static int launch_steps_ranked(hamsm_ctx *c, hipStream_t q, const StepPack &pk, const RankPack &rk, int ny, long long max_nb, int maxK,
+                               int64_t ldx, double ratio, bool any_perm) {
+  const int KB = (c->D + 16) / 16;  // blocks of 16 feature slots: the features, the csq slot, padding
+  // the light form's certificate (assign.hip, launch_sorted): 3 MFMAs x 17 roundings per 16 slots, taken four times (204 KB);
+  // the three dropped 2^-14-level piece products (6186 u, u = 2^-24); rounding of c and of f64 frames to f32 (2 u); the index
+  // bits (64 u, 32 u); the csq slot loses its third piece (1024 u)
+  const float c1 = 2.02f * (float)(6186 + 2 * (2 + 204 * KB) + 64) / 16777216.0f;
+  const float c2 = 2.02f * (float)(1024 + 204 * KB + 1 + 32) / 16777216.0f;
+  const char *rt_s = getenv("HAMSM_RANKED_RT");  // (tests / experiments force a tile count)
+  const long long tiles = (max_nb + 31) / 32 * ny;
+  const int rt = rt_s ? (atoi(rt_s) == 2 ? 2 : 1) : (tiles >= 2 * 256 ? 2 : 1);
+  const dim3 ga((unsigned)((max_nb + 32 * rt - 1) / (32 * rt)), (unsigned)ny);
+  const bool sample = q == c->stream && !HAMSM_CAPTURING(c) && c->ks_stamps && (c->ks_tick++ & 127) == 0 && c->ks_pending.size() < HAMSM_KS_SLOTS;
+  hamsm_ctx::KSample ks{nullptr, nullptr, nullptr};
+  unsigned long long *stamp = nullptr;
+  if (sample) {
+    stamp = c->ks_stamps + 2 * c->ks_pending.size();
+    auto ev = [&]() {
+      if (!c->ks_free.empty()) {
+        hipEvent_t e = c->ks_free.back();
+        c->ks_free.pop_back();
+        return e;
+      }
+      hipEvent_t e = nullptr;
+      hipEventCreate(&e);
+      return e;
+    };
+    ks.e0 = ev();
+    ks.e1 = ev();
+    ks.e2 = ev();
+    hipEventRecord(ks.e0, q);
+  }
+  switch (KB * 2 + (rt - 1)) {
+#define CASE(KBV, RTV)                                                                                                              \
+  case KBV * 2 + (RTV - 1):                                                                                                         \
+    hipLaunchKernelGGL((k_step_assign_ranked<XT, KBV, RTV>), ga, dim3(256), 0, q, pk, rk, ldx, c->D, c->KS, ratio, c1, c2, stamp);  \
+    break;
+    CASE(1, 1) CASE(1, 2) CASE(2, 1) CASE(2, 2) CASE(3, 1) CASE(3, 2) CASE(4, 1) CASE(4, 2) CASE(5, 1) CASE(5, 2)
+#undef CASE
+    default: return hamsm_fail(c, HAMSM_ENOTSUP, "ranked E-step: %d blocks of feature slots", KB);
+  }
+  if (sample) hipEventRecord(ks.e1, q);
+  const size_t lds = sizeof(int) * (4 * UPD_LIST);
+  const dim3 gu((unsigned)((maxK + 3) / 4), (unsigned)ny);
+  if (max_nb > 4096) hipLaunchKernelGGL((k_step_update_ranked<XT, 4>), gu, dim3(256), lds, q, pk, rk, ldx, c->D, c->KS, KB);
+  else hipLaunchKernelGGL((k_step_update_ranked<XT, 1>), gu, dim3(256), lds, q, pk, rk, ldx, c->D, c->KS, KB);
+  if (sample) {
+    hipEventRecord(ks.e2, q);
+    c->ks_pending.push_back(ks);
+  }
+  if (any_perm) hipLaunchKernelGGL((k_step_reassign_ranked<XT>), dim3((unsigned)ny), dim3(256), 0, q, pk, rk, ldx, c->D, c->KS, ratio, KB);
+  return HAMSM_OK;
+}
+
 // steps [0,n): consecutive steps of distinct strata share launches (grid.y)
 #ifdef HAMSM_EXPERIMENTS
 static int run_steps_experiments(hamsm_ctx *c, const void *X, int dt, int64_t ldx, const int32_t *d_rows, const double *d_w,
@@ -2272,6 +2805,23 @@ static int run_steps(hamsm_ctx *c, const void *X, int dt, int64_t ldx, const int
   const int wstride = (int)((((nb_max + 63) >> 6) + 63) & ~(int64_t)63);  // bitmap words per centroid
   const size_t mb_bytes = sizeof(unsigned long long) * (size_t)nslot * Kmax * wstride;
   size_t o_mb = take(mb_bytes), o_tail = take(sizeof(StepDev) * (size_t)c->S);
+  // Calls whose E-step is bound by the f64 matrix unit rank their centroids on the bf16 unit instead (k_step_assign_ranked: same
+  // labels).  Decided per run -- the fragments are maintained from step to step -- by its heaviest launch group; at most 64
+  // features, a planned pass with row lists.  HAMSM_STEP_RANKED = 0 never, 1 by size (default), 2 always (tests).
+  const int KBr = (c->D + 16) / 16;
+  bool ranked = c->step_ranked && c->assign_filter && !generic && c->KS <= 16 && d_rows && h_report && nslot == c->S;
+  if (ranked && c->step_ranked == 1) {
+    double top = 0;
+    for (size_t g = 0; g + 1 < gstart.size(); g++) {
+      double flop = 0;
+      for (int64_t q = gstart[g]; q < gstart[g + 1]; q++) flop += 2.0 * (double)h_steps[q].n_b * c->st[h_steps[q].stratum].K * c->D;
+      top = flop > top ? flop : top;
+    }
+    ranked = top >= c->step_ranked_min_flop;
+  }
+  const size_t apk_words = (size_t)((Kmax + 31) / 32) * KBr * 2 * 256;  // per stratum
+  size_t o_apk = take(ranked ? sizeof(unsigned) * apk_words * (size_t)c->S : 0), o_bnd = take(ranked ? sizeof(unsigned) * RANK_SLOTS * (size_t)c->S : 0),
+         o_rstat = take(sizeof(unsigned long long) * 4);
   int rc = hamsm_ensure_scratch(c, off);
   if (rc) return rc;
   char *b = (char *)c->scratch;
@@ -2334,6 +2884,18 @@ static int run_steps(hamsm_ctx *c, const void *X, int dt, int64_t ldx, const int
   const StepDev *d_steps = (const StepDev *)(b + o_steps);
   const bool dbg_enq = getenv("HAMSM_DEBUG_ENQUEUE") != nullptr;
   hamsm_timer_begin(c);
+  if (ranked) {
+    // the run's fragments and bounds, from the tables as they stand (whoever changed them between runs -- the host's settling of
+    // a stopped chain, a new seeding -- needs no hook)
+    HIPCHK(c, hipMemsetAsync(b + o_bnd, 0, sizeof(unsigned) * RANK_SLOTS * (size_t)c->S, c->stream));
+    HIPCHK(c, hipMemsetAsync(b + o_rstat, 0, sizeof(unsigned long long) * 4, c->stream));
+    for (int s = 0; s < c->S; s++) {
+      const Stratum &t = c->st[s];
+      if (t.K > 0)
+        hipLaunchKernelGGL(k_rank_pack, dim3((unsigned)((t.K + 31) / 32)), dim3(64), 0, c->stream, (const double *)t.C, (const double *)t.csq, t.K,
+                           c->D, KBr, (unsigned *)(b + o_apk) + apk_words * s, (unsigned *)(b + o_bnd) + RANK_SLOTS * s);
+    }
+  }
   // lanes: stratum s always runs on queue s % n_lanes, so every stratum's chain stays ordered; a lane's part of a
   // launch group travels by value (<= PACK_NY strata) -- otherwise one queue and descriptors in memory
   int n_lanes = c->step_lanes;
@@ -2378,6 +2940,36 @@ static int run_steps(hamsm_ctx *c, const void *X, int dt, int64_t ldx, const int
       }
       const int ny = (int)mine.size();
       if (ny == 0 || max_nb <= 0) continue;
+      if (ranked) {
+        for (size_t c0_ = 0; c0_ < mine.size() && !rc; c0_ += PACK_NY) {  // (descriptors by value: PACK_NY strata per launch)
+          const int nyc = (int)(mine.size() - c0_ < PACK_NY ? mine.size() - c0_ : PACK_NY);
+          RankPack rk;
+          memset(&rk, 0, sizeof(rk));
+          long long mnb = 0;
+          int mK = 0;
+          bool ap = false;
+          for (int q = 0; q < nyc; q++) {
+            const int64_t sq = mine[c0_ + q];
+            const int y = h_steps[sq].stratum;
+            pk.s[q] = sd[sq];
+            rk.apk[q] = (unsigned *)(b + o_apk) + apk_words * y;
+            rk.bnd[q] = (unsigned *)(b + o_bnd) + RANK_SLOTS * y;
+            ap = ap || sd[sq].perm;
+            mnb = h_steps[sq].n_b > mnb ? h_steps[sq].n_b : mnb;
+            mK = c->st[y].K > mK ? c->st[y].K : mK;
+          }
+          rk.stat = (unsigned long long *)(b + o_rstat);
+          pk.n_next = 0;
+          if (mnb <= 0) continue;
+          rc = (dt == HAMSM_F32) ? launch_steps_ranked<float>(c, lanes[l], pk, rk, nyc, mnb, mK, ldx, ratio, ap)
+                                 : launch_steps_ranked<double>(c, lanes[l], pk, rk, nyc, mnb, mK, ldx, ratio, ap);
+        }
+        if (rc) {
+          hipDeviceSynchronize();
+          return rc;
+        }
+        continue;
+      }
       // (one lane: `mine` is the whole group, in order; several lanes: at most PACK_NY strata each, by construction of n_lanes)
       const StepDev *dptr = d_steps + i;
       if (ny <= PACK_NY && !generic) {
@@ -2435,7 +3027,13 @@ static int run_steps(hamsm_ctx *c, const void *X, int dt, int64_t ldx, const int
   {
     hipError_t e = hipMemcpyAsync(hw.data(), b + o_halt, sizeof(int32_t) * 2 * c->S, hipMemcpyDeviceToHost, c->stream);
     if (e == hipSuccess) e = hipMemcpyAsync(h_report, b + o_rep, sizeof(int32_t) * 2 * n_steps, hipMemcpyDeviceToHost, c->stream);
-    hipError_t es = hipStreamSynchronize(c->stream);  // always: `sd` and `hw` are locals the copies above read / write
+    unsigned long long rstat[4] = {0, 0, 0, 0};
+    if (ranked && e == hipSuccess) e = hipMemcpyAsync(rstat, b + o_rstat, sizeof(rstat), hipMemcpyDeviceToHost, c->stream);
+    hipError_t es = hipStreamSynchronize(c->stream);  // always: `sd`, `hw` and `rstat` are locals the copies above read / write
+    if (ranked) {
+      for (int k = 0; k < 3; k++) c->rank_stat[k] += rstat[k];
+      c->rank_stat[3]++;
+    }
     if (e == hipSuccess) e = es;
     if (e != hipSuccess) return hamsm_fail(c, HAMSM_EDEVICE, "minibatch_run read-back: %s", hipGetErrorString(e));
   }
@@ -2462,6 +3060,18 @@ static int run_steps(hamsm_ctx *c, const void *X, int dt, int64_t ldx, const int
 #include "experiments/run_steps_experiments.inc"
 #endif
 
+
+// Not part of the product ABI (test / bench hook): out[4] = batch rows the ranked E-step certified / settled between two candidates /
+// swept exactly, and the runs that took it, since the last reset; mode >= 0 also sets HAMSM_STEP_RANKED's value for the context
+extern "C" int hamsm_debug_rank_stats(hamsm_ctx *c, unsigned long long *out, int reset, int mode) {
+  CTX(c);
+  for (int k = 0; k < 4; k++) {
+    if (out) out[k] = c->rank_stat[k];
+    if (reset) c->rank_stat[k] = 0;
+  }
+  if (mode >= 0) c->step_ranked = mode > 2 ? 2 : mode;
+  return HAMSM_OK;
+}
 
 extern "C" int hamsm_minibatch_run(hamsm_ctx *c, const void *X, int dt, int64_t ldx, const int32_t *d_rows, const double *d_w,
                                    const hamsm_step *h_steps, int64_t n_steps, double ratio, const int32_t *h_perm,

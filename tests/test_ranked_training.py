@@ -1,0 +1,157 @@
+"""The ranked E-step of MFMA-bound training calls (k_step_assign_ranked, train.hip): centroids ranked on the bf16
+matrix unit from fragments the M-step maintains, a label final only under a proven bound, rows between two candidates settled by
+the contract's two f64 chains, everything else swept exactly.  The labels are the contract's by construction, so a whole planned
+pass -- seeding, steps, re-seeding on the device, stop / settle / resume -- must stay bit-identical to the oracle with this path
+FORCED on shapes of every kind (production takes it by size: >= 1 GFLOP per launch group, BASELINE config 5's regime).
+Arithmetic it must reproduce: sklearn `_k_means_lloyd.pyx:168-218` as called from `/root/reference/msm_we/_hamsm/_clustering.py:909-911`."""
+import ctypes
+
+import numpy as np
+import pytest
+
+from msm_we_amd import synthetic
+from test_training_paths import _run
+
+pytestmark = pytest.mark.gpu
+
+
+def _rank(h, mode=-1, reset=True):
+    """(certified, settled between two candidates, swept exactly, runs) since the last reset; mode >= 0 sets HAMSM_STEP_RANKED"""
+    out = (ctypes.c_ulonglong * 4)()
+    fn = h.lib.hamsm_debug_rank_stats
+    fn.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int]
+    fn.restype = ctypes.c_int
+    assert fn(h.ctx, out, int(reset), int(mode)) == 0
+    return dict(certified=out[0], two=out[1], full=out[2], runs=out[3])
+
+
+CASES = [
+    # name, config (seed, iterations, segments, D, S, K_s), clusters, kwargs
+    ("balanced", synthetic.WEConfig("rk1", 3, 30, 1500, 10, 3, 12), 12, {}),
+    ("c3-like", synthetic.WEConfig("rk2", 8, 24, 4000, 30, 4, 60), 60, {}),
+    ("weighted", synthetic.WEConfig("rk3", 4, 30, 1200, 10, 2, 12), 12, dict(weights=True)),
+    ("d64", synthetic.WEConfig("rk5", 12, 20, 2400, 64, 3, 40), 40, {}),
+    ("d48-two-tiles-per-wave", synthetic.WEConfig("rk5b", 14, 8, 9000, 48, 2, 300), 300, {}),
+    ("d17", synthetic.WEConfig("rk5c", 15, 12, 2000, 17, 2, 33), 33, {}),
+    ("many-strata", synthetic.WEConfig("rk6", 13, 20, 3300, 12, 11, 8), 8, {}),
+    ("more-centroids-than-modes", synthetic.WEConfig("rk7", 5, 20, 2500, 6, 2, 2), 20, {}),   # twins: rows between two candidates
+    ("reseeding", synthetic.WEConfig("rk8", 5, 16, 2500, 6, 2, 2), 20, dict(shift=True)),      # device re-seeding keeps the fragments
+    ("reseeding-weighted", synthetic.WEConfig("rk8w", 5, 16, 2500, 6, 2, 2), 20, dict(shift=True, weights=True)),
+    ("outliers", synthetic.WEConfig("rk9", 5, 12, 2500, 6, 2, 2), 40, dict(outliers=True)),   # scale 100 vs 0.01: wide bounds
+]
+
+
+@pytest.mark.parametrize("name,cfg,k,kw", CASES, ids=[c[0] for c in CASES])
+def test_ranked_training_pass_equals_the_oracle(hip_h, oracle_h, name, cfg, k, kw):
+    o = _run(oracle_h, cfg, k, True, **kw)
+    _rank(hip_h, 2)
+    g = _run(hip_h, cfg, k, True, **kw)
+    st = _rank(hip_h, 1)
+    assert st["runs"] >= 1 and st["certified"] + st["two"] + st["full"] > 0, st
+    assert g[0].training_path == o[0].training_path
+    assert np.array_equal(g[1], o[1]), f"{int((g[1] != o[1]).sum())} labels differ"
+    for i, (x, y) in enumerate(zip(g[2] + g[3], o[2] + o[3])):
+        assert np.array_equal(x, y), f"array {i} (centroid tables, then counts) differs in {int((x != y).sum())} places"
+    # the shipped default for calls this small is the f64 E-step: same results, and the ranked path is not taken
+    g2 = _run(hip_h, cfg, k, True, **kw)
+    assert _rank(hip_h)["runs"] == 0
+    assert np.array_equal(g2[1], g[1])
+    for x, y in zip(g2[2] + g2[3], g[2] + g[3]):
+        assert np.array_equal(x, y)
+
+
+@pytest.mark.parametrize("rt", ["1", "2"])
+def test_ranked_row_tile_variants(hip_h, oracle_h, rt, monkeypatch):
+    monkeypatch.setenv("HAMSM_RANKED_RT", rt)
+    cfg = synthetic.WEConfig("rkt", 21, 6, 6000, 30, 2, 100)
+    o = _run(oracle_h, cfg, 100, True)
+    _rank(hip_h, 2)
+    g = _run(hip_h, cfg, 100, True)
+    assert _rank(hip_h, 1)["runs"] >= 1
+    assert np.array_equal(g[1], o[1])
+    for x, y in zip(g[2] + g[3], o[2] + o[3]):
+        assert np.array_equal(x, y)
+
+
+def test_ranked_pass_with_adversarial_rows(hip_h, oracle_h):
+    """exact ties (duplicated rows become duplicated seeds: every member of such a cluster ties between twins), rows scaled by
+    1e18 (the f32 scores overflow: nothing may be certified), NaN / inf rows (label 0 like the oracle's all-NaN rule): the
+    exact parts of the kernel decide all of these"""
+    from conftest import RectilinearBinMapper
+    from msm_we_amd.data import InMemorySource
+    from msm_we_amd.model import modelWE
+
+    cfg = synthetic.WEConfig("rka", 31, 10, 1500, 12, 2, 16)
+    lat = synthetic.latent_centres(cfg)
+    iters = {i: synthetic.make_iteration(cfg, i, lat) for i in range(1, cfg.n_iters + 1)}
+    rng = np.random.default_rng(5)
+    for it, d in iters.items():
+        for key in ("Xp", "Xc"):
+            X = d[key]
+            X[rng.choice(len(X), 40, replace=False)] = X[0]            # many copies of one row
+            X[rng.choice(len(X), 5, replace=False)] *= np.float32(1e18)
+            if it > 3:   # (a NaN in the seeding batch would poison k-means++ itself, in the reference too)
+                X[rng.choice(len(X), 3, replace=False), 2] = np.nan
+                X[rng.choice(len(X), 2, replace=False), 5] = np.inf
+    res = []
+    for h in (oracle_h, hip_h):
+        if h is hip_h:
+            _rank(h, 2)
+        m = modelWE(h=h)
+        m.set_iteration_source(InMemorySource(iters))
+        basis, target = synthetic.basis_target_bounds(cfg.S)
+        m.initialize(["x"], {"coords": None, "nAtoms": cfg.D, "coord_ndim": 1}, "t", basis_pcoord_bounds=basis,
+                     target_pcoord_bounds=target, tau=1.0)
+        m.get_iterations()
+        m.dimReduce()
+        bm = RectilinearBinMapper([synthetic.strata_boundaries(cfg.S)])
+        try:
+            m.cluster_coordinates(16, streaming=True, use_ray=True, stratified=True, user_bin_mapper=bm, random_state=3)
+            res.append(("ok", [cm.cluster_centers_.copy() for cm in m.clusters.cluster_models],
+                        [cm._counts.copy() for cm in m.clusters.cluster_models], np.concatenate(m.dtrajs)))
+        except Exception as e:  # noqa: BLE001 -- whatever the oracle does with such data, the HIP path must do the same
+            res.append((type(e).__name__,))
+    st = _rank(hip_h, 1)
+    assert res[0][0] == res[1][0]
+    if res[0][0] == "ok":
+        assert st["runs"] >= 1 and st["full"] > 0
+        for x, y in zip(res[0][1] + res[0][2], res[1][1] + res[1][2]):
+            assert np.array_equal(x, y, equal_nan=True)
+        assert np.array_equal(res[0][3], res[1][3])
+
+
+def test_c5_shape_takes_the_ranked_path_by_size(hip_lib, oracle_lib):
+    """BASELINE config 5's shape (50 000 segments per iteration, 64 features, 4 x 1250): the shipped default takes the ranked
+    E-step there (>= 1 GFLOP per launch group); 3 iterations against the oracle, bit for bit, and most rows certified"""
+    from conftest import RectilinearBinMapper
+    from msm_we_amd import _abi
+    from msm_we_amd.data import DeviceStore
+    from msm_we_amd.model import modelWE
+
+    cfg = synthetic.WEConfig("c5r", 5, 3, 50000, 64, 4, 1250)
+    blk = synthetic.make_block(cfg, 1, cfg.n_iters)
+    out = []
+    for lib in (oracle_lib, hip_lib):
+        h = _abi.Hamsm(lib=lib)
+        try:
+            store = DeviceStore.from_host(h, blk["Xp"], blk["Xc"], blk["p0"], blk["p1"], blk["w"], blk["offsets"])
+            m = modelWE(h=h)
+            m.pcoord_ndim = 1
+            basis, target = synthetic.basis_target_bounds(cfg.S)
+            m.basis_pcoord_bounds, m.target_pcoord_bounds, m.tau = basis, target, 1.0
+            m.attach_store(store)
+            m.maxIter = cfg.n_iters + 1
+            m.numSegments = np.diff(blk["offsets"]).astype(float)
+            m.launch_ray_discretization = lambda progress_bar=None: None   # training only (the oracle's discretization would take minutes)
+            bm = RectilinearBinMapper([synthetic.strata_boundaries(cfg.S)])
+            m.cluster_coordinates(cfg.K_s, streaming=True, use_ray=True, stratified=True, user_bin_mapper=bm, random_state=5)
+            out.append(([cm.cluster_centers_.copy() for cm in m.clusters.cluster_models], [cm._counts.copy() for cm in m.clusters.cluster_models]))
+            if lib is hip_lib:
+                st = _rank(h)
+                assert st["runs"] >= 1, st
+                tot = st["certified"] + st["two"] + st["full"]
+                assert tot > 0 and st["full"] < 0.02 * tot, st
+        finally:
+            h.close()
+    for x, y in zip(out[0][0] + out[0][1], out[1][0] + out[1][1]):
+        assert np.array_equal(x, y)
