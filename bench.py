@@ -606,6 +606,21 @@ def main():
         elapsed = float(t.item())
 
     timers = h.timers()   # HIP events on the library's stream around every kernel (lazy: no sync on the launch path)
+    # training E-step on the bf16 matrix unit (train.hip, k_step_assign_ranked; taken by size): rows certified by the ranking /
+    # settled between two candidates by two f64 chains / swept exactly, over the timed steps
+    rank_stats = None
+    if hasattr(h.lib, "hamsm_debug_rank_stats"):
+        try:
+            out4 = (ctypes.c_ulonglong * 4)()
+            h.lib.hamsm_debug_rank_stats.restype = ctypes.c_int
+            h.lib.hamsm_debug_rank_stats.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int]
+            if h.lib.hamsm_debug_rank_stats(h.ctx, out4, 0, -1) == 0 and out4[3] > 0:
+                tot = max(1, out4[0] + out4[1] + out4[2])
+                rank_stats = {"runs": int(out4[3]), "rows_certified": int(out4[0]), "rows_two_candidates": int(out4[1]),
+                              "rows_swept_exactly": int(out4[2]), "frac_certified": out4[0] / tot, "frac_two": out4[1] / tot,
+                              "frac_swept": out4[2] / tot}
+        except (AttributeError, OSError):
+            rank_stats = None
     e_ms, e_n = h.step_kernel_ms(0)   # the dominant kernel, live: events around every 128th k_step_assign / k_step_update launch
     m_ms, m_n = h.step_kernel_ms(1)
     e_dev_ms, _ = h.step_kernel_ms(2)  # ... and by the device clock (first wave in -> last wave out, no launch boundary)
@@ -710,6 +725,9 @@ def main():
         "roofline_by_kernel": roofline_by_kernel(cfg, n_iters, n_seg, timers, args.steps, tflops, peak, assign_avg_ms),
         "labels_to_host_ms": labels_to_host_ms,
         "flux_ms": flux_ms,
+        "training_estep": ("ranked on the bf16 matrix unit (k_step_assign_ranked), exact f64 where the ranking cannot decide"
+                           if rank_stats else "f64 matrix unit (k_step_assign)"),
+        "training_estep_rows": rank_stats,
     }
     if world == 1 and not args.no_ingest:
         out["ingest"] = ingest_leg(h, cfg, min(n_iters, 100, max(4, int(264e6 / (cfg.segs_per_iter * cfg.D * 8)))), log)

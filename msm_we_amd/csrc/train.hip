@@ -10,6 +10,7 @@
 // workgroups, and several strata share one launch.  Every reduction follows the order fixed in
 // oracle/hamsm_oracle.c so that results are bit-identical.
 #include "common.h"
+#include <type_traits>
 
 #include <time.h>
 
@@ -1440,21 +1441,62 @@ __device__ __forceinline__ void upd_add_listed(double (&acc)[H], const GAS doubl
 // Arithmetic of the exact parts: d = fma(-2, chain, csq), chain = fma over ascending k from +0.0 -- the contract (hamsm.h), what
 // v_mfma_f64_16x16x4_f64 computes in k_step_assign; first strict minimum over ascending j.  Labels are therefore those of
 // k_step_assign bit for bit; tests/test_ranked_training.py compares whole passes with the oracle with this path forced.
-// Layout: a workgroup = 4 waves on RT tiles of 32 batch rows; every wave holds ALL the rows' operand pieces (B operand, from global
-// memory straight into registers, as k_assign_filter does) and sweeps the centroid tiles t = wave, wave + 4, ... whose fragments it
-// streams from L2 (A operand); the four partial top-3 are merged through LDS.  No barrier before that merge.
+// Layout: a workgroup = 128 batch rows (four tiles of 32) x 8 waves.  Prologue: waves w and w + 4 turn row tile w into operand pieces
+// (from global memory straight into registers, as k_assign_filter's bf16 forms) and leave them in LDS as the B-operand images all
+// eight waves read.  Sweep: wave w takes the centroid tiles w, w + 8, ... -- fragments (A operand) from L2 into registers, one tile
+// ahead, -csq / 2 as the accumulator's initial value -- against all four row tiles: 12 KB MFMAs per (tile, row tile), then the 64
+// ranking instructions; two waves per SIMD, so one's ranking overlaps the other's MFMAs.  No barrier inside the sweep; the eight
+// partial top-3 per row are merged through LDS (the operand images' bytes, re-used).
+// What was measured on the way (C5-shaped pass, profiles/r04_*, tools/rankprof.py: phase stamps per workgroup):
+//   waves split the tiles, 64 rows per workgroup, rows' pieces in every wave's registers: E-step 87 -> 60 us per launch (107 us for
+//     k_step_assign); the exact parts were the tail (per-row sweeps over all centroids by the workgroup: 10 us each, one workgroup
+//     130 us) until rows between two candidates went to one wave per row and the rest to the f64 matrix unit, 16 rows at a time;
+//   waves own row tiles, fragments through an LDS ring by global_load_lds (k_assign_filter's shape): 72 us -- one barrier per group
+//     of 3 tiles, and a group's sweep (0.65 us) is shorter than the L2 -> LDS latency;
+//   this layout with 4 waves: 60 us, sweep 23.5 us per workgroup of which ranking 11 (one wave per SIMD: its MFMAs and its ranking
+//     do not overlap; interleaving them in program order between scheduling fences: 32 us); with 8 waves: sweep 14.5 us, 45 us per
+//     launch.  What is left of the sweep is the fragment stream itself: ~9 us with the MFMAs compiled out (62 MB per launch out
+//     of L2, every workgroup the same 320 KB per stratum).
 #define RANK_SLOTS 64
+#ifdef RANK_PROFILE  // (diagnostic build only, tools/rankprof.py: where a workgroup of the ranked E-step spends its time, 100 MHz ticks)
+__device__ unsigned long long g_rank_prof[16];
+#define RPROF_INIT unsigned long long rp_t_ = wall_clock64(), rp_n_;
+#define RPROF(i)                                                        \
+  {                                                                     \
+    rp_n_ = wall_clock64();                                             \
+    if (threadIdx.x == 0) atomicAdd(&g_rank_prof[i], rp_n_ - rp_t_);    \
+    if (threadIdx.x == 0 && (i) == 4) atomicMax(&g_rank_prof[9], rp_n_ - rp_t_); \
+    rp_t_ = rp_n_;                                                      \
+  }
+#define RPROF_END if (threadIdx.x == 0) atomicAdd(&g_rank_prof[8], 1ull);
+extern "C" int hamsm_debug_rank_profile(unsigned long long *h_out, int reset) {
+  if (h_out && hipMemcpyFromSymbol(h_out, HIP_SYMBOL(g_rank_prof), sizeof(unsigned long long) * 16) != hipSuccess) return -1;
+  if (reset) {
+    unsigned long long z[16] = {0};
+    if (hipMemcpyToSymbol(HIP_SYMBOL(g_rank_prof), z, sizeof(z)) != hipSuccess) return -1;
+  }
+  return 0;
+}
+#else
+#define RPROF_INIT
+#define RPROF(i)
+#define RPROF_END
+#endif
 struct RankPack {
   unsigned *apk[PACK_NY];        // [tile32][KB][2 pieces][64 lanes][4 words]: lane l = centroid l % 32, slots 16 m + 8 (l / 32) + i
+  float *hcs[PACK_NY];           // [tiles32 x 32] -csq_j / 2 as f32: the scores' initial accumulator (-3e38 past K: never ranks first)
   unsigned *bnd[PACK_NY];        // [RANK_SLOTS] f32 bit patterns, max = upper bound of every ||c_j||^2 (and |csq_j|) of the stratum
   unsigned long long *stat;      // [4] rows certified / settled between two candidates / swept exactly / (unused)   (nullable)
 };
 typedef float v16f32 __attribute__((ext_vector_type(16)));
 typedef __bf16 v8bf16 __attribute__((ext_vector_type(8)));
 typedef unsigned v4u32 __attribute__((ext_vector_type(4)));
+typedef double v2f64 __attribute__((ext_vector_type(2)));
+typedef float v4f32 __attribute__((ext_vector_type(4)));
 
 // fragment slots of ONE centroid row: lane k < D holds feature k's new value; `csq` (all lanes) its new ||c||^2
-__device__ __forceinline__ void rank_store_row(GAS unsigned short *apk, int KB, int j, int lane, int D, double vk, double csq) {
+__device__ __forceinline__ void rank_store_row(GAS unsigned short *apk, GAS float *hcs, int KB, int j, int lane, int D, double vk,
+                                               double csq) {
   const size_t tile = (size_t)(j >> 5) * KB;
   const int row = j & 31;
   auto put = [&](int k, float vf) {
@@ -1465,12 +1507,12 @@ __device__ __forceinline__ void rank_store_row(GAS unsigned short *apk, int KB, 
     apk[at + 512] = (unsigned short)(__float_as_uint(r1) >> 16);
   };
   if (lane < D) put(lane, (float)vk);
-  if (lane == 0) put(D, (float)(-0.5 * csq));
+  if (lane == 0) hcs[j] = (float)(-0.5 * csq);
 }
 
 // the run's fragments and bounds from the strata's tables (one wave per 32-centroid tile)
 __global__ __launch_bounds__(64) void k_rank_pack(const double *__restrict__ C, const double *__restrict__ csq, int K, int D, int KB,
-                                                  unsigned *__restrict__ apk, unsigned *__restrict__ bnd) {
+                                                  unsigned *__restrict__ apk, float *__restrict__ hcs, unsigned *__restrict__ bnd) {
   const int jt = blockIdx.x, lane = threadIdx.x, row = lane & 31, h = lane >> 5, j = jt * 32 + row;
   const bool live = j < K;
   const double cs = live ? csq[j] : 0.0;
@@ -1481,8 +1523,7 @@ __global__ __launch_bounds__(64) void k_rank_pack(const double *__restrict__ C, 
       const int k = 16 * m + 8 * h + i;
       const double v = (live && k < D) ? C[(size_t)j * D + k] : 0.0;
       n2 += v * v;
-      float vf = (float)v;
-      if (k == D) vf = live ? (float)(-0.5 * cs) : -3.0e38f;  // (a row past K never ranks first; finite: its index bits must not make a NaN)
+      const float vf = (float)v;
       const unsigned p1 = __float_as_uint(vf) & 0xffff0000u;
       const unsigned p2 = __float_as_uint(vf - __uint_as_float(p1)) & 0xffff0000u;
       if (i & 1) {
@@ -1497,6 +1538,8 @@ __global__ __launch_bounds__(64) void k_rank_pack(const double *__restrict__ C, 
       for (int z = 0; z < 4; z++) apk[((((size_t)jt * KB + m) * 2 + q) * 64 + lane) * 4 + z] = w[q][z];
   }
   n2 += __shfl_xor(n2, 32, 64);
+  // (a row past K never ranks first; finite: the index bits in the ranked values must not turn an infinity into a signalling NaN)
+  if (h == 0) hcs[j] = live ? (float)(-0.5 * cs) : -3.0e38f;
   if (h == 0 && live) {  // (non-negative floats order like their bit patterns; NaN patterns sort above +inf and poison the bound)
     const float a = (float)n2 * 1.000001f, b = __builtin_fabsf((float)cs) * 1.000001f;
     atomicMax(&bnd[j & (RANK_SLOTS - 1)], __float_as_uint(a > b || !(b == b) ? a : b));
@@ -1524,11 +1567,14 @@ __device__ __forceinline__ void rank_merge3(float &A1, float &A2, float &A3, int
     A3 = __builtin_fmaxf(A3, B1);
 }
 
-template <typename XT, int KB, int RT>
-__global__ __launch_bounds__(256, 2) void k_step_assign_ranked(const StepPack pk, const RankPack rk, int64_t ldx, int D, int KS,
-                                                               double ratio, float c1, float c2, unsigned long long *stamp) {
+#define RANK_NW 8  // waves per workgroup of the ranked E-step: two per SIMD, so that one's ranking (vector unit) overlaps the other's MFMAs
+template <typename XT, int KB>
+__global__ __launch_bounds__(RANK_NW * 64, 2) void k_step_assign_ranked(const StepPack pk, const RankPack rk, int64_t ldx, int D, int KS,
+                                                                        double ratio, float c1, float c2, unsigned long long *stamp) {
   if (stamp && threadIdx.x == 0) atomicMin(&stamp[0], (unsigned long long)wall_clock64());
-  constexpr int RW = 32 * RT;  // rows per workgroup
+  RPROF_INIT
+  constexpr int NW = RANK_NW, NT = NW * 64;
+  constexpr int RW = 128;  // rows per workgroup: four tiles of 32
   const StepDev sdesc = pk.s[blockIdx.y];
   const StepG st(sdesc);
   const long long r0 = (long long)blockIdx.x * RW;
@@ -1536,102 +1582,133 @@ __global__ __launch_bounds__(256, 2) void k_step_assign_ranked(const StepPack pk
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, row = lane & 31, h = lane >> 5;
   const GAS XT *X = (const GAS XT *)st.X;
   const GAS v4u32 *apk = (const GAS v4u32 *)gp(rk.apk[blockIdx.y]);
+  const GAS float *hcs = gp(rk.hcs[blockIdx.y]);
   GAS unsigned *bndw = gp(rk.bnd[blockIdx.y]);
   const float ninf = -__builtin_huge_valf();
   const double inf = __builtin_huge_val();
-  __shared__ float s_m[4][RW][3];
-  __shared__ int s_j[4][RW][2];
-  __shared__ float s_x[RW];
-  __shared__ int s_full[RW], s_nfull;
-  __shared__ double s_d[4];
-  __shared__ int s_i[4];
-  __shared__ double s_row[64];
-  if (tid == 0) s_nfull = 0;
-  // the rows: lane l carries batch row l % 32 of each tile, the 8 feature slots 16 m + 8 (l / 32) + i of every 16-slot block
-  long long fr[RT];
-#pragma unroll
-  for (int rt = 0; rt < RT; rt++) {
-    const long long r = r0 + rt * 32 + row;
-    const long long rc = r < st.n_b ? r : st.n_b - 1;  // (rows past the batch repeat its last row; nothing of them is kept)
-    fr[rt] = st.rows ? (long long)st.rows[rc] : rc;
+  // LDS: the four row tiles' operand images (B operand, as the lanes hold them) during the sweep; afterwards the same bytes hold
+  // the waves' partial top-3 and the strips of the two-candidate chains
+  constexpr int SB_BYTES = 4 * KB * 2 * 64 * 16, SM_BYTES = NW * RW * 3 * 4, SJ_BYTES = NW * RW * 2 * 4, ST_BYTES = NW * 3 * 64 * 8;
+  constexpr int BUF_BYTES = SB_BYTES > SM_BYTES + SJ_BYTES + ST_BYTES ? SB_BYTES : SM_BYTES + SJ_BYTES + ST_BYTES;
+  __shared__ __attribute__((aligned(16))) unsigned char s_buf[BUF_BYTES];
+  v4u32(*s_b)[KB][2][64] = (v4u32(*)[KB][2][64])s_buf;                    // [4][KB][2][64]
+  float(*s_m)[RW][3] = (float(*)[RW][3])s_buf;                            // [NW][RW][3]
+  int(*s_j)[RW][2] = (int(*)[RW][2])(s_buf + SM_BYTES);                   // [NW][RW][2]
+  double(*s_t)[3][64] = (double(*)[3][64])(s_buf + SM_BYTES + SJ_BYTES);  // [NW][3][64]
+  __shared__ float s_x[2][RW];
+  __shared__ int s_full[RW], s_nfull, s_two[RW][3], s_ntwo, s_lab[RW];
+  __shared__ double s_d[NW];
+  __shared__ double s_fd[NW][16];
+  __shared__ int s_fi[NW][16];
+  if (tid == 0) s_nfull = s_ntwo = 0;
+  if (tid < RW) s_lab[tid] = -1;
+  const int njt = (st.K + 31) >> 5;
+  // ---- prologue: waves w and w + 4 turn row tile w into operand pieces, the 16-slot blocks of even / odd number each (lane l:
+  // batch row l % 32 of the tile, the 8 feature slots 16 m + 8 (l / 32) + i of a block -- from global memory straight into
+  // registers, as k_assign_filter's bf16 forms) and leave them in LDS for all eight waves ----
+  const int rtw = wv & 3, mpar = wv >> 2;
+  const long long rmine = r0 + 32 * rtw + row;
+  const bool ok = rmine < st.n_b;
+  const long long rcl = ok ? rmine : st.n_b - 1;  // (rows past the batch repeat its last row; nothing of them is kept)
+  const long long fr = st.rows ? (long long)st.rows[rcl] : rcl;
+  // (the row of the stratum's NEXT call that this lane will touch towards this XCD's L2, as k_step_assign's wave 3 does)
+  const bool pf_on = wv < 4 && (int)blockIdx.y < pk.n_next && rmine < pk.nx[blockIdx.y].n_b;
+  long long fn = 0;
+  if (pf_on) {
+    const GAS int32_t *nrows = gp(pk.nx[blockIdx.y].rows);
+    fn = nrows ? (long long)nrows[rmine] : rmine;
   }
   unsigned bu = bndw[lane & (RANK_SLOTS - 1)];
-  const int njt = (st.K + 31) >> 5;
-  // this wave's first centroid tile does not depend on the rows: requested before the gather waits for the row indices
+  // this wave's first centroid tile does not depend on the rows: requested before the gather waits for the row indices.
+  // Tiles are walked from a start that differs from workgroup to workgroup (every workgroup of a stratum reads the same 256 B
+  // per centroid: walking them in the same order at the same time queues them all on the same L2 channels)
+  const int nmy = (njt - wv + NW - 1) / NW;  // tiles of this wave: wv, wv + NW, ...  (<= 0: none)
+  const int rot = nmy > 0 ? (int)(blockIdx.x % (unsigned)nmy) : 0;
   struct Frag {
     v4u32 c[KB][2];
+    v4f32 i0[4];  // the accumulator's initial value: -csq / 2 of the lane's 16 centroids
   };
-  auto load_frag = [&](int t) {
+  auto tile_of = [&](int i) {  // i-th tile of this wave's walk
+    int q = i + rot;
+    q = q >= nmy ? q - nmy : q;
+    return wv + NW * q;
+  };
+  auto load_frag = [&](int i) {
     Frag f;
-    const GAS v4u32 *ap = apk + (size_t)(t < njt ? t : njt - 1) * (KB * 2 * 64) + lane;
+    const int t = nmy > 0 ? tile_of(i < nmy ? i : nmy - 1) : 0;
+    const int tc = t < njt ? t : njt - 1;
+    const GAS v4u32 *ap = apk + (size_t)tc * (KB * 2 * 64) + lane;
 #pragma unroll
     for (int m = 0; m < KB; m++) {
       f.c[m][0] = ap[(m * 2 + 0) * 64];
       f.c[m][1] = ap[(m * 2 + 1) * 64];
     }
+    const GAS v4f32 *hp = (const GAS v4f32 *)(hcs + (size_t)tc * 32 + 4 * h);
+#pragma unroll
+    for (int g = 0; g < 4; g++) f.i0[g] = hp[2 * g];  // centroids 8 g + 4 h + (0..3) of the tile
     return f;
   };
-  Frag cur = load_frag(wv);
+  Frag cur = load_frag(0);
   typedef XT xt4u __attribute__((ext_vector_type(4), aligned(sizeof(XT))));
-  v4u32 x1[RT][KB], x2[RT][KB];
-  float xn2[RT];
-  const int ldg = 4 * KS;
+  constexpr int KBH = (KB + 1) / 2;  // blocks per converting wave
+  XT raw[KBH][8];                    // (kept to the end: the batch copy for the M-step is written from them)
+  {
+    const GAS XT *rp = X + fr * ldx;
 #pragma unroll
-  for (int rt = 0; rt < RT; rt++) {
-    const GAS XT *rp = X + fr[rt] * ldx;
-    XT raw[KB][8];
-#pragma unroll
-    for (int m = 0; m < KB; m++) {
+    for (int mm = 0; mm < KBH; mm++) {
+      const int m = 2 * mm + mpar;  // (wave-uniform)
       const int k0 = 16 * m + 8 * h;
-      if (16 * m + 16 <= D) {  // (wave-uniform) both half-waves stay inside the row
+      if (m < KB && 16 * m + 16 <= D) {  // both half-waves stay inside the row
         const xt4u va = *(const GAS xt4u *)(rp + k0), vb = *(const GAS xt4u *)(rp + k0 + 4);
 #pragma unroll
         for (int i = 0; i < 4; i++) {
-          raw[m][i] = va[i];
-          raw[m][4 + i] = vb[i];
+          raw[mm][i] = va[i];
+          raw[mm][4 + i] = vb[i];
         }
       } else {
 #pragma unroll
         for (int i = 0; i < 8; i++) {  // (slots past the row arrive as zeros; the load itself stays inside the row)
           const int k = k0 + i;
           const XT v = rp[k < D ? k : D - 1];
-          raw[m][i] = k < D ? v : (XT)0;
+          raw[mm][i] = (m < KB && k < D) ? v : (XT)0;
         }
       }
     }
-    float q2 = 0.f;
-    const bool copy = ((rt + 1) & 3) == wv;  // the batch rows as f64 for the M-step: tile rt by wave (rt + 1) & 3
-    const long long r = r0 + rt * 32 + row;
+    float xn2 = 0.f;
 #pragma unroll
-    for (int m = 0; m < KB; m++)
+    for (int mm = 0; mm < KBH; mm++) {
+      const int m = 2 * mm + mpar;
+      v4u32 p1, p2;
 #pragma unroll
       for (int w = 0; w < 4; w++) {
         float a0[2], a1[2];
 #pragma unroll
         for (int i = 0; i < 2; i++) {
-          const float v = (float)raw[m][2 * w + i];
-          q2 = __builtin_fmaf(v, v, q2);
+          const float v = (float)raw[mm][2 * w + i];
+          xn2 = __builtin_fmaf(v, v, xn2);
           a0[i] = v;
           a1[i] = v - __uint_as_float(__float_as_uint(v) & 0xffff0000u);
-          const int k = 16 * m + 8 * h + 2 * w + i;
-          if (copy && k < ldg) st.Xg[(size_t)r * ldg + k] = (double)raw[m][2 * w + i];  // (whole tiles of the padded batch: unconditional in r)
         }
-        // slot D of the operand is the constant 1 (the csq term): its bf16 pattern in piece 1
-        const int ke = 16 * m + 8 * h + 2 * w;
-        const unsigned one = (ke == D ? 0x3f80u : 0u) | (ke + 1 == D ? 0x3f800000u : 0u);
-        x1[rt][m][w] = __builtin_amdgcn_perm(__float_as_uint(a0[1]), __float_as_uint(a0[0]), 0x07060302u) | one;
-        x2[rt][m][w] = __builtin_amdgcn_perm(__float_as_uint(a1[1]), __float_as_uint(a1[0]), 0x07060302u);
+        // pieces by truncation: piece 1 = the upper half of the f32 pattern, piece 2 = the upper half of the exact remainder; two
+        // slots share a word, picked by ONE v_perm_b32.  A value that is not finite leaves a NaN in piece 2 (inf - inf, NaN - x)
+        p1[w] = __builtin_amdgcn_perm(__float_as_uint(a0[1]), __float_as_uint(a0[0]), 0x07060302u);
+        p2[w] = __builtin_amdgcn_perm(__float_as_uint(a1[1]), __float_as_uint(a1[0]), 0x07060302u);
       }
-    q2 += __shfl_xor(q2, 32, 64);
-    xn2[rt] = q2;
+      if (m < KB) {
+        s_b[rtw][m][0][lane] = p1;
+        s_b[rtw][m][1][lane] = p2;
+      }
+    }
+    xn2 += __shfl_xor(xn2, 32, 64);
+    if (lane < 32) s_x[mpar][32 * rtw + row] = xn2;  // (the row's ||x||^2 = the two waves' parts, summed by whoever needs it)
   }
   if (blockIdx.x == 0 && (st.flags & 6) && st.idx < *gp(sdesc.halt)) {
-    // (k_step_assign's block, unchanged: the stratum's chain is live.)  `counts < ratio * max(counts)` for the stratum's previous
+    // (k_step_assign's block: the stratum's chain is live.)  `counts < ratio * max(counts)` for the stratum's previous
     // step when the host predicted that none would be low (_kmeans.py:1645), `(counts == 0).any()` before this one (:2037)
     const GAS int32_t *prev = gp(sdesc.prev_report);
     int z = 0;
     double mx = -inf;
-    for (int j = tid; j < st.K; j += 256) {
+    for (int j = tid; j < st.K; j += NT) {
       double cj = st.counts[j];
       z |= (cj == 0.0);
       mx = cj > mx ? cj : mx;
@@ -1647,10 +1724,10 @@ __global__ __launch_bounds__(256, 2) void k_step_assign_ranked(const StepPack pk
       __syncthreads();
       mx = s_d[0];
 #pragma unroll
-      for (int w = 1; w < 4; w++) mx = s_d[w] > mx ? s_d[w] : mx;
+      for (int w = 1; w < NW; w++) mx = s_d[w] > mx ? s_d[w] : mx;
       const double thr = ratio * mx;
       int low = 0;
-      for (int j = tid; j < st.K; j += 256) low += st.counts[j] < thr;
+      for (int j = tid; j < st.K; j += NT) low += st.counts[j] < thr;
       if (low) __hip_atomic_fetch_add((GAS int32_t *)prev + 1, low, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       any_low = __syncthreads_or(low);
     }
@@ -1666,27 +1743,45 @@ __global__ __launch_bounds__(256, 2) void k_step_assign_ranked(const StepPack pk
       }
     }
   }
-  // ---- the sweep: three largest scores per row (and half-wave), the tiles of the largest two ----
-  float M1[RT], M2[RT], M3[RT];
-  int J1[RT], J2[RT];
+  __syncthreads();  // the four tiles' operand images are in LDS
+  RPROF(0)
+  XT pfv[2] = {(XT)0, (XT)0};
+  if (pf_on) {  // (one dword per 128-byte line of the next call's row; lanes l and l + 32 share a row: every other line each)
+    const GAS XT *Xn = gp((const XT *)pk.nx[blockIdx.y].X) + fn * ldx;
+    const int per = 128 / (int)sizeof(XT);
 #pragma unroll
-  for (int rt = 0; rt < RT; rt++) {
+    for (int i = 0; i < 2; i++) {
+      int k = (h + 2 * i) * per;
+      k = k < D ? k : D - 1;
+      pfv[i] = Xn[k];
+    }
+  }
+  // ---- the sweep: this wave's centroid tiles against ALL four row tiles (12 KB MFMAs per tile of fragments: the next tile's
+  // loads have that long to arrive); per row tile the three largest scores per row (and half-wave), the tiles of the largest
+  // two.  The MFMAs of a (tile, row tile) unit are followed by its 64 ranking instructions: within one wave they do not overlap,
+  // the SIMD's other wave fills the matrix unit meanwhile (measured: interleaving them in one wave's instruction order between
+  // scheduling fences is slower -- the fences also pin the operand reads from LDS in front of their MFMAs) ----
+  float M1[4], M2[4], M3[4];
+  int J1[4], J2[4];
+#pragma unroll
+  for (int rt = 0; rt < 4; rt++) {
     M1[rt] = M2[rt] = M3[rt] = ninf;
     J1[rt] = J2[rt] = 0;
   }
-  v16f32 zero;
+  for (int i = 0; i < nmy; i++) {
+    const int t = tile_of(i);
+    const Frag nxt = load_frag(i + 1);  // (clamped; unused past the last tile)
+    v16f32 init;
 #pragma unroll
-  for (int r = 0; r < 16; r++) zero[r] = 0.f;
-  for (int t = wv; t < njt; t += 4) {
-    const Frag nxt = load_frag(t + 4);  // (clamped; unused past the last tile)
+    for (int r = 0; r < 16; r++) init[r] = cur.i0[r >> 2][r & 3];
 #pragma unroll
-    for (int rt = 0; rt < RT; rt++) {
+    for (int rt = 0; rt < 4; rt++) {
       v16f32 acc;
 #pragma unroll
       for (int m = 0; m < KB; m++) {
         const v8bf16 a1 = __builtin_bit_cast(v8bf16, cur.c[m][0]), a2 = __builtin_bit_cast(v8bf16, cur.c[m][1]);
-        const v8bf16 b1 = __builtin_bit_cast(v8bf16, x1[rt][m]), b2 = __builtin_bit_cast(v8bf16, x2[rt][m]);
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b2, m == 0 ? zero : acc, 0, 0, 0);
+        const v8bf16 b1 = __builtin_bit_cast(v8bf16, s_b[rt][m][0][lane]), b2 = __builtin_bit_cast(v8bf16, s_b[rt][m][1][lane]);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b2, m == 0 ? init : acc, 0, 0, 0);
         acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, b1, acc, 0, 0, 0);
         acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, acc, 0, 0, 0);
       }
@@ -1713,9 +1808,11 @@ __global__ __launch_bounds__(256, 2) void k_step_assign_ranked(const StepPack pk
     }
     cur = nxt;
   }
+  RPROF(1)
+  __syncthreads();  // nobody reads the operand images any more: their bytes take the waves' partial results
   // -> centroid indices; lanes l and l ^ 32 (same row, the other half of every tile's centroids) merged; one triple per wave and row
 #pragma unroll
-  for (int rt = 0; rt < RT; rt++) {
+  for (int rt = 0; rt < 4; rt++) {
     const int q1 = (int)(__float_as_uint(M1[rt]) & 15u), q2 = (int)(__float_as_uint(M2[rt]) & 15u);
     int j1 = J1[rt] * 32 + 8 * (q1 >> 2) + 4 * h + (q1 & 3), j2 = J2[rt] * 32 + 8 * (q2 >> 2) + 4 * h + (q2 & 3);
     float a1 = M1[rt], a2 = M2[rt], a3 = M3[rt];
@@ -1727,11 +1824,11 @@ __global__ __launch_bounds__(256, 2) void k_step_assign_ranked(const StepPack pk
       s_m[wv][rt * 32 + row][2] = a3;
       s_j[wv][rt * 32 + row][0] = j1;
       s_j[wv][rt * 32 + row][1] = j2;
-      if (wv == 0) s_x[rt * 32 + row] = xn2[rt];
     }
   }
   __syncthreads();
-  // ---- one thread per row: certify, or settle between the two candidates exactly ----
+  RPROF(2)
+  // ---- one thread per row (waves 0 and 1): certify, or name the row's two candidates, or leave it to the exact sweep ----
   // the bound's scale: the largest of the stratum's RANK_SLOTS words (as integers: a NaN pattern wins and nothing is certified)
 #pragma unroll
   for (int off = 32; off >= 1; off >>= 1) {
@@ -1741,7 +1838,6 @@ __global__ __launch_bounds__(256, 2) void k_step_assign_ranked(const StepPack pk
   const float bnd = __uint_as_float(bu);
   const float thr_x = c1 * 1.000001f * __builtin_sqrtf(bnd) * 1.000001f, thr_0 = c2 * bnd + 1e-30f;
   int label = -1, kind = 0;  // kind: 0 certified, 1 settled between two candidates, 2 swept exactly
-  bool full = false;
   const long long rme = r0 + tid;
   const bool mine = tid < RW && rme < st.n_b;
   float xq = 0.f;
@@ -1749,123 +1845,175 @@ __global__ __launch_bounds__(256, 2) void k_step_assign_ranked(const StepPack pk
     float a1 = s_m[0][tid][0], a2 = s_m[0][tid][1], a3 = s_m[0][tid][2];
     int j1 = s_j[0][tid][0], j2 = s_j[0][tid][1];
 #pragma unroll
-    for (int w = 1; w < 4; w++) rank_merge3(a1, a2, a3, j1, j2, s_m[w][tid][0], s_m[w][tid][1], s_m[w][tid][2], s_j[w][tid][0], s_j[w][tid][1]);
-    xq = s_x[tid];
+    for (int w = 1; w < NW; w++) rank_merge3(a1, a2, a3, j1, j2, s_m[w][tid][0], s_m[w][tid][1], s_m[w][tid][2], s_j[w][tid][0], s_j[w][tid][1]);
+    xq = (s_x[0][tid] + s_x[1][tid]) * 1.000001f;  // (two partial fma chains instead of one: the factor covers the difference)
     const float thr = thr_x * __builtin_sqrtf(xq) + thr_0;
     // (scores can only be infinite -- and their index bits turn an infinity into a signalling NaN -- if the operands are this large)
     const bool tame = xq * bnd < 1e36f;
     if (tame && 2.f * (a1 - a2) > thr && j1 < st.K) {  // d = -2 s; every NaN: the comparison is false
       label = j1;
     } else if (tame && 2.f * (a1 - a3) > thr && j1 != j2 && j1 < st.K && j2 < st.K) {
-      const long long f = st.rows ? (long long)st.rows[rme] : rme;
-      const GAS XT *xr = X + f * ldx;
-      const int lo = j1 < j2 ? j1 : j2, hi = j1 < j2 ? j2 : j1;
-      const GAS double *cl = st.C + (size_t)lo * D, *ch = st.C + (size_t)hi * D;
-      double dl = 0.0, dh = 0.0;
-      for (int k0 = 0; k0 < D; k0 += 8) {  // 3 x 8 loads in flight, then the two chains' 8 steps each
-        double xv[8], lv[8], hv[8];
-#pragma unroll
-        for (int i = 0; i < 8; i++) {
-          const int k = k0 + i < D ? k0 + i : D - 1;
-          xv[i] = (double)xr[k];
-          lv[i] = cl[k];
-          hv[i] = ch[k];
-        }
-#pragma unroll
-        for (int i = 0; i < 8; i++)
-          if (k0 + i < D) {
-            dl = __builtin_fma(lv[i], xv[i], dl);
-            dh = __builtin_fma(hv[i], xv[i], dh);
-          }
-      }
-      dl = __builtin_fma(-2.0, dl, st.csq[lo]);
-      dh = __builtin_fma(-2.0, dh, st.csq[hi]);
-      label = dl <= dh ? lo : (dh < dl ? hi : -1);  // first strict minimum over ascending j; a NaN: to the exact sweep
-      if (label < 0) full = true;
-      else kind = 1;
-    } else
-      full = true;
-    if (full) s_full[atomicAdd(&s_nfull, 1)] = tid;
+      kind = 1;
+      const int e = atomicAdd(&s_ntwo, 1);
+      s_two[e][0] = tid;
+      s_two[e][1] = j1 < j2 ? j1 : j2;
+      s_two[e][2] = j1 < j2 ? j2 : j1;
+    } else {
+      kind = 2;
+      s_full[atomicAdd(&s_nfull, 1)] = tid;
+    }
   }
-  // the rows seen so far bound the centroids to come (see the header): wave 0 publishes its largest ||x||^2
-  if (wv == 0) {
-    float mq = mine ? xq * 1.00001f : 0.f;
-    if (RT == 1) mq = lane < 32 ? mq : 0.f;
-    unsigned mu = __float_as_uint(mq);  // (non-negative or NaN: ordered like its bit pattern)
+  // the rows seen so far bound the centroids to come (see the header): waves 0 and 1 publish their largest ||x||^2
+  if (wv < 2) {
+    unsigned mu = __float_as_uint(mine ? xq * 1.00001f : 0.f);  // (non-negative or NaN: ordered like its bit pattern)
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) {
       const unsigned o = __shfl_xor(mu, off, 64);
       mu = o > mu ? o : mu;
     }
-    if (lane == 0 && mu > bu) atomicMax((unsigned *)&bndw[blockIdx.x & (RANK_SLOTS - 1)], mu);
+    if (lane == 0 && mu > bu) atomicMax((unsigned *)&bndw[(blockIdx.x * 2 + wv) & (RANK_SLOTS - 1)], mu);
   }
   __syncthreads();
-  // ---- rows the ranking could not narrow down: the contract's distances to EVERY centroid, by the whole workgroup ----
-  const int nfull = s_nfull;
-  for (int e = 0; e < nfull; e++) {
-    const int lr = s_full[e];
+  RPROF(3)
+  // ---- rows between two candidates: the contract's two f64 chains, one wave per row (lane = feature for the loads; the chains
+  // themselves are sequential: every lane walks them over the wave's LDS strip) ----
+  const int ntwo = s_ntwo;
+  for (int e = wv; e < ntwo; e += NW) {
+    const int lr = s_two[e][0], lo = s_two[e][1], hi = s_two[e][2];
     const long long r = r0 + lr, f = st.rows ? (long long)st.rows[r] : r;
-    if (tid < D) s_row[tid] = (double)X[f * ldx + tid];
-    __syncthreads();
-    double bd = inf;
-    int bj = 0x7fffffff;
-    for (int j = tid; j < st.K; j += 256) {  // a thread's centroids ascend: strict < keeps its lowest index
-      const GAS double *cj = st.C + (size_t)j * D;
-      double dot = 0.0;
-      for (int k0 = 0; k0 < D; k0 += 8) {
-        double cv[8];
-#pragma unroll
-        for (int i = 0; i < 8; i++) cv[i] = cj[k0 + i < D ? k0 + i : D - 1];
-#pragma unroll
-        for (int i = 0; i < 8; i++)
-          if (k0 + i < D) dot = __builtin_fma(cv[i], s_row[k0 + i], dot);
-      }
-      const double d = __builtin_fma(-2.0, dot, st.csq[j]);
-      if (d < bd) {
-        bd = d;
-        bj = j;
-      }
+    const int kc = lane < D ? lane : D - 1;
+    const double xv = (double)X[f * ldx + kc], lv = st.C[(size_t)lo * D + kc], hv = st.C[(size_t)hi * D + kc];
+    const double cslo = st.csq[lo], cshi = st.csq[hi];
+    s_t[wv][0][lane] = xv;
+    s_t[wv][1][lane] = lv;
+    s_t[wv][2][lane] = hv;
+    __builtin_amdgcn_wave_barrier();  // (the strip is the wave's own: LDS accesses of one wave complete in order)
+    double dl = 0.0, dh = 0.0;
+    for (int k = 0; k + 1 < D; k += 2) {
+      const double2 tx = *(const double2 *)&s_t[wv][0][k], tl = *(const double2 *)&s_t[wv][1][k], th = *(const double2 *)&s_t[wv][2][k];
+      dl = __builtin_fma(tl.x, tx.x, dl);
+      dh = __builtin_fma(th.x, tx.x, dh);
+      dl = __builtin_fma(tl.y, tx.y, dl);
+      dh = __builtin_fma(th.y, tx.y, dh);
     }
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) {
-      const double d2 = __shfl_xor(bd, off, 64);
-      const int j2 = __shfl_xor(bj, off, 64);
-      const bool take = (d2 < bd) || (d2 == bd && j2 < bj);
-      bd = take ? d2 : bd;
-      bj = take ? j2 : bj;
+    if (D & 1) {
+      dl = __builtin_fma(s_t[wv][1][D - 1], s_t[wv][0][D - 1], dl);
+      dh = __builtin_fma(s_t[wv][2][D - 1], s_t[wv][0][D - 1], dh);
     }
+    __builtin_amdgcn_wave_barrier();
+    dl = __builtin_fma(-2.0, dl, cslo);
+    dh = __builtin_fma(-2.0, dh, cshi);
     if (lane == 0) {
-      s_d[wv] = bd;
-      s_i[wv] = bj;
+      const int lab = dl <= dh ? lo : (dh < dl ? hi : -1);  // first strict minimum over ascending j; a NaN: to the exact sweep
+      s_lab[lr] = lab;
+      if (lab < 0) s_full[atomicAdd(&s_nfull, 1)] = lr;
     }
-    __syncthreads();
-    if (tid == lr) {
-      double d = s_d[0];
-      int j = s_i[0];
-#pragma unroll
-      for (int w = 1; w < 4; w++) {
-        const bool take = (s_d[w] < d) || (s_d[w] == d && s_i[w] < j);
-        d = take ? s_d[w] : d;
-        j = take ? s_i[w] : j;
-      }
-      label = j == 0x7fffffff ? 0 : j;  // all-NaN row: label 0 like the oracle
-    }
-    __syncthreads();
   }
+  __syncthreads();
+  // ---- rows the ranking could not narrow down: the contract's distances to EVERY centroid on the f64 matrix unit, 16 rows at a
+  // time -- k_step_assign's arithmetic and orders (centroid fragments as the A operand, rows as B, d = fma(-2, chain, csq), first
+  // minimum: register-local per lane, then over the four lane groups, then over the waves) ----
+  const int nfull = s_nfull;
+  if (nfull > 0) {
+    constexpr int KSM = 4 * KB;  // k-steps this instantiation can need (KS = ceil(D / 4) <= KSM)
+    const int njt16 = (st.K + 15) >> 4;
+    for (int g0 = 0; g0 < nfull; g0 += 16) {
+      const int li = g0 + (lane & 15);
+      const int lr = s_full[li < nfull ? li : g0];
+      const long long r = r0 + lr, f = st.rows ? (long long)st.rows[r] : r;
+      double a[KSM];
+#pragma unroll
+      for (int ks = 0; ks < KSM; ks++) {
+        const int k = ks * 4 + (lane >> 4);
+        const double v = (double)X[f * ldx + (k < D ? k : D - 1)];  // (unconditional: features past D meet zero fragments or no MFMA at all)
+        a[ks] = k < D ? v : 0.0;
+      }
+      double bd = inf;
+      int bi = 0x7fffffff;
+      for (int jt = wv; jt < njt16; jt += NW) {
+        v4f64 acc = (v4f64){0.0, 0.0, 0.0, 0.0};
+        double cs[4];
+#pragma unroll
+        for (int q = 0; q < 4; q++) cs[q] = st.csq[jt * 16 + (lane >> 4) + 4 * q];
+        double bq[KSM];
+#pragma unroll
+        for (int ks = 0; ks < KSM; ks++) bq[ks] = st.Bpack[((size_t)jt * KS + (ks < KS ? ks : KS - 1)) * 64 + lane];
+#pragma unroll
+        for (int ks = 0; ks < KSM; ks++)
+          if (ks < KS) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(bq[ks], a[ks], acc, 0, 0, 0);  // (wave-uniform)
+        const int j0 = jt * 16 + (lane >> 4);
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+          const double d = __builtin_fma(-2.0, acc[q], cs[q]);
+          const bool lt = d < bd;  // a lane's centroids ascend (q, then tile), so strict < keeps its lowest j
+          bd = lt ? d : bd;
+          bi = lt ? j0 + 4 * q : bi;
+        }
+      }
+#pragma unroll
+      for (int off = 16; off <= 32; off <<= 1) {  // lanes l, l^16, l^32, l^48 hold the same row
+        const double d2 = __shfl_xor(bd, off, 64);
+        const int j2 = __shfl_xor(bi, off, 64);
+        const bool take = (d2 < bd) || (d2 == bd && j2 < bi);
+        bd = take ? d2 : bd;
+        bi = take ? j2 : bi;
+      }
+      if (lane < 16) {
+        s_fd[wv][lane] = bd;
+        s_fi[wv][lane] = bi;
+      }
+      __syncthreads();
+      if (tid < 16 && g0 + tid < nfull) {
+        double d = s_fd[0][tid];
+        int j = s_fi[0][tid];
+#pragma unroll
+        for (int w = 1; w < NW; w++) {
+          const bool take = (s_fd[w][tid] < d) || (s_fd[w][tid] == d && s_fi[w][tid] < j);
+          d = take ? s_fd[w][tid] : d;
+          j = take ? s_fi[w][tid] : j;
+        }
+        s_lab[s_full[g0 + tid]] = j == 0x7fffffff ? 0 : j;  // all-NaN row: label 0 like the oracle
+      }
+      __syncthreads();
+    }
+  }
+  if (mine && kind != 0) {
+    kind = s_lab[tid] >= 0 && kind == 1 ? 1 : 2;  // (a two-candidate row whose chains were not comparable went to the sweep)
+    label = s_lab[tid];
+  }
+  RPROF(4)
   if (mine) {
     st.labels[rme] = label;
     // (result unused: a non-returning atomic -- the workgroup does not wait for it)
     __hip_atomic_fetch_or(&st.mbits[(size_t)label * sdesc.wstride + (rme >> 6)], 1ull << (rme & 63), __ATOMIC_RELAXED,
                           __HIP_MEMORY_SCOPE_AGENT);
   }
-  if (wv == 0 && rk.stat) {  // (the rows' threads all sit in wave 0: one add per kind and workgroup)
-    kind = full ? 2 : kind;
+  if (wv < 2 && rk.stat) {  // (the rows' threads sit in waves 0 and 1: one add per kind and wave)
 #pragma unroll
     for (int q = 0; q < 3; q++) {
       const int n = __popcll(__ballot(mine && kind == q));
       if (lane == 0 && n) atomicAdd(rk.stat + q, (unsigned long long)n);
     }
   }
+  {
+    // the batch rows as f64 for the M-step (rows of 4 KS doubles, the batch padded to whole 64-row tiles), from the values the
+    // prologue loaded.  LAST: stores count in vmcnt, and issued in the prologue every later wait of the wave for a load also waited
+    // for their acknowledgements (the sweep of a copying wave took 3 us longer).  Here nothing waits for them but the end of the kernel.
+    const int ldg = 4 * KS;
+    const long long n_pad = (st.n_b + 63) & ~63LL;
+    if (rmine < n_pad) {
+      GAS double *xg = st.Xg + (size_t)rmine * ldg;
+#pragma unroll
+      for (int mm = 0; mm < KBH; mm++)
+#pragma unroll
+        for (int w = 0; w < 4; w++)
+          if (const int k = 16 * (2 * mm + mpar) + 8 * h + 2 * w; k < ldg)  // (ldg is a multiple of 4, k even: the pair stays inside the row)
+            *(GAS v2f64 *)(xg + k) = (v2f64){(double)raw[mm][2 * w], (double)raw[mm][2 * w + 1]};
+    }
+  }
+  asm volatile("" ::"v"(pfv[0]), "v"(pfv[1]));  // the touched lines are only wanted in L2
+  RPROF(5)
+  RPROF_END
   if (stamp && threadIdx.x == 0) atomicMax(&stamp[1], (unsigned long long)wall_clock64());
 }
 
@@ -1879,7 +2027,7 @@ __global__ __launch_bounds__(256, 2) void k_step_assign_ranked(const StepPack pk
 // (`apk` != null -- the ranked E-step's run, below: the wave also rewrites its centroid's bf16 fragments, KB blocks of 16 slots)
 template <typename XT, int H, bool BYVAL, int UPD_NBK>
 __device__ __forceinline__ void step_update_body(const StepDev *__restrict__ steps, const StepPack &pk, int64_t ldx, int D, int KS,
-                                                 GAS unsigned short *apk, int KB) {
+                                                 GAS unsigned short *apk, GAS float *hcs, int KB) {
   SPROF_ID
   SPROF(1, 0)
   const StepDev sdesc = load_step<BYVAL>(steps, pk, blockIdx.y);
@@ -2007,7 +2155,7 @@ __device__ __forceinline__ void step_update_body(const StepDev *__restrict__ ste
   if (D & 1) a = __builtin_fma(vb[D - 1], vb[D - 1], a);
   if (lane == 0) st.csq[j] = a;
   if constexpr (H == 1) {
-    if (apk) rank_store_row(apk, KB, j, lane, D, v[0], a);
+    if (apk) rank_store_row(apk, hcs, KB, j, lane, D, v[0], a);
   }
   SPROF_W(1, 5)
 #if defined(STEP_PROFILE) && STEP_PROFILE < 2
@@ -2018,11 +2166,11 @@ __device__ __forceinline__ void step_update_body(const StepDev *__restrict__ ste
 template <typename XT, int H, bool BYVAL, int UPD_NBK>
 __global__ __launch_bounds__(256) void k_step_update(const StepDev *__restrict__ steps, const StepPack pk, int64_t ldx, int D,
                                                      int KS) {
-  step_update_body<XT, H, BYVAL, UPD_NBK>(steps, pk, ldx, D, KS, nullptr, 0);
+  step_update_body<XT, H, BYVAL, UPD_NBK>(steps, pk, ldx, D, KS, nullptr, nullptr, 0);
 }
 template <typename XT, int UPD_NBK>
 __global__ __launch_bounds__(256) void k_step_update_ranked(const StepPack pk, const RankPack rk, int64_t ldx, int D, int KS, int KB) {
-  step_update_body<XT, 1, true, UPD_NBK>(nullptr, pk, ldx, D, KS, (GAS unsigned short *)gp(rk.apk[blockIdx.y]), KB);
+  step_update_body<XT, 1, true, UPD_NBK>(nullptr, pk, ldx, D, KS, (GAS unsigned short *)gp(rk.apk[blockIdx.y]), gp(rk.hcs[blockIdx.y]), KB);
 }
 
 
@@ -2078,7 +2226,7 @@ __global__ __launch_bounds__(256) void k_step_check(const StepDev *__restrict__ 
 // the permutation fails (nothing low, or more than the rule / the supplied head allows) the stratum's chain stops.
 template <typename XT, bool BYVAL>
 __device__ __forceinline__ void step_reassign_body(const StepDev *__restrict__ steps, const StepPack &pk, int64_t ldx, int D, int KS,
-                                                   double ratio, GAS unsigned short *apk, int KB) {
+                                                   double ratio, GAS unsigned short *apk, GAS float *hcs, int KB) {
   const StepDev sdesc = load_step<BYVAL>(steps, pk, blockIdx.x);
   const StepG st(sdesc);
   if (!(st.flags & 1) || !sdesc.perm || st.idx >= *gp(sdesc.halt)) return;
@@ -2195,7 +2343,7 @@ __device__ __forceinline__ void step_reassign_body(const StepDev *__restrict__ s
         st.csq[jc] = a;
         st.counts[jc] = new_count;
       }
-      if (apk) rank_store_row(apk, KB, jc, lane, D, v[0], a);  // (the ranked E-step's run: D <= 64, one feature per lane)
+      if (apk) rank_store_row(apk, hcs, KB, jc, lane, D, v[0], a);  // (the ranked E-step's run: D <= 64, one feature per lane)
     }
     base += total;
     __syncthreads();
@@ -2204,12 +2352,12 @@ __device__ __forceinline__ void step_reassign_body(const StepDev *__restrict__ s
 template <typename XT, bool BYVAL>
 __global__ __launch_bounds__(256) void k_step_reassign(const StepDev *__restrict__ steps, const StepPack pk, int64_t ldx, int D,
                                                        int KS, double ratio) {
-  step_reassign_body<XT, BYVAL>(steps, pk, ldx, D, KS, ratio, nullptr, 0);
+  step_reassign_body<XT, BYVAL>(steps, pk, ldx, D, KS, ratio, nullptr, nullptr, 0);
 }
 template <typename XT>
 __global__ __launch_bounds__(256) void k_step_reassign_ranked(const StepPack pk, const RankPack rk, int64_t ldx, int D, int KS, double ratio,
                                                               int KB) {
-  step_reassign_body<XT, true>(nullptr, pk, ldx, D, KS, ratio, (GAS unsigned short *)gp(rk.apk[blockIdx.x]), KB);
+  step_reassign_body<XT, true>(nullptr, pk, ldx, D, KS, ratio, (GAS unsigned short *)gp(rk.apk[blockIdx.x]), gp(rk.hcs[blockIdx.x]), KB);
 }
 
 // ---- more than 128 features: generic training kernels ---------------------------------------------------
@@ -2684,16 +2832,13 @@ static int launch_steps(hamsm_ctx *c, hipStream_t q, const StepDev *d_steps, con
 template <typename XT>
 static int launch_steps_ranked(hamsm_ctx *c, hipStream_t q, const StepPack &pk, const RankPack &rk, int ny, long long max_nb, int maxK,
                                int64_t ldx, double ratio, bool any_perm) {
-  const int KB = (c->D + 16) / 16;  // blocks of 16 feature slots: the features, the csq slot, padding
+  const int KB = (c->D + 15) / 16;  // blocks of 16 feature slots (the csq term rides in the accumulator's initial value)
   // the light form's certificate (assign.hip, launch_sorted): 3 MFMAs x 17 roundings per 16 slots, taken four times (204 KB);
   // the three dropped 2^-14-level piece products (6186 u, u = 2^-24); rounding of c and of f64 frames to f32 (2 u); the index
-  // bits (64 u, 32 u); the csq slot loses its third piece (1024 u)
+  // bits (64 u, 32 u); -csq / 2 rounded to f32 once (1 u)
   const float c1 = 2.02f * (float)(6186 + 2 * (2 + 204 * KB) + 64) / 16777216.0f;
-  const float c2 = 2.02f * (float)(1024 + 204 * KB + 1 + 32) / 16777216.0f;
-  const char *rt_s = getenv("HAMSM_RANKED_RT");  // (tests / experiments force a tile count)
-  const long long tiles = (max_nb + 31) / 32 * ny;
-  const int rt = rt_s ? (atoi(rt_s) == 2 ? 2 : 1) : (tiles >= 2 * 256 ? 2 : 1);
-  const dim3 ga((unsigned)((max_nb + 32 * rt - 1) / (32 * rt)), (unsigned)ny);
+  const float c2 = 2.02f * (float)(204 * KB + 1 + 32) / 16777216.0f;
+  const dim3 ga((unsigned)((max_nb + 127) / 128), (unsigned)ny);
   const bool sample = q == c->stream && !HAMSM_CAPTURING(c) && c->ks_stamps && (c->ks_tick++ & 127) == 0 && c->ks_pending.size() < HAMSM_KS_SLOTS;
   hamsm_ctx::KSample ks{nullptr, nullptr, nullptr};
   unsigned long long *stamp = nullptr;
@@ -2714,12 +2859,10 @@ static int launch_steps_ranked(hamsm_ctx *c, hipStream_t q, const StepPack &pk, 
     ks.e2 = ev();
     hipEventRecord(ks.e0, q);
   }
-  switch (KB * 2 + (rt - 1)) {
-#define CASE(KBV, RTV)                                                                                                              \
-  case KBV * 2 + (RTV - 1):                                                                                                         \
-    hipLaunchKernelGGL((k_step_assign_ranked<XT, KBV, RTV>), ga, dim3(256), 0, q, pk, rk, ldx, c->D, c->KS, ratio, c1, c2, stamp);  \
-    break;
-    CASE(1, 1) CASE(1, 2) CASE(2, 1) CASE(2, 2) CASE(3, 1) CASE(3, 2) CASE(4, 1) CASE(4, 2) CASE(5, 1) CASE(5, 2)
+  switch (KB) {
+#define CASE(KBV) \
+  case KBV: hipLaunchKernelGGL((k_step_assign_ranked<XT, KBV>), ga, dim3(RANK_NW * 64), 0, q, pk, rk, ldx, c->D, c->KS, ratio, c1, c2, stamp); break;
+    CASE(1) CASE(2) CASE(3) CASE(4)
 #undef CASE
     default: return hamsm_fail(c, HAMSM_ENOTSUP, "ranked E-step: %d blocks of feature slots", KB);
   }
@@ -2808,7 +2951,7 @@ static int run_steps(hamsm_ctx *c, const void *X, int dt, int64_t ldx, const int
   // Calls whose E-step is bound by the f64 matrix unit rank their centroids on the bf16 unit instead (k_step_assign_ranked: same
   // labels).  Decided per run -- the fragments are maintained from step to step -- by its heaviest launch group; at most 64
   // features, a planned pass with row lists.  HAMSM_STEP_RANKED = 0 never, 1 by size (default), 2 always (tests).
-  const int KBr = (c->D + 16) / 16;
+  const int KBr = (c->D + 15) / 16;
   bool ranked = c->step_ranked && c->assign_filter && !generic && c->KS <= 16 && d_rows && h_report && nslot == c->S;
   if (ranked && c->step_ranked == 1) {
     double top = 0;
@@ -2820,8 +2963,9 @@ static int run_steps(hamsm_ctx *c, const void *X, int dt, int64_t ldx, const int
     ranked = top >= c->step_ranked_min_flop;
   }
   const size_t apk_words = (size_t)((Kmax + 31) / 32) * KBr * 2 * 256;  // per stratum
+  const size_t hcs_words = (size_t)((Kmax + 31) / 32) * 32;
   size_t o_apk = take(ranked ? sizeof(unsigned) * apk_words * (size_t)c->S : 0), o_bnd = take(ranked ? sizeof(unsigned) * RANK_SLOTS * (size_t)c->S : 0),
-         o_rstat = take(sizeof(unsigned long long) * 4);
+         o_hcs = take(ranked ? sizeof(float) * hcs_words * (size_t)c->S : 0), o_rstat = take(sizeof(unsigned long long) * 4);
   int rc = hamsm_ensure_scratch(c, off);
   if (rc) return rc;
   char *b = (char *)c->scratch;
@@ -2893,7 +3037,8 @@ static int run_steps(hamsm_ctx *c, const void *X, int dt, int64_t ldx, const int
       const Stratum &t = c->st[s];
       if (t.K > 0)
         hipLaunchKernelGGL(k_rank_pack, dim3((unsigned)((t.K + 31) / 32)), dim3(64), 0, c->stream, (const double *)t.C, (const double *)t.csq, t.K,
-                           c->D, KBr, (unsigned *)(b + o_apk) + apk_words * s, (unsigned *)(b + o_bnd) + RANK_SLOTS * s);
+                           c->D, KBr, (unsigned *)(b + o_apk) + apk_words * s, (float *)(b + o_hcs) + hcs_words * s,
+                           (unsigned *)(b + o_bnd) + RANK_SLOTS * s);
     }
   }
   // lanes: stratum s always runs on queue s % n_lanes, so every stratum's chain stays ordered; a lane's part of a
@@ -2953,6 +3098,7 @@ static int run_steps(hamsm_ctx *c, const void *X, int dt, int64_t ldx, const int
             const int y = h_steps[sq].stratum;
             pk.s[q] = sd[sq];
             rk.apk[q] = (unsigned *)(b + o_apk) + apk_words * y;
+            rk.hcs[q] = (float *)(b + o_hcs) + hcs_words * y;
             rk.bnd[q] = (unsigned *)(b + o_bnd) + RANK_SLOTS * y;
             ap = ap || sd[sq].perm;
             mnb = h_steps[sq].n_b > mnb ? h_steps[sq].n_b : mnb;
@@ -2960,6 +3106,14 @@ static int run_steps(hamsm_ctx *c, const void *X, int dt, int64_t ldx, const int
           }
           rk.stat = (unsigned long long *)(b + o_rstat);
           pk.n_next = 0;
+          if (g + 2 < gstart.size()) {  // the same strata's steps of the next group, in the same positions (none: n_b = 0)
+            for (int q = 0; q < nyc; q++) {
+              pk.nx[q] = StepNext{nullptr, nullptr, 0};
+              for (int64_t q2 = j; q2 < gstart[g + 2]; q2++)
+                if (h_steps[q2].stratum == h_steps[mine[c0_ + q]].stratum) pk.nx[q] = StepNext{sd[q2].X, sd[q2].rows, sd[q2].n_b};
+            }
+            pk.n_next = nyc;
+          }
           if (mnb <= 0) continue;
           rc = (dt == HAMSM_F32) ? launch_steps_ranked<float>(c, lanes[l], pk, rk, nyc, mnb, mK, ldx, ratio, ap)
                                  : launch_steps_ranked<double>(c, lanes[l], pk, rk, nyc, mnb, mK, ldx, ratio, ap);

@@ -60,19 +60,6 @@ def test_ranked_training_pass_equals_the_oracle(hip_h, oracle_h, name, cfg, k, k
         assert np.array_equal(x, y)
 
 
-@pytest.mark.parametrize("rt", ["1", "2"])
-def test_ranked_row_tile_variants(hip_h, oracle_h, rt, monkeypatch):
-    monkeypatch.setenv("HAMSM_RANKED_RT", rt)
-    cfg = synthetic.WEConfig("rkt", 21, 6, 6000, 30, 2, 100)
-    o = _run(oracle_h, cfg, 100, True)
-    _rank(hip_h, 2)
-    g = _run(hip_h, cfg, 100, True)
-    assert _rank(hip_h, 1)["runs"] >= 1
-    assert np.array_equal(g[1], o[1])
-    for x, y in zip(g[2] + g[3], o[2] + o[3]):
-        assert np.array_equal(x, y)
-
-
 def test_ranked_pass_with_adversarial_rows(hip_h, oracle_h):
     """exact ties (duplicated rows become duplicated seeds: every member of such a cluster ties between twins), rows scaled by
     1e18 (the f32 scores overflow: nothing may be certified), NaN / inf rows (label 0 like the oracle's all-NaN rule): the
