@@ -339,13 +339,22 @@ def full_pipeline(m, cfg, seed, flux_mode):
             "validation_JtargetSS": [float(v.JtargetSS) for v in m.validation_models]}
 
 
-def pmc_kernel_bytes(name_part):
+def pmc_file(workload):
+    """the committed rocprofv3 --pmc summary of this workload (latest round first); None when there is none"""
+    names = {"c3": ["r04_pmc_summary.csv", "r03_pmc_summary.csv", "r02_pmc_summary.csv"], "c5s": ["r04_pmc_summary_c5s.csv"],
+             "c5": ["r04_pmc_summary_c5s.csv"]}.get(workload, [])   # (c5's launches are c5s's: same per-iteration shapes)
+    for n in names:
+        p = os.path.join(ROOT, "profiles", n)
+        if os.path.exists(p):
+            return p
+    return None
+
+
+def pmc_kernel_bytes(name_part, workload="c3"):
     """(2 x FETCH_SIZE + WRITE_SIZE) x 1024 per dispatch of the kernel whose name contains `name_part`, from the committed
-    r03 PMC summary (C3 workload); None when absent"""
-    path = os.path.join(ROOT, "profiles", "r03_pmc_summary.csv")
-    if not os.path.exists(path):
-        path = os.path.join(ROOT, "profiles", "r02_pmc_summary.csv")
-    if not os.path.exists(path):
+    PMC summary of the workload; None when absent"""
+    path = pmc_file(workload)
+    if path is None:
         return None
     v = {}
     for line in open(path).read().splitlines()[1:]:
@@ -357,15 +366,15 @@ def pmc_kernel_bytes(name_part):
     return (2.0 * v["FETCH_SIZE"] + v["WRITE_SIZE"]) * 1024.0
 
 
-def step_roofline(cfg, n_iters, n_seg, e_ms, e_n, m_ms, e_events_ms):
-    """`roofline` of the bench line = the DOMINANT kernel of the timed step: k_step_assign, the E-step of a training step
-    (48 % of all kernel time, profiles/r03_bench_c3_kernel_stats.csv; with its M-step 78 %).  One launch serves the batches of the
-    two strata that share a queue: algorithmic flops = 2 strata x n_b x K_s x D x 2 (2 K_s D per row), n_b = the
-    rows of one WE iteration that fall into one stratum outside basis / target; duration = every 128th launch on the library's
-    queue, in this run: by the device's 100 MHz clock from the first wave's entry to the last wave's exit (`avg_launch_ms`,
-    what rocprofv3's kernel trace reports: 9.2 us in profiles/r03_bench_c3_kernel_stats.csv), and event to event
-    (`avg_launch_ms_hip_events`: the same launch INCLUDING its kernel boundary, ~3 us more -- an event pair cannot bracket a
-    10 us kernel any tighter)."""
+def step_roofline(cfg, n_iters, n_seg, e_ms, e_n, m_ms, e_events_ms, ranked=False):
+    """`roofline` of the bench line = the DOMINANT kernel of the timed step: the E-step of a training step -- `k_step_assign`
+    (f64 matrix unit; C3: 48 % of all kernel time, with its M-step 78 %) or, for calls that are bound by that unit (>= 1 GFLOP per
+    launch group: BASELINE config 5's shape), `k_step_assign_ranked` (bf16 matrix unit, exact f64 where the ranking cannot decide).
+    One launch serves the batches of the two strata that share a queue: algorithmic flops = 2 strata x n_b x K_s x D x 2 (SURVEY
+    §8d: 2 K_s D per row), n_b = the rows of one WE iteration that fall into one stratum outside basis / target; duration = every
+    128th launch on the library's queue, in this run: by the device's 100 MHz clock from the first wave's entry to the last wave's
+    exit (`avg_launch_ms`, what rocprofv3's kernel trace reports), and event to event (`avg_launch_ms_hip_events`: the same launch
+    INCLUDING its kernel boundary, ~3 us more -- an event pair cannot bracket a 10 us kernel any tighter)."""
     S, K_s, D = cfg.S, cfg.K_s, cfg.D
     strata_per_launch = 2 if S >= 2 else 1
     n_b = cfg.segs_per_iter * (1.0 - 0.1 / S) / S
@@ -373,14 +382,27 @@ def step_roofline(cfg, n_iters, n_seg, e_ms, e_n, m_ms, e_events_ms):
     bytes_alg = strata_per_launch * n_b * (D * 4 + 4)         # rows read + labels; centroid fragments are L2-resident
     e_ms = e_ms or float("nan")
     tf = flops / (e_ms * 1e-3) / 1e12
-    traffic = pmc_kernel_bytes("k_step_assign") if (cfg.name == "c3") else None
-    return {"bound": "mfma", "achieved": tf, "peak": PEAK_F64_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": tf / PEAK_F64_MFMA_TFLOPS,
-            "traffic": traffic,
-            "traffic_source": "profiles/r03_pmc_summary.csv (committed rocprofv3 --pmc passes of this workload; not measured in this "
-                              "run)" if traffic is not None else None,
+    kname = "k_step_assign_ranked" if ranked else "k_step_assign<"
+    traffic = pmc_kernel_bytes(kname, cfg.name)
+    src = pmc_file(cfg.name)
+    common = {"traffic": traffic,
+              "traffic_source": (f"profiles/{os.path.basename(src)} (committed rocprofv3 --pmc passes of this workload's launches; "
+                                 "not measured in this run)") if traffic is not None else None,
+              "avg_launch_ms": e_ms, "avg_launch_ms_hip_events": e_events_ms, "launches_sampled": e_n, "flop_per_launch": flops,
+              "algorithmic_bytes_per_launch": bytes_alg, "m_step_avg_launch_ms_hip_events": m_ms}
+    if ranked:
+        # every f32 product is formed from 3 of the 9 bf16 piece products (operands = exact sums of bf16 pieces): the roof of an
+        # algorithmic flop on this path is the bf16 MFMA peak / 3, as for the assignment's light ranking form
+        peak = PEAK_BF16_MFMA_TFLOPS / 3.0
+        return {"bound": "mfma", "achieved": tf, "peak": peak, "unit": "TFLOP/s", "frac": tf / peak, **common,
+                "frac_of_f64_mfma_peak": tf / PEAK_F64_MFMA_TFLOPS,
+                "kernel": "k_step_assign_ranked (v_mfma_f32_32x32x16_bf16 on fragments the M-step maintains; rows the ranking cannot "
+                          "certify: two f64 fma chains, or v_mfma_f64_16x16x4_f64 over all centroids), the E-step of one training step "
+                          "for the two strata of a queue",
+                "note": "what binds it is the fragment stream out of L2 (every workgroup reads its stratum's 256 B per centroid) and the "
+                        "chain prologue -> sweep -> merge -> settle of 195 workgroups per launch, not the matrix unit (DESIGN.md 5.3e)"}
+    return {"bound": "mfma", "achieved": tf, "peak": PEAK_F64_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": tf / PEAK_F64_MFMA_TFLOPS, **common,
             "kernel": "k_step_assign (v_mfma_f64_16x16x4_f64), the E-step of one training step for the two strata of a queue",
-            "avg_launch_ms": e_ms, "avg_launch_ms_hip_events": e_events_ms, "launches_sampled": e_n, "flop_per_launch": flops,
-            "algorithmic_bytes_per_launch": bytes_alg, "m_step_avg_launch_ms_hip_events": m_ms,
             "note": "latency-bound: ~2 500-row batches, 2 x n_iterations dependent launches per queue (DESIGN.md 5.3, 5.3a); the "
                     "assignment kernels have their own object, roofline_assign"}
 
@@ -395,7 +417,8 @@ def roofline_by_kernel(cfg, n_iters, n_seg, timers, steps, assign_tflops, assign
     train_flops = 2.0 * rows_trained * K_s * D        # E-step distances (the M-step adds 2 D per row)
     train_bytes = rows_trained * (2 * (D * 4 + 8) + 8 * D)   # rows read by the E-step, f64 copy written and re-read by the M-step
     out = [
-        {"stage": "training steps", "kernels": "k_step_assign (v_mfma_f64_16x16x4_f64) + k_step_update, one pair per WE iteration "
+        {"stage": "training steps", "kernels": "k_step_assign (v_mfma_f64_16x16x4_f64; calls of >= 1 GFLOP per launch group: "
+                                               "k_step_assign_ranked, bf16 matrix unit) + k_step_update, one pair per WE iteration "
                                                "and queue, two strata per launch", "launches_per_step": 4 * (n_iters - 0),
          "device_ms_per_step": per["step"], "flop": train_flops, "achieved_TFLOPs": train_flops / (per["step"] * 1e-3) / 1e12,
          "peak_TFLOPs": PEAK_F64_MFMA_TFLOPS, "frac": train_flops / (per["step"] * 1e-3) / 1e12 / PEAK_F64_MFMA_TFLOPS,
@@ -450,23 +473,14 @@ def ingest_leg(h, cfg, n_it, log):
 
 def pmc_traffic(cfg, n_iters):
     """HBM bytes per assign launch (ranking pass + exact pass) from the committed rocprofv3 PMC passes of this same workload
-    (profiles/r01_m_pmc_summary.csv: separate --pmc FETCH_SIZE / WRITE_SIZE runs; FETCH_SIZE doubled as
-    MI355X_MICROARCH.md prescribes for gfx950, calibrated here on k_sort_count's 80 MB pcoord read)."""
-    path = os.path.join(ROOT, "profiles", "r03_pmc_summary.csv")
-    for older in ("r02_pmc_summary.csv", "r01_m_pmc_summary.csv"):
-        if not os.path.exists(path):
-            path = os.path.join(ROOT, "profiles", older)
-    if cfg.name != "c3" or n_iters != cfg.n_iters or not os.path.exists(path):
+    (separate --pmc FETCH_SIZE / WRITE_SIZE runs; FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950, calibrated
+    here on k_sort_count's 80 MB pcoord read)."""
+    if n_iters != cfg.n_iters or cfg.name not in ("c3", "c5s"):
         return None
     filt = os.environ.get("HAMSM_ASSIGN_FILTER", "1") != "0"
-    vals = {}
-    for line in open(path).read().splitlines()[1:]:
-        k, c, _, v = line.rsplit(",", 3)
-        if "k_assign_sorted" in k or (filt and "k_assign_filter" in k):
-            vals[c] = vals.get(c, 0.0) + float(v)
-    if "FETCH_SIZE" not in vals or "WRITE_SIZE" not in vals:
-        return None
-    return (2.0 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024.0
+    a = pmc_kernel_bytes("k_assign_sorted", cfg.name)
+    b = pmc_kernel_bytes("k_assign_filter", cfg.name) if filt else 0.0
+    return None if a is None or b is None else a + b
 
 
 def main():
@@ -711,11 +725,11 @@ def main():
                                 "all the data" if train_on == "all" else
                                 "rank 0 trains on its own block of iterations only (iters_to_use); --train-on all gathers every shard")
                    if world > 1 else "all resident iterations", "exchange": exchange},
-        "roofline": step_roofline(cfg, n_iters, n_seg, e_dev_ms or e_ms, e_n, m_ms, e_ms),
+        "roofline": step_roofline(cfg, n_iters, n_seg, e_dev_ms or e_ms, e_n, m_ms, e_ms, ranked=rank_stats is not None),
         "roofline_assign": {"bound": "mfma", "achieved": tflops, "peak": peak, "unit": "TFLOP/s",
                             "frac": tflops / peak, "traffic": pmc_traffic(cfg, n_iters),
-                            "traffic_source": "committed rocprofv3 --pmc passes of this workload under profiles/ (r03_pmc_summary.csv, "
-                                              "else r01_m_pmc_summary.csv); not measured in this run" if pmc_traffic(cfg, n_iters) is not None else None,
+                            "traffic_source": (f"profiles/{os.path.basename(pmc_file(cfg.name))} (committed rocprofv3 --pmc passes of this "
+                                               "workload); not measured in this run") if pmc_traffic(cfg, n_iters) is not None else None,
                             "kernel": kernel, "arithmetic": arithmetic,
                             "f64_mfma_peak": PEAK_F64_MFMA_TFLOPS, "frac_of_f64_peak": tflops / PEAK_F64_MFMA_TFLOPS, **extra,
                             "avg_launch_ms": assign_avg_ms, "last_launch_ms": assign_ms,
