@@ -185,15 +185,8 @@ class ClusteringMixin:
                 for b in range(S):
                     clusters.we_remap[b] = int(remap[b])
 
-        old = self.__dict__.get("clusters")
         self.clusters = clusters
         self.clusters.model = self
-        if old is not None and old is not clusters:
-            # the object this call replaces: if the model held the only reference to it (besides its own parts'), its streams go
-            # back for re-use now rather than whenever the cycle collector finds it (StratumKMeans.__del__)
-            if sys.getrefcount(old) <= old._internal_refs() + 2:
-                old._retire_streams()
-        del old
         self.n_clusters = n_clusters * S  # :742 (quirk Q3)
         self.clusters.toggle = False
         self.launch_ray_discretization(progress_bar)

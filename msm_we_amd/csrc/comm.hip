@@ -41,6 +41,15 @@ extern "C" int hamsm_comm_init(hamsm_ctx *c, int nranks, int rank, const char *i
   // nranks / rank are published only with a live communicator: a failed init leaves the ctx a 1-rank context
   // whose collectives are no-ops, never "nranks > 1 with a null comm"
   NCCLCHK(c, ncclCommInitRank(&comm, nranks, id, rank));
+  // the device words every collective pre-check below needs are allocated HERE, with the communicator: a rank must never fail an
+  // allocation between "the others have entered a collective" and "this rank enters it" 
+  const size_t want = sizeof(int64_t) * (2 * (size_t)nranks + 8) + sizeof(int32_t) * HAMSM_MAX_STRATA;
+  if (hipMalloc(&c->comm_buf, want) != hipSuccess) {
+    ncclCommDestroy(comm);
+    c->comm_buf = nullptr;
+    return hamsm_fail(c, HAMSM_EDEVICE, "comm_init: %zu bytes of exchange scratch", want);
+  }
+  c->comm_buf_bytes = want;
   c->comm = (void *)comm;
   c->nranks = nranks;
   c->rank = rank;
@@ -52,6 +61,11 @@ extern "C" int hamsm_comm_destroy(hamsm_ctx *c) {
   if (c->comm) {
     ncclCommDestroy((ncclComm_t)c->comm);
     c->comm = nullptr;
+  }
+  if (c->comm_buf) {
+    hipFree(c->comm_buf);
+    c->comm_buf = nullptr;
+    c->comm_buf_bytes = 0;
   }
   c->nranks = 1;
   c->rank = 0;
@@ -124,11 +138,15 @@ extern "C" int hamsm_gather_to_root(hamsm_ctx *c, const void *d_send, size_t sen
   v[2 * R] = complaint;
   v[2 * R + 1] = -(int64_t)root;  // with its twin below: every rank names the same root
   v.push_back((int64_t)root);
-  int rc = hamsm_ensure_scratch(c, sizeof(int64_t) * v.size());
-  if (rc) return rc;
-  HIPCHK(c, hipMemcpyAsync(c->scratch, v.data(), sizeof(int64_t) * v.size(), hipMemcpyHostToDevice, c->stream));
-  NCCLCHK(c, ncclAllReduce(c->scratch, c->scratch, v.size(), ncclInt64, ncclMax, cm, c->stream));
-  HIPCHK(c, hipMemcpyAsync(v.data(), c->scratch, sizeof(int64_t) * v.size(), hipMemcpyDeviceToHost, c->stream));
+  // From here to the all-reduce NO rank-local return: a rank that left now would strand the others inside it.  The words live in
+  // the buffer comm_init allocated; a failed upload (the device is in an error state: nothing this library can repair) is
+  // remembered, the rank still enters the collective with whatever the buffer holds, and reports its own failure afterwards.
+  int64_t *d_v = (int64_t *)c->comm_buf;
+  const hipError_t e_up = hipMemcpyAsync(d_v, v.data(), sizeof(int64_t) * v.size(), hipMemcpyHostToDevice, c->stream);
+  const ncclResult_t e_ar = ncclAllReduce(d_v, d_v, v.size(), ncclInt64, ncclMax, cm, c->stream);
+  if (e_up != hipSuccess) return hamsm_fail(c, HAMSM_EDEVICE, "gather_to_root: upload of the argument check failed: %s", hipGetErrorString(e_up));
+  if (e_ar != ncclSuccess) return hamsm_fail(c, HAMSM_EDEVICE, "gather_to_root: ncclAllReduce failed: %s", ncclGetErrorString(e_ar));
+  HIPCHK(c, hipMemcpyAsync(v.data(), d_v, sizeof(int64_t) * v.size(), hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
   if (v[2 * R])
     return hamsm_fail(c, HAMSM_EINVAL, "gather_to_root: a rank's arguments are inconsistent (largest flag word over all ranks %lld, here %lld: "
@@ -160,56 +178,75 @@ extern "C" int hamsm_gather_to_root(hamsm_ctx *c, const void *d_send, size_t sen
   return HAMSM_OK;
 }
 
-// centroids, counts, ||c||^2 and remap of every stratum, root -> all (exact-mode training: SURVEY §7 hard part 3)
+// centroids, counts, ||c||^2 and remap of every stratum, root -> all (exact-mode training: SURVEY §7 hard part 3).
+// Collective discipline: between two collectives a rank never returns on a failure of its own -- it carries the
+// failure into the next collective (a min-all-reduce of "ready" flags), after which EVERY rank returns or EVERY rank goes on;
+// everything that can only fail locally and needs no partner (re-packing the fragments) comes after the last collective.
 extern "C" int hamsm_bcast_model(hamsm_ctx *c, int root) {
   CTX(c);
   if (c->nranks == 1 && !c->comm) return HAMSM_OK;
   if (!c->comm) return hamsm_fail(c, HAMSM_EINVAL, "comm not initialised");
   const int S = c->S;
-  int rc = hamsm_ensure_scratch(c, sizeof(int32_t) * S);
-  if (rc) return rc;
+  ncclComm_t cm = (ncclComm_t)c->comm;
+  if (sizeof(int64_t) * 8 + sizeof(int32_t) * (size_t)S > c->comm_buf_bytes) return hamsm_fail(c, HAMSM_EINVAL, "bcast_model: %d strata", S);
+  int64_t *d_flag = (int64_t *)c->comm_buf;               // [1] ready flag
+  int32_t *d_K = (int32_t *)((char *)c->comm_buf + 64);   // [S] fitted centroids per stratum, root's
   std::vector<int32_t> Ks(S);
   for (int s = 0; s < S; s++) Ks[s] = c->st[s].K;
-  HIPCHK(c, hipMemcpyAsync(c->scratch, Ks.data(), sizeof(int32_t) * S, hipMemcpyHostToDevice, c->stream));
-  rc = hamsm_bcast(c, c->scratch, sizeof(int32_t) * S, root);
-  if (rc) return rc;
-  HIPCHK(c, hipMemcpyAsync(Ks.data(), c->scratch, sizeof(int32_t) * S, hipMemcpyDeviceToHost, c->stream));
-  HIPCHK(c, hipStreamSynchronize(c->stream));
-  for (int s = 0; s < S; s++) {
-    Stratum &t = c->st[s];
-    if (Ks[s] > 0) {
-      rc = hamsm_stratum_reserve(c, s, Ks[s]);
-      if (rc) return rc;
-    }
-    t.K = Ks[s];
+  // (1) the strata's sizes.  A failed upload is carried along: the rank still enters the broadcast.
+  hipError_t e_loc = hipMemcpyAsync(d_K, Ks.data(), sizeof(int32_t) * S, hipMemcpyHostToDevice, c->stream);
+  ncclResult_t e_n = ncclBroadcast(d_K, d_K, sizeof(int32_t) * (size_t)S, ncclChar, root, cm, c->stream);
+  if (e_loc == hipSuccess && e_n == ncclSuccess) e_loc = hipMemcpyAsync(Ks.data(), d_K, sizeof(int32_t) * S, hipMemcpyDeviceToHost, c->stream);
+  if (e_loc == hipSuccess) e_loc = hipStreamSynchronize(c->stream);
+  // (2) room for them -- may fail on this rank alone (memory) -- then everybody learns whether everybody is ready
+  int rc_loc = (e_loc != hipSuccess || e_n != ncclSuccess) ? HAMSM_EDEVICE : HAMSM_OK;
+  for (int s = 0; s < S && !rc_loc; s++) {
+    if (Ks[s] < 0) rc_loc = HAMSM_EINVAL;
+    else if (Ks[s] > 0) rc_loc = hamsm_stratum_reserve(c, s, Ks[s]);
   }
+  int64_t ready = rc_loc ? 0 : 1;
+  const hipError_t e_up = hipMemcpyAsync(d_flag, &ready, sizeof(ready), hipMemcpyHostToDevice, c->stream);
+  const ncclResult_t e_ar = ncclAllReduce(d_flag, d_flag, 1, ncclInt64, ncclMin, cm, c->stream);
+  int64_t all_ready = 0;
+  hipError_t e_dn = hipMemcpyAsync(&all_ready, d_flag, sizeof(all_ready), hipMemcpyDeviceToHost, c->stream);
+  if (e_dn == hipSuccess) e_dn = hipStreamSynchronize(c->stream);  // (also: `ready` is a local the upload reads)
+  if (rc_loc) return hamsm_fail(c, rc_loc, "bcast_model: this rank could not prepare (sizes: %s / %s; or no room for the strata)",
+                                hipGetErrorString(e_loc), ncclGetErrorString(e_n));
+  if (e_up != hipSuccess || e_ar != ncclSuccess || e_dn != hipSuccess)
+    return hamsm_fail(c, HAMSM_EDEVICE, "bcast_model: readiness exchange failed (%s / %s / %s)", hipGetErrorString(e_up), ncclGetErrorString(e_ar),
+                      hipGetErrorString(e_dn));
+  if (!all_ready) return hamsm_fail(c, HAMSM_EDEVICE, "bcast_model: another rank could not prepare to receive the model; nothing was sent");
+  for (int s = 0; s < S; s++) c->st[s].K = Ks[s];
+  // (3) the tables and the remap, one group: the last collective of this call
   ncclResult_t first = ncclSuccess;
   NCCLCHK(c, ncclGroupStart());
   for (int s = 0; s < S; s++) {
     Stratum &t = c->st[s];
     if (t.K == 0) continue;
-    ncclComm_t cm = (ncclComm_t)c->comm;
     ncclResult_t r3[3] = {ncclBroadcast(t.C, t.C, (size_t)t.K * c->D, ncclDouble, root, cm, c->stream),
                           ncclBroadcast(t.csq, t.csq, (size_t)t.K, ncclDouble, root, cm, c->stream),
                           ncclBroadcast(t.counts, t.counts, (size_t)t.K, ncclDouble, root, cm, c->stream)};
     for (ncclResult_t r_ : r3)
       if (first == ncclSuccess) first = r_;
   }
-  ncclResult_t end = ncclGroupEnd();
+  {
+    const ncclResult_t r_ = ncclBroadcast(c->d_remap, c->d_remap, sizeof(int32_t) * (size_t)S, ncclChar, root, cm, c->stream);
+    if (first == ncclSuccess) first = r_;
+  }
+  ncclResult_t end = ncclGroupEnd();  // (always closed, also after a failed call inside it)
+  c->table_dirty = true;
   if (first != ncclSuccess) return hamsm_fail(c, HAMSM_EDEVICE, "bcast_model: ncclBroadcast failed: %s", ncclGetErrorString(first));
   if (end != ncclSuccess) return hamsm_fail(c, HAMSM_EDEVICE, "bcast_model: ncclGroupEnd failed: %s", ncclGetErrorString(end));
+  // (4) local only: re-pack the MFMA B fragments from the broadcast rows, keeping the broadcast ||c||^2
   for (int s = 0; s < S; s++) {
-    // re-pack the MFMA B fragments locally from the broadcast rows, keeping the broadcast ||c||^2
     Stratum &t = c->st[s];
     if (t.K == 0) continue;
-    rc = hamsm_ensure_scratch(c, sizeof(double) * t.K);
+    int rc = hamsm_ensure_scratch(c, sizeof(double) * t.K);
     if (rc) return rc;
     HIPCHK(c, hipMemcpyAsync(c->scratch, t.csq, sizeof(double) * t.K, hipMemcpyDeviceToDevice, c->stream));
     rc = hamsm_pack_stratum(c, s, (const double *)c->scratch);
     if (rc) return rc;
     HIPCHK(c, hipStreamSynchronize(c->stream));
   }
-  rc = hamsm_bcast(c, c->d_remap, sizeof(int32_t) * S, root);
-  c->table_dirty = true;
-  return rc;
+  return HAMSM_OK;
 }

@@ -180,6 +180,8 @@ struct hamsm_ctx {
   int assign_waves = 4;    // waves per workgroup of the sorted assign kernel (HAMSM_ASSIGN_W=8: 8 waves x 2 centroid tiles)
   void *seed_chosen_dev = nullptr;  // chosen indices of the last seeding's first item (device)
   void *comm = nullptr;  // ncclComm_t
+  void *comm_buf = nullptr;  // device words of the collectives' argument / readiness exchanges (allocated with the communicator)
+  size_t comm_buf_bytes = 0;
   int nranks = 1, rank = 0;
 };
 

@@ -273,6 +273,10 @@ extern "C" int hamsm_train_build_rows_batched(hamsm_ctx *c, const int32_t *bin, 
     off = (off + bytes + 255) & ~(size_t)255;
     return o;
   };
+  // the calls' remap rows name strata: an entry outside [0, S) would index the kernels' per-stratum counters out of bounds
+  for (int64_t i = 0; i < G * (int64_t)c->S; i++)
+    if (h_cr[i] < 0 || h_cr[i] >= c->S)
+      return hamsm_fail(c, HAMSM_EINVAL, "call_remap[%lld][%lld] = %d is not a stratum (0..%d)", (long long)(i / c->S), (long long)(i % c->S), h_cr[i], c->S - 1);
   size_t o_rg = take(sizeof(long long) * 2 * G), o_cr = take(sizeof(int32_t) * G * c->S),
          o_cnt = take(sizeof(long long) * G * c->S), o_st = take(sizeof(long long) * G * c->S),
          o_rank = take(sizeof(int32_t) * (size_t)hi);
@@ -282,11 +286,15 @@ extern "C" int hamsm_train_build_rows_batched(hamsm_ctx *c, const int32_t *bin, 
   HIPCHK(c, hipMemcpyAsync(b + o_rg, h_range, sizeof(long long) * 2 * G, hipMemcpyHostToDevice, c->stream));
   HIPCHK(c, hipMemcpyAsync(b + o_cr, h_cr, sizeof(int32_t) * G * c->S, hipMemcpyHostToDevice, c->stream));
   hamsm_timer_begin(c);
-  if (nmax <= BR_WAVE_MAX)
-    hipLaunchKernelGGL(c->S <= BR_SREG ? k_build_rows_wave<true> : k_build_rows_wave<false>, dim3((unsigned)((G + 3) / 4)), dim3(256),
-                       sizeof(int) * 8 * c->S, c->stream, bin, (const long long *)(b + o_rg), (const int32_t *)(b + o_cr), c->S,
-                       (long long)G, rows, (long long *)(b + o_cnt), (long long *)(b + o_st));
-  else
+  // (the wave form keeps 32 B of LDS per stratum: more than the default 64 KB from 2049 strata on -- a 50 x 50 bin mapper -- and
+  // within the CU's 160 KB for every S this library accepts, HAMSM_MAX_STRATA = 4096; beyond that the sweep form, which needs none)
+  const size_t br_lds = sizeof(int) * 8 * (size_t)c->S;
+  if (nmax <= BR_WAVE_MAX && br_lds <= 160 * 1024) {
+    auto kern = c->S <= BR_SREG ? k_build_rows_wave<true> : k_build_rows_wave<false>;
+    if (br_lds > 48 * 1024) HIPCHK(c, hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)br_lds));
+    hipLaunchKernelGGL(kern, dim3((unsigned)((G + 3) / 4)), dim3(256), br_lds, c->stream, bin, (const long long *)(b + o_rg),
+                       (const int32_t *)(b + o_cr), c->S, (long long)G, rows, (long long *)(b + o_cnt), (long long *)(b + o_st));
+  } else
     hipLaunchKernelGGL(k_build_rows, dim3((unsigned)G), dim3(BR_T), 0, c->stream, bin, (const long long *)(b + o_rg),
                        (const int32_t *)(b + o_cr), c->S, (int32_t *)(b + o_rank), rows, (long long *)(b + o_cnt),
                        (long long *)(b + o_st));

@@ -146,10 +146,14 @@ class WestpaH5Source:
 
     def load(self, n):
         key = "iterations/iter_%08d" % int(n)
+        nxt = "iterations/iter_%08d/seg_index" % (int(n) + 1)
         parts = []
         with self.session():
             for file_idx, f in enumerate(self._files):
-                if key not in f:
+                # the reference's test is PER FILE (`_data.py:857-866`): a file contributes iteration n only if it also holds
+                # iteration n + 1 ("last iterations have incomplete data") -- with files of different lengths the segment sets,
+                # westList / segindList and numSegments depend on it
+                if (key + "/seg_index") not in f or nxt not in f:
                     continue
                 g = f[key]
                 pc = np.asarray(g["pcoord"][:])
@@ -286,7 +290,13 @@ class DataMixin:
         with self._source_session():
             its = self._source.iterations()
             complete = [i for i in its if (i + 1) in set(its)]
-            self.numSegments = np.array([len(self._load(i)["w"]) for i in complete], dtype=float)
+            segs = []
+            for i in complete:   # (the reference counts on while an iteration has segments, :953-987; a source whose files
+                try:             # hold an iteration but not its successor in the SAME file yields none: KeyError)
+                    segs.append(len(self._load(i)["w"]))
+                except KeyError:
+                    break
+            self.numSegments = np.array(segs, dtype=float)
         self.maxIter = self.numSegments.size
 
     def load_iter_data(self, n_iter):
@@ -527,8 +537,10 @@ class DataMixin:
                             else:
                                 for b_ in raw:
                                     b_.free()
+                                raw = []
                                 raw = [h.alloc(max(rows_max, 1) * raw_w, np.float64) for _ in range(2)]
                             free_slabs(slabs)
+                            slabs = []   # (if the allocation below raises, the `finally` must not meet the freed slabs again)
                             up_dtype, widened = np.float64, True
                             slabs = alloc_slabs(up_dtype)
                             n, nan_p, nan_c, fits = self._fill_slab(ch, mode, slabs[k & 1], up_dtype, preloaded, readers)

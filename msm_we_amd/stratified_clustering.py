@@ -17,7 +17,6 @@ Objects pickle / deepcopy as plain NumPy (no live handles), as the restart plugi
 from __future__ import annotations
 
 import numbers
-import sys
 import weakref
 
 import numpy as np
@@ -27,26 +26,14 @@ from . import _abi
 __all__ = ["StratifiedClusters", "StratumKMeans"]
 
 
-# RandomState objects whose only owner -- a StratumKMeans that made them from an integer seed -- is gone.  Constructing a
-# RandomState costs ~0.1 ms (the bit generator first seeds itself from OS entropy), seeding an existing one 1.5 us, and a model
-# build makes one per stratum before anything can be launched; `seed(s)` leaves exactly the state `RandomState(s)` starts in
-# (legacy seeding, Gaussian cache cleared).
-_RS_SPARE = []
-
-
 def _check_random_state(seed, owner=None):
-    # sklearn.utils.check_random_state semantics (utils/validation.py)
+    # sklearn.utils.check_random_state semantics (utils/validation.py).  (Round 3 recycled the RandomState objects of models that
+    # had been replaced, deciding ownership by reference counts -- 0.1 ms per construction saved, fragile under any caller that
+    # held one: dropped in round 4.)
     if seed is None or seed is np.random:
         return np.random.mtrand._rand
     if isinstance(seed, numbers.Integral):
-        if _RS_SPARE:
-            rs = _RS_SPARE.pop()
-            rs.seed(seed)
-        else:
-            rs = np.random.RandomState(seed)
-        if owner is not None:
-            owner.__dict__["_rs_own"] = rs
-        return rs
+        return np.random.RandomState(seed)
     if isinstance(seed, np.random.RandomState):
         return seed
     raise ValueError(f"{seed!r} cannot be used to seed a numpy.random.RandomState instance")
@@ -128,15 +115,6 @@ class StratumKMeans:
             self.__dict__["_counts_cache"] = None
             return
         self.__dict__[name] = value
-
-    def __del__(self):
-        # hand a RandomState this model created itself back for re-use, unless somebody else still holds it
-        try:
-            rs = self.__dict__.get("_rs_own")
-            if rs is not None and rs is self.__dict__.get("_random_state") and sys.getrefcount(rs) <= 4 and len(_RS_SPARE) < 64:
-                _RS_SPARE.append(rs)
-        except Exception:  # (interpreter shutdown)
-            pass
 
     def __getstate__(self):
         if self._device_newer and self._owner._h is not None:
@@ -327,21 +305,6 @@ class StratifiedClusters:
         if self._remap_dirty:
             h.set_remap([self._remap[b] for b in range(self.bin_mapper.nbins)])
             self._remap_dirty = False
-
-    def _internal_refs(self):
-        """references this object's own parts hold on it (its models' `_owner`, the remap dict's)"""
-        return sum(1 for m in self.cluster_models if m.__dict__.get("_owner") is self) + (
-            1 if getattr(self.__dict__.get("_remap"), "_owner", None) is self else 0)
-
-    def _retire_streams(self):
-        """Called when nothing outside refers to this object any more: the RandomStates its models made from integer seeds
-        are handed back for re-use (see _RS_SPARE), unless somebody else still holds one."""
-        for m in self.cluster_models:
-            d = m.__dict__
-            rs = d.get("_rs_own")
-            if rs is not None and rs is d.get("_random_state") and sys.getrefcount(rs) <= 4 and len(_RS_SPARE) < 64:
-                del d["_rs_own"], d["_random_state"]
-                _RS_SPARE.append(rs)
 
     def _adopt_device_state(self):
         """After a model broadcast the ctx holds the authoritative centroids: become their owner."""

@@ -914,6 +914,8 @@ int hamsm_train_build_rows(hamsm_ctx *c, const int32_t *bin, int64_t n, const in
                            int64_t *counts, int64_t *starts) {
   CTX(c);
   if (!c->st || c->S < 1) return fail(c, HAMSM_EINVAL, "set_geometry first");
+  for (int s = 0; s < c->S; s++) /* the remap row names strata */
+    if (call_remap[s] < 0 || call_remap[s] >= c->S) return fail(c, HAMSM_EINVAL, "call_remap[%d] = %d is not a stratum", s, call_remap[s]);
   memset(counts, 0, sizeof(int64_t) * (size_t)c->S);
   for (int64_t i = 0; i < n; i++)
     if (bin[i] >= 0) counts[call_remap[bin[i]]]++;

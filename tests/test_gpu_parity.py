@@ -1029,3 +1029,46 @@ def test_bf16_mfma_accumulation_error_is_within_the_certificates_premise(hip_h):
         worst = max(worst, float((err / np.maximum(budget, 1e-300)).max()))
     print(f"bf16 MFMA: worst error / assumed per-instruction budget = {worst:.4f}")
     assert worst <= 1.0
+
+
+@pytest.mark.parametrize("S", [9, 700, 2500, 4096])
+def test_row_lists_with_many_strata_match_oracle(hip_h, oracle_h, S):
+    """the wave form of the row-list kernel keeps 32 B of LDS per stratum -- beyond the default 64 KB from 2049
+    strata on (a 50 x 50 bin mapper).  Row lists of batched training calls for 9 .. 4096 strata (`HAMSM_MAX_STRATA`), with a remap
+    row per call, against the oracle; and a remap entry that names no stratum is an error in both libraries, not an access."""
+    from msm_we_amd._abi import HamsmError
+
+    rng = np.random.default_rng(S)
+    n, G = 30000, 5
+    bins = rng.integers(-1, S, n).astype(np.int32)                      # -1: basis / target rows (not listed)
+    bounds = np.sort(rng.choice(np.arange(1, n), G - 1, replace=False))
+    gb, ge = np.concatenate([[0], bounds]), np.concatenate([bounds, [n]])
+    cr = np.tile(np.arange(S, dtype=np.int32), (G, 1))
+    for g in range(G):   # a few bins folded into others, per call (the tail remap of _clustering.py:811-821)
+        src = rng.choice(S, min(S, 5), replace=False)
+        cr[g, src] = rng.integers(0, S, len(src))
+    out = []
+    for h in (oracle_h, hip_h):
+        h.set_geometry(4, 1, S)
+        d_bin, d_rows = h.to_device(bins), h.alloc(n, np.int32)
+        h.memset(d_rows, 0xff, 4 * n)
+        cnt, st = h.train_build_rows_batched(d_bin, gb, ge, cr, d_rows)
+        out.append((cnt, st, d_rows.to_host()))
+        bad = cr.copy()
+        bad[G - 1, S // 2] = S
+        with pytest.raises(HamsmError):
+            h.train_build_rows_batched(d_bin, gb, ge, bad, d_rows)
+        bad[G - 1, S // 2] = -1
+        with pytest.raises(HamsmError):
+            h.train_build_rows_batched(d_bin, gb, ge, bad, d_rows)
+    for x, y in zip(out[0], out[1]):
+        assert np.array_equal(x, y)
+    # and against a plain restatement: per call, the ranks of the listed rows grouped by remapped stratum, in row order
+    cnt, st, rows = out[1]
+    for g in range(G):
+        b = bins[gb[g]: ge[g]]
+        listed = np.nonzero(b >= 0)[0]
+        s_of = cr[g][b[listed]]
+        for s in np.unique(s_of):
+            assert np.array_equal(rows[st[g, s]: st[g, s] + cnt[g, s]], np.nonzero(s_of == s)[0])
+        assert cnt[g].sum() == len(listed)

@@ -212,57 +212,18 @@ def test_wide_feature_training_matches_oracle(hip_lib, oracle_h, stage_kb, rt, o
         h.close()
 
 
-def test_recycled_random_state_objects_give_the_same_streams(oracle_h):
-    """a StratumKMeans hands the RandomState it made from an integer seed back when it dies; the next model re-seeds it
-    instead of constructing one: same draws, same model"""
-    import gc
-
-    from msm_we_amd import stratified_clustering as sc
-
-    # the primitive: re-seeding a used object == a new one (Gaussian cache included)
-    used = np.random.RandomState(3)
-    used.normal(size=3), used.permutation(17), used.uniform(size=5)
-    sc._RS_SPARE.clear()
-    sc._RS_SPARE.append(used)
-    got, new = sc._check_random_state(11), np.random.RandomState(11)
-    assert got is used and not sc._RS_SPARE
-    assert np.array_equal(got.randint(0, 1000, 50), new.randint(0, 1000, 50))
-    assert got.normal() == new.normal() and np.array_equal(got.permutation(40), new.permutation(40))
-    assert np.array_equal(got.choice(30, p=np.full(30, 1 / 30)), new.choice(30, p=np.full(30, 1 / 30)))
-    # model level: the first build constructs its streams, the second one (after the first died) recycles them
-    cfg = synthetic.WEConfig("rsreuse", 21, 12, 160, 10, 3, 8)
-    gc.collect()  # (models of earlier tests that are only now collected would hand their streams in below)
-    sc._RS_SPARE.clear()
+def test_a_held_cluster_model_keeps_its_random_stream(oracle_h):
+    """sklearn semantics: a model's RandomState is its own for life.  A caller who keeps a StratumKMeans of a build that the
+    model has since replaced still owns a live stream that CONTINUES (round 3 recycled such objects by reference counts: dropped)."""
+    cfg = synthetic.WEConfig("rskeep", 21, 12, 160, 10, 3, 8)
     a, la, ca, na = _run(oracle_h, cfg, 8, True)
-    n_models = sum(1 for cm in a.clusters.cluster_models if "_rs_own" in cm.__dict__)
-    assert n_models >= 2
-    held = a.clusters.cluster_models[0]._random_state  # somebody else holds this one: it must not be recycled
-    del a
-    gc.collect()
-    assert len(sc._RS_SPARE) == n_models - 1 and all(r is not held for r in sc._RS_SPARE)
-    spare_ids = {id(r) for r in sc._RS_SPARE}
-    b, lb, cb, nb = _run(oracle_h, cfg, 8, True)
-    assert any(id(cm.__dict__.get("_rs_own")) in spare_ids for cm in b.clusters.cluster_models)
-    assert np.array_equal(la, lb)
-    for x, y in zip(ca + na, cb + nb):
-        assert np.array_equal(x, y)
-    for cm in b.clusters.cluster_models:  # and the streams continue identically (what a later partial_fit would draw)
-        if "_rs_own" in cm.__dict__:
-            assert cm._random_state is not held
-    # replacing model.clusters by a new build retires the old object's streams at once -- unless somebody else holds the old object
+    kept = a.clusters.cluster_models[0]
+    rs = kept._random_state
+    twin = np.random.RandomState()
+    twin.set_state(rs.get_state())
     bm = RectilinearBinMapper([synthetic.strata_boundaries(cfg.S)])
-
-    def again(m):
-        m.cluster_coordinates(8, streaming=True, use_ray=True, stratified=True, user_bin_mapper=bm, random_state=7)
-
-    del held
-    gc.collect()
-    sc._RS_SPARE.clear()
-    again(b)                       # the build of `_run` is replaced: nobody else holds it
-    assert len(sc._RS_SPARE) == n_models
-    kept = b.clusters              # a user's reference
-    kept_rs = [cm._random_state for cm in kept.cluster_models if "_rs_own" in cm.__dict__]
-    again(b)                       # (takes the spare ones; `kept` is replaced but still referenced: not retired)
-    assert not sc._RS_SPARE and all(cm.__dict__.get("_random_state") is r
-                                    for cm, r in zip([c for c in kept.cluster_models if "_rs_own" in c.__dict__], kept_rs))
-    assert np.array_equal(np.concatenate(b.dtrajs), la)
+    for _ in range(2):   # the model replaces its clusters object twice
+        a.cluster_coordinates(8, streaming=True, use_ray=True, stratified=True, user_bin_mapper=bm, random_state=7)
+    assert kept._random_state is rs
+    assert np.array_equal(rs.randint(0, 1000, 20), twin.randint(0, 1000, 20))   # untouched by the later builds
+    assert all(cm._random_state is not rs for cm in a.clusters.cluster_models)
