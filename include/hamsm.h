@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define HAMSM_ABI_VERSION 6
+#define HAMSM_ABI_VERSION 7
 
 #define HAMSM_OK 0
 #define HAMSM_EINVAL (-1)   /* bad argument / call order                                         */
@@ -301,6 +301,12 @@ int hamsm_kmeans_seed_multi(hamsm_ctx *ctx, int n_items, const int32_t *h_stratu
                             const int64_t *h_rows_off, const int64_t *h_n_b, const double *d_w,
                             const int64_t *h_sub, const int64_t *h_n_sub, const int32_t *h_K,
                             const int64_t *h_first, const double *h_u, const int32_t *h_L);
+
+/* (ABI 7) The batch indices item `item` of the LAST hamsm_kmeans_seed_multi call chose, in order (h_chosen[K_s]; index into the
+ * subsample when one was given) -- what hamsm_kmeans_seed returns through its own h_chosen.  The parity tests compare them
+ * with the reference's `_kmeans_plusplus` indices (sklearn _kmeans.py:214-276, returned as `indices`); the product never
+ * calls it (it synchronises).                                                                                              */
+int hamsm_kmeans_seed_chosen(hamsm_ctx *ctx, int item, int64_t *h_chosen);
 
 /* One planned minibatch step: batch rows d_rows[rows_off .. rows_off+n_b) (relative to frame x_off)
  * update the centroids of `stratum`.

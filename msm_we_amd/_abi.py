@@ -20,7 +20,7 @@ _vp, _i32, _i64, _f64, _sz = C.c_void_p, C.c_int32, C.c_int64, C.c_double, C.c_s
 _int = C.c_int
 
 # name -> (restype, argtypes); kept in the order of include/hamsm.h
-ABI_VERSION = 6  # HAMSM_ABI_VERSION of include/hamsm.h
+ABI_VERSION = 7  # HAMSM_ABI_VERSION of include/hamsm.h
 
 SYMBOLS = {
     "hamsm_abi_version": (_int, []),
@@ -75,6 +75,7 @@ SYMBOLS = {
     "hamsm_reassign": (_int, [_vp, _int, _vp, _int, _i64, _vp, _vp, _vp, _int, _f64]),
     "hamsm_train_build_rows_batched": (_int, [_vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp]),
     "hamsm_kmeans_seed_multi": (_int, [_vp, _int, _vp, _vp, _int, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "hamsm_kmeans_seed_chosen": (_int, [_vp, _int, _vp]),
     "hamsm_minibatch_run": (_int, [_vp, _vp, _int, _i64, _vp, _vp, _vp, _i64, _f64, _vp, _i64, _vp, _vp, _vp]),
     "hamsm_comm_unique_id": (_int, [_vp]),
     "hamsm_comm_init": (_int, [_vp, _int, _int, _vp]),
@@ -561,6 +562,12 @@ class Hamsm:
         self._ck(self.lib.hamsm_kmeans_seed_multi(self.ctx, n, _hp(st), _dp(d_X), int(x_dtype), int(ldx), _hp(xo), _dp(d_rows),
                                                   _hp(ro), _hp(nb), _dp(d_w), _hp(sub), _hp(n_sub), _hp(Ks), _hp(fs), _hp(u),
                                                   _hp(Ls)))
+
+    def kmeans_seed_chosen(self, item, K):
+        """batch indices item `item` of the last `kmeans_seed_multi` chose (parity tests; synchronises)"""
+        out = np.empty(int(K), dtype=np.int64)
+        self._ck(self.lib.hamsm_kmeans_seed_chosen(self.ctx, int(item), _hp(out)))
+        return out
 
     def minibatch_run(self, d_X, x_dtype, ldx, d_rows, d_w, steps, ratio, perm=None):
         """-> (report[n_steps, 2], resume[S], reason[S]); steps without a permutation carry perm_off = -1"""

@@ -12,6 +12,7 @@
 
 #include <map>
 #include <unordered_map>
+#include <utility>
 #include <vector>
 
 #include "../../include/hamsm.h"
@@ -179,6 +180,7 @@ struct hamsm_ctx {
   unsigned long long *filter_cnt2 = nullptr;  // (debug) uncertain-row counters of the last filtered assign, [S] in scratch2
   int assign_waves = 4;    // waves per workgroup of the sorted assign kernel (HAMSM_ASSIGN_W=8: 8 waves x 2 centroid tiles)
   void *seed_chosen_dev = nullptr;  // chosen indices of the last seeding's first item (device)
+  std::vector<std::pair<void *, int>> seed_chosen_items;  // ... of every item of the last seeding call (device pointer, K)
   void *comm = nullptr;  // ncclComm_t
   void *comm_buf = nullptr;  // device words of the collectives' argument / readiness exchanges (allocated with the communicator)
   size_t comm_buf_bytes = 0;

@@ -1001,6 +1001,16 @@ extern "C" int hamsm_kmeans_seed_multi(hamsm_ctx *c, int n_items, const int32_t 
   hamsm_timer_end(c, ST_SEED);
   // h_u / h_sub were pageable host memory: hipMemcpyAsync staged them before returning, no sync needed.
   c->seed_chosen_dev = b + lay[0].ch;  // hamsm_kmeans_seed reads item 0's choices
+  c->seed_chosen_items.resize(n_items);
+  for (int i = 0; i < n_items; i++) c->seed_chosen_items[i] = {b + lay[i].ch, h_K[i]};  // (hamsm_kmeans_seed_chosen; valid until the scratch arena is reused)
+  return HAMSM_OK;
+}
+
+extern "C" int hamsm_kmeans_seed_chosen(hamsm_ctx *c, int item, int64_t *h_chosen) {
+  CTX(c);
+  if (item < 0 || (size_t)item >= c->seed_chosen_items.size() || !h_chosen) return hamsm_fail(c, HAMSM_EINVAL, "seed_chosen: no such item of the last seeding call");
+  HIPCHK(c, hipMemcpyAsync(h_chosen, c->seed_chosen_items[item].first, sizeof(long long) * c->seed_chosen_items[item].second, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
   return HAMSM_OK;
 }
 

@@ -59,6 +59,9 @@ struct hamsm_ctx {
   int32_t *ext_own;         /* copy of host-supplied bins */
   int ext_set;
   stratum_t *st;
+  int64_t *seed_chosen;     /* chosen batch indices of the last hamsm_kmeans_seed_multi call, items back to back */
+  int64_t *seed_chosen_off; /* [n_items + 1] */
+  int seed_chosen_n;
   double *pca_S2, *pca_mu0; /* streaming PCA fit: running sums [Dp][Dp] (a <= b), shift [Dp] */
   int pca_D;
   int64_t pca_n;
@@ -162,6 +165,10 @@ void hamsm_destroy(hamsm_ctx *c) {
   free(c->ext_own);
   free(c->pca_S2);
   free(c->pca_mu0);
+  free(c->seed_chosen);
+  free(c->seed_chosen_off);
+  c->seed_chosen = c->seed_chosen_off = NULL;
+  c->seed_chosen_n = 0;
   c->centers = NULL;
   c->ext_own = NULL;
   c->pca_S2 = c->pca_mu0 = NULL;
@@ -1142,15 +1149,29 @@ int hamsm_kmeans_seed_multi(hamsm_ctx *c, int n_items, const int32_t *stratum, c
                             const int64_t *first, const double *u, const int32_t *L) {
   CTX(c);
   size_t esz = dt == HAMSM_F32 ? 4 : 8;
+  free(c->seed_chosen);
+  free(c->seed_chosen_off);
+  c->seed_chosen = NULL;
+  c->seed_chosen_off = (int64_t *)calloc((size_t)n_items + 1, sizeof(int64_t));
+  c->seed_chosen_n = n_items > 0 ? n_items : 0;
+  for (int i = 0; i < n_items; i++) c->seed_chosen_off[i + 1] = c->seed_chosen_off[i] + (K[i] > 0 ? K[i] : 0);
+  c->seed_chosen = (int64_t *)calloc((size_t)(n_items > 0 ? c->seed_chosen_off[n_items] : 0) + 1, sizeof(int64_t));
   for (int i = 0; i < n_items; i++) {
     const char *Xi = (const char *)X + (size_t)x_off[i] * ldx * esz;
     const double *wi = wf ? wf + x_off[i] : NULL;
     int rc = hamsm_kmeans_seed(c, stratum[i], Xi, dt, ldx, rows + rows_off[i], n_b[i], wi, n_sub[i] ? sub : NULL, n_sub[i],
-                               K[i], first[i], u, L[i], NULL);
+                               K[i], first[i], u, L[i], c->seed_chosen + c->seed_chosen_off[i]);
     if (rc) return rc;
     u += (size_t)(K[i] - 1) * L[i];
     sub += n_sub[i];
   }
+  return HAMSM_OK;
+}
+
+int hamsm_kmeans_seed_chosen(hamsm_ctx *c, int item, int64_t *chosen) {
+  CTX(c);
+  if (item < 0 || item >= c->seed_chosen_n || !chosen || !c->seed_chosen) return fail(c, HAMSM_EINVAL, "seed_chosen: no such item of the last seeding call");
+  memcpy(chosen, c->seed_chosen + c->seed_chosen_off[item], sizeof(int64_t) * (size_t)(c->seed_chosen_off[item + 1] - c->seed_chosen_off[item]));
   return HAMSM_OK;
 }
 

@@ -40,6 +40,10 @@ def pytest_terminal_summary(terminalreporter):
     if FORCED_SEEDINGS:
         terminalreporter.write_line("k-means++ seedings teacher-forced (exact ties) / compared, per golden case: " +
                                     ", ".join(f"{k}: {a}/{b}" for k, (a, b) in sorted(FORCED_SEEDINGS.items())))
+    if TIE_WITNESSES:
+        terminalreporter.write_line("tie witnesses (seeding, greedy step, exact relative difference of the two potentials): " +
+                                    ", ".join(f"{k}: " + " ".join(f"({i}, {s}, {r:.1e})" for i, s, r in v)
+                                              for k, v in sorted(TIE_WITNESSES.items())))
 
 
 def _build_oracle():
@@ -212,9 +216,67 @@ def golden_iterations(g):
             for i in range(len(offs) - 1)}
 
 
+def _exact_ints(A):
+    """a float64 array as exact Python integers times 2**emin (object array, emin): every float64 is m * 2**e"""
+    A = np.asarray(A, dtype=np.float64)
+    if not np.all(np.isfinite(A)):
+        raise ValueError("tie witness: non-finite data")
+    m, e = np.frexp(A)
+    mi = (m * 2.0 ** 53).astype(np.int64)          # exact: 53-bit significands
+    ee = e.astype(np.int64) - 53
+    nz = A != 0
+    emin = int(ee[nz].min()) if nz.any() else 0
+    out = np.zeros(A.shape, dtype=object)
+    flat_o, flat_m, flat_e, flat_nz = out.reshape(-1), mi.reshape(-1), ee.reshape(-1), nz.reshape(-1)
+    for i in range(flat_o.size):
+        flat_o[i] = (int(flat_m[i]) << int(flat_e[i] - emin)) if flat_nz[i] else 0
+    return out, emin
+
+
+def tie_witness(Xb, wb, mine, ref):
+    """a k-means++ seeding that differs from the reference's may only be teacher-forced if it is a TIE.
+    At the first greedy step where the two index lists diverge both runs hold the same centres and the same candidates
+    (sklearn `_kmeans.py:214-276`) and picked different ones; the step minimises pot(c) = sum_i w_i min(closest_i, |x_i - x_c|^2).
+    Both potentials are evaluated here in EXACT integer arithmetic on the float64 data; they must agree to 4 ulp (2^-50
+    relative) -- i.e. no float64 summation order can be said to be the right one -- or the test fails: the difference would
+    then be this build's own arithmetic, not a tie.  Returns (step, relative difference as a float)."""
+    mine, ref = np.asarray(mine), np.asarray(ref)
+    c = int(np.nonzero(mine != ref)[0][0])
+    assert c >= 1, "the first centre is drawn by the host (random_state.choice): it cannot differ"
+    Xo, _ = _exact_ints(Xb)
+    wo = np.ones(len(Xb), dtype=object) if wb is None else _exact_ints(wb)[0]
+    closest = None
+    for j in ref[:c]:
+        d = ((Xo - Xo[int(j)]) ** 2).sum(axis=1)
+        closest = d if closest is None else np.minimum(closest, d)
+    pots = []
+    for cand in (int(mine[c]), int(ref[c])):
+        d = ((Xo - Xo[cand]) ** 2).sum(axis=1)
+        pots.append(int((wo * np.minimum(closest, d)).sum()))
+    pa, pb = pots
+    big = max(abs(pa), abs(pb), 1)
+    assert abs(pa - pb) << 50 <= big, (f"seeding differs from the reference's at greedy step {c} and it is NOT a tie: exact potentials "
+                                       f"differ by {abs(pa - pb) / big:.3e} relative (candidates {int(mine[c])} / {int(ref[c])})")
+    return c, abs(pa - pb) / big
+
+
+TIE_WITNESSES = {}   # golden case -> [(stratum seeding number, greedy step, exact relative difference of the two potentials)]
+# The seedings that ARE teacher-forced, per case: pinned.  Each is a witnessed exact tie (`tie_witness`: the two candidates'
+# potentials are equal in exact arithmetic -- two mutually nearest isolated rows -- and the reference breaks it by BLAS rounding,
+# the oracle by its own summation order); every other seeding of every case must equal the reference's index for index.
+EXPECTED_FORCED = {"c1p_d30": 1, "grid2d_d10": 1, "late_start_d10": 1, "fuzz_03": 2, "fuzz_53": 1}
+
+
+def expected_forced(case):
+    return EXPECTED_FORCED.get(case, 0)
+
+
+
 def build_model(h, g, meta, seed_forcing=True, planned=True, source=None, mapper_dfunc=None):
-    """modelWE on golden inputs, up to (and including) cluster_coordinates.  Returns (model, forced)
-    where forced counts k-means++ seedings replaced by the reference's (exact-tie flips)."""
+    """modelWE on golden inputs, up to (and including) cluster_coordinates.  Returns (model, state); state["forced"] counts
+    k-means++ seedings replaced by the reference's -- only ever after `tie_witness` has shown, in exact arithmetic, that the
+    reference's choice and this build's are a tie at the step where they diverge."""
+    from msm_we_amd import _abi
     from msm_we_amd.data import InMemorySource
     from msm_we_amd.model import modelWE
 
@@ -227,34 +289,53 @@ def build_model(h, g, meta, seed_forcing=True, planned=True, source=None, mapper
     m.get_iterations()
     m.get_coordSet(m.maxIter)
     m.dimReduce()
-    state = {"i": 0, "forced": 0, "chosen": []}
+    state = {"i": 0, "forced": 0, "chosen": [], "witness": []}
     orig = h.kmeans_seed
 
-    def seed(stratum, d_X, x_dtype, ldx, d_rows, n_b, d_w, sub, K_s, first, u, L, want_chosen=False):
-        ch = orig(stratum, d_X, x_dtype, ldx, d_rows, n_b, d_w, sub, K_s, first, u, L, want_chosen=True)
+    def batch_on_host(d_X, x_dtype, ldx, x_off, d_rows, rows_off, n_b, d_w, sub):
+        """the seeding's batch as k-means++ sees it: float64 rows (and weights) in batch / subsample order"""
+        dt = np.float32 if int(x_dtype) == _abi.F32 else np.float64
+        rows = np.empty(int(n_b), dtype=np.int32)
+        h.d2h(rows, _abi._dp(d_rows) + 4 * int(rows_off))
+        span = int(rows.max()) + 1
+        X = np.empty((span, int(ldx)), dtype=dt)
+        h.d2h(X, _abi._dp(d_X) + int(x_off) * int(ldx) * dt().itemsize)
+        Xb = X[rows][:, : h.D].astype(np.float64)
+        wb = None
+        if d_w is not None:
+            w = np.empty(span, dtype=np.float64)
+            h.d2h(w, _abi._dp(d_w) + 8 * int(x_off))
+            wb = w[rows]
+        if sub is not None:
+            Xb, wb = Xb[np.asarray(sub)], (None if wb is None else wb[np.asarray(sub)])
+        return Xb, wb
+
+    def settle(stratum, ch, batch):
+        """compare one seeding with the reference's indices; a difference must be a witnessed tie, and is then teacher-forced"""
         ref = g["pp_indices"][state["i"]]
-        state["chosen"].append((ch.copy(), ref.copy()))
+        state["chosen"].append((np.asarray(ch).copy(), ref.copy()))
         if seed_forcing and not np.array_equal(ch, ref):
+            step, rel = tie_witness(*batch(), ch, ref)
+            state["witness"].append((state["i"], step, rel))
             state["forced"] += 1
             h.set_centroids(stratum, g["pp_centers"][state["i"]])
         state["i"] += 1
+
+    def seed(stratum, d_X, x_dtype, ldx, d_rows, n_b, d_w, sub, K_s, first, u, L, want_chosen=False):
+        ch = orig(stratum, d_X, x_dtype, ldx, d_rows, n_b, d_w, sub, K_s, first, u, L, want_chosen=True)
+        settle(stratum, ch, lambda: batch_on_host(d_X, x_dtype, ldx, 0, d_rows, 0, n_b, d_w, sub))
         return ch
 
     orig_multi = h.kmeans_seed_multi
 
-    def seed_multi(strata, *a, **k):
-        # the planned training path seeds several strata in one call (same order as the reference's
-        # k-means++ calls); compare / teacher-force on the resulting centroids
-        orig_multi(strata, *a, **k)
-        for s in strata:
-            ref_c = g["pp_centers"][state["i"]]
-            mine = h.get_centroids(s)[0]
-            same = np.array_equal(mine, ref_c)
-            state["chosen"].append((np.zeros(1, int), np.zeros(1, int)) if same else (np.zeros(1, int), np.ones(1, int)))
-            if seed_forcing and not same:
-                state["forced"] += 1
-                h.set_centroids(s, ref_c)
-            state["i"] += 1
+    def seed_multi(strata, d_X, x_dtype, ldx, x_off, d_rows, rows_off, n_b, d_w, subs, K, first, us, L):
+        # the planned training path seeds several strata in one call (same order as the reference's k-means++ calls): the
+        # CHOSEN INDICES of every item are compared (hamsm_kmeans_seed_chosen, ABI 7) -- not the centroids' bits, which differ
+        # by an ulp wherever the features do (PCA golden) although the seeding is the same
+        orig_multi(strata, d_X, x_dtype, ldx, x_off, d_rows, rows_off, n_b, d_w, subs, K, first, us, L)
+        chosen = [h.kmeans_seed_chosen(i, K[i]) for i in range(len(strata))]   # (all read before a forced set_centroids)
+        for i, s in enumerate(strata):
+            settle(s, chosen[i], lambda i=i: batch_on_host(d_X, x_dtype, ldx, x_off[i], d_rows, rows_off[i], n_b[i], d_w, subs[i]))
 
     h.kmeans_seed = seed
     h.kmeans_seed_multi = seed_multi
@@ -278,6 +359,8 @@ def build_model(h, g, meta, seed_forcing=True, planned=True, source=None, mapper
     if seed_forcing:
         prev = FORCED_SEEDINGS.get(meta["case"], (0, 0))
         FORCED_SEEDINGS[meta["case"]] = (max(prev[0], state["forced"]), max(prev[1], state["i"]))
+        if state["witness"]:
+            TIE_WITNESSES[meta["case"]] = state["witness"]
     return m, state
 
 

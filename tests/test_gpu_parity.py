@@ -6,7 +6,8 @@ import ctypes
 import numpy as np
 import pytest
 
-from conftest import GOLDEN_CASES, build_model, check_block_validation, check_cluster_structures, check_committor, load_golden
+from conftest import (GOLDEN_CASES, build_model, check_block_validation, check_cluster_structures, check_committor, expected_forced,
+                      load_golden)
 
 pytestmark = pytest.mark.gpu
 
@@ -736,7 +737,7 @@ def test_pipeline_on_reference_goldens(hip_h, case):
     (tests/golden/*.npz): same assertions as tests/test_oracle_golden.py."""
     g, meta = load_golden(case)
     m, st = build_model(hip_h, g, meta)
-    assert st["forced"] <= 1
+    assert st["forced"] == expected_forced(case) and all(rel == 0.0 for _, _, rel in st["witness"])   # (witnessed exact ties only)
     assert [m.clusters.we_remap[b] for b in range(meta["S"])] == list(g["remap_post_cluster"])
     for b, cm in enumerate(m.clusters.cluster_models):
         assert cm.fitted == bool(g["fitted_post_cluster"][b])

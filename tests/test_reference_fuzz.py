@@ -10,7 +10,7 @@ import os
 import numpy as np
 import pytest
 
-from conftest import GOLDEN, _Golden, build_model
+from conftest import GOLDEN, _Golden, build_model, expected_forced
 from msm_we_amd import synthetic
 
 PACK = np.load(os.path.join(GOLDEN, "fuzz_pack.npz"))
@@ -64,7 +64,8 @@ def check_fuzz_case(h, i):
         expect_failure(lambda: build_model(h, g, meta))
         return
     m, st = build_model(h, g, meta)
-    assert st["forced"] <= meta["S"]
+    # seedings teacher-forced: the pinned, witnessed exact ties only (conftest.EXPECTED_FORCED / tie_witness)
+    assert st["forced"] == expected_forced(meta["case"]) and all(rel == 0.0 for _, _, rel in st["witness"])
     assert m.maxIter == meta["maxIter"]
     assert [m.clusters.we_remap[b] for b in range(meta["S"])] == list(g["remap_post"])
     assert m.n_clusters == int(g["n_clusters_post"])
