@@ -92,34 +92,56 @@ def is_connected(matrix, source_states, target_states, directed=True):
     return True
 
 
-def inverse_iteration(guess, matrix, mu=1):
+class _ShiftedSolver:
+    """(T^T - mu I) factorised ONCE: the reference's `inverse_iteration` forms the inverse anew at every step of
+    `get_steady_state`'s loop (`utils.py:138`, `_analysis.py:144-146`) although the matrix does not change -- at 2600 states
+    the factorisation is 95 % of a step.  LAPACK getrf or SuperLU by `_prefer_dense_lu`; `solve` returns None when the shifted
+    matrix is exactly singular (the caller then retries with mu = 0.999, as the reference does)."""
+
+    def __init__(self, matrix, mu=1):
+        self.n = n = matrix.shape[0]
+        self.mu = mu
+        self.lu = self.splu = None
+        matrix = sp.csr_matrix(matrix)
+        if _prefer_dense_lu(matrix, n):
+            # cleaned haMSM matrices are often 30-50 % dense: LAPACK getrf beats SuperLU there by 2-4x
+            with warnings.catch_warnings(), _bounded_blas(n):
+                warnings.simplefilter("ignore", sla.LinAlgWarning)
+                A = matrix.toarray().T
+                A[np.diag_indices(n)] -= mu
+                lu = sla.lu_factor(A, overwrite_a=True, check_finite=False)
+                if np.all(np.diagonal(lu[0]) != 0):
+                    self.lu = lu
+        else:
+            try:
+                self.splu = spla.splu((matrix.T - mu * sp.eye(n)).tocsc())
+            except RuntimeError:
+                self.splu = None
+
+    def solve(self, guess):
+        guess = np.asarray(guess, dtype=np.float64)
+        x = None
+        if self.lu is not None:
+            with _bounded_blas(self.n):
+                x = sla.lu_solve(self.lu, guess, check_finite=False)
+        elif self.splu is not None:
+            x = self.splu.solve(guess)
+        if x is None or not np.all(np.isfinite(x)):
+            return None
+        return x / sum(x)
+
+
+def inverse_iteration(guess, matrix, mu=1, _solver=None):
     """One step of inverse iteration towards the eigenvalue-1 left eigenvector (reference
     `utils.py:116-161`): solve (T^T - mu I) x = guess, normalise; fall back to mu=0.999 when the
-    shifted matrix is exactly singular."""
-    n = guess.shape[0]
-    guess = np.asarray(guess, dtype=np.float64)
-    matrix = sp.csr_matrix(matrix)
-    x = None
-    if _prefer_dense_lu(matrix, n):
-        # cleaned haMSM matrices are often 30-50 % dense: LAPACK getrf beats SuperLU there by 2-4x
-        with warnings.catch_warnings(), _bounded_blas(n):
-            warnings.simplefilter("ignore", sla.LinAlgWarning)
-            A = matrix.toarray().T
-            A[np.diag_indices(n)] -= mu
-            lu = sla.lu_factor(A, overwrite_a=True, check_finite=False)
-            if np.all(np.diagonal(lu[0]) != 0):
-                x = sla.lu_solve(lu, guess, check_finite=False)
-    else:
-        try:
-            x = spla.splu((matrix.T - mu * sp.eye(n)).tocsc()).solve(guess)
-        except RuntimeError:
-            x = None
-    if x is None or not np.all(np.isfinite(x)):
+    shifted matrix is exactly singular.  `_solver`: a factorisation of the same shifted matrix to re-use."""
+    solver = _solver if (_solver is not None and _solver.mu == mu) else _ShiftedSolver(matrix, mu)
+    x = solver.solve(guess)
+    if x is None:
         if mu != 1:
             raise RuntimeError("inverse iteration failed: shifted matrix is singular")
         log.error("When solving steady-state, failed to perform inverse iteration! Trying again with mu=0.999.")
         return inverse_iteration(guess, matrix, mu=0.999)
-    x = x / sum(x)
     return x
 
 
@@ -210,8 +232,9 @@ class AnalysisMixin:
         T = self._T_csr()
         last_pSS = self.get_steady_state_algebraic(max_iters=10, check_negative=False, set=False)
         last_flux = self.get_steady_state_target_flux(pSS=last_pSS, _set=False)
+        solver = _ShiftedSolver(T, 1)   # the loop's matrix never changes: factorised once, not once per step
         for N in range(max_iters):
-            iterated = inverse_iteration(matrix=T, guess=last_pSS)
+            iterated = inverse_iteration(matrix=T, guess=last_pSS, _solver=solver)
             last_pSS = iterated
             new_flux = self.get_steady_state_target_flux(pSS=last_pSS, _set=False)
             flux_change = new_flux - last_flux
