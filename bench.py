@@ -12,12 +12,17 @@ clusters (K = 1000).  One *step* = one pass of the hot path over the resident sh
     -> flux-matrix accumulation over the segments (+ D2H of the (K+2)^2 matrix)
 
 Inputs are generated on the host, uploaded once, and are resident in HBM when the timed region
-starts.  N > 1 (weak scaling): every rank holds its own 10 M-segment shard of an N x 10 M-segment
-run; rank 0 trains on its iterations (the reference's ``iters_to_use``), the model is broadcast with
-RCCL, every rank discretizes its shard and the partial flux matrices are all-reduced over xGMI.
+starts.  N > 1, default = BASELINE config 4 (strong scaling): the workload's 10 M frames are split over
+the ranks by WE iteration; every rank's training frames reach every rank once at staging and stratum s
+trains on rank s % N (the strata's chains of partial_fits are independent), its model travels from
+there with RCCL; every rank discretizes its shard and the partial flux matrices are all-reduced over
+xGMI -- N ranks produce the model of one process on the same data.  ``--scaling weak``: every rank its
+own full shard, rank 0 trains on its block (the reference's ``iters_to_use``).
 
-Rank 0 prints ONE JSON line (contract in the task statement) with ``roofline`` for the dominant
-kernel (k_assign: f64 MFMA) and ``cpu_baseline`` (the oracle = scalar C port, 1 core, bounded sample).
+Rank 0 prints ONE JSON line (contract in the task statement) with ``roofline`` for the dominant kernel
+of the step -- the E-step of the training pass: ``k_step_assign`` (f64 matrix unit) at C3,
+``k_step_assign_ranked`` (bf16 matrix unit) at C5's shape -- and ``cpu_baseline`` (the oracle = scalar C
+port, bounded sample).
 """
 from __future__ import annotations
 
@@ -307,7 +312,16 @@ def torch_exchange(h, dist, torch, rank, world, dev="cuda"):
         if rank == root:
             h.h2d(d_recv, np.concatenate(parts))
 
-    h.bcast, h.bcast_model, h.gather_to_root = bcast, bcast_model, gather_to_root
+    def bcast_strata(roots):
+        for s in range(h.S):
+            root = int(roots[s])
+            state = [h.get_centroids(s) if rank == root else None]
+            dist.broadcast_object_list(state, src=root)
+            if rank != root:
+                Cm, counts, csq = state[0]
+                h.set_centroids(s, Cm if len(Cm) else None, csq=csq if len(Cm) else None, counts=counts if len(Cm) else None)
+
+    h.bcast, h.bcast_model, h.gather_to_root, h.bcast_strata = bcast, bcast_model, gather_to_root, bcast_strata
     h.comm_destroy = lambda: None
 
 
@@ -500,13 +514,14 @@ def main():
     ap.add_argument("--cpu-iters", type=int, default=0, help="iterations of the CPU baseline's sample (0: about the work of 32 C3 iterations)")
     ap.add_argument("--cpu-cores", type=int, default=min(16, os.cpu_count() or 1), help="processes of the all-cores CPU leg")
     ap.add_argument("--no-full-pipeline", action="store_true")
-    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
-                    help="weak: every rank its own full shard (N x the frames); strong: the workload's frames split over the ranks "
-                         "(BASELINE config 4: 10 M frames in all)")
-    ap.add_argument("--train-on", default=None, choices=["rank0", "all"],
-                    help="sharded runs: rank 0 trains on its own block of iterations (default for weak scaling: training time does "
-                         "not grow with N) or on every rank's iterations, gathered to it once at staging (default for strong "
-                         "scaling: N ranks == one process on the same data)")
+    ap.add_argument("--scaling", default=None, choices=["weak", "strong"],
+                    help="N > 1.  strong (default; BASELINE config 4: the workload's 10 M frames in all, split over the ranks) or "
+                         "weak (every rank its own full shard: N x the frames)")
+    ap.add_argument("--train-on", default=None, choices=["rank0", "all", "strata"],
+                    help="sharded runs.  strata (default for strong scaling): every rank receives every shard's training frames once "
+                         "at staging and trains the strata s %% N == rank, stratum s's model travels from its rank: N ranks == one "
+                         "process on the same data, training spread over min(N, S) GPUs; all: the same model trained by rank 0 "
+                         "alone; rank0 (default for weak scaling): rank 0 trains on its own block of iterations only")
     ap.add_argument("--no-ingest", action="store_true")
     ap.add_argument("--lib", default=None, help="(kernel A/B experiments) path of an alternative build of the HIP library")
     args = ap.parse_args()
@@ -526,12 +541,12 @@ def main():
         import torch
         import torch.distributed as dist
 
-        # (HAMSM_BENCH_BACKEND=gloo: CPU rehearsal of the N > 1 flow, tests/test_distributed_gloo.py)
-        backend = os.environ.get("HAMSM_BENCH_BACKEND", "nccl")
-        dev = "cuda" if backend == "nccl" else "cpu"
-        if dev == "cuda":
-            torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend, rank=rank, world_size=world)
+        # torch only BOOTSTRAPS the run -- the 128-byte RCCL id of the library's own communicator, two scalars, the barriers --
+        # over gloo on CPU tensors: it never initialises a GPU (the collectives of the product are the library's, csrc/comm.hip)
+        dev = "cpu"
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    if args.scaling is None:
+        args.scaling = "strong" if world > 1 else "weak"
 
     cfg = bench_configs()[args.workload]
     n_total = args.iters or cfg.n_iters
@@ -541,7 +556,7 @@ def main():
         n_iters = per if rank < world - 1 else n_total - per * (world - 1)
     else:
         n_iters, first_iter = n_total, 1 + rank * n_total
-    train_on = args.train_on or ("all" if args.scaling == "strong" else "rank0")
+    train_on = args.train_on or ("strata" if args.scaling == "strong" else "rank0")
     seed = 1337
     exchange = "none (one rank)"
 
@@ -595,11 +610,7 @@ def main():
     def barrier():
         h.sync()
         if dist is not None:
-            import torch
-
-            if dev == "cuda":
-                torch.cuda.synchronize()
-            dist.barrier()
+            dist.barrier()   # (h.sync() above drained this rank's GPU queue: the library's stream is the only one in use)
 
     for _ in range(args.warmup):
         one_step(m, cfg, seed, args.flux_mode)
@@ -721,9 +732,13 @@ def main():
                                f"train + assign(2N) + flux per step", "frames_per_gpu": n_seg,
                    "flux_mode": "atomic" if args.flux_mode == 0 else "deterministic",
                    "frames_total": n_seg_all, "parallelism": f"iteration-sharded x{world}",
-                   "training": ("rank 0 trains on every rank's iterations (gathered to it at staging): same model as one process on "
-                                "all the data" if train_on == "all" else
-                                "rank 0 trains on its own block of iterations only (iters_to_use); --train-on all gathers every shard")
+                   "training": ({"all": "rank 0 trains on every rank's iterations (gathered to it at staging): same model as one process "
+                                        "on all the data",
+                                 "strata": "every rank's iterations reach every rank at staging; stratum s trains on rank s % N and its "
+                                           "model travels from there: same model as one process on all the data, training spread over "
+                                           "min(N, S) GPUs",
+                                 "rank0": "rank 0 trains on its own block of iterations only (iters_to_use); --train-on all / strata "
+                                          "use every shard"}[train_on])
                    if world > 1 else "all resident iterations", "exchange": exchange},
         "roofline": step_roofline(cfg, n_iters, n_seg, e_dev_ms or e_ms, e_n, m_ms, e_ms, ranked=rank_stats is not None),
         "roofline_assign": {"bound": "mfma", "achieved": tflops, "peak": peak, "unit": "TFLOP/s",

@@ -373,6 +373,11 @@ int hamsm_gather_to_root(hamsm_ctx *ctx, const void *d_send, size_t send_bytes, 
                          int root);
 /* broadcast the whole model state (centroids, counts, csq, remap) from root to every rank.       */
 int hamsm_bcast_model(hamsm_ctx *ctx, int root);
+/* (ABI 7) the same with a root PER STRATUM: stratum s's centroids, counts and csq travel from rank h_root[s] (h_root[S], the same
+ * on every rank), the remap table from rank 0.  The reference fits one MiniBatchKMeans per WE bin (`_clustering.py:890-911`,
+ * `stratified_clustering.py:55-99`): the strata's chains of partial_fits are independent, so different ranks can train
+ * different strata and the model is the single-process one bit for bit (`train_shards = "strata"`).                    */
+int hamsm_bcast_strata(hamsm_ctx *ctx, const int32_t *h_root);
 
 /* ---- timers: seconds of device time per stage since the last reset, measured with HIP events on
  *      the library's stream.  h_out[8]: assign, flux, stats, seed, step, reassign, prepass, other */

@@ -87,6 +87,7 @@ SYMBOLS = {
     "hamsm_bcast": (_int, [_vp, _vp, _sz, _int]),
     "hamsm_gather_to_root": (_int, [_vp, _vp, _sz, _vp, _vp, _int]),
     "hamsm_bcast_model": (_int, [_vp, _int]),
+    "hamsm_bcast_strata": (_int, [_vp, _vp]),
     "hamsm_timers": (_int, [_vp, _vp, _int]),
     "hamsm_step_kernel_ms": (_int, [_vp, _int, _vp, _vp, _int]),
     "hamsm_last_kernel_ms": (_int, [_vp, _int, _vp]),
@@ -614,6 +615,12 @@ class Hamsm:
     def gather_to_root(self, d_send, send_bytes, d_recv, recv_bytes, root=0):
         rb = np.ascontiguousarray(recv_bytes, dtype=np.int64)
         self._ck(self.lib.hamsm_gather_to_root(self.ctx, _dp(d_send), int(send_bytes), _dp(d_recv), _hp(rb), int(root)))
+
+    def bcast_strata(self, roots):
+        """stratum s's model from rank roots[s] to every rank (remap table from rank 0)"""
+        r = np.ascontiguousarray(roots, dtype=np.int32)
+        assert r.size == self.S
+        self._ck(self.lib.hamsm_bcast_strata(self.ctx, _hp(r)))
 
     def bcast_model(self, root=0):
         self._ck(self.lib.hamsm_bcast_model(self.ctx, int(root)))

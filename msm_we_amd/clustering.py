@@ -138,8 +138,18 @@ class ClusteringMixin:
         S = bin_mapper.nbins
         self.dtrajs = []
         # sharded runs (SURVEY §8e "exact" mode): rank 0 trains -- on every rank's iterations (`train_shards == "all"`: the
-        # frames were gathered to it once, DataMixin.training_store) or on its own block -- and the model is broadcast
-        trains_here = getattr(h, "rank", 0) == 0
+        # frames were gathered to it once, DataMixin.training_store) or on its own block -- and the model is broadcast.
+        # `train_shards == "strata"`: EVERY rank holds every iteration's training frames and trains the strata s with
+        # s % nranks == rank -- the strata's chains of partial_fits are independent (one MiniBatchKMeans per bin,
+        # `_clustering.py:890-911`), so the model is the single-process one bit for bit; then stratum s travels from its rank.
+        R, rank = getattr(h, "nranks", 1), getattr(h, "rank", 0)
+        by_strata = R > 1 and self.train_shards == "strata"
+        if by_strata and not all(isinstance(m.random_state, numbers.Integral) for m in clusters.cluster_models):
+            # models that share one RandomState object (random_state=None or an instance, sklearn semantics) draw from it in call
+            # order across strata: their chains are not independent
+            raise ValueError('train_shards = "strata" needs an integer random_state (independent streams per stratum); '
+                             'use train_shards = "all"')
+        trains_here = by_strata or rank == 0
         tstore, t_maxIter = self.training_store()
         all_filled = set()
         if trains_here:
@@ -155,6 +165,9 @@ class ClusteringMixin:
             hist = h.train_prepass(tstore.p0, tstore.N, tstore.offsets, d_bin)
             d_rows = h.alloc(max(tstore.N, 1), np.int32)
             plan, all_filled = self._plan_training_calls(hist, iters_to_use, n_clusters, bin_mapper, store=tstore, maxIter=t_maxIter)
+            if by_strata:   # the plan is a function of the histogram only: the same on every rank; each fits its own strata
+                mine = (np.arange(S) % R) == rank
+                plan["fit"] = plan["fit"] & mine[None, :]
             done = False
             if getattr(self, "speculative_training", True):
                 done = self._train_planned(plan, clusters, tstore, d_bin, d_rows)
@@ -176,14 +189,31 @@ class ClusteringMixin:
                 clusters._activate()
             remap = np.array([clusters.we_remap[b] for b in range(S)], dtype=np.int32)
             d_remap = h.to_device(remap)
-            h.bcast_model(0)
+            if by_strata:
+                h.bcast_strata(np.arange(S) % R)
+                # what the streaming bookkeeping of a stratum's model holds on its owner, for every rank's copy (the RandomState
+                # streams themselves stay with the owner)
+                book = np.zeros((S, 3), dtype=np.int64)
+                for b, cm in enumerate(clusters.cluster_models):
+                    if b % R == rank and cm.fitted:
+                        book[b] = (1, getattr(cm, "n_steps_", 0), getattr(cm, "_n_since_last_reassign", 0))
+                d_book = h.to_device(book)
+                h.allreduce_sum_i64(d_book, book.size)
+                book = d_book.to_host().reshape(S, 3)
+                d_book.free()
+            else:
+                h.bcast_model(0)
             h.bcast(d_remap, remap.nbytes, 0)
             remap = d_remap.to_host()
             d_remap.free()
-            if not trains_here:
+            if by_strata or not trains_here:
                 clusters._adopt_device_state()
                 for b in range(S):
                     clusters.we_remap[b] = int(remap[b])
+            if by_strata:
+                for b, cm in enumerate(clusters.cluster_models):
+                    if b % R != rank and book[b, 0]:
+                        cm.n_steps_, cm._n_since_last_reassign = int(book[b, 1]), int(book[b, 2])
 
         self.clusters = clusters
         self.clusters.model = self

@@ -178,31 +178,40 @@ extern "C" int hamsm_gather_to_root(hamsm_ctx *c, const void *d_send, size_t sen
   return HAMSM_OK;
 }
 
-// centroids, counts, ||c||^2 and remap of every stratum, root -> all (exact-mode training: SURVEY §7 hard part 3).
+// centroids, counts and ||c||^2 of every stratum, each from the rank that trained it, to all: stratum s from rank h_root[s].
+// (Strata are independent chains of partial_fits -- `_clustering.py:890-911` fits one MiniBatchKMeans per bin -- so they can be
+// trained on different GPUs and the result is the single-process model bit for bit: `train_shards = "strata"`, DESIGN.md 7.  With
+// every root 0 this is the "rank 0 trains" exchange of SURVEY §7 hard part 3.)  The remap table travels from rank 0.
 // Collective discipline: between two collectives a rank never returns on a failure of its own -- it carries the
 // failure into the next collective (a min-all-reduce of "ready" flags), after which EVERY rank returns or EVERY rank goes on;
 // everything that can only fail locally and needs no partner (re-packing the fragments) comes after the last collective.
-extern "C" int hamsm_bcast_model(hamsm_ctx *c, int root) {
+extern "C" int hamsm_bcast_strata(hamsm_ctx *c, const int32_t *h_root) {
   CTX(c);
   if (c->nranks == 1 && !c->comm) return HAMSM_OK;
   if (!c->comm) return hamsm_fail(c, HAMSM_EINVAL, "comm not initialised");
-  const int S = c->S;
+  const int S = c->S, R = c->nranks;
   ncclComm_t cm = (ncclComm_t)c->comm;
-  if (sizeof(int64_t) * 8 + sizeof(int32_t) * (size_t)S > c->comm_buf_bytes) return hamsm_fail(c, HAMSM_EINVAL, "bcast_model: %d strata", S);
+  if (sizeof(int64_t) * 8 + sizeof(int32_t) * (size_t)S > c->comm_buf_bytes) return hamsm_fail(c, HAMSM_EINVAL, "bcast_strata: %d strata", S);
   int64_t *d_flag = (int64_t *)c->comm_buf;               // [1] ready flag
-  int32_t *d_K = (int32_t *)((char *)c->comm_buf + 64);   // [S] fitted centroids per stratum, root's
-  std::vector<int32_t> Ks(S);
-  for (int s = 0; s < S; s++) Ks[s] = c->st[s].K;
-  // (1) the strata's sizes.  A failed upload is carried along: the rank still enters the broadcast.
+  int32_t *d_K = (int32_t *)((char *)c->comm_buf + 64);   // [S] fitted centroids per stratum, as their roots know them
+  // (0) every rank must name the same, valid roots: checked locally, agreed on in (2)
+  int rc_loc = h_root ? HAMSM_OK : HAMSM_EINVAL;
+  for (int s = 0; s < S && !rc_loc; s++)
+    if (h_root[s] < 0 || h_root[s] >= R) rc_loc = HAMSM_EINVAL;
+  // (1) the strata's sizes: each root contributes its own, the others 0; one max-all-reduce.  A failed upload is carried along:
+  // the rank still enters the collective.
+  std::vector<int32_t> Ks(S, 0);
+  for (int s = 0; s < S; s++)
+    if (!rc_loc && h_root[s] == c->rank) Ks[s] = c->st[s].K;
   hipError_t e_loc = hipMemcpyAsync(d_K, Ks.data(), sizeof(int32_t) * S, hipMemcpyHostToDevice, c->stream);
-  ncclResult_t e_n = ncclBroadcast(d_K, d_K, sizeof(int32_t) * (size_t)S, ncclChar, root, cm, c->stream);
+  ncclResult_t e_n = ncclAllReduce(d_K, d_K, (size_t)S, ncclInt32, ncclMax, cm, c->stream);
   if (e_loc == hipSuccess && e_n == ncclSuccess) e_loc = hipMemcpyAsync(Ks.data(), d_K, sizeof(int32_t) * S, hipMemcpyDeviceToHost, c->stream);
   if (e_loc == hipSuccess) e_loc = hipStreamSynchronize(c->stream);
   // (2) room for them -- may fail on this rank alone (memory) -- then everybody learns whether everybody is ready
-  int rc_loc = (e_loc != hipSuccess || e_n != ncclSuccess) ? HAMSM_EDEVICE : HAMSM_OK;
+  if (!rc_loc && (e_loc != hipSuccess || e_n != ncclSuccess)) rc_loc = HAMSM_EDEVICE;
   for (int s = 0; s < S && !rc_loc; s++) {
     if (Ks[s] < 0) rc_loc = HAMSM_EINVAL;
-    else if (Ks[s] > 0) rc_loc = hamsm_stratum_reserve(c, s, Ks[s]);
+    else if (Ks[s] > 0 && h_root[s] != c->rank) rc_loc = hamsm_stratum_reserve(c, s, Ks[s]);
   }
   int64_t ready = rc_loc ? 0 : 1;
   const hipError_t e_up = hipMemcpyAsync(d_flag, &ready, sizeof(ready), hipMemcpyHostToDevice, c->stream);
@@ -210,12 +219,12 @@ extern "C" int hamsm_bcast_model(hamsm_ctx *c, int root) {
   int64_t all_ready = 0;
   hipError_t e_dn = hipMemcpyAsync(&all_ready, d_flag, sizeof(all_ready), hipMemcpyDeviceToHost, c->stream);
   if (e_dn == hipSuccess) e_dn = hipStreamSynchronize(c->stream);  // (also: `ready` is a local the upload reads)
-  if (rc_loc) return hamsm_fail(c, rc_loc, "bcast_model: this rank could not prepare (sizes: %s / %s; or no room for the strata)",
+  if (rc_loc) return hamsm_fail(c, rc_loc, "bcast_strata: this rank could not prepare (roots; sizes: %s / %s; or no room for the strata)",
                                 hipGetErrorString(e_loc), ncclGetErrorString(e_n));
   if (e_up != hipSuccess || e_ar != ncclSuccess || e_dn != hipSuccess)
-    return hamsm_fail(c, HAMSM_EDEVICE, "bcast_model: readiness exchange failed (%s / %s / %s)", hipGetErrorString(e_up), ncclGetErrorString(e_ar),
+    return hamsm_fail(c, HAMSM_EDEVICE, "bcast_strata: readiness exchange failed (%s / %s / %s)", hipGetErrorString(e_up), ncclGetErrorString(e_ar),
                       hipGetErrorString(e_dn));
-  if (!all_ready) return hamsm_fail(c, HAMSM_EDEVICE, "bcast_model: another rank could not prepare to receive the model; nothing was sent");
+  if (!all_ready) return hamsm_fail(c, HAMSM_EDEVICE, "bcast_strata: another rank could not prepare to receive the model; nothing was sent");
   for (int s = 0; s < S; s++) c->st[s].K = Ks[s];
   // (3) the tables and the remap, one group: the last collective of this call
   ncclResult_t first = ncclSuccess;
@@ -223,6 +232,7 @@ extern "C" int hamsm_bcast_model(hamsm_ctx *c, int root) {
   for (int s = 0; s < S; s++) {
     Stratum &t = c->st[s];
     if (t.K == 0) continue;
+    const int root = h_root[s];
     ncclResult_t r3[3] = {ncclBroadcast(t.C, t.C, (size_t)t.K * c->D, ncclDouble, root, cm, c->stream),
                           ncclBroadcast(t.csq, t.csq, (size_t)t.K, ncclDouble, root, cm, c->stream),
                           ncclBroadcast(t.counts, t.counts, (size_t)t.K, ncclDouble, root, cm, c->stream)};
@@ -230,17 +240,17 @@ extern "C" int hamsm_bcast_model(hamsm_ctx *c, int root) {
       if (first == ncclSuccess) first = r_;
   }
   {
-    const ncclResult_t r_ = ncclBroadcast(c->d_remap, c->d_remap, sizeof(int32_t) * (size_t)S, ncclChar, root, cm, c->stream);
+    const ncclResult_t r_ = ncclBroadcast(c->d_remap, c->d_remap, sizeof(int32_t) * (size_t)S, ncclChar, 0, cm, c->stream);
     if (first == ncclSuccess) first = r_;
   }
   ncclResult_t end = ncclGroupEnd();  // (always closed, also after a failed call inside it)
   c->table_dirty = true;
-  if (first != ncclSuccess) return hamsm_fail(c, HAMSM_EDEVICE, "bcast_model: ncclBroadcast failed: %s", ncclGetErrorString(first));
-  if (end != ncclSuccess) return hamsm_fail(c, HAMSM_EDEVICE, "bcast_model: ncclGroupEnd failed: %s", ncclGetErrorString(end));
-  // (4) local only: re-pack the MFMA B fragments from the broadcast rows, keeping the broadcast ||c||^2
+  if (first != ncclSuccess) return hamsm_fail(c, HAMSM_EDEVICE, "bcast_strata: ncclBroadcast failed: %s", ncclGetErrorString(first));
+  if (end != ncclSuccess) return hamsm_fail(c, HAMSM_EDEVICE, "bcast_strata: ncclGroupEnd failed: %s", ncclGetErrorString(end));
+  // (4) local only: re-pack the MFMA B fragments of the strata that arrived, keeping the broadcast ||c||^2
   for (int s = 0; s < S; s++) {
     Stratum &t = c->st[s];
-    if (t.K == 0) continue;
+    if (t.K == 0 || h_root[s] == c->rank) continue;
     int rc = hamsm_ensure_scratch(c, sizeof(double) * t.K);
     if (rc) return rc;
     HIPCHK(c, hipMemcpyAsync(c->scratch, t.csq, sizeof(double) * t.K, hipMemcpyDeviceToDevice, c->stream));
@@ -249,4 +259,18 @@ extern "C" int hamsm_bcast_model(hamsm_ctx *c, int root) {
     HIPCHK(c, hipStreamSynchronize(c->stream));
   }
   return HAMSM_OK;
+}
+
+// centroids, counts, ||c||^2 and remap of every stratum, root -> all
+extern "C" int hamsm_bcast_model(hamsm_ctx *c, int root) {
+  CTX(c);
+  if (c->nranks == 1 && !c->comm) return HAMSM_OK;
+  std::vector<int32_t> roots((size_t)(c->S > 0 ? c->S : 1), root);
+  if (root != 0 && c->comm) {
+    // (the remap table of hamsm_bcast_strata travels from rank 0; a model broadcast from another root sends it from there)
+    int rc = hamsm_bcast_strata(c, roots.data());
+    if (rc) return rc;
+    return hamsm_bcast(c, c->d_remap, sizeof(int32_t) * (size_t)c->S, root);
+  }
+  return hamsm_bcast_strata(c, roots.data());
 }

@@ -605,6 +605,8 @@ class DataMixin:
 
     # -- sharded runs: the frames training needs, on the rank that trains --------------------------------------------
     train_shards = "all"   # "all": rank 0 trains on every rank's iterations (N ranks == one process on the same data);
+                           # "strata": the same model, but the strata's independent chains are dealt over the ranks (stratum s
+                           #   trains on rank s % N; every rank holds every iteration's training frames);
                            # "rank0": on its own shard only (the reference's `iters_to_use` restricted to that block)
 
     def training_store(self):
@@ -616,7 +618,7 @@ class DataMixin:
         h = self.h
         R = getattr(h, "nranks", 1)
         store = self.stage_iterations()
-        if R == 1 or self.train_shards != "all":
+        if R == 1 or self.train_shards not in ("all", "strata"):
             return store, self.maxIter
         if getattr(self, "_train_store", None) is not None:
             return self._train_store
@@ -645,14 +647,18 @@ class DataMixin:
         rows = np.array([all_sizes[int(cnt[:r].sum()): int(cnt[: r + 1].sum())].sum() for r in range(R)], dtype=np.int64)
         n_local = int(rows[h.rank])
         esz = 4 if store.x_dtype == _abi.F32 else 8
-        root = h.rank == 0
+        # "all": the frames go to rank 0; "strata": to every rank (one gather per root: a one-off at staging, and the checked
+        # send / recv group of hamsm_gather_to_root is the only exchange pattern the library needs for it)
+        roots = [0] if self.train_shards == "all" else list(range(R))
+        root = h.rank in roots
         N = int(rows.sum())
         Xc = h.alloc(max(N, 1) * store.D, np.float32 if esz == 4 else np.float64) if root else None
         p0 = h.alloc(max(N, 1) * store.ndim, np.float64) if root else None
         w = h.alloc(max(N, 1), np.float64) if root else None
-        h.gather_to_root(store.Xc, n_local * store.D * esz, Xc, rows * store.D * esz, 0)
-        h.gather_to_root(store.p0, n_local * store.ndim * 8, p0, rows * store.ndim * 8, 0)
-        h.gather_to_root(store.w, n_local * 8, w, rows * 8, 0)
+        for r in roots:
+            h.gather_to_root(store.Xc, n_local * store.D * esz, Xc, rows * store.D * esz, r)
+            h.gather_to_root(store.p0, n_local * store.ndim * 8, p0, rows * store.ndim * 8, r)
+            h.gather_to_root(store.w, n_local * 8, w, rows * 8, r)
         h.sync()
         if root:
             offsets = np.concatenate([[0], np.cumsum(all_sizes)]).astype(np.int64)

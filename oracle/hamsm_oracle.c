@@ -1317,6 +1317,11 @@ int hamsm_bcast_model(hamsm_ctx *c, int root) {
   (void)c, (void)root;
   return HAMSM_OK;
 }
+int hamsm_bcast_strata(hamsm_ctx *c, const int32_t *roots) {
+  CTX(c);
+  (void)c, (void)roots; /* one rank */
+  return HAMSM_OK;
+}
 int hamsm_timers(hamsm_ctx *c, double *out, int reset) {
   CTX(c);
   (void)c, (void)reset;

@@ -59,6 +59,17 @@ def _gloo_comm(h, dist, rank, world):
 
     h.bcast_model = bcast_model
 
+    def bcast_strata(roots):
+        for s in range(h.S):
+            root = int(roots[s])
+            state = [h.get_centroids(s) if rank == root else None]
+            dist.broadcast_object_list(state, src=root)
+            if rank != root:
+                Cm, counts, csq = state[0]
+                h.set_centroids(s, Cm if len(Cm) else None, csq=csq if len(Cm) else None, counts=counts if len(Cm) else None)
+
+    h.bcast_strata = bcast_strata
+
     def gather_to_root(d_send, send_bytes, d_recv, recv_bytes, root=0):
         a = np.empty(int(send_bytes), dtype=np.uint8)
         h.d2h(a, d_send)
@@ -107,6 +118,8 @@ def _worker(rank, world, port, out, train_shards="all"):
                           random_state=meta["seed"])
     m.get_fluxMatrix(0, first_iter=0, last_iter=m.maxIter)  # every local iteration with pairs
     res = dict(labels=np.concatenate(m.dtrajs), flux=m.fluxMatrixRaw, centers0=m.clusters.cluster_models[0].cluster_centers_,
+               centers1=m.clusters.cluster_models[1].cluster_centers_, counts1=m.clusters.cluster_models[1]._counts,
+               steps=[getattr(cm, "n_steps_", -1) for cm in m.clusters.cluster_models],
                remap=[m.clusters.we_remap[b] for b in range(2)])
     # the rest of build_analyze_model on the shards: cleaning (re-discretize + re-flux), cluster statistics, T, solve
     m.organize_fluxMatrix(use_ray=True)
@@ -120,16 +133,19 @@ def _worker(rank, world, port, out, train_shards="all"):
     dist.destroy_process_group()
 
 
-def test_two_ranks_equal_one_process_on_all_iterations(tmp_path, oracle_lib):
+@pytest.mark.parametrize("mode", ["all", "strata"])
+def test_two_ranks_equal_one_process_on_all_iterations(tmp_path, oracle_lib, mode):
     """`train_shards = "all"` (the default): the training frames of every shard are gathered to rank 0, which then trains
     on all iterations in order -- the two-rank run IS the single-process run of the same data: every label, the raw flux
-    matrix, the cleaned model, T, the steady state."""
+    matrix, the cleaned model, T, the steady state.  `"strata"`: every rank receives every shard's training frames and trains
+    the strata s % 2 == rank (independent chains, `_clustering.py:890-911`); stratum s's model travels from its rank
+    (`hamsm_bcast_strata`) -- the same single-process model, bit for bit, with the training spread over the ranks."""
     import torch.multiprocessing as mp
 
     from msm_we_amd import _abi
 
     out = str(tmp_path / "rank{}.npz")
-    mp.spawn(_worker, args=(2, _free_port(), out, "all"), nprocs=2, join=True)
+    mp.spawn(_worker, args=(2, _free_port(), out, mode), nprocs=2, join=True)
     r0, r1 = np.load(out.format(0)), np.load(out.format(1))
     g, meta = load_golden("c1p_d10")
     bm = RectilinearBinMapper([np.array(meta["boundaries"], dtype=np.float32)])
@@ -139,6 +155,10 @@ def test_two_ranks_equal_one_process_on_all_iterations(tmp_path, oracle_lib):
     labels = np.concatenate(c.dtrajs)
     assert np.array_equal(np.concatenate([r0["labels"], r1["labels"]]), labels)
     assert np.array_equal(r0["centers0"], c.clusters.cluster_models[0].cluster_centers_) and np.array_equal(r0["centers0"], r1["centers0"])
+    assert np.array_equal(r0["centers1"], c.clusters.cluster_models[1].cluster_centers_) and np.array_equal(r0["centers1"], r1["centers1"])
+    assert np.array_equal(r0["counts1"], c.clusters.cluster_models[1]._counts) and np.array_equal(r1["counts1"], r0["counts1"])
+    if mode == "strata":   # the streaming bookkeeping of every stratum reached every rank
+        assert list(r0["steps"]) == list(r1["steps"]) == [cm.n_steps_ for cm in c.clusters.cluster_models]
     c.get_fluxMatrix(0, first_iter=0, last_iter=c.maxIter)
     assert np.array_equal(r0["flux"], r1["flux"])
     np.testing.assert_allclose(r0["flux"], c.fluxMatrixRaw, rtol=1e-12, atol=1e-300)
@@ -218,7 +238,7 @@ def test_bench_two_rank_flow_on_cpu(tmp_path, oracle_lib):
     import json
     import subprocess
 
-    env = dict(os.environ, HAMSM_BENCH_BACKEND="gloo", OMP_NUM_THREADS="1", HAMSM_BENCH_ALLOW_FALLBACK="1")
+    env = dict(os.environ, OMP_NUM_THREADS="1", HAMSM_BENCH_ALLOW_FALLBACK="1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1",
            "--workload", "tiny", "--lib", _build_oracle()]
@@ -227,8 +247,11 @@ def test_bench_two_rank_flow_on_cpu(tmp_path, oracle_lib):
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1  # ONE line, from rank 0
     out = json.loads(lines[0])
-    assert out["n_gpus"] == 2 and out["scaling"] == "weak" and out["unit"] == "frames/s" and out["value"] > 0
+    # the default for N > 1 is BASELINE config 4's shape of run: the workload's frames split over the ranks (strong scaling), the
+    # strata's training spread over the ranks, the model of one process on the same data
+    assert out["n_gpus"] == 2 and out["scaling"] == "strong" and out["unit"] == "frames/s" and out["value"] > 0
     assert "cpu_baseline" not in out and out["config"]["parallelism"] == "iteration-sharded x2"
+    assert "stratum s trains on rank s % N" in out["config"]["training"]
     assert "torch.distributed" in r.stderr  # the stand-in was used (the oracle cannot create a communicator) ...
     assert out["config"]["exchange"].startswith("torch-fallback")   # ... and the line says so
     # without the explicit permission a run whose RCCL communicator cannot be created stops instead of measuring a stand-in
@@ -236,11 +259,16 @@ def test_bench_two_rank_flow_on_cpu(tmp_path, oracle_lib):
     cmd[cmd.index("--master-port") + 1] = str(_free_port())
     r2 = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=600)
     assert r2.returncode != 0 and "refusing to fall back" in r2.stderr
-    # strong scaling (BASELINE config 4's shape of run): the workload's frames split over the ranks, rank 0 trains on all
+    # weak scaling on request: every rank its own full shard, rank 0 trains on its block; and rank-0 training of all shards
     env["HAMSM_BENCH_ALLOW_FALLBACK"] = "1"
     cmd[cmd.index("--master-port") + 1] = str(_free_port())
-    r3 = subprocess.run(cmd + ["--scaling", "strong"], capture_output=True, text=True, env=env, timeout=600)
+    r3 = subprocess.run(cmd + ["--scaling", "weak"], capture_output=True, text=True, env=env, timeout=600)
     assert r3.returncode == 0, r3.stderr[-2000:]
     o3 = json.loads([ln for ln in r3.stdout.splitlines() if ln.startswith("{")][0])
-    assert o3["scaling"] == "strong" and o3["config"]["frames_total"] == out["config"]["frames_total"] // 2
-    assert "every rank's iterations" in o3["config"]["training"]
+    assert o3["scaling"] == "weak" and o3["config"]["frames_total"] == 2 * out["config"]["frames_total"]
+    assert "its own block" in o3["config"]["training"]
+    cmd[cmd.index("--master-port") + 1] = str(_free_port())
+    r4 = subprocess.run(cmd + ["--train-on", "all"], capture_output=True, text=True, env=env, timeout=600)
+    assert r4.returncode == 0, r4.stderr[-2000:]
+    o4 = json.loads([ln for ln in r4.stdout.splitlines() if ln.startswith("{")][0])
+    assert o4["scaling"] == "strong" and "rank 0 trains on every rank's iterations" in o4["config"]["training"]
