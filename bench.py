@@ -458,15 +458,16 @@ def ingest_leg(h, cfg, n_it, log):
     slabs, uploads on the copy stream -- against the same frames uploaded from one host array in one piece."""
     import shutil
     import tempfile
-    from msm_we_amd.data import InMemorySource, NpzDirectorySource
+    from msm_we_amd.data import InMemorySource, NpyDirectorySource, NpzDirectorySource
 
     lat = synthetic.latent_centres(cfg)
     its = {it: synthetic.make_iteration(cfg, it, lat) for it in range(1, n_it + 2)}
     tmp = tempfile.mkdtemp(prefix="hamsm_ingest_")
     try:
-        src = NpzDirectorySource.export(InMemorySource(its), tmp)
+        src = NpzDirectorySource.export(InMemorySource(its), os.path.join(tmp, "npz"))
+        raw = NpyDirectorySource.export(InMemorySource(its), os.path.join(tmp, "npy"))
         res = {}
-        for name, source in (("npz_files", src), ("in_memory", InMemorySource(its))):
+        for name, source in (("npz_files", src), ("npy_files_mmap", raw), ("in_memory", InMemorySource(its))):
             m = modelWE(h=h)
             m.pcoord_ndim = 1
             m.set_iteration_source(source)

@@ -74,6 +74,11 @@ int hamsm_copy_sync(hamsm_ctx *ctx);
  * float64 on load, _data.py:265,565) and switches to float64 in the middle of its one pass when a block holds a value float32
  * cannot carry: what was uploaded before is converted where it lies instead of being read again.  Runs on the compute stream. */
 int hamsm_widen_f32(hamsm_ctx *ctx, const float *d_src, double *d_dst, int64_t count);
+/* (ABI 7) d_flags[i] = 1 when row i of d_X (n rows of D values at pitch ldx, x_dtype) holds a NaN, else 0.  The reference drops /
+ * zero-weights segments whose coordinates contain NaN (`_data.py:303-313, 549-553`); staging used to find them with a host scan
+ * of every block (3 GB/s per core -- slower than the copy into the upload slab), now the block is scanned where it lands in HBM.
+ * Compute stream.                                                                                                              */
+int hamsm_nan_rows(hamsm_ctx *ctx, const void *d_X, int x_dtype, int64_t ldx, int D, int64_t n, uint8_t *d_flags);
 int hamsm_sync(hamsm_ctx *ctx);
 
 /* ---- model state (replaces the attributes of StratifiedClusters / modelWE that predict() reads:

@@ -38,6 +38,7 @@ SYMBOLS = {
     "hamsm_memcpy_h2d_async": (_int, [_vp, _vp, _vp, _sz]),
     "hamsm_copy_sync": (_int, [_vp]),
     "hamsm_widen_f32": (_int, [_vp, _vp, _vp, _i64]),
+    "hamsm_nan_rows": (_int, [_vp, _vp, _int, _i64, _int, _i64, _vp]),
     "hamsm_sync": (_int, [_vp]),
     "hamsm_set_geometry": (_int, [_vp, _int, _int, _int]),
     "hamsm_set_mapper_rectilinear": (_int, [_vp, _vp, _vp]),
@@ -292,6 +293,10 @@ class Hamsm:
     def widen_f32(self, d_src, d_dst, count):
         """float32 frames resident in HBM -> float64 (exact), on the compute stream"""
         self._ck(self.lib.hamsm_widen_f32(self.ctx, _dp(d_src), _dp(d_dst), int(count)))
+
+    def nan_rows(self, d_X, x_dtype, ldx, D, n, d_flags):
+        """d_flags[i] (uint8) = row i of d_X holds a NaN; on the compute stream"""
+        self._ck(self.lib.hamsm_nan_rows(self.ctx, _dp(d_X), int(x_dtype), int(ldx), int(D), int(n), _dp(d_flags)))
 
     def zeros(self, shape, dtype) -> DevBuf:
         b = self.alloc(shape, dtype)

@@ -329,6 +329,35 @@ extern "C" int hamsm_widen_f32(hamsm_ctx *c, const float *d_src, double *d_dst, 
   HIPCHK(c, hipGetLastError());
   return HAMSM_OK;
 }
+// rows that hold a NaN: one wave per row at a time (lane l reads elements l, l + 64, ...; a ballot decides), grid-stride over the
+// rows.  HBM-bound (every byte read once, one byte per row written).
+template <typename XT>
+__global__ __launch_bounds__(256) void k_nan_rows(const XT *__restrict__ X, int64_t ldx, int D, int64_t n, uint8_t *__restrict__ flags) {
+  const int lane = threadIdx.x & 63;
+  const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+  for (int64_t i = wave; i < n; i += nwaves) {
+    const XT *row = X + i * ldx;
+    bool bad = false;
+    for (int k = lane; k < D; k += 64) {
+      const XT v = row[k];
+      bad = bad || (v != v);
+    }
+    const unsigned long long any = __ballot(bad);
+    if (lane == 0) flags[i] = any ? 1 : 0;
+  }
+}
+extern "C" int hamsm_nan_rows(hamsm_ctx *c, const void *d_X, int dt, int64_t ldx, int D, int64_t n, uint8_t *d_flags) {
+  CTX(c);
+  if (dt != HAMSM_F32 && dt != HAMSM_F64) return hamsm_fail(c, HAMSM_EINVAL, "x_dtype");
+  if (n < 0 || D < 1 || ldx < D || (n > 0 && (!d_X || !d_flags))) return hamsm_fail(c, HAMSM_EINVAL, "nan_rows: bad arguments");
+  if (n == 0) return HAMSM_OK;
+  int64_t blocks = (n + 3) / 4;  // 4 waves per workgroup, a row per wave and turn
+  if (blocks > 256 * 32) blocks = 256 * 32;
+  if (dt == HAMSM_F32) hipLaunchKernelGGL(k_nan_rows<float>, dim3((unsigned)blocks), dim3(256), 0, c->stream, (const float *)d_X, ldx, D, n, d_flags);
+  else hipLaunchKernelGGL(k_nan_rows<double>, dim3((unsigned)blocks), dim3(256), 0, c->stream, (const double *)d_X, ldx, D, n, d_flags);
+  HIPCHK(c, hipGetLastError());
+  return HAMSM_OK;
+}
 extern "C" int hamsm_memset(hamsm_ctx *c, void *d, int b, size_t n) {
   CTX(c);
   HIPCHK(c, hipMemsetAsync(d, b, n, c->stream));

@@ -76,6 +76,50 @@ class NpzDirectorySource:
         return cls(directory)
 
 
+class NpyDirectorySource:
+    """Iterations as raw, memory-mapped arrays: ``<dir>/iter_%08d.<key>.npy``, one file per array of the source contract
+    (``Xp`` / ``Xc`` or ``parent`` / ``child``, ``p0``, ``p1``, ``w``, ...).  `load` maps the files (no read, no copy); staging's
+    reader threads then copy each array ONCE, from the page cache straight into the page-locked upload slab -- where the
+    ``.npz`` layout pays a zip-member read, a CRC pass and a copy into a fresh array first (1.4 GB/s against the slab's copy
+    rate).  The layout to export a long WESTPA run to for repeated analyses on a host without h5py."""
+
+    PATTERN = "iter_%08d.%s.npy"
+    parallel_safe = True   # every `load` maps its own files
+
+    def __init__(self, directory):
+        import os
+        import re
+
+        self.dir = str(directory)
+        keys = {}
+        for f in os.listdir(self.dir):
+            m = re.fullmatch(r"iter_(\d{8})\.(\w+)\.npy", f)
+            if m:
+                keys.setdefault(int(m.group(1)), []).append(m.group(2))
+        if not keys:
+            raise FileNotFoundError(f"no iter_XXXXXXXX.<key>.npy files in {self.dir}")
+        self._keys = keys
+
+    def iterations(self):
+        return sorted(self._keys)
+
+    def load(self, n):
+        import os
+
+        return {k: np.load(os.path.join(self.dir, self.PATTERN % (int(n), k)), mmap_mode="r") for k in self._keys[int(n)]}
+
+    @classmethod
+    def export(cls, source, directory, iterations=None):
+        """write any source (e.g. a WestpaH5Source) in this layout"""
+        import os
+
+        os.makedirs(str(directory), exist_ok=True)
+        for n in (source.iterations() if iterations is None else iterations):
+            for k, v in source.load(n).items():
+                np.save(os.path.join(str(directory), cls.PATTERN % (int(n), k)), np.ascontiguousarray(v))
+        return cls(directory)
+
+
 def resolve_object(spec):
     """``westpa.core.extloader.get_object``: 'package.module.attribute' -> object (objects pass through; westpa's own
     loader is used where WESTPA is installed)."""
@@ -396,7 +440,7 @@ class DataMixin:
         return (X[0], X[1], np.asarray(d["p0"], dtype=np.float64).reshape(n, -1)[:, : self.pcoord_ndim],
                 np.asarray(d["p1"], dtype=np.float64).reshape(n, -1)[:, : self.pcoord_ndim], np.asarray(d["w"], dtype=np.float64))
 
-    STAGE_READERS = None  # reader threads per block; None: up to 8 where the source and the featurizer allow it, else 1
+    STAGE_READERS = None  # reader threads per block; None: up to 12 where the source and the featurizer allow it, else 1
 
     def _stage_readers(self):
         """how many threads may load / featurize iterations at once: the source must say it is safe (`parallel_safe`: the in-memory
@@ -409,7 +453,7 @@ class DataMixin:
         builtin = type(self).processCoordinates is DataMixin.processCoordinates and self._featurizer is None and self._featurizer_spec is None
         if not (getattr(self._source, "parallel_safe", False) and builtin):
             return 1
-        return max(1, min(8, (os.cpu_count() or 2) - 1))
+        return max(1, min(12, (os.cpu_count() or 2) - 1))
 
     def _fill_slab(self, its, mode, slab, up_dtype, preloaded=None, pool=None):
         """reader thread: iterations `its` written straight into a page-locked slab (one copy, no intermediate concatenation);
@@ -422,16 +466,17 @@ class DataMixin:
             n = len(blk[4])
             if n_expected is not None and n != n_expected:
                 raise ValueError(f"iteration {it} holds {n} segments, {n_expected} were announced")
-            fits, nan = True, []
+            fits = True
             for side in range(2):
                 x = blk[side]
                 dst = slab["X"][side][o: o + n]
                 dst[...] = x                                  # (casts when the dtypes differ)
-                nan.append(np.isnan(x).any(axis=1))
+                # (NaN-coordinate segments are found on the device, where the block lands: `hamsm_nan_rows` -- a host scan runs
+                # at 3 GB/s per core, slower than this copy)
                 if x.dtype != up_dtype and up_dtype == np.float32 and fits:
                     fits = bool(np.array_equal(dst.astype(x.dtype), x, equal_nan=True))
             slab["p0"][o: o + n], slab["p1"][o: o + n], slab["w"][o: o + n] = blk[2], blk[3], blk[4]
-            return n, nan[0], nan[1], fits
+            return n, None, None, fits
 
         sizes = getattr(self, "_stage_sizes", None)
         if pool is not None and sizes is not None and len(its) > 1:
@@ -443,8 +488,7 @@ class DataMixin:
                 r = one(it, o, None)
                 res.append(r)
                 o += r[0]
-        cat = lambda v: np.concatenate(v) if v else np.zeros(0, dtype=bool)  # noqa: E731
-        return sum(r[0] for r in res), cat([r[1] for r in res]), cat([r[2] for r in res]), all(r[3] for r in res)
+        return sum(r[0] for r in res), None, None, all(r[3] for r in res)
 
     def stage_iterations(self):
         """Featurize and upload iterations 1..maxIter once.  Idempotent.  ONE pass over the source: a reader thread loads and
@@ -506,7 +550,15 @@ class DataMixin:
                     mid = [h.alloc(max(rows_max, 1) * len(feat[1]), np.float64) for _ in range(2)]
             d_p0, d_p1, d_w = h.alloc(n_all * ndim, np.float64), h.alloc(n_all * ndim, np.float64), h.alloc(n_all, np.float64)
             slabs = alloc_slabs(up_dtype)
-            nan = [np.zeros(N, dtype=bool), np.zeros(N, dtype=bool)]
+            d_nan = h.zeros((2, max(N, 1)), np.uint8)   # rows with a NaN, parent / child: filled block by block on the device
+            scan = None                                  # host mode: the block whose upload is in flight (scanned once it has landed)
+
+            def scan_now():
+                if scan is not None:
+                    f0_, n_, dt_ = scan
+                    for side_ in range(2):
+                        h.nan_rows(Xd[side_].offset(f0_ * D), dt_, D, D, n_, d_nan.offset(side_ * max(N, 1) + f0_))
+
             w_all = np.empty(N)
             widened = False
             done = False
@@ -517,8 +569,10 @@ class DataMixin:
                 with ThreadPoolExecutor(1) as pool:
                     fut = pool.submit(self._fill_slab, chunks[0], mode, slabs[0], up_dtype, preloaded, readers)
                     for k, ch in enumerate(chunks):
-                        n, nan_p, nan_c, fits = fut.result()          # slab k & 1 holds block k
+                        n, _, _, fits = fut.result()                  # slab k & 1 holds block k
                         h.copy_sync()                                 # block k-1 has left the other slab ...
+                        scan_now()                                    # ... and lies in HBM: its NaN rows (host mode)
+                        scan = None
                         if mode != "host":
                             h.sync()                                  # ... and the kernels that read its raw upload are done
                         if not fits:
@@ -543,7 +597,7 @@ class DataMixin:
                             slabs = []   # (if the allocation below raises, the `finally` must not meet the freed slabs again)
                             up_dtype, widened = np.float64, True
                             slabs = alloc_slabs(up_dtype)
-                            n, nan_p, nan_c, fits = self._fill_slab(ch, mode, slabs[k & 1], up_dtype, preloaded, readers)
+                            n, _, _, fits = self._fill_slab(ch, mode, slabs[k & 1], up_dtype, preloaded, readers)
                         if k + 1 < len(chunks):
                             fut = pool.submit(self._fill_slab, chunks[k + 1], mode, slabs[(k + 1) & 1], up_dtype, None, readers)
                         up_dt = _abi.F32 if up_dtype == np.float32 else _abi.F64
@@ -552,7 +606,6 @@ class DataMixin:
                         if n == 0:
                             continue
                         sl = slabs[k & 1]
-                        nan[0][f0: f0 + n], nan[1][f0: f0 + n] = nan_p, nan_c
                         w_all[f0: f0 + n] = sl["w"][:n]
                         for side in range(2):
                             dst = Xd[side].offset(f0 * D) if mode == "host" else raw[side]
@@ -560,9 +613,12 @@ class DataMixin:
                         h.h2d_async(d_p0.offset(f0 * ndim), sl["p0"], n * ndim * 8)
                         h.h2d_async(d_p1.offset(f0 * ndim), sl["p1"], n * ndim * 8)
                         h.h2d_async(d_w.offset(f0), sl["w"], n * 8)
-                        if mode != "host":
+                        if mode == "host":
+                            scan = (f0, n, up_dt)
+                        else:
                             h.copy_sync()   # the device stage reads the uploaded block
                             for side in range(2):
+                                h.nan_rows(raw[side], up_dt, raw_w, raw_w, n, d_nan.offset(side * max(N, 1) + f0))
                                 src, src_dt, src_w = raw[side], up_dt, raw_w
                                 if feat is not None:
                                     out = mid[side] if lin is not None else Xd[side].offset(f0 * D)
@@ -571,6 +627,7 @@ class DataMixin:
                                 if lin is not None:
                                     h.project(src, src_dt, src_w, n, lin[0], lin[1], lin[2], d_Y=Xd[side].offset(f0 * D))
                     h.copy_sync()
+                    scan_now()
                     h.sync()
                     done = True
             finally:
@@ -582,10 +639,12 @@ class DataMixin:
                     for b_ in bufs or ():
                         b_.free()
                 if not done:
-                    for b_ in (*Xd, d_p0, d_p1, d_w):
+                    for b_ in (*Xd, d_p0, d_p1, d_w, d_nan):
                         b_.free()
         x_dt = (_abi.F32 if up_dtype == np.float32 else _abi.F64) if mode == "host" else _abi.F64
         store = DeviceStore(h, D, ndim, x_dt, offsets, Xd[0], Xd[1], d_p0, d_p1, d_w)
+        nan = d_nan.to_host().astype(bool)[:, :N]
+        d_nan.free()
         store.mark_nan_segments(nan[0], nan[1], w_all)
         self._store = store
         nbytes = N * (2 * raw_w * (4 if store.x_dtype == _abi.F32 and mode == "host" else first[0].dtype.itemsize) + 16 * ndim + 8)

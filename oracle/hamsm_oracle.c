@@ -234,6 +234,20 @@ int hamsm_widen_f32(hamsm_ctx *c, const float *src, double *dst, int64_t count) 
   for (int64_t i = 0; i < count; i++) dst[i] = (double)src[i];
   return HAMSM_OK;
 }
+int hamsm_nan_rows(hamsm_ctx *c, const void *X, int dt, int64_t ldx, int D, int64_t n, uint8_t *flags) {
+  CTX(c);
+  if (dt != HAMSM_F32 && dt != HAMSM_F64) return fail(c, HAMSM_EINVAL, "x_dtype");
+  if (n < 0 || D < 1 || ldx < D || (n > 0 && (!X || !flags))) return fail(c, HAMSM_EINVAL, "nan_rows: bad arguments");
+  for (int64_t i = 0; i < n; i++) { /* `_data.py:303-313`: a segment whose coordinates contain a NaN */
+    int bad = 0;
+    for (int k = 0; k < D; k++) {
+      const double v = dt == HAMSM_F32 ? (double)((const float *)X)[i * ldx + k] : ((const double *)X)[i * ldx + k];
+      bad |= v != v;
+    }
+    flags[i] = (uint8_t)bad;
+  }
+  return HAMSM_OK;
+}
 int hamsm_memcpy_h2d(hamsm_ctx *c, void *d, const void *h, size_t n) {
   CTX(c);
   (void)c;

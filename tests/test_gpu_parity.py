@@ -1073,3 +1073,22 @@ def test_row_lists_with_many_strata_match_oracle(hip_h, oracle_h, S):
         for s in np.unique(s_of):
             assert np.array_equal(rows[st[g, s]: st[g, s] + cnt[g, s]], np.nonzero(s_of == s)[0])
         assert cnt[g].sum() == len(listed)
+
+
+@pytest.mark.parametrize("D,ldx,dtype", [(30, 30, np.float32), (3, 5, np.float64), (64, 64, np.float32), (200, 208, np.float32), (1, 1, np.float64)])
+def test_nan_rows_match_oracle(hip_h, oracle_h, D, ldx, dtype):
+    """`hamsm_nan_rows` (staging's NaN-coordinate scan, `_data.py:303-313`): rows with a NaN, padded pitch ignored, inf is not NaN"""
+    rng = np.random.default_rng(D)
+    n = 70001
+    X = rng.standard_normal((n, ldx)).astype(dtype)
+    X[rng.choice(n, 300, replace=False), rng.integers(0, D, 300)] = np.nan
+    X[rng.choice(n, 50, replace=False), rng.integers(0, D, 50)] = np.inf
+    if ldx > D:
+        X[:, D:] = np.nan          # the padding is not part of a row
+    want = np.isnan(X[:, :D]).any(axis=1)
+    for h in (oracle_h, hip_h):
+        d_X, d_f = h.to_device(X), h.alloc(n, np.uint8)
+        h.memset(d_f, 7, n)
+        h.nan_rows(d_X, 0 if dtype == np.float32 else 1, ldx, D, n, d_f)
+        h.sync()
+        assert np.array_equal(d_f.to_host().astype(bool), want) and set(np.unique(d_f.to_host())) <= {0, 1}

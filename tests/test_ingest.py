@@ -8,7 +8,7 @@ import numpy as np
 import pytest
 
 from conftest import build_model, golden_iterations, load_golden
-from msm_we_amd.data import InMemorySource, NpzDirectorySource
+from msm_we_amd.data import InMemorySource, NpyDirectorySource, NpzDirectorySource
 
 
 class _FakeNode(dict):
@@ -226,13 +226,17 @@ def test_h5_source_without_h5py_says_so(monkeypatch):
         data.WestpaH5Source("west.h5")
 
 
+@pytest.mark.parametrize("layout", [NpzDirectorySource, NpyDirectorySource], ids=["npz", "npy-mmap"])
 @pytest.mark.parametrize("case", ["c1p_d10", "nan_d10"])
-def test_streaming_staging_in_many_blocks(oracle_h, tmp_path, monkeypatch, case):
-    """blocks of ~3 iterations through the two pinned slabs: the staged arrays are those of a single-block staging"""
+def test_streaming_staging_in_many_blocks(oracle_h, tmp_path, monkeypatch, case, layout):
+    """blocks of ~3 iterations through the two pinned slabs: the staged arrays are those of a single-block staging -- from
+    per-iteration .npz files and from the raw memory-mapped .npy layout; NaN-coordinate segments (found on the device,
+    `hamsm_nan_rows`) included"""
     from msm_we_amd.model import modelWE
 
     g, meta = load_golden(case)
-    src = NpzDirectorySource.export(InMemorySource(golden_iterations(g)), tmp_path / "iters")
+    src = layout.export(InMemorySource(golden_iterations(g)), tmp_path / "iters")
+    assert src.iterations() == sorted(golden_iterations(g)) and layout(tmp_path / "iters").iterations() == src.iterations()
     stores = []
     for chunk_bytes in (64 << 20, 3 * 128 * (2 * 10 * 4 + 24)):
         monkeypatch.setattr(modelWE, "STAGE_CHUNK_BYTES", chunk_bytes)
