@@ -477,7 +477,8 @@ def ingest_leg(h, cfg, n_it, log):
             h.sync()
             dt = time.perf_counter() - t0
             res[name] = {"seconds": dt, "GBps": m.ingest_stats["bytes"] / dt / 1e9, "bytes": m.ingest_stats["bytes"],
-                         "blocks": m.ingest_stats["blocks"], "frames": int(st.N)}
+                         "blocks": m.ingest_stats["blocks"], "frames": int(st.N), "readers": m.ingest_stats.get("readers"), "direct_read_blocks": m.ingest_stats.get("direct_read_blocks"),
+                         "host_waits_s": m.ingest_stats.get("host_waits_s")}
             for b in (st.Xp, st.Xc, st.p0, st.p1, st.w):
                 b.free()
         log(f"ingest: {res}")
@@ -760,7 +761,10 @@ def main():
         "training_estep_rows": rank_stats,
     }
     if world == 1 and not args.no_ingest:
-        out["ingest"] = ingest_leg(h, cfg, min(n_iters, 100, max(4, int(264e6 / (cfg.segs_per_iter * cfg.D * 8)))), log)
+        # (a bounded sample: ~264 MB of frames; HAMSM_BENCH_INGEST_ITERS: another number of iterations, e.g. 400 = 1 GB at C3, where
+        # the fixed costs -- page-locking two upload slabs, the device allocations -- weigh less)
+        n_ing = int(os.environ.get("HAMSM_BENCH_INGEST_ITERS", 0)) or min(100, max(4, int(264e6 / (cfg.segs_per_iter * cfg.D * 8))))
+        out["ingest"] = ingest_leg(h, cfg, min(n_iters, n_ing), log)
     if world == 1 and not args.no_full_pipeline:
         # BASELINE.json's second figure (steady-state solve wall-time) and SURVEY §8d's build_analyze_model-equivalent
         log("timing the full build_analyze_model sequence (clean, T, solve, block validation) ...")

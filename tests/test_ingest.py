@@ -245,6 +245,8 @@ def test_streaming_staging_in_many_blocks(oracle_h, tmp_path, monkeypatch, case,
         stores.append([st.Xp.to_host(), st.Xc.to_host(), st.p0.to_host(), st.p1.to_host(), st.w.to_host(), st.w_flux.to_host(),
                        np.concatenate(m.dtrajs), m.ingest_stats["blocks"]])
     assert stores[0][-1] == 1 and stores[1][-1] > 10
+    # the raw layout's blocks go file -> upload slab (preadv), never through a per-iteration array
+    assert m.ingest_stats["direct_read_blocks"] == (m.ingest_stats["blocks"] if layout is NpyDirectorySource else 0)
     for a, b in zip(stores[0][:-1], stores[1][:-1]):
         assert np.array_equal(a, b, equal_nan=True)
     assert np.array_equal(stores[1][6], g["dtrajs_post_cluster"])
