@@ -630,9 +630,12 @@ class DataMixin:
             D = raw_w if mode == "host" else ((len(feat[1]) if feat is not None else raw_w) if lin is None else lin[0].shape[0])
             n_all = max(N, 1)
 
+            def alloc_slab(dt):
+                return dict(X=[h.pinned((rows_max, raw_w), dt) for _ in range(2)], p0=h.pinned((rows_max, ndim), np.float64),
+                            p1=h.pinned((rows_max, ndim), np.float64), w=h.pinned(rows_max, np.float64))
+
             def alloc_slabs(dt):
-                return [dict(X=[h.pinned((rows_max, raw_w), dt) for _ in range(2)], p0=h.pinned((rows_max, ndim), np.float64),
-                             p1=h.pinned((rows_max, ndim), np.float64), w=h.pinned(rows_max, np.float64)) for _ in range(2)]
+                return [alloc_slab(dt) for _ in range(2)]
 
             def free_slabs(slabs_):
                 for sl_ in slabs_:
@@ -640,15 +643,10 @@ class DataMixin:
                         h.free_pinned(a_)
 
             raw = mid = None
+            Xd, d_rest = [], []
+            d_p0 = d_p1 = d_w = d_nan = None
             t0_ = time.perf_counter()
-            Xd = [h.alloc(n_all * D, up_dtype if mode == "host" else np.float64) for _ in range(2)]
-            if mode != "host":
-                raw = [h.alloc(max(rows_max, 1) * raw_w, up_dtype) for _ in range(2)]       # uploaded block, parent / child
-                if feat is not None and lin is not None:
-                    mid = [h.alloc(max(rows_max, 1) * len(feat[1]), np.float64) for _ in range(2)]
-            d_p0, d_p1, d_w = h.alloc(n_all * ndim, np.float64), h.alloc(n_all * ndim, np.float64), h.alloc(n_all, np.float64)
-            slabs = alloc_slabs(up_dtype)
-            d_nan = h.zeros((2, max(N, 1)), np.uint8)   # rows with a NaN, parent / child: filled block by block on the device
+            slabs = [alloc_slab(up_dtype)]               # (the second slab and the device arrays: while block 0 is being read)
             lap("alloc", t0_)
             scan = None                                  # host mode: the block whose upload is in flight (scanned once it has landed)
 
@@ -668,6 +666,20 @@ class DataMixin:
             try:
                 with ThreadPoolExecutor(1) as pool:
                     fut = pool.submit(self._fill_slab, chunks[0], mode, slabs[0], up_dtype, preloaded, readers)
+                    # page-locking the second slab and allocating the device arrays (20-30 ms per GB staged) overlap the reading of
+                    # block 0
+                    t0_ = time.perf_counter()
+                    Xd = [h.alloc(n_all * D, up_dtype if mode == "host" else np.float64) for _ in range(2)]
+                    if mode != "host":
+                        raw = [h.alloc(max(rows_max, 1) * raw_w, up_dtype) for _ in range(2)]       # uploaded block, parent / child
+                        if feat is not None and lin is not None:
+                            mid = [h.alloc(max(rows_max, 1) * len(feat[1]), np.float64) for _ in range(2)]
+                    d_p0, d_p1, d_w = h.alloc(n_all * ndim, np.float64), h.alloc(n_all * ndim, np.float64), h.alloc(n_all, np.float64)
+                    d_rest = [d_p0, d_p1, d_w]
+                    slabs.append(alloc_slab(up_dtype))
+                    d_nan = h.zeros((2, max(N, 1)), np.uint8)   # rows with a NaN, parent / child: filled block by block on the device
+                    d_rest.append(d_nan)
+                    lap("alloc", t0_)
                     for k, ch in enumerate(chunks):
                         t0_ = time.perf_counter()
                         n, _, _, fits = fut.result()                  # slab k & 1 holds block k
@@ -743,7 +755,7 @@ class DataMixin:
                     for b_ in bufs or ():
                         b_.free()
                 if not done:
-                    for b_ in (*Xd, d_p0, d_p1, d_w, d_nan):
+                    for b_ in (*Xd, *d_rest):
                         b_.free()
         x_dt = (_abi.F32 if up_dtype == np.float32 else _abi.F64) if mode == "host" else _abi.F64
         store = DeviceStore(h, D, ndim, x_dt, offsets, Xd[0], Xd[1], d_p0, d_p1, d_w)

@@ -917,6 +917,17 @@ def test_rccl_collectives_on_one_rank_communicator(hip_lib):
             assert np.array_equal(Cm, C2) and np.array_equal(csq, csq2) and np.array_equal(cnt, cnt2)
         assert h.num_centroids(2) == 0
         assert np.array_equal(h.predict_host(X, p), before)
+        # the per-stratum form (train_shards = "strata"): every stratum from "its" rank -- rank 0 for all of them here; roots that
+        # name no rank are an error on every rank (the readiness exchange), and the communicator stays usable
+        h.bcast_strata(np.zeros(S, dtype=np.int32))
+        for s, (Cm, cnt, csq) in zip((0, 1, 3), cents):
+            C2, cnt2, csq2 = h.get_centroids(s)
+            assert np.array_equal(Cm, C2) and np.array_equal(csq, csq2) and np.array_equal(cnt, cnt2)
+        assert h.num_centroids(2) == 0 and np.array_equal(h.predict_host(X, p), before)
+        with pytest.raises(_abi.HamsmError, match="could not prepare"):
+            h.bcast_strata(np.array([0, 1, 0, 0], dtype=np.int32))
+        h.bcast_strata(np.zeros(S, dtype=np.int32))
+        assert np.array_equal(h.predict_host(X, p), before)
         # gather_to_root: ncclSend / ncclRecv in one group (rank 0 sends to itself here)
         d_r = h.zeros(v.size, np.float64)
         h.gather_to_root(d_v, v.nbytes, d_r, [v.nbytes], 0)
