@@ -454,8 +454,10 @@ def roofline_by_kernel(cfg, n_iters, n_seg, timers, steps, assign_tflops, assign
 
 
 def ingest_leg(h, cfg, n_it, log):
-    """f2: `stage_iterations` from per-iteration files (NpzDirectorySource, the h5py-free layout) -- reader thread, two pinned
-    slabs, uploads on the copy stream -- against the same frames uploaded from one host array in one piece."""
+    """f2: `stage_iterations` -- two page-locked slabs, the next block filled while the current one is uploaded on the copy stream
+    -- from per-iteration `.npz` files (zip members: the interpreter copies), from the run-level raw layout (`NpyDirectorySource`:
+    the library's threads pread file -> slab, `hamsm_host_read_parts`) and from iterations held in memory
+    (`hamsm_host_copy_parts`).  Everything is inside the figure: slab allocation and release, device allocations, the NaN scan."""
     import shutil
     import tempfile
     from msm_we_amd.data import InMemorySource, NpyDirectorySource, NpzDirectorySource
@@ -467,7 +469,7 @@ def ingest_leg(h, cfg, n_it, log):
         src = NpzDirectorySource.export(InMemorySource(its), os.path.join(tmp, "npz"))
         raw = NpyDirectorySource.export(InMemorySource(its), os.path.join(tmp, "npy"))
         res = {}
-        for name, source in (("npz_files", src), ("npy_files_mmap", raw), ("in_memory", InMemorySource(its))):
+        for name, source in (("npz_files", src), ("raw_files", raw), ("in_memory", InMemorySource(its))):
             m = modelWE(h=h)
             m.pcoord_ndim = 1
             m.set_iteration_source(source)
@@ -761,9 +763,9 @@ def main():
         "training_estep_rows": rank_stats,
     }
     if world == 1 and not args.no_ingest:
-        # (a bounded sample: ~264 MB of frames; HAMSM_BENCH_INGEST_ITERS: another number of iterations, e.g. 400 = 1 GB at C3, where
-        # the fixed costs -- page-locking two upload slabs, the device allocations -- weigh less)
-        n_ing = int(os.environ.get("HAMSM_BENCH_INGEST_ITERS", 0)) or min(100, max(4, int(264e6 / (cfg.segs_per_iter * cfg.D * 8))))
+        # (a bounded sample: ~1 GB of frames, 400 iterations at C3; HAMSM_BENCH_INGEST_ITERS: another number of iterations.  The
+        # fixed costs -- page-locking and releasing two upload slabs, the device allocations: ~20 ms -- are inside the figure)
+        n_ing = int(os.environ.get("HAMSM_BENCH_INGEST_ITERS", 0)) or min(400, max(4, int(1.056e9 / (cfg.segs_per_iter * cfg.D * 8))))
         out["ingest"] = ingest_leg(h, cfg, min(n_iters, n_ing), log)
     if world == 1 and not args.no_full_pipeline:
         # BASELINE.json's second figure (steady-state solve wall-time) and SURVEY §8d's build_analyze_model-equivalent

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define HAMSM_ABI_VERSION 7
+#define HAMSM_ABI_VERSION 8
 
 #define HAMSM_OK 0
 #define HAMSM_EINVAL (-1)   /* bad argument / call order                                         */
@@ -79,6 +79,18 @@ int hamsm_widen_f32(hamsm_ctx *ctx, const float *d_src, double *d_dst, int64_t c
  * of every block (3 GB/s per core -- slower than the copy into the upload slab), now the block is scanned where it lands in HBM.
  * Compute stream.                                                                                                              */
 int hamsm_nan_rows(hamsm_ctx *ctx, const void *d_X, int x_dtype, int64_t ldx, int D, int64_t n, uint8_t *d_flags);
+/* (ABI 8) The host side of staging without the interpreter: n_parts byte ranges moved into the upload slab by `threads` native
+ * threads (parts are cut into pieces of at most 1 MB and dealt out through one counter, so one long part and fifty short ones
+ * load the threads alike).  hamsm_host_copy_parts: part i = bytes[i] bytes from h_src[i] to h_dst[i] (the iterations' arrays of
+ * an in-memory source).  hamsm_host_read_parts: part i = bytes[i] bytes at offset file_off[i] of the open descriptor fd[i]
+ * (pread: the run-level raw arrays of NpyDirectorySource; a short read is an error).  Replaces the reference's per-iteration
+ * h5py reads + per-segment appends + concatenations (`_data.py:254-320, 531-618`); a Python thread pool doing the same copies
+ * is bound by its dispatch (~60 us per job through the interpreter lock: 1.0 GB in 26-50 ms whatever the job size, measured on
+ * the MI355X host).  The calls touch no device and no context state besides the error string; they may run on a thread of
+ * their own while the context's owner enqueues uploads.  threads < 1 means 1; more than 64 are not started.                 */
+int hamsm_host_copy_parts(hamsm_ctx *ctx, int64_t n_parts, const void *const *h_src, void *const *h_dst, const int64_t *bytes, int threads);
+int hamsm_host_read_parts(hamsm_ctx *ctx, int64_t n_parts, const int32_t *fd, const int64_t *file_off, void *const *h_dst,
+                          const int64_t *bytes, int threads);
 int hamsm_sync(hamsm_ctx *ctx);
 
 /* ---- model state (replaces the attributes of StratifiedClusters / modelWE that predict() reads:

@@ -20,7 +20,7 @@ _vp, _i32, _i64, _f64, _sz = C.c_void_p, C.c_int32, C.c_int64, C.c_double, C.c_s
 _int = C.c_int
 
 # name -> (restype, argtypes); kept in the order of include/hamsm.h
-ABI_VERSION = 7  # HAMSM_ABI_VERSION of include/hamsm.h
+ABI_VERSION = 8  # HAMSM_ABI_VERSION of include/hamsm.h
 
 SYMBOLS = {
     "hamsm_abi_version": (_int, []),
@@ -39,6 +39,8 @@ SYMBOLS = {
     "hamsm_copy_sync": (_int, [_vp]),
     "hamsm_widen_f32": (_int, [_vp, _vp, _vp, _i64]),
     "hamsm_nan_rows": (_int, [_vp, _vp, _int, _i64, _int, _i64, _vp]),
+    "hamsm_host_copy_parts": (_int, [_vp, _i64, _vp, _vp, _vp, _int]),
+    "hamsm_host_read_parts": (_int, [_vp, _i64, _vp, _vp, _vp, _vp, _int]),
     "hamsm_sync": (_int, [_vp]),
     "hamsm_set_geometry": (_int, [_vp, _int, _int, _int]),
     "hamsm_set_mapper_rectilinear": (_int, [_vp, _vp, _vp]),
@@ -293,6 +295,24 @@ class Hamsm:
     def widen_f32(self, d_src, d_dst, count):
         """float32 frames resident in HBM -> float64 (exact), on the compute stream"""
         self._ck(self.lib.hamsm_widen_f32(self.ctx, _dp(d_src), _dp(d_dst), int(count)))
+
+    def host_copy_parts(self, src_ptrs, dst_ptrs, nbytes, threads=1):
+        """native threads copy part i (nbytes[i] bytes) from address src_ptrs[i] to dst_ptrs[i]; the interpreter lock is released
+        for the duration.  The caller keeps the arrays behind the addresses alive."""
+        src = np.ascontiguousarray(src_ptrs, dtype=np.uintp)
+        dst = np.ascontiguousarray(dst_ptrs, dtype=np.uintp)
+        nb = np.ascontiguousarray(nbytes, dtype=np.int64)
+        assert len(src) == len(dst) == len(nb)
+        self._ck(self.lib.hamsm_host_copy_parts(self.ctx, len(nb), _hp(src), _hp(dst), _hp(nb), int(threads)))
+
+    def host_read_parts(self, fds, file_offsets, dst_ptrs, nbytes, threads=1):
+        """native threads `pread` part i (nbytes[i] bytes at file_offsets[i] of descriptor fds[i]) to address dst_ptrs[i]"""
+        fd = np.ascontiguousarray(fds, dtype=np.int32)
+        fo = np.ascontiguousarray(file_offsets, dtype=np.int64)
+        dst = np.ascontiguousarray(dst_ptrs, dtype=np.uintp)
+        nb = np.ascontiguousarray(nbytes, dtype=np.int64)
+        assert len(fd) == len(fo) == len(dst) == len(nb)
+        self._ck(self.lib.hamsm_host_read_parts(self.ctx, len(nb), _hp(fd), _hp(fo), _hp(dst), _hp(nb), int(threads)))
 
     def nan_rows(self, d_X, x_dtype, ldx, D, n, d_flags):
         """d_flags[i] (uint8) = row i of d_X holds a NaN; on the compute stream"""

@@ -27,6 +27,7 @@ class InMemorySource:
     """Iterations held in a dict {n_iter: dict(Xp, Xc, p0, p1, w)} (e.g. from msm_we_amd.synthetic)."""
 
     parallel_safe = True   # `load` may be called from several threads at once (staging's reader pool)
+    cheap_load = True      # `load` hands out arrays it holds: not worth a thread
 
     def __init__(self, iters: dict):
         self._iters = iters
@@ -126,6 +127,14 @@ class NpyDirectorySource:
     def dtype_shape(self, key):
         arr = self._arrays()[key]
         return arr.dtype, arr.shape[1:]
+
+    def file_range(self, key, row0, row1):
+        """(path, byte offset, byte count) of rows [row0, row1) of array `key`: what `hamsm_host_read_parts` reads"""
+        import os
+
+        arr = self._arrays()[key]
+        row_bytes = arr.dtype.itemsize * int(np.prod(arr.shape[1:], dtype=np.int64))
+        return os.path.join(self.dir, key + ".npy"), int(arr.offset + row0 * row_bytes), int((row1 - row0) * row_bytes)
 
     def read_rows(self, key, row0, row1, out):
         """rows [row0, row1) of array `key` into `out` (C-contiguous, same dtype and row shape): ``preadv`` from the file"""
@@ -302,11 +311,12 @@ class DeviceStore:
         self.w_flux = w
         self.nan_parent = self.nan_child = None
 
-    def mark_nan_segments(self, nan_parent, nan_child, w_host):
+    def mark_nan_segments(self, nan_parent, nan_child, w_host=None):
+        """`w_host`: the weights on the host if the caller holds them; read back from HBM otherwise (only when a NaN row exists)"""
         if not (nan_parent.any() or nan_child.any()):
             return
         self.nan_parent, self.nan_child = nan_parent, nan_child
-        wz = np.array(w_host, dtype=np.float64, copy=True)
+        wz = np.array(self.w.to_host() if w_host is None else w_host, dtype=np.float64, copy=True).reshape(-1)
         wz[nan_parent | nan_child] = 0.0
         self.w_flux = self.h.to_device(wz)
 
@@ -474,7 +484,9 @@ class DataMixin:
         return np.asarray(W, dtype=np.float64), (None if c.mean_ is None else np.asarray(c.mean_, dtype=np.float64)), scale
 
     # -- staging: one pass over the iterations, host work overlapped with the uploads --------------
-    STAGE_CHUNK_BYTES = 64 << 20  # host bytes per upload block
+    STAGE_CHUNK_BYTES = 32 << 20  # host bytes per upload block (page-locking + releasing the two slabs costs ~0.3 ms per MB: DESIGN.md 5.5)
+    STAGE_PIECE_BYTES = 2 << 20   # least bytes per reader job
+    STAGE_JOBS_PER_READER = 1     # a block is cut into at most readers x this many jobs
 
     def _iteration_host(self, it, mode):
         """host side of one iteration: (Xp, Xc, p0, p1, w) ready for the upload slab"""
@@ -523,22 +535,15 @@ class DataMixin:
         `preloaded`: {iteration: its host block} for blocks that are in memory already.
         -> (rows, nan_parent, nan_child, fits): `fits` is False when a value does not survive the slab's dtype"""
 
-        def one(it, o, n_expected):
-            blk = preloaded[it] if preloaded and it in preloaded else self._iteration_host(it, mode)
-            n = len(blk[4])
-            if n_expected is not None and n != n_expected:
-                raise ValueError(f"iteration {it} holds {n} segments, {n_expected} were announced")
-            fits = True
-            for side in range(2):
-                x = blk[side]
-                dst = slab["X"][side][o: o + n]
-                dst[...] = x                                  # (casts when the dtypes differ)
-                # (NaN-coordinate segments are found on the device, where the block lands: `hamsm_nan_rows` -- a host scan runs
-                # at 3 GB/s per core, slower than this copy)
-                if x.dtype != up_dtype and up_dtype == np.float32 and fits:
-                    fits = bool(np.array_equal(dst.astype(x.dtype), x, equal_nan=True))
-            slab["p0"][o: o + n], slab["p1"][o: o + n], slab["w"][o: o + n] = blk[2], blk[3], blk[4]
-            return n, None, None, fits
+        PIECE = int(self.STAGE_PIECE_BYTES)   # bytes per copy job: small enough to spread a block over the readers, large enough to hide the dispatch
+        nt = max(1, getattr(pool, "_max_workers", 1) if pool is not None else 1)
+        run = (lambda f, jobs: list(pool.map(f, jobs))) if pool is not None else (lambda f, jobs: [f(j) for j in jobs])
+        row_bytes = 2 * slab["X"][0].shape[1] * slab["X"][0].dtype.itemsize + 16 * slab["p0"].shape[1] + 8
+
+        def cuts_of(n):
+            k = int(max(1, min(nt * int(self.STAGE_JOBS_PER_READER), (n * row_bytes) // PIECE)))
+            c = np.linspace(0, n, k + 1).astype(np.int64)
+            return [(int(c[t]), int(c[t + 1])) for t in range(k) if c[t + 1] > c[t]]
 
         sizes = getattr(self, "_stage_sizes", None)
         src = self._source
@@ -552,33 +557,86 @@ class DataMixin:
             n = r1 - r0
             if sizes is not None and n != sum(sizes[it] for it in its):
                 raise ValueError(f"iterations {its[0]}..{its[-1]} hold {n} segments, another number was announced")
-            nt = max(1, getattr(pool, "_max_workers", 1) if pool is not None else 1)
-            cuts = np.linspace(0, n, nt + 1).astype(np.int64)
-            jobs = [(key, dst, int(cuts[t]), int(cuts[t + 1])) for t in range(nt) for key, dst in
-                    (("Xp", slab["X"][0]), ("Xc", slab["X"][1]), ("p0", slab["p0"]), ("p1", slab["p1"]), ("w", slab["w"]))
-                    if cuts[t + 1] > cuts[t]]
+            dsts = (("Xp", slab["X"][0]), ("Xc", slab["X"][1]), ("p0", slab["p0"]), ("p1", slab["p1"]), ("w", slab["w"]))
 
-            def rd(job):
-                key, dst, a, b = job
-                src.read_rows(key, r0 + a, r0 + b, dst[a:b])
+            def rd(ab):
+                for key, dst in dsts:
+                    src.read_rows(key, r0 + ab[0], r0 + ab[1], dst[ab[0]: ab[1]])
 
-            if pool is not None:
-                list(pool.map(rd, jobs))
+            if hasattr(src, "file_range") and n > 0:
+                # the library's own threads pread the five ranges (no interpreter lock, pieces of 1 MB dealt out by a counter)
+                import os
+
+                fds = []
+                try:
+                    offs_, nb_ = [], []
+                    for key, dst in dsts:
+                        path, fo, nb = src.file_range(key, r0, r1)
+                        assert nb == dst[:n].nbytes and dst.flags.c_contiguous
+                        fds.append(os.open(path, os.O_RDONLY))
+                        offs_.append(fo)
+                        nb_.append(nb)
+                    self.h.host_read_parts(fds, offs_, [d_.__array_interface__["data"][0] for _, d_ in dsts], nb_, threads=nt)
+                finally:
+                    for fd in fds:
+                        os.close(fd)
             else:
-                for j in jobs:
-                    rd(j)
+                run(rd, cuts_of(n))
             self.__dict__["_stage_direct_blocks"] = self.__dict__.get("_stage_direct_blocks", 0) + 1
             return n, None, None, True
-        if pool is not None and sizes is not None and len(its) > 1:
-            offs = np.concatenate([[0], np.cumsum([sizes[it] for it in its])]).astype(np.int64)
-            res = list(pool.map(lambda a: one(a[0], int(a[1]), int(a[2])), zip(its, offs[:-1], np.diff(offs))))
-        else:
-            res, o = [], 0
-            for it in its:
-                r = one(it, o, None)
-                res.append(r)
-                o += r[0]
-        return sum(r[0] for r in res), None, None, all(r[3] for r in res)
+
+        # 1. the iterations' host blocks (a file read, the featurizer: parallel by iteration; a source that only hands out arrays
+        # it holds is asked in this thread -- a pool dispatch costs ~60 us, more than the lookup); 2. the block's rows into the
+        # slab in pieces of >= PIECE bytes whatever the iterations' sizes (a block of one 27 MB iteration still uses every reader,
+        # a block of fifty small ones is not fifty dispatches)
+        load = lambda it: preloaded[it] if preloaded and it in preloaded else self._iteration_host(it, mode)  # noqa: E731
+        cheap = getattr(src, "cheap_load", False) and (mode == "device_featurizer" or self._features_are_stored())
+        blks = [load(it) for it in its] if cheap else run(load, list(its))
+        starts = np.concatenate([[0], np.cumsum([len(b_[4]) for b_ in blks])]).astype(np.int64)
+        if sizes is not None and len(its) > 1:
+            for it, b_ in zip(its, blks):
+                if len(b_[4]) != sizes[it]:
+                    raise ValueError(f"iteration {it} holds {len(b_[4])} segments, {sizes[it]} were announced")
+        n_all = int(starts[-1])
+
+        def put(ab):
+            fits = True
+            for q in range(int(np.searchsorted(starts, ab[0], side="right")) - 1, len(blks)):
+                o_ = int(starts[q])
+                a, b = max(ab[0], o_) - o_, min(ab[1], int(starts[q + 1])) - o_
+                if b <= a:
+                    if o_ >= ab[1]:
+                        break
+                    continue
+                blk = blks[q]
+                for side in range(2):
+                    x = blk[side][a:b]
+                    dst = slab["X"][side][o_ + a: o_ + b]
+                    dst[...] = x                                  # (casts when the dtypes differ)
+                    # (NaN-coordinate segments are found on the device, where the block lands: `hamsm_nan_rows` -- a host scan
+                    # runs at 3 GB/s per core, slower than this copy)
+                    if x.dtype != up_dtype and up_dtype == np.float32 and fits:
+                        fits = bool(np.array_equal(dst.astype(x.dtype), x, equal_nan=True))
+                slab["p0"][o_ + a: o_ + b], slab["p1"][o_ + a: o_ + b], slab["w"][o_ + a: o_ + b] = blk[2][a:b], blk[3][a:b], blk[4][a:b]
+            return fits
+
+        want = (np.dtype(up_dtype), np.dtype(up_dtype), np.dtype(np.float64), np.dtype(np.float64), np.dtype(np.float64))
+        if all(isinstance(a_, np.ndarray) and a_.dtype == dt_ and a_.flags.c_contiguous for b_ in blks for a_, dt_ in zip(b_, want)):
+            # same bytes on both sides: the library's threads memcpy them (no cast, so nothing to check: `fits` holds)
+            dsts = (slab["X"][0], slab["X"][1], slab["p0"], slab["p1"], slab["w"])
+            sp, dp, nb = [], [], []
+            for q, b_ in enumerate(blks):
+                o_ = int(starts[q])
+                for a_, d_ in zip(b_, dsts):
+                    if a_.nbytes:
+                        assert a_.shape[1:] == d_.shape[1:]
+                        sp.append(a_.__array_interface__["data"][0])
+                        dp.append(d_.__array_interface__["data"][0] + o_ * (d_.nbytes // max(1, len(d_))))
+                        nb.append(a_.nbytes)
+            if nb:
+                self.h.host_copy_parts(sp, dp, nb, threads=nt)
+            return n_all, None, None, True
+        return n_all, None, None, all(run(put, cuts_of(n_all)))
 
     def stage_iterations(self):
         """Featurize and upload iterations 1..maxIter once.  Idempotent.  ONE pass over the source: a reader thread loads and
@@ -597,7 +655,7 @@ class DataMixin:
 
         h = self.h
         t_start = time.perf_counter()
-        phase = {"first_iteration": 0.0, "alloc": 0.0, "wait_fill": 0.0, "wait_copy": 0.0}   # where the host thread stood still
+        phase = {"first_iteration": 0.0, "alloc": 0.0, "wait_fill": 0.0, "wait_copy": 0.0, "release": 0.0, "finish": 0.0}   # where the host thread stood still
 
         def lap(key, t0):
             phase[key] += time.perf_counter() - t0
@@ -656,7 +714,6 @@ class DataMixin:
                     for side_ in range(2):
                         h.nan_rows(Xd[side_].offset(f0_ * D), dt_, D, D, n_, d_nan.offset(side_ * max(N, 1) + f0_))
 
-            w_all = np.empty(N)
             widened = False
             done = False
             n_readers = self._stage_readers()
@@ -722,7 +779,6 @@ class DataMixin:
                         if n == 0:
                             continue
                         sl = slabs[k & 1]
-                        w_all[f0: f0 + n] = sl["w"][:n]
                         for side in range(2):
                             dst = Xd[side].offset(f0 * D) if mode == "host" else raw[side]
                             h.h2d_async(dst, sl["X"][side], n * raw_w * np.dtype(up_dtype).itemsize)
@@ -747,6 +803,7 @@ class DataMixin:
                     h.sync()
                     done = True
             finally:
+                t0_ = time.perf_counter()
                 if readers is not None:
                     readers.shutdown(wait=True)
                 self._stage_sizes = None
@@ -754,15 +811,18 @@ class DataMixin:
                 for bufs in (raw, mid):
                     for b_ in bufs or ():
                         b_.free()
+                lap("release", t0_)
                 if not done:
                     for b_ in (*Xd, *d_rest):
                         b_.free()
+        t0_ = time.perf_counter()
         x_dt = (_abi.F32 if up_dtype == np.float32 else _abi.F64) if mode == "host" else _abi.F64
         store = DeviceStore(h, D, ndim, x_dt, offsets, Xd[0], Xd[1], d_p0, d_p1, d_w)
         nan = d_nan.to_host().astype(bool)[:, :N]
         d_nan.free()
-        store.mark_nan_segments(nan[0], nan[1], w_all)
+        store.mark_nan_segments(nan[0], nan[1])
         self._store = store
+        lap("finish", t0_)
         nbytes = N * (2 * raw_w * (4 if store.x_dtype == _abi.F32 and mode == "host" else first[0].dtype.itemsize) + 16 * ndim + 8)
         self.ingest_stats = {"seconds": time.perf_counter() - t_start, "bytes": int(nbytes), "blocks": len(chunks), "mode": mode,
                              "widened_mid_pass": widened, "readers": n_readers, "direct_read_blocks": self.__dict__.get("_stage_direct_blocks", 0), "host_waits_s": {k: round(v, 5) for k, v in phase.items()}}

@@ -25,6 +25,8 @@
 #include <stdlib.h>
 #include <string.h>
 #include <sys/mman.h>
+#include <unistd.h>
+#include <errno.h>
 
 #define MAX_NDIM 8
 #define POT_LANES 1024 /* strided partial sums for potentials */
@@ -232,6 +234,40 @@ int hamsm_widen_f32(hamsm_ctx *c, const float *src, double *dst, int64_t count) 
   if (count > 0 && (const char *)src < (const char *)dst + 8 * count && (const char *)dst < (const char *)src + 4 * count)
     return fail(c, HAMSM_EINVAL, "widen_f32: source and destination overlap");
   for (int64_t i = 0; i < count; i++) dst[i] = (double)src[i];
+  return HAMSM_OK;
+}
+/* (ABI 8) staging's host-side movers, restated without threads: the bytes are what matters, `threads` is advice */
+int hamsm_host_copy_parts(hamsm_ctx *c, int64_t n_parts, const void *const *h_src, void *const *h_dst, const int64_t *bytes, int threads) {
+  CTX(c);
+  (void)threads;
+  if (n_parts < 0 || (n_parts > 0 && (!h_src || !h_dst || !bytes))) return fail(c, HAMSM_EINVAL, "host_copy_parts: null table");
+  for (int64_t i = 0; i < n_parts; i++) {
+    if (bytes[i] < 0) return fail(c, HAMSM_EINVAL, "host_copy_parts: part %lld has a negative size", (long long)i);
+    if (bytes[i] > 0 && (!h_src[i] || !h_dst[i])) return fail(c, HAMSM_EINVAL, "host_copy_parts: part %lld has a null pointer", (long long)i);
+  }
+  for (int64_t i = 0; i < n_parts; i++) memcpy(h_dst[i], h_src[i], (size_t)bytes[i]);
+  return HAMSM_OK;
+}
+int hamsm_host_read_parts(hamsm_ctx *c, int64_t n_parts, const int32_t *fd, const int64_t *file_off, void *const *h_dst,
+                          const int64_t *bytes, int threads) {
+  CTX(c);
+  (void)threads;
+  if (n_parts < 0 || (n_parts > 0 && (!fd || !file_off || !h_dst || !bytes))) return fail(c, HAMSM_EINVAL, "host_read_parts: null table");
+  for (int64_t i = 0; i < n_parts; i++) {
+    if (bytes[i] < 0) return fail(c, HAMSM_EINVAL, "host_read_parts: part %lld has a negative size", (long long)i);
+    if (bytes[i] > 0 && (!h_dst[i] || fd[i] < 0 || file_off[i] < 0))
+      return fail(c, HAMSM_EINVAL, "host_read_parts: part %lld has a null pointer, a closed descriptor or a negative offset", (long long)i);
+  }
+  for (int64_t i = 0; i < n_parts; i++) {
+    int64_t done = 0;
+    while (done < bytes[i]) {
+      ssize_t r = pread(fd[i], (char *)h_dst[i] + done, (size_t)(bytes[i] - done), (off_t)(file_off[i] + done));
+      if (r < 0 && errno == EINTR) continue;
+      if (r < 0) return fail(c, HAMSM_EINVAL, "host_read_parts: part %lld of %lld: %s", (long long)i, (long long)n_parts, strerror(errno));
+      if (r == 0) return fail(c, HAMSM_EINVAL, "host_read_parts: part %lld of %lld: short read (the file ends inside the range)", (long long)i, (long long)n_parts);
+      done += r;
+    }
+  }
   return HAMSM_OK;
 }
 int hamsm_nan_rows(hamsm_ctx *c, const void *X, int dt, int64_t ldx, int D, int64_t n, uint8_t *flags) {

@@ -33,4 +33,5 @@ def test_bench_line_has_the_contract_keys():
     assert {"training steps", "assign (2 launches)", "k-means++ seeding", "flux matrix"} <= stages
     assert out["config"]["flux_mode"] == "deterministic" and set(out["flux_ms"]) == {"atomic", "deterministic"}
     assert out["config"]["exchange"].startswith("none") and "traffic_source" in out["roofline_assign"] and out["labels_to_host_ms"] >= 0
-    assert set(out["ingest"]) == {"npz_files", "in_memory"} and out["ingest"]["npz_files"]["GBps"] > 0
+    assert set(out["ingest"]) == {"npz_files", "raw_files", "in_memory"} and out["ingest"]["npz_files"]["GBps"] > 0
+    assert out["ingest"]["raw_files"]["direct_read_blocks"] == out["ingest"]["raw_files"]["blocks"]   # file -> slab by the library

@@ -1,6 +1,7 @@
 """a15 / f2: the ingest side of the path -- the WESTPA HDF5 reader (against a stand-in `h5py`: the real one is not in the
 image), the per-iteration .npz fallback, and the streaming double-buffered staging (several blocks, float32 fallback to
 float64, NaN bookkeeping) -- all must give the model the in-memory source gives."""
+import os
 import sys
 import types
 
@@ -8,6 +9,7 @@ import numpy as np
 import pytest
 
 from conftest import build_model, golden_iterations, load_golden
+from msm_we_amd import _abi
 from msm_we_amd.data import InMemorySource, NpyDirectorySource, NpzDirectorySource
 
 
@@ -386,6 +388,51 @@ def test_widen_f32_oracle(oracle_h):
 @pytest.mark.gpu
 def test_widen_f32_hip(hip_h):
     _widen_case(hip_h)
+
+
+def _host_movers_case(h, tmp_path):
+    """`hamsm_host_copy_parts` / `hamsm_host_read_parts` (ABI 8): staging's host side in the library's own threads.  Parts of
+    every size class (empty, a few bytes, several 1 MB pieces with a ragged tail) must arrive byte for byte, with any thread
+    count; a range that runs past the end of its file and a negative size are errors, not short copies."""
+    rng = np.random.default_rng(8)
+    sizes = [0, 7, 1 << 20, (1 << 20) + 1, 3_500_001, 64]
+    srcs = [rng.integers(0, 256, n, dtype=np.uint8) for n in sizes]
+    for threads in (0, 1, 5, 200):
+        dsts = [np.zeros(n + 16, dtype=np.uint8) for n in sizes]
+        h.host_copy_parts([a.ctypes.data for a in srcs], [d.ctypes.data + 8 for d in dsts], sizes, threads=threads)
+        for a, d in zip(srcs, dsts):
+            assert np.array_equal(d[8: 8 + len(a)], a) and not d[:8].any() and not d[8 + len(a):].any()
+    path = tmp_path / "blob.bin"
+    blob = rng.integers(0, 256, 5_000_000, dtype=np.uint8)
+    blob.tofile(path)
+    fd = os.open(path, os.O_RDONLY)
+    try:
+        offs, lens = [0, 11, 2_000_000, 4_999_990], [5, 1_500_000, 2_345_678, 10]
+        for threads in (1, 6):
+            outs = [np.zeros(n, dtype=np.uint8) for n in lens]
+            h.host_read_parts([fd] * 4, offs, [o.ctypes.data for o in outs], lens, threads=threads)
+            for o, a, n in zip(outs, offs, lens):
+                assert np.array_equal(o, blob[a: a + n])
+        out = np.zeros(100, dtype=np.uint8)
+        with pytest.raises(_abi.HamsmError, match="short read"):
+            h.host_read_parts([fd], [4_999_950], [out.ctypes.data], [100], threads=2)
+        with pytest.raises(_abi.HamsmError, match="negative"):
+            h.host_read_parts([fd], [0], [out.ctypes.data], [-1], threads=2)
+    finally:
+        os.close(fd)
+    with pytest.raises(_abi.HamsmError, match="negative"):
+        h.host_copy_parts([srcs[1].ctypes.data], [out.ctypes.data], [-3])
+    with pytest.raises(_abi.HamsmError, match="null"):
+        h.host_copy_parts([0], [out.ctypes.data], [4])
+
+
+def test_host_movers_oracle(oracle_h, tmp_path):
+    _host_movers_case(oracle_h, tmp_path)
+
+
+@pytest.mark.gpu
+def test_host_movers_hip(hip_h, tmp_path):
+    _host_movers_case(hip_h, tmp_path)
 
 
 def test_reader_pool_stages_the_same_arrays(oracle_h, tmp_path, monkeypatch):
