@@ -12,6 +12,7 @@ import logging
 import numbers
 import os
 import sys
+import time
 from copy import deepcopy
 
 import numpy as np
@@ -488,23 +489,24 @@ class ClusteringMixin:
             models[int(bb[0])].__dict__["_device_newer"] = True
         predict = {b: False for b in chain}
         total_calls = int(max((len(c["g"]) for c in chain.values()), default=0))
-        span = G  # calls per fused run; halved after a stop, doubled after a clean run
+        span = G  # calls per fused run; 64 after a stop, doubled after a clean run
+        t_prev = time.perf_counter()
         g_lo = 0
         n_runs = 0
         while any(c["pos"] < len(c["g"]) for c in chain.values()):
             live = [b for b, c in chain.items() if c["pos"] < len(c["g"])]
-            g_lo = min(int(chain[b]["g"][chain[b]["pos"]]) for b in live)
-            g_hi = g_lo + span
-            sel = {}
-            for b in live:
-                c = chain[b]
-                n_take = int(np.searchsorted(c["g"], g_hi, side="left")) - c["pos"]
-                if n_take > 0:
-                    sel[b] = (c["pos"], c["pos"] + n_take)
+            # every live stratum contributes its NEXT `span` steps, whatever their call numbers, and the run interleaves them
+            # position by position: a launch group of the device (a maximal run of distinct strata) then always carries every
+            # live stratum.  Strata are independent chains (own model, own RandomState; shared ones run stepwise), so the
+            # order between strata is free -- cutting runs by call RANGE instead made a stratum that had stopped early catch
+            # up alone, a quarter of the chip at a time (C5: 2.5 launches per call and queue instead of 1).
+            sel = {b: (chain[b]["pos"], min(chain[b]["pos"] + span, len(chain[b]["g"]))) for b in live}
             gcat = np.concatenate([chain[b]["g"][a:e] for b, (a, e) in sel.items()])
+            g_lo, g_hi = int(gcat.min()), int(gcat.max()) + 1
             bcat = np.concatenate([np.full(e - a, b) for b, (a, e) in sel.items()])
+            kcat = np.concatenate([np.arange(e - a) for b, (a, e) in sel.items()])
             scat = np.concatenate([chain[b]["st"][a:e] for b, (a, e) in sel.items()])
-            order = np.lexsort((bcat, gcat))  # call order, bins ascending inside a call (:890)
+            order = np.lexsort((bcat, kcat))  # each stratum's steps in its own call order (:890), strata side by side
             steps = scat[order].copy()
             steps["perm_off"], steps["n_perm"] = -1, 0
             # speculative draws, per model in step order (models own their RandomState here; shared ones never predict)
@@ -521,13 +523,18 @@ class ClusteringMixin:
                 steps["perm_off"][i], steps["n_perm"][i] = off, len(head)
                 perms.append(head)
                 off += len(head)
+            t_run = time.perf_counter()
             report, resume, reason = h.minibatch_run(store.Xc, store.x_dtype, store.D, d_rows, d_w, steps, ratio,
                                                      np.concatenate(perms) if perms else None)
             n_runs += 1
             if os.environ.get("HAMSM_DEBUG_REPORT"):
-                print(f"[plan] run {n_runs}: calls {g_lo}..{g_hi}, {len(steps)} steps, {int((steps['flags'] & 1).sum())} tests "
-                      f"({len(perms)} with a permutation), stops {dict((b, int(reason[b])) for b in sel if reason[b])}", flush=True,
-                      file=sys.stderr)
+                t_now = time.perf_counter()
+                applied = {b: int(np.searchsorted(np.nonzero(steps["stratum"] == b)[0], resume[b], side="left")) for b in sel}
+                print(f"[plan] run {n_runs}: calls {g_lo}..{g_hi}, {len(steps)} steps ({sum(applied.values())} applied), "
+                      f"{int((steps['flags'] & 1).sum())} tests ({len(perms)} with a permutation), stops "
+                      f"{dict((b, int(reason[b])) for b in sel if reason[b])}; host {1e3 * (t_run - t_prev):.2f} ms before, "
+                      f"run {1e3 * (t_now - t_run):.2f} ms", flush=True, file=sys.stderr)
+                t_prev = t_now
             stopped = False
             for b, (a, e) in sel.items():
                 m = models[b]
@@ -558,7 +565,9 @@ class ClusteringMixin:
                                      d_rows.offset(int(st_l["rows_off"])), int(st_l["n_b"]))
                     m._counts_cache = None
                     predict[b] = True
-            span = max(span // 2, 16) if stopped else min(span * 2, G)
+            # after a stop the next run is short: a stratum that has just been re-seeded carries a speculative permutation on
+            # every test (0.1 ms each at 12 500-row batches) and is the likeliest to stop again at its first one
+            span = min(64, G) if stopped else min(span * 2, G)
             if n_runs > 64 + total_calls // 8:
                 log.info("training plan keeps mispredicting: rerunning stepwise")
                 return undo()

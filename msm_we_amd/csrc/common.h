@@ -76,6 +76,12 @@ struct hamsm_ctx {
   // between `stream` and these side queues so that the chains overlap (fork/join with events inside run_steps)
   hipStream_t side_stream[3] = {nullptr, nullptr, nullptr};
   hipEvent_t ev_fork = nullptr, ev_join[3] = {nullptr, nullptr, nullptr};
+  // bounded run-ahead of the training enqueue (run_steps, MFMA-bound calls): a ring of events per queue, a queue of its own and a
+  // page-locked buffer for reading the chains' stop words while the pass runs
+  hipEvent_t ev_ring[4][4] = {};
+  hipStream_t poll_stream = nullptr;
+  int32_t *h_poll = nullptr;
+  size_t h_poll_n = 0;
   int step_lanes = 2;  // queues used by the training steps (HAMSM_STEP_LANES = 1..4)
 #ifdef HAMSM_EXPERIMENTS
   // ---- csrc/experiments/ (libhamsm_hip_exp.so only; every one of these measured slower than the shipped path and ships OFF) ----
@@ -163,6 +169,7 @@ struct hamsm_ctx {
   double ks_dev_sum_ms = 0.0;               // ... summed kernel-only durations (100 MHz clock)
   double ks_sum_ms[2] = {0, 0};
   long long ks_n[2] = {0, 0};
+  long long ks_dev_n = 0;                   // ... and how many of them carried both stamps
   long long ks_tick = 0;
   size_t seed_g_budget = (size_t)4 << 30;  // bytes of Gram matrices resident at once (HAMSM_SEED_G_MB): 56 strata of 3072 rows
   unsigned long long *h_und = nullptr;  // pinned [S]: undecided counts of the last filtered assign

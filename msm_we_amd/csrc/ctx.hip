@@ -174,6 +174,16 @@ extern "C" void hamsm_destroy(hamsm_ctx *c) {
     if (c->ev_join[i]) hipEventDestroy(c->ev_join[i]);
   }
   if (c->ev_fork) hipEventDestroy(c->ev_fork);
+  for (int l = 0; l < 4; l++)
+    for (int k = 0; k < 4; k++) {
+      if (c->ev_ring[l][k]) hipEventDestroy(c->ev_ring[l][k]);
+      c->ev_ring[l][k] = nullptr;
+    }
+  if (c->poll_stream) hipStreamDestroy(c->poll_stream);
+  c->poll_stream = nullptr;
+  if (c->h_poll) hipHostFree(c->h_poll);
+  c->h_poll = nullptr;
+  c->h_poll_n = 0;
   hipStreamDestroy(c->stream);
   // the struct stays (see the registry note): drop what it owns on the heap, null every pointer, mark it dead
   release(c->blk_live);
@@ -480,7 +490,10 @@ extern "C" int hamsm_step_kernel_ms(hamsm_ctx *c, int which, double *ms, int64_t
     std::vector<unsigned long long> st(2 * c->ks_pending.size());
     HIPCHK(c, hipMemcpy(st.data(), c->ks_stamps, sizeof(unsigned long long) * st.size(), hipMemcpyDeviceToHost));
     for (size_t i = 0; i < c->ks_pending.size(); i++)
-      if (st[2 * i + 1] > st[2 * i]) c->ks_dev_sum_ms += (double)(st[2 * i + 1] - st[2 * i]) * 1e-5;  // 10 ns ticks
+      if (st[2 * i + 1] > st[2 * i]) {  // (a launch that only drained a stopped chain leaves no stamps: not an E-step, not counted)
+        c->ks_dev_sum_ms += (double)(st[2 * i + 1] - st[2 * i]) * 1e-5;  // 10 ns ticks
+        c->ks_dev_n++;
+      }
   }
   for (auto &k : c->ks_pending) {
     float a = 0.f, b = 0.f;
@@ -503,10 +516,10 @@ extern "C" int hamsm_step_kernel_ms(hamsm_ctx *c, int which, double *ms, int64_t
     HIPCHK(c, hipMemcpy(c->ks_stamps, init.data(), sizeof(unsigned long long) * init.size(), hipMemcpyHostToDevice));
   }
   // which = 2: the E-step's duration by the device clock (first wave in -> last wave out), without the launch boundary
-  if (which == 2) *ms = c->ks_n[0] ? c->ks_dev_sum_ms / (double)c->ks_n[0] : 0.0;
+  if (which == 2) *ms = c->ks_dev_n ? c->ks_dev_sum_ms / (double)c->ks_dev_n : 0.0;
   else *ms = c->ks_n[which] ? c->ks_sum_ms[which] / (double)c->ks_n[which] : 0.0;
-  if (samples) *samples = c->ks_n[which == 2 ? 0 : which];
-  if (reset) c->ks_sum_ms[0] = c->ks_sum_ms[1] = c->ks_dev_sum_ms = 0.0, c->ks_n[0] = c->ks_n[1] = 0;
+  if (samples) *samples = which == 2 ? c->ks_dev_n : c->ks_n[which];
+  if (reset) c->ks_sum_ms[0] = c->ks_sum_ms[1] = c->ks_dev_sum_ms = 0.0, c->ks_n[0] = c->ks_n[1] = c->ks_dev_n = 0;
   return HAMSM_OK;
 }
 

@@ -1589,14 +1589,19 @@ __device__ __forceinline__ void rank_merge3(float &A1, float &A2, float &A3, int
 template <typename XT, int KB>
 __global__ __launch_bounds__(RANK_NW * 64, 2) void k_step_assign_ranked(const StepPack pk, const RankPack rk, int64_t ldx, int D, int KS,
                                                                         double ratio, float c1, float c2, unsigned long long *stamp) {
-  if (stamp && threadIdx.x == 0) atomicMin(&stamp[0], (unsigned long long)wall_clock64());
-  RPROF_INIT
   constexpr int NW = RANK_NW, NT = NW * 64;
   constexpr int RW = 128;  // rows per workgroup: four tiles of 32
   const StepDev sdesc = pk.s[blockIdx.y];
   const StepG st(sdesc);
   const long long r0 = (long long)blockIdx.x * RW;
   if (r0 >= st.n_b) return;
+  // A stratum whose chain has stopped (an earlier launch set its stop word: visible here by stream order) only drains: this step
+  // will not be applied, nobody reads its labels.  At this kernel's size that matters -- the fused first steps stop nearly every
+  // stratum of a C5-shaped pass at once, and a 1000-call run then drained at the full 45 us per launch (the f64 kernel of the
+  // small shapes keeps working through: 10 us launches, rare stops, and the extra dependent load would sit on its critical path).
+  if (st.idx >= *gp(sdesc.halt)) return;
+  if (stamp && threadIdx.x == 0) atomicMin(&stamp[0], (unsigned long long)wall_clock64());
+  RPROF_INIT
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, row = lane & 31, h = lane >> 5;
   const GAS XT *X = (const GAS XT *)st.X;
   const GAS v4u32 *apk = (const GAS v4u32 *)gp(rk.apk[blockIdx.y]);
@@ -3086,9 +3091,50 @@ static int run_steps(hamsm_ctx *c, const void *X, int dt, int64_t ldx, const int
   memset(&pk, 0, sizeof(pk));
   timespec ts0, ts1;
   if (dbg_enq) clock_gettime(CLOCK_MONOTONIC, &ts0);
+  // Bounded run-ahead (MFMA-bound calls only).  The host enqueues a launch group in ~7 us; where the device needs ~60 us for it
+  // the whole pass is in the queues long before its first steps have run, and a chain that stops -- at C5's shape the fused first
+  // steps stop every stratum, every pass -- left thousands of launches to drain (16 ms per 1000-call run even as near-empty
+  // kernels).  So the enqueue waits, every RA_W groups, until the device is at most 2 RA_W groups behind (events per queue: no
+  // bubble, >= RA_W groups are still queued), reads the stop words through a queue of its own, drops stopped strata from the
+  // launches that follow and ends the run when no live stratum is left.  Latency-bound calls (C3: 17 us of device work per
+  // group, the host barely ahead, stops rare) enqueue as before.
+  const bool bounded = ranked && h_report && h_resume && gstart.size() > 2 * 16 + 1;
+  constexpr size_t RA_W = 16;
+  std::vector<char> halted(c->S, 0);
+  std::vector<int64_t> last_group(c->S, -1);
+  if (bounded) {
+    for (size_t g = 0; g + 1 < gstart.size(); g++)
+      for (int64_t q = gstart[g]; q < gstart[g + 1]; q++) last_group[h_steps[q].stratum] = (int64_t)g;
+    if (!c->poll_stream) HIPCHK(c, hipStreamCreateWithFlags(&c->poll_stream, hipStreamNonBlocking));
+    if (c->h_poll_n < (size_t)c->S) {
+      if (c->h_poll) hipHostFree(c->h_poll);
+      c->h_poll = nullptr;
+      c->h_poll_n = 0;
+      HIPCHK(c, hipHostMalloc((void **)&c->h_poll, sizeof(int32_t) * (size_t)c->S));
+      c->h_poll_n = (size_t)c->S;
+    }
+    for (int l = 0; l < n_lanes; l++)
+      for (int k = 0; k < 4; k++)
+        if (!c->ev_ring[l][k]) HIPCHK(c, hipEventCreateWithFlags(&c->ev_ring[l][k], hipEventDisableTiming));
+  }
   std::vector<int64_t> mine;
   for (size_t g = 0; g + 1 < gstart.size(); g++) {
     const int64_t i = gstart[g], j = gstart[g + 1];
+    if (bounded && g > 0 && g % RA_W == 0) {
+      const size_t k = g / RA_W;  // windows 0 .. k - 1 are enqueued
+      for (int l = 0; l < n_lanes; l++) HIPCHK(c, hipEventRecord(c->ev_ring[l][(k - 1) & 3], lanes[l]));
+      if (k >= 2) {
+        for (int l = 0; l < n_lanes; l++) HIPCHK(c, hipEventSynchronize(c->ev_ring[l][(k - 2) & 3]));
+        HIPCHK(c, hipMemcpyAsync(c->h_poll, b + o_halt, sizeof(int32_t) * (size_t)c->S, hipMemcpyDeviceToHost, c->poll_stream));
+        HIPCHK(c, hipStreamSynchronize(c->poll_stream));
+        bool any_live = false;
+        for (int s = 0; s < c->S; s++) {
+          halted[s] = c->h_poll[s] < (int32_t)(n_steps < 0x7f000000 ? n_steps : 0x7f000000);
+          any_live = any_live || (!halted[s] && last_group[s] >= (int64_t)g);
+        }
+        if (!any_live) break;  // every chain with steps left has stopped: the host settles them, the next run resumes
+      }
+    }
     for (int l = 0; l < n_lanes; l++) {
       long long max_nb = 0;
       int maxK = 0;
@@ -3096,6 +3142,7 @@ static int run_steps(hamsm_ctx *c, const void *X, int dt, int64_t ldx, const int
       mine.clear();
       for (int64_t q = i; q < j; q++) {
         if (lane_of(q) != l) continue;
+        if (halted[h_steps[q].stratum]) continue;  // (its steps from here on would only drain)
         mine.push_back(q);
         any_perm = any_perm || sd[q].perm;
         if (h_steps[q].n_b > max_nb) max_nb = h_steps[q].n_b;
