@@ -230,9 +230,20 @@ class AnalysisMixin:
     def get_steady_state(self, flux_fractional_convergence=1e-4, max_iters=10):
         """`_analysis.py:97-191`"""
         T = self._T_csr()
-        last_pSS = self.get_steady_state_algebraic(max_iters=10, check_negative=False, set=False)
-        last_flux = self.get_steady_state_target_flux(pSS=last_pSS, _set=False)
+        n = T.shape[0]
         solver = _ShiftedSolver(T, 1)   # the loop's matrix never changes: factorised once, not once per step
+        # The seed.  The reference takes it from a dense `eig` (`get_steady_state_algebraic`); above `dense_eig_max` states this
+        # package used ARPACK for it (0.1 s at 2661 states, more than the factorisation).  But (T^T - I) is singular by
+        # construction, so ONE solve with its factors from any positive vector already is the eigenvector to rounding (3e-15 of
+        # ARPACK's at 2661 states): the seed costs a pair of triangular solves, and the loop below confirms it as before.
+        last_pSS = None
+        if n > self.dense_eig_max:
+            last_pSS = solver.solve(np.full(n, 1.0 / n))
+            if last_pSS is not None and not np.all(last_pSS >= 0):
+                last_pSS = None
+        if last_pSS is None:
+            last_pSS = self.get_steady_state_algebraic(max_iters=10, check_negative=False, set=False)
+        last_flux = self.get_steady_state_target_flux(pSS=last_pSS, _set=False)
         for N in range(max_iters):
             iterated = inverse_iteration(matrix=T, guess=last_pSS, _solver=solver)
             last_pSS = iterated
