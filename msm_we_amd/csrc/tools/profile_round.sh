@@ -7,12 +7,6 @@ tag=${1:-rXX}
 out=$PWD/gpurun_out/$tag
 mkdir -p $out
 root=$PWD
-python bench.py --steps 20 --warmup 5 > $out/${tag}_bench_c3.json 2> $out/bench_c3.err
-echo "bench c3 done: $(python -c "import json;d=json.load(open('$out/${tag}_bench_c3.json'));print(d['ms_per_step'], d['value'])")"
-python bench.py --workload c5s --steps 5 --warmup 2 --no-cpu-baseline --no-ingest > $out/${tag}_bench_c5s.json 2> $out/bench_c5s.err
-echo "bench c5s done: $(python -c "import json;d=json.load(open('$out/${tag}_bench_c5s.json'));print(d['ms_per_step'], d['value'])")"
-python bench.py --workload c5 --steps 3 --warmup 1 > $out/${tag}_bench_c5.json 2> $out/bench_c5.err
-echo "bench c5 done: $(python -c "import json;d=json.load(open('$out/${tag}_bench_c5.json'));print(d['ms_per_step'], d['value'])")"
 cd /tmp && export TMPDIR=/tmp
 for wl in c3 c5s; do
   sfx=""; [ $wl = c5s ] && sfx="_c5s"
@@ -26,4 +20,13 @@ for wl in c3 c5s; do
   (cd $root && python msm_we_amd/csrc/tools/pmc_summary.py $out/${tag}_pmc_summary$sfx.csv $out/pmc_${wl}_FETCH_SIZE $out/pmc_${wl}_WRITE_SIZE > /dev/null)
   rm -rf $out/stats_$wl $out/pmc_${wl}_FETCH_SIZE $out/pmc_${wl}_WRITE_SIZE
 done
+# the PMC summaries the bench lines quote as `traffic` are the ones just taken (the bench reads profiles/<tag>_pmc_summary*.csv)
+cd $root
+cp $out/${tag}_pmc_summary.csv $out/${tag}_pmc_summary_c5s.csv profiles/
+python bench.py --steps 20 --warmup 5 > $out/${tag}_bench_c3.json 2> $out/bench_c3.err
+echo "bench c3 done: $(python -c "import json;d=json.load(open('$out/${tag}_bench_c3.json'));print(d['ms_per_step'], d['value'])")"
+python bench.py --workload c5s --steps 5 --warmup 2 --no-cpu-baseline --no-ingest > $out/${tag}_bench_c5s.json 2> $out/bench_c5s.err
+echo "bench c5s done: $(python -c "import json;d=json.load(open('$out/${tag}_bench_c5s.json'));print(d['ms_per_step'], d['value'])")"
+python bench.py --workload c5 --steps 3 --warmup 1 > $out/${tag}_bench_c5.json 2> $out/bench_c5.err
+echo "bench c5 done: $(python -c "import json;d=json.load(open('$out/${tag}_bench_c5.json'));print(d['ms_per_step'], d['value'])")"
 ls -la $out

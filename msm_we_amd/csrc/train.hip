@@ -333,7 +333,7 @@ struct SeedItem {
   int K, L;
   void *XbT;            // [D][n]  feature-major copy of the batch (coalesced over rows): double, or the frames' type
   double *w, *xsq, *closest, *cum, *cand /*[L][n]*/, *chunk_tot;
-  double *G;            // [n][n] Gram matrix of the batch (k_seed_g only)
+  double *G;            // k_seed_g: [n][n] Gram matrix of the batch; k_seed: null, or [L][D] candidate rows that do not fit LDS
   double *C;            // stratum centroids [K][D]
   long long *chosen;    // [K]
 };
@@ -379,8 +379,11 @@ __global__ __launch_bounds__(SEED_T) void k_seed(const SeedItem *__restrict__ it
   const GAS double *itu = gp(it.u);
   const long long n = it.n;
   const int K = it.K, L = it.L;
-  double *crow = sm;                         // [L][D] candidate rows
-  double *part = crow + (size_t)L * D;       // [L][SEED_T] per-thread partial potentials
+  // [L][D] candidate rows: in LDS, or -- rows too long for that (it.G set: L (D + 1057) 8 B > 160 KB, e.g. 12 candidates of 816
+  // features) -- in global memory, where every thread's read of crow[l][k] is the same address for the whole workgroup (one L1 /
+  // L2 transaction per wave and element: slower than LDS, never a limit)
+  double *crow = it.G ? it.G : sm;
+  double *part = it.G ? sm : sm + (size_t)L * D;  // [L][SEED_T] per-thread partial potentials
   double *grp = part + L * SEED_T;           // [L][SEED_T/SEED_GROUP]
   double *pots = grp + L * (SEED_T / SEED_GROUP);  // [L]
   __shared__ long long cid[SEED_LMAX];
@@ -396,6 +399,7 @@ __global__ __launch_bounds__(SEED_T) void k_seed(const SeedItem *__restrict__ it
     it.C[k] = v;
   }
   if (tid == 0) it.chosen[0] = it.first;
+  if (it.G) __threadfence_block();
   __syncthreads();
   {
     const double xs0 = it.xsq[it.first];
@@ -462,6 +466,7 @@ __global__ __launch_bounds__(SEED_T) void k_seed(const SeedItem *__restrict__ it
     }
     __syncthreads();
     for (int e = tid; e < L * D; e += SEED_T) crow[e] = XbT[(size_t)(e % D) * n + cid[e / D]];
+    if (it.G) __threadfence_block();  // (rows in global memory: written by other waves of this workgroup)
     __syncthreads();
     {
       double a[SEED_LMAX];
@@ -872,7 +877,7 @@ extern "C" int hamsm_kmeans_seed_multi(hamsm_ctx *c, int n_items, const int32_t 
     return o;
   };
   struct Lay {
-    size_t XbT, w, xsq, cl, cum, cand, ct, u, ch, sub;
+    size_t XbT, w, xsq, cl, cum, cand, ct, u, ch, sub, crow;
     int64_t n;
   };
   std::vector<Lay> lay(n_items);
@@ -908,6 +913,13 @@ extern "C" int hamsm_kmeans_seed_multi(hamsm_ctx *c, int n_items, const int32_t 
   bool fast = true;
   for (int i = 0; i < n_items; i++) fast = fast && lay[i].n <= SEED_NLDS && h_L[i] <= SEED_LFAST && h_L[i] == h_L[0];
   const size_t lds_fast = sizeof(double) * SEED_G_LDS(h_L[0]);
+  // the general kernel keeps its candidate rows in LDS while they fit beside the partial potentials, else in global memory
+  int Lmax = 1;
+  for (int i = 0; i < n_items; i++) Lmax = h_L[i] > Lmax ? h_L[i] : Lmax;
+  const size_t lds_part = sizeof(double) * (size_t)Lmax * (SEED_T + SEED_T / SEED_GROUP + 1);
+  const bool crow_global = !fast && lds_part + sizeof(double) * (size_t)Lmax * D > 160 * 1024 - 256;
+  if (crow_global)
+    for (int i = 0; i < n_items; i++) lay[i].crow = take(sizeof(double) * (size_t)h_L[i] * D);
   const size_t g_bytes = (sizeof(double) * (size_t)nmax * nmax + 255) & ~(size_t)255;
   int g_slots = 1;  // strata whose Gram matrices are resident at once (<= ctx seed_g_budget bytes)
   size_t o_G = 0;
@@ -942,7 +954,7 @@ extern "C" int hamsm_kmeans_seed_multi(hamsm_ctx *c, int n_items, const int32_t 
     it.cum = (double *)(b + l.cum);
     it.cand = (double *)(b + l.cand);
     it.chunk_tot = (double *)(b + l.ct);
-    it.G = fast ? (double *)(b + o_G + g_bytes * (size_t)(i % g_slots)) : nullptr;
+    it.G = fast ? (double *)(b + o_G + g_bytes * (size_t)(i % g_slots)) : (crow_global ? (double *)(b + l.crow) : nullptr);
     it.C = c->st[h_stratum[i]].C;
     it.chosen = (long long *)(b + l.ch);
     if (K > 1) HIPCHK(c, hipMemcpyAsync(b + l.u, up, sizeof(double) * (size_t)(K - 1) * L, hipMemcpyHostToDevice, c->stream));
@@ -979,12 +991,7 @@ extern "C" int hamsm_kmeans_seed_multi(hamsm_ctx *c, int n_items, const int32_t 
       HIPCHK(c, hipLaunchKernel(fn, dim3((unsigned)ng), dim3(SEED_TL), args, lds_fast, c->stream));
     }
   } else {
-    int Lmax = 1;
-    for (int i = 0; i < n_items; i++) Lmax = h_L[i] > Lmax ? h_L[i] : Lmax;
-    size_t lds = sizeof(double) * (size_t)Lmax * ((size_t)D + SEED_T + SEED_T / SEED_GROUP + 1);
-    if (lds > 160 * 1024 - 256)
-      return hamsm_fail(c, HAMSM_ENOTSUP, "k-means++ seeding of a batch of more than %d rows with %d candidates of %d features needs %zu B of LDS",
-                        SEED_NLDS, Lmax, D, lds);
+    const size_t lds = crow_global ? lds_part : lds_part + sizeof(double) * (size_t)Lmax * D;  // (L <= 16: lds_part <= 135 KB)
     HIPCHK(c, hipFuncSetAttribute((const void *)k_seed, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(k_seed, dim3((unsigned)n_items), dim3(SEED_T), lds, c->stream, (const SeedItem *)(b + o_items), D);
   }

