@@ -506,6 +506,9 @@ typedef float v16f32 __attribute__((ext_vector_type(16)));
 typedef const float __attribute__((address_space(1))) *gcfp;
 struct FiltDev {
   const float *A;  // [tiles32][KH][64] f32 MFMA fragments: lane l = centroid l % 32, slot 2 ks + l / 32; slot D = -csq / 2
+  const float *H;  // bf16 forms with D a multiple of 16: [tiles32][2][16] -csq / 2 in the order a lane's 16 accumulator
+                   // registers hold a tile's centroids (half l / 32, register r: centroid 8 (r / 4) + 4 (l / 32) + r % 4) -- the
+                   // csq term is the accumulator's INITIAL value there, not a 17th slot that would open a block of its own
 };
 struct FiltArgs {
   const FiltDev *ft;        // [S]
@@ -570,7 +573,7 @@ __device__ __forceinline__ void bf16_split3(float v, unsigned &p1, unsigned &p2,
 
 // A fragments for the bf16 form: [tile][KB][3 pieces][64 lanes][8 bf16]; lane l = centroid l % 32, slots 16 m + 8 (l / 32) + i
 __global__ __launch_bounds__(64) void k_pack_bf16(const StratumDev *__restrict__ table, const FiltDev *__restrict__ ft,
-                                                  unsigned *__restrict__ bnd, int KS, int KB, int D) {
+                                                  unsigned *__restrict__ bnd, int KS, int KB, int D, int hinit) {
   const int s = blockIdx.y, jt = blockIdx.x;
   const StratumDev sd = table[s];
   if (jt * 32 >= sd.K) return;
@@ -600,6 +603,10 @@ __global__ __launch_bounds__(64) void k_pack_bf16(const StratumDev *__restrict__
       for (int z = 0; z < 4; z++) A[((((size_t)jt * KB + m) * 3 + q) * 64 + lane) * 4 + z] = w[q][z];
   }
   n2 += __shfl_xor(n2, 32, 64);
+  if (hinit && h == 0) {  // (16 KB slots == D: no slot carries csq; a row past K starts at -3e38 and never ranks first)
+    float *H = (float *)ft[s].H;
+    H[(size_t)jt * 32 + 16 * ((row >> 2) & 1) + (row & 3) + 4 * (row >> 3)] = live ? (float)(-0.5 * cs) : -3.0e38f;
+  }
   if (h == 0 && live) {
     atomicMax(&bnd[2 * s], __float_as_uint((float)n2 * 1.000001f));
     atomicMax(&bnd[2 * s + 1], __float_as_uint(__builtin_fabsf((float)cs) * 1.000001f));
@@ -635,7 +642,10 @@ template <typename XT, int KS, int AUGX, int FORM>
 __global__ __launch_bounds__(FILT_NW(KS, FORM) * 64) __attribute__((amdgpu_waves_per_eu(FORM ? 2 : (KS <= 8 ? 3 : 2)))) void k_assign_filter(SortArgs g, FiltArgs f) {
   constexpr bool BF = FORM != 0, lite = FORM == 2;
   constexpr int NW = FILT_NW(KS, FORM), NT = NW * 64, KH = 2 * KS + AUGX;
-  constexpr int KB = (4 * KS + 13) / 16 + AUGX;            // bf16 form: blocks of 16 feature slots (features, csq slot, padding)
+  // bf16 form: blocks of 16 feature slots (features, csq slot, padding).  D a multiple of 16 (AUGX): the csq slot would open a block
+  // of its own -- a fifth of the MFMAs at D = 64 -- so -csq / 2 is the accumulator's initial value instead (FiltDev::H)
+  constexpr bool HINIT = BF && AUGX != 0;
+  constexpr int KB = (4 * KS + 13) / 16;
   constexpr int TW = BF ? KB * 3 * 256 : KH * 64;         // 32-bit words of fragments per centroid tile
   APROF_INIT
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -664,6 +674,8 @@ __global__ __launch_bounds__(FILT_NW(KS, FORM) * 64) __attribute__((amdgpu_waves
   const bool oneg = njt <= G;  // all fragments of the stratum fit: loaded once
   float *Xw = (float *)smem + (size_t)wv * 32 * DS;   // [NW][32][DS]: this wave's slab (f32 form; the bf16 form has none: DS = 0)
   float *As = (float *)smem + (size_t)NW * 32 * DS;   // [G][KH][64]
+  float *Hs = As + (size_t)(dbuf ? 2 : 1) * G * TWr;  // HINIT: [buffers][G][32] initial accumulator values, beside the fragments
+  const gcfp Hg = HINIT ? (gcfp)f.ft[s].H : nullptr;
   const long long base_s = g.base[s];
   const long long p0 = base_s + (long long)(blockIdx.x - g.blkbase[s]) * g.FRB;
   const long long pend = g.base[s + 1];
@@ -688,6 +700,10 @@ __global__ __launch_bounds__(FILT_NW(KS, FORM) * 64) __attribute__((amdgpu_waves
       const gcfp srcA = Ag + ((size_t)((g0 + t) * KB + m) * 3 + q) * 256 + lane * 4;
       float *dst = As + (size_t)buf * G * TWr + (size_t)ch * 256;  // (wave-uniform)
       __builtin_amdgcn_global_load_lds(srcA, (lfp)dst, 16, 0, 0);
+    }
+    if constexpr (HINIT) {  // 32 floats per tile, a wave's dword load covers two tiles (the array is padded to whole loads)
+      for (int ch = wv; ch < (gcn + 1) / 2; ch += NW)
+        __builtin_amdgcn_global_load_lds(Hg + (size_t)g0 * 32 + ch * 64 + lane, (lfp)(Hs + (size_t)buf * G * 32 + ch * 64), 4, 0, 0);
     }
   };
   int cur_buf = 0;
@@ -885,10 +901,22 @@ __global__ __launch_bounds__(FILT_NW(KS, FORM) * 64) __attribute__((amdgpu_waves
     // tile, Jr = accumulator register (both only change when the maximum does)
     float M1 = ninf, M2 = ninf;
     int Jr = 0, Jt = 0;
-    auto chain = [&](const float *ap) {
+    auto load_init = [&](const float *hp) {  // hp: the tile's 32 initial values; this lane's half, in register order
+      v16f32 i0;
+      const v4f32 *h4 = (const v4f32 *)(hp + 16 * (lane >> 5));
+#pragma unroll
+      for (int q = 0; q < 4; q++) {
+        const v4f32 t = h4[q];
+#pragma unroll
+        for (int z = 0; z < 4; z++) i0[4 * q + z] = t[z];
+      }
+      return i0;
+    };
+    auto chain = [&](const float *ap, const float *hp) {
       v16f32 acc, zero;
 #pragma unroll
       for (int r = 0; r < 16; r++) zero[r] = 0.f;
+      if constexpr (HINIT) zero = load_init(hp);
       if constexpr (BF) {
         const v4u32 *aq = (const v4u32 *)ap;  // (ap = tile base + lane * 4 words in this form)
 #pragma unroll
@@ -942,6 +970,8 @@ __global__ __launch_bounds__(FILT_NW(KS, FORM) * 64) __attribute__((amdgpu_waves
         const gcfp srcA = Ag + (size_t)g0 * TW;
         const int tot = gc * TW;
         for (int e = tid * 4; e < tot; e += NT * 4) *(v4f32 *)(As + e) = *(gv4p)(srcA + e);
+        if constexpr (HINIT)
+          for (int e = tid; e < gc * 32; e += NT) Hs[e] = Hg[(size_t)g0 * 32 + e];
         __syncthreads();
       } else if (dbuf && !oneg) {
         // the group after this one -- the next of this frame tile, or the first of the wave's next tile -- travels into the
@@ -952,6 +982,7 @@ __global__ __launch_bounds__(FILT_NW(KS, FORM) * 64) __attribute__((amdgpu_waves
       if (live) {
         // two accumulators in rotation: the matrix unit works on tile t + 1 while the vector unit ranks tile t
         const float *ap = As + (dbuf && !oneg ? (size_t)cur_buf * G * TWr : 0) + (BF ? lane * 4 : lane);
+        const float *hp0 = Hs + (dbuf && !oneg ? (size_t)cur_buf * G * 32 : 0);  // (HINIT only)
         if constexpr (BF && KS > 8) {
           // ... and, where a workgroup per CU leaves ONE wave on a SIMD (wide rows: the fragments take the LDS), in this wave's
           // own instruction order: each MFMA of tile t + 1 is followed by its share of the 48 ranking instructions of tile t (an
@@ -975,12 +1006,17 @@ __global__ __launch_bounds__(FILT_NW(KS, FORM) * 64) __attribute__((amdgpu_waves
 #pragma unroll
           for (int r = 0; r < 16; r++) zero[r] = 0.f;
           Frag cur = load_frag(ap, 0);
+          v16f32 icur = zero;  // HINIT: the initial accumulator values of the tile about to start, read one tile ahead
+          if constexpr (HINIT) icur = load_init(hp0);
           // MFMAs of tile jt into accN (fragments of its first block already in cur); RANK: the values of accP (tile jt - 1) in between
           auto step = [&](auto rank_tag, v16f32 &accN, const v16f32 &accP, int jt) {
             constexpr bool RANK = decltype(rank_tag)::value;
             const float *apt = ap + (size_t)jt * TWr;
             const bool more = jt + 1 < gc;  // wave-uniform
             const float before = M1;
+            const v16f32 ini = icur;
+            if constexpr (HINIT)
+              if (more) icur = load_init(hp0 + (jt + 1) * 32);
 #pragma unroll
             for (int m = 0; m < KB; m++) {
               Frag nxt = cur;
@@ -990,7 +1026,7 @@ __global__ __launch_bounds__(FILT_NW(KS, FORM) * 64) __attribute__((amdgpu_waves
               for (int st = 0; st < NS; st++) {
                 const int q = m * NS + st, sel = lite ? st + 3 : st;
                 accN = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(v8bf16, cur.c[AI[sel]]), __builtin_bit_cast(v8bf16, bp[m][BI[sel]]),
-                                                               q == 0 ? zero : accN, 0, 0, 0);
+                                                               q == 0 ? ini : accN, 0, 0, 0);
                 if constexpr (RANK) {
                   __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -1022,12 +1058,12 @@ __global__ __launch_bounds__(FILT_NW(KS, FORM) * 64) __attribute__((amdgpu_waves
           } else
             rank(accA, g0 + jt - 1);
         } else {
-          v16f32 accA = chain(ap), accB;
+          v16f32 accA = chain(ap, hp0), accB;
           for (int jt = 0; jt < gc; jt += 2) {
             const bool b1 = jt + 1 < gc, b2 = jt + 2 < gc;  // wave-uniform
-            if (b1) accB = chain(ap + (size_t)(jt + 1) * TWr);
+            if (b1) accB = chain(ap + (size_t)(jt + 1) * TWr, hp0 + (jt + 1) * 32);
             rank(accA, g0 + jt);
-            if (b2) accA = chain(ap + (size_t)(jt + 2) * TWr);
+            if (b2) accA = chain(ap + (size_t)(jt + 2) * TWr, hp0 + (jt + 2) * 32);
             if (b1) rank(accB, g0 + jt + 1);
           }
         }
@@ -1111,7 +1147,7 @@ template <typename XT, int KS>
 static int launch_filter_ks(hamsm_ctx *c, SortArgs g, FiltArgs f, int TW, int aug, bool bf) {
   const int NW = bf ? FILT_NW(KS, 1) : FILT_NW(KS, 0), FB = 32 * NW;
   const int FRB = g.FRB;  // FB * blocks per workgroup
-  size_t lds = sizeof(float) * (size_t)FB * f.DS + sizeof(float) * (size_t)f.G * TW * (f.dbuf ? 2 : 1) + 16;  // (TW: words per tile in LDS)
+  size_t lds = sizeof(float) * (size_t)FB * f.DS + sizeof(float) * (size_t)f.G * (TW + (bf && aug ? 32 : 0)) * (f.dbuf ? 2 : 1) + 16;  // (TW: words per tile in LDS; bf16 forms with D a multiple of 16: + 32 initial values)
   if (lds > 160 * 1024) return hamsm_fail(c, HAMSM_ENOTSUP, "assign filter needs %zu B of LDS", lds);
   const void *kern = !bf      ? (aug ? (const void *)k_assign_filter<XT, KS, 1, 0> : (const void *)k_assign_filter<XT, KS, 0, 0>)
                      : !f.lite ? (aug ? (const void *)k_assign_filter<XT, KS, 1, 1> : (const void *)k_assign_filter<XT, KS, 0, 1>)
@@ -1143,7 +1179,7 @@ static int launch_sorted(hamsm_ctx *c, const AssignArgs &a) {
   size_t o_code = take(sizeof(int32_t) * n), o_perm = take(sizeof(int32_t) * n), o_cnt = take(sizeof(long long) * S),
          o_cur = take(sizeof(long long) * S), o_base = take(sizeof(long long) * (S + 1)), o_blk = take(sizeof(long long) * (S + 1));
   // filter: f32 fragments of the centroids, undecided-frame lists and the second set of block offsets
-  size_t o_perm2 = 0, o_zero = 0, o_end2 = 0, o_blk2 = 0, o_ft = 0, o_A = 0;
+  size_t o_perm2 = 0, o_zero = 0, o_end2 = 0, o_blk2 = 0, o_ft = 0, o_A = 0, o_H = 0;
   const int KH = a.D == 4 * KS ? 2 * KS + 1 : 2 * KS;  // feature slots of the f32 fragments, in pairs: the features, the csq slot, padding
   // bf16 forms of the ranking pass: D <= 32 both (full: f32-equivalent; light: 3 of 6 piece products, goes first unless it stepped
   // aside); 32 < D <= 64 only the light one (measured at D = 64, K_s = 1250, fragments swept through LDS in groups: f32 form
@@ -1152,8 +1188,10 @@ static int launch_sorted(hamsm_ctx *c, const AssignArgs &a) {
   const bool lite_ok = filt && c->filter_bf16 != 0 && KS <= 16 &&
                        (c->filter_lite == 2 || (c->filter_lite == 1 && (rows_given || !(c->filter_lite_skip > 0 && c->filter_lite_skip--))));
   const bool bf = c->filter_bf16 != 0 && (KS <= 8 || (KS <= 16 && (lite_ok || c->filter_bf16 == 2)));        // bf16 x 3 form of the ranking pass (D <= 32; measured slower at D = 64, K_s = 1250)
-  const int KBmin = (4 * KS + 13) / 16, KB = (a.D + 16) / 16;  // bf16 form: blocks of 16 slots
-  const int aug = bf ? KB - KBmin : KH - 2 * KS;
+  // bf16 form: blocks of 16 slots; D a multiple of 16: csq rides in the accumulator's initial value (FiltDev::H), no block for it
+  const bool hinit = bf && a.D % 16 == 0;
+  const int KBmin = (4 * KS + 13) / 16, KB = hinit ? a.D / 16 : (a.D + 16) / 16;
+  const int aug = bf ? (hinit ? 1 : KB - KBmin) : KH - 2 * KS;
   const int TW = bf ? KB * 3 * 256 : KH * 64;            // 32-bit words of fragments per centroid tile
   int tw_lds = TW;                                        // ... and as held in LDS (light bf16 form in two buffers: 2 pieces)
   std::vector<size_t> tile0(S + 1, 0);
@@ -1170,6 +1208,7 @@ static int launch_sorted(hamsm_ctx *c, const AssignArgs &a) {
     o_blk2 = take(sizeof(long long) * (S + 1));
     o_ft = take(sizeof(FiltDev) * S);
     o_A = take(sizeof(float) * tile0[S] * TW);
+    o_H = take(hinit ? sizeof(float) * (tile0[S] * 32 + 64) : 0);  // (+ 64: the last group's dword loads run to a whole wave)
   }
   int rc = hamsm_ensure_scratch2(c, off);
   if (rc) return rc;
@@ -1193,7 +1232,8 @@ static int launch_sorted(hamsm_ctx *c, const AssignArgs &a) {
     // centroid tiles per LDS group: frames + fragments within filter_lds_kb
     // (the bf16 form's fragments are 1.5x larger: one workgroup per CU, up to 112 KB)
     long long room = (long long)(bf && c->filter_lds_kb < 112 ? 112 : c->filter_lds_kb) * 1024 - (long long)(sizeof(float) * (size_t)FB * f.DS);
-    f.G = room > 0 ? (int)(room / (long long)(sizeof(float) * TW)) : 0;
+    const int twh = hinit ? 32 : 0;  // words of initial values per tile beside the fragments
+    f.G = room > 0 ? (int)(room / (long long)(sizeof(float) * (TW + twh))) : 0;
     f.G = f.G < 2 ? 2 : (f.G > tmax ? (tmax > 0 ? tmax : 1) : f.G & ~1);
     if (bf && f.G < tmax && c->filter_dbuf) {
       // bf16 form and the largest stratum's fragments do not fit at once: two buffers filled by global_load_lds, the next group
@@ -1202,7 +1242,7 @@ static int launch_sorted(hamsm_ctx *c, const AssignArgs &a) {
       f.dbuf = 1;
       tw_lds = KB * (lite_ok ? 2 : 3) * 256;
       room = 156LL * 1024 - (long long)(sizeof(float) * (size_t)FB * f.DS);
-      f.G = (int)(room / (2LL * (long long)sizeof(float) * tw_lds));
+      f.G = (int)(room / (2LL * (long long)sizeof(float) * (tw_lds + twh)));
       f.G = f.G < 2 ? 2 : (f.G > tmax ? tmax : f.G & ~1);
     }
   }
@@ -1230,6 +1270,7 @@ static int launch_sorted(hamsm_ctx *c, const AssignArgs &a) {
     FiltDev *ft = (FiltDev *)c->h_stage.data();
     for (int s = 0; s < S; s++) {
       ft[s].A = (const float *)(b + o_A) + tile0[s] * TW;
+      ft[s].H = hinit ? (const float *)(b + o_H) + tile0[s] * 32 : nullptr;
     }
     HIPCHK(c, hipMemcpyAsync(b + o_ft, ft, sizeof(FiltDev) * S, hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipMemsetAsync(b + o_zero, 0, sizeof(long long) * S + sizeof(unsigned) * 2 * S, c->stream));
@@ -1247,8 +1288,9 @@ static int launch_sorted(hamsm_ctx *c, const AssignArgs &a) {
       // are truncations to 8 significant bits) and the three smaller ones (< 2^-20 together): s off by < 3.02 x 2^-14 ||x|| ||c||,
       // d = -2 s by twice that = 6186 u (u = 2^-24); the csq slot (frame side exactly 1) loses c3: < 2^-14 |csq| / 2 in s = 1024 u |csq|
       // in d; + rounding of c and of f64 frames to f32 (2 u), + the index bits (64 u, 32 u)
+      // (D a multiple of 16: -csq / 2 enters as the accumulator's initial value, rounded to f32 once -- 1 u -- and nothing of it is dropped)
       f.c1 = 2.02f * (float)(6186 + 2 * (2 + 204 * KB) + 64) / 16777216.0f;
-      f.c2 = 2.02f * (float)(1024 + 204 * KB + 1 + 32) / 16777216.0f;
+      f.c2 = 2.02f * (float)((hinit ? 0 : 1024) + 204 * KB + 1 + 32) / 16777216.0f;
     } else
     if (bf) {  // per 16 slots: 6 MFMAs x (16 products + 1 accumulate) roundings, taken FOUR times (unit roundoff 2^-22 as in the
                // f32 form: truncating or reordered accumulation inside the matrix unit is covered); + the dropped terms (16 u)
@@ -1264,7 +1306,7 @@ static int launch_sorted(hamsm_ctx *c, const AssignArgs &a) {
     c->filter_cnt2 = f.cnt2;
     if (tmax > 0 && bf)
       hipLaunchKernelGGL(k_pack_bf16, dim3((unsigned)tmax, (unsigned)S), dim3(64), 0, c->stream, a.table, f.ft, (unsigned *)f.bnd, KS, KB,
-                         a.D);
+                         a.D, hinit ? 1 : 0);
     else if (tmax > 0)
       hipLaunchKernelGGL(k_pack_f32, dim3((unsigned)tmax, (unsigned)S), dim3(64), 0, c->stream, a.table, f.ft, (unsigned *)f.bnd, KS, KH,
                          a.D);

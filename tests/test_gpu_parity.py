@@ -335,7 +335,8 @@ def test_bf16_ranking_with_fragment_groups(hip_lib, oracle_h, monkeypatch, lite,
     monkeypatch.setenv("HAMSM_FILTER_DBUF", dbuf)
     h = _abi.Hamsm(lib=hip_lib, device=0)
     try:
-        for D, Ks, n in ((30, [1000, 40, 1500], 30011), (20, [700, 700, 33], 9000)):
+        # (D = 32 / 16: csq as the accumulator's initial value, FiltDev::H -- its 32 floats per tile travel with every fragment group)
+        for D, Ks, n in ((30, [1000, 40, 1500], 30011), (20, [700, 700, 33], 9000), (32, [1000, 40, 1500], 20011), (16, [1430, 65, 100], 9000)):
             labs = []
             for hh in (oracle_h, h):
                 rng = np.random.default_rng(14)
