@@ -9,7 +9,7 @@ clusters (K = 1000).  One *step* = one pass of the hot path over the resident sh
 
     stratified mini-batch k-means training (999 iterations, sklearn-exact control flow and draws)
     -> assignment of the parent and child frame of every segment (2 x 10 M rows)
-    -> flux-matrix accumulation over the segments (+ D2H of the (K+2)^2 matrix)
+    -> flux-matrix accumulation over the segments (the (K+2)^2 matrix stays in HBM)
 
 Inputs are generated on the host, uploaded once, and are resident in HBM when the timed region
 starts.  N > 1, default = BASELINE config 4 (strong scaling): the workload's 10 M frames are split over

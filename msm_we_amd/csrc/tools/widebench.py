@@ -31,4 +31,9 @@ print(f"D={D} S={cfg.S} K_s={cfg.K_s}: {dt * 1e3:.1f} ms per step of {frames} fr
 # assign: algorithmic flops 2 * frames-in-strata * K_s * D
 fl = 2.0 * frames * cfg.K_s * D
 print(f"assign: {fl / (tm['assign'] * 1e-3) / 1e12:.2f} TFLOP/s f64 (algorithmic), {frames * D * 4 / (tm['assign'] * 1e-3) / 1e9:.0f} GB/s of frames")
+import ctypes
+fn = h.lib.hamsm_debug_filter_undecided
+fn.restype = ctypes.c_longlong
+fn.argtypes = [ctypes.c_void_p]
+print("undecided frames of the last assign call:", fn(h.ctx), "of", frames // 2)
 h.close()
