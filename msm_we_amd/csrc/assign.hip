@@ -413,7 +413,7 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void k_assign_sorted(SortArgs g) {
 // reference's notebooks: 816 features) with KS = ceil(D / 4) a run-time value: one wave owns a 16-frame tile and sweeps
 // the stratum's centroid tiles four at a time; per k-step it loads one frame operand (reused by the four centroid
 // tiles) and four fragments of Bpack.  Same arithmetic as k_assign_sorted: the MFMA's k-ascending accumulation,
-// d = fma(-2, dot, csq), first minimum.  No f32 ranking pass in front of it.
+// d = fma(-2, dot, csq), first minimum.  (k_filter_generic, further down, ranks in front of it since round 4.)
 template <typename XT>
 __global__ __launch_bounds__(256) void k_assign_generic(SortArgs g, int KS) {
   int s = 0;
