@@ -676,6 +676,7 @@ __global__ __launch_bounds__(FILT_NW(KS, FORM) * 64) __attribute__((amdgpu_waves
   float *As = (float *)smem + (size_t)NW * 32 * DS;   // [G][KH][64]
   float *Hs = As + (size_t)(dbuf ? 2 : 1) * G * TWr;  // HINIT: [buffers][G][32] initial accumulator values, beside the fragments
   const gcfp Hg = HINIT ? (gcfp)f.ft[s].H : nullptr;
+  const int GH = (G + 1) & ~1;  // tiles of initial values per buffer: whole dword loads of a wave (two tiles each)
   const long long base_s = g.base[s];
   const long long p0 = base_s + (long long)(blockIdx.x - g.blkbase[s]) * g.FRB;
   const long long pend = g.base[s + 1];
@@ -703,7 +704,7 @@ __global__ __launch_bounds__(FILT_NW(KS, FORM) * 64) __attribute__((amdgpu_waves
     }
     if constexpr (HINIT) {  // 32 floats per tile, a wave's dword load covers two tiles (the array is padded to whole loads)
       for (int ch = wv; ch < (gcn + 1) / 2; ch += NW)
-        __builtin_amdgcn_global_load_lds(Hg + (size_t)g0 * 32 + ch * 64 + lane, (lfp)(Hs + (size_t)buf * G * 32 + ch * 64), 4, 0, 0);
+        __builtin_amdgcn_global_load_lds(Hg + (size_t)g0 * 32 + ch * 64 + lane, (lfp)(Hs + (size_t)buf * GH * 32 + ch * 64), 4, 0, 0);
     }
   };
   int cur_buf = 0;
@@ -982,7 +983,7 @@ __global__ __launch_bounds__(FILT_NW(KS, FORM) * 64) __attribute__((amdgpu_waves
       if (live) {
         // two accumulators in rotation: the matrix unit works on tile t + 1 while the vector unit ranks tile t
         const float *ap = As + (dbuf && !oneg ? (size_t)cur_buf * G * TWr : 0) + (BF ? lane * 4 : lane);
-        const float *hp0 = Hs + (dbuf && !oneg ? (size_t)cur_buf * G * 32 : 0);  // (HINIT only)
+        const float *hp0 = Hs + (dbuf && !oneg ? (size_t)cur_buf * GH * 32 : 0);  // (HINIT only)
         if constexpr (BF && KS > 8) {
           // ... and, where a workgroup per CU leaves ONE wave on a SIMD (wide rows: the fragments take the LDS), in this wave's
           // own instruction order: each MFMA of tile t + 1 is followed by its share of the 48 ranking instructions of tile t (an
@@ -1383,7 +1384,7 @@ template <typename XT, int KS>
 static int launch_filter_ks(hamsm_ctx *c, SortArgs g, FiltArgs f, int TW, int aug, bool bf) {
   const int NW = bf ? FILT_NW(KS, 1) : FILT_NW(KS, 0), FB = 32 * NW;
   const int FRB = g.FRB;  // FB * blocks per workgroup
-  size_t lds = sizeof(float) * (size_t)FB * f.DS + sizeof(float) * (size_t)f.G * (TW + (bf && aug ? 32 : 0)) * (f.dbuf ? 2 : 1) + 16;  // (TW: words per tile in LDS; bf16 forms with D a multiple of 16: + 32 initial values)
+  size_t lds = sizeof(float) * (size_t)FB * f.DS + sizeof(float) * ((size_t)f.G * TW + (bf && aug ? (size_t)((f.G + 1) & ~1) * 32 : 0)) * (f.dbuf ? 2 : 1) + 16;  // (TW: words per tile in LDS; bf16 forms with D a multiple of 16: + 32 initial values)
   if (lds > 160 * 1024) return hamsm_fail(c, HAMSM_ENOTSUP, "assign filter needs %zu B of LDS", lds);
   const void *kern = !bf      ? (aug ? (const void *)k_assign_filter<XT, KS, 1, 0> : (const void *)k_assign_filter<XT, KS, 0, 0>)
                      : !f.lite ? (aug ? (const void *)k_assign_filter<XT, KS, 1, 1> : (const void *)k_assign_filter<XT, KS, 0, 1>)
@@ -1489,7 +1490,8 @@ static int launch_sorted(hamsm_ctx *c, const AssignArgs &a) {
     // centroid tiles per LDS group: frames + fragments within filter_lds_kb
     // (the bf16 form's fragments are 1.5x larger: one workgroup per CU, up to 112 KB)
     long long room = (long long)(bf && c->filter_lds_kb < 112 ? 112 : c->filter_lds_kb) * 1024 - (long long)(sizeof(float) * (size_t)FB * f.DS);
-    const int twh = hinit ? 32 : 0;  // words of initial values per tile beside the fragments
+    const int twh = hinit ? 32 : 0;  // words of initial values per tile beside the fragments (an odd G is rounded up: 256 B kept free below)
+    if (hinit) room -= 256;
     f.G = room > 0 ? (int)(room / (long long)(sizeof(float) * (TW + twh))) : 0;
     f.G = f.G < 2 ? 2 : (f.G > tmax ? (tmax > 0 ? tmax : 1) : f.G & ~1);
     if (bf && f.G < tmax && c->filter_dbuf) {
@@ -1498,7 +1500,7 @@ static int launch_sorted(hamsm_ctx *c, const AssignArgs &a) {
       // 2 of the 3 pieces there
       f.dbuf = 1;
       tw_lds = KB * (lite_ok ? 2 : 3) * 256;
-      room = 156LL * 1024 - (long long)(sizeof(float) * (size_t)FB * f.DS);
+      room = 156LL * 1024 - (long long)(sizeof(float) * (size_t)FB * f.DS) - (hinit ? 256 : 0);
       f.G = (int)(room / (2LL * (long long)sizeof(float) * (tw_lds + twh)));
       f.G = f.G < 2 ? 2 : (f.G > tmax ? tmax : f.G & ~1);
     }
