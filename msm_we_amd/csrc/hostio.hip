@@ -45,7 +45,13 @@ int run_pieces(hamsm_ctx *c, int64_t n_parts, const int64_t *bytes, int threads,
   };
   std::vector<std::thread> pool;
   pool.reserve(threads - 1);
-  for (int t = 1; t < threads; t++) pool.emplace_back(work);
+  for (int t = 1; t < threads; t++) {
+    try {
+      pool.emplace_back(work);
+    } catch (...) {  // (no more threads to be had: the ones that exist, this one included, take all pieces)
+      break;
+    }
+  }
   work();
   for (auto &t : pool) t.join();
   if (err.load()) return hamsm_fail(c, HAMSM_EINVAL, "%s: part %lld of %lld: %s", what, (long long)bad_part.load(), (long long)n_parts,

@@ -557,6 +557,8 @@ class DataMixin:
             n = r1 - r0
             if sizes is not None and n != sum(sizes[it] for it in its):
                 raise ValueError(f"iterations {its[0]}..{its[-1]} hold {n} segments, another number was announced")
+            if n > len(slab["w"]):
+                raise ValueError(f"iterations {its[0]}..{its[-1]} hold {n} segments, the upload slab was sized for {len(slab['w'])}")
             dsts = (("Xp", slab["X"][0]), ("Xc", slab["X"][1]), ("p0", slab["p0"]), ("p1", slab["p1"]), ("w", slab["w"]))
 
             def rd(ab):
@@ -572,7 +574,8 @@ class DataMixin:
                     offs_, nb_ = [], []
                     for key, dst in dsts:
                         path, fo, nb = src.file_range(key, r0, r1)
-                        assert nb == dst[:n].nbytes and dst.flags.c_contiguous
+                        if nb != dst[:n].nbytes or not dst.flags.c_contiguous:
+                            raise ValueError(f"{key}: {nb} bytes on file for {n} rows of a slab that holds {dst[:n].nbytes}")
                         fds.append(os.open(path, os.O_RDONLY))
                         offs_.append(fo)
                         nb_.append(nb)
@@ -598,6 +601,8 @@ class DataMixin:
                 if len(b_[4]) != sizes[it]:
                     raise ValueError(f"iteration {it} holds {len(b_[4])} segments, {sizes[it]} were announced")
         n_all = int(starts[-1])
+        if n_all > len(slab["w"]):   # (the copies below write raw memory: never past the slab)
+            raise ValueError(f"iterations {its[0]}..{its[-1]} hold {n_all} segments, the upload slab was sized for {len(slab['w'])}")
 
         def put(ab):
             fits = True
@@ -629,7 +634,8 @@ class DataMixin:
                 o_ = int(starts[q])
                 for a_, d_ in zip(b_, dsts):
                     if a_.nbytes:
-                        assert a_.shape[1:] == d_.shape[1:]
+                        if a_.shape[1:] != d_.shape[1:] or len(a_) != len(b_[4]):
+                            raise ValueError(f"iteration {its[q]}: an array of shape {a_.shape} for {len(b_[4])} segments of row shape {d_.shape[1:]}")
                         sp.append(a_.__array_interface__["data"][0])
                         dp.append(d_.__array_interface__["data"][0] + o_ * (d_.nbytes // max(1, len(d_))))
                         nb.append(a_.nbytes)
