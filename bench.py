@@ -455,9 +455,9 @@ def roofline_by_kernel(cfg, n_iters, n_seg, timers, steps, assign_tflops, assign
 
 def ingest_leg(h, cfg, n_it, log):
     """f2: `stage_iterations` -- two page-locked slabs, the next block filled while the current one is uploaded on the copy stream
-    -- from per-iteration `.npz` files (zip members: the interpreter copies), from the run-level raw layout (`NpyDirectorySource`:
-    the library's threads pread file -> slab, `hamsm_host_read_parts`) and from iterations held in memory
-    (`hamsm_host_copy_parts`).  Everything is inside the figure: slab allocation and release, device allocations, the NaN scan."""
+    -- from per-iteration `.npz` files (stored members = byte ranges of the files) and from the run-level raw layout
+    (`NpyDirectorySource`), both read file -> slab by the library's threads (`hamsm_host_read_parts`), and from iterations held in
+    memory (`hamsm_host_copy_parts`).  The sources are fresh objects: the `.npz` files' headers are parsed inside the figure.  Everything is inside the figure: slab allocation and release, device allocations, the NaN scan."""
     import shutil
     import tempfile
     from msm_we_amd.data import InMemorySource, NpyDirectorySource, NpzDirectorySource
@@ -469,7 +469,7 @@ def ingest_leg(h, cfg, n_it, log):
         src = NpzDirectorySource.export(InMemorySource(its), os.path.join(tmp, "npz"))
         raw = NpyDirectorySource.export(InMemorySource(its), os.path.join(tmp, "npy"))
         res = {}
-        for name, source in (("npz_files", src), ("raw_files", raw), ("in_memory", InMemorySource(its))):
+        for name, source in (("npz_files", NpzDirectorySource(src.dir)), ("raw_files", raw), ("in_memory", InMemorySource(its))):
             m = modelWE(h=h)
             m.pcoord_ndim = 1
             m.set_iteration_source(source)

@@ -6,7 +6,8 @@ import bench
 from msm_we_amd import _abi, synthetic
 from msm_we_amd.data import DeviceStore
 
-cfg = synthetic.CONFIGS["c3"]
+_wl = os.environ.get("HAMSM_TRACE_WORKLOAD", "c3")
+cfg = synthetic.WEConfig("c5s", 5, 200, 50000, 64, 4, 1250) if _wl == "c5s" else synthetic.CONFIGS[_wl]
 h = _abi.Hamsm()
 Xp, Xc, p0, p1, w, offs = bench.make_shard(cfg, 1, cfg.n_iters)
 store = DeviceStore.from_host(h, Xp, Xc, p0, p1, w, offs)

@@ -42,7 +42,8 @@ class InMemorySource:
 class NpzDirectorySource:
     """Iterations as ``<dir>/iter_%08d.npz`` files holding the arrays of the source contract above -- the raw fallback
     for hosts without h5py: export once where the WESTPA run lives (`export`), analyse anywhere.
-    Files are memory-mapped lazily, one iteration at a time."""
+    `load` goes through `zipfile` (2 GB/s); staging does not: `np.savez` STORES its members, so every array is a byte range of
+    its file (`member_ranges`) that the library's threads read straight into the upload slab."""
 
     PATTERN = "iter_%08d.npz"
     parallel_safe = True   # every `load` opens its own file
@@ -56,6 +57,40 @@ class NpzDirectorySource:
         self._its = sorted(int(m.group(1)) for m in found if m)
         if not self._its:
             raise FileNotFoundError(f"no iter_XXXXXXXX.npz files in {self.dir}")
+        self._ranges = {}
+        self._load_index()
+
+    INDEX = "member_ranges.json"   # written by `export`: where every array lies in its file (see `member_ranges`)
+
+    def _load_index(self):
+        """the byte ranges `export` recorded; an entry is used only while its file still has the recorded size and time stamp"""
+        import json
+        import os
+
+        try:
+            with open(os.path.join(self.dir, self.INDEX)) as f:
+                idx = json.load(f)
+            for k, e in idx.items():
+                path = os.path.join(self.dir, self.PATTERN % int(k))
+                st = os.stat(path)
+                if st.st_size == e["size"] and st.st_mtime_ns == e["mtime_ns"]:
+                    self._ranges[int(k)] = {a: (int(r[0]), int(r[1]), np.dtype(r[2]), tuple(int(v) for v in r[3])) for a, r in e["ranges"].items()}
+        except (OSError, ValueError, KeyError, TypeError):
+            pass
+
+    def _write_index(self):
+        import json
+        import os
+
+        idx = {}
+        for n in self._its:
+            r = self.member_ranges(n)
+            if r is not None:
+                st = os.stat(os.path.join(self.dir, self.PATTERN % n))
+                idx[str(n)] = {"size": st.st_size, "mtime_ns": st.st_mtime_ns,
+                               "ranges": {a: [v[0], v[1], v[2].str, list(v[3])] for a, v in r.items()}}
+        with open(os.path.join(self.dir, self.INDEX), "w") as f:
+            json.dump(idx, f)
 
     def iterations(self):
         return list(self._its)
@@ -66,6 +101,48 @@ class NpzDirectorySource:
         with np.load(os.path.join(self.dir, self.PATTERN % int(n))) as z:
             return {k: z[k] for k in z.files}
 
+    def member_ranges(self, n):
+        """{key: (byte offset, byte count, dtype, shape)} of iteration n's arrays inside its ``.npz``, or None when a member is
+        deflated, Fortran-ordered or of object type.  `np.savez` STORES its members: each array's bytes are one contiguous range
+        of the file, which staging reads straight into the upload slab (`hamsm_host_read_parts`) instead of going through
+        `zipfile` + a copy (2 GB/s).  Parsed once per file (the zip's local headers, then the ``.npy`` header) and kept."""
+        import os
+        import struct
+        import zipfile
+
+        n = int(n)
+        cache = self._ranges
+        if n in cache:
+            return cache[n]
+        path = os.path.join(self.dir, self.PATTERN % n)
+        out = {}
+        try:
+            with zipfile.ZipFile(path) as z, open(path, "rb") as f:
+                for zi in z.infolist():
+                    if zi.compress_type != zipfile.ZIP_STORED or not zi.filename.endswith(".npy"):
+                        out = None
+                        break
+                    f.seek(zi.header_offset)
+                    hdr = f.read(30)
+                    if len(hdr) != 30 or hdr[:4] != b"PK\x03\x04":
+                        out = None
+                        break
+                    nlen, xlen = struct.unpack("<HH", hdr[26:30])
+                    start = zi.header_offset + 30 + nlen + xlen
+                    f.seek(start)
+                    ver = np.lib.format.read_magic(f)
+                    rd = np.lib.format.read_array_header_1_0 if ver == (1, 0) else np.lib.format.read_array_header_2_0
+                    shape, fortran, dtype = rd(f)
+                    nbytes = int(np.prod(shape, dtype=np.int64)) * dtype.itemsize
+                    if (fortran and len(shape) > 1) or dtype.hasobject or f.tell() + nbytes > start + zi.file_size:
+                        out = None
+                        break
+                    out[zi.filename[:-4]] = (int(f.tell()), nbytes, dtype, tuple(int(v) for v in shape))
+        except (OSError, ValueError, zipfile.BadZipFile):
+            out = None
+        cache[n] = out
+        return out
+
     @classmethod
     def export(cls, source, directory, iterations=None):
         """write any source (e.g. a WestpaH5Source) in this layout"""
@@ -74,17 +151,19 @@ class NpzDirectorySource:
         os.makedirs(str(directory), exist_ok=True)
         for n in (source.iterations() if iterations is None else iterations):
             np.savez(os.path.join(str(directory), cls.PATTERN % int(n)), **{k: np.asarray(v) for k, v in source.load(n).items()})
-        return cls(directory)
+        out = cls(directory)
+        out._write_index()
+        return out
 
 
 class NpyDirectorySource:
     """A whole run as raw arrays: ``<dir>/{Xp,Xc,p0,p1,w}.npy`` hold the rows of ALL iterations back to back (iteration-major, like
     the staged frames in HBM), ``offsets.npy`` / ``iterations.npy`` say where each iteration lies.  `load(n)` returns memory-mapped
     slices; staging does not even map them: a block of iterations is one contiguous byte range per array, read with ``preadv``
-    by its reader threads STRAIGHT into the page-locked upload slab (`read_rows`) -- one copy, no page faults, no per-file Python
-    work.  (Per-iteration files -- ``.npz`` or ``.npy`` -- measured 1.2-2.0 GB/s on the GPU box whatever the thread count: opening
-    and parsing five files per iteration is serial work under the interpreter lock.)  The layout to export a long WESTPA run to
-    for repeated analyses."""
+    by the library's threads STRAIGHT into the page-locked upload slab (`file_range` -> `hamsm_host_read_parts`) -- one copy, no
+    page faults, no per-file Python work.  (Per-iteration files read through numpy -- ``.npz`` members or ``.npy`` files --
+    measured 1.2-2.0 GB/s on the GPU box whatever the thread count: opening and parsing five arrays per iteration is serial work
+    under the interpreter lock.)  The layout to export a long WESTPA run to for repeated analyses."""
 
     KEYS = ("Xp", "Xc", "p0", "p1", "w")
     parallel_safe = True
@@ -587,6 +666,45 @@ class DataMixin:
                 run(rd, cuts_of(n))
             self.__dict__["_stage_direct_blocks"] = self.__dict__.get("_stage_direct_blocks", 0) + 1
             return n, None, None, True
+
+        if mode == "host" and hasattr(src, "member_ranges") and hasattr(src, "PATTERN") and self._features_are_stored() and len(its):
+            # per-iteration ``.npz`` files whose members are stored: every array is a byte range of its file -> file to slab by the
+            # library's threads, no zipfile, no intermediate arrays.  (Anything unusual -- a deflated member, another dtype or
+            # width, raw coordinates instead of features -- takes the general path below.)
+            import os
+
+            dsts = (("Xp", slab["X"][0]), ("Xc", slab["X"][1]), ("p0", slab["p0"]), ("p1", slab["p1"]), ("w", slab["w"]))
+            rngs = [src.member_ranges(it) for it in its]
+            plain = all(r is not None and all(k in r and r[k][2] == d_.dtype and r[k][3][1:] == d_.shape[1:] and r[k][3][:1] == r["w"][3][:1]
+                                              for k, d_ in dsts) for r in rngs)
+            if plain:
+                ns = [int(r["w"][3][0]) for r in rngs]
+                if sizes is not None and len(its) > 1:
+                    for it, n_ in zip(its, ns):
+                        if n_ != sizes[it]:
+                            raise ValueError(f"iteration {it} holds {n_} segments, {sizes[it]} were announced")
+                n_all = int(sum(ns))
+                if n_all > len(slab["w"]):
+                    raise ValueError(f"iterations {its[0]}..{its[-1]} hold {n_all} segments, the upload slab was sized for {len(slab['w'])}")
+                fds, f_of, offs_, dp, nb_ = [], [], [], [], []
+                try:
+                    o_ = 0
+                    for it, r, n_ in zip(its, rngs, ns):
+                        fds.append(os.open(os.path.join(src.dir, src.PATTERN % int(it)), os.O_RDONLY))
+                        for k, d_ in dsts:
+                            if r[k][1]:
+                                f_of.append(fds[-1])
+                                offs_.append(r[k][0])
+                                dp.append(d_.__array_interface__["data"][0] + o_ * (d_.nbytes // max(1, len(d_))))
+                                nb_.append(r[k][1])
+                        o_ += n_
+                    if nb_:
+                        self.h.host_read_parts(f_of, offs_, dp, nb_, threads=nt)
+                finally:
+                    for fd in fds:
+                        os.close(fd)
+                self.__dict__["_stage_direct_blocks"] = self.__dict__.get("_stage_direct_blocks", 0) + 1
+                return n_all, None, None, True
 
         # 1. the iterations' host blocks (a file read, the featurizer: parallel by iteration; a source that only hands out arrays
         # it holds is asked in this thread -- a pool dispatch costs ~60 us, more than the lookup); 2. the block's rows into the

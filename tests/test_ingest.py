@@ -247,11 +247,45 @@ def test_streaming_staging_in_many_blocks(oracle_h, tmp_path, monkeypatch, case,
         stores.append([st.Xp.to_host(), st.Xc.to_host(), st.p0.to_host(), st.p1.to_host(), st.w.to_host(), st.w_flux.to_host(),
                        np.concatenate(m.dtrajs), m.ingest_stats["blocks"]])
     assert stores[0][-1] == 1 and stores[1][-1] > 10
-    # the raw layout's blocks go file -> upload slab (preadv), never through a per-iteration array
-    assert m.ingest_stats["direct_read_blocks"] == (m.ingest_stats["blocks"] if layout is NpyDirectorySource else 0)
+    # both layouts' blocks go file -> upload slab (pread of byte ranges: the run-level arrays, or the STORED members of the
+    # per-iteration .npz files), never through a per-iteration array
+    assert m.ingest_stats["direct_read_blocks"] == m.ingest_stats["blocks"]
     for a, b in zip(stores[0][:-1], stores[1][:-1]):
         assert np.array_equal(a, b, equal_nan=True)
     assert np.array_equal(stores[1][6], g["dtrajs_post_cluster"])
+
+
+@pytest.mark.parametrize("variant", ["deflated", "float64-features", "wide-pcoord"])
+def test_npz_members_that_are_not_plain_byte_ranges_take_the_general_path(oracle_h, tmp_path, monkeypatch, variant):
+    """the file -> slab byte-range read of `.npz` members applies to stored members of exactly the slab's dtype and width; a
+    deflated archive, float64 features (cast on the way in) or a pcoord wider than `pcoord_ndim` (a strided view) go through the
+    general path and stage the same arrays"""
+    import os
+
+    from msm_we_amd.model import modelWE
+
+    g, meta = load_golden("c1p_d10")
+    its = golden_iterations(g)
+    ref_src = NpzDirectorySource.export(InMemorySource(its), tmp_path / "plain")
+    os.makedirs(tmp_path / "odd")
+    for n, d in its.items():
+        d = {k: np.asarray(v) for k, v in d.items()}
+        if variant == "float64-features":
+            d["Xp"], d["Xc"] = d["Xp"].astype(np.float64), d["Xc"].astype(np.float64)
+        if variant == "wide-pcoord":
+            d["p0"] = np.column_stack([np.asarray(d["p0"]).reshape(len(d["w"]), -1)[:, 0], np.zeros(len(d["w"]))])
+            d["p1"] = np.column_stack([np.asarray(d["p1"]).reshape(len(d["w"]), -1)[:, 0], np.ones(len(d["w"]))])
+        (np.savez_compressed if variant == "deflated" else np.savez)(tmp_path / "odd" / (NpzDirectorySource.PATTERN % n), **d)
+    monkeypatch.setattr(modelWE, "STAGE_CHUNK_BYTES", 3 * 128 * (2 * 10 * 4 + 24))
+    stores = []
+    for src in (ref_src, NpzDirectorySource(tmp_path / "odd")):
+        m, _ = build_model(oracle_h, g, meta, source=src)
+        st = m._store
+        stores.append([st.Xp.to_host(), st.Xc.to_host(), st.p0.to_host(), st.p1.to_host(), st.w.to_host(), np.concatenate(m.dtrajs)])
+        direct = m.ingest_stats["direct_read_blocks"]
+        assert direct == (m.ingest_stats["blocks"] if src is ref_src else 0)
+    for a, b in zip(*stores):
+        assert np.array_equal(a, b, equal_nan=True)
 
 
 def test_staging_falls_back_to_float64_when_float32_would_lose_bits(oracle_h):
