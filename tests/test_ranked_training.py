@@ -38,6 +38,12 @@ CASES = [
     ("reseeding", synthetic.WEConfig("rk8", 5, 16, 2500, 6, 2, 2), 20, dict(shift=True)),      # device re-seeding keeps the fragments
     ("reseeding-weighted", synthetic.WEConfig("rk8w", 5, 16, 2500, 6, 2, 2), 20, dict(shift=True, weights=True)),
     ("outliers", synthetic.WEConfig("rk9", 5, 12, 2500, 6, 2, 2), 40, dict(outliers=True)),   # scale 100 vs 0.01: wide bounds
+    # more than 32 launch groups per run: the enqueue runs a bounded distance ahead of the device, polls the chains' stop words,
+    # drops stopped strata from the launches that follow and ends a run early (run_steps, "bounded run-ahead") -- with chains
+    # that do stop (re-seeding), on two queues and on one (11 strata)
+    ("reseeding-long", synthetic.WEConfig("rk8l", 5, 70, 2500, 6, 2, 2), 20, dict(shift=True)),
+    ("reseeding-weighted-long", synthetic.WEConfig("rk8wl", 6, 50, 2000, 6, 3, 2), 16, dict(shift=True, weights=True)),
+    ("many-strata-long", synthetic.WEConfig("rk6l", 13, 45, 3300, 12, 11, 8), 8, dict(shift=True)),
 ]
 
 
