@@ -1007,17 +1007,16 @@ __global__ __launch_bounds__(FILT_NW(KS, FORM) * 64) __attribute__((amdgpu_waves
 #pragma unroll
           for (int r = 0; r < 16; r++) zero[r] = 0.f;
           Frag cur = load_frag(ap, 0);
-          v16f32 icur = zero;  // HINIT: the initial accumulator values of the tile about to start, read one tile ahead
-          if constexpr (HINIT) icur = load_init(hp0);
           // MFMAs of tile jt into accN (fragments of its first block already in cur); RANK: the values of accP (tile jt - 1) in between
           auto step = [&](auto rank_tag, v16f32 &accN, const v16f32 &accP, int jt) {
             constexpr bool RANK = decltype(rank_tag)::value;
             const float *apt = ap + (size_t)jt * TWr;
             const bool more = jt + 1 < gc;  // wave-uniform
             const float before = M1;
-            const v16f32 ini = icur;
-            if constexpr (HINIT)
-              if (more) icur = load_init(hp0 + (jt + 1) * 32);
+            // HINIT: the tile's initial values go from LDS straight into the accumulator's own registers (free since the tile before
+            // last was ranked) -- handed over through a second variable the compiler copied them, 16 moves behind an MFMA's full
+            // latency per tile
+            if constexpr (HINIT) accN = load_init(hp0 + jt * 32);
 #pragma unroll
             for (int m = 0; m < KB; m++) {
               Frag nxt = cur;
@@ -1027,7 +1026,7 @@ __global__ __launch_bounds__(FILT_NW(KS, FORM) * 64) __attribute__((amdgpu_waves
               for (int st = 0; st < NS; st++) {
                 const int q = m * NS + st, sel = lite ? st + 3 : st;
                 accN = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(v8bf16, cur.c[AI[sel]]), __builtin_bit_cast(v8bf16, bp[m][BI[sel]]),
-                                                               q == 0 ? ini : accN, 0, 0, 0);
+                                                               (!HINIT && q == 0) ? zero : accN, 0, 0, 0);
                 if constexpr (RANK) {
                   __builtin_amdgcn_sched_barrier(0);
 #pragma unroll

@@ -9,7 +9,7 @@ for set in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES" "SQ_WAIT_ANY SQ_WAIT_INST_ANY" "SQ_AC
            "SQ_INSTS_SALU SQ_INSTS_VMEM" "SQ_WAIT_INST_LDS SQ_ACTIVE_INST_SCA" "SQ_INST_CYCLES_VMEM SQ_WAVES" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE"; do
   i=$((i+1))
   rocprofv3 --pmc $set --kernel-trace --kernel-include-regex k_assign_filter --output-format csv -d $out/p$i -o p -- \
-    python3 $root/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-full-pipeline --no-ingest > /dev/null 2> $out/err_$i.txt
+    python3 $root/bench.py --workload ${HAMSM_PMC_WORKLOAD:-c3} --steps 1 --warmup 1 --no-cpu-baseline --no-full-pipeline --no-ingest > /dev/null 2> $out/err_$i.txt
   echo "pass $i ($set) rc=$?"
 done
 cd $root
