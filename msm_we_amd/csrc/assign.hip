@@ -1020,14 +1020,24 @@ __global__ __launch_bounds__(FILT_NW(KS, FORM) * 64) __attribute__((amdgpu_waves
 #pragma unroll
             for (int m = 0; m < KB; m++) {
               Frag nxt = cur;
+#ifndef FILT_ABL_NOFRAG  // (diagnostic builds, tools/assignabl.py: what the sweep costs without its LDS reads / ranking / MFMAs)
               if (m + 1 < KB) nxt = load_frag(apt, m + 1);
               else if (more) nxt = load_frag(apt + TWr, 0);
+#endif
 #pragma unroll
               for (int st = 0; st < NS; st++) {
                 const int q = m * NS + st, sel = lite ? st + 3 : st;
+#ifndef FILT_ABL_NOMFMA
                 accN = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(v8bf16, cur.c[AI[sel]]), __builtin_bit_cast(v8bf16, bp[m][BI[sel]]),
                                                                (!HINIT && q == 0) ? zero : accN, 0, 0, 0);
+#else
+                asm volatile("" : "+v"(accN) : "v"(cur.c[AI[sel]]), "v"(bp[m][BI[sel]]));
+#endif
+#ifdef FILT_ABL_NORANK
+                if constexpr (false) {
+#else
                 if constexpr (RANK) {
+#endif
                   __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                   for (int r = 16 * q / NM; r < 16 * (q + 1) / NM; r++) {
