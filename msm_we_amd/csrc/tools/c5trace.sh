@@ -3,7 +3,7 @@ cd /tmp && export TMPDIR=/tmp
 OUT=$GRAFT_REPO_ROOT/gpurun_out/c5trace
 rm -rf $OUT && mkdir -p $OUT
 cd $GRAFT_REPO_ROOT
-rocprofv3 --kernel-trace --output-format csv -d $OUT/trace -o c5 -- python3 bench.py --workload c5s --steps 2 --warmup 1 --no-cpu-baseline --no-ingest --no-full-pipeline > $OUT/bench.json 2> $OUT/bench.err
+rocprofv3 --kernel-trace --output-format csv -d $OUT/trace -o c5 -- python3 bench.py --workload ${HAMSM_TRACE_WORKLOAD:-c5s} --steps 2 --warmup 1 --no-cpu-baseline --no-ingest --no-full-pipeline > $OUT/bench.json 2> $OUT/bench.err
 echo rc=$?
 python3 - <<'PY'
 import csv, glob, collections, statistics, os
