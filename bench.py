@@ -515,7 +515,7 @@ def main():
     ap.add_argument("--iters", type=int, default=0, help="override iterations per rank (debug)")
     ap.add_argument("--flux-mode", type=int, default=1, help="1 = deterministic sort-based (the product default), 0 = f64 atomics")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-iters", type=int, default=0, help="iterations of the CPU baseline's sample (0: about the work of 32 C3 iterations)")
+    ap.add_argument("--cpu-iters", type=int, default=0, help="iterations of the CPU baseline's sample (0: about the work of 128 C3 iterations, ~10 s on one core)")
     ap.add_argument("--cpu-cores", type=int, default=min(16, os.cpu_count() or 1), help="processes of the all-cores CPU leg")
     ap.add_argument("--no-full-pipeline", action="store_true")
     ap.add_argument("--scaling", default=None, choices=["weak", "strong"],
@@ -779,7 +779,7 @@ def main():
         if not args.no_cpu_baseline and world == 1:
             log("timing the CPU oracle on a bounded sample ...")
             # a BOUNDED sample: the work of 32 C3 iterations (~20 s on one core), never fewer than 2 iterations
-            cpu_iters = args.cpu_iters or max(2, int(32 * (10000 * 250 * 30) / (cfg.segs_per_iter * cfg.K_s * cfg.D)))
+            cpu_iters = args.cpu_iters or max(2, int(128 * (10000 * 250 * 30) / (cfg.segs_per_iter * cfg.K_s * cfg.D)))
             out["cpu_baseline"] = cpu_baseline(args.workload, min(cpu_iters, n_iters), seed, args.cpu_cores)
             out["cpu_baseline"]["gpu_over_cpu"] = out["value"] / out["cpu_baseline"]["value"]
         print(json.dumps(out), flush=True)
