@@ -753,13 +753,38 @@ __global__ void k_pack(const double *__restrict__ C, const double *__restrict__ 
     Bpack[((size_t)jt * KS + (k >> 2)) * 64 + (k & 3) * 16 + col] = v;
   }
 }
+// the same for long rows (D > 128): the fragment fill is spread over the row (blockIdx.y: 64 features each); ||c||^2 stays ONE fma
+// chain over ascending k per centroid (the contract), formed by the threads of the first slice
+__global__ void k_pack_long(const double *__restrict__ C, const double *__restrict__ csq_in, int K, int Kpad, int D, int KS,
+                            double *__restrict__ csq, double *__restrict__ Bpack) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x, k0 = blockIdx.y * 64;
+  if (j >= Kpad) return;
+  if (k0 == 0) {
+    if (j < K) {
+      if (csq_in) csq[j] = csq_in[j];
+      else {
+        double a = 0.0;
+        for (int k = 0; k < D; k++) a = __builtin_fma(C[(size_t)j * D + k], C[(size_t)j * D + k], a);
+        csq[j] = a;
+      }
+    } else csq[j] = __builtin_huge_val();
+  }
+  const int jt = j >> 4, col = j & 15;
+  for (int k = k0; k < k0 + 64 && k < KS * 4; k++) {
+    const double v = (j < K && k < D) ? C[(size_t)j * D + k] : 0.0;
+    Bpack[((size_t)jt * KS + (k >> 2)) * 64 + (k & 3) * 16 + col] = v;
+  }
+}
 
 int hamsm_pack_stratum(hamsm_ctx *c, int s, const double *d_csq_in) {
   Stratum &t = c->st[s];
   if (t.K == 0) return HAMSM_OK;
   int Kp = kpad(t.K);
-  hipLaunchKernelGGL(k_pack, dim3((Kp + 63) / 64), dim3(64), 0, c->stream, t.C, d_csq_in, t.K, Kp, c->D, c->KS, t.csq,
-                     t.Bpack);
+  if (c->KS > 32)
+    hipLaunchKernelGGL(k_pack_long, dim3((Kp + 63) / 64, (c->KS * 4 + 63) / 64), dim3(64), 0, c->stream, t.C, d_csq_in, t.K, Kp, c->D, c->KS,
+                       t.csq, t.Bpack);
+  else
+    hipLaunchKernelGGL(k_pack, dim3((Kp + 63) / 64), dim3(64), 0, c->stream, t.C, d_csq_in, t.K, Kp, c->D, c->KS, t.csq, t.Bpack);
   HIPCHK(c, hipGetLastError());
   return HAMSM_OK;
 }
