@@ -524,7 +524,7 @@ def main():
     ap.add_argument("--train-on", default=None, choices=["rank0", "all", "strata"],
                     help="sharded runs.  strata (default for strong scaling): every rank receives every shard's training frames once "
                          "at staging and trains the strata s %% N == rank, stratum s's model travels from its rank: N ranks == one "
-                         "process on the same data, training spread over min(N, S) GPUs; all: the same model trained by rank 0 "
+                         "process on the same data, the strata's chains spread over min(N, S) GPUs; all: the same model trained by rank 0 "
                          "alone; rank0 (default for weak scaling): rank 0 trains on its own block of iterations only")
     ap.add_argument("--no-ingest", action="store_true")
     ap.add_argument("--lib", default=None, help="(kernel A/B experiments) path of an alternative build of the HIP library")
