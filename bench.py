@@ -13,10 +13,11 @@ clusters (K = 1000).  One *step* = one pass of the hot path over the resident sh
 
 Inputs are generated on the host, uploaded once, and are resident in HBM when the timed region
 starts.  N > 1, default = BASELINE config 4 (strong scaling): the workload's 10 M frames are split over
-the ranks by WE iteration; every rank's training frames reach every rank once at staging and stratum s
-trains on rank s % N (the strata's chains of partial_fits are independent), its model travels from
-there with RCCL; every rank discretizes its shard and the partial flux matrices are all-reduced over
-xGMI -- N ranks produce the model of one process on the same data.  ``--scaling weak``: every rank its
+the ranks by WE iteration; the training frames of every rank reach rank 0 once at staging, which trains
+on all of them and broadcasts the model with RCCL (where a stratum's training call is matrix-bound --
+config 5's shape -- they reach every rank instead and stratum s trains on rank s % N: the strata's
+chains of partial_fits are independent); every rank discretizes its shard and the partial flux matrices
+are all-reduced over xGMI -- N ranks produce the model of one process on the same data.  ``--scaling weak``: every rank its
 own full shard, rank 0 trains on its block (the reference's ``iters_to_use``).
 
 Rank 0 prints ONE JSON line (contract in the task statement) with ``roofline`` for the dominant kernel
@@ -522,10 +523,13 @@ def main():
                     help="N > 1.  strong (default; BASELINE config 4: the workload's 10 M frames in all, split over the ranks) or "
                          "weak (every rank its own full shard: N x the frames)")
     ap.add_argument("--train-on", default=None, choices=["rank0", "all", "strata"],
-                    help="sharded runs.  strata (default for strong scaling): every rank receives every shard's training frames once "
-                         "at staging and trains the strata s %% N == rank, stratum s's model travels from its rank: N ranks == one "
-                         "process on the same data, the strata's chains spread over min(N, S) GPUs; all: the same model trained by rank 0 "
-                         "alone; rank0 (default for weak scaling): rank 0 trains on its own block of iterations only")
+                    help="sharded runs.  all: rank 0 trains on every rank's iterations (gathered to it at staging): N ranks == one "
+                         "process on the same data.  strata: the same model, every rank receives every shard's training frames and "
+                         "trains the strata s %% N == rank, stratum s's model travels from its rank.  Default for strong scaling: "
+                         "strata where a stratum's training call is matrix-bound (>= 0.5 GFLOP: BASELINE config 5's shape, 2.2x "
+                         "shorter pass with a stratum per GPU), all where it is latency-bound (config 3 / 4: one stratum's chain "
+                         "ALONE takes 24.8 us per call, the four chains overlapped on one chip 17.4 -- tools/onestratum.py).  "
+                         "rank0 (default for weak scaling): rank 0 trains on its own block of iterations only")
     ap.add_argument("--no-ingest", action="store_true")
     ap.add_argument("--lib", default=None, help="(kernel A/B experiments) path of an alternative build of the HIP library")
     args = ap.parse_args()
@@ -560,7 +564,8 @@ def main():
         n_iters = per if rank < world - 1 else n_total - per * (world - 1)
     else:
         n_iters, first_iter = n_total, 1 + rank * n_total
-    train_on = args.train_on or ("strata" if args.scaling == "strong" else "rank0")
+    call_flop = 2.0 * (cfg.segs_per_iter / cfg.S) * cfg.K_s * cfg.D   # one stratum's training call
+    train_on = args.train_on or (("strata" if call_flop >= 5e8 else "all") if args.scaling == "strong" else "rank0")
     seed = 1337
     exchange = "none (one rank)"
 
