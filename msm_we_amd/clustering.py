@@ -489,6 +489,7 @@ class ClusteringMixin:
             models[int(bb[0])].__dict__["_device_newer"] = True
         predict = {b: False for b in chain}
         pred_tests = {b: 4 for b in chain}   # tests a stratum may run ahead on a "low counts" prediction
+        low_streak = {b: 0 for b in chain}   # consecutive tests of a stratum that found low counts and stopped its chain
         total_calls = int(max((len(c["g"]) for c in chain.values()), default=0))
         span = G  # calls per fused run; 64 after a stop, doubled after a clean run
         t_prev = time.perf_counter()
@@ -564,6 +565,8 @@ class ClusteringMixin:
                 if why == h.STOP_NONE:
                     if predict[b]:
                         pred_tests[b] = min(2 * pred_tests[b], 1 << 20)
+                    elif n_applied and (steps["flags"][mine[:n_applied]] & 1).any():
+                        low_streak[b] = 0   # a test passed without low counts
                     continue
                 stopped = True
                 pred_tests[b] = 4
@@ -572,13 +575,19 @@ class ClusteringMixin:
                     return undo()
                 if why == h.STOP_UNUSED:
                     predict[b] = False
+                    low_streak[b] = 0
                 else:  # the step is applied, its re-seeding is still due: on the host, with the model's RandomState
                     st_l = steps[last]
                     m.__dict__["_device_newer"] = True
                     m._host_reassign(store.Xc.offset(int(st_l["x_off"]) * store.D), store.x_dtype, store.D,
                                      d_rows.offset(int(st_l["rows_off"])), int(st_l["n_b"]))
                     m._counts_cache = None
-                    predict[b] = True
+                    # "low again at the next test" is predicted only from the second low test in a row on: right after a re-seeding
+                    # the re-seeded clusters carry the smallest kept count, so an isolated low test is usually followed by a
+                    # clean one (C5's shape: every low stop was followed by an unused-permutation stop, two runs for one event);
+                    # streaks -- a stratum that is low test after test -- switch to the device's own re-seeding after two stops
+                    low_streak[b] += 1
+                    predict[b] = low_streak[b] >= 2
             # after a stop the next run is short: a stratum that has just been re-seeded carries a speculative permutation on
             # every test (0.1 ms each at 12 500-row batches) and is the likeliest to stop again at its first one
             span = min(64, G) if stopped else min(span * 2, G)
