@@ -491,7 +491,7 @@ class ClusteringMixin:
         pred_tests = {b: 4 for b in chain}   # tests a stratum may run ahead on a "low counts" prediction
         low_streak = {b: 0 for b in chain}   # consecutive tests of a stratum that found low counts and stopped its chain
         total_calls = int(max((len(c["g"]) for c in chain.values()), default=0))
-        span = G  # calls per fused run; 64 after a stop, doubled after a clean run
+        span = G  # calls per fused run; 64 after a stop, four times as many after every clean run
         t_prev = time.perf_counter()
         g_lo = 0
         n_runs = 0
@@ -590,7 +590,7 @@ class ClusteringMixin:
                     predict[b] = low_streak[b] >= 2
             # after a stop the next run is short: a stratum that has just been re-seeded carries a speculative permutation on
             # every test (0.1 ms each at 12 500-row batches) and is the likeliest to stop again at its first one
-            span = min(64, G) if stopped else min(span * 2, G)
+            span = min(64, G) if stopped else min(span * 4, G)
             if n_runs > 64 + total_calls // 8:
                 log.info("training plan keeps mispredicting: rerunning stepwise")
                 return undo()
