@@ -109,9 +109,9 @@ struct hamsm_ctx {
   bool capturing = false;   // ... while its stream capture is open (no event timing inside)
 #endif
   // the E-step of training calls that are bound by the f64 matrix unit ranks the centroids on the bf16 unit (k_step_assign_ranked,
-  // train.hip; same labels): 0 never, 1 when a run's heaviest launch group has >= step_ranked_min_flop (default), 2 always
+  // train.hip; same labels): 0 never, 1 when a run's heaviest call has >= step_ranked_min_flop (default), 2 always
   int step_ranked = 1;                      // HAMSM_STEP_RANKED
-  double step_ranked_min_flop = 1.0e9;      // HAMSM_STEP_RANKED_MFLOP
+  double step_ranked_min_flop = 1.5e8;      // HAMSM_STEP_RANKED_MFLOP: flop of a run's heaviest call from which the ranked E-step is taken
   unsigned long long rank_stat[4] = {0, 0, 0, 0};  // rows certified / settled between two candidates / swept exactly; runs
   int generic_stage_kb = 150;  // D > 128: the E-step stages its 16 rows in LDS while they fit this (HAMSM_GENERIC_STAGE_KB; 0 = never)
   // hamsm_malloc / hamsm_free keep released blocks for reuse (hipMalloc costs ~1 ms per 40 MB block and hipFree

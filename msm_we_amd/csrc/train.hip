@@ -2979,15 +2979,16 @@ static int run_steps(hamsm_ctx *c, const void *X, int dt, int64_t ldx, const int
   const size_t mb_bytes = sizeof(unsigned long long) * (size_t)nslot * Kmax * wstride;
   size_t o_mb = take(mb_bytes), o_tail = take(sizeof(StepDev) * (size_t)c->S);
   // Calls whose E-step is bound by the f64 matrix unit rank their centroids on the bf16 unit instead (k_step_assign_ranked: same
-  // labels).  Decided per run -- the fragments are maintained from step to step -- by its heaviest launch group; at most 64
-  // features, a planned pass with row lists.  HAMSM_STEP_RANKED = 0 never, 1 by size (default), 2 always (tests).
+  // labels).  Decided per run -- the fragments are maintained from step to step -- by its heaviest CALL (rows x centroids x
+  // features x 2 of one stratum's step: 0.15 GFLOP by default -- tools/rankgate.py: at 0.04 GFLOP, C3, the f64 kernel is 1.3x
+  // faster, at 0.16 the two are even, at 0.3 the ranked one is 1.5x faster, at 2 GFLOP, C5, 4.7x); at most 64 features, a planned
+  // pass with row lists.  HAMSM_STEP_RANKED = 0 never, 1 by size (default), 2 always (tests).
   const int KBr = (c->D + 15) / 16;
   bool ranked = c->step_ranked && c->assign_filter && !generic && c->KS <= 16 && d_rows && h_report && nslot == c->S;
   if (ranked && c->step_ranked == 1) {
     double top = 0;
-    for (size_t g = 0; g + 1 < gstart.size(); g++) {
-      double flop = 0;
-      for (int64_t q = gstart[g]; q < gstart[g + 1]; q++) flop += 2.0 * (double)h_steps[q].n_b * c->st[h_steps[q].stratum].K * c->D;
+    for (int64_t q = 0; q < n_steps; q++) {
+      const double flop = 2.0 * (double)h_steps[q].n_b * c->st[h_steps[q].stratum].K * c->D;
       top = flop > top ? flop : top;
     }
     ranked = top >= c->step_ranked_min_flop;

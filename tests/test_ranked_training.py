@@ -2,7 +2,7 @@
 matrix unit from fragments the M-step maintains, a label final only under a proven bound, rows between two candidates settled by
 the contract's two f64 chains, everything else swept exactly.  The labels are the contract's by construction, so a whole planned
 pass -- seeding, steps, re-seeding on the device, stop / settle / resume -- must stay bit-identical to the oracle with this path
-FORCED on shapes of every kind (production takes it by size: >= 1 GFLOP per launch group, BASELINE config 5's regime).
+FORCED on shapes of every kind (production takes it by size: >= 0.15 GFLOP per call, BASELINE config 5's regime).
 Arithmetic it must reproduce: sklearn `_k_means_lloyd.pyx:168-218` as called from `/root/reference/msm_we/_hamsm/_clustering.py:909-911`."""
 import ctypes
 
@@ -115,7 +115,7 @@ def test_ranked_pass_with_adversarial_rows(hip_h, oracle_h):
 
 def test_c5_shape_takes_the_ranked_path_by_size(hip_lib, oracle_lib):
     """BASELINE config 5's shape (50 000 segments per iteration, 64 features, 4 x 1250): the shipped default takes the ranked
-    E-step there (>= 1 GFLOP per launch group); 3 iterations against the oracle, bit for bit, and most rows certified"""
+    E-step there (>= 0.15 GFLOP per call); 3 iterations against the oracle, bit for bit, and most rows certified"""
     from conftest import RectilinearBinMapper
     from msm_we_amd import _abi
     from msm_we_amd.data import DeviceStore
