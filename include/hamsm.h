@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define HAMSM_ABI_VERSION 8
+#define HAMSM_ABI_VERSION 9
 
 #define HAMSM_OK 0
 #define HAMSM_EINVAL (-1)   /* bad argument / call order                                         */
@@ -69,6 +69,14 @@ int hamsm_malloc_host(hamsm_ctx *ctx, size_t bytes, void **h_out);
 int hamsm_free_host(hamsm_ctx *ctx, void *h_ptr);
 int hamsm_memcpy_h2d_async(hamsm_ctx *ctx, void *d_dst, const void *h_src, size_t bytes);
 int hamsm_copy_sync(hamsm_ctx *ctx);
+/* (ABI 9) Page-locked host blocks that belong to the PROCESS, not to a context: the destination of the discretization's
+ * device-to-host copy.  The reference's post-condition is host arrays (`self.dtrajs`, `self.pair_dtrajs`,
+ * `_clustering.py:1206-1240`); the caller's arrays are views of such a block and may outlive the context that filled them, so the
+ * block is freed by its owner (hamsm_host_block_free), never by hamsm_destroy.  A device-to-host copy into pageable memory runs
+ * at ~6 GB/s here (the runtime stages it through its own bounce buffer); into a page-locked block at the link's rate.
+ * Returns HAMSM_OK / HAMSM_EINVAL / HAMSM_ENOMEM (no context: no hamsm_last_error text).                                      */
+int hamsm_host_block_alloc(size_t bytes, void **h_out);
+int hamsm_host_block_free(void *h_ptr);
 /* float32 frames already resident in HBM widened to float64, exactly (d_dst[i] = (double)d_src[i], i < count; the buffers must
  * not overlap).  Staging starts in float32 (WESTPA's auxdata/coord, augmentation_driver.py:173-180; the reference up-casts to
  * float64 on load, _data.py:265,565) and switches to float64 in the middle of its one pass when a block holds a value float32

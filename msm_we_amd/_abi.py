@@ -20,7 +20,7 @@ _vp, _i32, _i64, _f64, _sz = C.c_void_p, C.c_int32, C.c_int64, C.c_double, C.c_s
 _int = C.c_int
 
 # name -> (restype, argtypes); kept in the order of include/hamsm.h
-ABI_VERSION = 8  # HAMSM_ABI_VERSION of include/hamsm.h
+ABI_VERSION = 9  # HAMSM_ABI_VERSION of include/hamsm.h
 
 SYMBOLS = {
     "hamsm_abi_version": (_int, []),
@@ -37,6 +37,8 @@ SYMBOLS = {
     "hamsm_free_host": (_int, [_vp, _vp]),
     "hamsm_memcpy_h2d_async": (_int, [_vp, _vp, _vp, _sz]),
     "hamsm_copy_sync": (_int, [_vp]),
+    "hamsm_host_block_alloc": (_int, [_sz, C.POINTER(_vp)]),
+    "hamsm_host_block_free": (_int, [_vp]),
     "hamsm_widen_f32": (_int, [_vp, _vp, _vp, _i64]),
     "hamsm_nan_rows": (_int, [_vp, _vp, _int, _i64, _int, _i64, _vp]),
     "hamsm_host_copy_parts": (_int, [_vp, _i64, _vp, _vp, _vp, _int]),
@@ -192,6 +194,64 @@ def _dp(b):
     if isinstance(b, DevBuf):
         return b.ptr
     return int(b)
+
+
+class HostBlock:
+    """A page-locked host block of the PROCESS (`hamsm_host_block_alloc`, ABI 9) as the owner of NumPy views: `array()` returns an
+    ndarray whose `base` chain ends in the block, so the memory lives exactly as long as some view of it does -- independent of
+    any context.  Page-locking costs ~0.3 ms per MB, so released blocks are kept for the next request of the same size (a build
+    discretizes the same run up to four times, block validation more often): at most `POOL_BLOCKS` per size and `POOL_BYTES` in
+    all, the rest is unlocked and freed."""
+
+    POOL_BLOCKS, POOL_BYTES = 2, 4 << 30
+    _pool: dict = {}          # (library handle, nbytes) -> [addresses]
+    _pooled_bytes = 0
+
+    def __init__(self, lib, nbytes):
+        self.lib, self.nbytes = lib, max(int(nbytes), 1)
+        free = HostBlock._pool.get((lib._handle, self.nbytes))
+        if free:
+            self.ptr = free.pop()
+            HostBlock._pooled_bytes -= self.nbytes
+        else:
+            p = _vp()
+            rc = lib.hamsm_host_block_alloc(self.nbytes, C.byref(p))
+            if rc != 0 or not p.value:
+                raise MemoryError(f"hamsm_host_block_alloc({self.nbytes}) failed with status {rc}")
+            self.ptr = p.value
+        self.__array_interface__ = {"data": (self.ptr, False), "shape": (self.nbytes,), "typestr": "|u1", "version": 3}
+
+    @classmethod
+    def array(cls, lib, shape, dtype) -> np.ndarray:
+        shape = (int(shape),) if np.isscalar(shape) else tuple(int(x) for x in shape)
+        count = int(np.prod(shape, dtype=np.int64))
+        blk = cls(lib, count * np.dtype(dtype).itemsize)
+        return np.asarray(blk)[: count * np.dtype(dtype).itemsize].view(dtype).reshape(shape)
+
+    def __del__(self):
+        ptr, self.ptr = getattr(self, "ptr", None), None
+        if not ptr:
+            return
+        try:
+            free = HostBlock._pool.setdefault((self.lib._handle, self.nbytes), [])
+            if len(free) < HostBlock.POOL_BLOCKS and HostBlock._pooled_bytes + self.nbytes <= HostBlock.POOL_BYTES:
+                free.append(ptr)
+                HostBlock._pooled_bytes += self.nbytes
+            else:
+                self.lib.hamsm_host_block_free(ptr)
+        except Exception:  # noqa: BLE001  (interpreter shutdown: the process is going away with its mappings)
+            pass
+
+    @classmethod
+    def drain(cls):
+        """unlock and free every pooled block"""
+        libs = {}
+        for (hd, nb), free in list(cls._pool.items()):
+            while free:
+                ptr = free.pop()
+                cls._pooled_bytes -= nb
+                libs.setdefault(hd, C.CDLL(None, handle=hd)).hamsm_host_block_free(_vp(ptr))
+        cls._pool.clear()
 
 
 class Hamsm:
@@ -439,12 +499,16 @@ class Hamsm:
         self._ck(self.lib.hamsm_assign(self.ctx, _dp(d_X), int(x_dtype), int(ldx), _dp(d_pcoord), int(n),
                                        _dp(d_labels), _dp(d_seen)))
 
-    def labels_to_host(self, d_parent, d_child, n):
-        """-> (child int64[n], pairs int64[n, 2]): the discretization in the reference's layout"""
-        child = np.empty(int(n), dtype=np.int64)
-        pairs = np.empty((int(n), 2), dtype=np.int64)
-        self._ck(self.lib.hamsm_labels_to_host(self.ctx, _dp(d_parent), _dp(d_child), int(n), _hp(child), _hp(pairs)))
-        return child, pairs
+    def labels_to_host(self, d_parent, d_child, n, child=True, pairs=True):
+        """-> (child int64[n] | None, pairs int64[n, 2] | None): the discretization in the reference's layout
+        (`_clustering.py:1226-1240`), widened and interleaved on the device and copied into page-locked process-level blocks
+        (`HostBlock`: the arrays are views of them and keep them alive -- also past this context's `close()`)."""
+        n = int(n)
+        a_child = HostBlock.array(self.lib, n, np.int64) if child else None
+        a_pairs = HostBlock.array(self.lib, (n, 2), np.int64) if pairs else None
+        self._ck(self.lib.hamsm_labels_to_host(self.ctx, _dp(d_parent), _dp(d_child), n,
+                                               _hp(a_child) if child else None, _hp(a_pairs) if pairs else None))
+        return a_child, a_pairs
 
     def predict_host(self, X: np.ndarray, pcoord: np.ndarray, want_seen=False):
         X = np.ascontiguousarray(X)

@@ -153,36 +153,23 @@ class ClusteringMixin:
         trains_here = by_strata or rank == 0
         tstore, t_maxIter = self.training_store()
         all_filled = set()
+        train_error = None
         if trains_here:
-            if iters_to_use is None:  # :640-651
-                iters_to_use = range(first_cluster_iter if first_cluster_iter is not None else 1, t_maxIter)
-            if not (isinstance(iters_to_use, range) and iters_to_use.step == 1):
-                iters_to_use = [int(i) for i in iters_to_use]
-            # a5 planning support: raw bin (or -1 in basis/target) of every frame's PARENT pcoord
-            # (:849-852 pcoord0List, quirk Q2) + per-iteration histograms, one pass over p0
-            d_bin = h.alloc(tstore.N, np.int32)
-            if self._mapper_external:
-                h.set_frame_bins(self._frame_bins("p0", bin_mapper, tstore))
-            hist = h.train_prepass(tstore.p0, tstore.N, tstore.offsets, d_bin)
-            d_rows = h.alloc(max(tstore.N, 1), np.int32)
-            plan, all_filled = self._plan_training_calls(hist, iters_to_use, n_clusters, bin_mapper, store=tstore, maxIter=t_maxIter)
-            if by_strata:   # the plan is a function of the histogram only: the same on every rank; each fits its own strata
-                mine = (np.arange(S) % R) == rank
-                plan["fit"] = plan["fit"] & mine[None, :]
-            done = False
-            if getattr(self, "speculative_training", True):
-                done = self._train_planned(plan, clusters, tstore, d_bin, d_rows)
-            if not done:
-                self._train_stepwise(plan, clusters, tstore, d_bin, d_rows)
-            self.training_path = "planned" if done else "stepwise"
-            d_bin.free()
-            d_rows.free()
-
-        # :718-731 never-trained bins are remapped to the nearest trained one
-        true_unfilled = np.setdiff1d(range(S), list(all_filled))
-        if trains_here:
-            for ub in true_unfilled:
-                clusters.we_remap[int(ub)] = int(self.find_nearest_bin(bin_mapper, ub, list(all_filled)))
+            # with more than one rank NOTHING rank-local may raise between here and the exchange below -- the other
+            # ranks would wait inside a collective for ever.  A failure of this rank's training phase (n_samples < n_clusters,
+            # a library error, out of memory ...) is carried into `_all_ranks_ok` and raised on EVERY rank.
+            try:
+                all_filled = self._train_on_this_rank(clusters, tstore, t_maxIter, iters_to_use, first_cluster_iter, n_clusters,
+                                                      bin_mapper, by_strata, S, R, rank)
+                # :718-731 never-trained bins are remapped to the nearest trained one
+                for ub in np.setdiff1d(range(S), list(all_filled)):
+                    clusters.we_remap[int(ub)] = int(self.find_nearest_bin(bin_mapper, ub, list(all_filled)))
+            except Exception as e:  # noqa: BLE001
+                if R == 1:
+                    raise
+                train_error = e
+        if R > 1:
+            self._all_ranks_ok(train_error, "training")
         if getattr(h, "nranks", 1) > 1:
             # exchange step 1: centroids / counts / ||c||^2 of every stratum and the remap table, rank 0 -> all
             # (replaces ray.put(deepcopy(clusters)), _clustering.py:1171-1174)
@@ -221,6 +208,54 @@ class ClusteringMixin:
         self.n_clusters = n_clusters * S  # :742 (quirk Q3)
         self.clusters.toggle = False
         self.launch_ray_discretization(progress_bar)
+
+    def _train_on_this_rank(self, clusters, tstore, t_maxIter, iters_to_use, first_cluster_iter, n_clusters, bin_mapper,
+                            by_strata, S, R, rank):
+        """the rank-local training phase of `cluster_stratified`: plan from the histogram, then the planned (or stepwise) pass over
+        the strata this rank fits.  Returns the set of bins some call fits (the same on every rank: a function of the histogram)."""
+        h = self.h
+        if iters_to_use is None:  # :640-651
+            iters_to_use = range(first_cluster_iter if first_cluster_iter is not None else 1, t_maxIter)
+        if not (isinstance(iters_to_use, range) and iters_to_use.step == 1):
+            iters_to_use = [int(i) for i in iters_to_use]
+        # a5 planning support: raw bin (or -1 in basis/target) of every frame's PARENT pcoord
+        # (:849-852 pcoord0List, quirk Q2) + per-iteration histograms, one pass over p0
+        d_bin = h.alloc(tstore.N, np.int32)
+        d_rows = None
+        try:
+            if self._mapper_external:
+                h.set_frame_bins(self._frame_bins("p0", bin_mapper, tstore))
+            hist = h.train_prepass(tstore.p0, tstore.N, tstore.offsets, d_bin)
+            d_rows = h.alloc(max(tstore.N, 1), np.int32)
+            plan, all_filled = self._plan_training_calls(hist, iters_to_use, n_clusters, bin_mapper, store=tstore, maxIter=t_maxIter)
+            if by_strata:   # the plan is a function of the histogram only: the same on every rank; each fits its own strata
+                mine = (np.arange(S) % R) == rank
+                plan["fit"] = plan["fit"] & mine[None, :]
+            done = False
+            if getattr(self, "speculative_training", True):
+                done = self._train_planned(plan, clusters, tstore, d_bin, d_rows)
+            if not done:
+                self._train_stepwise(plan, clusters, tstore, d_bin, d_rows)
+            self.training_path = "planned" if done else "stepwise"
+        finally:
+            d_bin.free()
+            if d_rows is not None:
+                d_rows.free()
+        return all_filled
+
+    def _all_ranks_ok(self, error, what):
+        """a collective success flag (min over the ranks of `error is None`): every rank leaves with the same outcome -- the
+        rank that failed re-raises its own exception, the others raise a RuntimeError naming the phase"""
+        h = self.h
+        d = h.to_device(np.array([0.0 if error is not None else 1.0]))
+        h.allreduce_min_f64(d, 1)
+        ok = float(d.to_host()[0]) > 0.5
+        d.free()
+        if error is not None:
+            raise error
+        if not ok:
+            raise RuntimeError(f"{what} failed on another rank (its own exception is raised there); this rank stops with it "
+                               "instead of waiting in the next collective")
 
     # ------------------------------------------------------------------------------------------
     def _plan_training_calls(self, hist, iters_to_use, n_clusters, bin_mapper, store=None, maxIter=None):
@@ -367,7 +402,10 @@ class ClusteringMixin:
 
         h = self.h
         G = len(plan["first"])
-        if G == 0:
+        if G == 0 or not plan["fit"].any():
+            # nothing to fit here: no call at all, or (train_shards = "strata") a rank that owns no fitted stratum -- more ranks
+            # than strata, or every stratum s with s % nranks == rank never filled (this used to die on `z[0]`
+            # below while the other ranks were already inside hamsm_bcast_strata)
             return True
         models = clusters.cluster_models
         ratios = {m.reassignment_ratio for m in models}
@@ -646,18 +684,19 @@ class ClusteringMixin:
                     if np.any(lab[mask] < Kfit):
                         raise ValueError("Input contains NaN.")
 
-    # dtrajs / pair_dtrajs are host views of the device labels, materialised on first access
-    def _labels_host(self):
+    # dtrajs / pair_dtrajs are host views of the device labels, materialised on first access -- each by itself: `dtrajs` costs
+    # one 8 N-byte device-to-host copy into a page-locked block, `pair_dtrajs` one of 16 N bytes (the
+    # pageable copy of both took 13 ms at C3; `_abi.HostBlock`)
+    def _labels_host(self, which):
         if getattr(self, "_d_child", None) is None:  # unpickled / never discretized: the plain host lists
-            return self.__dict__.get("_dtrajs_plain", []), self.__dict__.get("_pairs_plain", [])
-        if getattr(self, "_dtrajs_cache", None) is None:
-            # widened to int64 and interleaved on the device, two copies; the per-iteration arrays are views of them
-            child, pairs = self.h.labels_to_host(self._d_parent, self._d_child, self._n_labelled)
-            offs = self._store.offsets
-            n_it = self.maxIter - 1
-            self._dtrajs_cache = [child[offs[i]: offs[i + 1]] for i in range(n_it)]
-            self._pairs_cache = [pairs[offs[i]: offs[i + 1]] for i in range(n_it)]
-        return self._dtrajs_cache, self._pairs_cache
+            return self.__dict__.get("_dtrajs_plain" if which == 0 else "_pairs_plain", [])
+        key = "_dtrajs_cache" if which == 0 else "_pairs_cache"
+        if getattr(self, key, None) is None:
+            # widened to int64 (and interleaved) on the device; the per-iteration arrays are views of the one host block
+            flat = self.h.labels_to_host(self._d_parent, self._d_child, self._n_labelled, child=which == 0, pairs=which == 1)[which]
+            offs = self._store.offsets[: self.maxIter].tolist()
+            setattr(self, key, [flat[a:b] for a, b in zip(offs[:-1], offs[1:])])
+        return getattr(self, key)
 
     def _labels_device(self):
         """(d_parent, d_child) -- uploaded again from the host lists when the model came out of a pickle"""
@@ -675,7 +714,7 @@ class ClusteringMixin:
     @property
     def dtrajs(self):
         """list over iterations 1..maxIter-1 of child-frame labels (`_clustering.py:1226,1238`)."""
-        return self._labels_host()[0]
+        return self._labels_host(0)
 
     @dtrajs.setter
     def dtrajs(self, v):
@@ -685,7 +724,7 @@ class ClusteringMixin:
     def pair_dtrajs(self):
         """per iteration an (nSeg, 2) array of (parent, child) labels -- `np.array(pair_dtrajs[i])` of the
         reference's list of tuples (`_clustering.py:1228,1240`; `_fluxmatrix.py:288`)."""
-        return self._labels_host()[1]
+        return self._labels_host(1)
 
     @pair_dtrajs.setter
     def pair_dtrajs(self, v):

@@ -298,6 +298,21 @@ extern "C" int hamsm_free_host(hamsm_ctx *c, void *p) {
   HIPCHK(c, hipHostFree(p));
   return HAMSM_OK;
 }
+// (ABI 9) process-level page-locked blocks: owned by the caller's arrays, not by a context (hamsm.h)
+extern "C" int hamsm_host_block_alloc(size_t bytes, void **out) {
+  if (!out) return HAMSM_EINVAL;
+  void *p = nullptr;
+  if (hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocPortable) != hipSuccess) {
+    (void)hipGetLastError();
+    return HAMSM_ENOMEM;
+  }
+  *out = p;
+  return HAMSM_OK;
+}
+extern "C" int hamsm_host_block_free(void *p) {
+  if (!p) return HAMSM_OK;
+  return hipHostFree(p) == hipSuccess ? HAMSM_OK : HAMSM_EINVAL;
+}
 extern "C" int hamsm_memcpy_h2d_async(hamsm_ctx *c, void *d, const void *h, size_t n) {
   CTX(c);
   if (n == 0) return HAMSM_OK;

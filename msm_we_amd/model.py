@@ -98,8 +98,7 @@ class modelWE(DataMixin, ClusteringMixin, FluxMatrixMixin, AnalysisMixin):
         d = dict(self.__dict__)
         d["_d_fluxMatrixRaw"] = d["_d_fluxMatrix"] = None
         if d.get("_d_child") is not None:
-            dtr, pairs = self._labels_host()
-            d["_dtrajs_plain"], d["_pairs_plain"] = dtr, pairs
+            d["_dtrajs_plain"], d["_pairs_plain"] = self._labels_host(0), self._labels_host(1)
         for k in self._DEVICE_STATE:
             if k in d:
                 d[k] = None

@@ -218,6 +218,16 @@ int hamsm_free(hamsm_ctx *c, void *p) {
 }
 int hamsm_malloc_host(hamsm_ctx *c, size_t bytes, void **out) { return hamsm_malloc(c, bytes, out); }
 int hamsm_free_host(hamsm_ctx *c, void *p) { return hamsm_free(c, p); }
+/* (ABI 9) process-level host blocks: plain heap here (there is no device to copy from) */
+int hamsm_host_block_alloc(size_t bytes, void **out) {
+  if (!out) return HAMSM_EINVAL;
+  *out = malloc(bytes ? bytes : 1);
+  return *out ? HAMSM_OK : HAMSM_ENOMEM;
+}
+int hamsm_host_block_free(void *p) {
+  free(p);
+  return HAMSM_OK;
+}
 int hamsm_memcpy_h2d_async(hamsm_ctx *c, void *d, const void *h, size_t n) {
   CTX(c);
   memcpy(d, h, n);

@@ -78,6 +78,10 @@ def hip_lib():
     if os.environ.get("HAMSM_HIP_STANDIN"):
         # sanitizer runs only (oracle/run_asan.sh --gpu-logic): the GPU suite's host logic with a second copy of the oracle in
         # the product's seat, so that AddressSanitizer sees every buffer the tests hand across the ABI.  Never set by the driver.
+        # the switch must not be able to turn `-m gpu` green on a box that HAS a GPU -- there it is an error.
+        if os.path.exists("/dev/kfd"):
+            raise RuntimeError("HAMSM_HIP_STANDIN is set on a machine with a GPU (/dev/kfd): the stand-in is for the CPU "
+                               "sanitizer script only (oracle/run_asan.sh --gpu-logic); unset it")
         import shutil, tempfile
         twin = os.path.join(tempfile.mkdtemp(), "libhamsm_standin.so")
         shutil.copy(os.environ["HAMSM_HIP_STANDIN"], twin)
@@ -102,6 +106,13 @@ def hip_h(hip_lib):
     assert h.backend == "hip-gfx950" or os.environ.get("HAMSM_HIP_STANDIN")
     yield h
     h.close()
+
+
+@pytest.fixture(params=["oracle", pytest.param("hip", marks=pytest.mark.gpu)])
+def any_h(request):
+    """the same test body on the oracle (CPU suite) and, under `-m gpu`, on the HIP library (host-side
+    pipelines -- staging, the NTL9 fixture chain -- were only ever run on the oracle's handle)"""
+    return request.getfixturevalue("oracle_h" if request.param == "oracle" else "hip_h")
 
 
 class RectilinearBinMapper:

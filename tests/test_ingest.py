@@ -228,35 +228,86 @@ def test_h5_source_without_h5py_says_so(monkeypatch):
         data.WestpaH5Source("west.h5")
 
 
+def _store_arrays(m):
+    st = m._store
+    return [st.Xp.to_host(), st.Xc.to_host(), st.p0.to_host(), st.p1.to_host(), st.w.to_host(), st.w_flux.to_host(),
+            np.concatenate(m.dtrajs)]
+
+
+@pytest.mark.parametrize("readers", [1, 5])
 @pytest.mark.parametrize("layout", [NpzDirectorySource, NpyDirectorySource], ids=["npz", "npy-mmap"])
 @pytest.mark.parametrize("case", ["c1p_d10", "nan_d10"])
-def test_streaming_staging_in_many_blocks(oracle_h, tmp_path, monkeypatch, case, layout):
+def test_streaming_staging_in_many_blocks(any_h, oracle_lib, tmp_path, monkeypatch, case, layout, readers):
     """blocks of ~3 iterations through the two pinned slabs: the staged arrays are those of a single-block staging -- from
     per-iteration .npz files and from the raw memory-mapped .npy layout; NaN-coordinate segments (found on the device,
-    `hamsm_nan_rows`) included"""
+    `hamsm_nan_rows`) included.  On the HIP library (`-m gpu`) this is the `preadv` -> pinned slab ->
+    async H2D on the copy stream -> slab reuse chain with > 10 blocks through the two slabs, 1 and 5 readers: everything staged
+    is read back and must equal, byte for byte, the single-block staging AND what the oracle staged from the in-memory source."""
     from msm_we_amd.model import modelWE
 
     g, meta = load_golden(case)
     src = layout.export(InMemorySource(golden_iterations(g)), tmp_path / "iters")
     assert src.iterations() == sorted(golden_iterations(g)) and layout(tmp_path / "iters").iterations() == src.iterations()
+    monkeypatch.setattr(modelWE, "STAGE_READERS", readers)
     stores = []
     for chunk_bytes in (64 << 20, 3 * 128 * (2 * 10 * 4 + 24)):
         monkeypatch.setattr(modelWE, "STAGE_CHUNK_BYTES", chunk_bytes)
-        m, _ = build_model(oracle_h, g, meta, source=src)
-        st = m._store
-        stores.append([st.Xp.to_host(), st.Xc.to_host(), st.p0.to_host(), st.p1.to_host(), st.w.to_host(), st.w_flux.to_host(),
-                       np.concatenate(m.dtrajs), m.ingest_stats["blocks"]])
+        m, _ = build_model(any_h, g, meta, source=src)
+        stores.append(_store_arrays(m) + [m.ingest_stats["blocks"]])
+        assert m.ingest_stats["readers"] == readers
     assert stores[0][-1] == 1 and stores[1][-1] > 10
     # both layouts' blocks go file -> upload slab (pread of byte ranges: the run-level arrays, or the STORED members of the
     # per-iteration .npz files), never through a per-iteration array
     assert m.ingest_stats["direct_read_blocks"] == m.ingest_stats["blocks"]
     for a, b in zip(stores[0][:-1], stores[1][:-1]):
-        assert np.array_equal(a, b, equal_nan=True)
+        assert a.dtype == b.dtype and np.array_equal(a, b, equal_nan=True)
     assert np.array_equal(stores[1][6], g["dtrajs_post_cluster"])
+    if any_h.backend != "cpu-oracle":
+        # the oracle's store of the same run (in-memory source, one block): the device holds exactly these bytes
+        ho = _abi.Hamsm(lib=oracle_lib)
+        try:
+            mo, _ = build_model(ho, g, meta)
+            for a, b in zip(_store_arrays(mo), stores[1][:-1]):
+                assert a.dtype == b.dtype and a.shape == b.shape
+                assert np.array_equal(a.view(np.uint8), b.view(np.uint8))     # bytes: NaN payloads included
+        finally:
+            ho.close()
+
+
+@pytest.mark.gpu
+def test_slab_reuse_against_the_copy_stream_with_large_blocks(hip_h, tmp_path, monkeypatch):
+    """the same chain at a size where a slab's H2D copy takes longer than the next block's host read (32 blocks of 4 MB
+    through the two slabs, raw run-level layout, 4 readers): a slab overwritten before its copy drained would show as a
+    block holding the NEXT block's rows.  Every staged byte is read back and compared with the source."""
+    from msm_we_amd.model import modelWE
+
+    rng = np.random.default_rng(11)
+    n_it, segs, D = 64, 4096, 30
+    its = {}
+    for it in range(1, n_it + 1):
+        p0 = rng.uniform(0, 2, (segs, 1))
+        its[it] = dict(Xp=rng.standard_normal((segs, D)).astype(np.float32), Xc=rng.standard_normal((segs, D)).astype(np.float32),
+                       p0=p0, p1=np.clip(p0 + rng.normal(0, 0.3, (segs, 1)), 0, 2.4), w=rng.exponential(1.0, segs))
+    src = NpyDirectorySource.export(InMemorySource(its), tmp_path / "run")
+    monkeypatch.setattr(modelWE, "STAGE_CHUNK_BYTES", 4 << 20)
+    monkeypatch.setattr(modelWE, "STAGE_READERS", 4)
+    m = modelWE(h=hip_h)
+    m.set_iteration_source(src)
+    m.initialize(["mem"], dict(coords=None, nAtoms=D, coord_ndim=1), "t", basis_pcoord_bounds=[[-np.inf, 0.05]],
+                 target_pcoord_bounds=[[1.95, np.inf]], dim_reduce_method="none", tau=1.0, pcoord_ndim=1)
+    m.get_iterations()
+    m.dimReduce()
+    st = m.stage_iterations()
+    assert m.ingest_stats["blocks"] >= 16 and m.ingest_stats["direct_read_blocks"] == m.ingest_stats["blocks"]
+    keep = [i for i in sorted(its) if i <= m.maxIter]
+    for name, arr in (("Xp", st.Xp), ("Xc", st.Xc), ("p0", st.p0), ("p1", st.p1), ("w", st.w)):
+        want = np.concatenate([its[i][name] for i in keep])
+        got = arr.to_host().reshape(want.shape)
+        assert got.dtype == want.dtype and np.array_equal(got, want), name
 
 
 @pytest.mark.parametrize("variant", ["deflated", "float64-features", "wide-pcoord"])
-def test_npz_members_that_are_not_plain_byte_ranges_take_the_general_path(oracle_h, tmp_path, monkeypatch, variant):
+def test_npz_members_that_are_not_plain_byte_ranges_take_the_general_path(any_h, tmp_path, monkeypatch, variant):
     """the file -> slab byte-range read of `.npz` members applies to stored members of exactly the slab's dtype and width; a
     deflated archive, float64 features (cast on the way in) or a pcoord wider than `pcoord_ndim` (a strided view) go through the
     general path and stage the same arrays"""
@@ -279,7 +330,7 @@ def test_npz_members_that_are_not_plain_byte_ranges_take_the_general_path(oracle
     monkeypatch.setattr(modelWE, "STAGE_CHUNK_BYTES", 3 * 128 * (2 * 10 * 4 + 24))
     stores = []
     for src in (ref_src, NpzDirectorySource(tmp_path / "odd")):
-        m, _ = build_model(oracle_h, g, meta, source=src)
+        m, _ = build_model(any_h, g, meta, source=src)
         st = m._store
         stores.append([st.Xp.to_host(), st.Xc.to_host(), st.p0.to_host(), st.p1.to_host(), st.w.to_host(), np.concatenate(m.dtrajs)])
         direct = m.ingest_stats["direct_read_blocks"]
@@ -288,17 +339,17 @@ def test_npz_members_that_are_not_plain_byte_ranges_take_the_general_path(oracle
         assert np.array_equal(a, b, equal_nan=True)
 
 
-def test_staging_falls_back_to_float64_when_float32_would_lose_bits(oracle_h):
+def test_staging_falls_back_to_float64_when_float32_would_lose_bits(any_h):
     g, meta = load_golden("c1p_d10")
     its = {k: {a: np.array(b, dtype=np.float64 if a in ("Xp", "Xc") else b.dtype) for a, b in v.items()}
            for k, v in golden_iterations(g).items()}
     its[23]["Xc"][5, 2] += 1e-12        # one value that float32 cannot hold, late in the run
-    m, _ = build_model(oracle_h, g, meta, source=InMemorySource(its), seed_forcing=False)
+    m, _ = build_model(any_h, g, meta, source=InMemorySource(its), seed_forcing=False)
     assert m._store.x_dtype == 1 and m._store.Xc.to_host().reshape(-1, 10)[m._store.offsets[22] + 5, 2] == its[23]["Xc"][5, 2]
 
 
 @pytest.mark.parametrize("late_iteration", [1, 23])
-def test_staging_switches_to_float64_in_the_middle_of_its_one_pass(oracle_h, monkeypatch, late_iteration):
+def test_staging_switches_to_float64_in_the_middle_of_its_one_pass(any_h, monkeypatch, late_iteration):
     """a value float32 cannot hold, met in block k of many: blocks 0..k-1 are widened where they lie (hamsm_widen_f32), block k
     is filled again, no iteration before it is loaded twice -- and the result is the all-float64 staging's"""
     from msm_we_amd.model import modelWE
@@ -319,7 +370,7 @@ def test_staging_switches_to_float64_in_the_middle_of_its_one_pass(oracle_h, mon
 
     monkeypatch.setattr(modelWE, "STAGE_CHUNK_BYTES", 3 * 128 * (2 * 10 * 8 + 24))   # ~3 iterations per block
     src = Counting(its)
-    m = modelWE(h=oracle_h)
+    m = modelWE(h=any_h)
     m.set_iteration_source(src)
     m.initialize(["mem"], dict(coords=None, nAtoms=10, coord_ndim=1), "t", basis_pcoord_bounds=meta["basis"],
                  target_pcoord_bounds=meta["target"], dim_reduce_method="none", tau=1.0, pcoord_ndim=1)
@@ -341,7 +392,7 @@ def test_staging_switches_to_float64_in_the_middle_of_its_one_pass(oracle_h, mon
 
 
 @pytest.mark.parametrize("late_iteration", [1, 23])
-def test_mid_pass_switch_to_float64_in_a_device_mode(oracle_h, monkeypatch, late_iteration):
+def test_mid_pass_switch_to_float64_in_a_device_mode(any_h, monkeypatch, late_iteration):
     """the same switch when the device turns the uploaded block into features (`device_pca`: a fitted linear map applied
     by hamsm_project at staging).  The staged features stay float64 throughout; what changes mid-pass is the width of the RAW
     upload buffers, which are re-allocated -- the staged features must equal the all-float64 staging's bit for bit."""
@@ -372,7 +423,7 @@ def test_mid_pass_switch_to_float64_in_a_device_mode(oracle_h, monkeypatch, late
         its = its_with(bump)
         if force64:
             its[1]["Xp"][0, 0] += 1e-12                   # the very first iteration already needs float64: no switch mid-pass
-        m = modelWE(h=oracle_h)
+        m = modelWE(h=any_h)
         m.set_iteration_source(InMemorySource(its))
         m.initialize(["mem"], dict(coords=None, nAtoms=10, coord_ndim=1), "t", basis_pcoord_bounds=meta["basis"],
                      target_pcoord_bounds=meta["target"], dim_reduce_method="none", tau=1.0, pcoord_ndim=1)
@@ -469,7 +520,8 @@ def test_host_movers_hip(hip_h, tmp_path):
     _host_movers_case(hip_h, tmp_path)
 
 
-def test_reader_pool_stages_the_same_arrays(oracle_h, tmp_path, monkeypatch):
+def test_reader_pool_stages_the_same_arrays(any_h, tmp_path, monkeypatch):
+    oracle_h = any_h
     """several iterations of a block loaded at once (each into its own rows of the pinned slab): same store as one reader;
     user featurizers and sources that do not declare `parallel_safe` keep to one thread"""
     from msm_we_amd.model import modelWE

@@ -1,6 +1,8 @@
 """The reference's own NTL9 fixtures (tests/golden/ntl9, copied data files; reference tests
 tests/test_msm_we.py:148-180): fluxmatrix.npy -> tmatrix.npy -> pSS.npy -> JtargetSS.npy, and the
-strongly-connected-set size implied by fluxmatrix_raw.npy -> 192 kept clusters."""
+strongly-connected-set size implied by fluxmatrix_raw.npy -> 192 kept clusters.
+Every test that touches the library runs on the oracle and, under `-m gpu`, on the HIP library (`any_h`): `hamsm_tmatrix_csr` on the
+GPU against the reference's own `tmatrix.npy`, bit for bit."""
 import os
 
 import numpy as np
@@ -20,8 +22,8 @@ def _model(h):
     return m
 
 
-def test_get_tmatrix(oracle_h):
-    m = _model(oracle_h)
+def test_get_tmatrix(any_h):
+    m = _model(any_h)
     m.get_Tmatrix()
     ref = np.load(os.path.join(NTL9, "tmatrix.npy"))
     assert np.array_equal(m.Tmatrix, ref)  # reference test uses np.allclose; we are bit-identical
@@ -30,13 +32,13 @@ def test_get_tmatrix(oracle_h):
 
 @pytest.mark.parametrize("dense_eig_max, dense_lu_density", [(10 ** 9, 0.10), (0, 0.10), (0, 2.0), (10 ** 9, 2.0)],
                          ids=["eig+lapack", "arpack+lapack", "arpack+superlu", "eig+superlu"])
-def test_get_steady_state_and_target_flux(oracle_h, monkeypatch, dense_eig_max, dense_lu_density):
+def test_get_steady_state_and_target_flux(any_h, monkeypatch, dense_eig_max, dense_lu_density):
     """every solver combination the host solve can pick (dense eig = the reference's chain; ARPACK seed above
     `dense_eig_max` states; LAPACK or SuperLU inverse iteration by matrix density) lands on the reference's numbers"""
     from msm_we_amd import analysis
 
     monkeypatch.setattr(analysis, "DENSE_LU_DENSITY", dense_lu_density)
-    m = _model(oracle_h)
+    m = _model(any_h)
     m.dense_eig_max = dense_eig_max
     m.get_Tmatrix()
     m.get_steady_state()
@@ -58,7 +60,7 @@ def test_connected_set_of_raw_fixture():
     assert 300 - removed == 192  # organized.obj: n_clusters == 192 (quirk Q9)
 
 
-def test_committor_bounds(oracle_h):
-    m = _model(oracle_h)
+def test_committor_bounds(any_h):
+    m = _model(any_h)
     m.get_committor(conv=1e-5)
     assert m.q[192] == 0.0 and m.q[193] == 1.0 and np.all((m.q >= 0) & (m.q <= 1 + 1e-12))
