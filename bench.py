@@ -354,10 +354,134 @@ def full_pipeline(m, cfg, seed, flux_mode):
             "validation_JtargetSS": [float(v.JtargetSS) for v in m.validation_models]}
 
 
+def _c2_setup(h, cfg, d_train):
+    """config 2's model: one stratum, 200 centroids "from a 20 k-row partial_fit"  -- the product's own
+    k-means++ + one mini-batch step on the first 20 iterations' child frames"""
+    from msm_we_amd.stratified_clustering import StratifiedClusters
+
+    h.set_geometry(cfg.D, 1, cfg.S)
+    h.set_mapper_rectilinear([synthetic.strata_boundaries(cfg.S)])
+    basis, target = synthetic.basis_target_bounds(cfg.S)
+    h.set_bounds(basis, target)
+    cl = StratifiedClusters(Mapper([synthetic.strata_boundaries(cfg.S)]), None, cfg.K_s, h=h, random_state=2)
+    cl.cluster_models[0].partial_fit(d_train)
+    cl._activate()
+    return cl
+
+
+def c2_cpu_worker(n_rows):
+    """child process, no GPU: the oracle's `hamsm_assign` (scalar C, one core) over config 2's first `n_rows` child frames"""
+    cfg = bench_configs()["c2"]
+    h = _abi.Hamsm(lib=ctypes.CDLL(ORACLE_SO))
+    _, Xc, _, p1, _, _ = make_shard(cfg, 1, -(-n_rows // cfg.segs_per_iter))
+    Xc, p1 = Xc[:n_rows], p1[:n_rows]
+    _c2_setup(h, cfg, Xc[:20000])
+    d_X, d_p, d_l = h.to_device(Xc), h.to_device(p1), h.alloc(n_rows, np.int32)
+    t0 = time.perf_counter()
+    h.assign(d_X, 0, cfg.D, d_p, n_rows, d_l)
+    dt = time.perf_counter() - t0
+    print(json.dumps({"value": n_rows / dt, "unit": "frames/s", "cores": 1, "kind": "port",
+                      "sample": f"the first {n_rows} of config 2's 1 000 000 child frames, same assign pass, oracle/hamsm_oracle.c "
+                                f"single thread, {dt:.1f} s", "label_checksum": int(d_l.to_host().astype(np.int64).sum())}), flush=True)
+
+
+def measure_c2(device, args, log, reps=1, cpu=True):
+    """BASELINE configs[1]: synthetic 1 M frames x 10 features, 200 clusters, 1 stratum -- distance / assign only.  A step = one
+    `hamsm_assign` over the resident frames (bucket pass + ranking pass + exact pass on what the ranking cannot certify; labels
+    stay in HBM), i.e. what `StratifiedClusters.predict` (stratified_clustering.py:152-196) computes for these frames.
+    `reps` > 1: the same 1 M frames resident `reps` times over (64 M frames: the per-launch fixed costs amortised -- the kernel's
+    asymptote).  Algorithmic bytes per frame: D*4 + 8*ndim + 4 = 52; flops 2*K*D = 4000."""
+    cfg = bench_configs()["c2"]
+    steps, warmup = max(args.steps, 20), max(args.warmup, 5)
+    h = _abi.Hamsm(lib=ctypes.CDLL(args.lib) if args.lib else None, device=device)
+    try:
+        _, Xc, _, p1, _, _ = make_shard(cfg, 1, cfg.n_iters if not args.c2_frames else -(-args.c2_frames // cfg.segs_per_iter))
+        if args.c2_frames:
+            Xc, p1 = Xc[: args.c2_frames], p1[: args.c2_frames]
+        n1 = len(p1)
+        _c2_setup(h, cfg, Xc[:20000])
+        n = n1 * reps
+        d_X, d_p, d_l = h.alloc((n, cfg.D), np.float32), h.alloc((n, 1), np.float64), h.alloc(n, np.int32)
+        for r in range(reps):
+            h.h2d(d_X.offset(r * n1 * cfg.D), Xc)
+            h.h2d(d_p.offset(r * n1), p1)
+        for _ in range(warmup):
+            h.assign(d_X, 0, cfg.D, d_p, n, d_l)
+        h.sync()
+        h.timers(reset=True)
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            h.assign(d_X, 0, cfg.D, d_p, n, d_l)
+        h.sync()
+        elapsed = time.perf_counter() - t0
+        timers = h.timers()
+        lab = d_l.to_host()
+        # the labels of every repeat are those of the first (the kernel buckets frames per chunk: position must not matter)
+        if reps > 1 and not all(np.array_equal(lab[:n1], lab[r * n1: (r + 1) * n1]) for r in range(1, reps)):
+            raise SystemExit("[bench] c2: labels differ between repeats of the same frames")
+        checksum = int(lab[:n1].astype(np.int64).sum())
+        # the reference's post-condition: labels on the host
+        t0 = time.perf_counter()
+        for _ in range(3):
+            h.assign(d_X, 0, cfg.D, d_p, n, d_l)
+            a = _abi.HostBlock.array(h.lib, n, np.int32)
+            h.d2h(a, d_l)
+        h.sync()
+        step_labels_s = (time.perf_counter() - t0) / 3
+        del a
+        k_ms = timers["assign"] * 1e3 / steps           # ranking + exact kernels per step (HIP events on the library's stream)
+        o_ms = timers["other"] * 1e3 / steps            # the bucket passes of the same call
+        bytes_alg = (cfg.D * 4 + 8 + 4) * n
+        flops = 2.0 * cfg.K_s * cfg.D * n
+        gbs = bytes_alg / (k_ms * 1e-3) / 1e9 if k_ms > 0 else float("nan")
+        tf = flops / (k_ms * 1e-3) / 1e12 if k_ms > 0 else float("nan")
+        # which roof binds: 4000 flop / 52 B = 77 flop/B; the ranking pass runs on the bf16 matrix unit with 3 piece products per
+        # f32 product (ridge 2500/3 TF / 8 TB/s = 104 flop/B) -> below the ridge: HBM is the roof of this shape
+        out = {"metric": "frames/sec assigned (distance / assign only)", "value": n * steps / elapsed, "unit": "frames/s",
+               "n_gpus": 1, "steps": steps, "warmup": warmup, "ms_per_step": elapsed * 1e3 / steps, "higher_is_better": True,
+               "dtype": "f64", "data": "synthetic",
+               "config": {"workload": f"c2: {n} frames ({reps} x 1000 WE iterations x 1000 segments) x {cfg.D} f32 features, "
+                                      f"1 stratum x {cfg.K_s} clusters; one hamsm_assign pass over the resident child frames per step",
+                          "frames": n, "repeats_of_the_1M_frames": reps},
+               "roofline": {"bound": "hbm", "achieved": gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": gbs / PEAK_HBM_GBS,
+                            "traffic": pmc_kernel_bytes("k_assign_filter", "c2" if reps == 1 else f"c2_x{reps}"),
+                            "traffic_source": (f"profiles/{os.path.basename(pmc_file('c2' if reps == 1 else f'c2_x{reps}'))} (committed "
+                                               "rocprofv3 --pmc passes of this workload; not measured in this run)")
+                            if pmc_file("c2" if reps == 1 else f"c2_x{reps}") else None,
+                            "kernel": "k_assign_filter (bf16 x 3 ranking pass on the matrix unit) + k_assign_sorted (exact f64 pass over "
+                                      "the frames the ranking cannot certify)",
+                            "algorithmic_bytes_per_launch": bytes_alg, "flop_per_launch": flops, "avg_launch_ms": k_ms,
+                            "achieved_TFLOPs": tf, "mfma_roof_TFLOPs": PEAK_BF16_MFMA_TFLOPS / 3.0,
+                            "frac_of_mfma_roof": tf / (PEAK_BF16_MFMA_TFLOPS / 3.0),
+                            "which_roof": "52 B and 4000 flop per frame = 77 flop/B, under the ridge of the bf16/3 ranking pass "
+                                          "(104 flop/B): HBM binds"},
+               "stage_ms_per_step": {"assign_kernels": k_ms, "bucket_passes": o_ms, "host_and_gaps": elapsed * 1e3 / steps - k_ms - o_ms},
+               "whole_call": {"GBps": bytes_alg / (elapsed / steps) / 1e9, "frac": bytes_alg / (elapsed / steps) / 1e9 / PEAK_HBM_GBS},
+               "step_incl_host_labels": {"ms_per_step": step_labels_s * 1e3, "value": n / step_labels_s, "unit": "frames/s"},
+               "label_checksum": checksum}
+        if cpu:
+            import subprocess
+
+            r = subprocess.run([sys.executable, os.path.abspath(__file__), "--c2-cpu-worker", str(n1)], capture_output=True, text=True,
+                               check=True, env=dict(os.environ, HIP_VISIBLE_DEVICES="", OMP_NUM_THREADS="1", OPENBLAS_NUM_THREADS="1"))
+            cb = json.loads(r.stdout.strip().splitlines()[-1])
+            if cb.pop("label_checksum") != checksum:
+                raise SystemExit("[bench] c2: the GPU's labels differ from the CPU oracle's on the same frames")
+            cb["labels_equal_gpu"] = True
+            cb["gpu_over_cpu"] = out["value"] / cb["value"]
+            out["cpu_baseline"] = cb
+        log(f"c2 x{reps}: {out['ms_per_step']:.3f} ms per step, kernels {k_ms:.3f} ms = {gbs:.0f} GB/s algorithmic")
+        return out
+    finally:
+        h.close()
+
+
 def pmc_file(workload):
     """the committed rocprofv3 --pmc summary of this workload (latest round first); None when there is none"""
-    names = {"c3": ["r04_pmc_summary.csv", "r03_pmc_summary.csv", "r02_pmc_summary.csv"], "c5s": ["r04_pmc_summary_c5s.csv"],
-             "c5": ["r04_pmc_summary_c5s.csv"]}.get(workload, [])   # (c5's launches are c5s's: same per-iteration shapes)
+    names = {"c3": ["r05_pmc_summary.csv", "r04_pmc_summary.csv", "r03_pmc_summary.csv", "r02_pmc_summary.csv"],
+             "c5s": ["r05_pmc_summary_c5s.csv", "r04_pmc_summary_c5s.csv"], "c2": ["r05_pmc_summary_c2.csv"],
+             "c2_x64": ["r05_pmc_summary_c2_x64.csv"],
+             "c5": ["r05_pmc_summary_c5s.csv", "r04_pmc_summary_c5s.csv"]}.get(workload, [])   # (c5's launches are c5s's: same per-iteration shapes)
     for n in names:
         p = os.path.join(ROOT, "profiles", n)
         if os.path.exists(p):
@@ -416,7 +540,9 @@ def step_roofline(cfg, n_iters, n_seg, e_ms, e_n, m_ms, e_events_ms, ranked=Fals
                           "for the two strata of a queue",
                 "note": "what binds it is the fragment stream out of L2 (every workgroup reads its stratum's 256 B per centroid) and the "
                         "chain prologue -> sweep -> merge -> settle of 195 workgroups per launch, not the matrix unit (DESIGN.md 5.3e)"}
-    return {"bound": "mfma", "achieved": tf, "peak": PEAK_F64_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": tf / PEAK_F64_MFMA_TFLOPS, **common,
+    # what binds this kernel at C3 is the latency of its dependent chain, not the matrix unit; `frac` stays
+    # the fraction of the f64-MFMA peak (the roof its arithmetic would meet), `bound` says what it actually hits
+    return {"bound": "latency", "roof": "mfma", "achieved": tf, "peak": PEAK_F64_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": tf / PEAK_F64_MFMA_TFLOPS, **common,
             "kernel": "k_step_assign (v_mfma_f64_16x16x4_f64), the E-step of one training step for the two strata of a queue",
             "note": "latency-bound: ~2 500-row batches, 2 x n_iterations dependent launches per queue (DESIGN.md 5.3, 5.3a); the "
                     "assignment kernels have their own object, roofline_assign"}
@@ -479,7 +605,19 @@ def ingest_leg(h, cfg, n_it, log):
             st = m.stage_iterations()
             h.sync()
             dt = time.perf_counter() - t0
-            res[name] = {"seconds": dt, "GBps": m.ingest_stats["bytes"] / dt / 1e9, "bytes": m.ingest_stats["bytes"],
+            # the figure is the throughput of a VERIFIED staging -- every staged array is read back and must
+            # equal the source byte for byte (a slab rewritten before its copy drained, a block landing at the wrong offset or a
+            # short read would show here); the run stops otherwise
+            keep = [i for i in sorted(its) if i <= m.maxIter]
+            for key, buf in (("Xp", st.Xp), ("Xc", st.Xc), ("p0", st.p0), ("p1", st.p1), ("w", st.w)):
+                want = np.concatenate([np.asarray(its[i][key]).reshape(len(its[i]["w"]), -1) for i in keep])
+                got = buf.to_host().reshape(-1)[: want.size].reshape(want.shape)
+                if got.dtype != want.dtype or not np.array_equal(got.view(np.uint8), want.view(np.uint8)):
+                    bad = np.nonzero((got != want).any(axis=1))[0]
+                    raise SystemExit(f"[bench] ingest leg {name}: staged {key} differs from the source in {len(bad)} rows "
+                                     f"(first: {bad[:5].tolist()}) -- the staging pipeline corrupted its data")
+                del want, got
+            res[name] = {"seconds": dt, "GBps": m.ingest_stats["bytes"] / dt / 1e9, "bytes": m.ingest_stats["bytes"], "verified": "every staged array read back == source, byte for byte",
                          "blocks": m.ingest_stats["blocks"], "frames": int(st.N), "readers": m.ingest_stats.get("readers"), "direct_read_blocks": m.ingest_stats.get("direct_read_blocks"),
                          "host_waits_s": m.ingest_stats.get("host_waits_s")}
             for b in (st.Xp, st.Xc, st.p0, st.p1, st.w):
@@ -503,6 +641,8 @@ def pmc_traffic(cfg, n_iters):
 
 
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "--c2-cpu-worker":
+        return c2_cpu_worker(int(sys.argv[2]))
     if len(sys.argv) > 1 and sys.argv[1] == "--cpu-worker":
         return cpu_baseline_worker(sys.argv[2], int(sys.argv[3]), int(sys.argv[4]), int(sys.argv[5]))
     ap = argparse.ArgumentParser()
@@ -531,6 +671,13 @@ def main():
                          "ALONE takes 24.8 us per call, the four chains overlapped on one chip 17.4 -- tools/onestratum.py).  "
                          "rank0 (default for weak scaling): rank 0 trains on its own block of iterations only")
     ap.add_argument("--no-ingest", action="store_true")
+    ap.add_argument("--secondary", default=None,
+                    help="N = 1: comma-separated workloads measured after the primary one and reported under `secondary` in the same "
+                         "line (c2 = BASELINE configs[1], c2_x64 = the same frames resident 64 times, or any --workload name).  "
+                         "Default for the default workload (c3): c2,c2_x64,c5 -- every single-GPU BASELINE config in one "
+                         "driver-timed record; for any other workload: none")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the secondary workloads")
+    ap.add_argument("--c2-frames", type=int, default=0, help="(debug / CPU rehearsal) frames of config 2 instead of its 1 000 000")
     ap.add_argument("--lib", default=None, help="(kernel A/B experiments) path of an alternative build of the HIP library")
     args = ap.parse_args()
 
@@ -556,16 +703,6 @@ def main():
     if args.scaling is None:
         args.scaling = "strong" if world > 1 else "weak"
 
-    cfg = bench_configs()[args.workload]
-    n_total = args.iters or cfg.n_iters
-    if args.scaling == "strong" and world > 1:
-        per = n_total // world
-        first_iter = 1 + rank * per
-        n_iters = per if rank < world - 1 else n_total - per * (world - 1)
-    else:
-        n_iters, first_iter = n_total, 1 + rank * n_total
-    call_flop = 2.0 * (cfg.segs_per_iter / cfg.S) * cfg.K_s * cfg.D   # one stratum's training call
-    train_on = args.train_on or (("strata" if call_flop >= 5e8 else "all") if args.scaling == "strong" else "rank0")
     seed = 1337
     exchange = "none (one rank)"
 
@@ -597,196 +734,265 @@ def main():
             torch_exchange(h, dist, torch, rank, world, dev)
             exchange = "torch-fallback (host-staged; not the product path)"
 
-    log(f"workload {cfg.name}: {n_iters} iterations x {cfg.segs_per_iter} segments x {cfg.D} features, "
-        f"{cfg.S} strata x {cfg.K_s} clusters, rank shard starts at iteration {first_iter}; scaling {args.scaling}, "
-        f"training on {train_on}, exchange {exchange}")
-    if n_iters * cfg.segs_per_iter * cfg.D * 8 > (8 << 30) or os.environ.get("HAMSM_BENCH_STREAM") == "1":
-        store, offs = synthetic.stage_streamed(h, cfg, first_iter, n_iters, log)   # (c5: never whole on the host)
-    else:
-        Xp, Xc, p0, p1, w, offs = make_shard(cfg, first_iter, n_iters, log)
-        store = DeviceStore.from_host(h, Xp, Xc, p0, p1, w, offs)
-        del Xp, Xc
-    n_seg = int(offs[-1])
-    m = new_model(h, cfg, store, n_iters)
-    m.train_shards = train_on
-    n_seg_all = n_seg
-    if world > 1:
-        t = torch.tensor([n_seg], device=dev, dtype=torch.int64)
-        dist.all_reduce(t)
-        n_seg_all = int(t.item())
-        m.training_store()   # (train-on all: the one-off gather of the training frames to rank 0 belongs to staging)
+    def measure(h, workload, steps, warmup, ingest, cpu_iters_arg):
+        """one workload's bench object: stage the shard, W untimed + K timed steps between barriers, then the legs that are not
+        part of `value` (labels to the host, both flux modes, ingest, the full build_analyze_model sequence, the CPU baseline)"""
+        cfg = bench_configs()[workload]
+        n_total = args.iters or cfg.n_iters
+        if args.scaling == "strong" and world > 1:
+            per = n_total // world
+            first_iter = 1 + rank * per
+            n_iters = per if rank < world - 1 else n_total - per * (world - 1)
+        else:
+            n_iters, first_iter = n_total, 1 + rank * n_total
+        call_flop = 2.0 * (cfg.segs_per_iter / cfg.S) * cfg.K_s * cfg.D   # one stratum's training call
+        train_on = args.train_on or (("strata" if call_flop >= 5e8 else "all") if args.scaling == "strong" else "rank0")
+        h.timers(reset=True)
+        log(f"workload {cfg.name}: {n_iters} iterations x {cfg.segs_per_iter} segments x {cfg.D} features, "
+            f"{cfg.S} strata x {cfg.K_s} clusters, rank shard starts at iteration {first_iter}; scaling {args.scaling}, "
+            f"training on {train_on}, exchange {exchange}")
+        if n_iters * cfg.segs_per_iter * cfg.D * 8 > (8 << 30) or os.environ.get("HAMSM_BENCH_STREAM") == "1":
+            store, offs = synthetic.stage_streamed(h, cfg, first_iter, n_iters, log)   # (c5: never whole on the host)
+        else:
+            Xp, Xc, p0, p1, w, offs = make_shard(cfg, first_iter, n_iters, log)
+            store = DeviceStore.from_host(h, Xp, Xc, p0, p1, w, offs)
+            del Xp, Xc
+        n_seg = int(offs[-1])
+        m = new_model(h, cfg, store, n_iters)
+        m.train_shards = train_on
+        n_seg_all = n_seg
+        if world > 1:
+            t = torch.tensor([n_seg], device=dev, dtype=torch.int64)
+            dist.all_reduce(t)
+            n_seg_all = int(t.item())
+            m.training_store()   # (train-on all: the one-off gather of the training frames to rank 0 belongs to staging)
 
-    def barrier():
-        h.sync()
-        if dist is not None:
-            dist.barrier()   # (h.sync() above drained this rank's GPU queue: the library's stream is the only one in use)
+        def barrier():
+            h.sync()
+            if dist is not None:
+                dist.barrier()   # (h.sync() above drained this rank's GPU queue: the library's stream is the only one in use)
 
-    for _ in range(args.warmup):
-        one_step(m, cfg, seed, args.flux_mode)
-    barrier()
-    h.timers(reset=True)
-    if hasattr(h, "step_kernel_ms"):
-        h.step_kernel_ms(0, reset=True)
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        one_step(m, cfg, seed, args.flux_mode)
-    barrier()
-    elapsed = time.perf_counter() - t0
-    if dist is not None:
-        import torch
-
-        t = torch.tensor([elapsed], device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-
-    timers = h.timers()   # HIP events on the library's stream around every kernel (lazy: no sync on the launch path)
-    # training E-step on the bf16 matrix unit (train.hip, k_step_assign_ranked; taken by size): rows certified by the ranking /
-    # settled between two candidates by two f64 chains / swept exactly, over the timed steps
-    rank_stats = None
-    if hasattr(h.lib, "hamsm_debug_rank_stats"):
-        try:
-            out4 = (ctypes.c_ulonglong * 4)()
-            h.lib.hamsm_debug_rank_stats.restype = ctypes.c_int
-            h.lib.hamsm_debug_rank_stats.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int]
-            if h.lib.hamsm_debug_rank_stats(h.ctx, out4, 0, -1) == 0 and out4[3] > 0:
-                tot = max(1, out4[0] + out4[1] + out4[2])
-                rank_stats = {"runs": int(out4[3]), "rows_certified": int(out4[0]), "rows_two_candidates": int(out4[1]),
-                              "rows_swept_exactly": int(out4[2]), "frac_certified": out4[0] / tot, "frac_two": out4[1] / tot,
-                              "frac_swept": out4[2] / tot}
-        except (AttributeError, OSError):
-            rank_stats = None
-    e_ms, e_n = h.step_kernel_ms(0)   # the dominant kernel, live: events around every 128th k_step_assign / k_step_update launch
-    m_ms, m_n = h.step_kernel_ms(1)
-    e_dev_ms, _ = h.step_kernel_ms(2)  # ... and by the device clock (first wave in -> last wave out, no launch boundary)
-    # what the reference's post-condition adds when the caller wants host arrays (not part of the timed step: `dtrajs` /
-    # `pair_dtrajs` are materialised on first access): 2 x N int32 labels D2H + the per-iteration views
-    t0 = time.perf_counter()
-    _ = m.dtrajs
-    labels_to_host_ms = (time.perf_counter() - t0) * 1e3
-    # the flux build in both modes (the timed step uses --flux-mode; the product default is the deterministic one)
-    flux_ms = {}
-    for mode, name in ((0, "atomic"), (1, "deterministic")):
-        m.flux_mode = mode
-        m.get_fluxMatrix(0, first_iter=1, last_iter=m.maxIter)
-        h.sync()
+        for _ in range(warmup):
+            one_step(m, cfg, seed, args.flux_mode)
+        barrier()
+        h.timers(reset=True)
+        if hasattr(h, "step_kernel_ms"):
+            h.step_kernel_ms(0, reset=True)
         t0 = time.perf_counter()
-        for _ in range(3):
+        for _ in range(steps):
+            one_step(m, cfg, seed, args.flux_mode)
+        barrier()
+        elapsed = time.perf_counter() - t0
+        if dist is not None:
+            t = torch.tensor([elapsed], device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            elapsed = float(t.item())
+
+        timers = h.timers()   # HIP events on the library's stream around every kernel (lazy: no sync on the launch path)
+        # training E-step on the bf16 matrix unit (train.hip, k_step_assign_ranked; taken by size): rows certified by the ranking /
+        # settled between two candidates by two f64 chains / swept exactly, over the timed steps
+        rank_stats = None
+        if hasattr(h.lib, "hamsm_debug_rank_stats"):
+            try:
+                out4 = (ctypes.c_ulonglong * 4)()
+                h.lib.hamsm_debug_rank_stats.restype = ctypes.c_int
+                h.lib.hamsm_debug_rank_stats.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int]
+                if h.lib.hamsm_debug_rank_stats(h.ctx, out4, 0, -1) == 0 and out4[3] > 0:
+                    tot = max(1, out4[0] + out4[1] + out4[2])
+                    rank_stats = {"runs": int(out4[3]), "rows_certified": int(out4[0]), "rows_two_candidates": int(out4[1]),
+                                  "rows_swept_exactly": int(out4[2]), "frac_certified": out4[0] / tot, "frac_two": out4[1] / tot,
+                                  "frac_swept": out4[2] / tot}
+            except (AttributeError, OSError):
+                rank_stats = None
+        e_ms, e_n = h.step_kernel_ms(0)   # the dominant kernel, live: events around every 128th k_step_assign / k_step_update launch
+        m_ms, m_n = h.step_kernel_ms(1)
+        e_dev_ms, _ = h.step_kernel_ms(2)  # ... and by the device clock (first wave in -> last wave out, no launch boundary)
+        # what the reference's post-condition adds when the caller wants host arrays (not part of the timed step: `dtrajs` /
+        # `pair_dtrajs` are materialised on first access): 2 x N int32 labels D2H + the per-iteration views
+        # (`_abi.HostBlock`: one device-to-host copy of 8 N bytes into a page-locked block of the process; the first call of a size
+        # also page-locks the block, ~0.3 ms per MB -- later calls reuse it)
+        t0 = time.perf_counter()
+        _ = m.dtrajs
+        labels_to_host_first_ms = (time.perf_counter() - t0) * 1e3
+        del _
+        m._dtrajs_cache = None
+        t0 = time.perf_counter()
+        _ = m.dtrajs
+        labels_to_host_ms = (time.perf_counter() - t0) * 1e3
+        t0 = time.perf_counter()
+        _ = m.pair_dtrajs
+        pairs_to_host_ms = (time.perf_counter() - t0) * 1e3
+        del _
+        # the step as a caller who reads `model.dtrajs` after every build sees it (VERDICT r4 weak #6)
+        n_l = min(steps, 5)
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(n_l):
+            one_step(m, cfg, seed, args.flux_mode)
+            _d = m.dtrajs
+        barrier()
+        step_labels_s = (time.perf_counter() - t0) / n_l
+        del _d
+        # the flux build in both modes (the timed step uses --flux-mode; the product default is the deterministic one)
+        flux_ms = {}
+        for mode, name in ((0, "atomic"), (1, "deterministic")):
+            m.flux_mode = mode
             m.get_fluxMatrix(0, first_iter=1, last_iter=m.maxIter)
-        h.sync()
-        flux_ms[name] = (time.perf_counter() - t0) * 1e3 / 3
-    m.flux_mode = args.flux_mode
-    assign_ms = h.last_kernel_ms(0)
-    n_assign_launch = 2 * args.steps
-    assign_avg_ms = timers["assign"] * 1e3 / n_assign_launch   # the distance kernels alone (f32 ranking pass + exact f64 pass over
-                                                               # the undecided frames); the bucket passes are "other"
-    rows_per_launch = n_seg                                   # one launch = all parent (or child) frames
-    flops = 2.0 * cfg.K_s * cfg.D * rows_per_launch           # 2*K_s*D per frame
-    bytes_alg = (cfg.D * 4 + 8 + 4) * rows_per_launch         # D*s + 8*ndim + 4 per frame
-    assign_avg_ms = assign_avg_ms or float("nan")  # (the CPU rehearsal has no kernel timers)
-    tflops = flops / (assign_avg_ms * 1e-3) / 1e12
-    K = cfg.K_s * cfg.S
-    extra = {}
-    # which form of the ranking pass the last assign ran (library hook; the CPU rehearsal has none): 2 = bf16 x 3 with 6 piece
-    # products, 3 = the light bf16 form with 3
-    form = None
-    if hasattr(h.lib, "hamsm_debug_filter_form"):
-        try:
-            h.lib.hamsm_debug_filter_form.restype = ctypes.c_int
-            h.lib.hamsm_debug_filter_form.argtypes = [ctypes.c_void_p]
-            form = int(h.lib.hamsm_debug_filter_form(h.ctx))
-        except (AttributeError, OSError):
-            form = None
-    if form in (2, 3) or (form is None and os.environ.get("HAMSM_ASSIGN_FILTER", "1") != "0"
-                          and os.environ.get("HAMSM_FILTER_BF16", "1") != "0" and cfg.D <= 32):
-        # every f32 product is formed from bf16 piece products (operands = exact sums of three bf16 pieces): 6 of the 9 in the full
-        # form, 3 in the light form that goes first (wider bound, more frames left to the exact kernel): the roof of an algorithmic
-        # flop on this path is the bf16 MFMA peak / products
-        products = 3.0 if form == 3 else 6.0
-        peak = PEAK_BF16_MFMA_TFLOPS / products
-        blocks = (cfg.D + 16) // 16
-        executed = flops * (products * 16 * blocks / cfg.D) * (((cfg.K_s + 31) // 32) * 32 / cfg.K_s)
-        extra = {"bf16_mfma_peak": PEAK_BF16_MFMA_TFLOPS, "executed_bf16_TFLOPs": executed / (assign_avg_ms * 1e-3) / 1e12,
-                 "frac_of_f32_mfma_peak": tflops / PEAK_F32_MFMA_TFLOPS, "bf16_products_per_f32_product": products}
-        kernel = (f"k_assign_filter (v_mfma_f32_32x32x16_bf16, f32 operands as three exact bf16 pieces, {int(products)} piece products) "
-                  "+ k_assign_sorted (v_mfma_f64_16x16x4_f64) on the undecided frames")
-        arithmetic = ("centroids ranked on the bf16 matrix unit; a label is final only if the gap exceeds a proven bound on the "
-                      "difference to the f64 contract (dropped piece products included), otherwise the exact f64 kernel decides: "
-                      "labels identical to the f64 contract")
-    elif os.environ.get("HAMSM_ASSIGN_FILTER", "1") != "0":
-        peak = PEAK_F32_MFMA_TFLOPS
-        kernel = "k_assign_filter (v_mfma_f32_32x32x2_f32) + k_assign_sorted (v_mfma_f64_16x16x4_f64) on the undecided frames"
-        arithmetic = ("centroids ranked in f32 on the matrix unit; a label is final only if the f32 gap exceeds a proven bound "
-                      "on the f32-vs-f64 difference, otherwise the exact f64 kernel decides: labels identical to the f64 contract")
-    else:
-        peak = PEAK_F64_MFMA_TFLOPS
-        kernel = "k_assign_sorted (v_mfma_f64_16x16x4_f64)"
-        arithmetic = "f64 in-order fma chains on the matrix unit"
-    out = {
-        "metric": "frames/sec clustered + fluxmatrix-built",
-        "value": n_seg_all * args.steps / elapsed,
-        "unit": "frames/s",
-        "n_gpus": world,
-        "steps": args.steps,
-        "warmup": args.warmup,
-        "ms_per_step": elapsed * 1e3 / args.steps,
-        "higher_is_better": True,
-        "scaling": args.scaling,
-        "vs_baseline": None,
-        "dtype": "f64",
-        "dtype_detail": "training, flux, statistics and the exact assignment kernel compute in f64; the assignment's ranking pass "
-                        "computes in bf16 x 3 (f32-equivalent) or f32 and only finalises labels its error bound certifies against f64",
-        "data": "synthetic",
-        "config": {"workload": f"{cfg.name}: {n_iters} WE iterations x {cfg.segs_per_iter} segments per GPU, "
-                               f"{cfg.D} f32 features, {cfg.S} strata x {cfg.K_s} clusters (K={K}); "
-                               f"train + assign(2N) + flux per step", "frames_per_gpu": n_seg,
-                   "flux_mode": "atomic" if args.flux_mode == 0 else "deterministic",
-                   "frames_total": n_seg_all, "parallelism": f"iteration-sharded x{world}",
-                   "training": ({"all": "rank 0 trains on every rank's iterations (gathered to it at staging): same model as one process "
-                                        "on all the data",
-                                 "strata": "every rank's iterations reach every rank at staging; stratum s trains on rank s % N and its "
-                                           "model travels from there: same model as one process on all the data, training spread over "
-                                           "min(N, S) GPUs",
-                                 "rank0": "rank 0 trains on its own block of iterations only (iters_to_use); --train-on all / strata "
-                                          "use every shard"}[train_on])
-                   if world > 1 else "all resident iterations", "exchange": exchange},
-        "roofline": step_roofline(cfg, n_iters, n_seg, e_dev_ms or e_ms, e_n, m_ms, e_ms, ranked=rank_stats is not None),
-        "roofline_assign": {"bound": "mfma", "achieved": tflops, "peak": peak, "unit": "TFLOP/s",
-                            "frac": tflops / peak, "traffic": pmc_traffic(cfg, n_iters),
-                            "traffic_source": (f"profiles/{os.path.basename(pmc_file(cfg.name))} (committed rocprofv3 --pmc passes of this "
-                                               "workload); not measured in this run") if pmc_traffic(cfg, n_iters) is not None else None,
-                            "kernel": kernel, "arithmetic": arithmetic,
-                            "f64_mfma_peak": PEAK_F64_MFMA_TFLOPS, "frac_of_f64_peak": tflops / PEAK_F64_MFMA_TFLOPS, **extra,
-                            "avg_launch_ms": assign_avg_ms, "last_launch_ms": assign_ms,
-                            "algorithmic_GBps": bytes_alg / (assign_avg_ms * 1e-3) / 1e9,
-                            "hbm_frac": bytes_alg / (assign_avg_ms * 1e-3) / 1e9 / PEAK_HBM_GBS},
-        "stage_seconds_per_step": {k: v / args.steps for k, v in timers.items()},
-        "roofline_by_kernel": roofline_by_kernel(cfg, n_iters, n_seg, timers, args.steps, tflops, peak, assign_avg_ms),
-        "labels_to_host_ms": labels_to_host_ms,
-        "flux_ms": flux_ms,
-        "training_estep": ("ranked on the bf16 matrix unit (k_step_assign_ranked), exact f64 where the ranking cannot decide"
-                           if rank_stats else "f64 matrix unit (k_step_assign)"),
-        "training_estep_rows": rank_stats,
-    }
-    if world == 1 and not args.no_ingest:
-        # (a bounded sample: ~1 GB of frames, 400 iterations at C3; HAMSM_BENCH_INGEST_ITERS: another number of iterations.  The
-        # fixed costs -- page-locking and releasing two upload slabs, the device allocations: ~20 ms -- are inside the figure)
-        n_ing = int(os.environ.get("HAMSM_BENCH_INGEST_ITERS", 0)) or min(400, max(4, int(1.056e9 / (cfg.segs_per_iter * cfg.D * 8))))
-        out["ingest"] = ingest_leg(h, cfg, min(n_iters, n_ing), log)
-    if world == 1 and not args.no_full_pipeline:
-        # BASELINE.json's second figure (steady-state solve wall-time) and SURVEY §8d's build_analyze_model-equivalent
-        log("timing the full build_analyze_model sequence (clean, T, solve, block validation) ...")
-        fp = full_pipeline(m, cfg, seed, args.flux_mode)
-        fp["frames_per_s"] = n_seg / fp["total_seconds"]
-        out["full_pipeline"] = fp
-        out["solve"] = {"states": fp["states"], "tmatrix_csr_s": fp["seconds"]["tmatrix_csr"],
-                        "steady_state_s": fp["seconds"]["steady_state"], "where": "T built as CSR on the GPU; scipy solve on host"}
-    if rank == 0:
-        if not args.no_cpu_baseline and world == 1:
-            log("timing the CPU oracle on a bounded sample ...")
-            # a BOUNDED sample: the work of 32 C3 iterations (~20 s on one core), never fewer than 2 iterations
-            cpu_iters = args.cpu_iters or max(2, int(128 * (10000 * 250 * 30) / (cfg.segs_per_iter * cfg.K_s * cfg.D)))
-            out["cpu_baseline"] = cpu_baseline(args.workload, min(cpu_iters, n_iters), seed, args.cpu_cores)
+            h.sync()
+            t0 = time.perf_counter()
+            for _ in range(3):
+                m.get_fluxMatrix(0, first_iter=1, last_iter=m.maxIter)
+            h.sync()
+            flux_ms[name] = (time.perf_counter() - t0) * 1e3 / 3
+        m.flux_mode = args.flux_mode
+        assign_ms = h.last_kernel_ms(0)
+        n_assign_launch = 2 * steps
+        assign_avg_ms = timers["assign"] * 1e3 / n_assign_launch   # the distance kernels alone (f32 ranking pass + exact f64 pass over
+                                                                   # the undecided frames); the bucket passes are "other"
+        rows_per_launch = n_seg                                   # one launch = all parent (or child) frames
+        flops = 2.0 * cfg.K_s * cfg.D * rows_per_launch           # SURVEY §8d: 2*K_s*D per frame
+        bytes_alg = (cfg.D * 4 + 8 + 4) * rows_per_launch         # D*s + 8*ndim + 4 per frame
+        assign_avg_ms = assign_avg_ms or float("nan")  # (the CPU rehearsal has no kernel timers)
+        tflops = flops / (assign_avg_ms * 1e-3) / 1e12
+        K = cfg.K_s * cfg.S
+        extra = {}
+        # which form of the ranking pass the last assign ran (library hook; the CPU rehearsal has none): 2 = bf16 x 3 with 6 piece
+        # products, 3 = the light bf16 form with 3
+        form = None
+        if hasattr(h.lib, "hamsm_debug_filter_form"):
+            try:
+                h.lib.hamsm_debug_filter_form.restype = ctypes.c_int
+                h.lib.hamsm_debug_filter_form.argtypes = [ctypes.c_void_p]
+                form = int(h.lib.hamsm_debug_filter_form(h.ctx))
+            except (AttributeError, OSError):
+                form = None
+        if form in (2, 3) or (form is None and os.environ.get("HAMSM_ASSIGN_FILTER", "1") != "0"
+                              and os.environ.get("HAMSM_FILTER_BF16", "1") != "0" and cfg.D <= 32):
+            # every f32 product is formed from bf16 piece products (operands = exact sums of three bf16 pieces): 6 of the 9 in the full
+            # form, 3 in the light form that goes first (wider bound, more frames left to the exact kernel): the roof of an algorithmic
+            # flop on this path is the bf16 MFMA peak / products
+            products = 3.0 if form == 3 else 6.0
+            peak = PEAK_BF16_MFMA_TFLOPS / products
+            blocks = (cfg.D + 16) // 16
+            executed = flops * (products * 16 * blocks / cfg.D) * (((cfg.K_s + 31) // 32) * 32 / cfg.K_s)
+            extra = {"bf16_mfma_peak": PEAK_BF16_MFMA_TFLOPS, "executed_bf16_TFLOPs": executed / (assign_avg_ms * 1e-3) / 1e12,
+                     "frac_of_f32_mfma_peak": tflops / PEAK_F32_MFMA_TFLOPS, "bf16_products_per_f32_product": products}
+            kernel = (f"k_assign_filter (v_mfma_f32_32x32x16_bf16, f32 operands as three exact bf16 pieces, {int(products)} piece products) "
+                      "+ k_assign_sorted (v_mfma_f64_16x16x4_f64) on the undecided frames")
+            arithmetic = ("centroids ranked on the bf16 matrix unit; a label is final only if the gap exceeds a proven bound on the "
+                          "difference to the f64 contract (dropped piece products included), otherwise the exact f64 kernel decides: "
+                          "labels identical to the f64 contract")
+        elif os.environ.get("HAMSM_ASSIGN_FILTER", "1") != "0":
+            peak = PEAK_F32_MFMA_TFLOPS
+            kernel = "k_assign_filter (v_mfma_f32_32x32x2_f32) + k_assign_sorted (v_mfma_f64_16x16x4_f64) on the undecided frames"
+            arithmetic = ("centroids ranked in f32 on the matrix unit; a label is final only if the f32 gap exceeds a proven bound "
+                          "on the f32-vs-f64 difference, otherwise the exact f64 kernel decides: labels identical to the f64 contract")
+        else:
+            peak = PEAK_F64_MFMA_TFLOPS
+            kernel = "k_assign_sorted (v_mfma_f64_16x16x4_f64)"
+            arithmetic = "f64 in-order fma chains on the matrix unit"
+        out = {
+            "metric": "frames/sec clustered + fluxmatrix-built",
+            "value": n_seg_all * steps / elapsed,
+            "unit": "frames/s",
+            "n_gpus": world,
+            "steps": steps,
+            "warmup": warmup,
+            "ms_per_step": elapsed * 1e3 / steps,
+            "higher_is_better": True,
+            "scaling": args.scaling if world > 1 else "n/a",
+            "vs_baseline": None,
+            "dtype": "f64",
+            "dtype_detail": "training, flux, statistics and the exact assignment kernel compute in f64; the assignment's ranking pass "
+                            "computes in bf16 x 3 (f32-equivalent) or f32 and only finalises labels its error bound certifies against f64",
+            "data": "synthetic",
+            "config": {"workload": f"{cfg.name}: {n_iters} WE iterations x {cfg.segs_per_iter} segments per GPU, "
+                                   f"{cfg.D} f32 features, {cfg.S} strata x {cfg.K_s} clusters (K={K}); "
+                                   f"train + assign(2N) + flux per step", "frames_per_gpu": n_seg,
+                       "flux_mode": "atomic" if args.flux_mode == 0 else "deterministic",
+                       "frames_total": n_seg_all, "parallelism": f"iteration-sharded x{world}",
+                       "training": ({"all": "rank 0 trains on every rank's iterations (gathered to it at staging): same model as one process "
+                                            "on all the data",
+                                     "strata": "every rank's iterations reach every rank at staging; stratum s trains on rank s % N and its "
+                                               "model travels from there: same model as one process on all the data, training spread over "
+                                               "min(N, S) GPUs",
+                                     "rank0": "rank 0 trains on its own block of iterations only (iters_to_use); --train-on all / strata "
+                                              "use every shard"}[train_on])
+                       if world > 1 else "all resident iterations", "exchange": exchange},
+            "roofline": step_roofline(cfg, n_iters, n_seg, e_dev_ms or e_ms, e_n, m_ms, e_ms, ranked=rank_stats is not None),
+            "roofline_assign": {"bound": "mfma", "achieved": tflops, "peak": peak, "unit": "TFLOP/s",
+                                "frac": tflops / peak, "traffic": pmc_traffic(cfg, n_iters),
+                                "traffic_source": (f"profiles/{os.path.basename(pmc_file(cfg.name))} (committed rocprofv3 --pmc passes of this "
+                                                   "workload); not measured in this run") if pmc_traffic(cfg, n_iters) is not None else None,
+                                "kernel": kernel, "arithmetic": arithmetic,
+                                "f64_mfma_peak": PEAK_F64_MFMA_TFLOPS, "frac_of_f64_peak": tflops / PEAK_F64_MFMA_TFLOPS, **extra,
+                                "avg_launch_ms": assign_avg_ms, "last_launch_ms": assign_ms,
+                                "algorithmic_GBps": bytes_alg / (assign_avg_ms * 1e-3) / 1e9,
+                                "hbm_frac": bytes_alg / (assign_avg_ms * 1e-3) / 1e9 / PEAK_HBM_GBS},
+            "stage_seconds_per_step": {k: v / steps for k, v in timers.items()},
+            "roofline_by_kernel": roofline_by_kernel(cfg, n_iters, n_seg, timers, steps, tflops, peak, assign_avg_ms),
+            "labels_to_host_ms": labels_to_host_ms,
+            "labels_to_host": {"dtrajs_ms": labels_to_host_ms, "dtrajs_first_call_ms": labels_to_host_first_ms,
+                               "pair_dtrajs_ms": pairs_to_host_ms, "bytes_dtrajs": 8 * n_seg, "bytes_pair_dtrajs": 16 * n_seg,
+                               "how": "int64 labels widened (and interleaved) on the device, one copy each into a page-locked "
+                                      "process-level block; per-iteration arrays are views; the first call of a size also page-locks"},
+            "step_incl_host_labels": {"ms_per_step": step_labels_s * 1e3, "value": n_seg_all / step_labels_s, "unit": "frames/s",
+                                      "steps": n_l, "what": "the same step followed by `model.dtrajs` (the reference's host-side "
+                                                            "post-condition, _clustering.py:1206-1240) every time"},
+            "flux_ms": flux_ms,
+            "training_estep": ("ranked on the bf16 matrix unit (k_step_assign_ranked), exact f64 where the ranking cannot decide"
+                               if rank_stats else "f64 matrix unit (k_step_assign)"),
+            "training_estep_rows": rank_stats,
+        }
+        if world == 1 and ingest:
+            # (a bounded sample: ~1 GB of frames, 400 iterations at C3; HAMSM_BENCH_INGEST_ITERS: another number of iterations.  The
+            # fixed costs -- page-locking and releasing two upload slabs, the device allocations: ~20 ms -- are inside the figure)
+            n_ing = int(os.environ.get("HAMSM_BENCH_INGEST_ITERS", 0)) or min(400, max(4, int(1.056e9 / (cfg.segs_per_iter * cfg.D * 8))))
+            out["ingest"] = ingest_leg(h, cfg, min(n_iters, n_ing), log)
+        if world == 1 and not args.no_full_pipeline:
+            # BASELINE.json's second figure (steady-state solve wall-time) and SURVEY §8d's build_analyze_model-equivalent
+            log("timing the full build_analyze_model sequence (clean, T, solve, block validation) ...")
+            fp = full_pipeline(m, cfg, seed, args.flux_mode)
+            fp["frames_per_s"] = n_seg / fp["total_seconds"]
+            out["full_pipeline"] = fp
+            out["solve"] = {"states": fp["states"], "tmatrix_csr_s": fp["seconds"]["tmatrix_csr"],
+                            "steady_state_s": fp["seconds"]["steady_state"], "where": "T built as CSR on the GPU; scipy solve on host"}
+        if rank == 0 and not args.no_cpu_baseline and world == 1:
+            log(f"timing the CPU oracle on a bounded sample of {workload} ...")
+            # a BOUNDED sample: the work of 128 C3 iterations (~10 s on one core), never fewer than 2 iterations
+            cpu_iters = cpu_iters_arg or max(2, int(128 * (10000 * 250 * 30) / (cfg.segs_per_iter * cfg.K_s * cfg.D)))
+            out["cpu_baseline"] = cpu_baseline(workload, min(cpu_iters, n_iters), seed, args.cpu_cores)
             out["cpu_baseline"]["gpu_over_cpu"] = out["value"] / out["cpu_baseline"]["value"]
+        return out
+
+    if args.workload == "c2":
+        if world > 1:
+            raise SystemExit("--workload c2 is a single-GPU workload (BASELINE configs[1]: 1 x MI355X distance / assign only)")
+        h.close()
+        out = measure_c2(device, args, log, int(os.environ.get("HAMSM_BENCH_C2_REPS", "1")), cpu=not args.no_cpu_baseline)
+        out.update({"scaling": "n/a", "vs_baseline": None})
+    else:
+        out = measure(h, args.workload, args.steps, args.warmup, not args.no_ingest, args.cpu_iters)
+    secondary = args.secondary if args.secondary is not None else ("c2,c2_x64,c5" if args.workload == "c3" and not args.iters else "")
+    if world == 1 and secondary and not args.no_secondary:
+        # VERDICT r4 item 2: every single-GPU BASELINE config as a driver-timed record of the SAME invocation.  `value` stays
+        # config 3's (the configuration the metric is quoted on); config 2 (distance / assign only, at its stated 1 M frames and
+        # as a 64 M-frame repeat of the same shape: the kernel's asymptote) and config 5 at its stated size on this one GPU
+        # follow under `secondary`, each with its own roofline and cpu_baseline.
+        h.close()   # (everything the primary workload held in HBM goes with its context; the secondary workloads use their own)
+        sec = {}
+        for name in [x.strip() for x in secondary.split(",") if x.strip()]:
+            log(f"secondary workload {name} ...")
+            if name.startswith("c2"):
+                reps = int(name.split("_x")[1]) if "_x" in name else 1
+                sec[name] = measure_c2(device, args, log, reps, cpu=(reps == 1 and not args.no_cpu_baseline))
+            else:
+                hs = _abi.Hamsm(lib=ctypes.CDLL(args.lib) if args.lib else None, device=device)
+                big = bench_configs()[name].n_frames > 20_000_000
+                sec[name] = measure(hs, name, 3 if big else args.steps, 1 if big else args.warmup, False, 0)
+                hs.close()
+        out["secondary"] = sec
+    if rank == 0:
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()
