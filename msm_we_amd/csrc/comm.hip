@@ -43,7 +43,8 @@ extern "C" int hamsm_comm_init(hamsm_ctx *c, int nranks, int rank, const char *i
   NCCLCHK(c, ncclCommInitRank(&comm, nranks, id, rank));
   // the device words every collective pre-check below needs are allocated HERE, with the communicator: a rank must never fail an
   // allocation between "the others have entered a collective" and "this rank enters it" 
-  const size_t want = sizeof(int64_t) * (2 * (size_t)nranks + 8) + sizeof(int32_t) * HAMSM_MAX_STRATA;
+  // (gather_to_root: 2 R + 3 words; bcast_strata: 8 + 3 S int32 -- sizes, roots, -roots; exchange: 2 R^2 + 1 words)
+  const size_t want = sizeof(int64_t) * (2 * (size_t)nranks * nranks + 2 * (size_t)nranks + 8) + sizeof(int32_t) * 3 * HAMSM_MAX_STRATA;
   if (hipMalloc(&c->comm_buf, want) != hipSuccess) {
     ncclCommDestroy(comm);
     c->comm_buf = nullptr;
@@ -157,7 +158,7 @@ extern "C" int hamsm_gather_to_root(hamsm_ctx *c, const void *d_send, size_t sen
   for (int r = 0; r < R; r++)
     if (v[r] != -v[R + r]) return hamsm_fail(c, HAMSM_EINVAL, "gather_to_root: the ranks hold different size tables (entry %d)", r);
   ncclResult_t first = ncclSuccess;
-  NCCLCHK(c, ncclGroupStart());
+  const ncclResult_t gs = ncclGroupStart();
   if (send_bytes) {
     ncclResult_t r_ = ncclSend(d_send, send_bytes, ncclChar, root, cm, c->stream);
     if (first == ncclSuccess) first = r_;
@@ -172,7 +173,7 @@ extern "C" int hamsm_gather_to_root(hamsm_ctx *c, const void *d_send, size_t sen
       off += (size_t)h_recv_bytes[r];
     }
   }
-  ncclResult_t end = ncclGroupEnd();  // (always closed, also after a failed call inside it)
+  ncclResult_t end = gs == ncclSuccess ? ncclGroupEnd() : gs;  // (always closed, also after a failed call inside it)
   if (first != ncclSuccess) return hamsm_fail(c, HAMSM_EDEVICE, "gather_to_root: ncclSend / ncclRecv failed: %s", ncclGetErrorString(first));
   if (end != ncclSuccess) return hamsm_fail(c, HAMSM_EDEVICE, "gather_to_root: ncclGroupEnd failed: %s", ncclGetErrorString(end));
   return HAMSM_OK;
@@ -191,24 +192,32 @@ extern "C" int hamsm_bcast_strata(hamsm_ctx *c, const int32_t *h_root) {
   if (!c->comm) return hamsm_fail(c, HAMSM_EINVAL, "comm not initialised");
   const int S = c->S, R = c->nranks;
   ncclComm_t cm = (ncclComm_t)c->comm;
-  if (sizeof(int64_t) * 8 + sizeof(int32_t) * (size_t)S > c->comm_buf_bytes) return hamsm_fail(c, HAMSM_EINVAL, "bcast_strata: %d strata", S);
+  if (sizeof(int64_t) * 8 + sizeof(int32_t) * 3 * (size_t)S > c->comm_buf_bytes) return hamsm_fail(c, HAMSM_EINVAL, "bcast_strata: %d strata", S);
   int64_t *d_flag = (int64_t *)c->comm_buf;               // [1] ready flag
-  int32_t *d_K = (int32_t *)((char *)c->comm_buf + 64);   // [S] fitted centroids per stratum, as their roots know them
-  // (0) every rank must name the same, valid roots: checked locally, agreed on in (2)
+  int32_t *d_K = (int32_t *)((char *)c->comm_buf + 64);   // [3 S] fitted centroids per stratum as their roots know them; roots; -roots
+  // (0) every rank must name valid roots -- checked locally -- and THE SAME roots: they travel with the sizes in (1) as [root,
+  // -root] under the max-all-reduce (equal on every rank iff max(root) == -max(-root), as hamsm_gather_to_root checks its root);
+  // ranks that disagree would otherwise enter the grouped broadcasts of (3) with different roots and hang
   int rc_loc = h_root ? HAMSM_OK : HAMSM_EINVAL;
   for (int s = 0; s < S && !rc_loc; s++)
     if (h_root[s] < 0 || h_root[s] >= R) rc_loc = HAMSM_EINVAL;
   // (1) the strata's sizes: each root contributes its own, the others 0; one max-all-reduce.  A failed upload is carried along:
   // the rank still enters the collective.
-  std::vector<int32_t> Ks(S, 0);
-  for (int s = 0; s < S; s++)
+  std::vector<int32_t> Ks(3 * (size_t)S, 0);
+  for (int s = 0; s < S; s++) {
     if (!rc_loc && h_root[s] == c->rank) Ks[s] = c->st[s].K;
-  hipError_t e_loc = hipMemcpyAsync(d_K, Ks.data(), sizeof(int32_t) * S, hipMemcpyHostToDevice, c->stream);
-  ncclResult_t e_n = ncclAllReduce(d_K, d_K, (size_t)S, ncclInt32, ncclMax, cm, c->stream);
-  if (e_loc == hipSuccess && e_n == ncclSuccess) e_loc = hipMemcpyAsync(Ks.data(), d_K, sizeof(int32_t) * S, hipMemcpyDeviceToHost, c->stream);
+    Ks[S + s] = h_root ? h_root[s] : -1;
+    Ks[2 * S + s] = h_root ? -h_root[s] : 1;
+  }
+  hipError_t e_loc = hipMemcpyAsync(d_K, Ks.data(), sizeof(int32_t) * 3 * S, hipMemcpyHostToDevice, c->stream);
+  ncclResult_t e_n = ncclAllReduce(d_K, d_K, 3 * (size_t)S, ncclInt32, ncclMax, cm, c->stream);
+  if (e_loc == hipSuccess && e_n == ncclSuccess) e_loc = hipMemcpyAsync(Ks.data(), d_K, sizeof(int32_t) * 3 * S, hipMemcpyDeviceToHost, c->stream);
   if (e_loc == hipSuccess) e_loc = hipStreamSynchronize(c->stream);
+  bool roots_differ = false;
+  for (int s = 0; s < S; s++) roots_differ = roots_differ || Ks[S + s] != -Ks[2 * S + s];
   // (2) room for them -- may fail on this rank alone (memory) -- then everybody learns whether everybody is ready
   if (!rc_loc && (e_loc != hipSuccess || e_n != ncclSuccess)) rc_loc = HAMSM_EDEVICE;
+  if (!rc_loc && roots_differ) rc_loc = HAMSM_EINVAL;  // (every rank sees the same reduced words: every rank stops here)
   for (int s = 0; s < S && !rc_loc; s++) {
     if (Ks[s] < 0) rc_loc = HAMSM_EINVAL;
     else if (Ks[s] > 0 && h_root[s] != c->rank) rc_loc = hamsm_stratum_reserve(c, s, Ks[s]);
@@ -219,16 +228,17 @@ extern "C" int hamsm_bcast_strata(hamsm_ctx *c, const int32_t *h_root) {
   int64_t all_ready = 0;
   hipError_t e_dn = hipMemcpyAsync(&all_ready, d_flag, sizeof(all_ready), hipMemcpyDeviceToHost, c->stream);
   if (e_dn == hipSuccess) e_dn = hipStreamSynchronize(c->stream);  // (also: `ready` is a local the upload reads)
-  if (rc_loc) return hamsm_fail(c, rc_loc, "bcast_strata: this rank could not prepare (roots; sizes: %s / %s; or no room for the strata)",
-                                hipGetErrorString(e_loc), ncclGetErrorString(e_n));
+  if (rc_loc) return hamsm_fail(c, rc_loc, "bcast_strata: this rank could not prepare (%s; sizes: %s / %s; or no room for the strata)",
+                                roots_differ ? "the ranks name DIFFERENT roots" : "roots", hipGetErrorString(e_loc), ncclGetErrorString(e_n));
   if (e_up != hipSuccess || e_ar != ncclSuccess || e_dn != hipSuccess)
     return hamsm_fail(c, HAMSM_EDEVICE, "bcast_strata: readiness exchange failed (%s / %s / %s)", hipGetErrorString(e_up), ncclGetErrorString(e_ar),
                       hipGetErrorString(e_dn));
   if (!all_ready) return hamsm_fail(c, HAMSM_EDEVICE, "bcast_strata: another rank could not prepare to receive the model; nothing was sent");
   for (int s = 0; s < S; s++) c->st[s].K = Ks[s];
-  // (3) the tables and the remap, one group: the last collective of this call
+  // (3) the tables and the remap, one group: the last collective of this call.  A failed ncclGroupStart is carried like every
+  // other rank-local failure: the broadcasts are still issued (ungrouped), the error is reported after them
   ncclResult_t first = ncclSuccess;
-  NCCLCHK(c, ncclGroupStart());
+  const ncclResult_t gs = ncclGroupStart();
   for (int s = 0; s < S; s++) {
     Stratum &t = c->st[s];
     if (t.K == 0) continue;
@@ -243,7 +253,7 @@ extern "C" int hamsm_bcast_strata(hamsm_ctx *c, const int32_t *h_root) {
     const ncclResult_t r_ = ncclBroadcast(c->d_remap, c->d_remap, sizeof(int32_t) * (size_t)S, ncclChar, 0, cm, c->stream);
     if (first == ncclSuccess) first = r_;
   }
-  ncclResult_t end = ncclGroupEnd();  // (always closed, also after a failed call inside it)
+  ncclResult_t end = gs == ncclSuccess ? ncclGroupEnd() : gs;  // (always closed, also after a failed call inside it)
   c->table_dirty = true;
   if (first != ncclSuccess) return hamsm_fail(c, HAMSM_EDEVICE, "bcast_strata: ncclBroadcast failed: %s", ncclGetErrorString(first));
   if (end != ncclSuccess) return hamsm_fail(c, HAMSM_EDEVICE, "bcast_strata: ncclGroupEnd failed: %s", ncclGetErrorString(end));

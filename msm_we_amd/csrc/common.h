@@ -111,6 +111,10 @@ struct hamsm_ctx {
   // the E-step of training calls that are bound by the f64 matrix unit ranks the centroids on the bf16 unit (k_step_assign_ranked,
   // train.hip; same labels): 0 never, 1 when a run's heaviest call has >= step_ranked_min_flop (default), 2 always
   int step_ranked = 1;                      // HAMSM_STEP_RANKED
+  int step_wide = 0;                        // HAMSM_STEP_WIDE: 256-row workgroups in the ranked E-step where 128-row ones overfill the chip
+  int n_cu = 256;                           // compute units of the device (hamsm_create)
+  int step_direct = 1;                      // HAMSM_STEP_DIRECT: ranked runs: the M-step fetches member rows from the frames through the
+                                            // row list (no f64 batch copy written by the E-step and read back); 0 = round 4's copy
   double step_ranked_min_flop = 1.5e8;      // HAMSM_STEP_RANKED_MFLOP: flop of a run's heaviest call from which the ranked E-step is taken
   unsigned long long rank_stat[4] = {0, 0, 0, 0};  // rows certified / settled between two candidates / swept exactly; runs
   int generic_stage_kb = 150;  // D > 128: the E-step stages its 16 rows in LDS while they fit this (HAMSM_GENERIC_STAGE_KB; 0 = never)

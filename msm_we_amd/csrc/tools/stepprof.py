@@ -12,7 +12,8 @@ import bench  # noqa: E402
 from msm_we_amd import _abi, synthetic  # noqa: E402
 from msm_we_amd.data import DeviceStore  # noqa: E402
 
-cfg = synthetic.WEConfig("c3s", 3, 60, 10000, 30, 4, 250)
+cfg = (synthetic.WEConfig("c5t", 5, 24, 50000, 64, 4, 1250) if os.environ.get("HAMSM_PROF_WORKLOAD") == "c5"
+       else synthetic.WEConfig("c3s", 3, 60, 10000, 30, 4, 250))
 Xp, Xc, p0, p1, w, offs = bench.make_shard(cfg, 1, cfg.n_iters)
 for level in (1, 2):
     lib = ctypes.CDLL(os.path.join(ROOT, "msm_we_amd/csrc/_var", f"lib_stepprof{level}.so"))
@@ -25,7 +26,7 @@ for level in (1, 2):
     prof = np.zeros((2, 4096, 8), dtype=np.uint64)
     lib.hamsm_debug_step_profile(prof.ctypes.data_as(ctypes.c_void_p))
     print(f"== STEP_PROFILE={level}  (100 MHz clock: 1 tick = 10 ns); timers: {h.timers()}")
-    for k, name, nslot in ((0, "k_step_assign", 8), (1, "k_step_update", 6)):
+    for k, name, nslot in ((0, "k_step_assign", 8), (1, "k_step_update", 6))[(1 if os.environ.get("HAMSM_PROF_WORKLOAD") == "c5" else 0):]:
         p = prof[k].astype(np.int64)
         live = p[:, nslot - 1] > p[:, nslot - 1].max() - 2000  # the last launch only (within 20 us of the last end)
         p = p[live]

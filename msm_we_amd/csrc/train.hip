@@ -1442,6 +1442,33 @@ __device__ __forceinline__ void upd_add_listed(double (&acc)[H], const GAS doubl
   }
 }
 
+// the same from the frames themselves: srow holds FRAME indices (batch rows translated through the call's row list), a row is
+// `ldx` values of XT, widened in registers -- no copy of the batch is written by the E-step and read back (round 5)
+template <int W, int H, typename XT>
+__device__ __forceinline__ void upd_add_direct(double (&acc)[H], const GAS XT *X, int64_t ldx, const unsigned *srow, const double *swl,
+                                               bool weighted, int m0, int mc, int D, int lane) {
+  XT xv[W][H];
+#pragma unroll
+  for (int q = 0; q < W; q++) {
+    const int mq = m0 + q < mc ? m0 + q : mc - 1;
+    const size_t rq = (size_t)srow[mq];
+#pragma unroll
+    for (int h = 0; h < H; h++) {
+      const int k = lane + 64 * h;
+      xv[q][h] = X[rq * ldx + (k < D ? k : D - 1)];  // unconditional; lanes past D carry a copy that is never stored
+    }
+  }
+#pragma unroll
+  for (int q = 0; q < W; q++) {
+    const int mq = m0 + q < mc ? m0 + q : mc - 1;
+    const double wq = weighted ? swl[mq] : 1.0;
+#pragma unroll
+    for (int h = 0; h < H; h++) {
+      double nv = acc[h] + (double)xv[q][h] * wq;
+      acc[h] = (m0 + q < mc) ? nv : acc[h];
+    }
+  }
+}
 
 // ---- the E-step of MFMA-bound calls: centroids RANKED on the bf16 matrix unit, f64 only where the ranking cannot decide ------------
 // At BASELINE config 5's shape (12 500-row batches x 1250 centroids x 64 features per stratum and call) k_step_assign is bound by
@@ -1593,11 +1620,18 @@ __device__ __forceinline__ void rank_merge3(float &A1, float &A2, float &A3, int
 }
 
 #define RANK_NW 8  // waves per workgroup of the ranked E-step: two per SIMD, so that one's ranking (vector unit) overlaps the other's MFMAs
-template <typename XT, int KB>
+// NRT = row tiles of 32 batch rows per workgroup.  4 (128 rows): round 4's shape.  8 (256 rows, round 5; runs without the f64 batch
+// copy only): at C5's shape a launch of two strata is 98 workgroups instead of 196, so the E-steps of BOTH queues (all four strata,
+// 196 workgroups) are resident on the 256 CUs at once -- with 128-row workgroups the two queues' launches (392 workgroups, one per
+// CU: 226 registers x 8 waves) took turns, two rounds of a ~28 us workgroup per call -- and every workgroup streams its stratum's
+// 320 KB of fragments through L2 once per 256 rows instead of once per 128.
+template <typename XT, int KB, int NRT>
 __global__ __launch_bounds__(RANK_NW * 64, 2) void k_step_assign_ranked(const StepPack pk, const RankPack rk, int64_t ldx, int D, int KS,
                                                                         double ratio, float c1, float c2, unsigned long long *stamp) {
   constexpr int NW = RANK_NW, NT = NW * 64;
-  constexpr int RW = 128;  // rows per workgroup: four tiles of 32
+  constexpr int RW = 32 * NRT;  // rows per workgroup
+  static_assert(NRT == 4 || NRT == 8, "prologue: 2 NRT (row tile, block parity) items over 8 waves");
+  constexpr int NIT = 2 * NRT / NW;  // prologue items per wave
   const StepDev sdesc = pk.s[blockIdx.y];
   const StepG st(sdesc);
   const long long r0 = (long long)blockIdx.x * RW;
@@ -1618,10 +1652,10 @@ __global__ __launch_bounds__(RANK_NW * 64, 2) void k_step_assign_ranked(const St
   const double inf = __builtin_huge_val();
   // LDS: the four row tiles' operand images (B operand, as the lanes hold them) during the sweep; afterwards the same bytes hold
   // the waves' partial top-3 and the strips of the two-candidate chains
-  constexpr int SB_BYTES = 4 * KB * 2 * 64 * 16, SM_BYTES = NW * RW * 3 * 4, SJ_BYTES = NW * RW * 2 * 4, ST_BYTES = NW * 3 * 64 * 8;
+  constexpr int SB_BYTES = NRT * KB * 2 * 64 * 16, SM_BYTES = NW * RW * 3 * 4, SJ_BYTES = NW * RW * 2 * 4, ST_BYTES = NW * 3 * 64 * 8;
   constexpr int BUF_BYTES = SB_BYTES > SM_BYTES + SJ_BYTES + ST_BYTES ? SB_BYTES : SM_BYTES + SJ_BYTES + ST_BYTES;
   __shared__ __attribute__((aligned(16))) unsigned char s_buf[BUF_BYTES];
-  v4u32(*s_b)[KB][2][64] = (v4u32(*)[KB][2][64])s_buf;                    // [4][KB][2][64]
+  v4u32(*s_b)[KB][2][64] = (v4u32(*)[KB][2][64])s_buf;                    // [NRT][KB][2][64]
   float(*s_m)[RW][3] = (float(*)[RW][3])s_buf;                            // [NW][RW][3]
   int(*s_j)[RW][2] = (int(*)[RW][2])(s_buf + SM_BYTES);                   // [NW][RW][2]
   double(*s_t)[3][64] = (double(*)[3][64])(s_buf + SM_BYTES + SJ_BYTES);  // [NW][3][64]
@@ -1636,13 +1670,15 @@ __global__ __launch_bounds__(RANK_NW * 64, 2) void k_step_assign_ranked(const St
   // ---- prologue: waves w and w + 4 turn row tile w into operand pieces, the 16-slot blocks of even / odd number each (lane l:
   // batch row l % 32 of the tile, the 8 feature slots 16 m + 8 (l / 32) + i of a block -- from global memory straight into
   // registers, as k_assign_filter's bf16 forms) and leave them in LDS for all eight waves ----
-  const int rtw = wv & 3, mpar = wv >> 2;
+  // (item `it` of wave wv: row tile (wv + NW it) % NRT, block parity (wv + NW it) / NRT -- NRT = 4: one item per wave, waves w and
+  // w + 4 share row tile w; NRT = 8: wave w converts both parities of row tile w)
+  const int rtw = wv % NRT;
   const long long rmine = r0 + 32 * rtw + row;
   const bool ok = rmine < st.n_b;
   const long long rcl = ok ? rmine : st.n_b - 1;  // (rows past the batch repeat its last row; nothing of them is kept)
   const long long fr = st.rows ? (long long)st.rows[rcl] : rcl;
   // (the row of the stratum's NEXT call that this lane will touch towards this XCD's L2, as k_step_assign's wave 3 does)
-  const bool pf_on = wv < 4 && (int)blockIdx.y < pk.n_next && rmine < pk.nx[blockIdx.y].n_b;
+  const bool pf_on = wv < NRT && (int)blockIdx.y < pk.n_next && rmine < pk.nx[blockIdx.y].n_b;
   long long fn = 0;
   if (pf_on) {
     const GAS int32_t *nrows = gp(pk.nx[blockIdx.y].rows);
@@ -1680,57 +1716,65 @@ __global__ __launch_bounds__(RANK_NW * 64, 2) void k_step_assign_ranked(const St
   };
   Frag cur = load_frag(0);
   typedef XT xt4u __attribute__((ext_vector_type(4), aligned(sizeof(XT))));
-  constexpr int KBH = (KB + 1) / 2;  // blocks per converting wave
-  XT raw[KBH][8];                    // (kept to the end: the batch copy for the M-step is written from them)
+  constexpr int KBH = (KB + 1) / 2;  // blocks per item
+  XT raw[NIT][KBH][8];               // (NRT = 4: kept to the end, the batch copy for the M-step is written from them)
   {
     const GAS XT *rp = X + fr * ldx;
 #pragma unroll
-    for (int mm = 0; mm < KBH; mm++) {
-      const int m = 2 * mm + mpar;  // (wave-uniform)
-      const int k0 = 16 * m + 8 * h;
-      if (m < KB && 16 * m + 16 <= D) {  // both half-waves stay inside the row
-        const xt4u va = *(const GAS xt4u *)(rp + k0), vb = *(const GAS xt4u *)(rp + k0 + 4);
+    for (int it = 0; it < NIT; it++) {
+      const int mpar = (wv + NW * it) / NRT;  // (wave-uniform)
 #pragma unroll
-        for (int i = 0; i < 4; i++) {
-          raw[mm][i] = va[i];
-          raw[mm][4 + i] = vb[i];
-        }
-      } else {
+      for (int mm = 0; mm < KBH; mm++) {
+        const int m = 2 * mm + mpar;
+        const int k0 = 16 * m + 8 * h;
+        if (m < KB && 16 * m + 16 <= D) {  // both half-waves stay inside the row
+          const xt4u va = *(const GAS xt4u *)(rp + k0), vb = *(const GAS xt4u *)(rp + k0 + 4);
 #pragma unroll
-        for (int i = 0; i < 8; i++) {  // (slots past the row arrive as zeros; the load itself stays inside the row)
-          const int k = k0 + i;
-          const XT v = rp[k < D ? k : D - 1];
-          raw[mm][i] = (m < KB && k < D) ? v : (XT)0;
+          for (int i = 0; i < 4; i++) {
+            raw[it][mm][i] = va[i];
+            raw[it][mm][4 + i] = vb[i];
+          }
+        } else {
+#pragma unroll
+          for (int i = 0; i < 8; i++) {  // (slots past the row arrive as zeros; the load itself stays inside the row)
+            const int k = k0 + i;
+            const XT v = rp[k < D ? k : D - 1];
+            raw[it][mm][i] = (m < KB && k < D) ? v : (XT)0;
+          }
         }
       }
     }
-    float xn2 = 0.f;
 #pragma unroll
-    for (int mm = 0; mm < KBH; mm++) {
-      const int m = 2 * mm + mpar;
-      v4u32 p1, p2;
+    for (int it = 0; it < NIT; it++) {
+      const int mpar = (wv + NW * it) / NRT;
+      float xn2 = 0.f;
 #pragma unroll
-      for (int w = 0; w < 4; w++) {
-        float a0[2], a1[2];
+      for (int mm = 0; mm < KBH; mm++) {
+        const int m = 2 * mm + mpar;
+        v4u32 p1, p2;
 #pragma unroll
-        for (int i = 0; i < 2; i++) {
-          const float v = (float)raw[mm][2 * w + i];
-          xn2 = __builtin_fmaf(v, v, xn2);
-          a0[i] = v;
-          a1[i] = v - __uint_as_float(__float_as_uint(v) & 0xffff0000u);
+        for (int w = 0; w < 4; w++) {
+          float a0[2], a1[2];
+#pragma unroll
+          for (int i = 0; i < 2; i++) {
+            const float v = (float)raw[it][mm][2 * w + i];
+            xn2 = __builtin_fmaf(v, v, xn2);
+            a0[i] = v;
+            a1[i] = v - __uint_as_float(__float_as_uint(v) & 0xffff0000u);
+          }
+          // pieces by truncation: piece 1 = the upper half of the f32 pattern, piece 2 = the upper half of the exact remainder; two
+          // slots share a word, picked by ONE v_perm_b32.  A value that is not finite leaves a NaN in piece 2 (inf - inf, NaN - x)
+          p1[w] = __builtin_amdgcn_perm(__float_as_uint(a0[1]), __float_as_uint(a0[0]), 0x07060302u);
+          p2[w] = __builtin_amdgcn_perm(__float_as_uint(a1[1]), __float_as_uint(a1[0]), 0x07060302u);
         }
-        // pieces by truncation: piece 1 = the upper half of the f32 pattern, piece 2 = the upper half of the exact remainder; two
-        // slots share a word, picked by ONE v_perm_b32.  A value that is not finite leaves a NaN in piece 2 (inf - inf, NaN - x)
-        p1[w] = __builtin_amdgcn_perm(__float_as_uint(a0[1]), __float_as_uint(a0[0]), 0x07060302u);
-        p2[w] = __builtin_amdgcn_perm(__float_as_uint(a1[1]), __float_as_uint(a1[0]), 0x07060302u);
+        if (m < KB) {
+          s_b[rtw][m][0][lane] = p1;
+          s_b[rtw][m][1][lane] = p2;
+        }
       }
-      if (m < KB) {
-        s_b[rtw][m][0][lane] = p1;
-        s_b[rtw][m][1][lane] = p2;
-      }
+      xn2 += __shfl_xor(xn2, 32, 64);
+      if (lane < 32) s_x[mpar][32 * rtw + row] = xn2;  // (the row's ||x||^2 = the two parities' parts, summed by whoever needs it)
     }
-    xn2 += __shfl_xor(xn2, 32, 64);
-    if (lane < 32) s_x[mpar][32 * rtw + row] = xn2;  // (the row's ||x||^2 = the two waves' parts, summed by whoever needs it)
   }
   if (blockIdx.x == 0 && (st.flags & 6) && st.idx < *gp(sdesc.halt)) {
     // (k_step_assign's block: the stratum's chain is live.)  `counts < ratio * max(counts)` for the stratum's previous
@@ -1773,7 +1817,7 @@ __global__ __launch_bounds__(RANK_NW * 64, 2) void k_step_assign_ranked(const St
       }
     }
   }
-  __syncthreads();  // the four tiles' operand images are in LDS
+  __syncthreads();  // the row tiles' operand images are in LDS
   RPROF(0)
   XT pfv[2] = {(XT)0, (XT)0};
   if (pf_on) {  // (one dword per 128-byte line of the next call's row; lanes l and l + 32 share a row: every other line each)
@@ -1791,10 +1835,10 @@ __global__ __launch_bounds__(RANK_NW * 64, 2) void k_step_assign_ranked(const St
   // two.  The MFMAs of a (tile, row tile) unit are followed by its 64 ranking instructions: within one wave they do not overlap,
   // the SIMD's other wave fills the matrix unit meanwhile (measured: interleaving them in one wave's instruction order between
   // scheduling fences is slower -- the fences also pin the operand reads from LDS in front of their MFMAs) ----
-  float M1[4], M2[4], M3[4];
-  int J1[4], J2[4];
+  float M1[NRT], M2[NRT], M3[NRT];
+  int J1[NRT], J2[NRT];
 #pragma unroll
-  for (int rt = 0; rt < 4; rt++) {
+  for (int rt = 0; rt < NRT; rt++) {
     M1[rt] = M2[rt] = M3[rt] = ninf;
     J1[rt] = J2[rt] = 0;
   }
@@ -1805,7 +1849,7 @@ __global__ __launch_bounds__(RANK_NW * 64, 2) void k_step_assign_ranked(const St
 #pragma unroll
     for (int r = 0; r < 16; r++) init[r] = cur.i0[r >> 2][r & 3];
 #pragma unroll
-    for (int rt = 0; rt < 4; rt++) {
+    for (int rt = 0; rt < NRT; rt++) {
       v16f32 acc;
 #pragma unroll
       for (int m = 0; m < KB; m++) {
@@ -1842,7 +1886,7 @@ __global__ __launch_bounds__(RANK_NW * 64, 2) void k_step_assign_ranked(const St
   __syncthreads();  // nobody reads the operand images any more: their bytes take the waves' partial results
   // -> centroid indices; lanes l and l ^ 32 (same row, the other half of every tile's centroids) merged; one triple per wave and row
 #pragma unroll
-  for (int rt = 0; rt < 4; rt++) {
+  for (int rt = 0; rt < NRT; rt++) {
     const int q1 = (int)(__float_as_uint(M1[rt]) & 15u), q2 = (int)(__float_as_uint(M2[rt]) & 15u);
     int j1 = J1[rt] * 32 + 8 * (q1 >> 2) + 4 * h + (q1 & 3), j2 = J2[rt] * 32 + 8 * (q2 >> 2) + 4 * h + (q2 & 3);
     float a1 = M1[rt], a2 = M2[rt], a3 = M3[rt];
@@ -1893,15 +1937,15 @@ __global__ __launch_bounds__(RANK_NW * 64, 2) void k_step_assign_ranked(const St
       s_full[atomicAdd(&s_nfull, 1)] = tid;
     }
   }
-  // the rows seen so far bound the centroids to come (see the header): waves 0 and 1 publish their largest ||x||^2
-  if (wv < 2) {
+  // the rows seen so far bound the centroids to come (see the header): the rows' waves publish their largest ||x||^2
+  if (wv < RW / 64) {
     unsigned mu = __float_as_uint(mine ? xq * 1.00001f : 0.f);  // (non-negative or NaN: ordered like its bit pattern)
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) {
       const unsigned o = __shfl_xor(mu, off, 64);
       mu = o > mu ? o : mu;
     }
-    if (lane == 0 && mu > bu) atomicMax((unsigned *)&bndw[(blockIdx.x * 2 + wv) & (RANK_SLOTS - 1)], mu);
+    if (lane == 0 && mu > bu) atomicMax((unsigned *)&bndw[(blockIdx.x * (RW / 64) + wv) & (RANK_SLOTS - 1)], mu);
   }
   __syncthreads();
   RPROF(3)
@@ -2018,27 +2062,28 @@ __global__ __launch_bounds__(RANK_NW * 64, 2) void k_step_assign_ranked(const St
     __hip_atomic_fetch_or(&st.mbits[(size_t)label * sdesc.wstride + (rme >> 6)], 1ull << (rme & 63), __ATOMIC_RELAXED,
                           __HIP_MEMORY_SCOPE_AGENT);
   }
-  if (wv < 2 && rk.stat) {  // (the rows' threads sit in waves 0 and 1: one add per kind and wave)
+  if (wv < RW / 64 && rk.stat) {  // (the rows' threads sit in the first RW / 64 waves: one add per kind and wave)
 #pragma unroll
     for (int q = 0; q < 3; q++) {
       const int n = __popcll(__ballot(mine && kind == q));
       if (lane == 0 && n) atomicAdd(rk.stat + q, (unsigned long long)n);
     }
   }
-  {
+  if constexpr (NRT == 4) {
     // the batch rows as f64 for the M-step (rows of 4 KS doubles, the batch padded to whole 64-row tiles), from the values the
     // prologue loaded.  LAST: stores count in vmcnt, and issued in the prologue every later wait of the wave for a load also waited
     // for their acknowledgements (the sweep of a copying wave took 3 us longer).  Here nothing waits for them but the end of the kernel.
     const int ldg = 4 * KS;
     const long long n_pad = (st.n_b + 63) & ~63LL;
-    if (rmine < n_pad) {
+    const int mpar = wv / NRT;
+    if (st.Xg && rmine < n_pad) {  // (null: the M-step fetches member rows from the frames, HAMSM_STEP_DIRECT)
       GAS double *xg = st.Xg + (size_t)rmine * ldg;
 #pragma unroll
       for (int mm = 0; mm < KBH; mm++)
 #pragma unroll
         for (int w = 0; w < 4; w++)
           if (const int k = 16 * (2 * mm + mpar) + 8 * h + 2 * w; k < ldg)  // (ldg is a multiple of 4, k even: the pair stays inside the row)
-            *(GAS v2f64 *)(xg + k) = (v2f64){(double)raw[mm][2 * w], (double)raw[mm][2 * w + 1]};
+            *(GAS v2f64 *)(xg + k) = (v2f64){(double)raw[0][mm][2 * w], (double)raw[0][mm][2 * w + 1]};
     }
   }
   asm volatile("" ::"v"(pfv[0]), "v"(pfv[1]));  // the touched lines are only wanted in L2
@@ -2055,7 +2100,7 @@ __global__ __launch_bounds__(RANK_NW * 64, 2) void k_step_assign_ranked(const St
 #define UPD_LIST 1024
 #define UPD_SC 768  // member rows the strip holds per pass: ints [0, 768); weights of a 64-member chunk: ints [768, 896)
 // (`apk` != null -- the ranked E-step's run, below: the wave also rewrites its centroid's bf16 fragments, KB blocks of 16 slots)
-template <typename XT, int H, bool BYVAL, int UPD_NBK>
+template <typename XT, int H, bool BYVAL, int UPD_NBK, bool DIRECT = false>
 __device__ __forceinline__ void step_update_body(const StepDev *__restrict__ steps, const StepPack &pk, int64_t ldx, int D, int KS,
                                                  GAS unsigned short *apk, GAS float *hcs, int KB) {
   SPROF_ID
@@ -2112,15 +2157,19 @@ __device__ __forceinline__ void step_update_body(const StepDev *__restrict__ ste
       if (bk < nblk) {
         if (w[bk]) mb[wb0 + 64 * bk + lane] = 0ull;  // ready for the stratum's next step
         const int pc = __popcll(w[bk]);
-        int inc = pc;  // inclusive prefix sum over the lanes
-#pragma unroll
-        for (int off = 1; off < 64; off <<= 1) {
-          const int t = __shfl_up(inc, off, 64);
-          inc += lane >= off ? t : 0;
+        // exclusive prefix sum of the popcounts over the lanes, level by level: sum_{l < lane} pc_l = sum_k #{l < lane: pc_l > k}.
+        // A cluster's members are a handful of set bits in the centroid's bitmap words: one or two ballots instead of six
+        // LDS-crossbar shuffles in a dependent chain (round 5: this phase was 1.8 of the M-step wave's 5.9 us at C5's shape)
+        int ex = 0, tot = 0;
+        for (int k = 0;; k++) {
+          const unsigned long long bal = __ballot(pc > k);
+          if (!bal) break;
+          ex += __builtin_amdgcn_mbcnt_hi((unsigned)(bal >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bal, 0u));
+          tot += __popcll(bal);
         }
-        excl[bk] = inc - pc;
+        excl[bk] = ex;
         base[bk] = blk;
-        blk += __shfl(inc, 63, 64);
+        blk += tot;
       }
     }
     SPROF_W(1, 2)
@@ -2137,18 +2186,34 @@ __device__ __forceinline__ void step_update_body(const StepDev *__restrict__ ste
         }
       }
       const int np = blk - p0 < UPD_SC ? blk - p0 : UPD_SC;
-      for (int m0 = 0; m0 < np; m0 += 64 / H) {
-        const int cm = np - m0 < 64 / H ? np - m0 : 64 / H;
+      if constexpr (DIRECT) {
+        // batch rows -> frame indices, the whole strip in one round trip (the call's row list is L2-warm: the E-step read it)
+        if (st.rows)
+          for (int e = lane; e < np; e += 64) srow[e] = (unsigned)st.rows[srow[e]];
+      }
+      // member rows fetched together per pass: 64 / H (f64 copy) -- or 32 from the frames: with 32 rows in flight the wave fits
+      // 128 registers, four waves per SIMD, and all ~630 workgroups of a C5 launch are resident at once (with 252 they were not:
+      // the launch's last workgroups started 7 us after its first)
+      constexpr int MW = DIRECT ? 32 / H : 64 / H;
+      for (int m0 = 0; m0 < np; m0 += MW) {
+        const int cm = np - m0 < MW ? np - m0 : MW;
         if (weighted) {
           if (lane < cm) {
             const long long r = srow[m0 + lane];
-            swl[lane] = st.wf[st.rows ? (long long)st.rows[r] : r];
+            swl[lane] = st.wf[(!DIRECT && st.rows) ? (long long)st.rows[r] : r];
           }
           for (int q = 0; q < cm; q++) wsum = wsum + swl[q];  // sample order (pyx:80-85)
         }
-        if (cm <= 16 / H) upd_add_listed<16 / H, H>(acc, Xg, ldg, srow + m0, swl, weighted, 0, cm, D, lane);
-        else if (cm <= 32 / H) upd_add_listed<32 / H, H>(acc, Xg, ldg, srow + m0, swl, weighted, 0, cm, D, lane);
-        else upd_add_listed<64 / H, H>(acc, Xg, ldg, srow + m0, swl, weighted, 0, cm, D, lane);
+        if constexpr (DIRECT) {
+          const GAS XT *Xf = (const GAS XT *)st.X;
+          if (cm <= 8 / H) upd_add_direct<8 / H, H, XT>(acc, Xf, ldx, srow + m0, swl, weighted, 0, cm, D, lane);
+          else if (cm <= 16 / H) upd_add_direct<16 / H, H, XT>(acc, Xf, ldx, srow + m0, swl, weighted, 0, cm, D, lane);
+          else upd_add_direct<32 / H, H, XT>(acc, Xf, ldx, srow + m0, swl, weighted, 0, cm, D, lane);
+        } else {
+          if (cm <= 16 / H) upd_add_listed<16 / H, H>(acc, Xg, ldg, srow + m0, swl, weighted, 0, cm, D, lane);
+          else if (cm <= 32 / H) upd_add_listed<32 / H, H>(acc, Xg, ldg, srow + m0, swl, weighted, 0, cm, D, lane);
+          else upd_add_listed<64 / H, H>(acc, Xg, ldg, srow + m0, swl, weighted, 0, cm, D, lane);
+        }
       }
     }
     total += blk;
@@ -2198,9 +2263,9 @@ __global__ __launch_bounds__(256) void k_step_update(const StepDev *__restrict__
                                                      int KS) {
   step_update_body<XT, H, BYVAL, UPD_NBK>(steps, pk, ldx, D, KS, nullptr, nullptr, 0);
 }
-template <typename XT, int UPD_NBK>
-__global__ __launch_bounds__(256) void k_step_update_ranked(const StepPack pk, const RankPack rk, int64_t ldx, int D, int KS, int KB) {
-  step_update_body<XT, 1, true, UPD_NBK>(nullptr, pk, ldx, D, KS, (GAS unsigned short *)gp(rk.apk[blockIdx.y]), gp(rk.hcs[blockIdx.y]), KB);
+template <typename XT, int UPD_NBK, bool DIRECT>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DIRECT ? 3 : 1))) void k_step_update_ranked(const StepPack pk, const RankPack rk, int64_t ldx, int D, int KS, int KB) {
+  step_update_body<XT, 1, true, UPD_NBK, DIRECT>(nullptr, pk, ldx, D, KS, (GAS unsigned short *)gp(rk.apk[blockIdx.y]), gp(rk.hcs[blockIdx.y]), KB);
 }
 
 
@@ -2868,7 +2933,13 @@ static int launch_steps_ranked(hamsm_ctx *c, hipStream_t q, const StepPack &pk, 
   // bits (64 u, 32 u); -csq / 2 rounded to f32 once (1 u)
   const float c1 = 2.02f * (float)(6186 + 2 * (2 + 204 * KB) + 64) / 16777216.0f;
   const float c2 = 2.02f * (float)(204 * KB + 1 + 32) / 16777216.0f;
-  const dim3 ga((unsigned)((max_nb + 127) / 128), (unsigned)ny);
+  // 256-row workgroups where 128-row ones of ALL the context's strata (the queues run side by side) would not fit the chip at one
+  // workgroup per CU -- C5's shape: 4 x 98 -> 4 x 49; runs without the f64 batch copy only (the copy is written per 128 rows)
+  const bool direct = pk.s[0].Xg == nullptr;
+  // (256-row workgroups: built, bit-identical, measured slower at C5's shape -- 54 against 50 us per launch: every phase of a
+  // workgroup scales with its rows, the fragment stream does not bind -- and taken only when forced: HAMSM_STEP_WIDE=2)
+  const bool wide = direct && c->step_wide == 2;
+  const dim3 ga((unsigned)((max_nb + (wide ? 255 : 127)) / (wide ? 256 : 128)), (unsigned)ny);
   const bool sample = q == c->stream && !HAMSM_CAPTURING(c) && c->ks_stamps && (c->ks_tick++ & 127) == 0 && c->ks_pending.size() < HAMSM_KS_SLOTS;
   hamsm_ctx::KSample ks{nullptr, nullptr, nullptr};
   unsigned long long *stamp = nullptr;
@@ -2891,7 +2962,10 @@ static int launch_steps_ranked(hamsm_ctx *c, hipStream_t q, const StepPack &pk, 
   }
   switch (KB) {
 #define CASE(KBV) \
-  case KBV: hipLaunchKernelGGL((k_step_assign_ranked<XT, KBV>), ga, dim3(RANK_NW * 64), 0, q, pk, rk, ldx, c->D, c->KS, ratio, c1, c2, stamp); break;
+  case KBV:                                                                                                                                 \
+    if (wide) hipLaunchKernelGGL((k_step_assign_ranked<XT, KBV, 8>), ga, dim3(RANK_NW * 64), 0, q, pk, rk, ldx, c->D, c->KS, ratio, c1, c2, stamp); \
+    else hipLaunchKernelGGL((k_step_assign_ranked<XT, KBV, 4>), ga, dim3(RANK_NW * 64), 0, q, pk, rk, ldx, c->D, c->KS, ratio, c1, c2, stamp);      \
+    break;
     CASE(1) CASE(2) CASE(3) CASE(4)
 #undef CASE
     default: return hamsm_fail(c, HAMSM_ENOTSUP, "ranked E-step: %d blocks of feature slots", KB);
@@ -2899,8 +2973,13 @@ static int launch_steps_ranked(hamsm_ctx *c, hipStream_t q, const StepPack &pk, 
   if (sample) hipEventRecord(ks.e1, q);
   const size_t lds = sizeof(int) * (4 * UPD_LIST);
   const dim3 gu((unsigned)((maxK + 3) / 4), (unsigned)ny);
-  if (max_nb > 4096) hipLaunchKernelGGL((k_step_update_ranked<XT, 4>), gu, dim3(256), lds, q, pk, rk, ldx, c->D, c->KS, KB);
-  else hipLaunchKernelGGL((k_step_update_ranked<XT, 1>), gu, dim3(256), lds, q, pk, rk, ldx, c->D, c->KS, KB);
+  if (direct) {
+    if (max_nb > 4096) hipLaunchKernelGGL((k_step_update_ranked<XT, 4, true>), gu, dim3(256), lds, q, pk, rk, ldx, c->D, c->KS, KB);
+    else hipLaunchKernelGGL((k_step_update_ranked<XT, 1, true>), gu, dim3(256), lds, q, pk, rk, ldx, c->D, c->KS, KB);
+  } else {
+    if (max_nb > 4096) hipLaunchKernelGGL((k_step_update_ranked<XT, 4, false>), gu, dim3(256), lds, q, pk, rk, ldx, c->D, c->KS, KB);
+    else hipLaunchKernelGGL((k_step_update_ranked<XT, 1, false>), gu, dim3(256), lds, q, pk, rk, ldx, c->D, c->KS, KB);
+  }
   if (sample) {
     hipEventRecord(ks.e2, q);
     c->ks_pending.push_back(ks);
@@ -2974,10 +3053,6 @@ static int run_steps(hamsm_ctx *c, const void *X, int dt, int64_t ldx, const int
   const size_t nb_pad = ((size_t)nb_max + 63) & ~(size_t)63;  // whole E-step tiles (up to 4 x 16 rows)
   int Kmax = 0;
   for (int s = 0; s < c->S; s++) Kmax = c->st[s].K > Kmax ? c->st[s].K : Kmax;
-  size_t o_xg = take(generic ? 0 : xg_row * (size_t)nslot * nb_pad);  // (the generic M-step reads the frames in place)
-  const int wstride = (int)((((nb_max + 63) >> 6) + 63) & ~(int64_t)63);  // bitmap words per centroid
-  const size_t mb_bytes = sizeof(unsigned long long) * (size_t)nslot * Kmax * wstride;
-  size_t o_mb = take(mb_bytes), o_tail = take(sizeof(StepDev) * (size_t)c->S);
   // Calls whose E-step is bound by the f64 matrix unit rank their centroids on the bf16 unit instead (k_step_assign_ranked: same
   // labels).  Decided per run -- the fragments are maintained from step to step -- by its heaviest CALL (rows x centroids x
   // features x 2 of one stratum's step: 0.15 GFLOP by default -- tools/rankgate.py: at 0.04 GFLOP, C3, the f64 kernel is 1.3x
@@ -2993,6 +3068,11 @@ static int run_steps(hamsm_ctx *c, const void *X, int dt, int64_t ldx, const int
     }
     ranked = top >= c->step_ranked_min_flop;
   }
+  const bool direct = ranked && c->step_direct;  // ranked runs: member rows straight from the frames (no copy)
+  size_t o_xg = take((generic || direct) ? 0 : xg_row * (size_t)nslot * nb_pad);  // (the generic M-step reads the frames in place)
+  const int wstride = (int)((((nb_max + 63) >> 6) + 63) & ~(int64_t)63);  // bitmap words per centroid
+  const size_t mb_bytes = sizeof(unsigned long long) * (size_t)nslot * Kmax * wstride;
+  size_t o_mb = take(mb_bytes), o_tail = take(sizeof(StepDev) * (size_t)c->S);
   const size_t apk_words = (size_t)((Kmax + 31) / 32) * KBr * 2 * 256;  // per stratum
   const size_t hcs_words = (size_t)((Kmax + 31) / 32) * 32;
   size_t o_apk = take(ranked ? sizeof(unsigned) * apk_words * (size_t)c->S : 0), o_bnd = take(ranked ? sizeof(unsigned) * RANK_SLOTS * (size_t)c->S : 0),
@@ -3044,7 +3124,7 @@ static int run_steps(hamsm_ctx *c, const void *X, int dt, int64_t ldx, const int
   for (size_t g = 0; g + 1 < gstart.size(); g++)
     for (int64_t j0 = gstart[g]; j0 < gstart[g + 1]; j0++) {
       const size_t slot = nslot == c->S ? (size_t)h_steps[j0].stratum : (size_t)(j0 - gstart[g]);
-      sd[j0].Xg = (double *)(b + o_xg + slot * nb_pad * xg_row);
+      sd[j0].Xg = direct ? nullptr : (double *)(b + o_xg + slot * nb_pad * xg_row);
       sd[j0].mbits = (unsigned long long *)(b + o_mb) + slot * Kmax * wstride;
       sd[j0].wstride = wstride;
     }
@@ -3290,6 +3370,14 @@ static int run_steps(hamsm_ctx *c, const void *X, int dt, int64_t ldx, const int
 
 // Not part of the product ABI (test / bench hook): out[4] = batch rows the ranked E-step certified / settled between two candidates /
 // swept exactly, and the runs that took it, since the last reset; mode >= 0 also sets HAMSM_STEP_RANKED's value for the context
+// (test hook) shape of the ranked training kernels: wide = 0 never / 1 by size / 2 always 256-row E-step workgroups; direct = 1: the
+// M-step fetches member rows from the frames, 0: round 4's f64 batch copy.  Negative: leave as is.
+extern "C" int hamsm_debug_step_shape(hamsm_ctx *c, int wide, int direct) {
+  CTX(c);
+  if (wide >= 0) c->step_wide = wide > 2 ? 2 : wide;
+  if (direct >= 0) c->step_direct = direct != 0;
+  return HAMSM_OK;
+}
 extern "C" int hamsm_debug_rank_stats(hamsm_ctx *c, unsigned long long *out, int reset, int mode) {
   CTX(c);
   for (int k = 0; k < 4; k++) {

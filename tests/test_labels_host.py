@@ -14,6 +14,8 @@ from msm_we_amd import _abi
 def test_dtrajs_are_lazy_views_that_outlive_the_context(request, backend):
     lib = request.getfixturevalue("oracle_lib" if backend == "oracle" else "hip_lib")
     g, meta = load_golden("c1p_d10")
+    gc.collect()
+    _abi.HostBlock.drain()            # (earlier tests of the session may have left blocks of this very size in the pool)
     h = _abi.Hamsm(lib=lib)
     m, _ = build_model(h, g, meta)
     assert m._dtrajs_cache is None and m._pairs_cache is None       # nothing crossed the link yet
