@@ -322,6 +322,20 @@ def torch_exchange(h, dist, torch, rank, world, dev="cuda"):
                 Cm, counts, csq = state[0]
                 h.set_centroids(s, Cm if len(Cm) else None, csq=csq if len(Cm) else None, counts=counts if len(Cm) else None)
 
+    def exchange(d_send, send_bytes, d_recv, recv_bytes):
+        sb, rb = [int(x) for x in send_bytes], [int(x) for x in recv_bytes]
+        a = np.empty(sum(sb), dtype=np.uint8)
+        if a.size:
+            h.d2h(a, d_send)
+        cuts = np.cumsum([0] + sb)
+        rows = [None] * world
+        dist.all_gather_object(rows, [a[cuts[q]: cuts[q + 1]] for q in range(world)])
+        mine = [rows[r][rank] for r in range(world)]
+        assert [len(x) for x in mine] == rb
+        if sum(rb):
+            h.h2d(d_recv, np.concatenate(mine))
+
+    h.exchange = exchange
     h.bcast, h.bcast_model, h.gather_to_root, h.bcast_strata = bcast, bcast_model, gather_to_root, bcast_strata
     h.comm_destroy = lambda: None
 

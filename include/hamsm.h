@@ -398,6 +398,16 @@ int hamsm_gather_to_root(hamsm_ctx *ctx, const void *d_send, size_t send_bytes, 
                          int root);
 /* broadcast the whole model state (centroids, counts, csq, remap) from root to every rank.       */
 int hamsm_bcast_model(hamsm_ctx *ctx, int root);
+/* (ABI 9) `train_shards = "strata"` without shipping every frame to every rank (round 4 did: R rooted gathers, each rank
+ * received ALL training frames).  The sender packs, per destination, the rows of its shard whose stratum -- after the training
+ * call's remap, `_clustering.py:800-826` -- trains on that rank (hamsm_gather_rows: d_dst row i = d_src row d_idx[i], rows of
+ * row_bytes = a multiple of 4 bytes), and ONE grouped exchange moves them (hamsm_exchange: h_send_bytes[q] bytes to rank q,
+ * consecutive in d_send in rank order; h_recv_bytes[q] bytes from rank q, consecutive in d_recv in rank order; the size tables
+ * are cross-checked collectively before any transfer, as in hamsm_gather_to_root).  Ranks hold consecutive blocks of WE
+ * iterations, so what arrives in rank order is in iteration order: the receiving rank trains its strata on exactly the rows, in
+ * exactly the order, one process holding every iteration would (`_clustering.py:843-899`).                                     */
+int hamsm_gather_rows(hamsm_ctx *ctx, const void *d_src, size_t row_bytes, const int64_t *d_idx, int64_t n, void *d_dst);
+int hamsm_exchange(hamsm_ctx *ctx, const void *d_send, const int64_t *h_send_bytes, void *d_recv, const int64_t *h_recv_bytes);
 /* (ABI 7) the same with a root PER STRATUM: stratum s's centroids, counts and csq travel from rank h_root[s] (h_root[S], the same
  * on every rank), the remap table from rank 0.  The reference fits one MiniBatchKMeans per WE bin (`_clustering.py:890-911`,
  * `stratified_clustering.py:55-99`): the strata's chains of partial_fits are independent, so different ranks can train

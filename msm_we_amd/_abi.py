@@ -91,6 +91,8 @@ SYMBOLS = {
     "hamsm_allreduce_sum_i64": (_int, [_vp, _vp, _i64]),
     "hamsm_bcast": (_int, [_vp, _vp, _sz, _int]),
     "hamsm_gather_to_root": (_int, [_vp, _vp, _sz, _vp, _vp, _int]),
+    "hamsm_gather_rows": (_int, [_vp, _vp, _sz, _vp, _i64, _vp]),
+    "hamsm_exchange": (_int, [_vp, _vp, _vp, _vp, _vp]),
     "hamsm_bcast_model": (_int, [_vp, _int]),
     "hamsm_bcast_strata": (_int, [_vp, _vp]),
     "hamsm_timers": (_int, [_vp, _vp, _int]),
@@ -704,6 +706,18 @@ class Hamsm:
     def gather_to_root(self, d_send, send_bytes, d_recv, recv_bytes, root=0):
         rb = np.ascontiguousarray(recv_bytes, dtype=np.int64)
         self._ck(self.lib.hamsm_gather_to_root(self.ctx, _dp(d_send), int(send_bytes), _dp(d_recv), _hp(rb), int(root)))
+
+    def gather_rows(self, d_src, row_bytes, d_idx, n, d_dst):
+        """d_dst row i = d_src row d_idx[i] (int64 indices on the device; rows of `row_bytes` = a multiple of 4 bytes)"""
+        self._ck(self.lib.hamsm_gather_rows(self.ctx, _dp(d_src), int(row_bytes), _dp(d_idx), int(n), _dp(d_dst)))
+
+    def exchange(self, d_send, send_bytes, d_recv, recv_bytes):
+        """send_bytes[q] bytes to rank q (consecutive in d_send, rank order), recv_bytes[q] from rank q (consecutive in d_recv)"""
+        sb = np.ascontiguousarray(send_bytes, dtype=np.int64)
+        rb = np.ascontiguousarray(recv_bytes, dtype=np.int64)
+        assert len(sb) == len(rb) == max(1, getattr(self, "nranks", 1))
+        self._ck(self.lib.hamsm_exchange(self.ctx, _dp(d_send) if d_send is not None else None, _hp(sb),
+                                         _dp(d_recv) if d_recv is not None else None, _hp(rb)))
 
     def bcast_strata(self, roots):
         """stratum s's model from rank roots[s] to every rank (remap table from rank 0)"""

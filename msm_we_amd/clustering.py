@@ -17,6 +17,8 @@ from copy import deepcopy
 
 import numpy as np
 
+from . import _abi
+from .data import DeviceStore
 from .stratified_clustering import StratifiedClusters
 
 log = logging.getLogger("msm_we_amd")
@@ -151,7 +153,13 @@ class ClusteringMixin:
             raise ValueError('train_shards = "strata" needs an integer random_state (independent streams per stratum); '
                              'use train_shards = "all"')
         trains_here = by_strata or rank == 0
-        tstore, t_maxIter = self.training_store()
+        plan_given = None
+        if by_strata:
+            # every rank receives the rows of ITS strata only (one grouped exchange, cached per (clusters, iterations, mapper)),
+            # with the global plan the rows were dealt by
+            tstore, t_maxIter, plan_given = self._strata_training_store(n_clusters, iters_to_use, first_cluster_iter, bin_mapper)
+        else:
+            tstore, t_maxIter = self.training_store()
         all_filled = set()
         train_error = None
         if trains_here:
@@ -160,7 +168,7 @@ class ClusteringMixin:
             # a library error, out of memory ...) is carried into `_all_ranks_ok` and raised on EVERY rank.
             try:
                 all_filled = self._train_on_this_rank(clusters, tstore, t_maxIter, iters_to_use, first_cluster_iter, n_clusters,
-                                                      bin_mapper, by_strata, S, R, rank)
+                                                      bin_mapper, by_strata, S, R, rank, plan_given=plan_given)
                 # :718-731 never-trained bins are remapped to the nearest trained one
                 for ub in np.setdiff1d(range(S), list(all_filled)):
                     clusters.we_remap[int(ub)] = int(self.find_nearest_bin(bin_mapper, ub, list(all_filled)))
@@ -210,7 +218,7 @@ class ClusteringMixin:
         self.launch_ray_discretization(progress_bar)
 
     def _train_on_this_rank(self, clusters, tstore, t_maxIter, iters_to_use, first_cluster_iter, n_clusters, bin_mapper,
-                            by_strata, S, R, rank):
+                            by_strata, S, R, rank, plan_given=None):
         """the rank-local training phase of `cluster_stratified`: plan from the histogram, then the planned (or stepwise) pass over
         the strata this rank fits.  Returns the set of bins some call fits (the same on every rank: a function of the histogram)."""
         h = self.h
@@ -220,17 +228,21 @@ class ClusteringMixin:
             iters_to_use = [int(i) for i in iters_to_use]
         # a5 planning support: raw bin (or -1 in basis/target) of every frame's PARENT pcoord
         # (:849-852 pcoord0List, quirk Q2) + per-iteration histograms, one pass over p0
-        d_bin = h.alloc(tstore.N, np.int32)
+        d_bin = plan_given[2] if plan_given is not None else h.alloc(max(tstore.N, 1), np.int32)
         d_rows = None
         try:
-            if self._mapper_external:
-                h.set_frame_bins(self._frame_bins("p0", bin_mapper, tstore))
-            hist = h.train_prepass(tstore.p0, tstore.N, tstore.offsets, d_bin)
             d_rows = h.alloc(max(tstore.N, 1), np.int32)
-            plan, all_filled = self._plan_training_calls(hist, iters_to_use, n_clusters, bin_mapper, store=tstore, maxIter=t_maxIter)
-            if by_strata:   # the plan is a function of the histogram only: the same on every rank; each fits its own strata
+            if plan_given is not None:
+                # `train_shards = "strata"`: the plan of the WHOLE run (from the all-reduced histogram, the same on every rank) and
+                # the bins the received frames are indexed under (`_strata_training_store`); this rank fits the strata it owns
+                plan, all_filled = dict(plan_given[0]), set(plan_given[1])
                 mine = (np.arange(S) % R) == rank
                 plan["fit"] = plan["fit"] & mine[None, :]
+            else:
+                if self._mapper_external:
+                    h.set_frame_bins(self._frame_bins("p0", bin_mapper, tstore))
+                hist = h.train_prepass(tstore.p0, tstore.N, tstore.offsets, d_bin)
+                plan, all_filled = self._plan_training_calls(hist, iters_to_use, n_clusters, bin_mapper, store=tstore, maxIter=t_maxIter)
             done = False
             if getattr(self, "speculative_training", True):
                 done = self._train_planned(plan, clusters, tstore, d_bin, d_rows)
@@ -238,10 +250,177 @@ class ClusteringMixin:
                 self._train_stepwise(plan, clusters, tstore, d_bin, d_rows)
             self.training_path = "planned" if done else "stepwise"
         finally:
-            d_bin.free()
+            if plan_given is None:
+                d_bin.free()
             if d_rows is not None:
                 d_rows.free()
         return all_filled
+
+    def _strata_training_store(self, n_clusters, iters_to_use, first_cluster_iter, bin_mapper):
+        """`train_shards = "strata"`: (store, maxIter, (plan, all_filled, d_bin)) this rank trains on.  Stratum s trains on rank
+        s % R.  Which rows a stratum's call sees is the reference's, quirk included: a training call lists, per (remapped) bin,
+        the POSITIONS of its rows among the call's rows whose parent pcoord is outside basis / target, and applies those
+        positions to the call's UNFILTERED frames (`_clustering.py:874` vs `:892-896`; `hamsm_train_build_rows`).  So the
+        frame a stratum needs is "frame number r of the call", where r is the filtered position of a row whose bin it owns.
+        Which calls exist is a function of the per-iteration bin histogram of the WHOLE run (`_plan_training_calls`).  Hence:
+        histograms (and iteration sizes) all-reduced, the plan formed on every rank, every rank packs -- per destination -- the
+        frames of its own iterations that the destination's strata will index (`hamsm_gather_rows`), each with its weight and
+        with the BIN of the row that selects it, and ONE grouped exchange per array (`hamsm_exchange`) moves them.  Ranks hold
+        consecutive blocks of iterations, so what arrives in rank order is in call order, positions ascending: the receiver's
+        row r of a call IS the frame its r-th row selects -- it trains on exactly the frames, in exactly the order, a single
+        process would.  Round 4 sent every frame to every rank (R rooted gathers; 12.8 GB per rank at C5 whatever R)."""
+        h = self.h
+        R, rank = h.nranks, h.rank
+        S = bin_mapper.nbins
+        key = (int(n_clusters), None if iters_to_use is None else tuple(int(i) for i in iters_to_use), first_cluster_iter,
+               type(bin_mapper).__name__, tuple(np.asarray(b, dtype=np.float64).tobytes() for b in getattr(bin_mapper, "boundaries", ())),
+               np.asarray(getattr(bin_mapper, "centers", ()), dtype=np.float64).tobytes())
+        cache = self.__dict__.get("_strata_store")
+        if cache is not None and cache[0] == key:
+            return cache[1]
+        store = self.stage_iterations()
+        n_it = max(self.maxIter - 1, 0)                      # local iterations 1..n_it are discretized / trained on
+        offs = np.asarray(store.offsets[: n_it + 1], dtype=np.int64)
+        N_loc = int(offs[-1]) if n_it else 0
+        nan = store.nan_child is not None
+
+        def allsum(a):
+            d = h.to_device(np.ascontiguousarray(a, dtype=np.int64))
+            h.allreduce_sum_i64(d, a.size)
+            out = d.to_host().reshape(a.shape)
+            d.free()
+            return out
+
+        # (a) how many iterations every rank holds, frame layout agreed
+        head = np.zeros(3 * R, dtype=np.int64)
+        head[rank], head[R + rank], head[2 * R + rank] = n_it, store.x_dtype * 4096 + store.D, int(nan)
+        head = allsum(head)
+        cnt = head[:R]
+        if head[2 * R:].any():
+            raise NotImplementedError("NaN-coordinate segments in a sharded run with train_shards='strata'")
+        assert (head[R: 2 * R] == store.x_dtype * 4096 + store.D).all(), "ranks staged different frame layouts"
+        T, lo = int(cnt.sum()), int(cnt[:rank].sum())
+        first_it = np.concatenate([[0], np.cumsum(cnt)])       # rank r holds global iterations first_it[r] + 1 .. first_it[r + 1]
+        # (b) raw bin (-1: basis / target) of every local row's parent pcoord; per-iteration histograms and sizes, all-reduced
+        d_bin = h.alloc(max(N_loc, 1), np.int32)
+        tab = np.zeros((T + 1, S + 1), dtype=np.int64)         # (+ one empty row: `iters_to_use` may name iteration T + 1)
+        bins = np.zeros(0, dtype=np.int64)
+        if N_loc:
+            if self._mapper_external:
+                h.set_frame_bins(self._frame_bins("p0", bin_mapper, store))
+            tab[lo: lo + n_it, :S] = h.train_prepass(store.p0, N_loc, offs, d_bin)
+            tab[lo: lo + n_it, S] = np.diff(offs)
+            bins = d_bin.to_host()[:N_loc].astype(np.int64)
+        d_bin.free()
+        tab = allsum(tab)
+        hist_g, sizes_g = tab[:, :S], tab[:T, S]
+        # (c) the plan of the whole run, in global iteration numbers 1..T
+        it_use = iters_to_use
+        if it_use is None:
+            it_use = range(first_cluster_iter if first_cluster_iter is not None else 1, T + 1)
+        if not (isinstance(it_use, range) and it_use.step == 1):
+            it_use = [int(i) for i in it_use]
+        plan, all_filled = self._plan_training_calls(hist_g, it_use, n_clusters, bin_mapper, store=None, maxIter=T + 1)
+        G = len(plan["first"])
+        # per (call, raw bin): the rank whose stratum the bin's rows feed, or -1 (bin not fitted by the call)
+        tgt = plan["call_remap"].astype(np.int64) if G else np.zeros((0, S), dtype=np.int64)
+        owner = np.where(np.take_along_axis(plan["fit"], tgt, axis=1), tgt % R, -1) if G else np.zeros((0, S), dtype=np.int64)
+        ca, cb = plan["first"].astype(np.int64) - 1, plan["last"].astype(np.int64)       # call g = global iterations [ca, cb) (0-based)
+        # (d) calls that straddle a shard boundary: their rows' bins are needed by every rank that holds a part of them
+        strad = [g for g in range(G) if np.searchsorted(first_it, ca[g], side="right") != np.searchsorted(first_it, cb[g] - 1, side="right")]
+        x_its = np.array(sorted({t for g in strad for t in range(int(ca[g]), int(cb[g]))}), dtype=np.int64)
+        x_off = np.concatenate([[0], np.cumsum(sizes_g[x_its])]).astype(np.int64) if len(x_its) else np.zeros(1, dtype=np.int64)
+        xb = np.zeros(int(x_off[-1]), dtype=np.int64)
+        for k, t in enumerate(x_its):
+            if lo <= t < lo + n_it:
+                xb[x_off[k]: x_off[k + 1]] = bins[offs[t - lo]: offs[t - lo + 1]] + 2      # (0 = not mine; + 2: bins >= -1)
+        xb = allsum(xb) - 2 if len(xb) else xb
+        # (e) destination of every local FRAME and the bin it is indexed under.  Call by call: the bins of the call's rows in
+        # order (local, or from (d)), the filtered ones numbered 0, 1, ...; frame number r of the call belongs to row r's stratum
+        dest = np.full(N_loc, -1, dtype=np.int64)
+        bin_of_frame = np.full(N_loc, -1, dtype=np.int64)
+        recv_rows = np.zeros(R, dtype=np.int64)               # rows this rank receives, by sender
+        call_rows = np.zeros(G, dtype=np.int64)               # rows of each call that arrive here
+        x_pos = {int(t): k for k, t in enumerate(x_its)}
+        # (calls inside one shard, vectorised over this rank's rows: position among the filtered rows since the call's start)
+        if N_loc:
+            call_of_it = np.full(T, -1, dtype=np.int64)
+            for g in range(G):
+                call_of_it[ca[g]: cb[g]] = g
+            inside = np.ones(G, dtype=bool)
+            inside[strad] = False
+            it_row = np.repeat(np.arange(n_it, dtype=np.int64), np.diff(offs))
+            g_row = call_of_it[lo + it_row]
+            ok = (bins >= 0) & (g_row >= 0)
+            ok[ok] &= inside[g_row[ok]]
+            start_frame = offs[np.maximum(ca[np.maximum(g_row, 0)] - lo, 0)]              # first local frame of the row's call
+            nf = np.concatenate([[0], np.cumsum(bins >= 0)])
+            pos = start_frame + (nf[:-1] - nf[start_frame])                                # the frame row i selects
+            own = owner[np.maximum(g_row, 0), np.maximum(bins, 0)]
+            sel = ok & (own >= 0)
+            dest[pos[sel]] = own[sel]
+            bin_of_frame[pos[sel]] = bins[sel]
+        for g in range(G):
+            mine_b = plan["fit"][g] & ((np.arange(S) % R) == rank)
+            call_rows[g] = int(plan["nrows"][g][mine_b].sum())
+        for r in range(R):     # senders of the calls inside one shard
+            gs = [g for g in range(G) if g not in set(strad) and first_it[r] <= ca[g] < first_it[r + 1]]
+            recv_rows[r] += int(call_rows[gs].sum()) if gs else 0
+        for g in strad:        # (rare: a call whose iterations lie on two or more ranks)
+            seq = np.concatenate([xb[x_off[x_pos[int(t)]]: x_off[x_pos[int(t)] + 1]] for t in range(int(ca[g]), int(cb[g]))])
+            nfb = seq[seq >= 0]
+            own_r = owner[g][nfb]                                                         # owner of frame number r of the call
+            sz = sizes_g[ca[g]: cb[g]]
+            frame_it = np.repeat(np.arange(int(ca[g]), int(cb[g])), sz)[: len(nfb)]       # iteration that holds frame number r
+            src_rank = np.searchsorted(first_it, frame_it, side="right") - 1
+            for r in range(R):
+                recv_rows[r] += int(((own_r == rank) & (src_rank == r)).sum())
+            here = (src_rank == rank) & (own_r >= 0)
+            if here.any():
+                base = int(np.concatenate([[0], np.cumsum(sz)])[max(lo - int(ca[g]), 0)])  # call-relative number of my first frame
+                loc0 = int(offs[max(int(ca[g]) - lo, 0)])
+                r_idx = np.nonzero(here)[0]
+                dest[loc0 + r_idx - base] = own_r[r_idx]
+                bin_of_frame[loc0 + r_idx - base] = nfb[r_idx]
+        if N_loc:
+            order = np.argsort(dest, kind="stable")
+            idx = order[dest[order] >= 0]
+            send_rows = np.bincount(dest[dest >= 0], minlength=R).astype(np.int64)
+        else:
+            idx, send_rows = np.zeros(0, dtype=np.int64), np.zeros(R, dtype=np.int64)
+        Nr = int(recv_rows.sum())
+        assert Nr == int(call_rows.sum()), (Nr, int(call_rows.sum()))
+        # (f) the receiver's frames lie call by call: all of a call's rows under its first iteration
+        per_it = np.zeros(T, dtype=np.int64)
+        per_it[ca] = call_rows
+        offsets_r = np.concatenate([[0], np.cumsum(per_it)]).astype(np.int64)
+        # (g) pack and exchange: child frames (`_data.py:616`), weights, and the bin each frame is indexed under
+        esz = 4 if store.x_dtype == _abi.F32 else 8
+        d_idx = h.to_device(idx if len(idx) else np.zeros(1, dtype=np.int64))
+        d_bsrc = h.to_device(bin_of_frame.astype(np.int32) if N_loc else np.zeros(1, dtype=np.int32))
+        got = []
+        for src, row_bytes, dt, shape in ((store.Xc, store.D * esz, np.float32 if esz == 4 else np.float64, (max(Nr, 1), store.D)),
+                                          (store.w, 8, np.float64, (max(Nr, 1),)), (d_bsrc, 4, np.int32, (max(Nr, 1),))):
+            d_send = h.alloc(max(len(idx), 1) * row_bytes, np.uint8)
+            h.gather_rows(src, row_bytes, d_idx, len(idx), d_send)
+            d_recv = h.alloc(shape, dt)
+            h.exchange(d_send, send_rows * row_bytes, d_recv, recv_rows * row_bytes)
+            h.sync()
+            d_send.free()
+            got.append(d_recv)
+        d_idx.free()
+        d_bsrc.free()
+        ts = DeviceStore(h, store.D, store.ndim, store.x_dtype, offsets_r, None, got[0], None, None, got[1])
+        out = (ts, T + 1, (plan, all_filled, got[2]))
+        old = self.__dict__.get("_strata_store")
+        if old is not None:
+            for buf in (old[1][0].Xc, old[1][0].w, old[1][2][2]):
+                buf.free()
+        self._strata_store = (key, out)
+        self.strata_exchange_stats = {"rows_sent": int(send_rows.sum()), "rows_received": Nr, "rows_local": N_loc,
+                                      "rows_all_ranks": int(sizes_g.sum()), "bytes_received": Nr * (store.D * esz + 12),
+                                      "calls_across_shards": len(strad)}
+        return out
 
     def _all_ranks_ok(self, error, what):
         """a collective success flag (min over the ranks of `error is None`): every rank leaves with the same outcome -- the

@@ -179,6 +179,102 @@ extern "C" int hamsm_gather_to_root(hamsm_ctx *c, const void *d_send, size_t sen
   return HAMSM_OK;
 }
 
+// ---- (ABI 9) the frames a rank trains on, and only those (`train_shards = "strata"`) --------------------------------------------
+// d_dst row i = d_src row d_idx[i]: the sender packs, per destination rank, the rows of its shard that the destination's strata
+// need (HBM-bound gather; a thread per 4-byte word, consecutive threads walk a row)
+__global__ void k_gather_rows(const unsigned *__restrict__ src, int64_t wpr, const int64_t *__restrict__ idx, int64_t n_words,
+                              unsigned *__restrict__ dst) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < n_words; t += stride) {
+    const int64_t i = t / wpr, k = t - i * wpr;
+    dst[t] = src[idx[i] * wpr + k];
+  }
+}
+extern "C" int hamsm_gather_rows(hamsm_ctx *c, const void *d_src, size_t row_bytes, const int64_t *d_idx, int64_t n, void *d_dst) {
+  CTX(c);
+  if (n < 0 || row_bytes == 0 || (row_bytes & 3)) return hamsm_fail(c, HAMSM_EINVAL, "gather_rows: n = %lld rows of %zu bytes (a positive multiple of 4)", (long long)n, row_bytes);
+  if (n == 0) return HAMSM_OK;
+  if (!d_src || !d_idx || !d_dst) return hamsm_fail(c, HAMSM_EINVAL, "gather_rows: null buffer");
+  const int64_t wpr = (int64_t)(row_bytes / 4), words = n * wpr;
+  const int64_t blocks = (words + 255) / 256;
+  hipLaunchKernelGGL(k_gather_rows, dim3((unsigned)(blocks < 65536 ? blocks : 65536)), dim3(256), 0, c->stream, (const unsigned *)d_src, wpr, d_idx,
+                     words, (unsigned *)d_dst);
+  HIPCHK(c, hipGetLastError());
+  return HAMSM_OK;
+}
+
+// Every rank sends h_send_bytes[q] bytes to rank q (consecutive in d_send, in rank order) and receives h_recv_bytes[q] bytes from
+// rank q (consecutive in d_recv, in rank order): one grouped send / recv over xGMI (ncclSend / ncclRecv pairs; point-to-point
+// links, so a rank's R - 1 transfers run side by side).  As in hamsm_gather_to_root the tables are cross-checked COLLECTIVELY
+// first -- rank r's send row must be what the others expect to receive from it -- so that either every rank enters the group or
+// every rank returns the same error; no rank-local return between the check and the group's end.
+extern "C" int hamsm_exchange(hamsm_ctx *c, const void *d_send, const int64_t *h_send_bytes, void *d_recv, const int64_t *h_recv_bytes) {
+  CTX(c);
+  if (c->nranks == 1 && !c->comm) {
+    if (!h_send_bytes || !h_recv_bytes || h_send_bytes[0] != h_recv_bytes[0] || h_send_bytes[0] < 0) return hamsm_fail(c, HAMSM_EINVAL, "exchange: size tables");
+    if (h_send_bytes[0]) HIPCHK(c, hipMemcpyAsync(d_recv, d_send, (size_t)h_send_bytes[0], hipMemcpyDeviceToDevice, c->stream));
+    return HAMSM_OK;
+  }
+  if (!c->comm) return hamsm_fail(c, HAMSM_EINVAL, "comm not initialised");
+  const int R = c->nranks, me = c->rank;
+  ncclComm_t cm = (ncclComm_t)c->comm;
+  int64_t complaint = 0;
+  if (!h_send_bytes || !h_recv_bytes) complaint |= 1;
+  size_t tot_s = 0, tot_r = 0;
+  for (int q = 0; q < R && !complaint; q++) {
+    if (h_send_bytes[q] < 0 || h_recv_bytes[q] < 0) complaint |= 2;
+    tot_s += (size_t)(h_send_bytes[q] > 0 ? h_send_bytes[q] : 0);
+    tot_r += (size_t)(h_recv_bytes[q] > 0 ? h_recv_bytes[q] : 0);
+  }
+  if ((tot_s && !d_send) || (tot_r && !d_recv)) complaint |= 4;
+  // A[r][q] = what r says it sends to q; B[r][q] = what q says it receives from r: every rank fills its own entries, the rest
+  // stay -1 under the max-all-reduce; the run is consistent iff A == B
+  std::vector<int64_t> v(2 * (size_t)R * R + 1, -1);
+  for (int q = 0; q < R; q++) {
+    v[(size_t)me * R + q] = h_send_bytes ? h_send_bytes[q] : 0;
+    v[(size_t)R * R + (size_t)q * R + me] = h_recv_bytes ? h_recv_bytes[q] : 0;
+  }
+  v[2 * (size_t)R * R] = complaint;
+  if (sizeof(int64_t) * v.size() > c->comm_buf_bytes) return hamsm_fail(c, HAMSM_EINVAL, "exchange: %d ranks", R);  // (same on every rank)
+  int64_t *d_v = (int64_t *)c->comm_buf;
+  const hipError_t e_up = hipMemcpyAsync(d_v, v.data(), sizeof(int64_t) * v.size(), hipMemcpyHostToDevice, c->stream);
+  const ncclResult_t e_ar = ncclAllReduce(d_v, d_v, v.size(), ncclInt64, ncclMax, cm, c->stream);
+  if (e_up != hipSuccess) return hamsm_fail(c, HAMSM_EDEVICE, "exchange: upload of the argument check failed: %s", hipGetErrorString(e_up));
+  if (e_ar != ncclSuccess) return hamsm_fail(c, HAMSM_EDEVICE, "exchange: ncclAllReduce failed: %s", ncclGetErrorString(e_ar));
+  HIPCHK(c, hipMemcpyAsync(v.data(), d_v, sizeof(int64_t) * v.size(), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  if (v[2 * (size_t)R * R]) return hamsm_fail(c, HAMSM_EINVAL, "exchange: a rank's arguments are inconsistent (flags %lld, here %lld: 1 no table, 2 negative size, 4 null buffer)",
+                                              (long long)v[2 * (size_t)R * R], (long long)complaint);
+  for (size_t e = 0; e < (size_t)R * R; e++)
+    if (v[e] != v[(size_t)R * R + e]) return hamsm_fail(c, HAMSM_EINVAL, "exchange: rank %zu sends %lld bytes to rank %zu, which expects %lld", e / R, (long long)v[e], e % R,
+                                                        (long long)v[(size_t)R * R + e]);
+  ncclResult_t first = ncclSuccess;
+  const ncclResult_t gs = ncclGroupStart();
+  size_t so = 0, ro = 0;
+  for (int q = 0; q < R; q++) {
+    if (q == me) {  // (own rows: a device copy, ordered on the same stream)
+      if (h_send_bytes[q] && hipMemcpyAsync((char *)d_recv + ro, (const char *)d_send + so, (size_t)h_send_bytes[q], hipMemcpyDeviceToDevice, c->stream) != hipSuccess &&
+          first == ncclSuccess)
+        first = ncclUnhandledCudaError;
+    } else {
+      if (h_send_bytes[q]) {
+        const ncclResult_t r_ = ncclSend((const char *)d_send + so, (size_t)h_send_bytes[q], ncclChar, q, cm, c->stream);
+        if (first == ncclSuccess) first = r_;
+      }
+      if (h_recv_bytes[q]) {
+        const ncclResult_t r_ = ncclRecv((char *)d_recv + ro, (size_t)h_recv_bytes[q], ncclChar, q, cm, c->stream);
+        if (first == ncclSuccess) first = r_;
+      }
+    }
+    so += (size_t)h_send_bytes[q];
+    ro += (size_t)h_recv_bytes[q];
+  }
+  const ncclResult_t end = gs == ncclSuccess ? ncclGroupEnd() : gs;
+  if (first != ncclSuccess) return hamsm_fail(c, HAMSM_EDEVICE, "exchange: send / recv failed: %s", ncclGetErrorString(first));
+  if (end != ncclSuccess) return hamsm_fail(c, HAMSM_EDEVICE, "exchange: ncclGroupEnd failed: %s", ncclGetErrorString(end));
+  return HAMSM_OK;
+}
+
 // centroids, counts and ||c||^2 of every stratum, each from the rank that trained it, to all: stratum s from rank h_root[s].
 // (Strata are independent chains of partial_fits -- `_clustering.py:890-911` fits one MiniBatchKMeans per bin -- so they can be
 // trained on different GPUs and the result is the single-process model bit for bit: `train_shards = "strata"`, DESIGN.md 7.  With

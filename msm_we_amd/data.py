@@ -965,7 +965,7 @@ class DataMixin:
     # -- sharded runs: the frames training needs, on the rank that trains --------------------------------------------
     train_shards = "all"   # "all": rank 0 trains on every rank's iterations (N ranks == one process on the same data);
                            # "strata": the same model, but the strata's independent chains are dealt over the ranks (stratum s
-                           #   trains on rank s % N; every rank holds every iteration's training frames);
+                           #   trains on rank s % N, which is sent the rows of its strata and nothing else);
                            # "rank0": on its own shard only (the reference's `iters_to_use` restricted to that block)
 
     def training_store(self):
@@ -977,7 +977,9 @@ class DataMixin:
         h = self.h
         R = getattr(h, "nranks", 1)
         store = self.stage_iterations()
-        if R == 1 or self.train_shards not in ("all", "strata"):
+        if R == 1 or self.train_shards != "all":
+            # ("strata": every rank is sent the rows of its own strata by `ClusteringMixin._strata_training_store`, which needs
+            # the training plan -- cluster count, iterations -- and therefore runs inside `cluster_stratified`)
             return store, self.maxIter
         if getattr(self, "_train_store", None) is not None:
             return self._train_store
@@ -1006,9 +1008,7 @@ class DataMixin:
         rows = np.array([all_sizes[int(cnt[:r].sum()): int(cnt[: r + 1].sum())].sum() for r in range(R)], dtype=np.int64)
         n_local = int(rows[h.rank])
         esz = 4 if store.x_dtype == _abi.F32 else 8
-        # "all": the frames go to rank 0; "strata": to every rank (one gather per root: a one-off at staging, and the checked
-        # send / recv group of hamsm_gather_to_root is the only exchange pattern the library needs for it)
-        roots = [0] if self.train_shards == "all" else list(range(R))
+        roots = [0]   # the frames go to rank 0
         root = h.rank in roots
         N = int(rows.sum())
         Xc = h.alloc(max(N, 1) * store.D, np.float32 if esz == 4 else np.float64) if root else None

@@ -1377,6 +1377,21 @@ int hamsm_bcast_model(hamsm_ctx *c, int root) {
   (void)c, (void)root;
   return HAMSM_OK;
 }
+/* (ABI 9) rows by index; the one-rank form of the grouped exchange (the oracle has no communicator: tests serve N > 1 with gloo) */
+int hamsm_gather_rows(hamsm_ctx *c, const void *src, size_t row_bytes, const int64_t *idx, int64_t n, void *dst) {
+  CTX(c);
+  if (n < 0 || row_bytes == 0 || (row_bytes & 3)) return fail(c, HAMSM_EINVAL, "gather_rows: n = %lld rows of %zu bytes (a positive multiple of 4)", (long long)n, row_bytes);
+  if (n == 0) return HAMSM_OK;
+  if (!src || !idx || !dst) return fail(c, HAMSM_EINVAL, "gather_rows: null buffer");
+  for (int64_t i = 0; i < n; i++) memcpy((char *)dst + (size_t)i * row_bytes, (const char *)src + (size_t)idx[i] * row_bytes, row_bytes);
+  return HAMSM_OK;
+}
+int hamsm_exchange(hamsm_ctx *c, const void *d_send, const int64_t *h_send_bytes, void *d_recv, const int64_t *h_recv_bytes) {
+  CTX(c);
+  if (!h_send_bytes || !h_recv_bytes || h_send_bytes[0] != h_recv_bytes[0] || h_send_bytes[0] < 0) return fail(c, HAMSM_EINVAL, "exchange: size tables");
+  if (h_send_bytes[0]) memcpy(d_recv, d_send, (size_t)h_send_bytes[0]);
+  return HAMSM_OK;
+}
 int hamsm_bcast_strata(hamsm_ctx *c, const int32_t *roots) {
   CTX(c);
   (void)c, (void)roots; /* one rank */

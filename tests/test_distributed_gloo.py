@@ -81,6 +81,21 @@ def _gloo_comm(h, dist, rank, world):
 
     h.gather_to_root = gather_to_root
 
+    def exchange(d_send, send_bytes, d_recv, recv_bytes):
+        sb, rb = [int(x) for x in send_bytes], [int(x) for x in recv_bytes]
+        a = np.empty(sum(sb), dtype=np.uint8)
+        if a.size:
+            h.d2h(a, d_send)
+        cuts = np.cumsum([0] + sb)
+        rows = [None] * world
+        dist.all_gather_object(rows, [a[cuts[q]: cuts[q + 1]] for q in range(world)])
+        mine = [rows[r][rank] for r in range(world)]
+        assert [len(x) for x in mine] == rb, ([len(x) for x in mine], rb)    # what the library checks collectively
+        if sum(rb):
+            h.h2d(d_recv, np.concatenate(mine))
+
+    h.exchange = exchange
+
 
 def _shard_model(h, g, meta, first, last):
     from msm_we_amd.data import InMemorySource
@@ -274,3 +289,181 @@ def test_bench_two_rank_flow_on_cpu(tmp_path, oracle_lib):
     o4 = json.loads([ln for ln in r4.stdout.splitlines() if ln.startswith("{")][0])
     assert o4["scaling"] == "strong" and "stratum s trains on rank s % N" in o4["config"]["training"]
     assert abs(o4["value"]) > 0 and o4["config"]["frames_total"] == out["config"]["frames_total"]
+
+
+def _worker4(rank, world, port, out, cuts):
+    """world size 4, S = 4 strata dealt one per rank: an uneven split of the iterations, and one rank without any"""
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+
+    from msm_we_amd import _abi, synthetic
+    from msm_we_amd.data import InMemorySource
+    from msm_we_amd.model import modelWE
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    cfg = synthetic.WEConfig("g4", 21, 26, 600, 8, 4, 6)
+    lat = synthetic.latent_centres(cfg)
+    h = _abi.Hamsm(lib=ctypes.CDLL(_build_oracle()))
+    _gloo_comm(h, dist, rank, world)
+    first, last = cuts[rank], cuts[rank + 1] - 1          # global iterations this rank discretizes (none: first > last)
+    # (the reference's maxIter bookkeeping discretizes all but the last two loaded iterations, _data.py:860-866: the idle rank
+    # loads two iterations and discretizes none)
+    shard = {i - first + 1: synthetic.make_iteration(cfg, i, lat) for i in range(first, last + 3)}
+    m = modelWE(h=h)
+    m.set_iteration_source(InMemorySource(shard))
+    basis, target = synthetic.basis_target_bounds(cfg.S)
+    m.initialize(["g"], {"coords": None, "nAtoms": cfg.D, "coord_ndim": 1}, "g", basis_pcoord_bounds=basis, target_pcoord_bounds=target,
+                 tau=1.0, pcoord_ndim=1)
+    m.get_iterations()
+    m.dimReduce()
+    m.train_shards = "strata"
+    bm = RectilinearBinMapper([synthetic.strata_boundaries(cfg.S)])
+    m.cluster_coordinates(cfg.K_s, streaming=True, use_ray=True, stratified=True, user_bin_mapper=bm, random_state=7)
+    st = dict(m.strata_exchange_stats)
+    m.cluster_coordinates(cfg.K_s, streaming=True, use_ray=True, stratified=True, user_bin_mapper=bm, random_state=7)   # (cached exchange)
+    m.get_fluxMatrix(0, first_iter=0, last_iter=m.maxIter)
+    res = dict(labels=np.concatenate(m.dtrajs) if len(m.dtrajs) else np.zeros(0, dtype=np.int64), flux=m.fluxMatrixRaw,
+               remap=[m.clusters.we_remap[b] for b in range(cfg.S)], steps=[getattr(cm, "n_steps_", -1) for cm in m.clusters.cluster_models],
+               stats=[st["rows_sent"], st["rows_received"], st["rows_local"], st["rows_all_ranks"]])
+    for b, cm in enumerate(m.clusters.cluster_models):
+        res[f"centers{b}"], res[f"counts{b}"] = cm.cluster_centers_, cm._counts
+    np.savez(out.format(rank), **res)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_four_ranks_one_stratum_each_uneven_split_and_an_idle_rank(tmp_path, oracle_lib):
+    """with `train_shards = "strata"` a rank is sent the rows of ITS strata only (one grouped
+    exchange instead of R rooted gathers of everything).  World size 4, four strata, iterations split 9 / 0 / 12 / 4 (rank 1
+    holds none): the model, every label and the flux matrix are the single process's; every rank received about a quarter of
+    the training rows, not all of them."""
+    import torch.multiprocessing as mp
+
+    from msm_we_amd import _abi, synthetic
+    from msm_we_amd.data import InMemorySource
+    from msm_we_amd.model import modelWE
+
+    cuts = [1, 10, 10, 22, 26]
+    out = str(tmp_path / "rank{}.npz")
+    mp.spawn(_worker4, args=(4, _free_port(), out, cuts), nprocs=4, join=True)
+    r = [np.load(out.format(k)) for k in range(4)]
+    cfg = synthetic.WEConfig("g4", 21, 26, 600, 8, 4, 6)
+    lat = synthetic.latent_centres(cfg)
+    h = _abi.Hamsm(lib=oracle_lib)
+    c = modelWE(h=h)
+    c.set_iteration_source(InMemorySource({i: synthetic.make_iteration(cfg, i, lat) for i in range(1, 28)}))
+    basis, target = synthetic.basis_target_bounds(cfg.S)
+    c.initialize(["g"], {"coords": None, "nAtoms": cfg.D, "coord_ndim": 1}, "g", basis_pcoord_bounds=basis, target_pcoord_bounds=target,
+                 tau=1.0, pcoord_ndim=1)
+    c.get_iterations()
+    c.dimReduce()
+    bm = RectilinearBinMapper([synthetic.strata_boundaries(cfg.S)])
+    c.cluster_coordinates(cfg.K_s, streaming=True, use_ray=True, stratified=True, user_bin_mapper=bm, random_state=7)
+    assert c.maxIter == 26 and np.array_equal(np.concatenate([x["labels"] for x in r]), np.concatenate(c.dtrajs))
+    for b, cm in enumerate(c.clusters.cluster_models):
+        for x in r:
+            assert np.array_equal(x[f"centers{b}"], cm.cluster_centers_) and np.array_equal(x[f"counts{b}"], cm._counts), (b,)
+    assert all(list(x["steps"]) == [cm.n_steps_ for cm in c.clusters.cluster_models] for x in r)
+    assert all(list(x["remap"]) == [c.clusters.we_remap[b] for b in range(cfg.S)] for x in r)
+    c.get_fluxMatrix(0, first_iter=0, last_iter=c.maxIter)
+    for x in r[1:]:
+        assert np.array_equal(x["flux"], r[0]["flux"])
+    np.testing.assert_allclose(r[0]["flux"], c.fluxMatrixRaw, rtol=1e-12, atol=1e-300)
+    # traffic: every training row is sent exactly once, every rank receives roughly its stratum's quarter
+    stats = np.array([x["stats"] for x in r])
+    assert stats[1, 2] == 0 and stats[1, 0] == 0 and stats[1, 1] > 0            # the idle rank sends nothing and still trains its stratum
+    assert stats[:, 0].sum() == stats[:, 1].sum() <= stats[0, 3]
+    assert (stats[:, 1] < 0.4 * stats[0, 3]).all()
+
+
+def _worker_fail(rank, world, port, out):
+    """a rank-local failure of the training phase must surface on EVERY rank, not strand the others in a collective"""
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+
+    from msm_we_amd import _abi
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    g, meta = load_golden("c1p_d10")
+    h = _abi.Hamsm(lib=ctypes.CDLL(_build_oracle()))
+    _gloo_comm(h, dist, rank, world)
+    m = _shard_model(h, g, meta, (1, 20)[rank], (20, 38)[rank])
+    m.train_shards = "strata"
+    if rank == 1:
+        def boom(*a, **k):
+            raise MemoryError("rank-local failure in the middle of training")
+        m._train_planned = boom
+    bm = RectilinearBinMapper([np.array(meta["boundaries"], dtype=np.float32)])
+    try:
+        m.cluster_coordinates(meta["K_s"], streaming=True, use_ray=True, stratified=True, user_bin_mapper=bm, random_state=meta["seed"])
+        msg = "no error"
+    except Exception as e:  # noqa: BLE001
+        msg = f"{type(e).__name__}: {e}"
+    open(out.format(rank), "w").write(msg)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_a_rank_local_training_failure_is_raised_on_every_rank(tmp_path):
+    import torch.multiprocessing as mp
+
+    out = str(tmp_path / "rank{}.txt")
+    mp.spawn(_worker_fail, args=(2, _free_port(), out), nprocs=2, join=True)
+    m0, m1 = open(out.format(0)).read(), open(out.format(1)).read()
+    assert m1.startswith("MemoryError") and m0.startswith("RuntimeError") and "another rank" in m0
+
+
+def _worker_straddle(rank, world, port, out):
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+
+    from msm_we_amd import _abi
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    g, meta = load_golden("sparse_d10")
+    h = _abi.Hamsm(lib=ctypes.CDLL(_build_oracle()))
+    _gloo_comm(h, dist, rank, world)
+    # rank 0 discretizes iterations 1..9, rank 1 iterations 10..58: the training call over iterations 9..11 lies on both
+    m = _shard_model(h, g, meta, (1, 10)[rank], (10, 59)[rank])
+    m.train_shards = "strata"
+    bm = RectilinearBinMapper([np.array(meta["boundaries"], dtype=np.float32)])
+    m.cluster_coordinates(meta["K_s"], streaming=True, use_ray=True, stratified=True, user_bin_mapper=bm, random_state=meta["seed"])
+    res = dict(labels=np.concatenate(m.dtrajs), across=m.strata_exchange_stats["calls_across_shards"],
+               remap=[m.clusters.we_remap[b] for b in range(2)])
+    for b, cm in enumerate(m.clusters.cluster_models):
+        res[f"centers{b}"], res[f"counts{b}"] = cm.cluster_centers_, cm._counts
+    np.savez(out.format(rank), **res)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_strata_shards_with_a_training_call_across_the_shard_boundary(tmp_path, oracle_lib):
+    """golden `sparse_d10`: strata so thinly populated that a training call pools several iterations (`_clustering.py:664-716`).
+    Cut inside such a call (iterations 9..11, shards 1..9 | 10..58): the frames a stratum indexes -- positions among the CALL's
+    filtered rows applied to its unfiltered frames, quirk of `_clustering.py:874 / :892-896` -- then come from both ranks, and the
+    model must still be the single process's (which equals the reference's golden)."""
+    import torch.multiprocessing as mp
+
+    from msm_we_amd import _abi
+
+    out = str(tmp_path / "rank{}.npz")
+    mp.spawn(_worker_straddle, args=(2, _free_port(), out), nprocs=2, join=True)
+    r0, r1 = np.load(out.format(0)), np.load(out.format(1))
+    assert int(r0["across"]) >= 1 and int(r1["across"]) == int(r0["across"])
+    g, meta = load_golden("sparse_d10")
+    bm = RectilinearBinMapper([np.array(meta["boundaries"], dtype=np.float32)])
+    h = _abi.Hamsm(lib=oracle_lib)
+    c = _shard_model(h, g, meta, 1, 59)
+    c.cluster_coordinates(meta["K_s"], streaming=True, use_ray=True, stratified=True, user_bin_mapper=bm, random_state=meta["seed"])
+    assert np.array_equal(np.concatenate(c.dtrajs), g["dtrajs_post_cluster"])          # (the single process is the reference's run)
+    assert np.array_equal(np.concatenate([r0["labels"], r1["labels"]]), np.concatenate(c.dtrajs))
+    for b, cm in enumerate(c.clusters.cluster_models):
+        for x in (r0, r1):
+            assert np.array_equal(x[f"centers{b}"], cm.cluster_centers_) and np.array_equal(x[f"counts{b}"], cm._counts), b
+    assert list(r0["remap"]) == list(r1["remap"]) == [c.clusters.we_remap[b] for b in range(2)]

@@ -997,6 +997,23 @@ def test_rccl_collectives_on_one_rank_communicator(hip_lib):
         h.gather_to_root(d_v, v.nbytes, d_r, [v.nbytes], 0)
         h.sync()
         assert np.array_equal(d_r.to_host(), v)
+        # (ABI 9) rows by index, then the grouped exchange on the RCCL path (one rank: its own part is a device copy inside the
+        # group); size tables that do not match are found by the collective check, the communicator stays usable
+        rows = rng.normal(size=(5000, 16)).astype(np.float32)
+        pick = rng.integers(0, 5000, size=7777).astype(np.int64)
+        d_rows_, d_pick, d_out = h.to_device(rows), h.to_device(pick), h.alloc((7777, 16), np.float32)
+        h.gather_rows(d_rows_, 64, d_pick, len(pick), d_out)
+        assert np.array_equal(d_out.to_host(), rows[pick])
+        d_x = h.zeros((7777, 16), np.float32)
+        h.exchange(d_out, [7777 * 64], d_x, [7777 * 64])
+        h.sync()
+        assert np.array_equal(d_x.to_host(), rows[pick])
+        with pytest.raises(_abi.HamsmError, match="expects"):
+            h.exchange(d_out, [7777 * 64], d_x, [7776 * 64])
+        with pytest.raises(_abi.HamsmError, match="multiple of 4"):
+            h.gather_rows(d_rows_, 6, d_pick, 10, d_out)
+        h.exchange(d_out, [64], d_x, [64])
+        h.sync()
         # a second communicator on a context that has one is refused; a failed / absent one leaves a 1-rank context
         with pytest.raises(_abi.HamsmError):
             h.comm_init(1, 0, h.comm_unique_id())
