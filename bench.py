@@ -963,11 +963,20 @@ def main():
             # fixed costs -- page-locking and releasing two upload slabs, the device allocations: ~20 ms -- are inside the figure)
             n_ing = int(os.environ.get("HAMSM_BENCH_INGEST_ITERS", 0)) or min(400, max(4, int(1.056e9 / (cfg.segs_per_iter * cfg.D * 8))))
             out["ingest"] = ingest_leg(h, cfg, min(n_iters, n_ing), log)
-        if world == 1 and not args.no_full_pipeline:
-            # BASELINE.json's second figure (steady-state solve wall-time) and SURVEY §8d's build_analyze_model-equivalent
+        if not args.no_full_pipeline and (world == 1 or os.environ.get("HAMSM_BENCH_FULL_PIPELINE_SHARDED", "1") != "0"):
+            # BASELINE.json's second figure (steady-state solve wall-time) and SURVEY §8d's build_analyze_model-equivalent.
+            # N > 1: the same sequence on the shards -- its 4 assign passes and 6 flux builds scale with the
+            # ranks, training does not; block validation splits every rank's own iterations into the blocks (the groups'
+            # matrices are all-reduced like the full one); every rank solves the same all-reduced matrix
             log("timing the full build_analyze_model sequence (clean, T, solve, block validation) ...")
+            barrier()
             fp = full_pipeline(m, cfg, seed, args.flux_mode)
-            fp["frames_per_s"] = n_seg / fp["total_seconds"]
+            barrier()
+            if dist is not None:
+                t = torch.tensor([fp["total_seconds"]], device=dev)
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                fp["total_seconds"] = float(t.item())
+            fp["frames_per_s"] = n_seg_all / fp["total_seconds"]
             out["full_pipeline"] = fp
             out["solve"] = {"states": fp["states"], "tmatrix_csr_s": fp["seconds"]["tmatrix_csr"],
                             "steady_state_s": fp["seconds"]["steady_state"], "where": "T built as CSR on the GPU; scipy solve on host"}

@@ -8,13 +8,15 @@ out=$PWD/gpurun_out/$tag
 mkdir -p $out
 root=$PWD
 cd /tmp && export TMPDIR=/tmp
-for wl in c3 c5s; do
-  sfx=""; [ $wl = c5s ] && sfx="_c5s"
-  rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats_$wl -o p -- python3 $root/bench.py --workload $wl --no-cpu-baseline --no-full-pipeline --no-ingest --steps 3 --warmup 1 > /dev/null 2> $out/stats_$wl.err
+for wl in c3 c5s c2 c2_x64; do
+  sfx=""; [ $wl != c3 ] && sfx="_$wl"
+  wlarg=$wl; unset HAMSM_BENCH_C2_REPS
+  if [ $wl = c2_x64 ]; then wlarg=c2; export HAMSM_BENCH_C2_REPS=64; fi
+  rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats_$wl -o p -- python3 $root/bench.py --workload $wlarg --no-cpu-baseline --no-full-pipeline --no-ingest --no-secondary --steps 3 --warmup 1 > /dev/null 2> $out/stats_$wl.err
   cp $(find $out/stats_$wl -name "*kernel_stats.csv" | head -1) $out/${tag}_bench_${wl}_kernel_stats.csv
   echo "kernel stats $wl done"
   for ctr in FETCH_SIZE WRITE_SIZE; do
-    rocprofv3 --pmc $ctr --kernel-trace --output-format csv -d $out/pmc_${wl}_$ctr -o p -- python3 $root/bench.py --workload $wl --no-cpu-baseline --no-full-pipeline --no-ingest --steps 1 --warmup 0 > /dev/null 2> $out/pmc_${wl}_$ctr.err
+    rocprofv3 --pmc $ctr --kernel-trace --output-format csv -d $out/pmc_${wl}_$ctr -o p -- python3 $root/bench.py --workload $wlarg --no-cpu-baseline --no-full-pipeline --no-ingest --no-secondary --steps 1 --warmup 0 > /dev/null 2> $out/pmc_${wl}_$ctr.err
     echo "pmc $wl $ctr done"
   done
   (cd $root && python msm_we_amd/csrc/tools/pmc_summary.py $out/${tag}_pmc_summary$sfx.csv $out/pmc_${wl}_FETCH_SIZE $out/pmc_${wl}_WRITE_SIZE > /dev/null)
@@ -22,11 +24,11 @@ for wl in c3 c5s; do
 done
 # the PMC summaries the bench lines quote as `traffic` are the ones just taken (the bench reads profiles/<tag>_pmc_summary*.csv)
 cd $root
-cp $out/${tag}_pmc_summary.csv $out/${tag}_pmc_summary_c5s.csv profiles/
-python bench.py --steps 20 --warmup 5 > $out/${tag}_bench_c3.json 2> $out/bench_c3.err
-echo "bench c3 done: $(python -c "import json;d=json.load(open('$out/${tag}_bench_c3.json'));print(d['ms_per_step'], d['value'])")"
+unset HAMSM_BENCH_C2_REPS
+cp $out/${tag}_pmc_summary*.csv profiles/
+# the default invocation: C3 (the headline) with C2, C2 x64 and C5 at full size under `secondary` (round 5)
+python bench.py --steps 20 --warmup 5 > $out/${tag}_bench_default.json 2> $out/bench_default.err
+echo "bench default done: $(python -c "import json;d=json.load(open('$out/${tag}_bench_default.json'));print(d['ms_per_step'], d['value'], {k: v['ms_per_step'] for k, v in d['secondary'].items()})")"
 python bench.py --workload c5s --steps 5 --warmup 2 --no-cpu-baseline --no-ingest > $out/${tag}_bench_c5s.json 2> $out/bench_c5s.err
 echo "bench c5s done: $(python -c "import json;d=json.load(open('$out/${tag}_bench_c5s.json'));print(d['ms_per_step'], d['value'])")"
-python bench.py --workload c5 --steps 3 --warmup 1 > $out/${tag}_bench_c5.json 2> $out/bench_c5.err
-echo "bench c5 done: $(python -c "import json;d=json.load(open('$out/${tag}_bench_c5.json'));print(d['ms_per_step'], d['value'])")"
 ls -la $out

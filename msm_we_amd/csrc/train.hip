@@ -1625,12 +1625,12 @@ __device__ __forceinline__ void rank_merge3(float &A1, float &A2, float &A3, int
 // 196 workgroups) are resident on the 256 CUs at once -- with 128-row workgroups the two queues' launches (392 workgroups, one per
 // CU: 226 registers x 8 waves) took turns, two rounds of a ~28 us workgroup per call -- and every workgroup streams its stratum's
 // 320 KB of fragments through L2 once per 256 rows instead of once per 128.
-template <typename XT, int KB, int NRT>
-__global__ __launch_bounds__(RANK_NW * 64, 2) void k_step_assign_ranked(const StepPack pk, const RankPack rk, int64_t ldx, int D, int KS,
+template <typename XT, int KB, int NRT, int NWV = RANK_NW>
+__global__ __launch_bounds__(NWV * 64, 2) void k_step_assign_ranked(const StepPack pk, const RankPack rk, int64_t ldx, int D, int KS,
                                                                         double ratio, float c1, float c2, unsigned long long *stamp) {
-  constexpr int NW = RANK_NW, NT = NW * 64;
+  constexpr int NW = NWV, NT = NW * 64;
   constexpr int RW = 32 * NRT;  // rows per workgroup
-  static_assert(NRT == 4 || NRT == 8, "prologue: 2 NRT (row tile, block parity) items over 8 waves");
+  static_assert((2 * NRT) % NW == 0 && NRT <= NW * 2 && (NRT == 4 || NRT == 8), "prologue: 2 NRT (row tile, block parity) items over the waves");
   constexpr int NIT = 2 * NRT / NW;  // prologue items per wave
   const StepDev sdesc = pk.s[blockIdx.y];
   const StepG st(sdesc);
@@ -2964,6 +2964,7 @@ static int launch_steps_ranked(hamsm_ctx *c, hipStream_t q, const StepPack &pk, 
 #define CASE(KBV) \
   case KBV:                                                                                                                                 \
     if (wide) hipLaunchKernelGGL((k_step_assign_ranked<XT, KBV, 8>), ga, dim3(RANK_NW * 64), 0, q, pk, rk, ldx, c->D, c->KS, ratio, c1, c2, stamp); \
+    else if (direct && c->step_wide == 3) hipLaunchKernelGGL((k_step_assign_ranked<XT, KBV, 4, 4>), ga, dim3(4 * 64), 0, q, pk, rk, ldx, c->D, c->KS, ratio, c1, c2, stamp); \
     else hipLaunchKernelGGL((k_step_assign_ranked<XT, KBV, 4>), ga, dim3(RANK_NW * 64), 0, q, pk, rk, ldx, c->D, c->KS, ratio, c1, c2, stamp);      \
     break;
     CASE(1) CASE(2) CASE(3) CASE(4)
@@ -3374,7 +3375,7 @@ static int run_steps(hamsm_ctx *c, const void *X, int dt, int64_t ldx, const int
 // M-step fetches member rows from the frames, 0: round 4's f64 batch copy.  Negative: leave as is.
 extern "C" int hamsm_debug_step_shape(hamsm_ctx *c, int wide, int direct) {
   CTX(c);
-  if (wide >= 0) c->step_wide = wide > 2 ? 2 : wide;
+  if (wide >= 0) c->step_wide = wide > 3 ? 3 : wide;
   if (direct >= 0) c->step_direct = direct != 0;
   return HAMSM_OK;
 }

@@ -267,6 +267,8 @@ def test_bench_two_rank_flow_on_cpu(tmp_path, oracle_lib):
     # (this workload, C3 / C4), stratum by stratum over the ranks where it is matrix-bound (C5's shape)
     assert out["n_gpus"] == 2 and out["scaling"] == "strong" and out["unit"] == "frames/s" and out["value"] > 0
     assert "cpu_baseline" not in out and out["config"]["parallelism"] == "iteration-sharded x2"
+    # the whole build_analyze_model sequence on the shards (cleaning, T, solve, block validation): in the N > 1 line too
+    assert out["full_pipeline"]["states"] > 2 and out["full_pipeline"]["total_seconds"] > 0 and len(out["full_pipeline"]["validation_JtargetSS"]) == 2
     assert "rank 0 trains on every rank's iterations" in out["config"]["training"]
     assert "torch.distributed" in r.stderr  # the stand-in was used (the oracle cannot create a communicator) ...
     assert out["config"]["exchange"].startswith("torch-fallback")   # ... and the line says so

@@ -58,12 +58,12 @@ def _shape(h, wide, direct):
 # round 5: the M-step reads member rows from the frames through the row list (no f64 batch copy), and the E-step takes 256-row
 # workgroups where 128-row ones overfill the chip (C5's shape) -- every case runs in the shipped shape, with the wide workgroups
 # FORCED, and in round 4's shape (batch copy, 128 rows)
-@pytest.mark.parametrize("shape", ["default", "wide", "copy"])
+@pytest.mark.parametrize("shape", ["default", "wide", "four-waves", "copy"])
 @pytest.mark.parametrize("name,cfg,k,kw", CASES, ids=[c[0] for c in CASES])
 def test_ranked_training_pass_equals_the_oracle(hip_h, oracle_h, name, cfg, k, kw, shape):
     o = _run(oracle_h, cfg, k, True, **kw)
     _rank(hip_h, 2)
-    _shape(hip_h, *{"default": (1, 1), "wide": (2, 1), "copy": (0, 0)}[shape])
+    _shape(hip_h, *{"default": (1, 1), "wide": (2, 1), "four-waves": (3, 1), "copy": (0, 0)}[shape])
     g = _run(hip_h, cfg, k, True, **kw)
     st = _rank(hip_h, 1)
     assert st["runs"] >= 1 and st["certified"] + st["two"] + st["full"] > 0, st
