@@ -330,8 +330,9 @@ int hamsm_kmeans_seed_multi(hamsm_ctx *ctx, int n_items, const int32_t *h_stratu
 /* (ABI 7) The batch indices item `item` of the LAST hamsm_kmeans_seed_multi call chose, in order (h_chosen[K_s]; index into the
  * subsample when one was given) -- what hamsm_kmeans_seed returns through its own h_chosen.  The parity tests compare them
  * with the reference's `_kmeans_plusplus` indices (sklearn _kmeans.py:214-276, returned as `indices`); the product never
- * calls it (it synchronises).                                                                                              */
-int hamsm_kmeans_seed_chosen(hamsm_ctx *ctx, int item, int64_t *h_chosen);
+ * calls it (it synchronises).  `capacity` (ABI 9): elements h_chosen can hold -- fewer than the item's K_s is an error, as is a
+ * call after another entry point has taken the scratch arena the indices live in.                                          */
+int hamsm_kmeans_seed_chosen(hamsm_ctx *ctx, int item, int64_t *h_chosen, int64_t capacity);
 
 /* One planned minibatch step: batch rows d_rows[rows_off .. rows_off+n_b) (relative to frame x_off)
  * update the centroids of `stratum`.

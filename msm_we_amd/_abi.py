@@ -80,7 +80,7 @@ SYMBOLS = {
     "hamsm_reassign": (_int, [_vp, _int, _vp, _int, _i64, _vp, _vp, _vp, _int, _f64]),
     "hamsm_train_build_rows_batched": (_int, [_vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp]),
     "hamsm_kmeans_seed_multi": (_int, [_vp, _int, _vp, _vp, _int, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
-    "hamsm_kmeans_seed_chosen": (_int, [_vp, _int, _vp]),
+    "hamsm_kmeans_seed_chosen": (_int, [_vp, _int, _vp, _i64]),
     "hamsm_minibatch_run": (_int, [_vp, _vp, _int, _i64, _vp, _vp, _vp, _i64, _f64, _vp, _i64, _vp, _vp, _vp]),
     "hamsm_comm_unique_id": (_int, [_vp]),
     "hamsm_comm_init": (_int, [_vp, _int, _int, _vp]),
@@ -658,7 +658,7 @@ class Hamsm:
     def kmeans_seed_chosen(self, item, K):
         """batch indices item `item` of the last `kmeans_seed_multi` chose (parity tests; synchronises)"""
         out = np.empty(int(K), dtype=np.int64)
-        self._ck(self.lib.hamsm_kmeans_seed_chosen(self.ctx, int(item), _hp(out)))
+        self._ck(self.lib.hamsm_kmeans_seed_chosen(self.ctx, int(item), _hp(out), len(out)))
         return out
 
     def minibatch_run(self, d_X, x_dtype, ldx, d_rows, d_w, steps, ratio, perm=None):

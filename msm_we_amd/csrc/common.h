@@ -190,6 +190,7 @@ struct hamsm_ctx {
   int assign_filter = 1;   // f32-MFMA filter in front of the exact f64 distance kernel (HAMSM_ASSIGN_FILTER=0: exact kernel only)
   unsigned long long *filter_cnt2 = nullptr;  // (debug) uncertain-row counters of the last filtered assign, [S] in scratch2
   int assign_waves = 4;    // waves per workgroup of the sorted assign kernel (HAMSM_ASSIGN_W=8: 8 waves x 2 centroid tiles)
+  unsigned long long scratch_epoch = 0, seed_chosen_epoch = 0;  // arena generation; ... of the seeding whose choices are recorded below
   void *seed_chosen_dev = nullptr;  // chosen indices of the last seeding's first item (device)
   std::vector<std::pair<void *, int>> seed_chosen_items;  // ... of every item of the last seeding call (device pointer, K)
   void *comm = nullptr;  // ncclComm_t

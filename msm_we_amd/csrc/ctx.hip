@@ -401,6 +401,7 @@ extern "C" int hamsm_sync(hamsm_ctx *c) {
 }
 
 int hamsm_ensure_scratch(hamsm_ctx *c, size_t bytes) {
+  c->scratch_epoch++;  // whoever asks for the arena is about to write into it: what an earlier call left there is gone
   if (bytes <= c->scratch_bytes) return HAMSM_OK;
   HIPCHK(c, hipStreamSynchronize(c->stream));
   hipFree(c->scratch);

@@ -1007,15 +1007,21 @@ extern "C" int hamsm_kmeans_seed_multi(hamsm_ctx *c, int n_items, const int32_t 
   c->table_dirty = true;
   hamsm_timer_end(c, ST_SEED);
   // h_u / h_sub were pageable host memory: hipMemcpyAsync staged them before returning, no sync needed.
+  c->seed_chosen_epoch = c->scratch_epoch;  // (the records below point into the scratch arena: valid until its next user)
   c->seed_chosen_dev = b + lay[0].ch;  // hamsm_kmeans_seed reads item 0's choices
   c->seed_chosen_items.resize(n_items);
   for (int i = 0; i < n_items; i++) c->seed_chosen_items[i] = {b + lay[i].ch, h_K[i]};  // (hamsm_kmeans_seed_chosen; valid until the scratch arena is reused)
   return HAMSM_OK;
 }
 
-extern "C" int hamsm_kmeans_seed_chosen(hamsm_ctx *c, int item, int64_t *h_chosen) {
+extern "C" int hamsm_kmeans_seed_chosen(hamsm_ctx *c, int item, int64_t *h_chosen, int64_t capacity) {
   CTX(c);
   if (item < 0 || (size_t)item >= c->seed_chosen_items.size() || !h_chosen) return hamsm_fail(c, HAMSM_EINVAL, "seed_chosen: no such item of the last seeding call");
+  // (the records point into the scratch arena -- gone once another call has taken it -- and the caller's buffer is the
+  // caller's guess of K)
+  if (c->seed_chosen_epoch != c->scratch_epoch) return hamsm_fail(c, HAMSM_EINVAL, "seed_chosen: the scratch arena has been reused since the seeding call");
+  if (capacity < (int64_t)c->seed_chosen_items[item].second)
+    return hamsm_fail(c, HAMSM_EINVAL, "seed_chosen: item %d has %d centroids, the buffer holds %lld", item, c->seed_chosen_items[item].second, (long long)capacity);
   HIPCHK(c, hipMemcpyAsync(h_chosen, c->seed_chosen_items[item].first, sizeof(long long) * c->seed_chosen_items[item].second, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
   return HAMSM_OK;

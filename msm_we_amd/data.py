@@ -74,7 +74,13 @@ class NpzDirectorySource:
                 path = os.path.join(self.dir, self.PATTERN % int(k))
                 st = os.stat(path)
                 if st.st_size == e["size"] and st.st_mtime_ns == e["mtime_ns"]:
-                    self._ranges[int(k)] = {a: (int(r[0]), int(r[1]), np.dtype(r[2]), tuple(int(v) for v in r[3])) for a, r in e["ranges"].items()}
+                    rng = {a: (int(r[0]), int(r[1]), np.dtype(r[2]), tuple(int(v) for v in r[3])) for a, r in e["ranges"].items()}
+                    # (the index is a file anyone can edit.  An entry is used only if every range is what its own
+                    # shape and dtype say -- the byte count staging will `pread` into the pinned slab -- and lies inside the
+                    # file; anything else is dropped and the file is parsed again on first use)
+                    if all(o >= 0 and nb == int(np.prod(sh, dtype=np.int64)) * dt.itemsize and o + nb <= st.st_size and not dt.hasobject
+                           for o, nb, dt, sh in rng.values()):
+                        self._ranges[int(k)] = rng
         except (OSError, ValueError, KeyError, TypeError):
             pass
 
@@ -692,6 +698,8 @@ class DataMixin:
                     for it, r, n_ in zip(its, rngs, ns):
                         fds.append(os.open(os.path.join(src.dir, src.PATTERN % int(it)), os.O_RDONLY))
                         for k, d_ in dsts:
+                            if r[k][1] != n_ * (d_.nbytes // max(1, len(d_))):   # (what the slab has room for, row for row)
+                                raise ValueError(f"iteration {it}: member {k} holds {r[k][1]} bytes, {n_} rows of the slab's width were expected")
                             if r[k][1]:
                                 f_of.append(fds[-1])
                                 offs_.append(r[k][0])

@@ -1228,9 +1228,11 @@ int hamsm_kmeans_seed_multi(hamsm_ctx *c, int n_items, const int32_t *stratum, c
   return HAMSM_OK;
 }
 
-int hamsm_kmeans_seed_chosen(hamsm_ctx *c, int item, int64_t *chosen) {
+int hamsm_kmeans_seed_chosen(hamsm_ctx *c, int item, int64_t *chosen, int64_t capacity) {
   CTX(c);
   if (item < 0 || item >= c->seed_chosen_n || !chosen || !c->seed_chosen) return fail(c, HAMSM_EINVAL, "seed_chosen: no such item of the last seeding call");
+  if (capacity < c->seed_chosen_off[item + 1] - c->seed_chosen_off[item])
+    return fail(c, HAMSM_EINVAL, "seed_chosen: item %d has %lld centroids, the buffer holds %lld", item, (long long)(c->seed_chosen_off[item + 1] - c->seed_chosen_off[item]), (long long)capacity);
   memcpy(chosen, c->seed_chosen + c->seed_chosen_off[item], sizeof(int64_t) * (size_t)(c->seed_chosen_off[item + 1] - c->seed_chosen_off[item]));
   return HAMSM_OK;
 }

@@ -119,3 +119,23 @@ def test_assign_fuzz_oracle_contexts_interleaved(oracle_lib, seed):
             j = lab[i] - off[s]
             assert 0 <= j < K_s[s] and d[j] <= d.min() + 1e-9 * max(1.0, abs(d.min()))
     a.close()
+
+
+def test_seed_chosen_checks_its_buffer_and_the_arena(oracle_h):
+    """`hamsm_kmeans_seed_chosen` copies the item's recorded K indices: a smaller caller buffer is an error, not an
+    overflow (the HIP library additionally refuses once another call has taken the scratch arena the indices live in:
+    tests/test_gpu_parity.py)"""
+    import numpy as np
+
+    from msm_we_amd import _abi
+
+    h = oracle_h
+    h.set_geometry(4, 1, 1)
+    rng = np.random.default_rng(0)
+    X = rng.normal(size=(200, 4)).astype(np.float32)
+    d_X = h.to_device(X)
+    K, L = 6, 3
+    h.kmeans_seed_multi([0], d_X, _abi.F32, 4, [0], None, [0], [200], None, [None], [K], [5], [rng.uniform(size=(K - 1) * L)], [L])
+    assert len(h.kmeans_seed_chosen(0, K)) == K
+    with pytest.raises(_abi.HamsmError, match="holds"):
+        h.kmeans_seed_chosen(0, K - 1)

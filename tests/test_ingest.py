@@ -548,3 +548,25 @@ def test_reader_pool_stages_the_same_arrays(any_h, tmp_path, monkeypatch):
     m2 = modelWE(h=oracle_h)
     m2.set_iteration_source(type("Plain", (), {"iterations": lambda s: [1], "load": lambda s, n: {}})())
     assert m2._stage_readers() == 1                     # the source did not say it may be read from several threads
+
+
+def test_a_tampered_member_range_index_is_not_trusted(tmp_path):
+    """`member_ranges.json` is a file anyone can edit; staging `pread`s the recorded byte counts into a pinned slab.
+    An entry whose byte count is not what its own shape and dtype say, or that runs past the end of its file, is dropped on
+    load (size and time stamp of the `.npz` still match) and the file is parsed again."""
+    import json
+
+    g, meta = load_golden("c1p_d10")
+    its = {k: v for k, v in golden_iterations(g).items() if k <= 4}
+    src = NpzDirectorySource.export(InMemorySource(its), tmp_path / "iters")
+    idx_path = tmp_path / "iters" / NpzDirectorySource.INDEX
+    idx = json.loads(idx_path.read_text())
+    good = {int(k): {a: tuple(r[:2]) for a, r in e["ranges"].items()} for k, e in idx.items()}
+    idx["2"]["ranges"]["Xc"][1] += 4096                       # more bytes than 128 x 10 float32
+    idx["3"]["ranges"]["w"][0] = idx["3"]["size"] - 8          # runs past the end of the file
+    idx_path.write_text(json.dumps(idx))
+    fresh = NpzDirectorySource(tmp_path / "iters")
+    assert set(fresh._ranges) == {1, 4}                        # the tampered entries were not taken over
+    for n in (2, 3):                                           # ... and parsing the files gives the true ranges again
+        r = fresh.member_ranges(n)
+        assert {a: (v[0], v[1]) for a, v in r.items()} == good[n]
