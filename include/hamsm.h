@@ -312,7 +312,9 @@ int hamsm_reassign(hamsm_ctx *ctx, int stratum, const void *d_X, int x_dtype, in
  * covers frames [h_group_range[2g], h_group_range[2g+1]) of d_bin (disjoint ranges) and uses
  * h_call_remap[g*S .. g*S+S).  Its row lists are written to d_rows starting at h_group_range[2g]
  * (ranks stay relative to the group's first frame); h_counts[g*S+s] rows of bin s start at
- * d_rows + h_starts[g*S+s].                                                                        */
+ * d_rows + h_starts[g*S+s].                                                                         (ABI 9) h_counts and h_starts may both be NULL: the caller derives them from the
+ * prepass histogram (counts = the histogram pushed through the call's remap; starts = group begin + running sum over the
+ * strata) and the call returns with the kernel enqueued instead of waiting for the read-back.                               */
 int hamsm_train_build_rows_batched(hamsm_ctx *ctx, const int32_t *d_bin, int64_t n_groups,
                                    const int64_t *h_group_range, const int32_t *h_call_remap,
                                    int32_t *d_rows, int64_t *h_counts, int64_t *h_starts);

@@ -632,10 +632,13 @@ class Hamsm:
                            ("perm_off", "<i8"), ("n_perm", "<i4"), ("n_span", "<i4")])
     STOP_NONE, STOP_LOW, STOP_UNUSED, STOP_CAP, STOP_ZERO = 0, 1, 2, 3, 4
 
-    def train_build_rows_batched(self, d_bin, group_begin, group_end, call_remap, d_rows):
+    def train_build_rows_batched(self, d_bin, group_begin, group_end, call_remap, d_rows, readback=True):
         goff = np.ascontiguousarray(np.stack([group_begin, group_end], axis=1), dtype=np.int64)
         G = len(goff)
         cr = np.ascontiguousarray(np.asarray(call_remap), dtype=np.int32).reshape(G, self.S)
+        if not readback:   # the caller knows counts and starts (ABI 9): enqueue only
+            self._ck(self.lib.hamsm_train_build_rows_batched(self.ctx, _dp(d_bin), G, _hp(goff), _hp(cr), _dp(d_rows), None, None))
+            return None, None
         counts = np.zeros((G, self.S), dtype=np.int64)
         starts = np.zeros((G, self.S), dtype=np.int64)
         self._ck(self.lib.hamsm_train_build_rows_batched(self.ctx, _dp(d_bin), G, _hp(goff), _hp(cr), _dp(d_rows),

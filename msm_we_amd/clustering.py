@@ -243,6 +243,8 @@ class ClusteringMixin:
                     h.set_frame_bins(self._frame_bins("p0", bin_mapper, tstore))
                 hist = h.train_prepass(tstore.p0, tstore.N, tstore.offsets, d_bin)
                 plan, all_filled = self._plan_training_calls(hist, iters_to_use, n_clusters, bin_mapper, store=tstore, maxIter=t_maxIter)
+            # (the plan's row counts describe the store's own frames unless the store is a rank's share of the strata)
+            self._rows_known = plan_given is None
             done = False
             if getattr(self, "speculative_training", True):
                 done = self._train_planned(plan, clusters, tstore, d_bin, d_rows)
@@ -594,9 +596,21 @@ class ClusteringMixin:
         offs = store.offsets
         gb = offs[plan["first"] - 1]
         ge = offs[plan["last"]]
-        counts, starts = h.train_build_rows_batched(d_bin, gb, ge, plan["call_remap"], d_rows)
         fit = plan["fit"]
-        assert np.array_equal(counts[fit], plan["nrows"][fit]), "row lists disagree with the prepass histogram"
+        if getattr(self, "_rows_known", False) and os.environ.get("HAMSM_CHECK_ROWS", "0") != "1":
+            # the row lists' sizes ARE the prepass histogram pushed through the calls' remaps (`plan["nrows"]`, all strata) and
+            # their starts the running sums over the strata behind the group's first frame (`hamsm_train_build_rows`): nothing
+            # to read back, the kernel is enqueued and the seedings follow at once (round 5: the read-back was a synchronisation
+            # point of ~0.3 ms in front of every pass; HAMSM_CHECK_ROWS=1 reads back and compares)
+            h.train_build_rows_batched(d_bin, gb, ge, plan["call_remap"], d_rows, readback=False)
+            counts = np.ascontiguousarray(plan["nrows"], dtype=np.int64)
+            starts = np.asarray(gb, dtype=np.int64)[:, None] + np.cumsum(counts, axis=1) - counts
+        else:
+            counts, starts = h.train_build_rows_batched(d_bin, gb, ge, plan["call_remap"], d_rows)
+            assert np.array_equal(counts[fit], plan["nrows"][fit]), "row lists disagree with the prepass histogram"
+            if getattr(self, "_rows_known", False):
+                kn = np.ascontiguousarray(plan["nrows"], dtype=np.int64)
+                assert np.array_equal(counts, kn) and np.array_equal(starts, np.asarray(gb, dtype=np.int64)[:, None] + np.cumsum(kn, axis=1) - kn)
         use_w = self.use_weights_in_clustering
         d_w = store.w if use_w else None
         # RandomState streams as they were, for the rerun

@@ -300,6 +300,10 @@ extern "C" int hamsm_train_build_rows_batched(hamsm_ctx *c, const int32_t *bin, 
                        (long long *)(b + o_st));
   hamsm_timer_end(c, ST_PREPASS);
   HIPCHK(c, hipGetLastError());
+  // (ABI 9) both null: the caller knows the counts -- they are the prepass histogram pushed through the calls' remaps -- and
+  // the lists' starts (running sums over the strata): nothing is read back, the call returns with the kernel enqueued
+  if (!h_counts && !h_starts) return HAMSM_OK;
+  if (!h_counts || !h_starts) return hamsm_fail(c, HAMSM_EINVAL, "train_build_rows_batched: counts and starts come together");
   HIPCHK(c, hipMemcpyAsync(h_counts, b + o_cnt, sizeof(int64_t) * G * c->S, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipMemcpyAsync(h_starts, b + o_st, sizeof(int64_t) * G * c->S, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));

@@ -1194,12 +1194,23 @@ int hamsm_reassign(hamsm_ctx *c, int s, const void *X, int dt, int64_t ldx, cons
 int hamsm_train_build_rows_batched(hamsm_ctx *c, const int32_t *bin, int64_t n_groups, const int64_t *goff,
                                    const int32_t *call_remap, int32_t *rows, int64_t *counts, int64_t *starts) {
   CTX(c);
+  if ((counts == NULL) != (starts == NULL)) return fail(c, HAMSM_EINVAL, "train_build_rows_batched: counts and starts come together");
+  int64_t *tmp = NULL;
+  if (!counts) { /* (ABI 9) the caller knows them: nothing is handed back */
+    tmp = (int64_t *)calloc(2 * (size_t)(c->S > 0 ? c->S : 1), sizeof(int64_t));
+    if (!tmp) return fail(c, HAMSM_ENOMEM, "train_build_rows_batched");
+  }
   for (int64_t g = 0; g < n_groups; g++) {
     int64_t b = goff[2 * g], e = goff[2 * g + 1];
-    int rc = hamsm_train_build_rows(c, bin + b, e - b, call_remap + g * c->S, rows + b, counts + g * c->S, starts + g * c->S);
-    if (rc) return rc;
-    for (int s = 0; s < c->S; s++) starts[g * c->S + s] += b;
+    int64_t *cg = counts ? counts + g * c->S : tmp, *sg = starts ? starts + g * c->S : tmp + c->S;
+    int rc = hamsm_train_build_rows(c, bin + b, e - b, call_remap + g * c->S, rows + b, cg, sg);
+    if (rc) {
+      free(tmp);
+      return rc;
+    }
+    for (int s = 0; s < c->S; s++) sg[s] += b;
   }
+  free(tmp);
   return HAMSM_OK;
 }
 

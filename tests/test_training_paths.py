@@ -227,3 +227,21 @@ def test_a_held_cluster_model_keeps_its_random_stream(oracle_h):
     assert kept._random_state is rs
     assert np.array_equal(rs.randint(0, 1000, 20), twin.randint(0, 1000, 20))   # untouched by the later builds
     assert all(cm._random_state is not rs for cm in a.clusters.cluster_models)
+
+
+@pytest.mark.parametrize("case", ["c1p_d10", "sparse_d10", "gap_d10", "c1p_d10_weighted"])
+def test_row_list_sizes_and_starts_are_known_without_a_read_back(oracle_h, monkeypatch, case):
+    """round 5: the planned pass enqueues the row-list kernel without reading its counts / starts back -- they ARE the prepass
+    histogram pushed through the calls' remaps and the running sums over the strata.  `HAMSM_CHECK_ROWS=1` takes the read-back
+    and asserts both equalities for every call (single- and multi-iteration calls, a never-visited bin, weights); the model
+    is the golden's either way."""
+    from conftest import build_model, load_golden
+
+    g, meta = load_golden(case)
+    out = []
+    for check in ("1", "0"):
+        monkeypatch.setenv("HAMSM_CHECK_ROWS", check)
+        m, _ = build_model(oracle_h, g, meta, seed_forcing=False)
+        assert m.training_path == "planned"
+        out.append(np.concatenate(m.dtrajs))
+    assert np.array_equal(out[0], out[1]) and np.array_equal(out[0], g["dtrajs_post_cluster"])
