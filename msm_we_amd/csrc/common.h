@@ -111,6 +111,7 @@ struct hamsm_ctx {
   // the E-step of training calls that are bound by the f64 matrix unit ranks the centroids on the bf16 unit (k_step_assign_ranked,
   // train.hip; same labels): 0 never, 1 when a run's heaviest call has >= step_ranked_min_flop (default), 2 always
   int step_ranked = 1;                      // HAMSM_STEP_RANKED
+  int step_pipe = 1;                        // HAMSM_STEP_PIPE: ranked E-step sweep as a software pipeline (MFMAs of the next unit between the ranking of this one)
   int step_wide = 0;                        // HAMSM_STEP_WIDE: 256-row workgroups in the ranked E-step where 128-row ones overfill the chip
   int n_cu = 256;                           // compute units of the device (hamsm_create)
   int step_direct = 1;                      // HAMSM_STEP_DIRECT: ranked runs: the M-step fetches member rows from the frames through the

@@ -1635,7 +1635,7 @@ __device__ __forceinline__ void rank_merge3(float &A1, float &A2, float &A3, int
 // 196 workgroups) are resident on the 256 CUs at once -- with 128-row workgroups the two queues' launches (392 workgroups, one per
 // CU: 226 registers x 8 waves) took turns, two rounds of a ~28 us workgroup per call -- and every workgroup streams its stratum's
 // 320 KB of fragments through L2 once per 256 rows instead of once per 128.
-template <typename XT, int KB, int NRT, int NWV = RANK_NW>
+template <typename XT, int KB, int NRT, int NWV = RANK_NW, bool PIPE = false>
 __global__ __launch_bounds__(NWV * 64, 2) void k_step_assign_ranked(const StepPack pk, const RankPack rk, int64_t ldx, int D, int KS,
                                                                         double ratio, float c1, float c2, unsigned long long *stamp) {
   constexpr int NW = NWV, NT = NW * 64;
@@ -1852,6 +1852,105 @@ __global__ __launch_bounds__(NWV * 64, 2) void k_step_assign_ranked(const StepPa
     M1[rt] = M2[rt] = M3[rt] = ninf;
     J1[rt] = J2[rt] = 0;
   }
+  // one accumulator register into the running top-3 of its row tile: the register's number rides in the 4 low mantissa bits (the
+  // bound charges the 16 ulp), so the maxima know their own index.  Written as instructions: through the builtins the compiler
+  // canonicalises v first.
+  auto rank1 = [&](float &m1, float &m2, float &m3, float a, int r) {
+    const float v = __uint_as_float((__float_as_uint(a) & 0xfffffff0u) | (unsigned)r);
+    float m3n, m2n, m1n;
+    asm("v_med3_f32 %0, %1, %2, %3" : "=v"(m3n) : "v"(m2), "v"(m3), "v"(v));
+    asm("v_med3_f32 %0, %1, %2, %3" : "=v"(m2n) : "v"(m1), "v"(m2), "v"(v));
+    asm("v_max_f32 %0, %1, %2" : "=v"(m1n) : "v"(m1), "v"(v));
+    m3 = m3n;
+    m2 = m2n;
+    m1 = m1n;
+  };
+  // whose tile?  (a value whose bits equal the old maximum's while a larger one arrived in this tile may be the demoted old maximum
+  // or a twin of it from this tile: then both are among the three best, M2 == M3, and the row is never settled between two
+  // candidates.)  Selects, not branches: the compiled form of the conditional expressions was three exec-mask regions per unit.
+  auto whose = [&](int rt_, unsigned o1, unsigned o2, int t) {
+    const unsigned n1 = __float_as_uint(M1[rt_]), n2 = __float_as_uint(M2[rt_]);
+    const int c1 = -(int)(n1 != o1), c2 = -(int)(n2 != o2), dm = -(int)(n2 == o1);
+    const int j2n = (J1[rt_] & (c1 & dm)) | (t & ~(c1 & dm));
+    J2[rt_] = (j2n & c2) | (J2[rt_] & ~c2);
+    J1[rt_] = (t & c1) | (J1[rt_] & ~c1);
+  };
+  if constexpr (PIPE) {
+    // Round 5: the sweep as a software pipeline.  The compiled form of the plain loop below is strictly phased per (tile, row tile)
+    // unit -- 8 x (ds_read_b128, s_waitcnt, MFMA...) with every LDS latency exposed, then the 64 ranking instructions, then three
+    // branch regions -- ~1 780 cycles per unit against 384 of MFMA time, and the SIMD's two waves run the same phases at the same
+    // time.  Here the MFMAs of unit u + 1 are issued BETWEEN the ranking instructions of unit u (one MFMA, then ~5 ranking
+    // instructions: the wave issues in order, so only fine interleaving lets its own vector work run under its own matrix work),
+    // its operand images are read from LDS one 16-slot block ahead, and the order is pinned by scheduling fences.
+    auto ldb = [&](int rt_, int m, v4u32 &b1, v4u32 &b2) {
+      b1 = s_b[rt_][m][0][lane];
+      b2 = s_b[rt_][m][1][lane];
+    };
+    auto init_of = [&](const Frag &f) {
+      v16f32 z;
+#pragma unroll
+      for (int r = 0; r < 16; r++) z[r] = f.i0[r >> 2][r & 3];
+      return z;
+    };
+    Frag nxt = load_frag(1);
+    v16f32 acc_cur = init_of(cur);
+    if (nmy > 0) {  // unit (0, 0) has nothing to hide behind
+#pragma unroll
+      for (int m = 0; m < KB; m++) {
+        v4u32 b1, b2;
+        ldb(0, m, b1, b2);
+        const v8bf16 a1 = __builtin_bit_cast(v8bf16, cur.c[m][0]), a2 = __builtin_bit_cast(v8bf16, cur.c[m][1]);
+        acc_cur = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, __builtin_bit_cast(v8bf16, b2), acc_cur, 0, 0, 0);
+        acc_cur = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, __builtin_bit_cast(v8bf16, b1), acc_cur, 0, 0, 0);
+        acc_cur = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, __builtin_bit_cast(v8bf16, b1), acc_cur, 0, 0, 0);
+      }
+    }
+    for (int i = 0; i < nmy; i++) {
+      const int t = tile_of(i);
+#pragma unroll
+      for (int rt = 0; rt < NRT; rt++) {
+        constexpr int NM = 3 * KB;  // MFMAs per unit
+        const bool last_rt = rt == NRT - 1;
+        const bool have_next = !last_rt || i + 1 < nmy;  // (wave-uniform)
+        const int rtn = last_rt ? 0 : rt + 1;
+        const unsigned o1 = __float_as_uint(M1[rt]), o2 = __float_as_uint(M2[rt]);
+        v16f32 acc_nxt;
+        if (have_next) {
+          const Frag &fa = last_rt ? nxt : cur;
+          acc_nxt = init_of(fa);
+          v4u32 b1, b2, nb1, nb2;
+          ldb(rtn, 0, b1, b2);
+#pragma unroll
+          for (int m = 0; m < KB; m++) {
+            if (m + 1 < KB) ldb(rtn, m + 1, nb1, nb2);
+            const v8bf16 a1 = __builtin_bit_cast(v8bf16, fa.c[m][0]), a2 = __builtin_bit_cast(v8bf16, fa.c[m][1]);
+#pragma unroll
+            for (int q = 0; q < 3; q++) {
+              const int k = 3 * m + q;
+              if (q == 0) acc_nxt = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, __builtin_bit_cast(v8bf16, b2), acc_nxt, 0, 0, 0);
+              if (q == 1) acc_nxt = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, __builtin_bit_cast(v8bf16, b1), acc_nxt, 0, 0, 0);
+              if (q == 2) acc_nxt = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, __builtin_bit_cast(v8bf16, b1), acc_nxt, 0, 0, 0);
+#pragma unroll
+              for (int r = 16 * k / NM; r < 16 * (k + 1) / NM; r++) rank1(M1[rt], M2[rt], M3[rt], acc_cur[r], r);
+              __builtin_amdgcn_sched_barrier(0);
+            }
+            b1 = nb1;
+            b2 = nb2;
+          }
+        } else {
+#pragma unroll
+          for (int r = 0; r < 16; r++) rank1(M1[rt], M2[rt], M3[rt], acc_cur[r], r);
+          acc_nxt = acc_cur;
+        }
+        whose(rt, o1, o2, t);
+        acc_cur = acc_nxt;
+      }
+      cur = nxt;
+      nxt = load_frag(i + 2);  // (clamped; unused past the last tile)
+    }
+  } else {
+  Frag nxt_unused = cur;
+  (void)nxt_unused;
   for (int i = 0; i < nmy; i++) {
     const int t = tile_of(i);
     const Frag nxt = load_frag(i + 1);  // (clamped; unused past the last tile)
@@ -1871,26 +1970,11 @@ __global__ __launch_bounds__(NWV * 64, 2) void k_step_assign_ranked(const StepPa
       }
       const unsigned o1 = __float_as_uint(M1[rt]), o2 = __float_as_uint(M2[rt]);
 #pragma unroll
-      for (int r = 0; r < 16; r++) {
-        // the accumulator register's number rides in the 4 low mantissa bits (the bound charges the 16 ulp): the maxima know
-        // their own index.  Written as instructions: through the builtins the compiler canonicalises v first.
-        const float v = __uint_as_float((__float_as_uint(acc[r]) & 0xfffffff0u) | (unsigned)r);
-        float m3n, m2n, m1n;
-        asm("v_med3_f32 %0, %1, %2, %3" : "=v"(m3n) : "v"(M2[rt]), "v"(M3[rt]), "v"(v));
-        asm("v_med3_f32 %0, %1, %2, %3" : "=v"(m2n) : "v"(M1[rt]), "v"(M2[rt]), "v"(v));
-        asm("v_max_f32 %0, %1, %2" : "=v"(m1n) : "v"(M1[rt]), "v"(v));
-        M3[rt] = m3n;
-        M2[rt] = m2n;
-        M1[rt] = m1n;
-      }
-      // whose tile?  (a value whose bits equal the old maximum's while a larger one arrived in this tile may be the demoted old
-      // maximum or a twin of it from this tile: then both are among the three best, M2 == M3, and the row is never settled
-      // between two candidates)
-      const bool ch1 = __float_as_uint(M1[rt]) != o1, ch2 = __float_as_uint(M2[rt]) != o2;
-      J2[rt] = ch2 ? ((ch1 && __float_as_uint(M2[rt]) == o1) ? J1[rt] : t) : J2[rt];
-      J1[rt] = ch1 ? t : J1[rt];
+      for (int r = 0; r < 16; r++) rank1(M1[rt], M2[rt], M3[rt], acc[r], r);
+      whose(rt, o1, o2, t);
     }
     cur = nxt;
+  }
   }
   RPROF(1)
   __syncthreads();  // nobody reads the operand images any more: their bytes take the waves' partial results
@@ -2973,8 +3057,11 @@ static int launch_steps_ranked(hamsm_ctx *c, hipStream_t q, const StepPack &pk, 
   switch (KB) {
 #define CASE(KBV) \
   case KBV:                                                                                                                                 \
-    if (wide) hipLaunchKernelGGL((k_step_assign_ranked<XT, KBV, 8>), ga, dim3(RANK_NW * 64), 0, q, pk, rk, ldx, c->D, c->KS, ratio, c1, c2, stamp); \
+    if (wide && c->step_pipe) hipLaunchKernelGGL((k_step_assign_ranked<XT, KBV, 8, RANK_NW, true>), ga, dim3(RANK_NW * 64), 0, q, pk, rk, ldx, c->D, c->KS, ratio, c1, c2, stamp); \
+    else if (wide) hipLaunchKernelGGL((k_step_assign_ranked<XT, KBV, 8>), ga, dim3(RANK_NW * 64), 0, q, pk, rk, ldx, c->D, c->KS, ratio, c1, c2, stamp); \
+    else if (direct && c->step_wide == 3 && c->step_pipe) hipLaunchKernelGGL((k_step_assign_ranked<XT, KBV, 4, 4, true>), ga, dim3(4 * 64), 0, q, pk, rk, ldx, c->D, c->KS, ratio, c1, c2, stamp); \
     else if (direct && c->step_wide == 3) hipLaunchKernelGGL((k_step_assign_ranked<XT, KBV, 4, 4>), ga, dim3(4 * 64), 0, q, pk, rk, ldx, c->D, c->KS, ratio, c1, c2, stamp); \
+    else if (c->step_pipe) hipLaunchKernelGGL((k_step_assign_ranked<XT, KBV, 4, RANK_NW, true>), ga, dim3(RANK_NW * 64), 0, q, pk, rk, ldx, c->D, c->KS, ratio, c1, c2, stamp); \
     else hipLaunchKernelGGL((k_step_assign_ranked<XT, KBV, 4>), ga, dim3(RANK_NW * 64), 0, q, pk, rk, ldx, c->D, c->KS, ratio, c1, c2, stamp);      \
     break;
     CASE(1) CASE(2) CASE(3) CASE(4)
