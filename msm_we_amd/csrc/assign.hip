@@ -213,15 +213,17 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void k_assign_sorted(SortArgs g) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr int NT = NW * 64;
   const int FRB = g.FRB;
-  // Blocks of FRB frames are dealt to the workgroups round-robin: the grid is sized by the host, which does not know how many
-  // frames the ranking pass left undecided -- an upper bound of n / FRB workgroups that mostly exit at once cost 36 us per 1 M
-  // frames (C2) and 69 us per 10 M (C3) -- so it is capped and a workgroup walks `blk = blockIdx.x, + gridDim.x, ...`.
-  const long long nblk = g.blkbase[g.S];
-  for (long long blk = blockIdx.x; blk < nblk; blk += gridDim.x) {
-  // which stratum does this block belong to?
+  // which stratum does this workgroup serve?  (The grid is an upper bound sized by the host, which does not know how many frames the
+  // ranking pass left undecided; surplus workgroups exit here.  Round 5 tried a capped grid whose workgroups walk the blocks
+  // round-robin: the loop-carried state cost 12 registers -- 64 B more scratch at KS = 16 -- and the kernel took 503 instead of
+  // 365 us per call at C5's shape; not kept.)
   int s = 0;
-  while (g.blkbase[s + 1] <= blk) s++;
-  const long long p0 = g.base[s] + (long long)(blk - g.blkbase[s]) * FRB;
+  {
+    const long long blk = blockIdx.x;
+    if (blk >= g.blkbase[g.S]) return;
+    while (g.blkbase[s + 1] <= blk) s++;
+  }
+  const long long p0 = g.base[s] + (long long)(blockIdx.x - g.blkbase[s]) * FRB;
   const long long pend = g.end ? g.end[s] : g.base[s + 1];
   const int nf = (int)((pend - p0) < FRB ? (pend - p0) : FRB);
   const int nts = (nf + 15) >> 4;
@@ -404,8 +406,6 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void k_assign_sorted(SortArgs g) {
       }
       APROF(5)
     }
-  }
-  __syncthreads();  // the workgroup's next block rewrites the staged rows, their frame indices and the partial minima
   }
   APROF_END
 }
@@ -1373,11 +1373,8 @@ static int launch_sorted_cfg(hamsm_ctx *c, SortArgs g) {
   if (lds > 160 * 1024) return hamsm_fail(c, HAMSM_ENOTSUP, "sorted assign needs %zu B of LDS", lds);
   auto kern = k_assign_sorted<XT, KS, MT, NW, JW>;
   HIPCHK(c, hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  // an upper bound of the blocks (the device knows how many there are); behind the ranking pass, which leaves a fraction of a
-  // percent of the frames, at most 8 workgroups per CU that walk the blocks round-robin
-  long long grid = (g.n + FRB - 1) / FRB + c->S;
-  if (g.end && grid > 8LL * c->n_cu) grid = 8LL * c->n_cu;
-  hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(NW * 64), lds, c->stream, g);
+  unsigned grid = (unsigned)((g.n + FRB - 1) / FRB + c->S);  // upper bound; surplus workgroups exit at once
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(NW * 64), lds, c->stream, g);
   HIPCHK(c, hipGetLastError());
   return HAMSM_OK;
 }
