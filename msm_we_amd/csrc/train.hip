@@ -628,7 +628,7 @@ __device__ __forceinline__ double readlane_f64(double v, int l) {
 #define SEED_PST (SEED_NCH + 1)             // stride of the transposed product array: lanes = chunks, conflict-free
 #define SEED_PL (32 * 33)                   // one candidate's 1024 partial potentials, groups of 32 padded to 33
 // LDS of k_seed_g in doubles
-#define SEED_G_LDS(LF) ((size_t)(LF) * SEED_PL + (LF) * 32 + 16 + SEED_NLDS + 2 * 64 * SEED_PST + SEED_NCH)
+#define SEED_G_LDS(LF) ((size_t)(LF) * SEED_PL + (LF) * 32 + 16 + SEED_NLDS + 2 * 64 * SEED_PST + 2 * SEED_NCH)
 template <typename XT, int LF>
 __global__ __launch_bounds__(SEED_TL) void k_seed_g(const SeedItem *__restrict__ items, int D) {
   extern __shared__ double sm[];
@@ -643,6 +643,7 @@ __global__ __launch_bounds__(SEED_TL) void k_seed_g(const SeedItem *__restrict__
   double *pT = lxsq + SEED_NLDS;        // [64][SEED_PST] w_i * closest_i, row i at (i % 64, i / 64); 0 past the batch
   double *lbase = pT + 64 * SEED_PST;   // [SEED_NCH] chunk totals
   double *pC = lbase + SEED_NCH;        // [64][SEED_PST] running sum of the products inside each chunk
+  double *lexc = pC + 64 * SEED_PST;    // [SEED_NCH] exclusive running sum of the chunk totals (the chunks' bases)
   __shared__ int cid[SEED_LFAST];
   __shared__ double s_pot;
   __shared__ int s_best;
@@ -735,6 +736,17 @@ __global__ __launch_bounds__(SEED_TL) void k_seed_g(const SeedItem *__restrict__
         pC[z * SEED_PST + tid] = loc;
       }
       lbase[tid] = loc;
+      // the chunks' bases: the exclusive running sum of the totals in chunk order (a serial left fold: the oracle's order), formed
+      // HERE, once, by the wave that holds the totals in its lanes -- every total goes round as a scalar (v_readlane), lane q keeps
+      // the sum in front of chunk q.  (Round 5: every searching wave used to form it again from 48 LDS broadcast reads.)
+      double run = 0.0, mine = 0.0;
+#pragma unroll
+      for (int q = 0; q < SEED_NCH; q++) {
+        const double tq = readlane_f64(loc, q);
+        mine = tid == q ? run : mine;
+        run = run + tq;
+      }
+      lexc[tid] = mine;
     }
     __syncthreads();
     PROF_T(0)
@@ -745,16 +757,8 @@ __global__ __launch_bounds__(SEED_TL) void k_seed_g(const SeedItem *__restrict__
         un0 = itu[(size_t)cc * L + wv];
         if (wv + SEED_TL / 64 < L) un1 = itu[(size_t)cc * L + wv + SEED_TL / 64];
       }
-      // exclusive running sum of the chunk totals, formed by every lane (the reads are LDS broadcasts); lane q keeps base q
-      double tv[SEED_NCH];
-#pragma unroll
-      for (int q = 0; q < SEED_NCH; q++) tv[q] = lbase[q];
-      double run = 0.0, mybase = 0.0;
-#pragma unroll
-      for (int q = 0; q < SEED_NCH; q++) {
-        mybase = lane == q ? run : mybase;
-        run = run + tv[q];
-      }
+      // lane q keeps the base of chunk q (the exclusive running sum of the chunk totals, formed once in the chunk phase)
+      const double mybase = lane < SEED_NCH ? lexc[lane] : 0.0;
       for (int l = wv; l < L; l += SEED_TL / 64) {
         const double v = (l == wv ? u0 : u1) * s_pot;  // :243
         // searchsorted over the cumulative sum: the last chunk whose base is below v (what a bisection of the
