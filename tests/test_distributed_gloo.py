@@ -469,3 +469,64 @@ def test_strata_shards_with_a_training_call_across_the_shard_boundary(tmp_path, 
         for x in (r0, r1):
             assert np.array_equal(x[f"centers{b}"], cm.cluster_centers_) and np.array_equal(x[f"counts{b}"], cm._counts), b
     assert list(r0["remap"]) == list(r1["remap"]) == [c.clusters.we_remap[b] for b in range(2)]
+
+
+def _worker_weighted(rank, world, port, out):
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+
+    from msm_we_amd import _abi
+    from msm_we_amd.data import InMemorySource
+    from msm_we_amd.model import modelWE
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    g, meta = load_golden("c1p_d10_weighted")
+    h = _abi.Hamsm(lib=ctypes.CDLL(_build_oracle()))
+    _gloo_comm(h, dist, rank, world)
+    its = golden_iterations(g)
+    first, last = (1, 14)[rank], (14, 38)[rank]
+    m = modelWE(h=h)
+    m.set_iteration_source(InMemorySource({i - first + 1: its[i] for i in range(first, last + 2)}))
+    m.initialize(["g"], {"coords": None, "nAtoms": meta["D"], "coord_ndim": 1}, "g", basis_pcoord_bounds=meta["basis"],
+                 target_pcoord_bounds=meta["target"], tau=meta["tau"], pcoord_ndim=1, use_weights_in_clustering=True)
+    m.get_iterations()
+    m.dimReduce()
+    m.train_shards = "strata"
+    bm = RectilinearBinMapper([np.array(meta["boundaries"], dtype=np.float32)])
+    m.cluster_coordinates(meta["K_s"], streaming=True, use_ray=True, stratified=True, user_bin_mapper=bm, random_state=meta["seed"])
+    np.savez(out.format(rank), labels=np.concatenate(m.dtrajs), **{f"centers{b}": cm.cluster_centers_ for b, cm in enumerate(m.clusters.cluster_models)},
+             **{f"counts{b}": cm._counts for b, cm in enumerate(m.clusters.cluster_models)})
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_strata_shards_with_sample_weights(tmp_path):
+    """the weights travel with the frames they belong to (the frame a row's position selects, `_clustering.py:892-911`): the
+    reference's weighted golden inputs, split 13 | 24 iterations over two ranks, give the single process's model and labels"""
+    import torch.multiprocessing as mp
+
+    out = str(tmp_path / "rank{}.npz")
+    mp.spawn(_worker_weighted, args=(2, _free_port(), out), nprocs=2, join=True)
+    r0, r1 = np.load(out.format(0)), np.load(out.format(1))
+    # one process on the same 37 discretized iterations (loaded 1..39), weights on
+    from msm_we_amd import _abi
+    from msm_we_amd.data import InMemorySource
+    from msm_we_amd.model import modelWE
+
+    g, meta = load_golden("c1p_d10_weighted")
+    its = golden_iterations(g)
+    h = _abi.Hamsm(lib=ctypes.CDLL(_build_oracle()))
+    c = modelWE(h=h)
+    c.set_iteration_source(InMemorySource({i: its[i] for i in range(1, 40)}))
+    c.initialize(["g"], {"coords": None, "nAtoms": meta["D"], "coord_ndim": 1}, "g", basis_pcoord_bounds=meta["basis"],
+                 target_pcoord_bounds=meta["target"], tau=meta["tau"], pcoord_ndim=1, use_weights_in_clustering=True)
+    c.get_iterations()
+    c.dimReduce()
+    bm = RectilinearBinMapper([np.array(meta["boundaries"], dtype=np.float32)])
+    c.cluster_coordinates(meta["K_s"], streaming=True, use_ray=True, stratified=True, user_bin_mapper=bm, random_state=meta["seed"])
+    assert np.array_equal(np.concatenate([r0["labels"], r1["labels"]]), np.concatenate(c.dtrajs))
+    for b, cm in enumerate(c.clusters.cluster_models):
+        for x in (r0, r1):
+            assert np.array_equal(x[f"centers{b}"], cm.cluster_centers_) and np.array_equal(x[f"counts{b}"], cm._counts), b
