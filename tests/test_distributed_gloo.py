@@ -530,3 +530,56 @@ def test_strata_shards_with_sample_weights(tmp_path):
     for b, cm in enumerate(c.clusters.cluster_models):
         for x in (r0, r1):
             assert np.array_equal(x[f"centers{b}"], cm.cluster_centers_) and np.array_equal(x[f"counts{b}"], cm._counts), b
+
+
+def _worker_case(rank, world, port, out, case, cut):
+    """golden `case` split at global iteration `cut` over two ranks, `train_shards = "strata"`, the case's own mapper / start"""
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+
+    from msm_we_amd import _abi
+    from msm_we_amd.data import InMemorySource
+    from msm_we_amd.model import modelWE
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    g, meta = load_golden(case)
+    h = _abi.Hamsm(lib=ctypes.CDLL(_build_oracle()))
+    _gloo_comm(h, dist, rank, world)
+    its = golden_iterations(g)
+    n_all = max(its) - 2                                   # the single process discretizes 1..n_all (loaded n_all + 2)
+    first, last = (1, cut)[rank], (cut - 1, n_all)[rank]
+    m = modelWE(h=h)
+    m.set_iteration_source(InMemorySource({i - first + 1: its[i] for i in range(first, last + 3)}))
+    m.initialize(["g"], {"coords": None, "nAtoms": meta["D"], "coord_ndim": 1}, "g", basis_pcoord_bounds=meta["basis"],
+                 target_pcoord_bounds=meta["target"], tau=meta["tau"], pcoord_ndim=meta.get("pcoord_ndim", 1),
+                 use_weights_in_clustering=meta["use_weights"])
+    m.get_iterations()
+    m.dimReduce()
+    m.train_shards = "strata"
+    if meta.get("voronoi"):
+        from msm_we_amd.binning import VoronoiBinMapper, euclidean_dfunc
+
+        bm = VoronoiBinMapper(euclidean_dfunc, np.array(meta["voronoi"], dtype=np.float32))
+    else:
+        bm = RectilinearBinMapper([np.array(meta["boundaries"], dtype=np.float32)])
+    kw = {"first_cluster_iter": meta["first_iter"]} if meta.get("first_iter", 1) != 1 else {}
+    m.cluster_coordinates(meta["K_s"], streaming=True, use_ray=True, stratified=True, user_bin_mapper=bm, random_state=meta["seed"], **kw)
+    np.savez(out.format(rank), labels=np.concatenate(m.dtrajs), remap=[m.clusters.we_remap[b] for b in range(bm.nbins)])
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("case,cut", [("late_start_d10", 12), ("voronoi_d10", 9), ("gap_d10", 15)])
+def test_strata_shards_reproduce_the_reference_goldens(tmp_path, case, cut):
+    """two ranks, stratum-sharded training, against the REFERENCE's own discretization of the same run: a late first training
+    iteration (`first_cluster_iter`, global numbering), a Voronoi mapper with a never-visited bin, four strata with a gap"""
+    import torch.multiprocessing as mp
+
+    out = str(tmp_path / "rank{}.npz")
+    mp.spawn(_worker_case, args=(2, _free_port(), out, case, cut), nprocs=2, join=True)
+    r0, r1 = np.load(out.format(0)), np.load(out.format(1))
+    g, meta = load_golden(case)
+    assert np.array_equal(np.concatenate([r0["labels"], r1["labels"]]), g["dtrajs_post_cluster"])
+    assert list(r0["remap"]) == list(r1["remap"])
