@@ -83,6 +83,7 @@ __global__ void k_flux_compare(const double *__restrict__ a, const double *__res
 }
 
 int hamsm_flux_sorted(hamsm_ctx *c, const MapperDev &m, const FluxArgs &g, const int64_t *d_offs, int64_t n_iters);
+int hamsm_flux_rows(hamsm_ctx *c, const MapperDev &m, const FluxArgs &g, const int64_t *d_offs, int64_t n_iters, int *taken);
 
 extern "C" int hamsm_flux_accumulate(hamsm_ctx *c, const int32_t *pa, const int32_t *ch, const double *p0, const double *p1,
                                      const double *w, int64_t n, int K, double *F, int mode, const int64_t *d_offs,
@@ -153,11 +154,26 @@ extern "C" int hamsm_flux_accumulate(hamsm_ctx *c, const int32_t *pa, const int3
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) rc = hamsm_fail(c, HAMSM_EDEVICE, "k_flux_atomic: %s", hipGetErrorString(e));
   } else {
-    rc = hamsm_flux_sorted(c, c->mapper, g, d_offs, n_iters);
+    // deterministic: by rows (hand-written throughout, flux_rows.hip) where the matrix has few enough states, else by a stable
+    // sort of the segments (flux_sorted.hip); the same bits either way
+    int taken = 0;
+    rc = hamsm_flux_rows(c, c->mapper, g, d_offs, n_iters, &taken);
+    if (!rc && !taken) rc = hamsm_flux_sorted(c, c->mapper, g, d_offs, n_iters);
+    c->flux_last_path = taken ? 2 : 1;
   }
+  if (mode == 0) c->flux_last_path = 0;
   hamsm_timer_end(c, ST_FLUX);
   if (rc) return rc;
   return hamsm_check_device_error(c, "flux_accumulate");
+}
+
+// Not part of the product ABI (test hook): which deterministic path hamsm_flux_accumulate may take (rows: -1 leave, 0 off, 1 on;
+// max_r: most states of the by-rows path, <= 0 leave); returns the path the LAST call took (0 atomics, 1 sorted, 2 by rows)
+extern "C" int hamsm_debug_flux_path(hamsm_ctx *c, int rows, int max_r) {
+  CTX(c);
+  if (rows >= 0) c->flux_rows = rows != 0;
+  if (max_r > 0) c->flux_rows_max_r = max_r;
+  return c->flux_last_path;
 }
 
 __global__ void k_scale(double *F, int64_t n, double div) {

@@ -11,7 +11,7 @@ SRC=${3:-train}
 F="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -munsafe-fp-atomics"
 /opt/rocm/bin/hipcc $F $2 -c $SRC.hip -o _var/${SRC}_$1.o
 OBJS=""
-for o in ctx hostio assign project pca flux flux_sorted train comm; do
+for o in ctx hostio assign project pca flux flux_sorted flux_rows train comm; do
   if [ "$o" = "$SRC" ]; then OBJS="$OBJS _var/${SRC}_$1.o"; else OBJS="$OBJS _build/$o.o"; fi
 done
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -Wl,-Bsymbolic -o _var/lib_$1.so $OBJS -L/opt/rocm/lib -lrccl -Wl,-rpath,/opt/rocm/lib

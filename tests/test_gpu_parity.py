@@ -557,6 +557,66 @@ def test_flux_matches_oracle(hip_h, oracle_h, mode, K, n_iters):
         np.testing.assert_allclose(Fs[1], Fs[0], rtol=1e-12)  # f64 atomics: order-free
 
 
+def _flux_path(h, rows=-1, max_r=0):
+    fn = h.lib.hamsm_debug_flux_path
+    fn.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int]
+    fn.restype = ctypes.c_int
+    return fn(h.ctx, rows, max_r)
+
+
+@pytest.mark.parametrize("K,n,n_iters,max_r", [(37, 20000, 60, 0), (2998, 20000, 300, 0), (5, 3000, 40, 0), (37, 200000, 5, 0),
+                                                (4500, 30000, 12, 0), (300, 400000, 700, 0), (1000, 300000, 1, 0),
+                                                (700, 150000, 33, 0), (37, 20000, 23, 30), (5398, 40000, 7, 0), (5399, 40000, 7, 0)])
+def test_deterministic_flux_by_rows_equals_the_sorted_path_and_the_oracle(hip_h, oracle_h, K, n, n_iters, max_r):
+    """round 5: the deterministic default orders the segments with two hand-written stable counting passes (flux_rows.hip: by row
+    across the whole call, then by column inside each row's workgroup, which also sums) instead of the library's radix sort,
+    wherever the matrix has <= 5400 states; beyond that the sorted path.  Both must give the oracle's bits: many duplicates of
+    few cells inside an iteration, iterations cut into several tiles (40 000 segments each in the fourth case), one iteration
+    only, 16 / 8 / 4 waves per row (K + 2 <= 512, <= 2048, beyond), accumulation on top of existing values, a sub-range of the
+    iterations, and the limit itself on either side (the last three cases)."""
+    Fs = []
+    for h, rows in ((oracle_h, -1), (hip_h, 1), (hip_h, 0)):
+        rng = np.random.default_rng(5)
+        _setup(h, 4, 4, 4, rng)
+        pa, ch, p0, p1, w, offs = _flux_inputs(rng, n, K, n_iters)
+        d = [h.to_device(a) for a in (pa, ch, p0, p1, w, offs)]
+        d_F = h.to_device(rng.uniform(size=(K + 2, K + 2)))
+        if h is hip_h:
+            _flux_path(h, rows, max_r)
+        h.flux_accumulate(d[0], d[1], d[2], d[3], d[4], n, K, d_F, 1, d[5], n_iters)
+        if h is hip_h:
+            assert _flux_path(h) == (2 if rows and K + 2 <= (max_r or 5400) else 1)
+        lo, hi = n_iters // 5, max(n_iters // 2, 1)
+        h.flux_accumulate(d[0], d[1], d[2], d[3], d[4], int(offs[hi] - offs[lo]), K, d_F, 1, d[5].offset(lo), hi - lo)
+        Fs.append(d_F.to_host())
+        for b in d + [d_F]:
+            b.free()
+    _flux_path(hip_h, 0, 5400)
+    assert np.array_equal(Fs[0], Fs[1]) and np.array_equal(Fs[0], Fs[2])
+
+
+def test_deterministic_flux_without_iteration_offsets(hip_h, oracle_h):
+    """no offsets = segments [0, n) are one iteration (include/hamsm.h), on both deterministic paths"""
+    K, n = 50, 30000
+    Fs = []
+    for h, rows in ((oracle_h, -1), (hip_h, 1), (hip_h, 0)):
+        rng = np.random.default_rng(11)
+        _setup(h, 4, 4, 4, rng)
+        pa, ch, p0, p1, w, _ = _flux_inputs(rng, n, K, 2)
+        d = [h.to_device(a) for a in (pa, ch, p0, p1, w)]
+        d_F = h.to_device(rng.uniform(size=(K + 2, K + 2)))
+        if h is hip_h:
+            _flux_path(h, rows)
+        h.flux_accumulate(d[0], d[1], d[2], d[3], d[4], n, K, d_F, 1, None, 0)
+        if h is hip_h:
+            assert _flux_path(h) == (2 if rows else 1)
+        Fs.append(d_F.to_host())
+        for b in d + [d_F]:
+            b.free()
+    _flux_path(hip_h, 0)
+    assert np.array_equal(Fs[0], Fs[1]) and np.array_equal(Fs[0], Fs[2])
+
+
 def test_flux_per_xcd_partials_match_oracle(hip_h, oracle_h):
     """calls of >= 1e5 segments accumulate into one private matrix per XCD (L2-scope atomics) folded into F afterwards; a bad
     label raises there too"""
