@@ -20,7 +20,7 @@ _vp, _i32, _i64, _f64, _sz = C.c_void_p, C.c_int32, C.c_int64, C.c_double, C.c_s
 _int = C.c_int
 
 # name -> (restype, argtypes); kept in the order of include/hamsm.h
-ABI_VERSION = 9  # HAMSM_ABI_VERSION of include/hamsm.h
+ABI_VERSION = 10  # HAMSM_ABI_VERSION of include/hamsm.h
 
 SYMBOLS = {
     "hamsm_abi_version": (_int, []),
@@ -62,6 +62,7 @@ SYMBOLS = {
     "hamsm_pca_accumulate": (_int, [_vp, _vp, _int, _i64, _i64]),
     "hamsm_pca_finish": (_int, [_vp, _vp, _vp, _vp, _vp]),
     "hamsm_assign": (_int, [_vp, _vp, _int, _i64, _vp, _i64, _vp, _vp]),
+    "hamsm_assign_pair": (_int, [_vp, _vp, _vp, _int, _i64, _vp, _vp, _i64, _vp, _vp, _vp]),
     "hamsm_labels_to_host": (_int, [_vp, _vp, _vp, _i64, _vp, _vp]),
     "hamsm_predict_host": (_int, [_vp, _vp, _int, _vp, _i64, _vp, _vp]),
     "hamsm_flux_accumulate": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _int, _vp, _int, _vp, _i64]),
@@ -500,6 +501,12 @@ class Hamsm:
     def assign(self, d_X, x_dtype, ldx, d_pcoord, n, d_labels, d_seen=None):
         self._ck(self.lib.hamsm_assign(self.ctx, _dp(d_X), int(x_dtype), int(ldx), _dp(d_pcoord), int(n),
                                        _dp(d_labels), _dp(d_seen)))
+
+    def assign_pair(self, d_Xp, d_Xc, x_dtype, ldx, d_p0, d_p1, n, d_parent, d_child, d_seen=None):
+        """both sides of the same segments: `assign(d_Xp, d_p0 -> d_parent)` then `assign(d_Xc, d_p1 -> d_child)`, enqueued
+        back to back and checked once (not with an external mapper)"""
+        self._ck(self.lib.hamsm_assign_pair(self.ctx, _dp(d_Xp), _dp(d_Xc), int(x_dtype), int(ldx), _dp(d_p0), _dp(d_p1), int(n),
+                                            _dp(d_parent), _dp(d_child), _dp(d_seen)))
 
     def labels_to_host(self, d_parent, d_child, n, child=True, pairs=True):
         """-> (child int64[n] | None, pairs int64[n, 2] | None): the discretization in the reference's layout

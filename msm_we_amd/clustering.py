@@ -847,13 +847,14 @@ class ClusteringMixin:
         d_child = h.alloc(max(nseg, 1), np.int32)
         d_seen = h.zeros((2, self.clusters.bin_mapper.nbins), np.int32)
         ext = getattr(self, "_mapper_external", False)
-        if nseg:
-            if ext:
-                h.set_frame_bins(self._frame_bins("p0", self.clusters.bin_mapper))
+        if nseg and ext:
+            h.set_frame_bins(self._frame_bins("p0", self.clusters.bin_mapper))
             h.assign(store.Xp, store.x_dtype, store.D, store.p0, nseg, d_parent, d_seen)  # :1299-1301
-            if ext:
-                h.set_frame_bins(self._frame_bins("p1", self.clusters.bin_mapper))
+            h.set_frame_bins(self._frame_bins("p1", self.clusters.bin_mapper))
             h.assign(store.Xc, store.x_dtype, store.D, store.p1, nseg, d_child, d_seen)   # :1315-1316
+        elif nseg:
+            # both sides in one call: enqueued back to back, one error read-back
+            h.assign_pair(store.Xp, store.Xc, store.x_dtype, store.D, store.p0, store.p1, nseg, d_parent, d_child, d_seen)
         seen = d_seen.to_host()
         d_seen.free()
         if getattr(h, "nranks", 1) > 1:  # which bins held target / basis frames: union over the shards

@@ -1692,6 +1692,25 @@ extern "C" long long hamsm_debug_filter_undecided(hamsm_ctx *c) {
   return t;
 }
 
+// the filter's own steering, from the undecided counts of the last launch (they have arrived: the caller has synchronised)
+static void assign_steer(hamsm_ctx *c, int64_t n) {
+  if (!c->filter_ran) return;
+  unsigned long long und = 0;
+  for (int s = 0; s < c->S; s++) und += c->h_und[s];
+  if (c->filter_form == 3) {
+    // the light form left more than 1/32 of the frames to the exact kernel: the full form for the next calls
+    if (n >= 4096 && und * 32 > (unsigned long long)n) c->filter_lite_skip = 7;
+  } else if (n >= 4096 && und * 4 > (unsigned long long)n) c->filter_skip = 7;
+}
+
+static int assign_enqueue(hamsm_ctx *c, const void *X, int dt, int64_t ldx, const double *p, int64_t n, int32_t *labels, int32_t *seen) {
+  AssignArgs g{X, ldx, p, n, labels, seen, c->d_table, c->S, c->D, c->Kfit, c->d_err};
+  hamsm_timer_begin(c);  // bucket passes -> ST_OTHER (ended inside launch_sorted), distance kernel -> ST_ASSIGN
+  int rc = (dt == HAMSM_F32) ? launch_sorted<float>(c, g) : launch_sorted<double>(c, g);
+  hamsm_timer_end(c, ST_ASSIGN);
+  return rc;
+}
+
 extern "C" int hamsm_assign(hamsm_ctx *c, const void *X, int dt, int64_t ldx, const double *p, int64_t n, int32_t *labels,
                             int32_t *seen) {
   CTX(c);
@@ -1703,20 +1722,31 @@ extern "C" int hamsm_assign(hamsm_ctx *c, const void *X, int dt, int64_t ldx, co
   if (rc) return rc;
   rc = hamsm_refresh_table(c);
   if (rc) return rc;
-  AssignArgs g{X, ldx, p, n, labels, seen, c->d_table, c->S, c->D, c->Kfit, c->d_err};
-  hamsm_timer_begin(c);  // bucket passes -> ST_OTHER (ended inside launch_sorted), distance kernel -> ST_ASSIGN
-  rc = (dt == HAMSM_F32) ? launch_sorted<float>(c, g) : launch_sorted<double>(c, g);
-  hamsm_timer_end(c, ST_ASSIGN);
+  rc = assign_enqueue(c, X, dt, ldx, p, n, labels, seen);
   if (rc) return rc;
   rc = hamsm_check_device_error(c, "assign");  // (synchronises: the undecided counts have arrived too)
-  if (c->filter_ran) {
-    unsigned long long und = 0;
-    for (int s = 0; s < c->S; s++) und += c->h_und[s];
-    if (c->filter_form == 3) {
-      // the light form left more than 1/32 of the frames to the exact kernel: the full form for the next calls
-      if (n >= 4096 && und * 32 > (unsigned long long)n) c->filter_lite_skip = 7;
-    } else if (n >= 4096 && und * 4 > (unsigned long long)n) c->filter_skip = 7;
-  }
+  assign_steer(c, n);
+  return rc;
+}
+
+// both sides of the same segments, enqueued back to back, one read-back of the error word (include/hamsm.h, ABI 10)
+extern "C" int hamsm_assign_pair(hamsm_ctx *c, const void *Xp, const void *Xc, int dt, int64_t ldx, const double *p0, const double *p1,
+                                 int64_t n, int32_t *parent, int32_t *child, int32_t *seen) {
+  CTX(c);
+  if (!c->have_mapper || !c->have_bounds) return hamsm_fail(c, HAMSM_EINVAL, "mapper/bounds not set");
+  if (dt != HAMSM_F32 && dt != HAMSM_F64) return hamsm_fail(c, HAMSM_EINVAL, "x_dtype");
+  if (ldx < c->D) return hamsm_fail(c, HAMSM_EINVAL, "ldx < D");
+  if (n <= 0) return HAMSM_OK;
+  if (c->mapper.kind == MAPPER_EXTERNAL) return hamsm_fail(c, HAMSM_EINVAL, "assign_pair: an external mapper's frame bins are set per side (two hamsm_assign calls)");
+  int rc = hamsm_refresh_table(c);
+  if (rc) return rc;
+  rc = assign_enqueue(c, Xp, dt, ldx, p0, n, parent, seen);
+  if (rc) return rc;
+  rc = assign_enqueue(c, Xc, dt, ldx, p1, n, child, seen);
+  if (rc) return rc;
+  // (the device's error word keeps the FIRST error: a parent-side failure is the one reported, as with two calls)
+  rc = hamsm_check_device_error(c, "assign");
+  assign_steer(c, n);
   return rc;
 }
 

@@ -607,6 +607,17 @@ int hamsm_labels_to_host(hamsm_ctx *c, const int32_t *pa, const int32_t *ch, int
   return HAMSM_OK;
 }
 
+/* (ABI 10) both sides of the same segments: the parent frames, then the child frames (_clustering.py:1299-1301, :1315-1316) */
+int hamsm_assign_pair(hamsm_ctx *c, const void *Xp, const void *Xc, int dt, int64_t ldx, const double *p0, const double *p1,
+                      int64_t n, int32_t *parent, int32_t *child, int32_t *seen) {
+  CTX(c);
+  if (c->have_mapper && c->mapper_kind == 2 && n > 0)
+    return fail(c, HAMSM_EINVAL, "assign_pair: an external mapper's frame bins are set per side (two hamsm_assign calls)");
+  int rc = hamsm_assign(c, Xp, dt, ldx, p0, n, parent, seen);
+  if (rc) return rc;
+  return hamsm_assign(c, Xc, dt, ldx, p1, n, child, seen);
+}
+
 int hamsm_predict_host(hamsm_ctx *c, const void *X, int dt, const double *p, int64_t n, int32_t *labels,
                        int32_t *seen) {
   CTX(c);

@@ -271,3 +271,24 @@ def test_nan_coordinates_fail_where_the_reference_fails(oracle_h):
     its[1]["Xc"][0, 0] = np.nan
     with pytest.raises(AssertionError):
         build_model(oracle_h, g, meta, source=InMemorySource(its))
+
+
+def test_random_state_from_an_integer_seed_is_numpys():
+    """`_check_random_state(int)` builds its RandomState without the SeedSequence detour: same type, same state, same draws as
+    `np.random.RandomState(seed)` (sklearn.utils.check_random_state)"""
+    import pickle
+
+    from msm_we_amd.stratified_clustering import _check_random_state
+
+    for seed in (0, 1, 1337, 2 ** 31, 2 ** 32 - 1, np.int64(42), np.uint32(7)):
+        a, b = np.random.RandomState(seed), _check_random_state(seed)
+        assert type(b) is np.random.RandomState
+        sa, sb = a.get_state(), b.get_state()
+        assert sa[0] == sb[0] and np.array_equal(sa[1], sb[1]) and sa[2:] == sb[2:]
+        assert np.array_equal(a.randint(0, 10 ** 6, 50), b.randint(0, 10 ** 6, 50))
+        assert a.choice(100, p=np.full(100, 0.01)) == b.choice(100, p=np.full(100, 0.01))
+        assert np.array_equal(a.uniform(size=9), b.uniform(size=9)) and a.standard_normal() == b.standard_normal()
+        c = pickle.loads(pickle.dumps(b))           # (models are pickled with their stream)
+        assert np.array_equal(c.permutation(20), b.permutation(20))
+    with pytest.raises((ValueError, TypeError, OverflowError)):
+        _check_random_state(-1)                     # as np.random.RandomState(-1)
