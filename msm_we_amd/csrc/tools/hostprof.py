@@ -1,5 +1,5 @@
 """Where the host spends a C3 step: cProfile over N steps (top functions by own time), and the device's idle gaps between
-kernels of a step from the timestamps hamsm's stage timers keep.  usage: python msm_we_amd/csrc/tools/hostprof.py [steps]"""
+kernels of a step from the timestamps hamsm's stage timers keep.  usage: [HAMSM_PROF_WORKLOAD=c5s] python msm_we_amd/csrc/tools/hostprof.py [steps]"""
 import cProfile
 import os
 import pstats
@@ -14,6 +14,8 @@ from msm_we_amd.data import DeviceStore  # noqa: E402
 
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 10
 cfg = synthetic.CONFIGS["c3"]
+if os.environ.get("HAMSM_PROF_WORKLOAD") == "c5s":
+    cfg = synthetic.WEConfig("c5s", 5, 200, 50000, 64, 4, 1250)   # C5's shape, 10 M frames
 h = _abi.Hamsm()
 Xp, Xc, p0, p1, w, offs = bench.make_shard(cfg, 1, cfg.n_iters)
 store = DeviceStore.from_host(h, Xp, Xc, p0, p1, w, offs)
