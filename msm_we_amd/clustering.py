@@ -719,7 +719,11 @@ class ClusteringMixin:
             chain[int(bb[0])] = dict(g=gs, st=st, pos=0)
             models[int(bb[0])].__dict__["_device_newer"] = True
         predict = {b: False for b in chain}
-        pred_tests = {b: 4 for b in chain}   # tests a stratum may run ahead on a "low counts" prediction
+        # tests a stratum may run ahead on a "low counts" prediction: one at first (a speculative permutation costs 0.15 ms of host
+        # time at 12 500-row batches and the first prediction after two low tests is the likeliest to fail -- C5: all four strata,
+        # 16 permutations drawn for nothing when this started at 4: 127.8 -> 123.3 ms per step), doubling while it keeps holding
+        PT0 = 1
+        pred_tests = {b: PT0 for b in chain}
         low_streak = {b: 0 for b in chain}   # consecutive tests of a stratum that found low counts and stopped its chain
         total_calls = int(max((len(c["g"]) for c in chain.values()), default=0))
         span = G  # calls per fused run; 64 after a stop, four times as many after every clean run
@@ -735,7 +739,7 @@ class ClusteringMixin:
             # up alone, a quarter of the chip at a time (C5: 2.5 launches per call and queue instead of 1).
             sel = {b: (chain[b]["pos"], min(chain[b]["pos"] + span, len(chain[b]["g"]))) for b in live}
             # a stratum that runs on the prediction "low counts again" carries a speculative permutation on EVERY test and stops at
-            # the first one that does not need it: it goes only a few tests ahead (4, doubling while the prediction keeps holding)
+            # the first one that does not need it: it goes only a few tests ahead (1, doubling while the prediction keeps holding)
             # -- a 64-call run of a stratum that tests at every call used to draw 117 permutations to apply 9 steps
             if not shared_rng:
                 for b in live:
@@ -800,7 +804,7 @@ class ClusteringMixin:
                         low_streak[b] = 0   # a test passed without low counts
                     continue
                 stopped = True
-                pred_tests[b] = 4
+                pred_tests[b] = PT0
                 if why == h.STOP_ZERO or shared_rng or last < 0:
                     log.info("training plan of stratum %d does not hold (stop %d): rerunning stepwise", b, why)
                     return undo()
