@@ -111,6 +111,9 @@ struct hamsm_ctx {
   // the E-step of training calls that are bound by the f64 matrix unit ranks the centroids on the bf16 unit (k_step_assign_ranked,
   // train.hip; same labels): 0 never, 1 when a run's heaviest call has >= step_ranked_min_flop (default), 2 always
   int step_ranked = 1;                      // HAMSM_STEP_RANKED
+  int step_direct_plain = 1;                // HAMSM_STEP_DIRECT_PLAIN=0: the f64-MFMA training kernels WITH the f64 batch copy (round 4's form)
+  int step_lrows = 1;                       // HAMSM_STEP_LROWS: ... with the call's row list in LDS (batches of <= 4096 rows)
+  bool cur_direct = false;                  // (the run being enqueued)
   int flux_last_path = -1;                  // (test hook) 0 atomics, 1 sorted, 2 by rows
   int flux_rows = 0, flux_rows_max_r = 5400;  // HAMSM_FLUX_ROWS / HAMSM_FLUX_ROWS_MAX_R: deterministic flux by rows (flux_rows.hip) up to this many states
   int step_pipe = 1;                        // HAMSM_STEP_PIPE: ranked E-step sweep as a software pipeline (MFMAs of the next unit between the ranking of this one)

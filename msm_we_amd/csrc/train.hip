@@ -1365,6 +1365,8 @@ __global__ __launch_bounds__(256) void k_step_assign(const StepDev *__restrict__
     }
   }
   // the batch rows as f64 for the M-step: row tile rt is written by wave (rt + 1) & 3
+  // (no copy where the M-step fetches its member rows from the frames: HAMSM_STEP_DIRECT_PLAIN)
+  if (st.Xg)
 #pragma unroll
   for (int rt = 0; rt < RT; rt++)
     if (((rt + 1) & 3) == wv) {
@@ -2198,7 +2200,8 @@ __global__ __launch_bounds__(NWV * 64, 2) void k_step_assign_ranked(const StepPa
 #define UPD_LIST 1024
 #define UPD_SC 768  // member rows the strip holds per pass: ints [0, 768); weights of a 64-member chunk: ints [768, 896)
 // (`apk` != null -- the ranked E-step's run, below: the wave also rewrites its centroid's bf16 fragments, KB blocks of 16 slots)
-template <typename XT, int H, bool BYVAL, int UPD_NBK, bool DIRECT = false>
+#define UPD_LROWS 4096  // batch rows whose row list a workgroup of the M-step keeps in LDS (LROWS)
+template <typename XT, int H, bool BYVAL, int UPD_NBK, bool DIRECT = false, bool LROWS = false>
 __device__ __forceinline__ void step_update_body(const StepDev *__restrict__ steps, const StepPack &pk, int64_t ldx, int D, int KS,
                                                  GAS unsigned short *apk, GAS float *hcs, int KB) {
   SPROF_ID
@@ -2213,20 +2216,43 @@ __device__ __forceinline__ void step_update_body(const StepDev *__restrict__ ste
   double *swl = (double *)(list + UPD_SC);
   const GAS double *Xg = st.Xg;
   const int ldg = 4 * KS;  // rows of the batch copy are padded to whole k-steps
+  // LROWS: the call's row list (batch row -> frame) comes into LDS while the bitmap words are on their way -- the translation of
+  // the members' batch rows was a dependent L2 round trip of its own between the bitmap and the member rows (one per M-step: ~1 us of
+  // a 999-step chain).  Requested first, so that waiting for it does not wait for anything younger; one barrier, before any wave leaves.
+  int *lrows = lds_i + 4 * UPD_LIST;
+  if constexpr (LROWS) {
+    int rv[UPD_LROWS / 256];
+    const int nb = (int)st.n_b;
+#pragma unroll
+    for (int q = 0; q < UPD_LROWS / 256; q++) {
+      const int e = q * 256 + (int)threadIdx.x;
+      rv[q] = (st.rows && e < nb) ? st.rows[e] : e;
+    }
+#pragma unroll
+    for (int q = 0; q < UPD_LROWS / 256; q++) lrows[q * 256 + threadIdx.x] = rv[q];
+  }
   const int j = blockIdx.x * 4 + wv;
-  if (j >= st.K) return;
+  if constexpr (!LROWS) {
+    if (j >= st.K) return;
+  }
+  const bool live = j < st.K;
+  const int jc = live ? j : st.K - 1;
   const int nw = (int)((st.n_b + 63) >> 6);
-  GAS unsigned long long *mb = st.mbits + (size_t)j * sdesc.wstride;
+  GAS unsigned long long *mb = st.mbits + (size_t)jc * sdesc.wstride;
   const int hv = *gp(sdesc.halt);
   const unsigned long long w0 = mb[lane];  // (wstride is a multiple of 64: always inside the centroid's row)
-  const double cnt0 = st.counts[j];
+  const double cnt0 = st.counts[jc];
   double c0[H];
 #pragma unroll
   for (int h = 0; h < H; h++) {
     const int k = lane + 64 * h;
-    c0[h] = st.C[(size_t)j * D + (k < D ? k : D - 1)];
+    c0[h] = st.C[(size_t)jc * D + (k < D ? k : D - 1)];
   }
   SPROF_W(1, 1)
+  if constexpr (LROWS) {
+    __syncthreads();
+    if (!live) return;
+  }
   if (st.idx >= hv) return;  // the stratum's chain stopped before this step
   const bool weighted = st.wf != nullptr;
   // c = c*count; c += x*w in sample order; count += wsum; c *= 1/count  (pyx:80-104)
@@ -2286,7 +2312,9 @@ __device__ __forceinline__ void step_update_body(const StepDev *__restrict__ ste
       const int np = blk - p0 < UPD_SC ? blk - p0 : UPD_SC;
       if constexpr (DIRECT) {
         // batch rows -> frame indices, the whole strip in one round trip (the call's row list is L2-warm: the E-step read it)
-        if (st.rows)
+        if constexpr (LROWS) {
+          for (int e = lane; e < np; e += 64) srow[e] = (unsigned)lrows[srow[e]];
+        } else if (st.rows)
           for (int e = lane; e < np; e += 64) srow[e] = (unsigned)st.rows[srow[e]];
       }
       // member rows fetched together per pass: 64 / H (f64 copy) -- or 32 from the frames: with 32 rows in flight the wave fits
@@ -2356,10 +2384,10 @@ __device__ __forceinline__ void step_update_body(const StepDev *__restrict__ ste
 #endif
   SPROF_FLUSH(1)
 }
-template <typename XT, int H, bool BYVAL, int UPD_NBK>
+template <typename XT, int H, bool BYVAL, int UPD_NBK, bool DIRECT = false, bool LROWS = false>
 __global__ __launch_bounds__(256) void k_step_update(const StepDev *__restrict__ steps, const StepPack pk, int64_t ldx, int D,
                                                      int KS) {
-  step_update_body<XT, H, BYVAL, UPD_NBK>(steps, pk, ldx, D, KS, nullptr, nullptr, 0);
+  step_update_body<XT, H, BYVAL, UPD_NBK, DIRECT, LROWS>(steps, pk, ldx, D, KS, nullptr, nullptr, 0);
 }
 template <typename XT, int UPD_NBK, bool DIRECT>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DIRECT ? 3 : 1))) void k_step_update_ranked(const StepPack pk, const RankPack rk, int64_t ldx, int D, int KS, int KB) {
@@ -2934,7 +2962,17 @@ static void launch_step_kernels(hamsm_ctx *c, hipStream_t q, const StepDev *d_st
   if (sample) hipEventRecord(ks.e1, q);
   size_t lds = sizeof(int) * (4 * UPD_LIST);
   dim3 gu((unsigned)((maxK + 3) / 4), (unsigned)ny);
-  if (c->D <= 64) {
+  if (c->cur_direct) {  // member rows from the frames (the E-step wrote no f64 copy)
+    if (c->D <= 64) {
+      if (max_nb > 4096) hipLaunchKernelGGL((k_step_update<XT, 1, BYVAL, 4, true>), gu, dim3(256), lds, q, d_steps, pk, ldx, c->D, c->KS);
+      else if (c->step_lrows && max_nb <= UPD_LROWS)
+        hipLaunchKernelGGL((k_step_update<XT, 1, BYVAL, 1, true, true>), gu, dim3(256), lds + sizeof(int) * UPD_LROWS, q, d_steps, pk, ldx, c->D, c->KS);
+      else hipLaunchKernelGGL((k_step_update<XT, 1, BYVAL, 1, true>), gu, dim3(256), lds, q, d_steps, pk, ldx, c->D, c->KS);
+    } else {
+      if (max_nb > 4096) hipLaunchKernelGGL((k_step_update<XT, 2, BYVAL, 4, true>), gu, dim3(256), lds, q, d_steps, pk, ldx, c->D, c->KS);
+      else hipLaunchKernelGGL((k_step_update<XT, 2, BYVAL, 1, true>), gu, dim3(256), lds, q, d_steps, pk, ldx, c->D, c->KS);
+    }
+  } else if (c->D <= 64) {
     if (max_nb > 4096) hipLaunchKernelGGL((k_step_update<XT, 1, BYVAL, 4>), gu, dim3(256), lds, q, d_steps, pk, ldx, c->D, c->KS);
     else hipLaunchKernelGGL((k_step_update<XT, 1, BYVAL, 1>), gu, dim3(256), lds, q, d_steps, pk, ldx, c->D, c->KS);
   } else {
@@ -3170,7 +3208,9 @@ static int run_steps(hamsm_ctx *c, const void *X, int dt, int64_t ldx, const int
     }
     ranked = top >= c->step_ranked_min_flop;
   }
-  const bool direct = ranked && c->step_direct;  // ranked runs: member rows straight from the frames (no copy)
+  // member rows straight from the frames (no f64 copy): ranked runs; the f64-MFMA kernels of up to 128 features on request
+  const bool direct = ranked ? c->step_direct != 0 : (!generic && c->step_direct_plain != 0);
+  c->cur_direct = direct;
   size_t o_xg = take((generic || direct) ? 0 : xg_row * (size_t)nslot * nb_pad);  // (the generic M-step reads the frames in place)
   const int wstride = (int)((((nb_max + 63) >> 6) + 63) & ~(int64_t)63);  // bitmap words per centroid
   const size_t mb_bytes = sizeof(unsigned long long) * (size_t)nslot * Kmax * wstride;
@@ -3478,6 +3518,14 @@ extern "C" int hamsm_debug_step_shape(hamsm_ctx *c, int wide, int direct) {
   CTX(c);
   if (wide >= 0) c->step_wide = wide > 3 ? 3 : wide;
   if (direct >= 0) c->step_direct = direct != 0;
+  return HAMSM_OK;
+}
+// (test hook) the f64-MFMA training kernels: plain = 1 member rows from the frames / 0 the f64 batch copy; lrows = 1 the call's row
+// list in LDS (batches of <= 4096 rows).  Negative: leave as is.
+extern "C" int hamsm_debug_step_plain(hamsm_ctx *c, int plain, int lrows) {
+  CTX(c);
+  if (plain >= 0) c->step_direct_plain = plain != 0;
+  if (lrows >= 0) c->step_lrows = lrows != 0;
   return HAMSM_OK;
 }
 extern "C" int hamsm_debug_rank_stats(hamsm_ctx *c, unsigned long long *out, int reset, int mode) {

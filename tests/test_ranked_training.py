@@ -161,3 +161,40 @@ def test_c5_shape_takes_the_ranked_path_by_size(hip_lib, oracle_lib):
             h.close()
     for x, y in zip(out[0][0] + out[0][1], out[1][0] + out[1][1]):
         assert np.array_equal(x, y)
+
+
+def _plain(h, plain, lrows):
+    """(test hook) the f64-MFMA training kernels: member rows from the frames (1) or the f64 batch copy (0); row list in LDS"""
+    fn = h.lib.hamsm_debug_step_plain
+    fn.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int]
+    fn.restype = ctypes.c_int
+    assert fn(h.ctx, int(plain), int(lrows)) == 0
+
+
+PLAIN_CASES = [c for c in CASES if c[0] in ("balanced", "c3-like", "weighted", "d64", "d17", "many-strata", "reseeding-weighted", "outliers",
+                                            "reseeding-long")] + [
+    ("d100-two-registers-per-lane", synthetic.WEConfig("pl1", 21, 12, 2000, 100, 2, 20), 20, {}),
+    ("batches-beyond-4096-rows", synthetic.WEConfig("pl2", 22, 6, 11000, 12, 2, 30), 30, {}),          # UPD_NBK = 4: no row list in LDS
+    ("batches-beyond-4096-rows-weighted", synthetic.WEConfig("pl3", 23, 6, 11000, 12, 2, 30), 30, dict(weights=True)),
+]
+
+
+# end of round 5: the f64-MFMA kernels (calls too small for the ranked E-step: C3's) drop the f64 batch copy too -- the M-step takes
+# member rows from the frames, the call's row list waits in LDS (batches of <= 4096 rows) -- C3 training 17.8 -> 16.95 ms.  Shipped
+# shape, without the LDS row list, and round 4's shape (copy) against the oracle.
+@pytest.mark.parametrize("shape", ["default", "frames", "copy"])
+@pytest.mark.parametrize("name,cfg,k,kw", PLAIN_CASES, ids=[c[0] for c in PLAIN_CASES])
+def test_plain_training_pass_equals_the_oracle_in_every_shape(hip_h, oracle_h, name, cfg, k, kw, shape):
+    o = _run(oracle_h, cfg, k, True, **kw)
+    _rank(hip_h, 0)   # never the ranked E-step
+    _plain(hip_h, *{"default": (1, 1), "frames": (1, 0), "copy": (0, 0)}[shape])
+    try:
+        g = _run(hip_h, cfg, k, True, **kw)
+    finally:
+        _plain(hip_h, 1, 1)
+        st = _rank(hip_h, 1)
+    assert st["runs"] == 0
+    assert g[0].training_path == o[0].training_path
+    assert np.array_equal(g[1], o[1]), f"{int((g[1] != o[1]).sum())} labels differ"
+    for i, (x, y) in enumerate(zip(g[2] + g[3], o[2] + o[3])):
+        assert np.array_equal(x, y), f"array {i} (centroid tables, then counts) differs in {int((x != y).sum())} places"
