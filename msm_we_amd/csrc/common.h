@@ -231,6 +231,13 @@ int hamsm_refresh_table(hamsm_ctx *c);                    // rebuilds d_table / 
 int hamsm_check_device_error(hamsm_ctx *c, const char *what);  // reads d_err (syncs the stream)
 int hamsm_stratum_reserve(hamsm_ctx *c, int s, int K);
 int hamsm_pack_stratum(hamsm_ctx *c, int s, const double *d_csq_in);
+#define PACK_MULTI 8
+struct PackMulti {
+  const double *C[PACK_MULTI];
+  double *csq[PACK_MULTI], *Bpack[PACK_MULTI], *counts[PACK_MULTI];
+  int K[PACK_MULTI], Kp[PACK_MULTI];
+};
+int hamsm_pack_seeded(hamsm_ctx *c, const int *strata, int n);
 #ifdef HAMSM_EXPERIMENTS
 int hamsm_assign_rows(hamsm_ctx *c, const void *X, int dt, int64_t ldx, int64_t n_span, int32_t *d_labels, const int32_t *d_perm,
                       const unsigned long long *d_cnt);  // assign.hip: the E-step of a heavy training call (experiments/train_ranked.inc)

@@ -803,6 +803,61 @@ __global__ void k_pack_long(const double *__restrict__ C, const double *__restri
   }
 }
 
+// the strata a seeding call has just seeded (train.hip): counts := 0 (_kmeans.py:2271), csq, fragments -- ONE launch for up to
+// PACK_MULTI strata (they used to be a memset and a k_pack launch each, between the seeding kernel and the first training step)
+__global__ void k_pack_multi(PackMulti pm, int D, int KS) {
+  const int y = blockIdx.y;
+  const int K = pm.K[y], Kpad = pm.Kp[y];
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= Kpad) return;
+  const double *C = pm.C[y];
+  double *csq = pm.csq[y], *Bpack = pm.Bpack[y];
+  if (j < K) {
+    pm.counts[y][j] = 0.0;
+    double a = 0.0;
+    for (int k = 0; k < D; k++) a = __builtin_fma(C[(size_t)j * D + k], C[(size_t)j * D + k], a);
+    csq[j] = a;
+  } else csq[j] = __builtin_huge_val();
+  const int jt = j >> 4, col = j & 15;
+  for (int k = 0; k < KS * 4; k++) {
+    const double v = (j < K && k < D) ? C[(size_t)j * D + k] : 0.0;
+    Bpack[((size_t)jt * KS + (k >> 2)) * 64 + (k & 3) * 16 + col] = v;
+  }
+}
+
+int hamsm_pack_seeded(hamsm_ctx *c, const int *strata, int n) {
+  if (c->KS > 32) {  // long rows: the per-stratum form
+    for (int i = 0; i < n; i++) {
+      Stratum &t = c->st[strata[i]];
+      HIPCHK(c, hipMemsetAsync(t.counts, 0, sizeof(double) * t.K, c->stream));
+      int rc = hamsm_pack_stratum(c, strata[i], nullptr);
+      if (rc) return rc;
+    }
+    return HAMSM_OK;
+  }
+  for (int i0 = 0; i0 < n; i0 += PACK_MULTI) {
+    PackMulti pm;
+    memset(&pm, 0, sizeof pm);
+    const int m = n - i0 < PACK_MULTI ? n - i0 : PACK_MULTI;
+    int kpmax = 0, live = 0;
+    for (int q = 0; q < m; q++) {
+      Stratum &t = c->st[strata[i0 + q]];
+      if (t.K == 0) continue;
+      pm.C[live] = t.C;
+      pm.csq[live] = t.csq;
+      pm.Bpack[live] = t.Bpack;
+      pm.counts[live] = t.counts;
+      pm.K[live] = t.K;
+      pm.Kp[live] = kpad(t.K);
+      kpmax = pm.Kp[live] > kpmax ? pm.Kp[live] : kpmax;
+      live++;
+    }
+    if (live) hipLaunchKernelGGL(k_pack_multi, dim3((kpmax + 63) / 64, live), dim3(64), 0, c->stream, pm, c->D, c->KS);
+  }
+  HIPCHK(c, hipGetLastError());
+  return HAMSM_OK;
+}
+
 int hamsm_pack_stratum(hamsm_ctx *c, int s, const double *d_csq_in) {
   Stratum &t = c->st[s];
   if (t.K == 0) return HAMSM_OK;

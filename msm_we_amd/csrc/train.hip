@@ -1004,12 +1004,13 @@ extern "C" int hamsm_kmeans_seed_multi(hamsm_ctx *c, int n_items, const int32_t 
     hipLaunchKernelGGL(k_seed, dim3((unsigned)n_items), dim3(SEED_T), lds, c->stream, (const SeedItem *)(b + o_items), D);
   }
   HIPCHK(c, hipGetLastError());
-  for (int i = 0; i < n_items; i++) {
-    int s = h_stratum[i];
-    Stratum &t = c->st[s];
-    t.K = h_K[i];
-    HIPCHK(c, hipMemsetAsync(t.counts, 0, sizeof(double) * t.K, c->stream));  // _kmeans.py:2271
-    rc = hamsm_pack_stratum(c, s, nullptr);
+  {
+    std::vector<int> seeded((size_t)n_items);
+    for (int i = 0; i < n_items; i++) {
+      seeded[i] = h_stratum[i];
+      c->st[h_stratum[i]].K = h_K[i];
+    }
+    rc = hamsm_pack_seeded(c, seeded.data(), n_items);  // counts := 0 (_kmeans.py:2271), csq, fragments: one launch
     if (rc) return rc;
   }
   c->table_dirty = true;
@@ -3459,8 +3460,8 @@ static int run_steps(hamsm_ctx *c, const void *X, int dt, int64_t ldx, const int
     StepDev *tails = (StepDev *)c->h_stage.data();
     for (size_t k = 0; k < tail_checks.size(); k++) tails[k] = sd[tail_checks[k]];
     HIPCHK(c, hipMemcpyAsync(b + o_tail, tails, sizeof(StepDev) * tail_checks.size(), hipMemcpyHostToDevice, c->stream));
-    for (size_t k = 0; k < tail_checks.size(); k++)
-      hipLaunchKernelGGL(k_step_check, dim3(1), dim3(256), 0, c->stream, (const StepDev *)(b + o_tail) + k, ratio, (int)n_steps);
+    // (one launch, a workgroup per stratum: they used to be one launch each, at the very end of the chain)
+    hipLaunchKernelGGL(k_step_check, dim3((unsigned)tail_checks.size()), dim3(256), 0, c->stream, (const StepDev *)(b + o_tail), ratio, (int)n_steps);
   }
   hamsm_timer_end(c, ST_STEP);
   if (hipError_t le = hipGetLastError(); le != hipSuccess) {
