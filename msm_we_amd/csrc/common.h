@@ -112,6 +112,7 @@ struct hamsm_ctx {
   // train.hip; same labels): 0 never, 1 when a run's heaviest call has >= step_ranked_min_flop (default), 2 always
   int step_ranked = 1;                      // HAMSM_STEP_RANKED
   int step_direct_plain = 1;                // HAMSM_STEP_DIRECT_PLAIN=0: the f64-MFMA training kernels WITH the f64 batch copy (round 4's form)
+  int enqueue_threads = 2;                  // HAMSM_ENQUEUE_THREADS=1: one host thread feeds both queues of a latency-bound training pass
   int step_lrows = 1;                       // HAMSM_STEP_LROWS: ... with the call's row list in LDS (batches of <= 4096 rows)
   bool cur_direct = false;                  // (the run being enqueued)
   int flux_last_path = -1;                  // (test hook) 0 atomics, 1 sorted, 2 by rows

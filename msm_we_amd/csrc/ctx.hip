@@ -72,6 +72,7 @@ extern "C" int hamsm_create(int device, hamsm_ctx **out) {
   if (const char *v = getenv("HAMSM_STEP_DIRECT")) c->step_direct = atoi(v) != 0;
   if (const char *v = getenv("HAMSM_STEP_DIRECT_PLAIN")) c->step_direct_plain = atoi(v) != 0;
   if (const char *v = getenv("HAMSM_STEP_LROWS")) c->step_lrows = atoi(v) != 0;
+  if (const char *v = getenv("HAMSM_ENQUEUE_THREADS")) c->enqueue_threads = atoi(v) < 1 ? 1 : atoi(v);
   if (const char *v = getenv("HAMSM_FLUX_ROWS")) c->flux_rows = atoi(v) != 0;
   if (const char *v = getenv("HAMSM_FLUX_ROWS_MAX_R")) c->flux_rows_max_r = atoi(v) < 2 ? 2 : atoi(v);
   if (const char *v = getenv("HAMSM_STEP_PIPE")) c->step_pipe = atoi(v) != 0;

@@ -9,6 +9,8 @@
 // round trip to L2 per phase (all operand loads issued before the first use) and for many small
 // workgroups, and several strata share one launch.  Every reduction follows the order fixed in
 // oracle/hamsm_oracle.c so that results are bit-identical.
+#include <thread>
+
 #include "common.h"
 #include <type_traits>
 
@@ -3348,8 +3350,66 @@ static int run_steps(hamsm_ctx *c, const void *X, int dt, int64_t ldx, const int
       for (int k = 0; k < 4; k++)
         if (!c->ev_ring[l][k]) HIPCHK(c, hipEventCreateWithFlags(&c->ev_ring[l][k], hipEventDisableTiming));
   }
+  // Latency-bound passes on two queues (C3: 2 x 2 000 launches, 3.6 us of host time each, against 16.9 ms of device time per
+  // pass): each queue is fed by a thread of its own, so that neither chain ever waits for the other's enqueue (one thread
+  // alternating between them stayed 1-4 ms ahead of the device at best).  Descriptors travel by value; the threads share nothing
+  // they write (launch sampling belongs to the context's own queue: the calling thread).
+  const bool threaded = c->enqueue_threads > 1 && !ranked && !bounded && !generic && n_lanes == 2 && gstart.size() > 64 && !HAMSM_CAPTURING(c);
+  if (threaded) {
+    auto enqueue_lane = [&](int l) -> int {
+      StepPack pk2;
+      memset(&pk2, 0, sizeof(pk2));
+      std::vector<int64_t> mine2;
+      for (size_t g = 0; g + 1 < gstart.size(); g++) {
+        const int64_t i = gstart[g], j = gstart[g + 1];
+        long long max_nb = 0;
+        int maxK = 0;
+        bool any_perm = false;
+        mine2.clear();
+        for (int64_t q = i; q < j; q++) {
+          if (lane_of(q) != l) continue;
+          mine2.push_back(q);
+          any_perm = any_perm || sd[q].perm;
+          if (h_steps[q].n_b > max_nb) max_nb = h_steps[q].n_b;
+          if (c->st[h_steps[q].stratum].K > maxK) maxK = c->st[h_steps[q].stratum].K;
+        }
+        const int ny = (int)mine2.size();
+        if (ny == 0 || max_nb <= 0) continue;
+        if (ny > PACK_NY) return HAMSM_EINVAL;  // (cannot happen: n_lanes is chosen so that a lane's strata fit)
+        for (int q = 0; q < ny; q++) pk2.s[q] = sd[mine2[q]];
+        pk2.n_next = 0;
+        if (g + 2 < gstart.size()) {  // the same strata of the next group, in the same positions
+          int nn = 0;
+          for (int64_t q = j; q < gstart[g + 2] && nn < ny; q++) {
+            if (lane_of(q) != l) continue;
+            pk2.nx[nn++] = StepNext{sd[q].X, sd[q].rows, sd[q].n_b};
+          }
+          pk2.n_next = nn;
+        }
+        const int r = (dt == HAMSM_F32) ? launch_steps<float>(c, lanes[l], nullptr, pk2, ny, max_nb, maxK, ldx, ratio, any_perm)
+                                        : launch_steps<double>(c, lanes[l], nullptr, pk2, ny, max_nb, maxK, ldx, ratio, any_perm);
+        if (r) return r;
+      }
+      return hipGetLastError() == hipSuccess ? HAMSM_OK : HAMSM_EDEVICE;  // (the launch error state is per thread)
+    };
+    int rc1 = HAMSM_OK;
+    std::thread side([&]() {
+      if (hipSetDevice(c->device) != hipSuccess) {
+        rc1 = HAMSM_EDEVICE;
+        return;
+      }
+      rc1 = enqueue_lane(1);
+    });
+    rc = enqueue_lane(0);
+    side.join();
+    if (!rc) rc = rc1;
+    if (rc) {
+      hipDeviceSynchronize();  // (all lanes: nothing may still read `sd` once it is gone)
+      return rc == HAMSM_EDEVICE ? hamsm_fail(c, HAMSM_EDEVICE, "step launches (threaded enqueue)") : rc;
+    }
+  }
   std::vector<int64_t> mine;
-  for (size_t g = 0; g + 1 < gstart.size(); g++) {
+  for (size_t g = 0; !threaded && g + 1 < gstart.size(); g++) {
     const int64_t i = gstart[g], j = gstart[g + 1];
     if (bounded && g > 0 && g % RA_W == 0) {
       const size_t k = g / RA_W;  // windows 0 .. k - 1 are enqueued
