@@ -3354,7 +3354,7 @@ static int run_steps(hamsm_ctx *c, const void *X, int dt, int64_t ldx, const int
   // pass): each queue is fed by a thread of its own, so that neither chain ever waits for the other's enqueue (one thread
   // alternating between them stayed 1-4 ms ahead of the device at best).  Descriptors travel by value; the threads share nothing
   // they write (launch sampling belongs to the context's own queue: the calling thread).
-  const bool threaded = c->enqueue_threads > 1 && !ranked && !bounded && !generic && n_lanes == 2 && gstart.size() > 64 && !HAMSM_CAPTURING(c);
+  const bool threaded = c->enqueue_threads > 1 && !ranked && !bounded && !generic && n_lanes >= 2 && gstart.size() > 64 && !HAMSM_CAPTURING(c);
   if (threaded) {
     auto enqueue_lane = [&](int l) -> int {
       StepPack pk2;
@@ -3392,17 +3392,21 @@ static int run_steps(hamsm_ctx *c, const void *X, int dt, int64_t ldx, const int
       }
       return hipGetLastError() == hipSuccess ? HAMSM_OK : HAMSM_EDEVICE;  // (the launch error state is per thread)
     };
-    int rc1 = HAMSM_OK;
-    std::thread side([&]() {
-      if (hipSetDevice(c->device) != hipSuccess) {
-        rc1 = HAMSM_EDEVICE;
-        return;
-      }
-      rc1 = enqueue_lane(1);
-    });
+    int rcl[4] = {HAMSM_OK, HAMSM_OK, HAMSM_OK, HAMSM_OK};
+    std::thread side[3];
+    for (int l = 1; l < n_lanes; l++)
+      side[l - 1] = std::thread([&, l]() {
+        if (hipSetDevice(c->device) != hipSuccess) {
+          rcl[l] = HAMSM_EDEVICE;
+          return;
+        }
+        rcl[l] = enqueue_lane(l);
+      });
     rc = enqueue_lane(0);
-    side.join();
-    if (!rc) rc = rc1;
+    for (int l = 1; l < n_lanes; l++) {
+      side[l - 1].join();
+      if (!rc) rc = rcl[l];
+    }
     if (rc) {
       hipDeviceSynchronize();  // (all lanes: nothing may still read `sd` once it is gone)
       return rc == HAMSM_EDEVICE ? hamsm_fail(c, HAMSM_EDEVICE, "step launches (threaded enqueue)") : rc;
