@@ -73,64 +73,71 @@ __global__ void k_flux_keys(MapperDev m, FluxArgs g, const int64_t *__restrict__
 }
 
 // pass 1: every (cell, iteration) run is summed in segment order (stable sort) by the thread at its first element, which also
-// raises the run's flag; pass 2 (after an exclusive scan of the flags) packs the run sums, in order, into a dense array -- a
-// cell's partials become CONTIGUOUS -- and pass 3 adds each cell's partials in ascending iteration on top of F.  (Walking the
-// runs in place, `e += len[e]`, was a chain of up to n_iterations dependent loads per cell: 1.5 ms of the 2.2 ms at C3.)
+// raises the run's flag -- and, in the upper half of the same word, the flag "first run of its cell"; pass 2 (after ONE exclusive
+// scan of the 64-bit words: both running counts at once) packs the run sums, in order, into a dense array -- a cell's partials
+// become CONTIGUOUS -- and notes where each cell's partials start; pass 3 is one thread per CELL adding its partials in ascending
+// iteration on top of F.  (Walking the runs in place, `e += len[e]`, was a chain of up to n_iterations dependent loads per cell: 1.5
+// ms of the 2.2 ms at C3.  Round 5: pass 3 used to be one thread per PARTIAL, of which the cell's first found the cell's end by
+// galloping and bisecting -- ~14 dependent loads in one lane of 25, in every wave: 200 us at C3; with the cells' starts from the scan
+// it is a dense launch over the cells.)
 template <typename KT>
-__global__ void k_flux_parts(const KT *__restrict__ ks, const double *__restrict__ ws, int64_t n,
-                             double *part, int32_t *flag) {
+__global__ void k_flux_parts(const KT *__restrict__ ks, const double *__restrict__ ws, int64_t n, int ib,
+                             double *part, unsigned long long *flag) {
   int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (j >= n) return;
+  // (everything a run of one element needs is requested at once: most runs are -- the walk below costs a dependent load per element)
   const KT k = ks[j];
-  if (j > 0 && ks[j - 1] == k) {  // not the first element of its (cell, iteration) run
+  const KT kp = j > 0 ? ks[j - 1] : k;
+  const KT kn = j + 1 < n ? ks[j + 1] : (KT)~k;
+  const double w0 = ws[j];
+  if (j > 0 && kp == k) {  // not the first element of its (cell, iteration) run
     flag[j] = 0;
     return;
   }
   double p = 0.0;
-  int64_t e = j;
-  while (e < n && ks[e] == k) {
-    p = p + ws[e];  // segment order inside the iteration (stable sort)
-    e++;
-  }
+  p = p + w0;
+  if (kn == k)
+    for (int64_t e = j + 1; e < n && ks[e] == k; e++) p = p + ws[e];  // segment order inside the iteration (stable sort)
   part[j] = p;
-  flag[j] = 1;
+  const bool cell_first = j == 0 || (kp >> ib) != (k >> ib);
+  flag[j] = 1ull | ((unsigned long long)cell_first << 32);
 }
 
 template <typename KT>
 __global__ void k_flux_pack(const KT *__restrict__ ks, const double *__restrict__ part,
-                            const int32_t *__restrict__ flag, const int32_t *__restrict__ pos, int64_t n,
-                            int ib, double *cpart, KT *ccell, int32_t *total) {
+                            const unsigned long long *__restrict__ flag, const unsigned long long *__restrict__ pos, int64_t n,
+                            int ib, double *cpart, KT *ccell, int32_t *cfirst, int32_t *total) {
   int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (j >= n) return;
-  if (flag[j]) {
-    cpart[pos[j]] = part[j];
-    ccell[pos[j]] = ks[j] >> ib;
+  const unsigned long long f = flag[j], p = pos[j];
+  if (f) {
+    cpart[(unsigned)p] = part[j];
+    ccell[(unsigned)p] = ks[j] >> ib;
+    if (f >> 32) cfirst[p >> 32] = (int32_t)(unsigned)p;
   }
-  if (j == n - 1) *total = pos[j] + flag[j];
+  if (j == n - 1) {
+    total[0] = (int32_t)((unsigned)p + (unsigned)f);   // partials
+    total[1] = (int32_t)((p >> 32) + (f >> 32));       // cells
+  }
 }
 
 template <typename KT>
-__global__ void k_flux_cells(const KT *__restrict__ ccell, const double *__restrict__ cpart,
+__global__ void k_flux_cells(const KT *__restrict__ ccell, const double *__restrict__ cpart, const int32_t *__restrict__ cfirst,
                              const int32_t *__restrict__ total, double *F) {
-  const int64_t m = (int64_t)blockIdx.x * blockDim.x + threadIdx.x, M = *total;
-  if (m >= M) return;
-  const KT cell = ccell[m];
-  if (m > 0 && ccell[m - 1] == cell) return;  // not the first partial of its cell
-  // the run's end first (the cells are sorted: gallop, then bisect), so that the additions below run over a KNOWN range and
-  // their loads do not wait for each other (a hot cell -- basis -> basis, anything -> target -- has one partial per iteration)
-  int64_t lo = m, step = 1;
-  while (lo + step < M && ccell[lo + step] == cell) {
-    lo += step;
-    step <<= 1;
-  }
-  int64_t hi = lo + step < M ? lo + step : M;  // ccell[lo] == cell, ccell[hi] != cell or hi == M
-  while (hi - lo > 1) {
-    const int64_t mid = (lo + hi) >> 1;
-    if (ccell[mid] == cell) lo = mid;
-    else hi = mid;
-  }
+  const int64_t m = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int32_t M = total[0], NC = total[1];
+  if (m >= NC) return;
+  const int64_t lo = cfirst[m], hi = m + 1 < NC ? cfirst[m + 1] : M;  // the cell's partials: a KNOWN range, its loads do not wait
+  const KT cell = ccell[lo];                                            // for each other
   double acc = F[cell];
-  int64_t e = m;
+  int64_t e = lo;
+  for (; e + 32 <= hi; e += 32) {  // (a hot cell -- anything -> target: one partial per iteration -- is the launch's tail: 32 loads in flight)
+    double v[32];
+#pragma unroll
+    for (int q = 0; q < 32; q++) v[q] = cpart[e + q];
+#pragma unroll
+    for (int q = 0; q < 32; q++) acc = acc + v[q];  // ascending iteration
+  }
   for (; e + 8 <= hi; e += 8) {
     double v[8];
 #pragma unroll
@@ -148,34 +155,38 @@ static int flux_sorted_run(hamsm_ctx *c, const MapperDev &m, const FluxArgs &g, 
   size_t temp_sort = 0, temp_scan = 0;
   KT *nullk = nullptr;
   double *nullv = nullptr;
-  int32_t *nulli = nullptr;
+  unsigned long long *nullu = nullptr;
   hipError_t e = rocprim::radix_sort_pairs(nullptr, temp_sort, nullk, nullk, nullv, nullv, (size_t)n, ib, ib + cb, c->stream);
   if (e != hipSuccess) return hamsm_fail(c, HAMSM_EDEVICE, "radix_sort_pairs(size): %s", hipGetErrorString(e));
-  e = rocprim::exclusive_scan(nullptr, temp_scan, nulli, nulli, 0, (size_t)n, rocprim::plus<int32_t>(), c->stream);
+  e = rocprim::exclusive_scan(nullptr, temp_scan, nullu, nullu, 0ull, (size_t)n, rocprim::plus<unsigned long long>(), c->stream);
   if (e != hipSuccess) return hamsm_fail(c, HAMSM_EDEVICE, "exclusive_scan(size): %s", hipGetErrorString(e));
   size_t temp_bytes = temp_sort > temp_scan ? temp_sort : temp_scan;
   size_t a8 = ((size_t)n * 8 + 255) & ~(size_t)255, a4 = ((size_t)n * 4 + 255) & ~(size_t)255;
-  // k_in | k_out | v_in (later: cpart) | v_out | part | flag | pos | total | temp ; ccell reuses k_in
-  size_t need = 5 * a8 + 2 * a4 + 256 + temp_bytes + 256;
+  // k_in | k_out | v_in (later: cpart) | v_out | part | flag | pos | cfirst | total | temp ; ccell reuses k_in
+  size_t need = 7 * a8 + a4 + 256 + temp_bytes + 256;
   int rc = hamsm_ensure_scratch(c, need);
   if (rc) return rc;
   char *base = (char *)c->scratch;
   KT *k_in = (KT *)base, *k_out = (KT *)(base + a8);
   double *v_in = (double *)(base + 2 * a8), *v_out = (double *)(base + 3 * a8), *part = (double *)(base + 4 * a8);
-  int32_t *flag = (int32_t *)(base + 5 * a8), *pos = (int32_t *)(base + 5 * a8 + a4), *total = (int32_t *)(base + 5 * a8 + 2 * a4);
-  void *temp = base + 5 * a8 + 2 * a4 + 256;
+  unsigned long long *flag = (unsigned long long *)(base + 5 * a8), *pos = (unsigned long long *)(base + 6 * a8);
+  int32_t *cfirst = (int32_t *)(base + 7 * a8), *total = (int32_t *)(base + 7 * a8 + a4);
+  void *temp = base + 7 * a8 + a4 + 256;
   unsigned grid = (unsigned)((n + 255) / 256);
   hipLaunchKernelGGL(k_flux_keys<KT>, dim3(grid), dim3(256), 0, c->stream, m, g, d_offs, n_iters, ib, k_in, v_in);
   // (stable, and only over the cell bits: the iteration bits below them are already in ascending order)
   e = rocprim::radix_sort_pairs(temp, temp_bytes, k_in, k_out, v_in, v_out, (size_t)n, ib, ib + cb, c->stream);
   if (e != hipSuccess) return hamsm_fail(c, HAMSM_EDEVICE, "radix_sort_pairs: %s", hipGetErrorString(e));
-  hipLaunchKernelGGL(k_flux_parts<KT>, dim3(grid), dim3(256), 0, c->stream, k_out, v_out, n, part, flag);
-  e = rocprim::exclusive_scan(temp, temp_bytes, flag, pos, 0, (size_t)n, rocprim::plus<int32_t>(), c->stream);
+  hipLaunchKernelGGL(k_flux_parts<KT>, dim3(grid), dim3(256), 0, c->stream, k_out, v_out, n, ib, part, flag);
+  e = rocprim::exclusive_scan(temp, temp_bytes, flag, pos, 0ull, (size_t)n, rocprim::plus<unsigned long long>(), c->stream);
   if (e != hipSuccess) return hamsm_fail(c, HAMSM_EDEVICE, "exclusive_scan: %s", hipGetErrorString(e));
   double *cpart = v_in;  // (the unsorted values are dead)
   KT *ccell = k_in;      // (so are the unsorted keys)
-  hipLaunchKernelGGL(k_flux_pack<KT>, dim3(grid), dim3(256), 0, c->stream, k_out, part, flag, pos, n, ib, cpart, ccell, total);
-  hipLaunchKernelGGL(k_flux_cells<KT>, dim3(grid), dim3(256), 0, c->stream, ccell, cpart, total, g.F);
+  hipLaunchKernelGGL(k_flux_pack<KT>, dim3(grid), dim3(256), 0, c->stream, k_out, part, flag, pos, n, ib, cpart, ccell, cfirst, total);
+  // one thread per cell: at most (K + 2)^2 cells, at most n
+  const unsigned long long cells_max = (unsigned long long)(g.K + 2) * (g.K + 2);
+  const unsigned gridc = (unsigned)(((cells_max < (unsigned long long)n ? cells_max : (unsigned long long)n) + 255) / 256);
+  hipLaunchKernelGGL(k_flux_cells<KT>, dim3(gridc), dim3(256), 0, c->stream, ccell, cpart, cfirst, total, g.F);
   e = hipGetLastError();
   if (e != hipSuccess) return hamsm_fail(c, HAMSM_EDEVICE, "flux_sorted: %s", hipGetErrorString(e));
   return HAMSM_OK;
