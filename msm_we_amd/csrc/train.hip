@@ -3394,17 +3394,24 @@ static int run_steps(hamsm_ctx *c, const void *X, int dt, int64_t ldx, const int
     };
     int rcl[4] = {HAMSM_OK, HAMSM_OK, HAMSM_OK, HAMSM_OK};
     std::thread side[3];
-    for (int l = 1; l < n_lanes; l++)
-      side[l - 1] = std::thread([&, l]() {
-        if (hipSetDevice(c->device) != hipSuccess) {
-          rcl[l] = HAMSM_EDEVICE;
-          return;
-        }
-        rcl[l] = enqueue_lane(l);
-      });
+    bool started[3] = {false, false, false};
+    for (int l = 1; l < n_lanes; l++) {
+      try {
+        side[l - 1] = std::thread([&, l]() {
+          if (hipSetDevice(c->device) != hipSuccess) {
+            rcl[l] = HAMSM_EDEVICE;
+            return;
+          }
+          rcl[l] = enqueue_lane(l);
+        });
+        started[l - 1] = true;
+      } catch (...) {  // (no thread to be had: this one feeds the queue too -- nothing leaves through the C ABI)
+      }
+    }
     rc = enqueue_lane(0);
     for (int l = 1; l < n_lanes; l++) {
-      side[l - 1].join();
+      if (started[l - 1]) side[l - 1].join();
+      else rcl[l] = enqueue_lane(l);
       if (!rc) rc = rcl[l];
     }
     if (rc) {
