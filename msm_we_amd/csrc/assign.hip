@@ -1373,8 +1373,10 @@ static int launch_sorted_cfg(hamsm_ctx *c, SortArgs g) {
   if (lds > 160 * 1024) return hamsm_fail(c, HAMSM_ENOTSUP, "sorted assign needs %zu B of LDS", lds);
   auto kern = k_assign_sorted<XT, KS, MT, NW, JW>;
   HIPCHK(c, hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  unsigned grid = (unsigned)((g.n + FRB - 1) / FRB + c->S);  // upper bound; surplus workgroups exit at once
-  hipLaunchKernelGGL(kern, dim3(grid), dim3(NW * 64), lds, c->stream, g);
+  long long grid = (g.n + FRB - 1) / FRB + c->S;  // upper bound; surplus workgroups exit at once
+  // behind the ranking pass: capped (see launch_sorted); hamsm_assign checks the counts after its synchronisation
+  if (c->exact_cap > 0 && c->exact_cap < grid) grid = c->exact_cap;
+  hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(NW * 64), lds, c->stream, g);
   HIPCHK(c, hipGetLastError());
   return HAMSM_OK;
 }
@@ -1422,6 +1424,8 @@ static int launch_sorted(hamsm_ctx *c, const AssignArgs &a) {
   const bool gfilt = generic && filt_any && c->filter_bf16 != 0 && !rows_given;
   const int KBg = (a.D + 15) / 16;
   c->filter_ran = 0;
+  c->exact_cap = 0;
+  c->exact_cap_of[c->und_slot] = 0;
   c->filter_form = 0;
   size_t off = 0;
   auto take = [&](size_t bytes) {
@@ -1593,16 +1597,29 @@ static int launch_sorted(hamsm_ctx *c, const AssignArgs &a) {
       default: return hamsm_fail(c, HAMSM_ENOTSUP, "KS=%d", KS);
     }
     if (rc) return rc;
-    // the undecided frames, by the exact kernel
-    g.FRB = FRB_exact;
+    // the undecided frames, by the exact kernel.  The host does not know how many there are (C3: 5 500 of 10 M after the light form).
+    // With the exact-only launch's 512-frame workgroups a dozen of them did all the work, one after the other through their 32 row
+    // tiles (69 us per side at C3), behind 19 500 workgroups that exit at once but each claim 64 KB of LDS first.  So: 64-frame
+    // workgroups (one batch of row tiles each), and a grid for 1/32 of the frames -- more than that and the ranking pass steps aside
+    // anyway; hamsm_assign compares the counts with the grid after its synchronisation and runs a side that did not fit again, in full.
+    int frb_x = FRB_exact;
+    c->exact_cap = 0;
+    if (c->exact_capped && !c->exact_full && !rows_given) {
+      frb_x = FRB_exact < 64 ? FRB_exact : 64;
+      const long long full = (n + frb_x - 1) / frb_x + S, cap = full / 32 + S + 256;
+      c->exact_cap = cap < full ? cap : 0;
+    }
+    c->exact_cap_of[c->und_slot] = c->exact_cap;
+    c->exact_frb_of[c->und_slot] = frb_x;
+    g.FRB = frb_x;
     g.perm = f.perm2;
     g.end = (const long long *)(b + o_end2);
     g.blkbase = (long long *)(b + o_blk2);
     hipLaunchKernelGGL(k_sort_offsets2, dim3(1), dim3(64), 0, c->stream, g, f.cnt2, (long long *)(b + o_end2), (long long *)(b + o_blk2));
     HIPCHK(c, hipGetLastError());
     if (!rows_given) {
-      if (!c->h_und) HIPCHK(c, hipHostMalloc((void **)&c->h_und, sizeof(unsigned long long) * S));
-      HIPCHK(c, hipMemcpyAsync(c->h_und, f.cnt2, sizeof(unsigned long long) * S, hipMemcpyDeviceToHost, c->stream));
+      if (!c->h_und) HIPCHK(c, hipHostMalloc((void **)&c->h_und, sizeof(unsigned long long) * 2 * S));
+      HIPCHK(c, hipMemcpyAsync(c->h_und + (size_t)c->und_slot * S, f.cnt2, sizeof(unsigned long long) * S, hipMemcpyDeviceToHost, c->stream));
       c->filter_ran = 1;
     }
   }
@@ -1640,8 +1657,8 @@ static int launch_sorted(hamsm_ctx *c, const AssignArgs &a) {
     g.blkbase = (long long *)(b + o_blk2);
     hipLaunchKernelGGL(k_sort_offsets2, dim3(1), dim3(64), 0, c->stream, g, f.cnt2, (long long *)(b + o_end2), (long long *)(b + o_blk2));
     HIPCHK(c, hipGetLastError());
-    if (!c->h_und) HIPCHK(c, hipHostMalloc((void **)&c->h_und, sizeof(unsigned long long) * S));
-    HIPCHK(c, hipMemcpyAsync(c->h_und, f.cnt2, sizeof(unsigned long long) * S, hipMemcpyDeviceToHost, c->stream));
+    if (!c->h_und) HIPCHK(c, hipHostMalloc((void **)&c->h_und, sizeof(unsigned long long) * 2 * S));
+    HIPCHK(c, hipMemcpyAsync(c->h_und + (size_t)c->und_slot * S, f.cnt2, sizeof(unsigned long long) * S, hipMemcpyDeviceToHost, c->stream));
     c->filter_ran = 1;
   }
   if (generic) {
@@ -1680,6 +1697,14 @@ extern "C" int hamsm_debug_filter_form(hamsm_ctx *c) {
   return c->filter_form;
 }
 
+// Not part of the product ABI (test hook): sides that were run again because their undecided frames outgrew the capped grid of the
+// exact pass; capped >= 0 sets HAMSM_EXACT_CAPPED.
+extern "C" long long hamsm_debug_exact_overflows(hamsm_ctx *c, int capped) {
+  CTX(c);
+  if (capped >= 0) c->exact_capped = capped != 0;
+  return c->exact_overflows;
+}
+
 // Not part of the product ABI (test hook): frames the last filtered hamsm_assign handed to the exact kernel.
 extern "C" long long hamsm_debug_filter_undecided(hamsm_ctx *c) {
   CTX(c);
@@ -1696,14 +1721,26 @@ extern "C" long long hamsm_debug_filter_undecided(hamsm_ctx *c) {
 static void assign_steer(hamsm_ctx *c, int64_t n) {
   if (!c->filter_ran) return;
   unsigned long long und = 0;
-  for (int s = 0; s < c->S; s++) und += c->h_und[s];
+  for (int s = 0; s < c->S; s++) und += c->h_und[(size_t)c->und_slot * c->S + s];
   if (c->filter_form == 3) {
     // the light form left more than 1/32 of the frames to the exact kernel: the full form for the next calls
     if (n >= 4096 && und * 32 > (unsigned long long)n) c->filter_lite_skip = 7;
   } else if (n >= 4096 && und * 4 > (unsigned long long)n) c->filter_skip = 7;
 }
 
-static int assign_enqueue(hamsm_ctx *c, const void *X, int dt, int64_t ldx, const double *p, int64_t n, int32_t *labels, int32_t *seen) {
+// did the capped grid of the exact pass (launch_sorted) cover every undecided frame of the side that reported into `slot`?
+static bool assign_exact_fit(hamsm_ctx *c, int slot) {
+  if (!c->filter_ran || !c->h_und || c->exact_cap_of[slot] <= 0) return true;
+  long long need = 0;
+  for (int s = 0; s < c->S; s++)
+    need += ((long long)c->h_und[(size_t)slot * c->S + s] + c->exact_frb_of[slot] - 1) / c->exact_frb_of[slot];
+  c->exact_overflows += need > c->exact_cap_of[slot];
+  return need <= c->exact_cap_of[slot];
+}
+
+static int assign_enqueue(hamsm_ctx *c, const void *X, int dt, int64_t ldx, const double *p, int64_t n, int32_t *labels, int32_t *seen,
+                          int slot = 0) {
+  c->und_slot = slot;
   AssignArgs g{X, ldx, p, n, labels, seen, c->d_table, c->S, c->D, c->Kfit, c->d_err};
   hamsm_timer_begin(c);  // bucket passes -> ST_OTHER (ended inside launch_sorted), distance kernel -> ST_ASSIGN
   int rc = (dt == HAMSM_F32) ? launch_sorted<float>(c, g) : launch_sorted<double>(c, g);
@@ -1725,6 +1762,12 @@ extern "C" int hamsm_assign(hamsm_ctx *c, const void *X, int dt, int64_t ldx, co
   rc = assign_enqueue(c, X, dt, ldx, p, n, labels, seen);
   if (rc) return rc;
   rc = hamsm_check_device_error(c, "assign");  // (synchronises: the undecided counts have arrived too)
+  if (!rc && !assign_exact_fit(c, 0)) {        // more undecided frames than the capped grid of the exact pass served: once more, in full
+    c->exact_full = true;
+    rc = assign_enqueue(c, X, dt, ldx, p, n, labels, seen);
+    c->exact_full = false;
+    if (!rc) rc = hamsm_check_device_error(c, "assign");
+  }
   assign_steer(c, n);
   return rc;
 }
@@ -1740,13 +1783,28 @@ extern "C" int hamsm_assign_pair(hamsm_ctx *c, const void *Xp, const void *Xc, i
   if (c->mapper.kind == MAPPER_EXTERNAL) return hamsm_fail(c, HAMSM_EINVAL, "assign_pair: an external mapper's frame bins are set per side (two hamsm_assign calls)");
   int rc = hamsm_refresh_table(c);
   if (rc) return rc;
-  rc = assign_enqueue(c, Xp, dt, ldx, p0, n, parent, seen);
+  rc = assign_enqueue(c, Xp, dt, ldx, p0, n, parent, seen, 0);
   if (rc) return rc;
-  rc = assign_enqueue(c, Xc, dt, ldx, p1, n, child, seen);
+  rc = assign_enqueue(c, Xc, dt, ldx, p1, n, child, seen, 1);
   if (rc) return rc;
   // (the device's error word keeps the FIRST error: a parent-side failure is the one reported, as with two calls)
   rc = hamsm_check_device_error(c, "assign");
+  const bool fit0 = assign_exact_fit(c, 0), fit1 = assign_exact_fit(c, 1);
+  if (!rc && !fit0) {  // (see hamsm_assign)
+    c->exact_full = true;
+    rc = assign_enqueue(c, Xp, dt, ldx, p0, n, parent, seen, 0);
+    c->exact_full = false;
+    if (!rc) rc = hamsm_check_device_error(c, "assign");
+  }
+  if (!rc && !fit1) {
+    c->exact_full = true;
+    rc = assign_enqueue(c, Xc, dt, ldx, p1, n, child, seen, 1);
+    c->exact_full = false;
+    if (!rc) rc = hamsm_check_device_error(c, "assign");
+  }
+  c->und_slot = 1;
   assign_steer(c, n);
+  c->und_slot = 0;
   return rc;
 }
 

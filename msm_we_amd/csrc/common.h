@@ -183,7 +183,14 @@ struct hamsm_ctx {
   long long ks_dev_n = 0;                   // ... and how many of them carried both stamps
   long long ks_tick = 0;
   size_t seed_g_budget = (size_t)4 << 30;  // bytes of Gram matrices resident at once (HAMSM_SEED_G_MB): 56 strata of 3072 rows
-  unsigned long long *h_und = nullptr;  // pinned [S]: undecided counts of the last filtered assign
+  unsigned long long *h_und = nullptr;  // pinned [2][S]: undecided counts of the last filtered assign (slot 1: the child side of a pair)
+  int und_slot = 0;                     // slot the assign being enqueued reports into
+  long long exact_cap = 0;              // workgroups the exact pass behind the ranking pass is launched with (0: the full upper bound)
+  long long exact_cap_of[2] = {0, 0};   // ... per slot, for the check after the synchronisation
+  int exact_frb_of[2] = {0, 0};         // frames per workgroup of that launch
+  bool exact_full = false;              // (re-run of a side whose undecided frames outgrew the capped grid)
+  int exact_capped = 1;                 // HAMSM_EXACT_CAPPED=0: the exact pass behind the ranking pass as before (512-frame workgroups, full grid)
+  long long exact_overflows = 0;        // (test hook) sides run again because their undecided frames outgrew the capped grid
   int filter_skip = 0;     // calls left that bypass the ranking pass (it settled < 3/4 of the frames last time)
   int filter_ran = 0;      // the last assign ran the ranking pass
   int filter_bf16 = 1;     // bf16 x 3 form of the ranking pass where it applies (D <= 32); HAMSM_FILTER_BF16=0: f32 form

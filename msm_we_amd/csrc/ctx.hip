@@ -70,6 +70,7 @@ extern "C" int hamsm_create(int device, hamsm_ctx **out) {
   if (const char *v = getenv("HAMSM_GENERIC_STAGE_KB")) c->generic_stage_kb = atoi(v) < 0 ? 0 : (atoi(v) > 150 ? 150 : atoi(v));
   if (const char *v = getenv("HAMSM_STEP_RANKED")) c->step_ranked = atoi(v) < 0 ? 0 : (atoi(v) > 2 ? 2 : atoi(v));
   if (const char *v = getenv("HAMSM_STEP_DIRECT")) c->step_direct = atoi(v) != 0;
+  if (const char *v = getenv("HAMSM_EXACT_CAPPED")) c->exact_capped = atoi(v) != 0;
   if (const char *v = getenv("HAMSM_STEP_DIRECT_PLAIN")) c->step_direct_plain = atoi(v) != 0;
   if (const char *v = getenv("HAMSM_STEP_LROWS")) c->step_lrows = atoi(v) != 0;
   if (const char *v = getenv("HAMSM_ENQUEUE_THREADS")) c->enqueue_threads = atoi(v) < 1 ? 1 : atoi(v);

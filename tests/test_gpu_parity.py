@@ -288,6 +288,63 @@ def test_assign_filter_steps_aside_on_data_full_of_ties(hip_h, oracle_h):
     assert und[0] > n // 2 and und[1] == und[0] and und[2:9] == [-1] * 7 and und[9] == und[0], und
 
 
+def _overflows(h, capped=-1):
+    fn = h.lib.hamsm_debug_exact_overflows
+    fn.restype = ctypes.c_longlong
+    fn.argtypes = [ctypes.c_void_p, ctypes.c_int]
+    return fn(h.ctx, capped)
+
+
+def test_assign_exact_pass_grid_is_capped_and_a_side_that_outgrows_it_runs_again(hip_h, oracle_h):
+    """behind the ranking pass the exact kernel runs in 64-frame workgroups on a grid for 1/32 of the frames (the host does not know
+    the count: a dozen 512-frame workgroups did all the work one tile after the other, 69 us per side at C3); a call whose undecided
+    frames do not fit is detected after the synchronisation and that side runs again with the full grid: labels equal the oracle's
+    either way, for hamsm_assign and for each side of hamsm_assign_pair, and with the capping switched off"""
+    from msm_we_amd import _abi
+
+    D, K_s, n = 12, 30, 400000
+    rng = np.random.default_rng(34)
+    Cm = np.repeat(rng.normal(size=(K_s, D)) * 3, 2, axis=0)          # every centroid twice: every frame an exact tie
+    X_tie, p = _frames(rng, n, D, 1, np.float32)
+    Cm2 = rng.normal(size=(2 * K_s, D)) * 3                             # distinct centroids: next to nothing undecided
+    res = {}
+    for key, h, capped in (("oracle", oracle_h, -1), ("capped", hip_h, 1), ("full", hip_h, 0)):
+        _setup(h, D, 1, K_s, np.random.default_rng(1))
+        if h is hip_h:
+            _overflows(h, capped)
+        d_X, d_p = h.to_device(X_tie), h.to_device(p)
+        la, lb = h.alloc(n, np.int32), h.alloc(n, np.int32)
+        out = []
+        for cents in (Cm, Cm2):
+            if h is hip_h:   # (ties make the ranking pass step aside for the next calls: a fresh geometry lets it run again)
+                h.set_geometry(D, 1, 1)
+                _setup(h, D, 1, K_s, np.random.default_rng(1))
+            h.set_centroids(0, cents, csq=np.einsum("ij,ij->i", cents, cents))
+            o0 = _overflows(h) if h is hip_h else 0
+            h.assign(d_X, _abi.F32, D, d_p, n, la)
+            o1 = _overflows(h) if h is hip_h else 0
+            one = la.to_host()
+            h.memset(la, 0xff, n * 4)
+            if h is hip_h:
+                h.set_geometry(D, 1, 1)
+                _setup(h, D, 1, K_s, np.random.default_rng(1))
+                h.set_centroids(0, cents, csq=np.einsum("ij,ij->i", cents, cents))
+                o1 = _overflows(h)
+            h.assign_pair(d_X, d_X, _abi.F32, D, d_p, d_p, n, la, lb)
+            o2 = _overflows(h) if h is hip_h else 0
+            out.append((one, la.to_host(), lb.to_host(), o1 - o0, o2 - o1))
+        res[key] = out
+        for b in (d_X, d_p, la, lb):
+            b.free()
+    _overflows(hip_h, 1)
+    for key in ("capped", "full"):
+        for o, g in zip(res["oracle"], res[key]):
+            assert np.array_equal(o[0], g[0]) and np.array_equal(o[1], g[1]) and np.array_equal(o[2], g[2]), key
+    assert res["capped"][0][3] == 1 and res["capped"][0][4] == 2, res["capped"][0][3:]   # all ties: the call and both sides of the pair ran again
+    assert res["capped"][1][3:] == (0, 0)                                                # ordinary data: the capped grid was enough
+    assert res["full"][0][3:] == (0, 0) and res["full"][1][3:] == (0, 0)
+
+
 def _filter_form(h):
     fn = h.lib.hamsm_debug_filter_form
     fn.restype = ctypes.c_int
